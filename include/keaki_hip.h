@@ -1,0 +1,133 @@
+/* keaki_hip.h -- C ABI of libkeaki_hip.so: the MI355X (gfx950) backend for keaki's BN254 hot path.
+ *
+ * keaki (the reference) has no FFI of its own; its "operator API" is the generic Rust functions
+ * kzg::commit/open/verify, kem::encapsulate/decapsulate and vec::vec_encrypt/vec_decrypt. Every
+ * expensive step inside them is a call into arkworks. The entry points below are what a
+ * feature-gated Rust shim binds in place of those arkworks calls (INTEGRATION.md shows the shim);
+ * each one cites the reference line it replaces.
+ *
+ * Conventions
+ *  - Every function returns a keaki_status (0 = ok, < 0 = error); nothing unwinds or aborts across
+ *    the boundary. keaki_hip_last_error(ctx) returns a human-readable message for the last failure.
+ *  - The caller owns every buffer. *_dev entry points take DEVICE pointers (memory already resident
+ *    in HBM, e.g. allocated by the caller's HIP runtime) and enqueue on the ctx stream without
+ *    synchronising unless stated; the plain entry points take HOST pointers, copy in/out and
+ *    synchronise.
+ *  - Field elements are little-endian 64-bit limbs in Montgomery form (R = 2^256) EXACTLY as ark-ff
+ *    0.4.2 holds them in `Fp.0.0`, so the shim copies limbs without conversion:
+ *        Fr, Fq        u64[4]
+ *        G1 affine     u64[8]   (x, y);                      identity = all-zero words
+ *        G1 Jacobian   u64[12]  (x, y, z) normalised: z = R (Montgomery one), identity = (R, R, 0)
+ *        G2 affine     u64[16]  (x.c0, x.c1, y.c0, y.c1);    identity = all-zero words
+ *        G2 Jacobian   u64[24]  normalised likewise
+ *        GT            384 bytes = ark-serialize `serialize_uncompressed` of Fq12:
+ *                      c0.c0.c0, c0.c0.c1, c0.c1.c0, ..., c1.c2.c1, each canonical 32-byte LE.
+ *    (arkworks' in-memory `Affine { x, y, infinity: bool }` is repr(Rust); the shim must write x,y
+ *    explicitly and map `infinity` to the all-zero encoding.)
+ *  - A ctx is bound to one GPU. Multi-GPU = one ctx (one process) per GPU: each rank runs
+ *    msm on its contiguous chunk of (scalar, point) pairs, the 96-byte partial sums are exchanged
+ *    with RCCL all-gather by the caller, and keaki_hip_g1_sum_dev adds them.
+ *  - Thread-safety: a ctx serialises calls internally (one mutex); use one ctx per host thread for
+ *    concurrency.
+ */
+#ifndef KEAKI_HIP_H
+#define KEAKI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t keaki_status;
+enum {
+  KEAKI_OK = 0,
+  KEAKI_ERR_BAD_ARG = -1,      /* null pointer, n out of range, n > srs length ...            */
+  KEAKI_ERR_HIP = -2,          /* a HIP runtime call failed (message has hipGetErrorString)   */
+  KEAKI_ERR_OOM = -3,          /* device allocation failed                                    */
+  KEAKI_ERR_NO_DEVICE = -4,    /* no gfx950 device visible                                    */
+  KEAKI_ERR_TOO_LARGE = -5     /* polynomial longer than the SRS: KZGError::PolynomialTooLarge */
+};
+
+typedef struct keaki_hip_ctx keaki_hip_ctx;
+typedef struct keaki_hip_srs_g1 keaki_hip_srs_g1; /* device-resident [tau^i]_1, affine */
+typedef struct keaki_hip_srs_g2 keaki_hip_srs_g2; /* device-resident G2 bases, affine  */
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* device: HIP device ordinal. stream: a hipStream_t to enqueue on, or NULL for a private stream. */
+keaki_status keaki_hip_ctx_create(int32_t device, void* stream, keaki_hip_ctx** out);
+void keaki_hip_ctx_destroy(keaki_hip_ctx* ctx);
+const char* keaki_hip_last_error(const keaki_hip_ctx* ctx); /* ctx may be NULL: last create error */
+keaki_status keaki_hip_synchronize(keaki_hip_ctx* ctx);
+const char* keaki_hip_version(void);
+
+/* ---- SRS: replaces KZGSetup::g1_aff (src/kzg.rs:22-29, built at :63) -------------------------- */
+keaki_status keaki_hip_srs_g1_upload(keaki_hip_ctx* ctx, const uint64_t* points_aff, size_t n, keaki_hip_srs_g1** out);
+/* wraps caller-owned device memory holding n affine points (not freed by _free) */
+keaki_status keaki_hip_srs_g1_wrap_dev(keaki_hip_ctx* ctx, const void* d_points_aff, size_t n, keaki_hip_srs_g1** out);
+size_t keaki_hip_srs_g1_len(const keaki_hip_srs_g1* srs);
+void keaki_hip_srs_g1_free(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs);
+keaki_status keaki_hip_srs_g2_upload(keaki_hip_ctx* ctx, const uint64_t* points_aff, size_t n, keaki_hip_srs_g2** out);
+keaki_status keaki_hip_srs_g2_wrap_dev(keaki_hip_ctx* ctx, const void* d_points_aff, size_t n, keaki_hip_srs_g2** out);
+void keaki_hip_srs_g2_free(keaki_hip_ctx* ctx, keaki_hip_srs_g2* srs);
+
+/* ---- MSM: replaces <E::G1 as VariableBaseMSM>::msm_unchecked(&setup.g1_aff, p) (src/kzg.rs:98) -
+ * out = sum_{i<n} scalars[i] * srs[i]; n <= len(srs) (zip-truncation as msm_unchecked).
+ * n > len(srs) -> KEAKI_ERR_TOO_LARGE (the check of src/kzg.rs:93-95 lives in the caller, this is a guard).
+ * out_jac: u64[12] normalised Jacobian. */
+keaki_status keaki_hip_msm_g1(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, const uint64_t* scalars, size_t n, uint64_t* out_jac);
+/* device-resident scalars and output (d_out_jac: 96 bytes of device memory); asynchronous on the ctx stream */
+keaki_status keaki_hip_msm_g1_dev(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, const void* d_scalars, size_t n, void* d_out_jac);
+/* same over G2 (no call site in keaki; north_star asks for it; out u64[24]) */
+keaki_status keaki_hip_msm_g2(keaki_hip_ctx* ctx, const keaki_hip_srs_g2* srs, const uint64_t* scalars, size_t n, uint64_t* out_jac);
+keaki_status keaki_hip_msm_g2_dev(keaki_hip_ctx* ctx, const keaki_hip_srs_g2* srs, const void* d_scalars, size_t n, void* d_out_jac);
+/* out = sum of k normalised-Jacobian G1 points (combines per-GPU partial sums after the all-gather) */
+keaki_status keaki_hip_g1_sum_dev(keaki_hip_ctx* ctx, const void* d_points_jac, size_t k, void* d_out_jac);
+keaki_status keaki_hip_g1_sum(keaki_hip_ctx* ctx, const uint64_t* points_jac, size_t k, uint64_t* out_jac);
+
+/* ---- batched scalar multiplication: replaces `.mul(scalar)` (src/kem.rs:22,30,36,37; src/kzg.rs:57,60,135,144)
+ * out[i] = scalars[i] * points[i]   (point_stride = 1) or scalars[i] * points[0] (point_stride = 0).
+ * points affine in, affine out. */
+keaki_status keaki_hip_g1_mul_batch(keaki_hip_ctx* ctx, const uint64_t* points_aff, int32_t point_stride, const uint64_t* scalars, size_t n, uint64_t* out_aff);
+keaki_status keaki_hip_g2_mul_batch(keaki_hip_ctx* ctx, const uint64_t* points_aff, int32_t point_stride, const uint64_t* scalars, size_t n, uint64_t* out_aff);
+keaki_status keaki_hip_g1_mul_batch_dev(keaki_hip_ctx* ctx, const void* d_points_aff, int32_t point_stride, const void* d_scalars, size_t n, void* d_out_aff);
+keaki_status keaki_hip_g2_mul_batch_dev(keaki_hip_ctx* ctx, const void* d_points_aff, int32_t point_stride, const void* d_scalars, size_t n, void* d_out_aff);
+
+/* ---- batched pairing: replaces E::pairing(p, q) (src/kem.rs:30,58; src/kzg.rs:148) + serialize_uncompressed (src/kem.rs:32,61)
+ * gt_out[i] = serialize_uncompressed(e(g1[i], g2[i * g2_stride])); identity in either slot -> GT one. */
+keaki_status keaki_hip_pairing_batch(keaki_hip_ctx* ctx, const uint64_t* g1_aff, const uint64_t* g2_aff, int32_t g2_stride, size_t n, uint8_t* gt_out);
+keaki_status keaki_hip_pairing_batch_dev(keaki_hip_ctx* ctx, const void* d_g1_aff, const void* d_g2_aff, int32_t g2_stride, size_t n, void* d_gt_out);
+
+/* ---- KEM composites: the bodies of the loops at src/vec.rs:63-66 and :75-78 --------------------
+ * encap_batch: for i < n (src/kem.rs:13-50 with the SAME com / tau_g2 for all i):
+ *     ct[i]  = r[i] * (tau_g2 - points[i] * g2)                       (affine G2, u64[16])
+ *     gt[i]  = serialize(e(r[i] * (com - values[i] * g1), g2))        (384 bytes)
+ *     key[i] = BLAKE3-XOF(gt[i])[0..msg_len]   if key_out != NULL     (src/kem.rs:42-46)
+ * r[i] are drawn by the caller (one Fr::rand per item in index order, src/kem.rs:26) so the
+ * randomness stream is the caller's. gt_out may be NULL when only keys are wanted. msg_len <= 1<<16. */
+keaki_status keaki_hip_encap_batch(keaki_hip_ctx* ctx, const uint64_t* com_aff, const uint64_t* tau_g2_aff,
+                                   const uint64_t* points, const uint64_t* values, const uint64_t* r, size_t n,
+                                   uint64_t* ct_out_aff, uint8_t* gt_out, uint8_t* key_out, size_t msg_len);
+keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff, const void* d_tau_g2_aff,
+                                       const void* d_points, const void* d_values, const void* d_r, size_t n,
+                                       void* d_ct_out_aff, void* d_gt_out, void* d_key_out, size_t msg_len);
+/* decap_batch (src/kem.rs:55-72): gt[i] = serialize(e(proofs[i], cts[i])), key[i] = BLAKE3-XOF(gt[i]) */
+keaki_status keaki_hip_decap_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_aff, const uint64_t* cts_aff, size_t n,
+                                   uint8_t* gt_out, uint8_t* key_out, size_t msg_len);
+keaki_status keaki_hip_decap_batch_dev(keaki_hip_ctx* ctx, const void* d_proofs_aff, const void* d_cts_aff, size_t n,
+                                       void* d_gt_out, void* d_key_out, size_t msg_len);
+
+/* ---- instrumentation (bench.py reads these; not part of the reference surface) ---------------- */
+/* device time in milliseconds of the dominant kernel (bucket accumulation) of the last msm_*_dev
+ * call, measured with HIP events on the ctx stream; < 0 if timing is disabled. */
+keaki_status keaki_hip_set_timing(keaki_hip_ctx* ctx, int32_t enabled);
+float keaki_hip_last_msm_bucket_ms(const keaki_hip_ctx* ctx);
+float keaki_hip_last_msm_total_ms(const keaki_hip_ctx* ctx);
+/* window size (bits) the last MSM used */
+int32_t keaki_hip_last_msm_window_bits(const keaki_hip_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KEAKI_HIP_H */

@@ -1,0 +1,402 @@
+// libkeaki_hip.so -- C ABI (include/keaki_hip.h) over the gfx950 kernels. Host side only does
+// launch plumbing: workspace management, stream ordering, error codes. No arithmetic happens on
+// the CPU here and there is no CPU fallback: without a gfx950 device every entry point fails.
+#include "internal.h"
+
+using namespace keaki_internal;
+
+struct keaki_hip_srs_g1 {
+  const void* d = nullptr;
+  size_t n = 0;
+  bool owned = false;
+};
+struct keaki_hip_srs_g2 {
+  const void* d = nullptr;
+  size_t n = 0;
+  bool owned = false;
+};
+
+namespace {
+thread_local std::string g_create_error;
+constexpr size_t G1_AFF_BYTES = 64, G2_AFF_BYTES = 128;
+}  // namespace
+
+namespace keaki_internal {
+
+keaki_status fail(keaki_hip_ctx* ctx, keaki_status code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf; else g_create_error = buf;
+  return code;
+}
+
+keaki_status reserve(keaki_hip_ctx* ctx, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return KEAKI_OK;
+  if (b.p) {
+    // the buffer may still be in use by enqueued work
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+  }
+  size_t want = bytes + bytes / 8 + 256;
+  HIP_TRY(ctx, hipMalloc(&b.p, want));
+  b.cap = want;
+  return KEAKI_OK;
+}
+
+keaki_status launch_check(keaki_hip_ctx* ctx, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ctx, KEAKI_ERR_HIP, "launch %s failed: %s", what, hipGetErrorString(e));
+  return KEAKI_OK;
+}
+
+}  // namespace keaki_internal
+
+namespace {
+
+void resolve_timing(keaki_hip_ctx* ctx) {
+  if (!ctx->timing_pending) return;
+  if (hipEventSynchronize(ctx->ev[3]) == hipSuccess) {
+    (void)hipEventElapsedTime(&ctx->last_bucket_ms, ctx->ev[1], ctx->ev[2]);
+    (void)hipEventElapsedTime(&ctx->last_total_ms, ctx->ev[0], ctx->ev[3]);
+  }
+  ctx->timing_pending = false;
+}
+
+keaki_status upload(keaki_hip_ctx* ctx, DevBuf& b, const void* host, size_t bytes) {
+  ST_TRY(reserve(ctx, b, bytes ? bytes : 16));
+  if (bytes) HIP_TRY(ctx, hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return KEAKI_OK;
+}
+keaki_status download(keaki_hip_ctx* ctx, void* host, const void* dev, size_t bytes) {
+  if (bytes) HIP_TRY(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return KEAKI_OK;
+}
+
+#define CTX_GUARD(ctx)                                \
+  if (!(ctx)) return KEAKI_ERR_BAD_ARG;               \
+  std::lock_guard<std::mutex> lock_((ctx)->mu);       \
+  if (hipSetDevice((ctx)->device) != hipSuccess) return fail(ctx, KEAKI_ERR_HIP, "hipSetDevice(%d) failed", (ctx)->device)
+
+}  // namespace
+
+extern "C" {
+
+const char* keaki_hip_version(void) { return "keaki-hip 0.1 (gfx950)"; }
+
+keaki_status keaki_hip_ctx_create(int32_t device, void* stream, keaki_hip_ctx** out) {
+  if (!out) return fail(nullptr, KEAKI_ERR_BAD_ARG, "ctx_create: out is null");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, KEAKI_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(nullptr, KEAKI_ERR_BAD_ARG, "device %d out of range (%d visible)", device, ndev);
+  HIP_TRY(nullptr, hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, KEAKI_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+  keaki_hip_ctx* ctx = new keaki_hip_ctx();
+  ctx->device = device;
+  if (stream) {
+    ctx->stream = (hipStream_t)stream;
+  } else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete ctx;
+      return fail(nullptr, KEAKI_ERR_HIP, "hipStreamCreate failed");
+    }
+    ctx->own_stream = true;
+  }
+  for (auto& e : ctx->ev) (void)hipEventCreate(&e);
+  *out = ctx;
+  return KEAKI_OK;
+}
+
+void keaki_hip_ctx_destroy(keaki_hip_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (DevBuf* b : {&ctx->digits, &ctx->hist, &ctx->offsets, &ctx->cursor, &ctx->sorted, &ctx->buckets, &ctx->partials, &ctx->wsums,
+                    &ctx->bsums, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->io_a, &ctx->io_b, &ctx->io_c, &ctx->io_d, &ctx->io_e})
+    if (b->p) (void)hipFree(b->p);
+  for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* keaki_hip_last_error(const keaki_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+keaki_status keaki_hip_synchronize(keaki_hip_ctx* ctx) {
+  CTX_GUARD(ctx);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  resolve_timing(ctx);
+  return KEAKI_OK;
+}
+
+keaki_status keaki_hip_set_timing(keaki_hip_ctx* ctx, int32_t enabled) {
+  CTX_GUARD(ctx);
+  ctx->timing = enabled != 0;
+  return KEAKI_OK;
+}
+float keaki_hip_last_msm_bucket_ms(const keaki_hip_ctx* ctx) { return ctx ? ctx->last_bucket_ms : -1.f; }
+float keaki_hip_last_msm_total_ms(const keaki_hip_ctx* ctx) { return ctx ? ctx->last_total_ms : -1.f; }
+int32_t keaki_hip_last_msm_window_bits(const keaki_hip_ctx* ctx) { return ctx ? ctx->last_c : 0; }
+
+// ---- SRS -----------------------------------------------------------------------------------------
+keaki_status keaki_hip_srs_g1_upload(keaki_hip_ctx* ctx, const uint64_t* points_aff, size_t n, keaki_hip_srs_g1** out) {
+  CTX_GUARD(ctx);
+  if (!out || (n && !points_aff)) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g1_upload: null pointer");
+  void* d = nullptr;
+  HIP_TRY(ctx, hipMalloc(&d, n ? n * G1_AFF_BYTES : 16));
+  if (n) {
+    hipError_t e = hipMemcpy(d, points_aff, n * G1_AFF_BYTES, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return fail(ctx, KEAKI_ERR_HIP, "srs upload copy failed: %s", hipGetErrorString(e)); }
+  }
+  *out = new keaki_hip_srs_g1{d, n, true};
+  return KEAKI_OK;
+}
+keaki_status keaki_hip_srs_g1_wrap_dev(keaki_hip_ctx* ctx, const void* d_points_aff, size_t n, keaki_hip_srs_g1** out) {
+  CTX_GUARD(ctx);
+  if (!out || (n && !d_points_aff)) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g1_wrap_dev: null pointer");
+  *out = new keaki_hip_srs_g1{d_points_aff, n, false};
+  return KEAKI_OK;
+}
+size_t keaki_hip_srs_g1_len(const keaki_hip_srs_g1* srs) { return srs ? srs->n : 0; }
+void keaki_hip_srs_g1_free(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs) {
+  if (!srs) return;
+  if (srs->owned && srs->d) {
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    (void)hipFree((void*)srs->d);
+  }
+  delete srs;
+}
+keaki_status keaki_hip_srs_g2_upload(keaki_hip_ctx* ctx, const uint64_t* points_aff, size_t n, keaki_hip_srs_g2** out) {
+  CTX_GUARD(ctx);
+  if (!out || (n && !points_aff)) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g2_upload: null pointer");
+  void* d = nullptr;
+  HIP_TRY(ctx, hipMalloc(&d, n ? n * G2_AFF_BYTES : 16));
+  if (n) {
+    hipError_t e = hipMemcpy(d, points_aff, n * G2_AFF_BYTES, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return fail(ctx, KEAKI_ERR_HIP, "srs upload copy failed: %s", hipGetErrorString(e)); }
+  }
+  *out = new keaki_hip_srs_g2{d, n, true};
+  return KEAKI_OK;
+}
+keaki_status keaki_hip_srs_g2_wrap_dev(keaki_hip_ctx* ctx, const void* d_points_aff, size_t n, keaki_hip_srs_g2** out) {
+  CTX_GUARD(ctx);
+  if (!out || (n && !d_points_aff)) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g2_wrap_dev: null pointer");
+  *out = new keaki_hip_srs_g2{d_points_aff, n, false};
+  return KEAKI_OK;
+}
+void keaki_hip_srs_g2_free(keaki_hip_ctx* ctx, keaki_hip_srs_g2* srs) {
+  if (!srs) return;
+  if (srs->owned && srs->d) {
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    (void)hipFree((void*)srs->d);
+  }
+  delete srs;
+}
+
+// ---- MSM -----------------------------------------------------------------------------------------
+keaki_status keaki_hip_msm_g1_dev(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, const void* d_scalars, size_t n, void* d_out_jac) {
+  CTX_GUARD(ctx);
+  if (!srs) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm_g1: srs is null");
+  return msm_g1_run(ctx, srs->d, srs->n, d_scalars, n, d_out_jac);
+}
+keaki_status keaki_hip_msm_g1(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, const uint64_t* scalars, size_t n, uint64_t* out_jac) {
+  CTX_GUARD(ctx);
+  if (!srs || !out_jac || (n && !scalars)) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm_g1: null pointer");
+  if (n > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", n, srs->n);
+  ST_TRY(upload(ctx, ctx->io_a, scalars, n * 32));
+  ST_TRY(reserve(ctx, ctx->io_b, 96));
+  ST_TRY(msm_g1_run(ctx, srs->d, srs->n, ctx->io_a.p, n, ctx->io_b.p));
+  ST_TRY(download(ctx, out_jac, ctx->io_b.p, 96));
+  resolve_timing(ctx);
+  return KEAKI_OK;
+}
+keaki_status keaki_hip_msm_g2_dev(keaki_hip_ctx* ctx, const keaki_hip_srs_g2* srs, const void* d_scalars, size_t n, void* d_out_jac) {
+  CTX_GUARD(ctx);
+  if (!srs) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm_g2: srs is null");
+  return msm_g2_run(ctx, srs->d, srs->n, d_scalars, n, d_out_jac);
+}
+keaki_status keaki_hip_msm_g2(keaki_hip_ctx* ctx, const keaki_hip_srs_g2* srs, const uint64_t* scalars, size_t n, uint64_t* out_jac) {
+  CTX_GUARD(ctx);
+  if (!srs || !out_jac || (n && !scalars)) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm_g2: null pointer");
+  if (n > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", n, srs->n);
+  ST_TRY(upload(ctx, ctx->io_a, scalars, n * 32));
+  ST_TRY(reserve(ctx, ctx->io_b, 192));
+  ST_TRY(msm_g2_run(ctx, srs->d, srs->n, ctx->io_a.p, n, ctx->io_b.p));
+  ST_TRY(download(ctx, out_jac, ctx->io_b.p, 192));
+  resolve_timing(ctx);
+  return KEAKI_OK;
+}
+keaki_status keaki_hip_g1_sum_dev(keaki_hip_ctx* ctx, const void* d_points_jac, size_t k, void* d_out_jac) {
+  CTX_GUARD(ctx);
+  if (!d_out_jac || (k && !d_points_jac)) return fail(ctx, KEAKI_ERR_BAD_ARG, "g1_sum: null pointer");
+  return g1_sum_run(ctx, d_points_jac, k, d_out_jac);
+}
+keaki_status keaki_hip_g1_sum(keaki_hip_ctx* ctx, const uint64_t* points_jac, size_t k, uint64_t* out_jac) {
+  CTX_GUARD(ctx);
+  if (!out_jac || (k && !points_jac)) return fail(ctx, KEAKI_ERR_BAD_ARG, "g1_sum: null pointer");
+  ST_TRY(upload(ctx, ctx->io_a, points_jac, k * 96));
+  ST_TRY(reserve(ctx, ctx->io_b, 96));
+  ST_TRY(g1_sum_run(ctx, ctx->io_a.p, k, ctx->io_b.p));
+  return download(ctx, out_jac, ctx->io_b.p, 96);
+}
+
+// ---- batched scalar multiplication -------------------------------------------------------------------
+keaki_status keaki_hip_g1_mul_batch_dev(keaki_hip_ctx* ctx, const void* d_points_aff, int32_t point_stride, const void* d_scalars, size_t n,
+                                        void* d_out_aff) {
+  CTX_GUARD(ctx);
+  if (n == 0) return KEAKI_OK;
+  if (!d_points_aff || !d_scalars || !d_out_aff || (point_stride != 0 && point_stride != 1)) return fail(ctx, KEAKI_ERR_BAD_ARG, "g1_mul_batch: bad argument");
+  return g1_mul_batch_run(ctx, d_points_aff, (int)point_stride, d_scalars, n, d_out_aff);
+}
+keaki_status keaki_hip_g2_mul_batch_dev(keaki_hip_ctx* ctx, const void* d_points_aff, int32_t point_stride, const void* d_scalars, size_t n,
+                                        void* d_out_aff) {
+  CTX_GUARD(ctx);
+  if (n == 0) return KEAKI_OK;
+  if (!d_points_aff || !d_scalars || !d_out_aff || (point_stride != 0 && point_stride != 1)) return fail(ctx, KEAKI_ERR_BAD_ARG, "g2_mul_batch: bad argument");
+  return g2_mul_batch_run(ctx, d_points_aff, (int)point_stride, d_scalars, n, d_out_aff);
+}
+keaki_status keaki_hip_g1_mul_batch(keaki_hip_ctx* ctx, const uint64_t* points_aff, int32_t point_stride, const uint64_t* scalars, size_t n,
+                                    uint64_t* out_aff) {
+  {
+    CTX_GUARD(ctx);
+    if (n == 0) return KEAKI_OK;
+    if (!points_aff || !scalars || !out_aff || (point_stride != 0 && point_stride != 1)) return fail(ctx, KEAKI_ERR_BAD_ARG, "g1_mul_batch: bad argument");
+    ST_TRY(upload(ctx, ctx->io_a, points_aff, (point_stride ? n : 1) * 64));
+    ST_TRY(upload(ctx, ctx->io_b, scalars, n * 32));
+    ST_TRY(reserve(ctx, ctx->io_c, n * 64));
+  }
+  ST_TRY(keaki_hip_g1_mul_batch_dev(ctx, ctx->io_a.p, point_stride, ctx->io_b.p, n, ctx->io_c.p));
+  CTX_GUARD(ctx);
+  return download(ctx, out_aff, ctx->io_c.p, n * 64);
+}
+keaki_status keaki_hip_g2_mul_batch(keaki_hip_ctx* ctx, const uint64_t* points_aff, int32_t point_stride, const uint64_t* scalars, size_t n,
+                                    uint64_t* out_aff) {
+  {
+    CTX_GUARD(ctx);
+    if (n == 0) return KEAKI_OK;
+    if (!points_aff || !scalars || !out_aff || (point_stride != 0 && point_stride != 1)) return fail(ctx, KEAKI_ERR_BAD_ARG, "g2_mul_batch: bad argument");
+    ST_TRY(upload(ctx, ctx->io_a, points_aff, (point_stride ? n : 1) * 128));
+    ST_TRY(upload(ctx, ctx->io_b, scalars, n * 32));
+    ST_TRY(reserve(ctx, ctx->io_c, n * 128));
+  }
+  ST_TRY(keaki_hip_g2_mul_batch_dev(ctx, ctx->io_a.p, point_stride, ctx->io_b.p, n, ctx->io_c.p));
+  CTX_GUARD(ctx);
+  return download(ctx, out_aff, ctx->io_c.p, n * 128);
+}
+
+// ---- pairing ---------------------------------------------------------------------------------------------
+keaki_status keaki_hip_pairing_batch_dev(keaki_hip_ctx* ctx, const void* d_g1_aff, const void* d_g2_aff, int32_t g2_stride, size_t n,
+                                         void* d_gt_out) {
+  CTX_GUARD(ctx);
+  if (n == 0) return KEAKI_OK;
+  if (!d_g1_aff || !d_g2_aff || !d_gt_out || (g2_stride != 0 && g2_stride != 1)) return fail(ctx, KEAKI_ERR_BAD_ARG, "pairing_batch: bad argument");
+  return pairing_run(ctx, d_g1_aff, d_g2_aff, (int)g2_stride, n, d_gt_out);
+}
+keaki_status keaki_hip_pairing_batch(keaki_hip_ctx* ctx, const uint64_t* g1_aff, const uint64_t* g2_aff, int32_t g2_stride, size_t n,
+                                     uint8_t* gt_out) {
+  {
+    CTX_GUARD(ctx);
+    if (n == 0) return KEAKI_OK;
+    if (!g1_aff || !g2_aff || !gt_out || (g2_stride != 0 && g2_stride != 1)) return fail(ctx, KEAKI_ERR_BAD_ARG, "pairing_batch: bad argument");
+    ST_TRY(upload(ctx, ctx->io_a, g1_aff, n * 64));
+    ST_TRY(upload(ctx, ctx->io_b, g2_aff, (g2_stride ? n : 1) * 128));
+    ST_TRY(reserve(ctx, ctx->io_c, n * 384));
+  }
+  ST_TRY(keaki_hip_pairing_batch_dev(ctx, ctx->io_a.p, ctx->io_b.p, g2_stride, n, ctx->io_c.p));
+  CTX_GUARD(ctx);
+  return download(ctx, gt_out, ctx->io_c.p, n * 384);
+}
+
+// ---- KEM composites ------------------------------------------------------------------------------------------
+keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff, const void* d_tau_g2_aff, const void* d_points,
+                                       const void* d_values, const void* d_r, size_t n, void* d_ct_out_aff, void* d_gt_out, void* d_key_out,
+                                       size_t msg_len) {
+  CTX_GUARD(ctx);
+  if (n == 0) return KEAKI_OK;
+  if (!d_com_aff || !d_tau_g2_aff || !d_points || !d_values || !d_r || !d_ct_out_aff || (!d_gt_out && !d_key_out) || msg_len > 65536)
+    return fail(ctx, KEAKI_ERR_BAD_ARG, "encap_batch: bad argument");
+  ST_TRY(reserve(ctx, ctx->tmp_a, n * G1_AFF_BYTES));
+  ST_TRY(reserve(ctx, ctx->tmp_c, G2_AFF_BYTES));
+  void* gt = d_gt_out;
+  if (!gt) { ST_TRY(reserve(ctx, ctx->tmp_b, n * 384)); gt = ctx->tmp_b.p; }
+  // generator g2 in device memory for the pairing's second slot (src/kem.rs:30 pairs with E::G2Affine::generator())
+  ST_TRY(g2_generator_to(ctx, ctx->tmp_c.p));
+  ST_TRY(encap_g1_run(ctx, d_com_aff, d_values, d_r, n, ctx->tmp_a.p));
+  ST_TRY(encap_g2_run(ctx, d_tau_g2_aff, d_points, d_r, n, d_ct_out_aff));
+  ST_TRY(pairing_run(ctx, ctx->tmp_a.p, ctx->tmp_c.p, 0, n, gt));
+  if (d_key_out && msg_len) ST_TRY(blake3_gt_run(ctx, gt, n, d_key_out, msg_len));
+  return KEAKI_OK;
+}
+keaki_status keaki_hip_decap_batch_dev(keaki_hip_ctx* ctx, const void* d_proofs_aff, const void* d_cts_aff, size_t n, void* d_gt_out,
+                                       void* d_key_out, size_t msg_len) {
+  CTX_GUARD(ctx);
+  if (n == 0) return KEAKI_OK;
+  if (!d_proofs_aff || !d_cts_aff || (!d_gt_out && !d_key_out) || msg_len > 65536) return fail(ctx, KEAKI_ERR_BAD_ARG, "decap_batch: bad argument");
+  void* gt = d_gt_out;
+  if (!gt) { ST_TRY(reserve(ctx, ctx->tmp_b, n * 384)); gt = ctx->tmp_b.p; }
+  ST_TRY(pairing_run(ctx, d_proofs_aff, d_cts_aff, 1, n, gt));
+  if (d_key_out && msg_len) ST_TRY(blake3_gt_run(ctx, gt, n, d_key_out, msg_len));
+  return KEAKI_OK;
+}
+keaki_status keaki_hip_encap_batch(keaki_hip_ctx* ctx, const uint64_t* com_aff, const uint64_t* tau_g2_aff, const uint64_t* points,
+                                   const uint64_t* values, const uint64_t* r, size_t n, uint64_t* ct_out_aff, uint8_t* gt_out, uint8_t* key_out,
+                                   size_t msg_len) {
+  size_t off_tau, off_pts, off_val, off_r, off_ct, off_gt, off_key, total;
+  {
+    CTX_GUARD(ctx);
+    if (n == 0) return KEAKI_OK;
+    if (!com_aff || !tau_g2_aff || !points || !values || !r || !ct_out_aff || (!gt_out && !key_out) || msg_len > 65536)
+      return fail(ctx, KEAKI_ERR_BAD_ARG, "encap_batch: bad argument");
+    off_tau = 64; off_pts = off_tau + 128; off_val = off_pts + n * 32; off_r = off_val + n * 32; off_ct = off_r + n * 32;
+    off_gt = off_ct + n * 128; off_key = off_gt + n * 384; total = off_key + n * msg_len + 16;
+    ST_TRY(reserve(ctx, ctx->io_a, total));
+    char* base = (char*)ctx->io_a.p;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(base, com_aff, 64, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + off_tau, tau_g2_aff, 128, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + off_pts, points, n * 32, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + off_val, values, n * 32, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + off_r, r, n * 32, hipMemcpyHostToDevice, st));
+  }
+  char* base = (char*)ctx->io_a.p;
+  ST_TRY(keaki_hip_encap_batch_dev(ctx, base, base + off_tau, base + off_pts, base + off_val, base + off_r, n, base + off_ct, base + off_gt,
+                                   key_out ? base + off_key : nullptr, msg_len));
+  CTX_GUARD(ctx);
+  hipStream_t st = ctx->stream;
+  HIP_TRY(ctx, hipMemcpyAsync(ct_out_aff, base + off_ct, n * 128, hipMemcpyDeviceToHost, st));
+  if (gt_out) HIP_TRY(ctx, hipMemcpyAsync(gt_out, base + off_gt, n * 384, hipMemcpyDeviceToHost, st));
+  if (key_out && msg_len) HIP_TRY(ctx, hipMemcpyAsync(key_out, base + off_key, n * msg_len, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return KEAKI_OK;
+}
+keaki_status keaki_hip_decap_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_aff, const uint64_t* cts_aff, size_t n, uint8_t* gt_out,
+                                   uint8_t* key_out, size_t msg_len) {
+  size_t off_ct, off_gt, off_key, total;
+  {
+    CTX_GUARD(ctx);
+    if (n == 0) return KEAKI_OK;
+    if (!proofs_aff || !cts_aff || (!gt_out && !key_out) || msg_len > 65536) return fail(ctx, KEAKI_ERR_BAD_ARG, "decap_batch: bad argument");
+    off_ct = n * 64; off_gt = off_ct + n * 128; off_key = off_gt + n * 384; total = off_key + n * msg_len + 16;
+    ST_TRY(reserve(ctx, ctx->io_a, total));
+    char* base = (char*)ctx->io_a.p;
+    HIP_TRY(ctx, hipMemcpyAsync(base, proofs_aff, n * 64, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(base + off_ct, cts_aff, n * 128, hipMemcpyHostToDevice, ctx->stream));
+  }
+  char* base = (char*)ctx->io_a.p;
+  ST_TRY(keaki_hip_decap_batch_dev(ctx, base, base + off_ct, n, base + off_gt, key_out ? base + off_key : nullptr, msg_len));
+  CTX_GUARD(ctx);
+  hipStream_t st = ctx->stream;
+  if (gt_out) HIP_TRY(ctx, hipMemcpyAsync(gt_out, base + off_gt, n * 384, hipMemcpyDeviceToHost, st));
+  if (key_out && msg_len) HIP_TRY(ctx, hipMemcpyAsync(key_out, base + off_key, n * msg_len, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return KEAKI_OK;
+}
+
+}  // extern "C"

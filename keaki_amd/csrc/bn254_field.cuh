@@ -1,0 +1,298 @@
+// BN254 prime-field arithmetic for gfx950 (CDNA4), Montgomery form, 8 x 32-bit limbs.
+//
+// Replaces ark-ff 0.4.2 `Fp<MontBackend<_, 4>>` (4 x u64 Montgomery, R = 2^256) on keaki's hot
+// path (reference call sites: src/kzg.rs:98, src/kem.rs:22-37,58). The residues are bit-identical
+// to ark-ff's: a u64[4] limb array from the host is read here as u32[8] little-endian, so the FFI
+// copies `Fp.0.0` without conversion.
+//
+// Integer-only (no MFMA: 256-bit modular products are not a dense contraction). The multiplier is
+// v_mad_u64_u32-based; everything is fully unrolled so limbs live in VGPRs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bn254 {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define KDEV __device__ __forceinline__
+
+struct FqParams;
+struct FrParams;
+
+template <class P>
+struct alignas(16) Fp {
+  u32 l[8];
+};
+using Fq = Fp<FqParams>;
+using Fr = Fp<FrParams>;
+struct alignas(16) Fq2 {
+  Fq c0, c1;
+};
+
+}  // namespace bn254
+
+#include "bn254_constants.cuh"
+
+namespace bn254 {
+
+// ---------------------------------------------------------------------------------------------
+// raw 256-bit helpers
+// ---------------------------------------------------------------------------------------------
+template <class P>
+KDEV bool fp_is_zero(const Fp<P>& a) {
+  u32 o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o |= a.l[i];
+  return o == 0;
+}
+template <class P>
+KDEV bool fp_eq(const Fp<P>& a, const Fp<P>& b) {
+  u32 o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o |= a.l[i] ^ b.l[i];
+  return o == 0;
+}
+template <class P>
+KDEV Fp<P> fp_zero() {
+  Fp<P> r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.l[i] = 0;
+  return r;
+}
+template <class P>
+KDEV Fp<P> fp_one() {
+  Fp<P> r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.l[i] = P::ONE[i];
+  return r;
+}
+
+// r = a - MOD if a >= MOD else a   (a < 2*MOD)
+template <class P>
+KDEV void fp_reduce_once(u32* t) {
+  u32 s[8];
+  u32 borrow = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    u64 d = (u64)t[j] - P::MOD[j] - borrow;
+    s[j] = (u32)d;
+    borrow = (u32)(d >> 63);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; j++) t[j] = borrow ? t[j] : s[j];
+}
+
+template <class P>
+KDEV Fp<P> fp_add(const Fp<P>& a, const Fp<P>& b) {
+  Fp<P> r;
+  u32 carry = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    u64 s = (u64)a.l[j] + b.l[j] + carry;
+    r.l[j] = (u32)s;
+    carry = (u32)(s >> 32);
+  }
+  // p < 2^254 so a+b < 2^255: no carry out of 256 bits
+  fp_reduce_once<P>(r.l);
+  return r;
+}
+template <class P>
+KDEV Fp<P> fp_dbl(const Fp<P>& a) {
+  return fp_add<P>(a, a);
+}
+template <class P>
+KDEV Fp<P> fp_sub(const Fp<P>& a, const Fp<P>& b) {
+  Fp<P> r;
+  u32 borrow = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    u64 d = (u64)a.l[j] - b.l[j] - borrow;
+    r.l[j] = (u32)d;
+    borrow = (u32)(d >> 63);
+  }
+  u32 mask = 0u - borrow;
+  u32 carry = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    u64 s = (u64)r.l[j] + (P::MOD[j] & mask) + carry;
+    r.l[j] = (u32)s;
+    carry = (u32)(s >> 32);
+  }
+  return r;
+}
+template <class P>
+KDEV Fp<P> fp_neg(const Fp<P>& a) {
+  Fp<P> r;
+  u32 nz = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) nz |= a.l[j];
+  u32 borrow = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    u64 d = (u64)P::MOD[j] - a.l[j] - borrow;
+    r.l[j] = nz ? (u32)d : 0u;
+    borrow = (u32)(d >> 63);
+  }
+  return r;
+}
+// conditional negate: r = neg ? -a : a
+template <class P>
+KDEV Fp<P> fp_cneg(const Fp<P>& a, bool neg) {
+  Fp<P> n = fp_neg<P>(a);
+  Fp<P> r;
+#pragma unroll
+  for (int j = 0; j < 8; j++) r.l[j] = neg ? n.l[j] : a.l[j];
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Montgomery multiplication: CIOS over 32-bit limbs. Because p < 2^254 (two spare bits) the
+// running value stays < 2p < 2^255 after every outer iteration, so no ninth limb is carried.
+// ---------------------------------------------------------------------------------------------
+template <class P>
+KDEV Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
+  u32 t[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    u64 c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      u64 x = (u64)a.l[j] * b.l[i] + (i ? t[j] : 0u) + c;
+      t[j] = (u32)x;
+      c = x >> 32;
+    }
+    u32 t8 = (u32)c;
+    u32 m = t[0] * P::INV;
+    u64 x = (u64)m * P::MOD[0] + t[0];
+    c = x >> 32;
+#pragma unroll
+    for (int j = 1; j < 8; j++) {
+      x = (u64)m * P::MOD[j] + t[j] + c;
+      t[j - 1] = (u32)x;
+      c = x >> 32;
+    }
+    t[7] = t8 + (u32)c;
+  }
+  fp_reduce_once<P>(t);
+  Fp<P> r;
+#pragma unroll
+  for (int j = 0; j < 8; j++) r.l[j] = t[j];
+  return r;
+}
+template <class P>
+KDEV Fp<P> fp_sqr(const Fp<P>& a) {
+  return fp_mul<P>(a, a);
+}
+// Montgomery -> canonical integer (ark-ff `into_bigint`): one Montgomery reduction of (a, 0)
+template <class P>
+KDEV void fp_from_mont(u32* out, const Fp<P>& a) {
+  u32 t[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) t[j] = a.l[j];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    u32 m = t[0] * P::INV;
+    u64 x = (u64)m * P::MOD[0] + t[0];
+    u64 c = x >> 32;
+#pragma unroll
+    for (int j = 1; j < 8; j++) {
+      x = (u64)m * P::MOD[j] + t[j] + c;
+      t[j - 1] = (u32)x;
+      c = x >> 32;
+    }
+    t[7] = (u32)c;
+  }
+  fp_reduce_once<P>(t);
+#pragma unroll
+  for (int j = 0; j < 8; j++) out[j] = t[j];
+}
+template <class P>
+KDEV Fp<P> fp_to_mont(const u32* canon) {
+  Fp<P> a, r2;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    a.l[j] = canon[j];
+    r2.l[j] = P::R2[j];
+  }
+  return fp_mul<P>(a, r2);
+}
+
+// a^(p-2). Not inlined: 380 multiplications, called once per batch / per pairing.
+static __device__ __noinline__ Fq fq_inv(const Fq& a) {
+  Fq acc = fp_one<FqParams>();
+  for (int i = 253; i >= 0; i--) {
+    acc = fp_sqr<FqParams>(acc);
+    if ((FQ_PM2[i >> 5] >> (i & 31)) & 1) acc = fp_mul<FqParams>(acc, a);
+  }
+  return acc;
+}
+
+// shorthand for Fq
+KDEV Fq operator+(const Fq& a, const Fq& b) { return fp_add<FqParams>(a, b); }
+KDEV Fq operator-(const Fq& a, const Fq& b) { return fp_sub<FqParams>(a, b); }
+KDEV Fq operator*(const Fq& a, const Fq& b) { return fp_mul<FqParams>(a, b); }
+KDEV Fq operator-(const Fq& a) { return fp_neg<FqParams>(a); }
+KDEV Fq fq_sqr(const Fq& a) { return fp_sqr<FqParams>(a); }
+KDEV Fq fq_dbl(const Fq& a) { return fp_dbl<FqParams>(a); }
+KDEV Fq fq_zero() { return fp_zero<FqParams>(); }
+KDEV Fq fq_one() { return fp_one<FqParams>(); }
+KDEV bool fq_is_zero(const Fq& a) { return fp_is_zero<FqParams>(a); }
+KDEV bool fq_eq(const Fq& a, const Fq& b) { return fp_eq<FqParams>(a, b); }
+
+// ---------------------------------------------------------------------------------------------
+// Fq2 = Fq[u]/(u^2+1)
+// ---------------------------------------------------------------------------------------------
+KDEV Fq2 operator+(const Fq2& a, const Fq2& b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
+KDEV Fq2 operator-(const Fq2& a, const Fq2& b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
+KDEV Fq2 operator-(const Fq2& a) { return {-a.c0, -a.c1}; }
+KDEV Fq2 fq2_dbl(const Fq2& a) { return {fq_dbl(a.c0), fq_dbl(a.c1)}; }
+KDEV Fq2 fq2_conj(const Fq2& a) { return {a.c0, -a.c1}; }
+KDEV Fq2 fq2_zero() { return {fq_zero(), fq_zero()}; }
+KDEV Fq2 fq2_one() { return {fq_one(), fq_zero()}; }
+KDEV bool fq2_is_zero(const Fq2& a) { return fq_is_zero(a.c0) && fq_is_zero(a.c1); }
+KDEV bool fq2_eq(const Fq2& a, const Fq2& b) { return fq_eq(a.c0, b.c0) && fq_eq(a.c1, b.c1); }
+KDEV Fq2 operator*(const Fq2& a, const Fq2& b) {  // Karatsuba: 3 Fq products
+  Fq t0 = a.c0 * b.c0, t1 = a.c1 * b.c1;
+  Fq t2 = (a.c0 + a.c1) * (b.c0 + b.c1);
+  return {t0 - t1, t2 - t0 - t1};
+}
+KDEV Fq2 fq2_sqr(const Fq2& a) {  // (a0+a1)(a0-a1) + 2 a0 a1 u
+  Fq m = a.c0 * a.c1;
+  return {(a.c0 + a.c1) * (a.c0 - a.c1), fq_dbl(m)};
+}
+KDEV Fq2 fq2_mul_fq(const Fq2& a, const Fq& k) { return {a.c0 * k, a.c1 * k}; }
+KDEV Fq2 fq2_mul_xi(const Fq2& a) {  // (9+u) a
+  Fq t0 = fq_dbl(fq_dbl(fq_dbl(a.c0))) + a.c0;
+  Fq t1 = fq_dbl(fq_dbl(fq_dbl(a.c1))) + a.c1;
+  return {t0 - a.c1, t1 + a.c0};
+}
+KDEV Fq2 fq2_inv(const Fq2& a) {
+  Fq n = fq_sqr(a.c0) + fq_sqr(a.c1);
+  Fq ni = fq_inv(n);
+  return {a.c0 * ni, -(a.c1 * ni)};
+}
+KDEV Fq2 fq2_cneg(const Fq2& a, bool neg) { return {fp_cneg<FqParams>(a.c0, neg), fp_cneg<FqParams>(a.c1, neg)}; }
+
+// field-generic front (lets the curve code be written once for Fq and Fq2)
+KDEV Fq f_sqr(const Fq& a) { return fq_sqr(a); }
+KDEV Fq2 f_sqr(const Fq2& a) { return fq2_sqr(a); }
+KDEV Fq f_dbl(const Fq& a) { return fq_dbl(a); }
+KDEV Fq2 f_dbl(const Fq2& a) { return fq2_dbl(a); }
+KDEV bool f_is_zero(const Fq& a) { return fq_is_zero(a); }
+KDEV bool f_is_zero(const Fq2& a) { return fq2_is_zero(a); }
+KDEV bool f_eq(const Fq& a, const Fq& b) { return fq_eq(a, b); }
+KDEV bool f_eq(const Fq2& a, const Fq2& b) { return fq2_eq(a, b); }
+KDEV Fq f_inv(const Fq& a) { return fq_inv(a); }
+KDEV Fq2 f_inv(const Fq2& a) { return fq2_inv(a); }
+KDEV Fq f_cneg(const Fq& a, bool n) { return fp_cneg<FqParams>(a, n); }
+KDEV Fq2 f_cneg(const Fq2& a, bool n) { return fq2_cneg(a, n); }
+template <class F> KDEV F f_zero();
+template <> KDEV Fq f_zero<Fq>() { return fq_zero(); }
+template <> KDEV Fq2 f_zero<Fq2>() { return fq2_zero(); }
+template <class F> KDEV F f_one();
+template <> KDEV Fq f_one<Fq>() { return fq_one(); }
+template <> KDEV Fq2 f_one<Fq2>() { return fq2_one(); }
+
+}  // namespace bn254

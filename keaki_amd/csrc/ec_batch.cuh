@@ -1,0 +1,69 @@
+// Batched (n independent outputs) scalar multiplication in G1 / G2 and the group part of
+// kem::encapsulate. One lane per item, Jacobian double-and-add from the top bit.
+//
+// Replaces `.mul(scalar)` at reference src/kem.rs:22,30,36,37 and src/kzg.rs:57,60,135,144 as they
+// occur inside the loops of src/vec.rs:63-66.
+#pragma once
+#include "bn254_curve.cuh"
+
+namespace bn254 {
+
+// k * P, k given as Montgomery Fr. MSB-first; the 256-bit scalar is shifted left one bit per step so
+// register indices stay static.
+template <class F>
+KDEV Jac<F> scalar_mul(const Aff<F>& p, const Fr& k_mont) {
+  u32 v[8];
+  fp_from_mont<FrParams>(v, k_mont);
+  Jac<F> acc = jac_inf<F>();
+  if (aff_is_inf(p)) return acc;
+  // skip the two always-zero top bits (r < 2^254)
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+#pragma unroll
+    for (int j = 7; j > 0; j--) v[j] = (v[j] << 1) | (v[j - 1] >> 31);
+    v[0] <<= 1;
+  }
+#pragma unroll 1
+  for (int i = 0; i < 254; i++) {
+    acc = jac_dbl(acc);
+    if (v[7] >> 31) acc = jac_add_mixed(acc, p);
+#pragma unroll
+    for (int j = 7; j > 0; j--) v[j] = (v[j] << 1) | (v[j - 1] >> 31);
+    v[0] <<= 1;
+  }
+  return acc;
+}
+
+template <class F>
+__global__ void __launch_bounds__(64) k_mul_batch(const Aff<F>* __restrict__ pts, int stride, const Fr* __restrict__ scalars, u32 n,
+                                                  Aff<F>* __restrict__ out) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F> p = pts[(size_t)i * stride];
+  out[i] = jac_to_aff(scalar_mul(p, scalars[i]));
+}
+
+// encapsulate, G1 side (src/kem.rs:22,30): out[i] = r[i] * (com - values[i] * g1)   (affine)
+static __global__ void __launch_bounds__(64) k_encap_g1(const G1Aff* __restrict__ com, const Fr* __restrict__ values, const Fr* __restrict__ rs,
+                                                 u32 n, G1Aff* __restrict__ out) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1Aff g = {G1_GEN_X, G1_GEN_Y};
+  G1Jac t = scalar_mul(g, values[i]);
+  t.y = -t.y;
+  G1Aff cb = jac_to_aff(jac_add_mixed(t, *com));
+  out[i] = jac_to_aff(scalar_mul(cb, rs[i]));
+}
+// encapsulate, G2 side (src/kem.rs:36-37): ct[i] = r[i] * (tau_g2 - points[i] * g2)   (affine)
+static __global__ void __launch_bounds__(64) k_encap_g2(const G2Aff* __restrict__ tau_g2, const Fr* __restrict__ points, const Fr* __restrict__ rs,
+                                                 u32 n, G2Aff* __restrict__ out) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G2Aff g = {G2_GEN_X, G2_GEN_Y};
+  G2Jac t = scalar_mul(g, points[i]);
+  t.y = -t.y;
+  G2Aff ta = jac_to_aff(jac_add_mixed(t, *tau_g2));
+  out[i] = jac_to_aff(scalar_mul(ta, rs[i]));
+}
+
+}  // namespace bn254

@@ -1,0 +1,21 @@
+// G2 batched scalar multiplication and the G2 half of encapsulate (reference src/kem.rs:36-37).
+#include "ec_batch.cuh"
+#include "internal.h"
+namespace keaki_internal {
+using namespace bn254;
+keaki_status g2_mul_batch_run(keaki_hip_ctx* ctx, const void* d_pts, int stride, const void* d_scalars, size_t n, void* d_out) {
+  hipLaunchKernelGGL((k_mul_batch<Fq2>), dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, (const G2Aff*)d_pts, stride, (const Fr*)d_scalars, (u32)n,
+                     (G2Aff*)d_out);
+  return launch_check(ctx, "g2_mul_batch");
+}
+keaki_status encap_g2_run(keaki_hip_ctx* ctx, const void* d_tau_g2, const void* d_points, const void* d_r, size_t n, void* d_out) {
+  hipLaunchKernelGGL(k_encap_g2, dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, (const G2Aff*)d_tau_g2, (const Fr*)d_points, (const Fr*)d_r, (u32)n,
+                     (G2Aff*)d_out);
+  return launch_check(ctx, "encap_g2");
+}
+keaki_status g2_generator_to(keaki_hip_ctx* ctx, void* d_dst) {
+  HIP_TRY(ctx, hipMemcpyFromSymbolAsync(d_dst, HIP_SYMBOL(G2_GEN_X), sizeof(Fq2), 0, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyFromSymbolAsync((char*)d_dst + sizeof(Fq2), HIP_SYMBOL(G2_GEN_Y), sizeof(Fq2), 0, hipMemcpyDeviceToDevice, ctx->stream));
+  return KEAKI_OK;
+}
+}  // namespace keaki_internal

@@ -1,0 +1,71 @@
+// Internal (not installed) declarations shared by the translation units of libkeaki_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "../../include/keaki_hip.h"
+
+namespace keaki_internal {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace keaki_internal
+
+struct keaki_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::mutex mu;
+  std::string err;
+  // grow-only workspaces (all used in stream order)
+  keaki_internal::DevBuf digits, hist, offsets, cursor, sorted, buckets, partials, wsums, bsums, tmp_a, tmp_b, tmp_c, io_a, io_b, io_c, io_d, io_e;
+  // instrumentation
+  bool timing = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  float last_bucket_ms = -1.f, last_total_ms = -1.f;
+  int last_c = 0;
+  bool timing_pending = false;
+};
+
+namespace keaki_internal {
+
+keaki_status fail(keaki_hip_ctx* ctx, keaki_status code, const char* fmt, ...);
+keaki_status reserve(keaki_hip_ctx* ctx, DevBuf& b, size_t bytes);
+keaki_status launch_check(keaki_hip_ctx* ctx, const char* what);
+inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
+
+#define HIP_TRY(ctx, call)                                                                              \
+  do {                                                                                                  \
+    hipError_t e_ = (call);                                                                             \
+    if (e_ != hipSuccess)                                                                               \
+      return keaki_internal::fail(ctx, e_ == hipErrorOutOfMemory ? KEAKI_ERR_OOM : KEAKI_ERR_HIP, "%s failed: %s (%s:%d)", #call, \
+                  hipGetErrorString(e_), __FILE__, __LINE__);                                           \
+  } while (0)
+#define ST_TRY(call)                 \
+  do {                               \
+    keaki_status s_ = (call);        \
+    if (s_ != KEAKI_OK) return s_;   \
+  } while (0)
+
+// launchers implemented in the kernel translation units (all enqueue on ctx->stream, no sync)
+keaki_status msm_g1_run(keaki_hip_ctx* ctx, const void* d_points, size_t srs_len, const void* d_scalars, size_t n, void* d_out_jac);
+keaki_status msm_g2_run(keaki_hip_ctx* ctx, const void* d_points, size_t srs_len, const void* d_scalars, size_t n, void* d_out_jac);
+keaki_status g1_sum_run(keaki_hip_ctx* ctx, const void* d_points_jac, size_t k, void* d_out_jac);
+keaki_status g1_mul_batch_run(keaki_hip_ctx* ctx, const void* d_pts, int stride, const void* d_scalars, size_t n, void* d_out);
+keaki_status g2_mul_batch_run(keaki_hip_ctx* ctx, const void* d_pts, int stride, const void* d_scalars, size_t n, void* d_out);
+keaki_status encap_g1_run(keaki_hip_ctx* ctx, const void* d_com, const void* d_values, const void* d_r, size_t n, void* d_out);
+keaki_status encap_g2_run(keaki_hip_ctx* ctx, const void* d_tau_g2, const void* d_points, const void* d_r, size_t n, void* d_out);
+keaki_status pairing_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, int g2_stride, size_t n, void* d_gt);
+keaki_status blake3_gt_run(keaki_hip_ctx* ctx, const void* d_gt, size_t n, void* d_key, size_t msg_len);
+keaki_status g2_generator_to(keaki_hip_ctx* ctx, void* d_dst);  // writes the affine G2 generator (128 B)
+
+}  // namespace keaki_internal

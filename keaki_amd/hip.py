@@ -1,0 +1,255 @@
+"""ctypes binding of libkeaki_hip.so (include/keaki_hip.h). Plumbing only -- no arithmetic here.
+
+Arrays are numpy uint64 in the C-ABI layouts (Montgomery limbs, see the header). The *_dev methods
+take raw device pointers (ints), e.g. torch_tensor.data_ptr(), so callers can keep data resident
+in HBM; torch itself is never imported here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+EXPORTS = [
+    "keaki_hip_ctx_create", "keaki_hip_ctx_destroy", "keaki_hip_last_error", "keaki_hip_synchronize", "keaki_hip_version",
+    "keaki_hip_srs_g1_upload", "keaki_hip_srs_g1_wrap_dev", "keaki_hip_srs_g1_len", "keaki_hip_srs_g1_free",
+    "keaki_hip_srs_g2_upload", "keaki_hip_srs_g2_wrap_dev", "keaki_hip_srs_g2_free",
+    "keaki_hip_msm_g1", "keaki_hip_msm_g1_dev", "keaki_hip_msm_g2", "keaki_hip_msm_g2_dev",
+    "keaki_hip_g1_sum_dev", "keaki_hip_g1_sum",
+    "keaki_hip_g1_mul_batch", "keaki_hip_g2_mul_batch", "keaki_hip_g1_mul_batch_dev", "keaki_hip_g2_mul_batch_dev",
+    "keaki_hip_pairing_batch", "keaki_hip_pairing_batch_dev",
+    "keaki_hip_encap_batch", "keaki_hip_encap_batch_dev", "keaki_hip_decap_batch", "keaki_hip_decap_batch_dev",
+    "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
+]
+
+KEAKI_ERR_TOO_LARGE = -5
+
+
+class KeakiHipError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"keaki_hip error {status}: {message}")
+        self.status = status
+        self.message = message
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "libkeaki_hip.so")
+
+
+def load_library():
+    """Loads libkeaki_hip.so. Raises (never falls back) when the HIP extension is missing."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise KeakiHipError(-100, f"{path} not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                      f"or `make -C keaki_amd/csrc`. There is no CPU fallback.")
+        lib = C.CDLL(path)
+        vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int32
+        lib.keaki_hip_version.restype = C.c_char_p
+        lib.keaki_hip_last_error.restype = C.c_char_p
+        lib.keaki_hip_last_error.argtypes = [vp]
+        lib.keaki_hip_ctx_create.argtypes = [i32, vp, C.POINTER(vp)]
+        lib.keaki_hip_ctx_destroy.argtypes = [vp]
+        lib.keaki_hip_ctx_destroy.restype = None
+        lib.keaki_hip_synchronize.argtypes = [vp]
+        for g in ("g1", "g2"):
+            getattr(lib, f"keaki_hip_srs_{g}_upload").argtypes = [vp, vp, sz, C.POINTER(vp)]
+            getattr(lib, f"keaki_hip_srs_{g}_wrap_dev").argtypes = [vp, vp, sz, C.POINTER(vp)]
+            getattr(lib, f"keaki_hip_srs_{g}_free").argtypes = [vp, vp]
+            getattr(lib, f"keaki_hip_srs_{g}_free").restype = None
+            getattr(lib, f"keaki_hip_msm_{g}").argtypes = [vp, vp, vp, sz, vp]
+            getattr(lib, f"keaki_hip_msm_{g}_dev").argtypes = [vp, vp, vp, sz, vp]
+            getattr(lib, f"keaki_hip_{g}_mul_batch").argtypes = [vp, vp, i32, vp, sz, vp]
+            getattr(lib, f"keaki_hip_{g}_mul_batch_dev").argtypes = [vp, vp, i32, vp, sz, vp]
+        lib.keaki_hip_srs_g1_len.argtypes = [vp]
+        lib.keaki_hip_srs_g1_len.restype = sz
+        lib.keaki_hip_g1_sum.argtypes = [vp, vp, sz, vp]
+        lib.keaki_hip_g1_sum_dev.argtypes = [vp, vp, sz, vp]
+        lib.keaki_hip_pairing_batch.argtypes = [vp, vp, vp, i32, sz, vp]
+        lib.keaki_hip_pairing_batch_dev.argtypes = [vp, vp, vp, i32, sz, vp]
+        lib.keaki_hip_encap_batch.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, sz]
+        lib.keaki_hip_encap_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, sz]
+        lib.keaki_hip_decap_batch.argtypes = [vp, vp, vp, sz, vp, vp, sz]
+        lib.keaki_hip_decap_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, sz]
+        lib.keaki_hip_set_timing.argtypes = [vp, i32]
+        lib.keaki_hip_last_msm_bucket_ms.argtypes = [vp]
+        lib.keaki_hip_last_msm_bucket_ms.restype = C.c_float
+        lib.keaki_hip_last_msm_total_ms.argtypes = [vp]
+        lib.keaki_hip_last_msm_total_ms.restype = C.c_float
+        lib.keaki_hip_last_msm_window_bits.argtypes = [vp]
+        _LIB = lib
+    return _LIB
+
+
+def _np(a, width=None):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if width is not None:
+        a = a.reshape(-1, width)
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class SrsG1:
+    def __init__(self, owner, handle, n):
+        self.owner, self.handle, self.n = owner, handle, n
+
+    def free(self):
+        if self.handle:
+            self.owner.lib.keaki_hip_srs_g1_free(self.owner.ctx, self.handle)
+            self.handle = None
+
+
+class SrsG2(SrsG1):
+    def free(self):
+        if self.handle:
+            self.owner.lib.keaki_hip_srs_g2_free(self.owner.ctx, self.handle)
+            self.handle = None
+
+
+class KeakiHip:
+    """One context = one GPU (one process per GPU in multi-GPU runs)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = load_library()
+        ctx = C.c_void_p()
+        st = self.lib.keaki_hip_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(ctx))
+        if st != 0:
+            raise KeakiHipError(st, self.lib.keaki_hip_last_error(None).decode())
+        self.ctx = ctx
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.keaki_hip_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, st):
+        if st != 0:
+            raise KeakiHipError(st, self.lib.keaki_hip_last_error(self.ctx).decode())
+
+    def synchronize(self):
+        self._ck(self.lib.keaki_hip_synchronize(self.ctx))
+
+    def set_timing(self, on: bool):
+        self._ck(self.lib.keaki_hip_set_timing(self.ctx, 1 if on else 0))
+
+    def last_msm_stats(self):
+        return {"bucket_ms": float(self.lib.keaki_hip_last_msm_bucket_ms(self.ctx)),
+                "total_ms": float(self.lib.keaki_hip_last_msm_total_ms(self.ctx)),
+                "window_bits": int(self.lib.keaki_hip_last_msm_window_bits(self.ctx))}
+
+    # ---- SRS
+    def srs_g1_upload(self, points) -> SrsG1:
+        pts = _np(points, 8); h = C.c_void_p()
+        self._ck(self.lib.keaki_hip_srs_g1_upload(self.ctx, _ptr(pts), pts.shape[0], C.byref(h)))
+        return SrsG1(self, h, pts.shape[0])
+
+    def srs_g1_wrap_dev(self, dptr: int, n: int) -> SrsG1:
+        h = C.c_void_p()
+        self._ck(self.lib.keaki_hip_srs_g1_wrap_dev(self.ctx, C.c_void_p(dptr), n, C.byref(h)))
+        return SrsG1(self, h, n)
+
+    def srs_g2_upload(self, points) -> SrsG2:
+        pts = _np(points, 16); h = C.c_void_p()
+        self._ck(self.lib.keaki_hip_srs_g2_upload(self.ctx, _ptr(pts), pts.shape[0], C.byref(h)))
+        return SrsG2(self, h, pts.shape[0])
+
+    # ---- MSM
+    def msm_g1(self, srs: SrsG1, scalars) -> np.ndarray:
+        sc = _np(scalars, 4); out = np.zeros(12, np.uint64)
+        self._ck(self.lib.keaki_hip_msm_g1(self.ctx, srs.handle, _ptr(sc), sc.shape[0], _ptr(out)))
+        return out
+
+    def msm_g1_dev(self, srs: SrsG1, d_scalars: int, n: int, d_out: int):
+        self._ck(self.lib.keaki_hip_msm_g1_dev(self.ctx, srs.handle, C.c_void_p(d_scalars), n, C.c_void_p(d_out)))
+
+    def msm_g2(self, srs: SrsG2, scalars) -> np.ndarray:
+        sc = _np(scalars, 4); out = np.zeros(24, np.uint64)
+        self._ck(self.lib.keaki_hip_msm_g2(self.ctx, srs.handle, _ptr(sc), sc.shape[0], _ptr(out)))
+        return out
+
+    def g1_sum(self, points_jac) -> np.ndarray:
+        p = _np(points_jac, 12); out = np.zeros(12, np.uint64)
+        self._ck(self.lib.keaki_hip_g1_sum(self.ctx, _ptr(p), p.shape[0], _ptr(out)))
+        return out
+
+    def g1_sum_dev(self, d_points: int, k: int, d_out: int):
+        self._ck(self.lib.keaki_hip_g1_sum_dev(self.ctx, C.c_void_p(d_points), k, C.c_void_p(d_out)))
+
+    # ---- batched scalar multiplication
+    def g1_mul_batch(self, points, scalars) -> np.ndarray:
+        pts = _np(points); sc = _np(scalars, 4); n = sc.shape[0]
+        stride = 0 if pts.size == 8 else 1
+        out = np.zeros((n, 8), np.uint64)
+        self._ck(self.lib.keaki_hip_g1_mul_batch(self.ctx, _ptr(pts), stride, _ptr(sc), n, _ptr(out)))
+        return out
+
+    def g2_mul_batch(self, points, scalars) -> np.ndarray:
+        pts = _np(points); sc = _np(scalars, 4); n = sc.shape[0]
+        stride = 0 if pts.size == 16 else 1
+        out = np.zeros((n, 16), np.uint64)
+        self._ck(self.lib.keaki_hip_g2_mul_batch(self.ctx, _ptr(pts), stride, _ptr(sc), n, _ptr(out)))
+        return out
+
+    def g1_mul_batch_dev(self, d_points: int, stride: int, d_scalars: int, n: int, d_out: int):
+        self._ck(self.lib.keaki_hip_g1_mul_batch_dev(self.ctx, C.c_void_p(d_points), stride, C.c_void_p(d_scalars), n, C.c_void_p(d_out)))
+
+    def g2_mul_batch_dev(self, d_points: int, stride: int, d_scalars: int, n: int, d_out: int):
+        self._ck(self.lib.keaki_hip_g2_mul_batch_dev(self.ctx, C.c_void_p(d_points), stride, C.c_void_p(d_scalars), n, C.c_void_p(d_out)))
+
+    # ---- pairing
+    def pairing_batch(self, g1, g2) -> np.ndarray:
+        p = _np(g1, 8); q = _np(g2); n = p.shape[0]
+        stride = 0 if q.size == 16 else 1
+        out = np.zeros((n, 384), np.uint8)
+        self._ck(self.lib.keaki_hip_pairing_batch(self.ctx, _ptr(p), _ptr(q), stride, n, _ptr(out)))
+        return out
+
+    def pairing_batch_dev(self, d_g1: int, d_g2: int, stride: int, n: int, d_gt: int):
+        self._ck(self.lib.keaki_hip_pairing_batch_dev(self.ctx, C.c_void_p(d_g1), C.c_void_p(d_g2), stride, n, C.c_void_p(d_gt)))
+
+    # ---- KEM composites
+    def encap_batch(self, com, tau_g2, points, values, rs, msg_len: int = 32):
+        com = _np(com); tau = _np(tau_g2); pts = _np(points, 4); vals = _np(values, 4); rs = _np(rs, 4)
+        n = pts.shape[0]
+        ct = np.zeros((n, 16), np.uint64); gt = np.zeros((n, 384), np.uint8); key = np.zeros((n, max(msg_len, 1)), np.uint8)
+        self._ck(self.lib.keaki_hip_encap_batch(self.ctx, _ptr(com), _ptr(tau), _ptr(pts), _ptr(vals), _ptr(rs), n,
+                                                _ptr(ct), _ptr(gt), _ptr(key) if msg_len else None, msg_len))
+        return ct, gt, key[:, :msg_len]
+
+    def encap_batch_dev(self, d_com, d_tau, d_points, d_values, d_r, n, d_ct, d_gt, d_key, msg_len):
+        v = lambda x: C.c_void_p(x) if x else None
+        self._ck(self.lib.keaki_hip_encap_batch_dev(self.ctx, v(d_com), v(d_tau), v(d_points), v(d_values), v(d_r), n, v(d_ct), v(d_gt), v(d_key), msg_len))
+
+    def decap_batch(self, proofs, cts, msg_len: int = 32):
+        p = _np(proofs, 8); c = _np(cts, 16); n = p.shape[0]
+        gt = np.zeros((n, 384), np.uint8); key = np.zeros((n, max(msg_len, 1)), np.uint8)
+        self._ck(self.lib.keaki_hip_decap_batch(self.ctx, _ptr(p), _ptr(c), n, _ptr(gt), _ptr(key) if msg_len else None, msg_len))
+        return gt, key[:, :msg_len]
+
+    def decap_batch_dev(self, d_proofs, d_cts, n, d_gt, d_key, msg_len):
+        v = lambda x: C.c_void_p(x) if x else None
+        self._ck(self.lib.keaki_hip_decap_batch_dev(self.ctx, v(d_proofs), v(d_cts), n, v(d_gt), v(d_key), msg_len))
+
+
+def jac_to_affine_words(jac) -> np.ndarray:
+    """normalised Jacobian u64[12] (x, y, 1 | 1, 1, 0) -> affine u64[8] (identity = zeros). Pure relabelling."""
+    j = _np(jac).reshape(-1)
+    w = j.size // 3
+    out = np.zeros(2 * w, np.uint64)
+    if np.any(j[2 * w:]):
+        out[:] = j[:2 * w]
+    return out

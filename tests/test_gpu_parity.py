@@ -1,0 +1,163 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+Bit-exact: integer work, so every comparison is equality of canonical limbs / bytes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def mont(oc, ints):
+    return oc.fr_to_mont(oc.ints_to_limbs(ints)) if len(ints) else np.zeros((0, 4), np.uint64)
+
+
+def jac_to_aff(j):
+    from keaki_amd.hip import jac_to_affine_words
+    return jac_to_affine_words(j)
+
+
+def make_points_g1(oc, hip, n, seed):
+    g1, _ = oc.generators()
+    from conftest import rand_fr_ints
+    ks = rand_fr_ints(n, seed)
+    pts = hip.g1_mul_batch(g1, mont(oc, ks)) if n else np.zeros((0, 8), np.uint64)
+    return ks, pts
+
+
+def test_g1_mul_batch_vs_oracle(oc, py, hip, rand_fr):
+    g1, _ = oc.generators()
+    ks = rand_fr(29, 11) + [0, 1, py.R - 1]
+    km = mont(oc, ks)
+    got = hip.g1_mul_batch(g1, km)
+    exp = oc.g1_mul_batch(g1, km)
+    assert np.array_equal(got, exp)
+    # per-item points, including the identity
+    pts = got.copy()
+    pts[3] = 0
+    k2 = mont(oc, rand_fr(32, 12))
+    assert np.array_equal(hip.g1_mul_batch(pts, k2), oc.g1_mul_batch(pts, k2))
+
+
+def test_g2_mul_batch_vs_oracle(oc, py, hip, rand_fr):
+    _, g2 = oc.generators()
+    ks = rand_fr(13, 21) + [0, 1, py.R - 1]
+    km = mont(oc, ks)
+    got = hip.g2_mul_batch(g2, km)
+    assert np.array_equal(got, oc.g2_mul_batch(g2, km))
+    k2 = mont(oc, rand_fr(16, 22))
+    assert np.array_equal(hip.g2_mul_batch(got, k2), oc.g2_mul_batch(got, k2))
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 31, 32, 33, 257, 1000, 4096])
+def test_msm_g1_vs_oracle(oc, hip, rand_fr, n):
+    _, pts = make_points_g1(oc, hip, n, 100 + n)
+    sc = mont(oc, rand_fr(n, 200 + n))
+    srs = hip.srs_g1_upload(pts)
+    try:
+        got = jac_to_aff(hip.msm_g1(srs, sc))
+    finally:
+        srs.free()
+    assert np.array_equal(got, oc.msm_g1(pts, sc, threads=4))
+
+
+def test_msm_g1_edge_cases(oc, py, hip, rand_fr):
+    n = 300
+    _, pts = make_points_g1(oc, hip, n, 7)
+    ints = rand_fr(n, 8)
+    ints[0] = 0; ints[1] = py.R - 1; ints[2] = 1; ints[3] = 2**253; ints[4] = (1 << 128) - 1
+    pts[5] = 0                      # identity point
+    pts[6] = pts[7]                 # repeated points (forces the doubling branch when digits match)
+    ints[6] = ints[7]
+    pts[8] = pts[9]; ints[8] = (py.R - ints[9]) % py.R   # P and -P contributions cancel
+    sc = mont(oc, ints)
+    srs = hip.srs_g1_upload(pts)
+    try:
+        assert np.array_equal(jac_to_aff(hip.msm_g1(srs, sc)), oc.msm_g1(pts, sc))
+        # all-equal scalars, all-equal points
+        sc2 = mont(oc, [ints[10]] * n)
+        assert np.array_equal(jac_to_aff(hip.msm_g1(srs, sc2)), oc.msm_g1(pts, sc2))
+        # all-zero scalars -> identity
+        z = hip.msm_g1(srs, np.zeros((n, 4), np.uint64))
+        assert not np.any(jac_to_aff(z)) and not np.any(z[8:])
+        # prefix (polynomial shorter than the SRS): zip-truncation like msm_unchecked
+        assert np.array_equal(jac_to_aff(hip.msm_g1(srs, sc[:100])), oc.msm_g1(pts[:100], sc[:100]))
+    finally:
+        srs.free()
+    same = np.repeat(pts[11:12], 64, 0)
+    srs = hip.srs_g1_upload(same)
+    try:
+        sc3 = mont(oc, rand_fr(64, 9))
+        assert np.array_equal(jac_to_aff(hip.msm_g1(srs, sc3)), oc.msm_g1(same, sc3))
+    finally:
+        srs.free()
+
+
+def test_msm_too_large_is_an_error(oc, hip):
+    from keaki_amd.hip import KeakiHipError, KEAKI_ERR_TOO_LARGE
+    g1, _ = oc.generators()
+    srs = hip.srs_g1_upload(np.repeat(g1[None, :], 4, 0))
+    try:
+        with pytest.raises(KeakiHipError) as e:
+            hip.msm_g1(srs, np.zeros((5, 4), np.uint64))
+        assert e.value.status == KEAKI_ERR_TOO_LARGE
+    finally:
+        srs.free()
+
+
+@pytest.mark.parametrize("n", [1, 33, 200])
+def test_msm_g2_vs_oracle(oc, hip, rand_fr, n):
+    _, g2 = oc.generators()
+    pts = hip.g2_mul_batch(g2, mont(oc, rand_fr(n, 300 + n)))
+    sc = mont(oc, rand_fr(n, 400 + n))
+    srs = hip.srs_g2_upload(pts)
+    try:
+        got = jac_to_aff(hip.msm_g2(srs, sc))
+    finally:
+        srs.free()
+    assert np.array_equal(got, oc.msm_g2(pts, sc, threads=4))
+
+
+def test_g1_sum_of_partials(oc, hip, rand_fr):
+    g1, _ = oc.generators()
+    pts = hip.g1_mul_batch(g1, mont(oc, rand_fr(8, 55)))
+    one = oc.fq_to_mont(oc.ints_to_limbs([1]))[0]
+    jac = np.concatenate([pts, np.tile(one, (8, 1))], axis=1)
+    jac[3, :4] = one; jac[3, 4:8] = one; jac[3, 8:] = 0    # identity partial (1,1,0)
+    pts[3] = 0
+    assert np.array_equal(jac_to_aff(hip.g1_sum(jac)), oc.g1_sum(pts))
+
+
+def test_pairing_batch_vs_oracle(oc, py, hip, rand_fr):
+    g1, g2 = oc.generators()
+    n = 24
+    P = hip.g1_mul_batch(g1, mont(oc, rand_fr(n, 31)))
+    Q = hip.g2_mul_batch(g2, mont(oc, rand_fr(n, 32)))
+    P[0] = g1; Q[0] = g2
+    P[1] = 0            # identity in the G1 slot -> GT one
+    Q[2] = 0            # identity in the G2 slot -> GT one
+    got = hip.pairing_batch(P, Q)
+    exp = oc.pairing_batch(P, Q, threads=8)
+    assert np.array_equal(got, exp)
+    one = py.gt_serialize(py.F12_ONE)
+    assert got[1].tobytes() == one and got[2].tobytes() == one
+    # broadcast Q (the encapsulate shape)
+    assert np.array_equal(hip.pairing_batch(P, g2), oc.pairing_batch(P, g2, threads=8))
+
+
+def test_encap_decap_vs_oracle(oc, py, hip, rand_fr):
+    g1, g2 = oc.generators()
+    n = 16
+    tau, c0 = rand_fr(2, 41)
+    com = hip.g1_mul_batch(g1, mont(oc, [c0]))[0]
+    tau_g2 = hip.g2_mul_batch(g2, mont(oc, [tau]))[0]
+    pts = mont(oc, rand_fr(n, 42)); vals = mont(oc, rand_fr(n, 43)); rs = mont(oc, rand_fr(n, 44))
+    ct, gt, key = hip.encap_batch(com, tau_g2, pts, vals, rs, 32)
+    ect, egt, ekey = oc.encap_batch(com, tau_g2, pts, vals, rs, 32, threads=8)
+    assert np.array_equal(ct, ect) and np.array_equal(gt, egt) and np.array_equal(key, ekey)
+    # long XOF output and odd length
+    _, _, key2 = hip.encap_batch(com, tau_g2, pts[:3], vals[:3], rs[:3], 77)
+    _, _, ekey2 = oc.encap_batch(com, tau_g2, pts[:3], vals[:3], rs[:3], 77)
+    assert np.array_equal(key2, ekey2)
+    proofs = hip.g1_mul_batch(g1, mont(oc, rand_fr(n, 45)))
+    dgt, dkey = hip.decap_batch(proofs, ct, 32)
+    egt2, ekey3 = oc.decap_batch(proofs, ct, 32, threads=8)
+    assert np.array_equal(dgt, egt2) and np.array_equal(dkey, ekey3)
