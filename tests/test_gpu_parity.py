@@ -161,3 +161,54 @@ def test_encap_decap_vs_oracle(oc, py, hip, rand_fr):
     dgt, dkey = hip.decap_batch(proofs, ct, 32)
     egt2, ekey3 = oc.decap_batch(proofs, ct, 32, threads=8)
     assert np.array_equal(dgt, egt2) and np.array_equal(dkey, ekey3)
+
+
+def test_golden_vectors_through_c_abi(oc, hip):
+    """The committed fixtures (tests/golden/bn254_vectors.json) against the HIP path."""
+    import json, os
+    vec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bn254_vectors.json")))
+    pg1 = lambda p: None if p is None else (int(p[0]), int(p[1]))
+    pg2 = lambda p: None if p is None else ((int(p[0][0]), int(p[0][1])), (int(p[1][0]), int(p[1][1])))
+    g1, g2 = oc.generators()
+    ks = mont(oc, [int(e["k"]) for e in vec["g1_mul"]])
+    assert oc.g1_to_ints(hip.g1_mul_batch(g1, ks)) == [pg1(e["p"]) for e in vec["g1_mul"]]
+    assert oc.g2_to_ints(hip.g2_mul_batch(g2, ks)) == [pg2(e["p"]) for e in vec["g2_mul"]]
+    for m in vec["msm_g1"]:
+        bases = hip.g1_mul_batch(g1, mont(oc, [int(k) for k in m["base_dlogs"]]))
+        srs = hip.srs_g1_upload(bases)
+        try:
+            got = jac_to_aff(hip.msm_g1(srs, mont(oc, [int(s) for s in m["scalars"]])))
+        finally:
+            srs.free()
+        assert oc.g1_to_ints(got)[0] == pg1(m["result"])
+    P = hip.g1_mul_batch(g1, mont(oc, [int(e["a"]) for e in vec["pairing"]]))
+    Q = hip.g2_mul_batch(g2, mont(oc, [int(e["b"]) for e in vec["pairing"]]))
+    gt = hip.pairing_batch(P, Q)
+    for i, e in enumerate(vec["pairing"]):
+        assert gt[i].tobytes().hex() == e["gt_hex"]
+    k = vec["kem"]
+    M = lambda x: mont(oc, [int(x)])
+    ct, gtb, key = hip.encap_batch(oc.g1_from_ints([pg1(k["commitment"])])[0], oc.g2_from_ints([pg2(k["tau_g2"])])[0],
+                                   M(k["point"]), M(k["value"]), M(k["r"]), 32)
+    assert oc.g2_to_ints(ct)[0] == pg2(k["ct"]) and gtb[0].tobytes().hex() == k["gt_hex"] and key[0].tobytes().hex() == k["key_hex"]
+    _, dkey = hip.decap_batch(oc.g1_from_ints([pg1(k["proof"])]), ct, 32)
+    assert dkey[0].tobytes().hex() == k["key_hex"]
+
+
+def test_msm_full_size_property(oc, hip, rand_fr):
+    """Size-independent property at a large size: MSM(s, k_i G) == (sum s_i k_i) G, n = 2^18."""
+    n = 1 << 18
+    g1, _ = oc.generators()
+    rng = np.random.default_rng(5)
+    def limbs(n):
+        a = rng.integers(0, 2**63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+        a[:, 3] &= np.uint64((1 << 60) - 1)          # < 2^252 < r: valid Montgomery residues
+        return a
+    k, s = limbs(n), limbs(n)
+    pts = hip.g1_mul_batch(g1, k)
+    srs = hip.srs_g1_upload(pts)
+    try:
+        got = jac_to_aff(hip.msm_g1(srs, s))
+    finally:
+        srs.free()
+    assert np.array_equal(got, oc.g1_mul_batch(g1, oc.fr_dot(s, k).reshape(1, 4))[0])

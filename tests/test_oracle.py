@@ -1,0 +1,224 @@
+"""CPU suite: pins the oracle. (1) big-int Python restatement against public known answers, the
+reference's own ptau fixture and its internal cross-checks; (2) committed golden vectors;
+(3) the C restatement against the Python one and the golden vectors."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def vec():
+    return json.load(open(os.path.join(GOLDEN, "bn254_vectors.json")))
+
+
+def pg1(p): return None if p is None else (int(p[0]), int(p[1]))
+def pg2(p): return None if p is None else ((int(p[0][0]), int(p[0][1])), (int(p[1][0]), int(p[1][1])))
+
+
+# ---------------------------------------------------------------- public known answers
+def test_bn254_parameters(py):
+    assert py.P.bit_length() == 254 and py.R.bit_length() == 254
+    assert py.g1_is_on_curve(py.G1_GEN) and py.g2_is_on_curve(py.G2_GEN)
+    assert py.g1_mul(py.G1_GEN, py.R) is None and py.g2_mul(py.G2_GEN, py.R - 1) == py.g2_neg(py.G2_GEN)
+    # 2*G1 (EIP-196 test vector)
+    assert py.g1_add(py.G1_GEN, py.G1_GEN) == (
+        1368015179489954701390400359078579693043519447331113978918064868415326638035,
+        9918110051302171585080402603319702774565515993150576347155970296011118125764)
+    # Montgomery constants quoted in SURVEY.md section 8c
+    assert (-pow(py.P, -1, 1 << 64)) % (1 << 64) == 0x87d20782e4866389
+    assert (-pow(py.R, -1, 1 << 64)) % (1 << 64) == 0xc2e1f593efffffff
+
+
+def test_blake3_official_vectors(py):
+    inp = bytes(i % 251 for i in range(2049))
+    assert py.blake3_xof(b"", 32).hex() == "af1349b9f5f9a1a6a0404dea36dcc9499bcb25c9adc112b7cc9a93cae41f3262"
+    assert py.blake3_xof(inp[:1], 32).hex() == "2d3adedff11b61f14c886e35afa036736dcd87a74d27b5c1510225d0f592e213"
+    assert py.blake3_xof(b"abc", 32).hex() == "6437b3ac38465133ffb63b75273a8db548c558465d79db03fd359c6cd5bd9d85"
+    assert py.blake3_xof(inp[:1024], 32).hex().startswith("42214739f095a406")
+    assert py.blake3_xof(inp[:1025], 32).hex().startswith("d00278ae47eb27b3")
+    # XOF prefix property
+    assert py.blake3_xof(inp[:384], 200)[:32] == py.blake3_xof(inp[:384], 32)
+
+
+def test_reference_ptau_fixture(py):
+    """The reference's own data file: after de-Montgomery every point is on its curve and the
+    ceremony's pairing relations hold (e(tau^i G1, G2) chain, beta consistency)."""
+    blob = open(os.path.join(GOLDEN, "ppot_0080_01.ptau.test"), "rb").read()
+    assert len(blob) == 95634  # src/kzg/ptau.rs:392-400
+    pts = py.ptau_points(blob)
+    assert [len(pts[k]) for k in ("tau_g1", "tau_g2", "alpha_tau_g1", "beta_tau_g1", "beta_g2")] == [3, 2, 2, 2, 1]
+    assert pts["tau_g1"][0] == py.G1_GEN and pts["tau_g2"][0] == py.G2_GEN
+    for k in ("tau_g1", "alpha_tau_g1", "beta_tau_g1"):
+        assert all(py.g1_is_on_curve(p) for p in pts[k])
+    for k in ("tau_g2", "beta_g2"):
+        assert all(py.g2_is_on_curve(p) for p in pts[k])
+    e = py.pairing
+    assert e(pts["tau_g1"][1], py.G2_GEN) == e(py.G1_GEN, pts["tau_g2"][1])
+    assert e(pts["tau_g1"][2], py.G2_GEN) == e(pts["tau_g1"][1], pts["tau_g2"][1])
+    assert e(pts["beta_tau_g1"][0], py.G2_GEN) == e(py.G1_GEN, pts["beta_g2"][0])
+    assert e(pts["alpha_tau_g1"][1], py.G2_GEN) == e(pts["alpha_tau_g1"][0], pts["tau_g2"][1])
+
+
+def test_final_exponent_and_bilinearity(py):
+    f = py.miller_loop(py.G1_GEN, py.G2_GEN)
+    e = py.final_exponentiation(f)
+    assert e == py.final_exponentiation_naive(f)           # the chain realises (p^12-1)/r * 2z(6z^2+3z+1)
+    assert e != py.F12_ONE and py.f12_pow(e, py.R) == py.F12_ONE
+    a, b = 0x1234567890abcdef1234567, 0xfedcba9876543210fedcb
+    assert py.pairing(py.g1_mul(py.G1_GEN, a), py.g2_mul(py.G2_GEN, b)) == py.f12_pow(e, a * b % py.R)
+    assert py.pairing(None, py.G2_GEN) == py.F12_ONE and py.pairing(py.G1_GEN, None) == py.F12_ONE
+    assert hashlib.sha256(py.gt_serialize(e)).hexdigest() == "e109983de6d3ff0d8d4e1236dd4d91d2a313d7e7a22e3a15062b6759ad70331c"
+
+
+def test_cyclotomic_square_matches_plain_square(py, oc):
+    # C oracle uses Granger-Scott squaring inside final_exp; Python uses plain squaring
+    g1, g2 = oc.generators()
+    f = oc.miller_loop_raw(g1, g2)
+    e_c = oc.limbs_to_ints(oc.fq_from_mont(oc.final_exp_raw(f).reshape(-1, 4)))
+    e_py = py.final_exponentiation(py.miller_loop(py.G1_GEN, py.G2_GEN))
+    assert e_c == [c for f6 in e_py for f2 in f6 for c in f2]
+
+
+# ---------------------------------------------------------------- reference tests restated on BN254 (relational)
+def test_kzg_commit_equals_naive_sum(py):
+    """src/kzg.rs:241-258 (MSM == naive sum), on BN254."""
+    g1p, _ = py.kzg_setup(12345678901234567890, 10)
+    p = [1, 2, 3]
+    naive = None
+    for c, g in zip(p, g1p):
+        naive = py.g1_add(naive, py.g1_mul(g, c))
+    assert py.kzg_commit(g1p, p) == naive
+
+
+def test_kzg_polynomial_too_large(py):
+    """src/kzg.rs:260-308: exact (len, max) tuple; `open` reports the QUOTIENT's length."""
+    g1p, _ = py.kzg_setup(99, 4)
+    with pytest.raises(ValueError) as e:
+        py.kzg_commit(g1p, [1] * 5)
+    assert e.value.args[0] == (5, 4)
+    with pytest.raises(ValueError) as e:
+        py.kzg_open(g1p, [1] * 6, 7)
+    assert e.value.args[0] == (5, 4)
+
+
+def test_kzg_open_verify_matrix(py):
+    """src/kzg.rs:310-468: valid proof verifies; wrong point / value / proof / commitment do not."""
+    tau = 0x1f2e3d4c5b6a79880123456789abcdef
+    g1p, tau_g2 = py.kzg_setup(tau, 10)
+    p = [(-24) % py.R, (-25) % py.R, (-5) % py.R, 9, 7]
+    z = 0xabcdef123456789
+    v = py.poly_eval(p, z)
+    com, proof = py.kzg_commit(g1p, p), py.kzg_open(g1p, p, z)
+    assert py.kzg_verify(tau_g2, com, z, v, proof)
+    assert not py.kzg_verify(tau_g2, com, z + 1, v, proof)
+    assert not py.kzg_verify(tau_g2, com, z, (v + 1) % py.R, proof)
+    q = list(p); q[1] = (-29) % py.R
+    assert not py.kzg_verify(tau_g2, com, z, v, py.kzg_open(g1p, q, z))
+    assert not py.kzg_verify(tau_g2, py.kzg_commit(g1p, q), z, v, proof)
+
+
+def test_kem_and_enc_round_trip(py, vec):
+    """src/kem.rs:87-224 and src/enc.rs:70-125 restated; also pins the committed known answer."""
+    k = vec["kem"]
+    g1p, tau_g2 = py.kzg_setup(int(k["tau"]), 10)
+    coeffs = [int(c) for c in k["coeffs"]]
+    com = py.kzg_commit(g1p, coeffs)
+    assert com == pg1(k["commitment"]) and tau_g2 == pg2(k["tau_g2"])
+    z, v, r = int(k["point"]), int(k["value"]), int(k["r"])
+    ct, key, gt = py.kem_encapsulate(r, tau_g2, com, z, v, 32)
+    assert ct == pg2(k["ct"]) and key.hex() == k["key_hex"] and gt.hex() == k["gt_hex"]
+    proof = py.kzg_open(g1p, coeffs, z)
+    assert proof == pg1(k["proof"])
+    assert py.kem_decapsulate(proof, ct, 32)[0] == key
+    bad = list(coeffs); bad[1] = (-29) % py.R
+    assert py.kem_decapsulate(py.kzg_open(g1p, bad, z), ct, 32)[0] != key          # wrong proof
+    assert py.kem_decapsulate(proof, py.g2_add(ct, py.G2_GEN), 32)[0] != key        # wrong ciphertext
+    ct2, key2, _ = py.kem_encapsulate(r, tau_g2, com, z + 1, v, 32)                 # wrong point
+    assert py.kem_decapsulate(proof, ct2, 32)[0] != key2
+    msg = b"helloworld"
+    c = py.enc_encrypt(r, tau_g2, com, z, v, msg)
+    assert py.enc_decrypt(proof, c) == msg
+    assert py.enc_decrypt(py.kzg_open(g1p, bad, z), c) != msg
+
+
+def test_fr_rand_restatement(py):
+    """ark-ff Fp::rand: 4 limbs, top two bits cleared, reject >= r; limbs are the Montgomery residue."""
+    stream = iter([0xFFFFFFFFFFFFFFFF] * 4 + [5, 6, 7, 0xC000000000000008])
+    limbs, canon = py.fr_rand_from_u64s(lambda: next(stream))
+    assert limbs == [5, 6, 7, 8]                       # first candidate (2^254-1) rejected, top bits masked on the second
+    assert canon == (sum(l << (64 * i) for i, l in enumerate(limbs)) * py.FR_RINV) % py.R
+
+
+# ---------------------------------------------------------------- golden vectors (Python and C)
+def test_golden_python(py, vec):
+    for e in vec["g1_mul"]:
+        assert py.g1_mul(py.G1_GEN, int(e["k"])) == pg1(e["p"])
+    for e in vec["g2_mul"]:
+        assert py.g2_mul(py.G2_GEN, int(e["k"])) == pg2(e["p"])
+    for e in vec["make_digits"]:
+        assert py.ark_make_digits(int(e["k"]), e["w"]) == e["digits"]
+    for n, c in vec["window_size"]:
+        assert py.ark_window_size(n) == c
+    for e in vec["blake3"]:
+        inp = bytes(i % 251 for i in range(e["in_len"]))
+        assert py.blake3_xof(inp, e["out_len"]).hex() == e["hex"]
+    e = vec["pairing"][1]
+    assert py.gt_serialize(py.pairing(py.g1_mul(py.G1_GEN, int(e["a"])), py.g2_mul(py.G2_GEN, int(e["b"])))).hex() == e["gt_hex"]
+
+
+def _mont(oc, ints):
+    return oc.fr_to_mont(oc.ints_to_limbs(ints))
+
+
+def test_golden_c_oracle(oc, vec):
+    g1, g2 = oc.generators()
+    ks = [int(e["k"]) for e in vec["g1_mul"]]
+    assert oc.g1_to_ints(oc.g1_mul_batch(g1, _mont(oc, ks))) == [pg1(e["p"]) for e in vec["g1_mul"]]
+    assert oc.g2_to_ints(oc.g2_mul_batch(g2, _mont(oc, ks), threads=4)) == [pg2(e["p"]) for e in vec["g2_mul"]]
+    for m in vec["msm_g1"]:
+        bases = oc.g1_mul_batch(g1, _mont(oc, [int(k) for k in m["base_dlogs"]]))
+        sc = _mont(oc, [int(s) for s in m["scalars"]])
+        for thr in (1, 3):
+            assert oc.g1_to_ints(oc.msm_g1(bases, sc, threads=thr))[0] == pg1(m["result"])
+    for e in vec["make_digits"]:
+        assert oc.make_digits(int(e["k"]), e["w"]) == e["digits"]
+    for n, c in vec["window_size"]:
+        assert oc.window_size(n) == c
+    for e in vec["blake3"]:
+        inp = bytes(i % 251 for i in range(e["in_len"]))
+        assert oc.blake3_xof(inp, e["out_len"]).hex() == e["hex"]
+    P = oc.g1_mul_batch(g1, _mont(oc, [int(e["a"]) for e in vec["pairing"]]))
+    Q = oc.g2_mul_batch(g2, _mont(oc, [int(e["b"]) for e in vec["pairing"]]))
+    gt = oc.pairing_batch(P, Q, threads=4)
+    for i, e in enumerate(vec["pairing"]):
+        assert gt[i].tobytes().hex() == e["gt_hex"]
+    P[0] = 0
+    assert oc.pairing_batch(P, Q)[0].tobytes().hex() == vec["gt_one_hex"]
+    k = vec["kem"]
+    M = lambda x: _mont(oc, [int(x)])
+    ct, gtb, key = oc.encap_batch(oc.g1_from_ints([pg1(k["commitment"])])[0], oc.g2_from_ints([pg2(k["tau_g2"])])[0],
+                                  M(k["point"]), M(k["value"]), M(k["r"]), 32)
+    assert oc.g2_to_ints(ct)[0] == pg2(k["ct"]) and gtb[0].tobytes().hex() == k["gt_hex"] and key[0].tobytes().hex() == k["key_hex"]
+    dgt, dkey = oc.decap_batch(oc.g1_from_ints([pg1(k["proof"])]), ct, 32)
+    assert dkey[0].tobytes().hex() == k["key_hex"]
+
+
+def test_c_oracle_msm_g2_and_edges(oc, py):
+    g1, g2 = oc.generators()
+    ks = [3, 0, py.R - 1, 77, 2**200 + 1]
+    pts = oc.g2_mul_batch(g2, _mont(oc, [5, 6, 7, 8, 9]))
+    exp = py.g2_mul(py.G2_GEN, sum(a * b for a, b in zip(ks, [5, 6, 7, 8, 9])) % py.R)
+    assert oc.g2_to_ints(oc.msm_g2(pts, _mont(oc, ks)))[0] == exp
+    assert not np.any(oc.msm_g1(np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64)))
+    base = oc.g1_mul_batch(g1, _mont(oc, [11]))
+    same = np.repeat(base, 40, 0)
+    sc = _mont(oc, list(range(1, 41)))
+    assert oc.g1_to_ints(oc.msm_g1(same, sc))[0] == py.g1_mul(py.G1_GEN, 11 * sum(range(1, 41)))
+    assert oc.g1_on_curve(base[0]) and oc.g2_on_curve(pts[0])
+    bad = base[0].copy(); bad[0] ^= np.uint64(1)
+    assert not oc.g1_on_curve(bad)
