@@ -1,4 +1,5 @@
 // G2 batched scalar multiplication and the G2 half of encapsulate (reference src/kem.rs:36-37).
+#define KEAKI_FQ2_OUTLINE 1
 #include "ec_batch.cuh"
 #include "internal.h"
 namespace keaki_internal {

@@ -22,11 +22,13 @@ namespace bn254 {
 struct Fq6 { Fq2 c0, c1, c2; };
 struct Fq12 { Fq6 c0, c1; };
 
-// out-of-line Fq2 product / square: the unit of code reuse for the tower
-static KNOINLINE Fq2 fq2_mul_nl(const Fq2 a, const Fq2 b) { return a * b; }
-static KNOINLINE Fq2 fq2_sqr_nl(const Fq2 a) { return fq2_sqr(a); }
-#define M2(a, b) fq2_mul_nl((a), (b))
-#define S2(a) fq2_sqr_nl((a))
+// Fq2 product / square are out-of-line functions in this translation unit (KEAKI_FQ2_OUTLINE): the
+// unit of code reuse for the tower
+#ifndef KEAKI_FQ2_OUTLINE
+#error "pairing.cuh expects KEAKI_FQ2_OUTLINE (see pairing.hip)"
+#endif
+#define M2(a, b) ((a) * (b))
+#define S2(a) fq2_sqr((a))
 
 KDEV Fq6 operator+(const Fq6& a, const Fq6& b) { return {a.c0 + b.c0, a.c1 + b.c1, a.c2 + b.c2}; }
 KDEV Fq6 operator-(const Fq6& a, const Fq6& b) { return {a.c0 - b.c0, a.c1 - b.c1, a.c2 - b.c2}; }

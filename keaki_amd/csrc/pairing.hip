@@ -1,4 +1,5 @@
 // Batched pairing + GT serialisation + BLAKE3 KDF kernels (reference src/kem.rs:30-46,58-69).
+#define KEAKI_FQ2_OUTLINE 1
 #include "internal.h"
 #include "pairing.cuh"
 namespace keaki_internal {

@@ -1,0 +1,357 @@
+// Host mirror of keaki's public API (see keaki.hpp). Group arithmetic = C-ABI calls into libkeaki_hip.so.
+#include "keaki.hpp"
+
+#include <cstring>
+
+namespace keaki {
+
+// ------------------------------------------------------------------------------------------------ Fr
+namespace {
+typedef unsigned __int128 u128;
+const uint64_t FR_MOD[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+const uint64_t FR_INV = 0xc2e1f593efffffffULL;
+const uint64_t FR_ONE[4] = {0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL};
+const uint64_t FR_R2[4] = {0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL};
+// ark-bn254 FrConfig::TWO_ADIC_ROOT_OF_UNITY = 5^((r-1)/2^28), Montgomery form; TWO_ADICITY = 28
+const uint64_t FR_TWO_ADIC_ROOT[4] = {0x636e735580d13d9cULL, 0xa22bf3742445ffd6ULL, 0x56452ac01eb203d8ULL, 0x1860ef942963f9e7ULL};
+const unsigned FR_TWO_ADICITY = 28;
+
+bool geq_mod(const uint64_t a[4]) {
+  for (int i = 3; i >= 0; i--) { if (a[i] > FR_MOD[i]) return true; if (a[i] < FR_MOD[i]) return false; }
+  return true;
+}
+void sub_mod_raw(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+  u128 br = 0;
+  for (int i = 0; i < 4; i++) { u128 t = (u128)a[i] - b[i] - (uint64_t)br; r[i] = (uint64_t)t; br = (t >> 64) & 1; }
+}
+void mont_mul(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) { c += (u128)a[j] * b[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+    c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+    uint64_t m = t[0] * FR_INV;
+    c = (u128)m * FR_MOD[0] + t[0]; c >>= 64;
+    for (int j = 1; j < 4; j++) { c += (u128)m * FR_MOD[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+    c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
+  }
+  if (t[4] || geq_mod(t)) sub_mod_raw(t, t, FR_MOD);
+  memcpy(r, t, 32);
+}
+}  // namespace
+
+Fr Fr::one() { Fr r; memcpy(r.l, FR_ONE, 32); return r; }
+Fr Fr::from_u64(uint64_t v) { Fr a; a.l[0] = v; Fr r; mont_mul(r.l, a.l, FR_R2); return r; }
+Fr Fr::from_i64(int64_t v) { return v >= 0 ? from_u64((uint64_t)v) : -from_u64((uint64_t)(-(v + 1)) + 1); }
+Fr Fr::operator+(const Fr& o) const {
+  Fr r; u128 c = 0;
+  for (int i = 0; i < 4; i++) { c += (u128)l[i] + o.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+  if (c || geq_mod(r.l)) sub_mod_raw(r.l, r.l, FR_MOD);
+  return r;
+}
+Fr Fr::operator-(const Fr& o) const {
+  Fr r; u128 br = 0;
+  for (int i = 0; i < 4; i++) { u128 t = (u128)l[i] - o.l[i] - (uint64_t)br; r.l[i] = (uint64_t)t; br = (t >> 64) & 1; }
+  if (br) { u128 c = 0; for (int i = 0; i < 4; i++) { c += (u128)r.l[i] + FR_MOD[i]; r.l[i] = (uint64_t)c; c >>= 64; } }
+  return r;
+}
+Fr Fr::operator*(const Fr& o) const { Fr r; mont_mul(r.l, l, o.l); return r; }
+Fr Fr::operator-() const { return is_zero() ? *this : Fr::zero() - *this; }
+Fr Fr::pow(uint64_t e) const {
+  Fr acc = Fr::one(), b = *this;
+  while (e) { if (e & 1) acc = acc * b; b = b * b; e >>= 1; }
+  return acc;
+}
+Fr Fr::inverse() const {
+  uint64_t e[4], two[4] = {2, 0, 0, 0};
+  sub_mod_raw(e, FR_MOD, two);
+  Fr acc = Fr::one();
+  for (int i = 255; i >= 0; i--) { acc = acc * acc; if ((e[i >> 6] >> (i & 63)) & 1) acc = acc * *this; }
+  return acc;
+}
+Fr fr_rand(Rng& rng) {
+  for (;;) {
+    Fr r;
+    for (int i = 0; i < 4; i++) r.l[i] = rng.next_u64();
+    r.l[3] &= 0xFFFFFFFFFFFFFFFFULL >> 2;
+    if (!geq_mod(r.l)) return r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ Device
+Device::Device(int ordinal) {
+  int st = keaki_hip_ctx_create(ordinal, nullptr, &ctx_);
+  if (st != KEAKI_OK) throw HipError(st, keaki_hip_last_error(nullptr));
+}
+Device::~Device() { keaki_hip_ctx_destroy(ctx_); }
+void Device::check(int status) const {
+  if (status != KEAKI_OK) throw HipError(status, keaki_hip_last_error(ctx_));
+}
+
+namespace {
+// Montgomery limbs of the BN254 generators (ark-bn254 g1.rs / g2.rs): G1 = (1, 2)
+const uint64_t G1_GEN_W[8] = {0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL,
+                              0xa6ba871b8b1e1b3aULL, 0x14f1d651eb8e167bULL, 0xccdd46def0f28c58ULL, 0x1c14ef83340fbe5eULL};
+G1 g1_generator() { G1 g; memcpy(g.w.data(), G1_GEN_W, 64); return g; }
+G2 g2_generator(const Device& dev) {
+  // obtained from the device library so there is one source of truth for the G2 generator:
+  // 1 * g2 via the fixed-generator path of encap (ct = r * (tau_g2 - 0 * g2) with tau_g2 = ... ) would be
+  // roundabout; instead keep the constant here.
+  static const uint64_t W[16] = {0x8e83b5d102bc2026ULL, 0xdceb1935497b0172ULL, 0xfbb8264797811adfULL, 0x19573841af96503bULL,
+                                 0xafb4737da84c6140ULL, 0x6043dd5a5802d8c4ULL, 0x09e950fc52a02f86ULL, 0x14fef0833aea7b6bULL,
+                                 0x619dfa9d886be9f6ULL, 0xfe7fd297f59e9b78ULL, 0xff9e1a62231b7dfeULL, 0x28fd7eebae9e4206ULL,
+                                 0x64095b56c71856eeULL, 0xdc57f922327d3cbbULL, 0x55f935be33351076ULL, 0x0da4a0e693fd6482ULL};
+  (void)dev;
+  G2 g; memcpy(g.w.data(), W, 128); return g;
+}
+// normalised Jacobian (x, y, 1 | 1, 1, 0) -> affine encoding
+G1 jac_to_g1(const uint64_t j[12]) {
+  G1 r;
+  if (j[8] | j[9] | j[10] | j[11]) memcpy(r.w.data(), j, 64);
+  return r;
+}
+G2 jac_to_g2(const uint64_t j[24]) {
+  G2 r; bool nz = false;
+  for (int i = 16; i < 24; i++) nz |= j[i] != 0;
+  if (nz) memcpy(r.w.data(), j, 128);
+  return r;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ kzg
+namespace kzg {
+
+std::string KZGError::to_string() const {
+  return "Can't commit to polynomial: polynomial has degree " + std::to_string(degree) + " but max degree is " + std::to_string(max_degree);
+}
+
+KZGSetup::~KZGSetup() { if (srs_ && dev_) keaki_hip_srs_g1_free(dev_->ctx(), srs_); }
+KZGSetup::KZGSetup(KZGSetup&& o) noexcept : dev_(std::move(o.dev_)), g1_aff_(std::move(o.g1_aff_)), tau_g2_(o.tau_g2_), srs_(o.srs_) { o.srs_ = nullptr; }
+
+KZGSetup KZGSetup::from_powers(std::shared_ptr<Device> dev, std::vector<G1> g1_aff, const G2& tau_g2) {
+  KZGSetup s;
+  s.dev_ = std::move(dev);
+  s.g1_aff_ = std::move(g1_aff);
+  s.tau_g2_ = tau_g2;
+  s.dev_->check(keaki_hip_srs_g1_upload(s.dev_->ctx(), s.g1_aff_.empty() ? nullptr : s.g1_aff_[0].w.data(), s.g1_aff_.size(), &s.srs_));
+  return s;
+}
+
+KZGSetup KZGSetup::setup(std::shared_ptr<Device> dev, const Fr& secret, size_t max_d) {
+  // g1_pow[i] = g1 * secret^i (src/kzg.rs:59-61), tau_g2 = g2 * secret (:57); batched on the GPU
+  std::vector<Fr> pw(max_d);
+  Fr acc = Fr::one();
+  for (size_t i = 0; i < max_d; i++) { pw[i] = acc; acc = acc * secret; }
+  std::vector<G1> pts(max_d);
+  G1 g1 = g1_generator();
+  if (max_d) dev->check(keaki_hip_g1_mul_batch(dev->ctx(), g1.w.data(), 0, pw[0].l, max_d, pts[0].w.data()));
+  G2 g2 = g2_generator(*dev), tau;
+  dev->check(keaki_hip_g2_mul_batch(dev->ctx(), g2.w.data(), 0, secret.l, 1, tau.w.data()));
+  return from_powers(std::move(dev), std::move(pts), tau);
+}
+
+Result<G1> commit(const KZGSetup& setup, const DensePolynomial& p) {
+  if (p.size() > setup.g1_pow().size())
+    return Result<G1>::Err(KZGError{KZGError::PolynomialTooLarge, p.size(), setup.g1_pow().size()});
+  uint64_t jac[12];
+  setup.device()->check(keaki_hip_msm_g1(setup.device()->ctx(), setup.srs(), p.empty() ? nullptr : p[0].l, p.size(), jac));
+  return Result<G1>::Ok(jac_to_g1(jac));
+}
+
+// DensePolynomial semantics: trailing zero coefficients are not part of the polynomial
+static void trim(DensePolynomial& p) { while (!p.empty() && p.back().is_zero()) p.pop_back(); }
+
+Result<G1> open(const KZGSetup& setup, const DensePolynomial& p_in, const Fr& point) {
+  // quotient (p(x) - p(point)) / (x - point): the Horner intermediates are its coefficients
+  DensePolynomial p = p_in;
+  trim(p);
+  DensePolynomial q;
+  if (p.size() > 1) {
+    q.resize(p.size() - 1);
+    Fr acc = Fr::zero();
+    for (size_t i = p.size() - 1; i >= 1; i--) { acc = acc * point + p[i]; q[i - 1] = acc; }
+  }
+  trim(q);
+  return commit(setup, q);
+}
+
+Result<bool> verify(const KZGSetup& setup, const G1& commitment, const Fr& point, const Fr& value, const G1& proof) {
+  const Device& dev = *setup.device();
+  // lhs point: commitment - value * g1  = MSM([commitment, g1], [1, -value]);  rhs: tau_g2 - point * g2
+  G1 g1 = g1_generator(); G2 g2 = g2_generator(dev);
+  uint64_t p2[16]; memcpy(p2, commitment.w.data(), 64); memcpy(p2 + 8, g1.w.data(), 64);
+  Fr sc[2] = {Fr::one(), -value};
+  keaki_hip_srs_g1* s1 = nullptr; uint64_t j1[12];
+  dev.check(keaki_hip_srs_g1_upload(dev.ctx(), p2, 2, &s1));
+  int st = keaki_hip_msm_g1(dev.ctx(), s1, sc[0].l, 2, j1);
+  keaki_hip_srs_g1_free(dev.ctx(), s1);
+  dev.check(st);
+  uint64_t q2[32]; memcpy(q2, setup.tau_g2().w.data(), 128); memcpy(q2 + 16, g2.w.data(), 128);
+  Fr sc2[2] = {Fr::one(), -point};
+  keaki_hip_srs_g2* s2 = nullptr; uint64_t j2[24];
+  dev.check(keaki_hip_srs_g2_upload(dev.ctx(), q2, 2, &s2));
+  st = keaki_hip_msm_g2(dev.ctx(), s2, sc2[0].l, 2, j2);
+  keaki_hip_srs_g2_free(dev.ctx(), s2);
+  dev.check(st);
+  G1 lhs = jac_to_g1(j1); G2 rhs = jac_to_g2(j2);
+  uint64_t ps[16], qs[32];
+  memcpy(ps, lhs.w.data(), 64); memcpy(ps + 8, proof.w.data(), 64);
+  memcpy(qs, g2.w.data(), 128); memcpy(qs + 16, rhs.w.data(), 128);
+  uint8_t gt[2 * 384];
+  dev.check(keaki_hip_pairing_batch(dev.ctx(), ps, qs, 1, 2, gt));
+  return Result<bool>::Ok(memcmp(gt, gt + 384, 384) == 0);
+}
+
+Result<std::vector<G1>> open_fk(const KZGSetup& setup, const std::vector<Fr>& p, size_t domain_size) {
+  vec::Radix2Domain d = vec::Radix2Domain::create(domain_size);
+  std::vector<Fr> el = d.elements();
+  std::vector<G1> out;
+  out.reserve(el.size());
+  for (const Fr& z : el) {
+    Result<G1> r = open(setup, p, z);
+    if (!r.ok) return Result<std::vector<G1>>::Err(r.error);
+    out.push_back(r.value);
+  }
+  return Result<std::vector<G1>>::Ok(std::move(out));
+}
+
+}  // namespace kzg
+
+// ------------------------------------------------------------------------------------------------ kem / enc
+namespace kem {
+
+std::pair<G2, std::vector<uint8_t>> encapsulate(Rng& rng, const kzg::KZGSetup& setup, const G1& commitment, const Fr& point,
+                                                const Fr& value, size_t msg_len) {
+  Fr r = fr_rand(rng);  // src/kem.rs:26
+  G2 ct; std::vector<uint8_t> key(msg_len), gt(384);
+  setup.device()->check(keaki_hip_encap_batch(setup.device()->ctx(), commitment.w.data(), setup.tau_g2().w.data(), point.l, value.l, r.l, 1,
+                                              ct.w.data(), gt.data(), msg_len ? key.data() : nullptr, msg_len));
+  return {ct, key};
+}
+std::vector<uint8_t> decapsulate(const kzg::KZGSetup& setup, const G1& proof, const G2& ciphertext, size_t msg_len) {
+  std::vector<uint8_t> key(msg_len), gt(384);
+  setup.device()->check(keaki_hip_decap_batch(setup.device()->ctx(), proof.w.data(), ciphertext.w.data(), 1, gt.data(),
+                                              msg_len ? key.data() : nullptr, msg_len));
+  return key;
+}
+
+}  // namespace kem
+
+namespace enc {
+Ciphertext encrypt(Rng& rng, const kzg::KZGSetup& setup, const G1& com, const Fr& point, const Fr& value, const std::vector<uint8_t>& msg) {
+  auto kc = kem::encapsulate(rng, setup, com, point, value, msg.size());
+  std::vector<uint8_t> ct(msg.size());
+  for (size_t i = 0; i < msg.size(); i++) ct[i] = kc.second[i] ^ msg[i];
+  return {kc.first, ct};
+}
+std::vector<uint8_t> decrypt(const kzg::KZGSetup& setup, const G1& proof, const Ciphertext& ct) {
+  std::vector<uint8_t> key = kem::decapsulate(setup, proof, ct.first, ct.second.size());
+  for (size_t i = 0; i < key.size(); i++) key[i] ^= ct.second[i];
+  return key;
+}
+}  // namespace enc
+
+// ------------------------------------------------------------------------------------------------ vec
+namespace vec {
+
+Radix2Domain Radix2Domain::create(size_t min_size) {
+  size_t size = 1; unsigned log = 0;
+  while (size < min_size) { size <<= 1; log++; }
+  if (log > FR_TWO_ADICITY) throw std::invalid_argument("domain larger than 2^28");
+  Fr g; memcpy(g.l, FR_TWO_ADIC_ROOT, 32);
+  for (unsigned i = log; i < FR_TWO_ADICITY; i++) g = g * g;
+  Radix2Domain d;
+  d.size = size; d.group_gen = g; d.group_gen_inv = g.inverse(); d.size_inv = Fr::from_u64(size).inverse();
+  return d;
+}
+std::vector<Fr> Radix2Domain::elements() const {
+  std::vector<Fr> e(size);
+  Fr acc = Fr::one();
+  for (size_t i = 0; i < size; i++) { e[i] = acc; acc = acc * group_gen; }
+  return e;
+}
+static void fft_in_place(std::vector<Fr>& a, const Fr& root) {
+  size_t n = a.size();
+  for (size_t i = 1, j = 0; i < n; i++) {  // bit reversal
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) std::swap(a[i], a[j]);
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    Fr w = root;
+    for (size_t k = len; k < n; k <<= 1) w = w * w;
+    for (size_t i = 0; i < n; i += len) {
+      Fr x = Fr::one();
+      for (size_t j = 0; j < len / 2; j++) {
+        Fr u = a[i + j], v = a[i + j + len / 2] * x;
+        a[i + j] = u + v; a[i + j + len / 2] = u - v;
+        x = x * w;
+      }
+    }
+  }
+}
+std::vector<Fr> Radix2Domain::fft(std::vector<Fr> c) const { c.resize(size); fft_in_place(c, group_gen); return c; }
+std::vector<Fr> Radix2Domain::ifft(std::vector<Fr> e) const {
+  e.resize(size);
+  fft_in_place(e, group_gen_inv);
+  for (auto& x : e) x = x * size_inv;
+  return e;
+}
+
+std::pair<G1, std::vector<G1>> vec_commit(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v) {
+  size_t d = v.size() + PADDING_LEN;
+  std::vector<Fr> padded(v);
+  padded.push_back(fr_rand(rng));                    // src/vec.rs:31-33
+  Radix2Domain domain = Radix2Domain::create(d);     // :36
+  std::vector<Fr> p_coeff = domain.ifft(padded);     // :37
+  std::vector<G1> proofs = kzg::open_fk(setup, p_coeff, domain.size).unwrap();  // :40
+  DensePolynomial dense = p_coeff;
+  while (!dense.empty() && dense.back().is_zero()) dense.pop_back();  // from_coefficients_vec trims
+  G1 com = kzg::commit(setup, dense).unwrap();       // :46
+  return {com, proofs};
+}
+
+std::vector<enc::Ciphertext> vec_encrypt(Rng& rng, const kzg::KZGSetup& setup, const G1& com, const std::vector<Fr>& points,
+                                         const std::vector<Fr>& values, const std::vector<std::vector<uint8_t>>& messages) {
+  size_t n = messages.size();
+  std::vector<enc::Ciphertext> out(n);
+  if (!n) return out;
+  // the reference draws one r per item in index order inside the loop (src/vec.rs:63-66 -> src/kem.rs:26)
+  std::vector<Fr> rs(n);
+  for (size_t i = 0; i < n; i++) rs[i] = fr_rand(rng);
+  size_t max_len = 0;
+  for (auto& m : messages) max_len = std::max(max_len, m.size());
+  std::vector<uint64_t> ct(16 * n);
+  std::vector<uint8_t> key(n * std::max<size_t>(max_len, 1));
+  setup.device()->check(keaki_hip_encap_batch(setup.device()->ctx(), com.w.data(), setup.tau_g2().w.data(), points[0].l, values[0].l, rs[0].l, n,
+                                              ct.data(), nullptr, key.data(), max_len));
+  for (size_t i = 0; i < n; i++) {
+    memcpy(out[i].first.w.data(), &ct[16 * i], 128);
+    out[i].second.resize(messages[i].size());
+    // BLAKE3 XOF: a shorter key is a prefix of a longer one, so one max_len call serves ragged messages
+    for (size_t j = 0; j < messages[i].size(); j++) out[i].second[j] = key[i * max_len + j] ^ messages[i][j];
+  }
+  return out;
+}
+
+std::vector<std::vector<uint8_t>> vec_decrypt(const kzg::KZGSetup& setup, const std::vector<G1>& proofs,
+                                              const std::vector<const enc::Ciphertext*>& cts) {
+  size_t n = cts.size();
+  std::vector<std::vector<uint8_t>> out(n);
+  if (!n) return out;
+  size_t max_len = 0;
+  for (auto* c : cts) max_len = std::max(max_len, c->second.size());
+  std::vector<uint64_t> pr(8 * n), ct(16 * n);
+  for (size_t i = 0; i < n; i++) { memcpy(&pr[8 * i], proofs[i].w.data(), 64); memcpy(&ct[16 * i], cts[i]->first.w.data(), 128); }
+  std::vector<uint8_t> key(n * std::max<size_t>(max_len, 1)), gt(n * 384);
+  setup.device()->check(keaki_hip_decap_batch(setup.device()->ctx(), pr.data(), ct.data(), n, gt.data(), key.data(), max_len));
+  for (size_t i = 0; i < n; i++) {
+    out[i].resize(cts[i]->second.size());
+    for (size_t j = 0; j < out[i].size(); j++) out[i][j] = key[i * max_len + j] ^ cts[i]->second[j];
+  }
+  return out;
+}
+
+}  // namespace vec
+}  // namespace keaki

@@ -1,0 +1,170 @@
+// keaki.hpp -- C++ mirror of keaki's public Rust API for E = Bn254, above the C ABI of
+// libkeaki_hip.so. (The reference's own toolchain, Rust, is absent from this image; INTEGRATION.md
+// shows the feature-gated Rust shim that binds the same C ABI.)
+//
+// Same module / function names, argument meaning and error behaviour as the reference:
+//   keaki::kzg::KZGSetup, commit, open, verify, KZGError::PolynomialTooLarge   (src/kzg.rs:22-151,205-209)
+//   keaki::kem::encapsulate, decapsulate                                        (src/kem.rs:13-72)
+//   keaki::enc::Ciphertext, encrypt, decrypt                                    (src/enc.rs:13-55)
+//   keaki::vec::PADDING_LEN, vec_commit, vec_encrypt, vec_decrypt               (src/vec.rs:18-81)
+// All group / pairing arithmetic runs on the GPU through the C ABI; the host only does what keaki's
+// own glue does on the host: O(n) scalar-field work (Horner, quotient, iFFT), RNG draws, XOR.
+// There is no CPU fallback for the group arithmetic.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/keaki_hip.h"
+
+namespace keaki {
+
+// ---- scalar field Fr (ark-ff Fp<MontBackend<FrConfig,4>>): 4 x u64 Montgomery limbs ------------------
+struct Fr {
+  uint64_t l[4] = {0, 0, 0, 0};
+  static Fr zero() { return Fr(); }
+  static Fr one();
+  static Fr from_u64(uint64_t v);
+  static Fr from_i64(int64_t v);  // Fr::from(-24) in the reference tests
+  bool operator==(const Fr& o) const { return l[0] == o.l[0] && l[1] == o.l[1] && l[2] == o.l[2] && l[3] == o.l[3]; }
+  bool operator!=(const Fr& o) const { return !(*this == o); }
+  bool is_zero() const { return (l[0] | l[1] | l[2] | l[3]) == 0; }
+  Fr operator+(const Fr& o) const;
+  Fr operator-(const Fr& o) const;
+  Fr operator*(const Fr& o) const;
+  Fr operator-() const;
+  Fr pow(uint64_t e) const;
+  Fr inverse() const;  // Fermat; zero -> zero
+};
+
+// rand::Rng: the only thing keaki needs from it is next_u64 (Fr::rand draws 4 per candidate)
+struct Rng {
+  virtual ~Rng() {}
+  virtual uint64_t next_u64() = 0;
+};
+// ark-ff 0.4.2 `impl Distribution<Fp> for Standard`: 4 x next_u64, clear the top 2 bits, reject >= r;
+// the accepted limbs ARE the Montgomery representation (src/kem.rs:26, src/vec.rs:32).
+Fr fr_rand(Rng& rng);
+
+// ---- group elements: affine, Montgomery limbs, identity = all zero (the C-ABI encodings) --------------
+struct G1 {
+  std::array<uint64_t, 8> w{};
+  bool operator==(const G1& o) const { return w == o.w; }
+  bool operator!=(const G1& o) const { return w != o.w; }
+  bool is_zero() const { for (auto x : w) if (x) return false; return true; }
+};
+struct G2 {
+  std::array<uint64_t, 16> w{};
+  bool operator==(const G2& o) const { return w == o.w; }
+  bool operator!=(const G2& o) const { return w != o.w; }
+};
+
+struct HipError : std::runtime_error {
+  int status;
+  HipError(int s, const std::string& m) : std::runtime_error(m), status(s) {}
+};
+
+// One GPU context shared by the setup objects created from it.
+class Device {
+ public:
+  explicit Device(int ordinal = 0);
+  ~Device();
+  Device(const Device&) = delete;
+  keaki_hip_ctx* ctx() const { return ctx_; }
+  void check(int status) const;  // throws HipError
+ private:
+  keaki_hip_ctx* ctx_ = nullptr;
+};
+
+using DensePolynomial = std::vector<Fr>;  // coefficients, low degree first (ark-poly DensePolynomial::coeffs)
+
+namespace kzg {
+
+// src/kzg.rs:205-209
+struct KZGError {
+  enum Kind { PolynomialTooLarge } kind;
+  size_t degree, max_degree;  // "{0}" and "{1}" of the thiserror message
+  bool operator==(const KZGError& o) const { return kind == o.kind && degree == o.degree && max_degree == o.max_degree; }
+  std::string to_string() const;
+};
+template <class T>
+struct Result {  // Result<T, KZGError>
+  bool ok;
+  T value;
+  KZGError error;
+  static Result Ok(T v) { return Result{true, std::move(v), KZGError{KZGError::PolynomialTooLarge, 0, 0}}; }
+  static Result Err(KZGError e) { return Result{false, T(), e}; }
+  const T& unwrap() const { if (!ok) throw std::runtime_error("called unwrap() on Err: " + error.to_string()); return value; }
+};
+
+// src/kzg.rs:22-86. g1_pow and g1_aff hold the same affine values here (the reference keeps a
+// projective and an affine copy; equality and serialisation only ever see the affine value).
+class KZGSetup {
+ public:
+  // `setup(secret, max_d)`: [secret^i]_1 for i < max_d and [secret]_2.  "Don't use this." (src/kzg.rs:54)
+  static KZGSetup setup(std::shared_ptr<Device> dev, const Fr& secret, size_t max_d);
+  // from already-known powers (what new_from_file produces after parsing; the .ptau parser itself is out of scope)
+  static KZGSetup from_powers(std::shared_ptr<Device> dev, std::vector<G1> g1_aff, const G2& tau_g2);
+  ~KZGSetup();
+  KZGSetup(KZGSetup&&) noexcept;
+  KZGSetup(const KZGSetup&) = delete;
+  const std::vector<G1>& g1_pow() const { return g1_aff_; }
+  const std::vector<G1>& g1_aff() const { return g1_aff_; }
+  const G2& tau_g2() const { return tau_g2_; }
+  const std::shared_ptr<Device>& device() const { return dev_; }
+  const keaki_hip_srs_g1* srs() const { return srs_; }
+ private:
+  KZGSetup() {}
+  std::shared_ptr<Device> dev_;
+  std::vector<G1> g1_aff_;
+  G2 tau_g2_;
+  keaki_hip_srs_g1* srs_ = nullptr;  // device-resident copy of g1_aff, uploaded once
+};
+
+Result<G1> commit(const KZGSetup& setup, const DensePolynomial& p);                          // src/kzg.rs:89-101
+Result<G1> open(const KZGSetup& setup, const DensePolynomial& p, const Fr& point);           // src/kzg.rs:104-124
+Result<bool> verify(const KZGSetup& setup, const G1& commitment, const Fr& point, const Fr& value, const G1& proof);  // :127-151
+// all openings at the roots of unity of a size-d domain (src/kzg.rs:157-203). Round 1: O(d^2) via
+// per-point `open`; the FK23 G1-FFT version is the "next" row.
+Result<std::vector<G1>> open_fk(const KZGSetup& setup, const std::vector<Fr>& p, size_t domain_size);
+
+}  // namespace kzg
+
+namespace kem {
+// src/kem.rs:13-50 / :55-72
+std::pair<G2, std::vector<uint8_t>> encapsulate(Rng& rng, const kzg::KZGSetup& setup, const G1& commitment, const Fr& point,
+                                                const Fr& value, size_t msg_len);
+std::vector<uint8_t> decapsulate(const kzg::KZGSetup& setup, const G1& proof, const G2& ciphertext, size_t msg_len);
+}  // namespace kem
+
+namespace enc {
+using Ciphertext = std::pair<G2, std::vector<uint8_t>>;  // src/enc.rs:13
+Ciphertext encrypt(Rng& rng, const kzg::KZGSetup& setup, const G1& com, const Fr& point, const Fr& value, const std::vector<uint8_t>& msg);
+std::vector<uint8_t> decrypt(const kzg::KZGSetup& setup, const G1& proof, const Ciphertext& ct);
+}  // namespace enc
+
+namespace vec {
+constexpr size_t PADDING_LEN = 1;  // src/vec.rs:18
+// Radix2EvaluationDomain over Fr (ark-poly): size = next power of two >= n, generator of that order
+struct Radix2Domain {
+  size_t size; Fr group_gen, group_gen_inv, size_inv;
+  static Radix2Domain create(size_t min_size);
+  std::vector<Fr> elements() const;
+  std::vector<Fr> ifft(std::vector<Fr> evals) const;  // pads with zeros to `size`
+  std::vector<Fr> fft(std::vector<Fr> coeffs) const;
+};
+// src/vec.rs:22-49
+std::pair<G1, std::vector<G1>> vec_commit(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v);
+// src/vec.rs:52-69: one Fr::rand per item in index order, then ONE batched GPU call for all items
+std::vector<enc::Ciphertext> vec_encrypt(Rng& rng, const kzg::KZGSetup& setup, const G1& com, const std::vector<Fr>& points,
+                                         const std::vector<Fr>& values, const std::vector<std::vector<uint8_t>>& messages);
+// src/vec.rs:72-81
+std::vector<std::vector<uint8_t>> vec_decrypt(const kzg::KZGSetup& setup, const std::vector<G1>& proofs,
+                                              const std::vector<const enc::Ciphertext*>& cts);
+}  // namespace vec
+
+}  // namespace keaki

@@ -1,0 +1,198 @@
+// Flat C front-end of the C++ host mirror (keaki.hpp) so the pytest harness and other FFI users can
+// drive kzg / kem / enc / vec exactly as the reference's tests do. Errors: 0 ok, 1 = KZGError
+// (degree/max written to err_out[2]), negative = HipError status; message via keaki_host_last_error().
+#include <cstring>
+#include <string>
+
+#include "keaki.hpp"
+
+using namespace keaki;
+
+namespace {
+thread_local std::string g_err;
+struct CallbackRng : Rng {
+  uint64_t (*fn)(void*); void* user;
+  uint64_t next_u64() override { return fn(user); }
+};
+struct SplitMix64Rng : Rng {  // deterministic stand-in for ark_std::test_rng() in the harness
+  uint64_t s;
+  explicit SplitMix64Rng(uint64_t seed) : s(seed) {}
+  uint64_t next_u64() override {
+    s += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+  }
+};
+struct Setup { std::shared_ptr<Device> dev; kzg::KZGSetup s; };
+
+template <class F>
+int guard(F&& f) {
+  try { return f(); }
+  catch (const HipError& e) { g_err = e.what(); return e.status; }
+  catch (const std::exception& e) { g_err = e.what(); return -1000; }
+}
+Fr fr_of(const uint64_t* p) { Fr r; memcpy(r.l, p, 32); return r; }
+std::vector<Fr> frs_of(const uint64_t* p, size_t n) { std::vector<Fr> v(n); for (size_t i = 0; i < n; i++) v[i] = fr_of(p + 4 * i); return v; }
+G1 g1_of(const uint64_t* p) { G1 r; memcpy(r.w.data(), p, 64); return r; }
+G2 g2_of(const uint64_t* p) { G2 r; memcpy(r.w.data(), p, 128); return r; }
+int kzg_err(const kzg::KZGError& e, uint64_t* err_out) { if (err_out) { err_out[0] = e.degree; err_out[1] = e.max_degree; } g_err = e.to_string(); return 1; }
+}  // namespace
+
+extern "C" {
+
+const char* keaki_host_last_error(void) { return g_err.c_str(); }
+
+void* keaki_host_rng_splitmix(uint64_t seed) { return new SplitMix64Rng(seed); }
+void* keaki_host_rng_callback(uint64_t (*fn)(void*), void* user) { auto* r = new CallbackRng(); r->fn = fn; r->user = user; return r; }
+void keaki_host_rng_free(void* rng) { delete (Rng*)rng; }
+void keaki_host_fr_rand(void* rng, uint64_t* out) { Fr r = fr_rand(*(Rng*)rng); memcpy(out, r.l, 32); }
+
+// Fr helpers for the harness (Fr::from(i64), arithmetic, polynomial evaluation)
+void keaki_host_fr_from_i64(int64_t v, uint64_t* out) { Fr r = Fr::from_i64(v); memcpy(out, r.l, 32); }
+void keaki_host_fr_mul(const uint64_t* a, const uint64_t* b, uint64_t* out) { Fr r = fr_of(a) * fr_of(b); memcpy(out, r.l, 32); }
+void keaki_host_fr_add(const uint64_t* a, const uint64_t* b, uint64_t* out) { Fr r = fr_of(a) + fr_of(b); memcpy(out, r.l, 32); }
+void keaki_host_fr_sub(const uint64_t* a, const uint64_t* b, uint64_t* out) { Fr r = fr_of(a) - fr_of(b); memcpy(out, r.l, 32); }
+void keaki_host_fr_inv(const uint64_t* a, uint64_t* out) { Fr r = fr_of(a).inverse(); memcpy(out, r.l, 32); }
+void keaki_host_poly_eval(const uint64_t* coeffs, size_t n, const uint64_t* x, uint64_t* out) {
+  Fr acc = Fr::zero(), xx = fr_of(x);
+  for (size_t i = n; i-- > 0;) acc = acc * xx + fr_of(coeffs + 4 * i);
+  memcpy(out, acc.l, 32);
+}
+size_t keaki_host_domain(size_t min_size, uint64_t* elements_out /* may be NULL */) {
+  auto d = vec::Radix2Domain::create(min_size);
+  if (elements_out) { auto e = d.elements(); for (size_t i = 0; i < e.size(); i++) memcpy(elements_out + 4 * i, e[i].l, 32); }
+  return d.size;
+}
+void keaki_host_ifft(const uint64_t* evals, size_t n, size_t domain_min, uint64_t* out) {
+  auto d = vec::Radix2Domain::create(domain_min);
+  auto c = d.ifft(frs_of(evals, n));
+  for (size_t i = 0; i < c.size(); i++) memcpy(out + 4 * i, c[i].l, 32);
+}
+void keaki_host_fft(const uint64_t* coeffs, size_t n, size_t domain_min, uint64_t* out) {
+  auto d = vec::Radix2Domain::create(domain_min);
+  auto c = d.fft(frs_of(coeffs, n));
+  for (size_t i = 0; i < c.size(); i++) memcpy(out + 4 * i, c[i].l, 32);
+}
+
+// KZGSetup::setup(secret, max_d)
+int keaki_host_setup(int device, const uint64_t* secret, size_t max_d, void** out) {
+  return guard([&] {
+    auto dev = std::make_shared<Device>(device);
+    auto* s = new Setup{dev, kzg::KZGSetup::setup(dev, fr_of(secret), max_d)};
+    *out = s; return 0;
+  });
+}
+int keaki_host_setup_from_powers(int device, const uint64_t* g1_aff, size_t n, const uint64_t* tau_g2, void** out) {
+  return guard([&] {
+    auto dev = std::make_shared<Device>(device);
+    std::vector<G1> pts(n);
+    for (size_t i = 0; i < n; i++) pts[i] = g1_of(g1_aff + 8 * i);
+    *out = new Setup{dev, kzg::KZGSetup::from_powers(dev, std::move(pts), g2_of(tau_g2))};
+    return 0;
+  });
+}
+void keaki_host_setup_free(void* s) { delete (Setup*)s; }
+size_t keaki_host_setup_len(void* s) { return ((Setup*)s)->s.g1_pow().size(); }
+void keaki_host_setup_g1_pow(void* s, size_t i, uint64_t* out) { memcpy(out, ((Setup*)s)->s.g1_pow()[i].w.data(), 64); }
+void keaki_host_setup_tau_g2(void* s, uint64_t* out) { memcpy(out, ((Setup*)s)->s.tau_g2().w.data(), 128); }
+
+int keaki_host_commit(void* s, const uint64_t* coeffs, size_t n, uint64_t* out_g1, uint64_t* err_out) {
+  return guard([&] {
+    auto r = kzg::commit(((Setup*)s)->s, frs_of(coeffs, n));
+    if (!r.ok) return kzg_err(r.error, err_out);
+    memcpy(out_g1, r.value.w.data(), 64); return 0;
+  });
+}
+int keaki_host_open(void* s, const uint64_t* coeffs, size_t n, const uint64_t* point, uint64_t* out_g1, uint64_t* err_out) {
+  return guard([&] {
+    auto r = kzg::open(((Setup*)s)->s, frs_of(coeffs, n), fr_of(point));
+    if (!r.ok) return kzg_err(r.error, err_out);
+    memcpy(out_g1, r.value.w.data(), 64); return 0;
+  });
+}
+int keaki_host_verify(void* s, const uint64_t* com, const uint64_t* point, const uint64_t* value, const uint64_t* proof, int* out_ok) {
+  return guard([&] {
+    auto r = kzg::verify(((Setup*)s)->s, g1_of(com), fr_of(point), fr_of(value), g1_of(proof));
+    *out_ok = r.value ? 1 : 0; return 0;
+  });
+}
+int keaki_host_open_fk(void* s, const uint64_t* coeffs, size_t n, size_t domain_size, uint64_t* out_g1s, uint64_t* err_out) {
+  return guard([&] {
+    auto r = kzg::open_fk(((Setup*)s)->s, frs_of(coeffs, n), domain_size);
+    if (!r.ok) return kzg_err(r.error, err_out);
+    for (size_t i = 0; i < r.value.size(); i++) memcpy(out_g1s + 8 * i, r.value[i].w.data(), 64);
+    return 0;
+  });
+}
+int keaki_host_encapsulate(void* rng, void* s, const uint64_t* com, const uint64_t* point, const uint64_t* value, size_t msg_len,
+                           uint64_t* ct_out, uint8_t* key_out) {
+  return guard([&] {
+    auto r = kem::encapsulate(*(Rng*)rng, ((Setup*)s)->s, g1_of(com), fr_of(point), fr_of(value), msg_len);
+    memcpy(ct_out, r.first.w.data(), 128);
+    if (msg_len) memcpy(key_out, r.second.data(), msg_len);
+    return 0;
+  });
+}
+int keaki_host_decapsulate(void* s, const uint64_t* proof, const uint64_t* ct, size_t msg_len, uint8_t* key_out) {
+  return guard([&] {
+    auto k = kem::decapsulate(((Setup*)s)->s, g1_of(proof), g2_of(ct), msg_len);
+    if (msg_len) memcpy(key_out, k.data(), msg_len);
+    return 0;
+  });
+}
+int keaki_host_encrypt(void* rng, void* s, const uint64_t* com, const uint64_t* point, const uint64_t* value, const uint8_t* msg, size_t len,
+                       uint64_t* ct_g2_out, uint8_t* ct_msg_out) {
+  return guard([&] {
+    auto c = enc::encrypt(*(Rng*)rng, ((Setup*)s)->s, g1_of(com), fr_of(point), fr_of(value), std::vector<uint8_t>(msg, msg + len));
+    memcpy(ct_g2_out, c.first.w.data(), 128);
+    if (len) memcpy(ct_msg_out, c.second.data(), len);
+    return 0;
+  });
+}
+int keaki_host_decrypt(void* s, const uint64_t* proof, const uint64_t* ct_g2, const uint8_t* ct_msg, size_t len, uint8_t* msg_out) {
+  return guard([&] {
+    enc::Ciphertext c{g2_of(ct_g2), std::vector<uint8_t>(ct_msg, ct_msg + len)};
+    auto m = enc::decrypt(((Setup*)s)->s, g1_of(proof), c);
+    if (len) memcpy(msg_out, m.data(), len);
+    return 0;
+  });
+}
+// vec_commit: v has n scalars; outputs commitment and `domain_size` proofs (caller sizes proofs_out with keaki_host_domain(n+1))
+int keaki_host_vec_commit(void* rng, void* s, const uint64_t* v, size_t n, uint64_t* com_out, uint64_t* proofs_out) {
+  return guard([&] {
+    auto r = vec::vec_commit(*(Rng*)rng, ((Setup*)s)->s, frs_of(v, n));
+    memcpy(com_out, r.first.w.data(), 64);
+    for (size_t i = 0; i < r.second.size(); i++) memcpy(proofs_out + 8 * i, r.second[i].w.data(), 64);
+    return 0;
+  });
+}
+// vec_encrypt with equal-length messages (msg_len each, concatenated)
+int keaki_host_vec_encrypt(void* rng, void* s, const uint64_t* com, const uint64_t* points, const uint64_t* values, const uint8_t* msgs,
+                           size_t n, size_t msg_len, uint64_t* ct_g2_out, uint8_t* ct_msg_out) {
+  return guard([&] {
+    std::vector<std::vector<uint8_t>> m(n);
+    for (size_t i = 0; i < n; i++) m[i].assign(msgs + i * msg_len, msgs + (i + 1) * msg_len);
+    auto c = vec::vec_encrypt(*(Rng*)rng, ((Setup*)s)->s, g1_of(com), frs_of(points, n), frs_of(values, n), m);
+    for (size_t i = 0; i < n; i++) { memcpy(ct_g2_out + 16 * i, c[i].first.w.data(), 128); if (msg_len) memcpy(ct_msg_out + i * msg_len, c[i].second.data(), msg_len); }
+    return 0;
+  });
+}
+int keaki_host_vec_decrypt(void* s, const uint64_t* proofs, const uint64_t* ct_g2, const uint8_t* ct_msgs, size_t n, size_t msg_len,
+                           uint8_t* msgs_out) {
+  return guard([&] {
+    std::vector<enc::Ciphertext> cts(n);
+    std::vector<const enc::Ciphertext*> ptrs(n);
+    std::vector<G1> pr(n);
+    for (size_t i = 0; i < n; i++) {
+      cts[i] = {g2_of(ct_g2 + 16 * i), std::vector<uint8_t>(ct_msgs + i * msg_len, ct_msgs + (i + 1) * msg_len)};
+      ptrs[i] = &cts[i]; pr[i] = g1_of(proofs + 8 * i);
+    }
+    auto m = vec::vec_decrypt(((Setup*)s)->s, pr, ptrs);
+    for (size_t i = 0; i < n; i++) if (msg_len) memcpy(msgs_out + i * msg_len, m[i].data(), msg_len);
+    return 0;
+  });
+}
+
+}  // extern "C"

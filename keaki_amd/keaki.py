@@ -1,0 +1,258 @@
+"""ctypes binding of libkeaki_host.so: the C++ mirror of keaki's public API (kzg / kem / enc / vec,
+reference src/kzg.rs, src/kem.rs, src/enc.rs, src/vec.rs) for E = Bn254. Used by the parity tests
+and the Laconic-OT harness so they read like the reference's own tests.
+
+Values: Fr = numpy uint64[4] (Montgomery limbs), G1 = uint64[8], G2 = uint64[16] (affine, identity = zeros).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+PADDING_LEN = 1  # src/vec.rs:18
+
+
+class KZGError(Exception):
+    """KZGError::PolynomialTooLarge(degree, max_degree) -- src/kzg.rs:205-209"""
+
+    def __init__(self, degree, max_degree):
+        super().__init__(f"Can't commit to polynomial: polynomial has degree {degree} but max degree is {max_degree}")
+        self.args_tuple = (degree, max_degree)
+
+    def __eq__(self, other):
+        return isinstance(other, KZGError) and self.args_tuple == other.args_tuple
+
+
+class KeakiHostError(RuntimeError):
+    pass
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        from . import hip
+        hip.load_library()  # the host mirror links against libkeaki_hip.so; fail loudly if it is missing
+        path = os.path.join(_HERE, "libkeaki_host.so")
+        if not os.path.exists(path):
+            raise KeakiHostError(f"{path} not built (make -C keaki_amd/host)")
+        lib = C.CDLL(path)
+        lib.keaki_host_last_error.restype = C.c_char_p
+        lib.keaki_host_rng_splitmix.restype = C.c_void_p
+        lib.keaki_host_rng_splitmix.argtypes = [C.c_uint64]
+        lib.keaki_host_rng_free.argtypes = [C.c_void_p]
+        lib.keaki_host_domain.restype = C.c_size_t
+        lib.keaki_host_domain.argtypes = [C.c_size_t, C.c_void_p]
+        lib.keaki_host_setup_len.restype = C.c_size_t
+        lib.keaki_host_setup_len.argtypes = [C.c_void_p]
+        _LIB = lib
+    return _LIB
+
+
+def _u64(a, width=None):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a.reshape(-1, width) if width else a
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _ck(st, err=None):
+    if st == 0:
+        return
+    if st == 1 and err is not None:
+        raise KZGError(int(err[0]), int(err[1]))
+    raise KeakiHostError(f"status {st}: {_lib().keaki_host_last_error().decode()}")
+
+
+class Rng:
+    """Deterministic u64 stream standing in for rand::Rng (SplitMix64)."""
+
+    def __init__(self, seed: int):
+        self.h = C.c_void_p(_lib().keaki_host_rng_splitmix(seed))
+
+    def fr_rand(self) -> np.ndarray:
+        out = np.zeros(4, np.uint64)
+        _lib().keaki_host_fr_rand(self.h, _p(out))
+        return out
+
+    def __del__(self):
+        try:
+            _lib().keaki_host_rng_free(self.h)
+        except Exception:
+            pass
+
+
+# ---- Fr helpers -------------------------------------------------------------------------------
+def fr(v: int) -> np.ndarray:
+    """Fr::from(i64)"""
+    out = np.zeros(4, np.uint64)
+    _lib().keaki_host_fr_from_i64(C.c_int64(v), _p(out))
+    return out
+
+
+def _binop(name, a, b):
+    out = np.zeros(4, np.uint64)
+    getattr(_lib(), name)(_p(_u64(a)), _p(_u64(b)), _p(out))
+    return out
+
+
+def fr_mul(a, b): return _binop("keaki_host_fr_mul", a, b)
+def fr_add(a, b): return _binop("keaki_host_fr_add", a, b)
+def fr_sub(a, b): return _binop("keaki_host_fr_sub", a, b)
+
+
+def poly_evaluate(coeffs, x) -> np.ndarray:
+    c = _u64(coeffs, 4); out = np.zeros(4, np.uint64)
+    _lib().keaki_host_poly_eval(_p(c), C.c_size_t(c.shape[0]), _p(_u64(x)), _p(out))
+    return out
+
+
+def domain_elements(min_size: int) -> np.ndarray:
+    """Radix2EvaluationDomain::new(min_size).elements()"""
+    size = _lib().keaki_host_domain(min_size, None)
+    out = np.zeros((size, 4), np.uint64)
+    _lib().keaki_host_domain(min_size, _p(out))
+    return out
+
+
+def ifft(evals, domain_min) -> np.ndarray:
+    e = _u64(evals, 4); size = _lib().keaki_host_domain(domain_min, None)
+    out = np.zeros((size, 4), np.uint64)
+    _lib().keaki_host_ifft(_p(e), C.c_size_t(e.shape[0]), C.c_size_t(domain_min), _p(out))
+    return out
+
+
+def fft(coeffs, domain_min) -> np.ndarray:
+    c = _u64(coeffs, 4); size = _lib().keaki_host_domain(domain_min, None)
+    out = np.zeros((size, 4), np.uint64)
+    _lib().keaki_host_fft(_p(c), C.c_size_t(c.shape[0]), C.c_size_t(domain_min), _p(out))
+    return out
+
+
+# ---- kzg --------------------------------------------------------------------------------------
+class KZGSetup:
+    def __init__(self, handle):
+        self.h = handle
+
+    @staticmethod
+    def setup(secret, max_d: int, device: int = 0) -> "KZGSetup":
+        h = C.c_void_p()
+        _ck(_lib().keaki_host_setup(device, _p(_u64(secret)), C.c_size_t(max_d), C.byref(h)))
+        return KZGSetup(h)
+
+    @staticmethod
+    def from_powers(g1_aff, tau_g2, device: int = 0) -> "KZGSetup":
+        pts = _u64(g1_aff, 8); h = C.c_void_p()
+        _ck(_lib().keaki_host_setup_from_powers(device, _p(pts), C.c_size_t(pts.shape[0]), _p(_u64(tau_g2)), C.byref(h)))
+        return KZGSetup(h)
+
+    def g1_pow(self) -> np.ndarray:
+        n = _lib().keaki_host_setup_len(self.h)
+        out = np.zeros((n, 8), np.uint64)
+        for i in range(n):
+            _lib().keaki_host_setup_g1_pow(self.h, C.c_size_t(i), _p(out[i]))
+        return out
+
+    g1_aff = g1_pow
+
+    def tau_g2(self) -> np.ndarray:
+        out = np.zeros(16, np.uint64)
+        _lib().keaki_host_setup_tau_g2(self.h, _p(out))
+        return out
+
+    def close(self):
+        if self.h:
+            _lib().keaki_host_setup_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def commit(setup: KZGSetup, p) -> np.ndarray:
+    c = _u64(p, 4); out = np.zeros(8, np.uint64); err = np.zeros(2, np.uint64)
+    _ck(_lib().keaki_host_commit(setup.h, _p(c), C.c_size_t(c.shape[0]), _p(out), _p(err)), err)
+    return out
+
+
+def open(setup: KZGSetup, p, point) -> np.ndarray:  # noqa: A001 (mirrors kzg::open)
+    c = _u64(p, 4); out = np.zeros(8, np.uint64); err = np.zeros(2, np.uint64)
+    _ck(_lib().keaki_host_open(setup.h, _p(c), C.c_size_t(c.shape[0]), _p(_u64(point)), _p(out), _p(err)), err)
+    return out
+
+
+def verify(setup: KZGSetup, commitment, point, value, proof) -> bool:
+    ok = C.c_int(0)
+    _ck(_lib().keaki_host_verify(setup.h, _p(_u64(commitment)), _p(_u64(point)), _p(_u64(value)), _p(_u64(proof)), C.byref(ok)))
+    return bool(ok.value)
+
+
+def open_fk(setup: KZGSetup, p, domain_size: int) -> np.ndarray:
+    c = _u64(p, 4); size = _lib().keaki_host_domain(domain_size, None)
+    out = np.zeros((size, 8), np.uint64); err = np.zeros(2, np.uint64)
+    _ck(_lib().keaki_host_open_fk(setup.h, _p(c), C.c_size_t(c.shape[0]), C.c_size_t(domain_size), _p(out), _p(err)), err)
+    return out
+
+
+# ---- kem / enc ---------------------------------------------------------------------------------
+def encapsulate(rng: Rng, setup: KZGSetup, commitment, point, value, msg_len: int):
+    ct = np.zeros(16, np.uint64); key = np.zeros(max(msg_len, 1), np.uint8)
+    _ck(_lib().keaki_host_encapsulate(rng.h, setup.h, _p(_u64(commitment)), _p(_u64(point)), _p(_u64(value)), C.c_size_t(msg_len), _p(ct), _p(key)))
+    return ct, key[:msg_len].tobytes()
+
+
+def decapsulate(setup: KZGSetup, proof, ciphertext, msg_len: int) -> bytes:
+    key = np.zeros(max(msg_len, 1), np.uint8)
+    _ck(_lib().keaki_host_decapsulate(setup.h, _p(_u64(proof)), _p(_u64(ciphertext)), C.c_size_t(msg_len), _p(key)))
+    return key[:msg_len].tobytes()
+
+
+def encrypt(rng: Rng, setup: KZGSetup, com, point, value, msg: bytes):
+    m = np.frombuffer(msg or b"\0", np.uint8).copy(); ct = np.zeros(16, np.uint64); out = np.zeros(max(len(msg), 1), np.uint8)
+    _ck(_lib().keaki_host_encrypt(rng.h, setup.h, _p(_u64(com)), _p(_u64(point)), _p(_u64(value)), _p(m), C.c_size_t(len(msg)), _p(ct), _p(out)))
+    return ct, out[:len(msg)].tobytes()
+
+
+def decrypt(setup: KZGSetup, proof, ct) -> bytes:
+    g2, body = ct
+    b = np.frombuffer(body or b"\0", np.uint8).copy(); out = np.zeros(max(len(body), 1), np.uint8)
+    _ck(_lib().keaki_host_decrypt(setup.h, _p(_u64(proof)), _p(_u64(g2)), _p(b), C.c_size_t(len(body)), _p(out)))
+    return out[:len(body)].tobytes()
+
+
+# ---- vec ---------------------------------------------------------------------------------------
+def vec_commit(rng: Rng, setup: KZGSetup, v):
+    v = _u64(v, 4); n = v.shape[0]
+    size = _lib().keaki_host_domain(n + PADDING_LEN, None)
+    com = np.zeros(8, np.uint64); proofs = np.zeros((size, 8), np.uint64)
+    _ck(_lib().keaki_host_vec_commit(rng.h, setup.h, _p(v), C.c_size_t(n), _p(com), _p(proofs)))
+    return com, proofs
+
+
+def vec_encrypt(rng: Rng, setup: KZGSetup, com, points, values, messages):
+    n = len(messages); ml = len(messages[0]) if n else 0
+    assert all(len(m) == ml for m in messages)
+    pts = _u64(points, 4)[:n]; vals = _u64(values, 4)[:n]
+    msgs = np.frombuffer(b"".join(messages) or b"\0", np.uint8).copy()
+    g2 = np.zeros((n, 16), np.uint64); body = np.zeros(max(n * ml, 1), np.uint8)
+    _ck(_lib().keaki_host_vec_encrypt(rng.h, setup.h, _p(_u64(com)), _p(np.ascontiguousarray(pts)), _p(np.ascontiguousarray(vals)), _p(msgs),
+                                     C.c_size_t(n), C.c_size_t(ml), _p(g2), _p(body)))
+    return [(g2[i].copy(), body[i * ml:(i + 1) * ml].tobytes()) for i in range(n)]
+
+
+def vec_decrypt(setup: KZGSetup, proofs, cts):
+    n = len(cts); ml = len(cts[0][1]) if n else 0
+    pr = np.ascontiguousarray(_u64(proofs, 8)[:n])
+    g2 = np.ascontiguousarray(np.stack([_u64(c[0]) for c in cts])) if n else np.zeros((0, 16), np.uint64)
+    body = np.frombuffer(b"".join(c[1] for c in cts) or b"\0", np.uint8).copy()
+    out = np.zeros(max(n * ml, 1), np.uint8)
+    _ck(_lib().keaki_host_vec_decrypt(setup.h, _p(pr), _p(g2), _p(body), C.c_size_t(n), C.c_size_t(ml), _p(out)))
+    return [out[i * ml:(i + 1) * ml].tobytes() for i in range(n)]

@@ -94,3 +94,43 @@ def test_bench_input_generation():
     vals = [int.from_bytes(x[i].tobytes(), "little") for i in range(5000)]
     assert max(vals) < b.R_MOD and len(set(vals)) == 5000
     assert np.array_equal(x, b.random_fr_limbs(5000, 7))
+
+
+def test_host_mirror_library_loads():
+    """libkeaki_host.so (C++ mirror of keaki's kzg/kem/enc/vec API) links against the C ABI and exports its front-end."""
+    import ctypes
+    from keaki_amd import hip
+    hip.load_library()
+    lib = ctypes.CDLL(os.path.join(ROOT, "keaki_amd", "libkeaki_host.so"))
+    for s in ["keaki_host_setup", "keaki_host_commit", "keaki_host_open", "keaki_host_verify", "keaki_host_open_fk", "keaki_host_encapsulate",
+              "keaki_host_decapsulate", "keaki_host_encrypt", "keaki_host_decrypt", "keaki_host_vec_commit", "keaki_host_vec_encrypt",
+              "keaki_host_vec_decrypt"]:
+        assert hasattr(lib, s), s
+
+
+def test_host_scalar_field_and_domain(py):
+    """Host-side Fr arithmetic / Radix-2 domain of the mirror (no GPU needed) against the big-int oracle."""
+    from keaki_amd import keaki as K
+    to_int = lambda a: (int.from_bytes(np.asarray(a, np.uint64).tobytes(), "little") * py.FR_RINV) % py.R
+    assert to_int(K.fr(-24)) == (-24) % py.R and to_int(K.fr(7)) == 7 and to_int(K.fr(0)) == 0
+    a, b = K.fr(123456789), K.fr(-987654321)
+    assert to_int(K.fr_mul(a, b)) == (123456789 * -987654321) % py.R
+    assert to_int(K.fr_add(a, b)) == (123456789 - 987654321) % py.R
+    assert to_int(K.fr_sub(a, b)) == (123456789 + 987654321) % py.R
+    coeffs = np.stack([K.fr(c) for c in [-24, -25, -5, 9, 7]])
+    assert to_int(K.poly_evaluate(coeffs, K.fr(3))) == py.poly_eval([c % py.R for c in [-24, -25, -5, 9, 7]], 3)
+    # Radix2EvaluationDomain: ark-bn254's two-adic root 5^((r-1)/2^28), size = next power of two
+    el = [to_int(e) for e in K.domain_elements(9)]
+    w = pow(5, (py.R - 1) >> 28, py.R)
+    g = pow(w, 1 << (28 - 4), py.R)
+    assert len(el) == 16 and el == [pow(g, i, py.R) for i in range(16)]
+    # ifft then fft is the identity; ifft gives the interpolating polynomial
+    ev = np.stack([K.fr(i * i + 1) for i in range(9)])
+    co = K.ifft(ev, 9)
+    back = K.fft(co, 9)
+    assert [to_int(x) for x in back[:9]] == [i * i + 1 for i in range(9)] and all(to_int(x) == 0 for x in back[9:])
+    ci = [to_int(c) for c in co]
+    assert all(py.poly_eval(ci, el[i]) == (i * i + 1 if i < 9 else 0) for i in range(16))
+    # Fr::rand semantics: SplitMix64 stream -> limbs with the top two bits cleared, < r
+    r = K.Rng(5).fr_rand()
+    assert int.from_bytes(r.tobytes(), "little") < py.R

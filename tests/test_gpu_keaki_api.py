@@ -1,0 +1,197 @@
+"""The reference's own tests, restated for E = Bn254 against the host mirror of keaki's public API
+(kzg / kem / enc / vec -> libkeaki_host.so -> C ABI -> HIP kernels). Same structure and assertions as
+src/kzg.rs:218-505, src/kem.rs:87-224, src/enc.rs:70-125 and tests/laconic_ot.rs:126-200; each result is
+additionally compared with the CPU oracle where the reference only checks relations."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    from keaki_amd import keaki
+    return keaki
+
+
+def canon(oc, fr_mont):
+    return oc.limbs_to_ints(oc.fr_from_mont(np.asarray(fr_mont).reshape(-1, 4)))
+
+
+POLY = [-24, -25, -5, 9, 7]  # p(x) = 7x^4 + 9x^3 - 5x^2 - 25x - 24 (src/kem.rs:91-98)
+
+
+def test_kzg_setup(K, oc, py):
+    """src/kzg.rs:218-239: g1_pow[i] == g * tau^i, tau_g2 == g2 * tau."""
+    rng = K.Rng(1)
+    secret = rng.fr_rand()
+    s = K.KZGSetup.setup(secret, 10)
+    tau = canon(oc, secret)[0]
+    assert oc.g1_to_ints(s.g1_pow()) == [py.g1_mul(py.G1_GEN, pow(tau, i, py.R)) for i in range(10)]
+    assert oc.g2_to_ints(s.tau_g2())[0] == py.g2_mul(py.G2_GEN, tau)
+
+
+def test_kzg_commit(K, oc, py):
+    """src/kzg.rs:241-258: commit == naive sum."""
+    rng = K.Rng(2)
+    s = K.KZGSetup.setup(rng.fr_rand(), 10)
+    p = np.stack([K.fr(1), K.fr(2), K.fr(3)])
+    com = K.commit(s, p)
+    pw = oc.g1_to_ints(s.g1_pow())
+    naive = None
+    for c, g in zip([1, 2, 3], pw):
+        naive = py.g1_add(naive, py.g1_mul(g, c))
+    assert oc.g1_to_ints(com)[0] == naive
+
+
+def test_kzg_commit_polynomial_too_large(K):
+    """src/kzg.rs:260-277: Err(PolynomialTooLarge(5, 4))."""
+    s = K.KZGSetup.setup(K.Rng(3).fr_rand(), 4)
+    p = np.stack([K.fr(i + 1) for i in range(5)])
+    with pytest.raises(K.KZGError) as e:
+        K.commit(s, p)
+    assert e.value == K.KZGError(5, 4)
+
+
+def test_kzg_open_polynomial_too_large(K):
+    """src/kzg.rs:279-308: the error carries the QUOTIENT's length (6 coeffs -> quotient 5, max 4)."""
+    s = K.KZGSetup.setup(K.Rng(4).fr_rand(), 4)
+    p = np.stack([K.fr(i + 1) for i in range(6)])
+    with pytest.raises(K.KZGError) as e:
+        K.open(s, p, K.fr(7))
+    assert e.value == K.KZGError(5, 4)
+
+
+def test_kzg_open_and_verify_matrix(K, oc, py):
+    """src/kzg.rs:310-468: valid proof verifies; wrong alpha / beta / proof / commitment do not."""
+    rng = K.Rng(5)
+    secret = rng.fr_rand()
+    s = K.KZGSetup.setup(secret, 10)
+    p = np.stack([K.fr(c) for c in POLY])
+    point = rng.fr_rand()
+    value = K.poly_evaluate(p, point)
+    com = K.commit(s, p)
+    proof = K.open(s, p, point)
+    # absolute check against the oracle's restatement
+    tau, z = canon(oc, secret)[0], canon(oc, point)[0]
+    g1p, _ = py.kzg_setup(tau, 10)
+    coeffs = [c % py.R for c in POLY]
+    assert oc.g1_to_ints(com)[0] == py.kzg_commit(g1p, coeffs)
+    assert oc.g1_to_ints(proof)[0] == py.kzg_open(g1p, coeffs, z)
+    assert canon(oc, value)[0] == py.poly_eval(coeffs, z)
+    assert K.verify(s, com, point, value, proof)
+    assert not K.verify(s, com, rng.fr_rand(), value, proof)          # wrong alpha
+    assert not K.verify(s, com, point, rng.fr_rand(), proof)          # wrong beta
+    q = np.stack([K.fr(c) for c in [-24, -29, -5, 9, 7]])
+    assert not K.verify(s, com, point, value, K.open(s, q, point))    # wrong proof
+    assert not K.verify(s, K.commit(s, q), point, value, proof)       # wrong commitment
+
+
+def test_kzg_open_fk(K):
+    """src/kzg.rs:470-505: open_fk proofs == open at each root of unity (d = 4, SRS 16)."""
+    rng = K.Rng(6)
+    s = K.KZGSetup.setup(rng.fr_rand(), 16)
+    p = np.stack([K.fr(c) for c in [1, 2, 3, 4]])
+    proofs = K.open_fk(s, p, 4)
+    el = K.domain_elements(4)
+    assert proofs.shape[0] == 4
+    for i in range(4):
+        assert np.array_equal(proofs[i], K.open(s, p, el[i]))
+        assert K.verify(s, K.commit(s, p), el[i], K.poly_evaluate(p, el[i]), proofs[i])
+
+
+def test_encapsulation_decapsulation(K, oc, py):
+    """src/kem.rs:87-116 (+ absolute check of ct / key against the oracle)."""
+    rng = K.Rng(7)
+    secret = rng.fr_rand()
+    s = K.KZGSetup.setup(secret, 10)
+    p = np.stack([K.fr(c) for c in POLY])
+    point = rng.fr_rand()
+    value = K.poly_evaluate(p, point)
+    com = K.commit(s, p)
+    # the r the next encapsulate will draw: replay the stream on a twin rng
+    twin = K.Rng(7); twin.fr_rand(); twin.fr_rand()
+    r = canon(oc, twin.fr_rand())[0]
+    ct, enc_key = K.encapsulate(rng, s, com, point, value, 32)
+    proof = K.open(s, p, point)
+    dec_key = K.decapsulate(s, proof, ct, 32)
+    assert enc_key == dec_key and len(enc_key) == 32
+    ect, ekey, _ = py.kem_encapsulate(r, oc.g2_to_ints(s.tau_g2())[0], oc.g1_to_ints(com)[0], canon(oc, point)[0], canon(oc, value)[0], 32)
+    assert oc.g2_to_ints(ct)[0] == ect and enc_key == ekey
+
+
+def test_decapsulation_negative_cases(K):
+    """src/kem.rs:118-224: invalid proof, invalid ciphertext, invalid point -> different keys."""
+    rng = K.Rng(8)
+    s = K.KZGSetup.setup(rng.fr_rand(), 10)
+    p = np.stack([K.fr(c) for c in POLY])
+    q = np.stack([K.fr(c) for c in [-24, -29, -5, 9, 7]])
+    point = rng.fr_rand()
+    value = K.poly_evaluate(p, point)
+    com = K.commit(s, p)
+    ct, enc_key = K.encapsulate(rng, s, com, point, value, 32)
+    assert K.decapsulate(s, K.open(s, q, point), ct, 32) != enc_key                       # invalid proof
+    ct2, _ = K.encapsulate(rng, s, com, point, value, 32)                                   # a different ciphertext (new r)
+    assert K.decapsulate(s, K.open(s, p, point), ct2, 32) != enc_key
+    wrong_point = rng.fr_rand()
+    ct3, key3 = K.encapsulate(rng, s, com, wrong_point, value, 32)                           # invalid point
+    assert K.decapsulate(s, K.open(s, p, point), ct3, 32) != key3
+
+
+def test_encrypt_decrypt(K):
+    """src/enc.rs:70-125."""
+    rng = K.Rng(9)
+    s = K.KZGSetup.setup(rng.fr_rand(), 10)
+    p = np.stack([K.fr(c) for c in POLY])
+    q = np.stack([K.fr(c) for c in [-24, -29, -5, 9, 7]])
+    point = rng.fr_rand()
+    value = K.poly_evaluate(p, point)
+    com = K.commit(s, p)
+    msg = b"helloworld"
+    ct = K.encrypt(rng, s, com, point, value, msg)
+    assert K.decrypt(s, K.open(s, p, point), ct) == msg
+    assert K.decrypt(s, K.open(s, q, point), ct) != msg
+
+
+def test_laconic_ot(K):
+    """tests/laconic_ot.rs:126-200 with the same parameters: SETUP_DEGREE 16, N_CHOICES 8, cardinality 2, 32-byte values."""
+    SETUP_DEGREE, N_CHOICES, VALUE_BYTES = 16, 8, 32
+    rng = K.Rng(10)
+    s = K.KZGSetup.setup(rng.fr_rand(), SETUP_DEGREE)
+    np_rng = np.random.default_rng(10)
+    choice_bits = [int(b) for b in np_rng.integers(0, 2, N_CHOICES)]
+    choices = np.stack([K.fr(b) for b in choice_bits])
+    # Receiver::new (tests/laconic_ot.rs:25-37)
+    commitment, proofs = K.vec_commit(rng, s, choices)
+    # Sender::send (:75-112)
+    private_set = [[np_rng.bytes(VALUE_BYTES) for _ in range(N_CHOICES)] for _ in range(2)]
+    elements = K.domain_elements(N_CHOICES + K.PADDING_LEN)
+    zero, one = K.fr(0), K.fr(1)
+    ct0 = K.vec_encrypt(rng, s, commitment, elements, np.stack([zero] * N_CHOICES), private_set[0])
+    ct1 = K.vec_encrypt(rng, s, commitment, elements, np.stack([one] * N_CHOICES), private_set[1])
+    # Receiver::receive (:39-57)
+    chosen = [ct0[i] if choice_bits[i] == 0 else ct1[i] for i in range(N_CHOICES)]
+    got = K.vec_decrypt(s, proofs, chosen)
+    for i in range(N_CHOICES):
+        assert got[i] == private_set[choice_bits[i]][i]
+    # and the non-chosen message stays hidden from this receiver
+    other = [ct1[i] if choice_bits[i] == 0 else ct0[i] for i in range(N_CHOICES)]
+    got_other = K.vec_decrypt(s, proofs, other)
+    for i in range(N_CHOICES):
+        assert got_other[i] != private_set[1 - choice_bits[i]][i]
+
+
+def test_vec_encrypt_matches_serial_reference_loop(K, oc, py):
+    """src/vec.rs:52-69 draws one r per item in index order; the batched GPU call must give exactly what the
+    serial loop of single encrypts gives on the same rng stream."""
+    rng_a, rng_b = K.Rng(11), K.Rng(11)
+    s = K.KZGSetup.setup(K.Rng(12).fr_rand(), 8)
+    com = K.commit(s, np.stack([K.fr(c) for c in POLY]))
+    n = 5
+    pts = K.domain_elements(8)[:n]
+    vals = np.stack([K.fr(i) for i in range(n)])
+    msgs = [bytes([i] * 16) for i in range(n)]
+    batched = K.vec_encrypt(rng_a, s, com, pts, vals, msgs)
+    serial = [K.encrypt(rng_b, s, com, pts[i], vals[i], msgs[i]) for i in range(n)]
+    for b, c in zip(batched, serial):
+        assert np.array_equal(b[0], c[0]) and b[1] == c[1]
