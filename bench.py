@@ -116,13 +116,22 @@ def main():
     d_all = torch.zeros((world, 12), dtype=torch.int64, device=dev)
     d_out = torch.zeros(12, dtype=torch.int64, device=dev)
 
-    def step():
+    from keaki_amd.dist import sharded_msm, torch_all_gather
+
+    def partial_fn():
         hip.msm_g1_dev(srs, d_s.data_ptr(), n, d_part.data_ptr())
-        if world > 1:
-            dist.all_gather_into_tensor(d_all.view(-1), d_part)
-            hip.g1_sum_dev(d_all.data_ptr(), world, d_out.data_ptr())
-        else:
-            d_out.copy_(d_part)
+        return d_part
+
+    def sum_fn(allp):
+        hip.g1_sum_dev(allp.data_ptr(), world, d_out.data_ptr())
+        return d_out
+
+    gather_fn = torch_all_gather(dist, d_all) if world > 1 else None
+
+    def step():
+        res = sharded_msm(partial_fn, gather_fn, sum_fn, world)
+        if world == 1:
+            d_out.copy_(res)
 
     hip.set_timing(True)
     for _ in range(args.warmup):
