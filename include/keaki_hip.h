@@ -127,6 +127,11 @@ float keaki_hip_last_msm_total_ms(const keaki_hip_ctx* ctx);
 /* window size (bits) the last MSM used */
 int32_t keaki_hip_last_msm_window_bits(const keaki_hip_ctx* ctx);
 
+/* On-device self-test: runs the hand-scheduled Fq instruction streams (product, add, sub, neg, square and a
+ * dependent chain) against the portable template code on `blocks` x 256 lanes x `iters` random and corner-case
+ * inputs; *mismatches_out must come back 0. */
+keaki_status keaki_hip_selftest_field(keaki_hip_ctx* ctx, uint32_t blocks, uint32_t iters, uint32_t seed, uint64_t* mismatches_out);
+
 #ifdef __cplusplus
 }
 #endif

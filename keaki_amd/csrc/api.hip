@@ -399,4 +399,14 @@ keaki_status keaki_hip_decap_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_af
   return KEAKI_OK;
 }
 
+// ---- self-test --------------------------------------------------------------------------------------------
+keaki_status keaki_hip_selftest_field(keaki_hip_ctx* ctx, uint32_t blocks, uint32_t iters, uint32_t seed, uint64_t* mismatches_out) {
+  CTX_GUARD(ctx);
+  if (!mismatches_out || blocks == 0) return fail(ctx, KEAKI_ERR_BAD_ARG, "selftest_field: bad argument");
+  ST_TRY(reserve(ctx, ctx->io_e, 16));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->io_e.p, 0, 8, ctx->stream));
+  ST_TRY(selftest_field_run(ctx, blocks, iters, seed, ctx->io_e.p));
+  return download(ctx, mismatches_out, ctx->io_e.p, 8);
+}
+
 }  // extern "C"

@@ -219,6 +219,24 @@ KDEV Fp<P> fp_to_mont(const u32* canon) {
   return fp_mul<P>(a, r2);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fq: hand-scheduled gfx950 streams (bn254_field_asm.cuh) replace the portable templates above.
+// The portable code stays the implementation for Fr and the reference the on-device self-test
+// (k_selftest_field) compares the streams with, through FqParamsRef.
+// ---------------------------------------------------------------------------------------------
+struct FqParamsRef : FqParams {};   // same constants, but takes the portable template path
+}  // namespace bn254
+#ifndef KEAKI_PORTABLE_FIELD
+#include "bn254_field_asm.cuh"
+namespace bn254 {
+template <> KDEV Fq fp_mul<FqParams>(const Fq& a, const Fq& b) { Fq r; fq_mul_asm(r.l, a.l, b.l); return r; }
+template <> KDEV Fq fp_add<FqParams>(const Fq& a, const Fq& b) { Fq r; fq_add_asm(r.l, a.l, b.l); return r; }
+template <> KDEV Fq fp_sub<FqParams>(const Fq& a, const Fq& b) { Fq r; fq_sub_asm(r.l, a.l, b.l); return r; }
+template <> KDEV Fq fp_neg<FqParams>(const Fq& a) { Fq r; fq_neg_asm(r.l, a.l); return r; }
+}  // namespace bn254
+#endif
+namespace bn254 {
+
 // a^(p-2). Not inlined: 380 multiplications, called once per batch / per pairing.
 static __device__ __noinline__ Fq fq_inv(const Fq& a) {
   Fq acc = fp_one<FqParams>();

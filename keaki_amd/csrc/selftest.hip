@@ -1,0 +1,57 @@
+// On-device self-test of the hand-scheduled Fq streams against the portable template code.
+#include "bn254_field.cuh"
+#include "internal.h"
+namespace bn254 {
+using FqRef = Fp<FqParamsRef>;
+KDEV u32 mix(u32& s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
+// a value < p with a choice of corner shapes
+KDEV Fq pick(u32& s, u32 shape) {
+  Fq x;
+#pragma unroll
+  for (int j = 0; j < 8; j++) x.l[j] = mix(s);
+  if (shape == 1) { for (int j = 0; j < 8; j++) x.l[j] = 0; }
+  else if (shape == 2) { for (int j = 0; j < 8; j++) x.l[j] = FqParams::MOD[j]; x.l[0] -= 1; }          // p - 1
+  else if (shape == 3) { for (int j = 0; j < 7; j++) x.l[j] = 0xFFFFFFFFu; x.l[7] = 0x2FFFFFFFu; }       // dense ones below p
+  else if (shape == 4) { for (int j = 1; j < 8; j++) x.l[j] = 0; x.l[0] = mix(s) & 3; }                 // tiny
+  else if (shape == 5) { for (int j = 0; j < 8; j++) x.l[j] = (j & 1) ? 0xFFFFFFFFu : 0u; x.l[7] = 0x1FFFFFFFu; }
+  x.l[7] &= 0x3FFFFFFFu;  // < 2^254
+  u32 t[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) t[j] = x.l[j];
+  fp_reduce_once<FqParamsRef>(t);   // < 2^254 < 2p -> < p
+#pragma unroll
+  for (int j = 0; j < 8; j++) x.l[j] = t[j];
+  return x;
+}
+KDEV FqRef as_ref(const Fq& a) { FqRef r; for (int j = 0; j < 8; j++) r.l[j] = a.l[j]; return r; }
+KDEV bool same(const Fq& a, const FqRef& b) { u32 o = 0; for (int j = 0; j < 8; j++) o |= a.l[j] ^ b.l[j]; return o == 0; }
+
+__global__ void __launch_bounds__(256) k_selftest_field(u32 seed, u32 iters, unsigned long long* mismatches) {
+  u32 s = seed ^ (blockIdx.x * 0x9E3779B9u) ^ (threadIdx.x * 0x85EBCA6Bu);
+  s |= 1;
+  unsigned long long bad = 0;
+  Fq chain = pick(s, 0);
+  FqRef chain_ref = as_ref(chain);
+  for (u32 it = 0; it < iters; it++) {
+    u32 sh = mix(s);
+    Fq a = pick(s, (sh & 15) < 6 ? (sh & 15) : 0), b = pick(s, ((sh >> 4) & 15) < 6 ? ((sh >> 4) & 15) : 0);
+    FqRef ar = as_ref(a), br = as_ref(b);
+    bad += !same(a * b, fp_mul<FqParamsRef>(ar, br));
+    bad += !same(a + b, fp_add<FqParamsRef>(ar, br));
+    bad += !same(a - b, fp_sub<FqParamsRef>(ar, br));
+    bad += !same(-a, fp_neg<FqParamsRef>(ar));
+    bad += !same(fq_sqr(a), fp_mul<FqParamsRef>(ar, ar));
+    // dependent chain (exercises back-to-back streams)
+    chain = chain * a + b - chain * chain;
+    chain_ref = fp_sub<FqParamsRef>(fp_add<FqParamsRef>(fp_mul<FqParamsRef>(chain_ref, ar), br), fp_mul<FqParamsRef>(chain_ref, chain_ref));
+    bad += !same(chain, chain_ref);
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+}  // namespace bn254
+namespace keaki_internal {
+keaki_status selftest_field_run(keaki_hip_ctx* ctx, uint32_t blocks, uint32_t iters, uint32_t seed, void* d_mismatches) {
+  hipLaunchKernelGGL(bn254::k_selftest_field, dim3(blocks), dim3(256), 0, ctx->stream, seed, iters, (unsigned long long*)d_mismatches);
+  return launch_check(ctx, "selftest_field");
+}
+}  // namespace keaki_internal

@@ -23,7 +23,7 @@ EXPORTS = [
     "keaki_hip_g1_mul_batch", "keaki_hip_g2_mul_batch", "keaki_hip_g1_mul_batch_dev", "keaki_hip_g2_mul_batch_dev",
     "keaki_hip_pairing_batch", "keaki_hip_pairing_batch_dev",
     "keaki_hip_encap_batch", "keaki_hip_encap_batch_dev", "keaki_hip_decap_batch", "keaki_hip_decap_batch_dev",
-    "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
+    "keaki_hip_selftest_field", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
 ]
 
 KEAKI_ERR_TOO_LARGE = -5
@@ -76,6 +76,7 @@ def load_library():
         lib.keaki_hip_encap_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, sz]
         lib.keaki_hip_decap_batch.argtypes = [vp, vp, vp, sz, vp, vp, sz]
         lib.keaki_hip_decap_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, sz]
+        lib.keaki_hip_selftest_field.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
         lib.keaki_hip_set_timing.argtypes = [vp, i32]
         lib.keaki_hip_last_msm_bucket_ms.argtypes = [vp]
         lib.keaki_hip_last_msm_bucket_ms.restype = C.c_float
@@ -150,6 +151,12 @@ class KeakiHip:
         return {"bucket_ms": float(self.lib.keaki_hip_last_msm_bucket_ms(self.ctx)),
                 "total_ms": float(self.lib.keaki_hip_last_msm_total_ms(self.ctx)),
                 "window_bits": int(self.lib.keaki_hip_last_msm_window_bits(self.ctx))}
+
+    def selftest_field(self, blocks: int = 1024, iters: int = 64, seed: int = 1) -> int:
+        """mismatch count of the hand-scheduled Fq streams vs the portable code (must be 0)"""
+        bad = C.c_uint64(1)
+        self._ck(self.lib.keaki_hip_selftest_field(self.ctx, blocks, iters, seed, C.byref(bad)))
+        return int(bad.value)
 
     # ---- SRS
     def srs_g1_upload(self, points) -> SrsG1:

@@ -212,3 +212,11 @@ def test_msm_full_size_property(oc, hip, rand_fr):
     finally:
         srs.free()
     assert np.array_equal(got, oc.g1_mul_batch(g1, oc.fr_dot(s, k).reshape(1, 4))[0])
+
+
+@pytest.mark.parametrize("blocks,iters", [(4, 256), (1024, 64), (8192, 16)])
+def test_field_asm_streams_selftest(hip, blocks, iters):
+    """Hand-scheduled Fq streams vs the portable template code, on device, at low and high occupancy
+    (a wait-state hazard inside an asm string would show up as rare mismatches)."""
+    for seed in (1, 2, 3):
+        assert hip.selftest_field(blocks, iters, seed) == 0
