@@ -3,17 +3,17 @@
 // Replaces `<E::G1 as VariableBaseMSM>::msm_unchecked(&setup.g1_aff, p)` (reference src/kzg.rs:98;
 // ark-ec 0.4.2 msm_bigint_wnaf). The *result* is the same group element; the schedule is GPU-native:
 //
-//   K1 digits     one lane per scalar: Montgomery -> canonical, signed radix-2^c digits,
-//                 per-(window,bucket) histogram                              [coalesced 32 B/lane]
-//   K2 scan       exclusive prefix over the histogram (bucket start offsets)
-//   K3 scatter    counting-sort of (point index | sign) into bucket order
+//   K1 part_count / K2 scan / K3 part_scatter / K3b part_fine
+//                 one lane per scalar: Montgomery -> canonical, signed radix-2^c digits; the n*W
+//                 (bucket, point) pairs are bucket-sorted by an LDS-staged two-pass radix partition
+//                 (no global atomics)                                        [coalesced 32 B/lane]
 //   K4 accumulate one lane per bucket: gather affine points (64 B rows), XYZZ mixed adds -- the
 //                 dominant kernel: n * windows adds of 8M+2S
 //   K5 reduce     per-window weighted bucket sum  sum_b (b+1) S_b  by chunked running sums
 //   K6 finish     window sums -> Horner by 2^c -> one point, normalised
 //
-// Order of additions inside a bucket depends on atomics; EC addition is exact and commutative, so
-// the affine result is bit-identical run to run.
+// Order of additions inside a bucket depends on LDS-atomic arrival order; EC addition is exact and
+// commutative, so the affine result is bit-identical run to run.
 #pragma once
 #include "bn254_curve.cuh"
 
@@ -21,42 +21,170 @@ namespace bn254 {
 
 constexpr u32 DIGIT_NONE = 0xFFFFFFFFu;
 
+// Window plan. The 254 scalar bits are spread over W windows as evenly as possible: the first `k`
+// windows are `c` bits wide, the remaining W - k are c - 1 bits wide (k >= 1, k*c + (W-k)*(c-1) = 254).
+// Equal widths keep every bucket equally loaded; a plain radix-2^c split would leave a narrow top
+// window whose few buckets receive up to 64x the points (one straggling workgroup / wave).
+// Windows 0..W-2 use signed digits (2^(width-1) buckets); the top window keeps its digit unsigned
+// (2^width buckets, ~76% populated since scalars are < r), so no carry ever leaves it.
 struct MsmShape {
-  u32 n;        // number of (scalar, point) pairs
-  u32 c;        // window bits
-  u32 W;        // number of windows = ceil(254 / c) (top window never carries out, see digit rule)
-  u32 B;        // buckets per window = 2^(c-1)
+  u32 n;   // number of (scalar, point) pairs
+  u32 c;   // width of the wide windows
+  u32 W;   // number of windows
+  u32 k;   // number of wide windows
 };
+KDEV u32 msm_width(const MsmShape& s, u32 w) { return w < s.k ? s.c : s.c - 1; }
+KDEV u32 msm_bit_offset(const MsmShape& s, u32 w) { return w < s.k ? w * s.c : s.k * s.c + (w - s.k) * (s.c - 1); }
+KDEV u32 msm_nbuckets(const MsmShape& s, u32 w) { u32 wd = msm_width(s, w); return w == s.W - 1 ? (1u << wd) : (1u << (wd - 1)); }
+KDEV u32 msm_bucket_base(const MsmShape& s, u32 w) {
+  return w <= s.k ? w * (1u << (s.c - 1)) : s.k * (1u << (s.c - 1)) + (w - s.k) * (1u << (s.c - 2));
+}
+// host-side mirror of the same plan
+struct MsmPlan {
+  MsmShape s;
+  size_t nb;       // total buckets
+  u32 max_b;       // largest per-window bucket count
+};
+inline MsmPlan msm_make_plan(size_t n, int c_target) {
+  MsmPlan p;
+  u32 W = (254 + c_target - 1) / c_target;
+  u32 base = 254 / W, rem = 254 % W;
+  p.s.n = (u32)n;
+  p.s.W = W;
+  if (rem == 0) { p.s.c = base; p.s.k = W; } else { p.s.c = base + 1; p.s.k = rem; }
+  size_t nb = 0; u32 mb = 0;
+  for (u32 w = 0; w < W; w++) {
+    u32 wd = w < p.s.k ? p.s.c : p.s.c - 1;
+    u32 b = (w == W - 1) ? (1u << wd) : (1u << (wd - 1));
+    nb += b; if (b > mb) mb = b;
+  }
+  p.nb = nb; p.max_b = mb;
+  return p;
+}
 
-// signed-digit rule: coef in [0, 2^c]; if coef > 2^(c-1): digit = coef - 2^c, carry 1.
-// => digits in [-(2^(c-1) - 1), 2^(c-1)]; bucket id = |digit| - 1 in [0, B).
-// The top window holds < c - 1 significant bits whenever c does not divide 254 (guaranteed by the
-// host-side choice of c), so it never produces a carry.
-static __global__ void __launch_bounds__(256) k_msm_digits(const Fr* __restrict__ scalars, MsmShape s, u32* __restrict__ digits,
-                                                    u32* __restrict__ hist) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= s.n) return;
-  Fr k = scalars[i];
+// Digits of one scalar, lowest window first. `emit(w, code)` is called for every non-zero digit with
+// code = bucket (= |d| - 1) | sign << 31. Signed rule for windows below the top: coef in [0, 2^wd];
+// coef > 2^(wd-1) -> digit coef - 2^wd with carry 1 (coef == 2^wd is digit 0 with carry 1).
+template <class Emit>
+KDEV void msm_for_each_digit(const Fr& k, const MsmShape& s, Emit emit) {
   u32 v[8];
   fp_from_mont<FrParams>(v, k);
   u32 carry = 0;
-  const u32 mask = (1u << s.c) - 1u, half = 1u << (s.c - 1);
   for (u32 w = 0; w < s.W; w++) {
-    u32 coef = (v[0] & mask) + carry;
-    // shift the 256-bit scalar right by c bits (static register indices; c <= 31)
+    const u32 wd = msm_width(s, w);
+    const u32 full = 1u << wd, half = full >> 1;
+    u32 coef = (v[0] & (full - 1u)) + carry;
+    // shift the 256-bit scalar right by wd bits (static register indices; wd <= 31)
 #pragma unroll
-    for (int j = 0; j < 7; j++) v[j] = (u32)((((u64)v[j + 1] << 32) | v[j]) >> s.c);
-    v[7] >>= s.c;
-    u32 out;
-    if (coef > half) {
-      out = ((1u << s.c) - coef - 1u) | 0x80000000u;  // negative digit, bucket = |d| - 1
+    for (int j = 0; j < 7; j++) v[j] = (u32)((((u64)v[j + 1] << 32) | v[j]) >> wd);
+    v[7] >>= wd;
+    if (w == s.W - 1) {
+      if (coef) emit(w, coef - 1u);      // top window: unsigned, 2^wd buckets (coef <= 0.76 * 2^wd + 1)
+    } else if (coef > half) {
       carry = 1;
+      if (coef != full) emit(w, (full - coef - 1u) | 0x80000000u);
     } else {
       carry = 0;
-      out = coef ? coef - 1u : DIGIT_NONE;
+      if (coef) emit(w, coef - 1u);
     }
-    digits[(size_t)w * s.n + i] = out;
-    if (out != DIGIT_NONE) atomicAdd(&hist[w * s.B + (out & 0x7FFFFFFFu)], 1u);
+  }
+}
+
+// ---- LDS-staged two-pass radix partition of the (bucket, point) pairs -------------------------------
+// Global bucket id g = w * B + bucket. Pass 1 partitions all n*W pairs by the coarse key g >> PART_SHIFT
+// (per-workgroup histograms and cursors live in LDS; the only global traffic is coalesced reads and
+// short contiguous runs of 8-byte writes). Pass 2 gives each coarse bin to one workgroup, which
+// histograms / scans / scatters its <= 2^PART_SHIFT fine buckets entirely in LDS and emits the final
+// bucket-ordered index stream plus the per-bucket offsets and counts. No global atomics anywhere.
+constexpr u32 PART_SHIFT = 12;
+constexpr u32 PART_FINE = 1u << PART_SHIFT;
+constexpr u32 PART_TILE = 1024;       // scalars per workgroup in pass 1
+constexpr u32 PART_MAX_BINS = 8192;   // coarse bins (LDS: 32 KB of counters)
+
+struct PartShape {
+  u32 nbins;    // coarse bins = ceil(W * B / PART_FINE)
+  u32 nwg;      // pass-1 workgroups = ceil(n / PART_TILE)
+};
+
+// pass 1a: counts[bin * nwg + wg]
+static __global__ void __launch_bounds__(256) k_part_count(const Fr* __restrict__ scalars, MsmShape s, PartShape ps, u32* __restrict__ counts) {
+  extern __shared__ u32 lds_hist[];
+  for (u32 b = threadIdx.x; b < ps.nbins; b += 256) lds_hist[b] = 0;
+  __syncthreads();
+  const u32 base = blockIdx.x * PART_TILE;
+  for (u32 t = threadIdx.x; t < PART_TILE; t += 256) {
+    u32 i = base + t;
+    if (i < s.n) {
+      msm_for_each_digit(scalars[i], s, [&](u32 w, u32 code) {
+        u32 g = msm_bucket_base(s, w) + (code & 0x7FFFFFFFu);
+        atomicAdd(&lds_hist[g >> PART_SHIFT], 1u);
+      });
+    }
+  }
+  __syncthreads();
+  for (u32 b = threadIdx.x; b < ps.nbins; b += 256) counts[(size_t)b * ps.nwg + blockIdx.x] = lds_hist[b];
+}
+// pass 1b: entries[pos] = fine (PART_SHIFT bits) << 32 | sign << 31 | point index
+static __global__ void __launch_bounds__(256) k_part_scatter(const Fr* __restrict__ scalars, MsmShape s, PartShape ps,
+                                                             const u32* __restrict__ offsets, u64* __restrict__ entries) {
+  extern __shared__ u32 lds_cur[];
+  for (u32 b = threadIdx.x; b < ps.nbins; b += 256) lds_cur[b] = offsets[(size_t)b * ps.nwg + blockIdx.x];
+  __syncthreads();
+  const u32 base = blockIdx.x * PART_TILE;
+  for (u32 t = threadIdx.x; t < PART_TILE; t += 256) {
+    u32 i = base + t;
+    if (i < s.n) {
+      msm_for_each_digit(scalars[i], s, [&](u32 w, u32 code) {
+        u32 g = msm_bucket_base(s, w) + (code & 0x7FFFFFFFu);
+        u32 pos = atomicAdd(&lds_cur[g >> PART_SHIFT], 1u);
+        entries[pos] = ((u64)(g & (PART_FINE - 1)) << 32) | (code & 0x80000000u) | i;
+      });
+    }
+  }
+}
+// grand total of entries = exclusive offset of the last (bin, workgroup) cell + its count
+static __global__ void k_part_total(const u32* __restrict__ counts, const u32* __restrict__ offsets, u32 ncounts, u32* __restrict__ total) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *total = offsets[ncounts - 1] + counts[ncounts - 1];
+}
+// pass 2: one workgroup per coarse bin. bin b covers global buckets [b * PART_FINE, (b+1) * PART_FINE).
+static __global__ void __launch_bounds__(256) k_part_fine(const u64* __restrict__ entries, const u32* __restrict__ offsets, PartShape ps,
+                                                          const u32* __restrict__ total_ptr, u32 nbuckets_total, u32* __restrict__ bucket_offsets,
+                                                          u32* __restrict__ bucket_counts, u32* __restrict__ sorted) {
+  __shared__ u32 hist[PART_FINE];
+  __shared__ u32 wsum[4];
+  const u32 bin = blockIdx.x;
+  const u32 lo = offsets[(size_t)bin * ps.nwg];
+  const u32 hi = (bin + 1 < ps.nbins) ? offsets[(size_t)(bin + 1) * ps.nwg] : *total_ptr;
+  for (u32 f = threadIdx.x; f < PART_FINE; f += 256) hist[f] = 0;
+  __syncthreads();
+  for (u32 e = lo + threadIdx.x; e < hi; e += 256) atomicAdd(&hist[(u32)(entries[e] >> 32)], 1u);
+  __syncthreads();
+  // exclusive scan of hist (PART_FINE counters, 16 per thread), in place; counts kept in registers
+  u32 cnt[PART_FINE / 256];
+  u32 sum = 0;
+#pragma unroll
+  for (u32 k = 0; k < PART_FINE / 256; k++) { cnt[k] = hist[threadIdx.x * (PART_FINE / 256) + k]; sum += cnt[k]; }
+  u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6, x = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { u32 y = __shfl_up(x, o, 64); if (lane >= (u32)o) x += y; }
+  if (lane == 63) wsum[wid] = x;
+  __syncthreads();
+  u32 wbase = 0;
+  for (u32 k = 0; k < wid; k++) wbase += wsum[k];
+  u32 ex = lo + wbase + x - sum;
+#pragma unroll
+  for (u32 k = 0; k < PART_FINE / 256; k++) {
+    u32 f = threadIdx.x * (PART_FINE / 256) + k;
+    u32 g = bin * PART_FINE + f;
+    hist[f] = ex;                      // becomes the running cursor of bucket f
+    if (g < nbuckets_total) { bucket_offsets[g] = ex; bucket_counts[g] = cnt[k]; }
+    ex += cnt[k];
+  }
+  __syncthreads();
+  for (u32 e = lo + threadIdx.x; e < hi; e += 256) {
+    u64 v = entries[e];
+    u32 pos = atomicAdd(&hist[(u32)(v >> 32)], 1u);
+    sorted[pos] = (u32)v;
   }
 }
 
@@ -135,19 +263,6 @@ static __global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(const u32* _
   }
 }
 
-// ---- K3: scatter point indices into bucket order ------------------------------------------------
-static __global__ void __launch_bounds__(256) k_msm_scatter(const u32* __restrict__ digits, MsmShape s, const u32* __restrict__ offsets,
-                                                     u32* __restrict__ cursor, u32* __restrict__ sorted) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  u32 w = blockIdx.y;
-  if (i >= s.n) return;
-  u32 d = digits[(size_t)w * s.n + i];
-  if (d == DIGIT_NONE) return;
-  u32 key = w * s.B + (d & 0x7FFFFFFFu);
-  u32 pos = offsets[key] + atomicAdd(&cursor[key], 1u);
-  sorted[pos] = i | (d & 0x80000000u);
-}
-
 // ---- K4: bucket accumulation (dominant kernel) ----------------------------------------------------
 template <class F>
 __global__ void __launch_bounds__(256) k_msm_accumulate(const Aff<F>* __restrict__ points, const u32* __restrict__ sorted,
@@ -174,16 +289,17 @@ __global__ void __launch_bounds__(64) k_msm_reduce(const Xyzz<F>* __restrict__ b
   if (g >= s.W * chunks_per_window) return;
   u32 w = g / chunks_per_window, t = g % chunks_per_window;
   u32 lo = t * L;
-  const Xyzz<F>* bk = buckets + (size_t)w * s.B;
+  const u32 Bw = msm_nbuckets(s, w);
+  const Xyzz<F>* bk = buckets + msm_bucket_base(s, w);
   Xyzz<F> run = xyzz_inf<F>(), ws = xyzz_inf<F>();
   for (u32 j = L; j-- > 0;) {
-    if (lo + j < s.B) {
+    if (lo + j < Bw) {
       run = xyzz_add(run, bk[lo + j]);
       ws = xyzz_add(ws, run);
     }
   }
-  // ws += lo * run   (lo < 2^(c-1)), MSB-first double-and-add
-  if (lo != 0) {
+  // ws += lo * run   (lo < 2^c), MSB-first double-and-add
+  if (lo != 0 && lo < Bw) {
     Xyzz<F> m = xyzz_inf<F>();
     for (int b = 31 - __clz(lo); b >= 0; b--) {
       m = xyzz_dbl(m);
@@ -210,7 +326,7 @@ __global__ void __launch_bounds__(64) k_msm_window_finish(const Xyzz<F>* __restr
   }
   if (l == 0) {
     Xyzz<F> r = sh[0];
-    for (u32 k = 0; k < w * s.c; k++) r = xyzz_dbl(r);
+    for (u32 k = 0, nd = msm_bit_offset(s, w); k < nd; k++) r = xyzz_dbl(r);
     window_sums[w] = r;
   }
 }

@@ -12,17 +12,15 @@ using namespace bn254;
 inline int choose_window(size_t n) {
   if (const char* e = getenv("KEAKI_MSM_C")) {
     int c = atoi(e);
-    if (c >= 3 && c <= 24 && 254 % c != 0) return c;
+    if (c >= 3 && c <= 24) return c;
   }
   if (n < 32) return 3;
   double best = 1e300;
   int bc = 3;
   for (int c = 3; c <= 22; c++) {
-    if (254 % c == 0) continue;
-    double W = (254 + c - 1) / c, B = (double)(1u << (c - 1));
-    double cost = (double)n * W + 2.8 * W * B;
-    double lanes = W * B;
-    if (lanes < 131072.0) cost *= 131072.0 / lanes;
+    MsmPlan p = msm_make_plan(n, c);
+    double cost = (double)n * p.s.W + 2.8 * (double)p.nb;
+    if ((double)p.nb < 131072.0) cost *= 131072.0 / (double)p.nb;   // too few buckets cannot fill 256 CUs
     if (cost < best) { best = cost; bc = c; }
   }
   return bc;
@@ -44,16 +42,13 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   if (!d_out_jac || (n && (!d_points || !d_scalars))) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: null pointer");
   if (n > srs_len) return fail(ctx, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", n, srs_len);
   if (n >= (1ull << 31)) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: n must be < 2^31 per device");
-  MsmShape s;
-  s.n = (u32)n;
-  s.c = (u32)choose_window(n);
-  s.W = (254 + s.c - 1) / s.c;
-  s.B = 1u << (s.c - 1);
+  const MsmPlan plan = msm_make_plan(n, choose_window(n));
+  const MsmShape s = plan.s;
   ctx->last_c = (int)s.c;
-  const size_t nb = (size_t)s.W * s.B;
+  const size_t nb = plan.nb;
   if ((double)n * s.W >= 4294967295.0) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: n * windows overflows 32-bit positions");
-  const u32 L = s.B >= 4096 ? 64 : (s.B >= 64 ? 16 : s.B);  // reduce chunk length
-  const u32 chunks = cdiv(s.B, L);
+  const u32 L = plan.max_b >= 4096 ? 64 : (plan.max_b >= 64 ? 16 : plan.max_b);  // reduce chunk length
+  const u32 chunks = cdiv(plan.max_b, L);
   ST_TRY(reserve(ctx, ctx->wsums, (size_t)s.W * sizeof(Xyzz<F>)));
   Xyzz<F>* wsums = (Xyzz<F>*)ctx->wsums.p;
   F* out = (F*)d_out_jac;
@@ -63,24 +58,34 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
     hipLaunchKernelGGL((k_msm_final<F>), dim3(1), dim3(64), 0, st, (const Xyzz<F>*)wsums, 0u, out);
     return launch_check(ctx, "msm_final");
   }
-  ST_TRY(reserve(ctx, ctx->digits, n * s.W * 4));
+  PartShape ps;
+  ps.nbins = cdiv(nb, PART_FINE);
+  ps.nwg = cdiv(n, PART_TILE);
+  if (ps.nbins > PART_MAX_BINS) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: %u coarse bins exceed the LDS budget (window too large)", ps.nbins);
+  const size_t ncounts = (size_t)ps.nbins * ps.nwg;
+  if (ncounts >= 4294967295ull) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: partition table too large");
+  ST_TRY(reserve(ctx, ctx->digits, n * s.W * 8));      // coarse-partitioned (fine | sign | index) entries
   ST_TRY(reserve(ctx, ctx->sorted, n * s.W * 4));
-  ST_TRY(reserve(ctx, ctx->hist, nb * 4));
-  ST_TRY(reserve(ctx, ctx->offsets, nb * 4));
-  ST_TRY(reserve(ctx, ctx->cursor, nb * 4));
+  ST_TRY(reserve(ctx, ctx->hist, nb * 4));             // per-bucket counts
+  ST_TRY(reserve(ctx, ctx->offsets, nb * 4));          // per-bucket start offsets
+  ST_TRY(reserve(ctx, ctx->cursor, (ncounts * 2 + 4) * 4));  // [counts | exclusive scan] of the (bin, workgroup) table
   ST_TRY(reserve(ctx, ctx->buckets, nb * sizeof(Xyzz<F>)));
   ST_TRY(reserve(ctx, ctx->partials, (size_t)s.W * chunks * sizeof(Xyzz<F>)));
-  u32 *digits = (u32*)ctx->digits.p, *sorted = (u32*)ctx->sorted.p, *hist = (u32*)ctx->hist.p, *offsets = (u32*)ctx->offsets.p,
-      *cursor = (u32*)ctx->cursor.p;
+  u64* entries = (u64*)ctx->digits.p;
+  u32 *sorted = (u32*)ctx->sorted.p, *hist = (u32*)ctx->hist.p, *offsets = (u32*)ctx->offsets.p;
+  u32 *pcounts = (u32*)ctx->cursor.p, *poffsets = pcounts + ncounts;
   Xyzz<F>* buckets = (Xyzz<F>*)ctx->buckets.p;
   Xyzz<F>* partials = (Xyzz<F>*)ctx->partials.p;
-  HIP_TRY(ctx, hipMemsetAsync(hist, 0, nb * 4, st));
-  HIP_TRY(ctx, hipMemsetAsync(cursor, 0, nb * 4, st));
-  hipLaunchKernelGGL(k_msm_digits, dim3(cdiv(n, 256)), dim3(256), 0, st, (const Fr*)d_scalars, s, digits, hist);
-  ST_TRY(launch_check(ctx, "msm_digits"));
-  ST_TRY(device_scan(ctx, hist, (u32)nb, offsets));
-  hipLaunchKernelGGL(k_msm_scatter, dim3(cdiv(n, 256), s.W), dim3(256), 0, st, (const u32*)digits, s, (const u32*)offsets, cursor, sorted);
-  ST_TRY(launch_check(ctx, "msm_scatter"));
+  const size_t lds = (size_t)ps.nbins * 4;
+  hipLaunchKernelGGL(k_part_count, dim3(ps.nwg), dim3(256), lds, st, (const Fr*)d_scalars, s, ps, pcounts);
+  ST_TRY(launch_check(ctx, "part_count"));
+  ST_TRY(device_scan(ctx, pcounts, (u32)ncounts, poffsets));
+  hipLaunchKernelGGL(k_part_scatter, dim3(ps.nwg), dim3(256), lds, st, (const Fr*)d_scalars, s, ps, (const u32*)poffsets, entries);
+  ST_TRY(launch_check(ctx, "part_scatter"));
+  hipLaunchKernelGGL(k_part_total, dim3(1), dim3(64), 0, st, (const u32*)pcounts, (const u32*)poffsets, (u32)ncounts, poffsets + ncounts);
+  hipLaunchKernelGGL(k_part_fine, dim3(ps.nbins), dim3(256), 0, st, (const u64*)entries, (const u32*)poffsets, ps, (const u32*)(poffsets + ncounts),
+                     (u32)nb, offsets, hist, sorted);
+  ST_TRY(launch_check(ctx, "part_fine"));
   if (ctx->timing) (void)hipEventRecord(ctx->ev[1], st);
   hipLaunchKernelGGL((k_msm_accumulate<F>), dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
                      (const u32*)hist, (u32)nb, buckets);
