@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""bench_kem.py -- secondary benchmark: batched KEM encapsulations / decapsulations per second on one MI355X
+(BASELINE config 3: 2^16 BN254 pairings; the loops of reference src/vec.rs:63-66 and :75-78).
+
+    python bench_kem.py --log2n 16 --steps 3 --warmup 1
+
+One "step" = keaki_hip_encap_batch_dev over n items (2 G1 + 2 G2 scalar-mults, 1 pairing, GT serialisation,
+BLAKE3 key) with inputs resident in HBM, then keaki_hip_decap_batch_dev over the n ciphertexts (1 pairing with
+a per-item Q + KDF). Prints one JSON line per phase. The CPU leg times the oracle's restatement of the same
+loops on a bounded sample (checker only) and verifies the GPU bytes against it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from bench import random_fr_limbs, SEED  # noqa: E402
+
+ALGO_BYTES_ENCAP = 608   # 96 B in (alpha, beta, r) + 128 B ct + 384 B GT out
+ALGO_BYTES_DECAP = 576   # 64 + 128 in, 384 out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log2n", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-n", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    import torch
+    from keaki_amd.hip import KeakiHip
+    if not torch.cuda.is_available():
+        raise SystemExit("needs an MI355X (no CPU fallback)")
+    dev = torch.device("cuda", 0)
+    hip = KeakiHip(0, torch.cuda.current_stream(dev).cuda_stream)
+    n = 1 << args.log2n
+    P_MOD = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    mont = lambda v: [((v << 256) % P_MOD >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+    g1 = np.array(mont(1) + mont(2), np.uint64)
+    G2 = ((10857046999023057135944570762232829481370756359578518086990519993285655852781, 11559732032986387107991004021392285783925812861821192530917403151452391805634),
+          (8495653923123431417604973247489272438418190587263600148770280649306958101930, 4082367875863433681332203403145435568316851327593401208105741076214120093531))
+    g2 = np.array(mont(G2[0][0]) + mont(G2[0][1]) + mont(G2[1][0]) + mont(G2[1][1]), np.uint64)
+    sk = random_fr_limbs(3, SEED + 99)
+    com = hip.g1_mul_batch(g1, sk[0:1])[0]          # a commitment
+    tau_g2 = hip.g2_mul_batch(g2, sk[1:2])[0]       # [tau]_2
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
+    h_pts, h_vals, h_rs = random_fr_limbs(n, SEED + 3), random_fr_limbs(n, SEED + 4), random_fr_limbs(n, SEED + 5)
+    d_com, d_tau = T(com), T(tau_g2)
+    d_pts, d_vals, d_rs = T(h_pts), T(h_vals), T(h_rs)
+    d_ct = torch.zeros((n, 16), dtype=torch.int64, device=dev)
+    d_gt = torch.zeros((n, 48), dtype=torch.int64, device=dev)
+    d_key = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+    d_proofs = torch.empty((n, 8), dtype=torch.int64, device=dev)
+    hip.g1_mul_batch_dev(T(g1).data_ptr(), 0, d_vals.data_ptr(), n, d_proofs.data_ptr())   # some valid G1 points as "proofs"
+    d_gt2 = torch.zeros((n, 48), dtype=torch.int64, device=dev)
+    d_key2 = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)
+
+    def encap():
+        hip.encap_batch_dev(d_com.data_ptr(), d_tau.data_ptr(), d_pts.data_ptr(), d_vals.data_ptr(), d_rs.data_ptr(), n,
+                            d_ct.data_ptr(), d_gt.data_ptr(), d_key.data_ptr(), 32)
+
+    def decap():
+        hip.decap_batch_dev(d_proofs.data_ptr(), d_ct.data_ptr(), n, d_gt2.data_ptr(), d_key2.data_ptr(), 32)
+
+    out = {}
+    for name, fn, ab in (("encaps", encap, ALGO_BYTES_ENCAP), ("decaps", decap, ALGO_BYTES_DECAP)):
+        for _ in range(args.warmup):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        out[name] = {"metric": "BN254 KEM %s/sec (batch 2^%d, 1 MI355X)" % (name, args.log2n), "value": n * args.steps / el, "unit": name + "/s",
+                     "ms_per_step": el / args.steps * 1e3, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                     "roofline": {"bound": "hbm", "achieved": ab * n * args.steps / el / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                  "frac": ab * n * args.steps / el / 1e9 / 8000.0, "traffic": None}}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as oc
+        m = min(n, args.cpu_n)
+        t0 = time.perf_counter()
+        ect, egt, ekey = oc.encap_batch(com, tau_g2, h_pts[:m], h_vals[:m], h_rs[:m], 32, threads=1)
+        cpu_e = time.perf_counter() - t0
+        ok_e = (np.array_equal(d_ct[:m].cpu().numpy().view(np.uint64), ect) and np.array_equal(d_gt[:m].cpu().numpy().view(np.uint8).reshape(m, 384), egt)
+                and np.array_equal(d_key[:m].cpu().numpy(), ekey))
+        proofs = d_proofs[:m].cpu().numpy().view(np.uint64)
+        t0 = time.perf_counter()
+        dgt, dkey = oc.decap_batch(proofs, ect, 32, threads=1)
+        cpu_d = time.perf_counter() - t0
+        ok_d = np.array_equal(d_gt2[:m].cpu().numpy().view(np.uint8).reshape(m, 384), dgt) and np.array_equal(d_key2[:m].cpu().numpy(), dkey)
+        out["encaps"]["cpu_baseline"] = {"value": m / cpu_e, "unit": "encaps/s", "cores": 1, "kind": "port",
+                                         "sample": "first %d items, CPU restatement of src/kem.rs:13-50; GPU bytes bit-exact: %s" % (m, bool(ok_e))}
+        out["decaps"]["cpu_baseline"] = {"value": m / cpu_d, "unit": "decaps/s", "cores": 1, "kind": "port",
+                                         "sample": "first %d items, CPU restatement of src/kem.rs:55-72; GPU bytes bit-exact: %s" % (m, bool(ok_d))}
+    print(json.dumps(out["encaps"]))
+    print(json.dumps(out["decaps"]))
+
+
+if __name__ == "__main__":
+    main()

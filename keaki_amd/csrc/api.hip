@@ -120,7 +120,8 @@ void keaki_hip_ctx_destroy(keaki_hip_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf* b : {&ctx->digits, &ctx->hist, &ctx->offsets, &ctx->cursor, &ctx->sorted, &ctx->buckets, &ctx->partials, &ctx->wsums,
-                    &ctx->bsums, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->io_a, &ctx->io_b, &ctx->io_c, &ctx->io_d, &ctx->io_e})
+                    &ctx->bsums, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->io_a, &ctx->io_b, &ctx->io_c, &ctx->io_d, &ctx->io_e,
+                    &ctx->fb_scalars, &ctx->fb_g1_gen, &ctx->fb_g2_gen, &ctx->fb_com, &ctx->fb_tau})
     if (b->p) (void)hipFree(b->p);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -328,8 +329,31 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
   if (!gt) { ST_TRY(reserve(ctx, ctx->tmp_b, n * 384)); gt = ctx->tmp_b.p; }
   // generator g2 in device memory for the pairing's second slot (src/kem.rs:30 pairs with E::G2Affine::generator())
   ST_TRY(g2_generator_to(ctx, ctx->tmp_c.p));
-  ST_TRY(encap_g1_run(ctx, d_com_aff, d_values, d_r, n, ctx->tmp_a.p));
-  ST_TRY(encap_g2_run(ctx, d_tau_g2_aff, d_points, d_r, n, d_ct_out_aff));
+  const size_t FB = 32 * 256;
+  if (n >= 256) {
+    // fixed-base window tables (see ec_batch.cuh): generators once per context, C and [tau]_2 per batch
+    if (!ctx->fb_ready) {
+      ST_TRY(reserve(ctx, ctx->fb_scalars, FB * 32));
+      ST_TRY(reserve(ctx, ctx->fb_g1_gen, FB * G1_AFF_BYTES + G1_AFF_BYTES));
+      ST_TRY(reserve(ctx, ctx->fb_g2_gen, FB * G2_AFF_BYTES));
+      ST_TRY(reserve(ctx, ctx->fb_com, FB * G1_AFF_BYTES));
+      ST_TRY(reserve(ctx, ctx->fb_tau, FB * G2_AFF_BYTES));
+      ST_TRY(fb_table_scalars_run(ctx, ctx->fb_scalars.p));
+      void* g1pt = (char*)ctx->fb_g1_gen.p + FB * G1_AFF_BYTES;   // scratch slot behind the table
+      ST_TRY(g1_generator_to(ctx, g1pt));
+      ST_TRY(g1_fb_table_run(ctx, g1pt, ctx->fb_scalars.p, ctx->fb_g1_gen.p));
+      ST_TRY(g2_fb_table_run(ctx, ctx->tmp_c.p, ctx->fb_scalars.p, ctx->fb_g2_gen.p));
+      ctx->fb_ready = true;
+    }
+    ST_TRY(g1_fb_table_run(ctx, d_com_aff, ctx->fb_scalars.p, ctx->fb_com.p));
+    ST_TRY(g2_fb_table_run(ctx, d_tau_g2_aff, ctx->fb_scalars.p, ctx->fb_tau.p));
+    ST_TRY(encap_g1_fixed_run(ctx, ctx->fb_com.p, ctx->fb_g1_gen.p, d_values, d_r, n, ctx->tmp_a.p));
+    ST_TRY(encap_g2_fixed_run(ctx, ctx->fb_tau.p, ctx->fb_g2_gen.p, d_points, d_r, n, d_ct_out_aff));
+  } else {
+    // small batches: the ladders are cheaper than building two 8192-entry tables
+    ST_TRY(encap_g1_run(ctx, d_com_aff, d_values, d_r, n, ctx->tmp_a.p));
+    ST_TRY(encap_g2_run(ctx, d_tau_g2_aff, d_points, d_r, n, d_ct_out_aff));
+  }
   ST_TRY(pairing_run(ctx, ctx->tmp_a.p, ctx->tmp_c.p, 0, n, gt));
   if (d_key_out && msg_len) ST_TRY(blake3_gt_run(ctx, gt, n, d_key_out, msg_len));
   return KEAKI_OK;

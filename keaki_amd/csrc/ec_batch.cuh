@@ -66,4 +66,69 @@ static __global__ void __launch_bounds__(64) k_encap_g2(const G2Aff* __restrict_
   out[i] = jac_to_aff(scalar_mul(ta, rs[i]));
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fixed-base path for encapsulate. In the batch loop of src/vec.rs:63-66 every item uses the SAME
+// bases: g1, g2 (generators), C (the commitment) and [tau]_2. So
+//     r (C - beta g1)       = r C + (-(r beta)) g1          (src/kem.rs:22,30)
+//     r ([tau]_2 - alpha g2) = r [tau]_2 + (-(r alpha)) g2   (src/kem.rs:36-37)
+// are sums of two FIXED-base multiples: with 8-bit window tables T[j][d] = d 2^(8j) B (32 x 256
+// affine entries per base, built once per batch by k_mul_batch) each costs 32 mixed additions and
+// no doublings, instead of a 254-step double-and-add ladder per scalar-mult.
+// ------------------------------------------------------------------------------------------------
+constexpr u32 FB_WINDOWS = 32, FB_ENTRIES = 256;
+
+// scalars[j * 256 + d] = Montgomery(d * 2^(8j)) (0 when the value is >= r: never indexed, scalars are < r)
+static __global__ void __launch_bounds__(256) k_fb_table_scalars(Fr* __restrict__ out) {
+  u32 j = blockIdx.x, d = threadIdx.x;
+  u32 v[8];
+#pragma unroll
+  for (int t = 0; t < 8; t++) v[t] = 0;
+  u32 bit = 8 * j;
+#pragma unroll
+  for (int t = 0; t < 8; t++) if ((bit >> 5) == (u32)t) v[t] = d << (bit & 31);   // 8-bit window never straddles a word
+  // >= r ?
+  bool ge = true;
+#pragma unroll
+  for (int t = 7; t >= 0; t--) {
+    if (v[t] != FrParams::MOD[t]) { ge = v[t] > FrParams::MOD[t]; break; }
+  }
+  if (ge) {
+#pragma unroll
+    for (int t = 0; t < 8; t++) v[t] = 0;
+  }
+  out[j * FB_ENTRIES + d] = fp_to_mont<FrParams>(v);
+}
+
+// acc += T[j][byte_j(k)] for all windows; k canonical (consumed)
+template <class F>
+KDEV Xyzz<F> fb_accumulate(Xyzz<F> acc, const Aff<F>* __restrict__ table, u32* v) {
+#pragma unroll 1
+  for (u32 j = 0; j < FB_WINDOWS; j++) {
+    u32 d = v[0] & 255u;
+#pragma unroll
+    for (int t = 0; t < 7; t++) v[t] = (v[t] >> 8) | (v[t + 1] << 24);
+    v[7] >>= 8;
+    if (d) acc = xyzz_add_mixed(acc, table[j * FB_ENTRIES + d]);
+  }
+  return acc;
+}
+
+// out[i] = r_i * BaseA + (-(r_i * x_i)) * BaseB   with tables for BaseA (C or [tau]_2) and BaseB (g1 or g2)
+template <class F>
+__global__ void __launch_bounds__(64) k_encap_fixed(const Aff<F>* __restrict__ tab_a, const Aff<F>* __restrict__ tab_b,
+                                                    const Fr* __restrict__ xs, const Fr* __restrict__ rs, u32 n, Aff<F>* __restrict__ out) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr r = rs[i];
+  Fr t = fp_neg<FrParams>(fp_mul<FrParams>(r, xs[i]));
+  u32 u[8], v[8];
+  fp_from_mont<FrParams>(u, r);
+  fp_from_mont<FrParams>(v, t);
+  Xyzz<F> acc = xyzz_inf<F>();
+  acc = fb_accumulate(acc, tab_a, u);
+  acc = fb_accumulate(acc, tab_b, v);
+  out[i] = xyzz_to_aff(acc);
+}
+
 }  // namespace bn254

@@ -13,4 +13,24 @@ keaki_status encap_g1_run(keaki_hip_ctx* ctx, const void* d_com, const void* d_v
                      (G1Aff*)d_out);
   return launch_check(ctx, "encap_g1");
 }
+keaki_status fb_table_scalars_run(keaki_hip_ctx* ctx, void* d_scalars) {
+  hipLaunchKernelGGL(k_fb_table_scalars, dim3(FB_WINDOWS), dim3(FB_ENTRIES), 0, ctx->stream, (Fr*)d_scalars);
+  return launch_check(ctx, "fb_table_scalars");
+}
+keaki_status g1_generator_to(keaki_hip_ctx* ctx, void* d_dst) {
+  HIP_TRY(ctx, hipMemcpyFromSymbolAsync(d_dst, HIP_SYMBOL(G1_GEN_X), sizeof(Fq), 0, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyFromSymbolAsync((char*)d_dst + sizeof(Fq), HIP_SYMBOL(G1_GEN_Y), sizeof(Fq), 0, hipMemcpyDeviceToDevice, ctx->stream));
+  return KEAKI_OK;
+}
+// table[j*256+d] = d 2^(8j) * base   (8192 affine entries)
+keaki_status g1_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void* d_table_scalars, void* d_table) {
+  hipLaunchKernelGGL((k_mul_batch<Fq>), dim3(cdiv(FB_WINDOWS * FB_ENTRIES, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_base, 0,
+                     (const Fr*)d_table_scalars, FB_WINDOWS * FB_ENTRIES, (G1Aff*)d_table);
+  return launch_check(ctx, "g1_fb_table");
+}
+keaki_status encap_g1_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, const void* d_tab_b, const void* d_xs, const void* d_rs, size_t n, void* d_out) {
+  hipLaunchKernelGGL((k_encap_fixed<Fq>), dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_tab_a, (const G1Aff*)d_tab_b, (const Fr*)d_xs,
+                     (const Fr*)d_rs, (u32)n, (G1Aff*)d_out);
+  return launch_check(ctx, "encap_g1_fixed");
+}
 }  // namespace keaki_internal

@@ -28,6 +28,9 @@ struct keaki_hip_ctx {
   std::string err;
   // grow-only workspaces (all used in stream order)
   keaki_internal::DevBuf digits, hist, offsets, cursor, sorted, buckets, partials, wsums, bsums, tmp_a, tmp_b, tmp_c, io_a, io_b, io_c, io_d, io_e;
+  // fixed-base window tables for encapsulate: generator tables are built once per context, the C / [tau]_2 tables per batch
+  keaki_internal::DevBuf fb_scalars, fb_g1_gen, fb_g2_gen, fb_com, fb_tau;
+  bool fb_ready = false;
   // instrumentation
   bool timing = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -67,6 +70,12 @@ keaki_status encap_g2_run(keaki_hip_ctx* ctx, const void* d_tau_g2, const void* 
 keaki_status pairing_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, int g2_stride, size_t n, void* d_gt);
 keaki_status blake3_gt_run(keaki_hip_ctx* ctx, const void* d_gt, size_t n, void* d_key, size_t msg_len);
 keaki_status g2_generator_to(keaki_hip_ctx* ctx, void* d_dst);  // writes the affine G2 generator (128 B)
+keaki_status g1_generator_to(keaki_hip_ctx* ctx, void* d_dst);  // affine G1 generator (64 B)
+keaki_status fb_table_scalars_run(keaki_hip_ctx* ctx, void* d_scalars);                       // 8192 Fr: d * 2^(8j)
+keaki_status g1_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void* d_table_scalars, void* d_table);
+keaki_status g2_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void* d_table_scalars, void* d_table);
+keaki_status encap_g1_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, const void* d_tab_b, const void* d_xs, const void* d_rs, size_t n, void* d_out);
+keaki_status encap_g2_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, const void* d_tab_b, const void* d_xs, const void* d_rs, size_t n, void* d_out);
 keaki_status selftest_field_run(keaki_hip_ctx* ctx, uint32_t blocks, uint32_t iters, uint32_t seed, void* d_mismatches);
 
 }  // namespace keaki_internal

@@ -220,3 +220,26 @@ def test_field_asm_streams_selftest(hip, blocks, iters):
     (a wait-state hazard inside an asm string would show up as rare mismatches)."""
     for seed in (1, 2, 3):
         assert hip.selftest_field(blocks, iters, seed) == 0
+
+
+def test_encap_fixed_base_tables_vs_oracle(oc, py, hip, rand_fr):
+    """Batches >= 256 take the fixed-base window-table path (r C - (r beta) g1, r tau_2 - (r alpha) g2);
+    it must give exactly what the ladder path / the oracle's serial loop gives, including corner scalars."""
+    g1, g2 = oc.generators()
+    n = 320
+    tau, c0 = rand_fr(2, 61)
+    com = hip.g1_mul_batch(g1, mont(oc, [c0]))[0]
+    tau_g2 = hip.g2_mul_batch(g2, mont(oc, [tau]))[0]
+    a, v, r = rand_fr(n, 62), rand_fr(n, 63), rand_fr(n, 64)
+    a[0] = 0; v[1] = 0; r[2] = 1; r[3] = py.R - 1; a[4] = py.R - 1; v[5] = 1; r[6] = 255; r[7] = 256; r[8] = (1 << 248)
+    A, V, Rr = mont(oc, a), mont(oc, v), mont(oc, r)
+    ct, gt, key = hip.encap_batch(com, tau_g2, A, V, Rr, 32)
+    ect, egt, ekey = oc.encap_batch(com, tau_g2, A, V, Rr, 32, threads=8)
+    assert np.array_equal(ct, ect) and np.array_equal(gt, egt) and np.array_equal(key, ekey)
+    # same batch, split below the table threshold -> ladder path; results must coincide
+    ct2, gt2, key2 = hip.encap_batch(com, tau_g2, A[:100], V[:100], Rr[:100], 32)
+    assert np.array_equal(ct2, ct[:100]) and np.array_equal(gt2, gt[:100])
+    # identity commitment (C = O): r C vanishes, only the g1 table contributes
+    ct3, gt3, _ = hip.encap_batch(np.zeros(8, np.uint64), tau_g2, A[:256], V[:256], Rr[:256], 32)
+    ect3, egt3, _ = oc.encap_batch(np.zeros(8, np.uint64), tau_g2, A[:256], V[:256], Rr[:256], 32, threads=8)
+    assert np.array_equal(ct3, ect3) and np.array_equal(gt3, egt3)
