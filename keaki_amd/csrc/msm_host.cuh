@@ -86,9 +86,18 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   hipLaunchKernelGGL(k_part_fine, dim3(ps.nbins), dim3(256), 0, st, (const u64*)entries, (const u32*)poffsets, ps, (const u32*)(poffsets + ncounts),
                      (u32)nb, offsets, hist, sorted);
   ST_TRY(launch_check(ctx, "part_fine"));
+  // bucket schedule: descending size
+  ST_TRY(reserve(ctx, ctx->perm, nb * 4 + 2 * CNT_BINS * 4));
+  u32* perm = (u32*)ctx->perm.p;
+  u32 *ghist = perm + nb, *gstart = ghist + CNT_BINS;
+  HIP_TRY(ctx, hipMemsetAsync(ghist, 0, CNT_BINS * 4, st));
+  hipLaunchKernelGGL(k_cnt_hist, dim3(cdiv(nb, 1024)), dim3(256), 0, st, (const u32*)hist, (u32)nb, ghist);
+  hipLaunchKernelGGL(k_cnt_offsets, dim3(1), dim3(CNT_BINS), 0, st, (const u32*)ghist, gstart);
+  hipLaunchKernelGGL(k_cnt_scatter, dim3(cdiv(nb, 1024)), dim3(256), 0, st, (const u32*)hist, (u32)nb, gstart, perm);
+  ST_TRY(launch_check(ctx, "cnt_sort"));
   if (ctx->timing) (void)hipEventRecord(ctx->ev[1], st);
   hipLaunchKernelGGL((k_msm_accumulate<F>), dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
-                     (const u32*)hist, (u32)nb, buckets);
+                     (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
   ST_TRY(launch_check(ctx, "msm_accumulate"));
   if (ctx->timing) (void)hipEventRecord(ctx->ev[2], st);
   hipLaunchKernelGGL((k_msm_reduce<F>), dim3(cdiv((size_t)s.W * chunks, 64)), dim3(64), 0, st, (const Xyzz<F>*)buckets, s, L, chunks, partials);

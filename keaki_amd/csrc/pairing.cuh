@@ -247,7 +247,7 @@ KDEV void gt_serialize(u32* out96, const Fq12* f) {
 }
 
 // gt_out[i] = serialize(e(P_i, Q_{i*stride})); identity in either slot -> one
-__global__ void __launch_bounds__(64) k_pairing_batch(const G1Aff* __restrict__ ps, const G2Aff* __restrict__ qs, int q_stride, u32 n,
+__global__ void __launch_bounds__(64, 2) k_pairing_batch(const G1Aff* __restrict__ ps, const G2Aff* __restrict__ qs, int q_stride, u32 n,
                                                       u32* __restrict__ gt_out) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
