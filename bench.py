@@ -171,9 +171,18 @@ def main():
     windows = (254 + stats["window_bits"] - 1) // stats["window_bits"]
     # integer roofline: one XYZZ mixed add = 8M + 2S = 10 Montgomery products; measured issue rate of
     # v_mad_u64_u32 / v_add on gfx950 is 1 wave-instruction per ~4.3 cycles per SIMD (profiles/r01_ubench_int_gfx950.txt);
-    # an ideal 8x32-bit Montgomery product needs >= 136 multiply-adds + ~200 carry/reduce instructions ~ 336 issues.
-    modmul_peak = 1024 * 2.4e9 / 4.3 * 64 / 336.0
+    # the hand-scheduled 8x32-bit Montgomery product is ~300 issues (128 mad + 8 mul_lo + 127 carry counts + slide/reduce).
+    modmul_peak = 1024 * 2.4e9 / 4.3 * 64 / 300.0
     modmuls = 10.0 * n * windows / avg_bucket_s
+    # HBM traffic of the dominant kernel from PMC counters (separate rocprofv3 --pmc passes, committed under profiles/)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_msm_2p24_hbm_traffic_pmc.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("log2n") == args.log2n:
+            for kname, kv in tj["kernels"].items():
+                if "k_msm_accumulate" in kname:
+                    traffic = kv["fetch_bytes"] + kv["write_bytes"]
     result = {
         "metric": "BN254 G1 scalar-mults/sec on 2^%d-point MSM (per GPU)" % args.log2n,
         "value": value,
@@ -191,7 +200,7 @@ def main():
             args.log2n, "" if world == 1 else "; %d chunks, RCCL all-gather of 96-B partial sums + %d EC adds" % (world, world - 1)),
             "points_per_gpu": n, "window_bits": stats["window_bits"], "windows": windows, "input_gen_s": round(gen_s, 2)},
         "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<Fq>", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": ALGO_BYTES_PER_SCALAR_MUL * n,
                      "kernel_ms": avg_bucket_s * 1e3, "msm_total_ms": stats["total_ms"]},
         "alu": {"bound": "integer issue (v_mad_u64_u32)", "achieved": modmuls / 1e9, "peak": modmul_peak / 1e9, "unit": "G modmul/s",
                 "frac": modmuls / modmul_peak},
