@@ -9,6 +9,10 @@ struct keaki_hip_srs_g1 {
   const void* d = nullptr;
   size_t n = 0;
   bool owned = false;
+  // precomputed window tables (keaki_hip_srs_g1_precompute): table[w * n + i] = 2^(offset_w) * P_i
+  void* table = nullptr;
+  size_t table_bytes = 0;
+  int c_table = 0;
 };
 struct keaki_hip_srs_g2 {
   const void* d = nullptr;
@@ -168,11 +172,20 @@ keaki_status keaki_hip_srs_g1_wrap_dev(keaki_hip_ctx* ctx, const void* d_points_
 size_t keaki_hip_srs_g1_len(const keaki_hip_srs_g1* srs) { return srs ? srs->n : 0; }
 void keaki_hip_srs_g1_free(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs) {
   if (!srs) return;
-  if (srs->owned && srs->d) {
-    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
-    (void)hipFree((void*)srs->d);
-  }
+  if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+  if (srs->owned && srs->d) (void)hipFree((void*)srs->d);
+  if (srs->table) (void)hipFree(srs->table);
   delete srs;
+}
+keaki_status keaki_hip_srs_g1_precompute(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, size_t* table_bytes_out) {
+  CTX_GUARD(ctx);
+  if (!srs) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g1_precompute: srs is null");
+  if (!srs->table && srs->n) {
+    ST_TRY(msm_g1_precompute_run(ctx, srs->d, srs->n, &srs->c_table, &srs->table_bytes, &srs->table));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (table_bytes_out) *table_bytes_out = srs->table_bytes;
+  return KEAKI_OK;
 }
 keaki_status keaki_hip_srs_g2_upload(keaki_hip_ctx* ctx, const uint64_t* points_aff, size_t n, keaki_hip_srs_g2** out) {
   CTX_GUARD(ctx);
@@ -205,7 +218,7 @@ void keaki_hip_srs_g2_free(keaki_hip_ctx* ctx, keaki_hip_srs_g2* srs) {
 keaki_status keaki_hip_msm_g1_dev(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, const void* d_scalars, size_t n, void* d_out_jac) {
   CTX_GUARD(ctx);
   if (!srs) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm_g1: srs is null");
-  return msm_g1_run(ctx, srs->d, srs->n, d_scalars, n, d_out_jac);
+  return msm_g1_run(ctx, srs->d, srs->n, d_scalars, n, d_out_jac, srs->table, srs->c_table);
 }
 keaki_status keaki_hip_msm_g1(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, const uint64_t* scalars, size_t n, uint64_t* out_jac) {
   CTX_GUARD(ctx);
@@ -213,7 +226,7 @@ keaki_status keaki_hip_msm_g1(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, c
   if (n > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", n, srs->n);
   ST_TRY(upload(ctx, ctx->io_a, scalars, n * 32));
   ST_TRY(reserve(ctx, ctx->io_b, 96));
-  ST_TRY(msm_g1_run(ctx, srs->d, srs->n, ctx->io_a.p, n, ctx->io_b.p));
+  ST_TRY(msm_g1_run(ctx, srs->d, srs->n, ctx->io_a.p, n, ctx->io_b.p, srs->table, srs->c_table));
   ST_TRY(download(ctx, out_jac, ctx->io_b.p, 96));
   resolve_timing(ctx);
   return KEAKI_OK;

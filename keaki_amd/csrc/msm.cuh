@@ -33,6 +33,9 @@ struct MsmShape {
   u32 c;   // width of the wide windows
   u32 W;   // number of windows
   u32 k;   // number of wide windows
+  u32 stride;  // 0: every window has its own bucket range and reads point i.
+               // N > 0 (precomputed SRS): all windows SHARE one bucket range and window w reads point
+               // table[w * N + i] = 2^(bit offset of w) * P_i, so no per-window reduction / Horner step is left.
 };
 KDEV u32 msm_width(const MsmShape& s, u32 w) { return w < s.k ? s.c : s.c - 1; }
 KDEV u32 msm_bit_offset(const MsmShape& s, u32 w) { return w < s.k ? w * s.c : s.k * s.c + (w - s.k) * (s.c - 1); }
@@ -52,6 +55,7 @@ inline MsmPlan msm_make_plan(size_t n, int c_target) {
   u32 base = 254 / W, rem = 254 % W;
   p.s.n = (u32)n;
   p.s.W = W;
+  p.s.stride = 0;
   if (rem == 0) { p.s.c = base; p.s.k = W; } else { p.s.c = base + 1; p.s.k = rem; }
   size_t nb = 0; u32 mb = 0;
   for (u32 w = 0; w < W; w++) {
@@ -117,7 +121,7 @@ static __global__ void __launch_bounds__(256) k_part_count(const Fr* __restrict_
     u32 i = base + t;
     if (i < s.n) {
       msm_for_each_digit(scalars[i], s, [&](u32 w, u32 code) {
-        u32 g = msm_bucket_base(s, w) + (code & 0x7FFFFFFFu);
+        u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
         atomicAdd(&lds_hist[g >> PART_SHIFT], 1u);
       });
     }
@@ -136,9 +140,9 @@ static __global__ void __launch_bounds__(256) k_part_scatter(const Fr* __restric
     u32 i = base + t;
     if (i < s.n) {
       msm_for_each_digit(scalars[i], s, [&](u32 w, u32 code) {
-        u32 g = msm_bucket_base(s, w) + (code & 0x7FFFFFFFu);
+        u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
         u32 pos = atomicAdd(&lds_cur[g >> PART_SHIFT], 1u);
-        entries[pos] = ((u64)(g & (PART_FINE - 1)) << 32) | (code & 0x80000000u) | i;
+        entries[pos] = ((u64)(g & (PART_FINE - 1)) << 32) | (code & 0x80000000u) | (i + w * s.stride);
       });
     }
   }
@@ -148,23 +152,24 @@ static __global__ void k_part_total(const u32* __restrict__ counts, const u32* _
   if (threadIdx.x == 0 && blockIdx.x == 0) *total = offsets[ncounts - 1] + counts[ncounts - 1];
 }
 // pass 2: one workgroup per coarse bin. bin b covers global buckets [b * PART_FINE, (b+1) * PART_FINE).
-static __global__ void __launch_bounds__(256) k_part_fine(const u64* __restrict__ entries, const u32* __restrict__ offsets, PartShape ps,
-                                                          const u32* __restrict__ total_ptr, u32 nbuckets_total, u32* __restrict__ bucket_offsets,
-                                                          u32* __restrict__ bucket_counts, u32* __restrict__ sorted) {
+constexpr u32 PF_THREADS = 1024, PF_PER = PART_FINE / PF_THREADS;
+static __global__ void __launch_bounds__(PF_THREADS) k_part_fine(const u64* __restrict__ entries, const u32* __restrict__ offsets, PartShape ps,
+                                                                 const u32* __restrict__ total_ptr, u32 nbuckets_total, u32* __restrict__ bucket_offsets,
+                                                                 u32* __restrict__ bucket_counts, u32* __restrict__ sorted) {
   __shared__ u32 hist[PART_FINE];
-  __shared__ u32 wsum[4];
+  __shared__ u32 wsum[PF_THREADS / 64];
   const u32 bin = blockIdx.x;
   const u32 lo = offsets[(size_t)bin * ps.nwg];
   const u32 hi = (bin + 1 < ps.nbins) ? offsets[(size_t)(bin + 1) * ps.nwg] : *total_ptr;
-  for (u32 f = threadIdx.x; f < PART_FINE; f += 256) hist[f] = 0;
+  for (u32 f = threadIdx.x; f < PART_FINE; f += PF_THREADS) hist[f] = 0;
   __syncthreads();
-  for (u32 e = lo + threadIdx.x; e < hi; e += 256) atomicAdd(&hist[(u32)(entries[e] >> 32)], 1u);
+  for (u32 e = lo + threadIdx.x; e < hi; e += PF_THREADS) atomicAdd(&hist[(u32)(entries[e] >> 32)], 1u);
   __syncthreads();
-  // exclusive scan of hist (PART_FINE counters, 16 per thread), in place; counts kept in registers
-  u32 cnt[PART_FINE / 256];
+  // exclusive scan of hist (PF_PER counters per thread), in place; counts kept in registers
+  u32 cnt[PF_PER];
   u32 sum = 0;
 #pragma unroll
-  for (u32 k = 0; k < PART_FINE / 256; k++) { cnt[k] = hist[threadIdx.x * (PART_FINE / 256) + k]; sum += cnt[k]; }
+  for (u32 k = 0; k < PF_PER; k++) { cnt[k] = hist[threadIdx.x * PF_PER + k]; sum += cnt[k]; }
   u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6, x = sum;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { u32 y = __shfl_up(x, o, 64); if (lane >= (u32)o) x += y; }
@@ -174,15 +179,15 @@ static __global__ void __launch_bounds__(256) k_part_fine(const u64* __restrict_
   for (u32 k = 0; k < wid; k++) wbase += wsum[k];
   u32 ex = lo + wbase + x - sum;
 #pragma unroll
-  for (u32 k = 0; k < PART_FINE / 256; k++) {
-    u32 f = threadIdx.x * (PART_FINE / 256) + k;
+  for (u32 k = 0; k < PF_PER; k++) {
+    u32 f = threadIdx.x * PF_PER + k;
     u32 g = bin * PART_FINE + f;
     hist[f] = ex;                      // becomes the running cursor of bucket f
     if (g < nbuckets_total) { bucket_offsets[g] = ex; bucket_counts[g] = cnt[k]; }
     ex += cnt[k];
   }
   __syncthreads();
-  for (u32 e = lo + threadIdx.x; e < hi; e += 256) {
+  for (u32 e = lo + threadIdx.x; e < hi; e += PF_THREADS) {
     u64 v = entries[e];
     u32 pos = atomicAdd(&hist[(u32)(v >> 32)], 1u);
     sorted[pos] = (u32)v;
@@ -368,6 +373,23 @@ __global__ void __launch_bounds__(64) k_msm_reduce(const Xyzz<F>* __restrict__ b
   partials[g] = ws;
 }
 
+// ---- K5b: sum groups of G consecutive chunk partials of each window (keeps K6a's serial part short) -------------
+template <class F>
+__global__ void __launch_bounds__(64) k_msm_partial_groups(const Xyzz<F>* __restrict__ in, u32 chunks_in, u32 G, u32 chunks_out,
+                                                           Xyzz<F>* __restrict__ out) {
+  __shared__ Xyzz<F> sh[64];
+  u32 w = blockIdx.y, x = blockIdx.x, l = threadIdx.x;
+  Xyzz<F> acc = xyzz_inf<F>();
+  for (u32 t = x * G + l; t < (x + 1) * G && t < chunks_in; t += 64) acc = xyzz_add(acc, in[(size_t)w * chunks_in + t]);
+  sh[l] = acc;
+  __syncthreads();
+  for (u32 o = 32; o > 0; o >>= 1) {
+    if (l < o) sh[l] = xyzz_add(sh[l], sh[l + o]);
+    __syncthreads();
+  }
+  if (l == 0) out[(size_t)w * chunks_out + x] = sh[0];
+}
+
 // ---- K6a: sum the chunk partials of each window, then scale by 2^(w c) ---------------------------------
 template <class F>
 __global__ void __launch_bounds__(64) k_msm_window_finish(const Xyzz<F>* __restrict__ partials, MsmShape s, u32 chunks_per_window,
@@ -406,6 +428,25 @@ __global__ void __launch_bounds__(64) k_msm_final(const Xyzz<F>* __restrict__ wi
   Xyzz<F> acc = xyzz_inf<F>();
   for (u32 w = 0; w < W; w++) acc = xyzz_add(acc, window_sums[w]);
   store_norm_jac(out_jac, acc);
+}
+
+
+// ---- precomputed window tables (one-time, at SRS upload) ------------------------------------------------------
+// table[w * N + i] = 2^(bit offset of window w) * P_i, affine. Lane i walks the windows, doubling
+// width(w-1) times between them (Jacobian) and normalising each multiple (one inversion each).
+template <class F>
+__global__ void __launch_bounds__(64) k_msm_build_tables(const Aff<F>* __restrict__ points, u32 N, MsmShape s, Aff<F>* __restrict__ table) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  Aff<F> p = points[i];
+  table[i] = p;
+#pragma unroll 1
+  for (u32 w = 1; w < s.W; w++) {
+    Jac<F> j = jac_from_aff(p);
+    for (u32 d = msm_width(s, w - 1); d > 0; d--) j = jac_dbl(j);
+    p = jac_to_aff(j);
+    table[(size_t)w * N + i] = p;
+  }
 }
 
 // ---- sum of k normalised-Jacobian points (multi-GPU partial combine) -------------------------------------

@@ -37,19 +37,33 @@ inline keaki_status device_scan(keaki_hip_ctx* ctx, const u32* in, u32 len, u32*
   return launch_check(ctx, "scan");
 }
 
+// d_table != nullptr: precomputed path (tables built by msm_build_tables with window target c_table for N = srs_len points)
 template <class F>
-keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len, const void* d_scalars, size_t n, void* d_out_jac) {
+keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len, const void* d_scalars, size_t n, void* d_out_jac,
+                     const Aff<F>* d_table = nullptr, int c_table = 0) {
   if (!d_out_jac || (n && (!d_points || !d_scalars))) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: null pointer");
   if (n > srs_len) return fail(ctx, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", n, srs_len);
   if (n >= (1ull << 31)) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: n must be < 2^31 per device");
-  const MsmPlan plan = msm_make_plan(n, choose_window(n));
-  const MsmShape s = plan.s;
+  const bool shared = d_table != nullptr && n * 2 > srs_len;   // short polynomials: the generic path with its own window size is faster
+  const MsmPlan plan = shared ? msm_make_plan(n, c_table) : msm_make_plan(n, choose_window(n));
+  MsmShape s = plan.s;
+  // reduction shape: generic = the plan itself; shared = ONE window holding max_b = 2^cr buckets (top-window rule: 2^width buckets)
+  MsmShape rs = s;
+  size_t nb = plan.nb;
+  if (shared) {
+    s.stride = (u32)srs_len;
+    u32 cr = 0;
+    while ((1u << cr) < plan.max_b) cr++;
+    rs.n = s.n; rs.c = cr; rs.W = 1; rs.k = 1; rs.stride = 0;
+    nb = plan.max_b;
+    d_points = d_table;
+    if ((double)srs_len * s.W >= 2147483647.0) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: precomputed table index overflows 31 bits");
+  }
   ctx->last_c = (int)s.c;
-  const size_t nb = plan.nb;
   if ((double)n * s.W >= 4294967295.0) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: n * windows overflows 32-bit positions");
   const u32 L = plan.max_b >= 4096 ? 64 : (plan.max_b >= 64 ? 16 : plan.max_b);  // reduce chunk length
   const u32 chunks = cdiv(plan.max_b, L);
-  ST_TRY(reserve(ctx, ctx->wsums, (size_t)s.W * sizeof(Xyzz<F>)));
+  ST_TRY(reserve(ctx, ctx->wsums, (size_t)rs.W * sizeof(Xyzz<F>)));
   Xyzz<F>* wsums = (Xyzz<F>*)ctx->wsums.p;
   F* out = (F*)d_out_jac;
   hipStream_t st = ctx->stream;
@@ -70,7 +84,7 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   ST_TRY(reserve(ctx, ctx->offsets, nb * 4));          // per-bucket start offsets
   ST_TRY(reserve(ctx, ctx->cursor, (ncounts * 2 + 4) * 4));  // [counts | exclusive scan] of the (bin, workgroup) table
   ST_TRY(reserve(ctx, ctx->buckets, nb * sizeof(Xyzz<F>)));
-  ST_TRY(reserve(ctx, ctx->partials, (size_t)s.W * chunks * sizeof(Xyzz<F>)));
+  ST_TRY(reserve(ctx, ctx->partials, ((size_t)rs.W * chunks + (size_t)rs.W * 256) * sizeof(Xyzz<F>)));
   u64* entries = (u64*)ctx->digits.p;
   u32 *sorted = (u32*)ctx->sorted.p, *hist = (u32*)ctx->hist.p, *offsets = (u32*)ctx->offsets.p;
   u32 *pcounts = (u32*)ctx->cursor.p, *poffsets = pcounts + ncounts;
@@ -83,7 +97,7 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   hipLaunchKernelGGL(k_part_scatter, dim3(ps.nwg), dim3(256), lds, st, (const Fr*)d_scalars, s, ps, (const u32*)poffsets, entries);
   ST_TRY(launch_check(ctx, "part_scatter"));
   hipLaunchKernelGGL(k_part_total, dim3(1), dim3(64), 0, st, (const u32*)pcounts, (const u32*)poffsets, (u32)ncounts, poffsets + ncounts);
-  hipLaunchKernelGGL(k_part_fine, dim3(ps.nbins), dim3(256), 0, st, (const u64*)entries, (const u32*)poffsets, ps, (const u32*)(poffsets + ncounts),
+  hipLaunchKernelGGL(k_part_fine, dim3(ps.nbins), dim3(PF_THREADS), 0, st, (const u64*)entries, (const u32*)poffsets, ps, (const u32*)(poffsets + ncounts),
                      (u32)nb, offsets, hist, sorted);
   ST_TRY(launch_check(ctx, "part_fine"));
   // bucket schedule: descending size
@@ -100,9 +114,19 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
                      (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
   ST_TRY(launch_check(ctx, "msm_accumulate"));
   if (ctx->timing) (void)hipEventRecord(ctx->ev[2], st);
-  hipLaunchKernelGGL((k_msm_reduce<F>), dim3(cdiv((size_t)s.W * chunks, 64)), dim3(64), 0, st, (const Xyzz<F>*)buckets, s, L, chunks, partials);
-  hipLaunchKernelGGL((k_msm_window_finish<F>), dim3(s.W), dim3(64), 0, st, (const Xyzz<F>*)partials, s, chunks, wsums);
-  hipLaunchKernelGGL((k_msm_final<F>), dim3(1), dim3(64), 0, st, (const Xyzz<F>*)wsums, s.W, out);
+  hipLaunchKernelGGL((k_msm_reduce<F>), dim3(cdiv((size_t)rs.W * chunks, 64)), dim3(64), 0, st, (const Xyzz<F>*)buckets, rs, L, chunks, partials);
+  // chunk partials -> (at most 128 per window) -> window sums
+  const Xyzz<F>* fin_in = partials;
+  u32 fin_chunks = chunks;
+  if (chunks > 256) {
+    const u32 G = cdiv(chunks, 128);
+    const u32 chunks2 = cdiv(chunks, G);
+    Xyzz<F>* partials2 = partials + (size_t)rs.W * chunks;
+    hipLaunchKernelGGL((k_msm_partial_groups<F>), dim3(chunks2, rs.W), dim3(64), 0, st, (const Xyzz<F>*)partials, chunks, G, chunks2, partials2);
+    fin_in = partials2; fin_chunks = chunks2;
+  }
+  hipLaunchKernelGGL((k_msm_window_finish<F>), dim3(rs.W), dim3(64), 0, st, fin_in, rs, fin_chunks, wsums);
+  hipLaunchKernelGGL((k_msm_final<F>), dim3(1), dim3(64), 0, st, (const Xyzz<F>*)wsums, rs.W, out);
   ST_TRY(launch_check(ctx, "msm_reduce/final"));
   if (ctx->timing) {
     (void)hipEventRecord(ctx->ev[3], st);
@@ -110,5 +134,31 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   }
   return KEAKI_OK;
 }
+
+// one-time table build for the precomputed path
+template <class F>
+keaki_status msm_build_tables(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t N, int c_table, Aff<F>* d_table) {
+  MsmPlan plan = msm_make_plan(N, c_table);
+  hipLaunchKernelGGL((k_msm_build_tables<F>), dim3(cdiv(N, 64)), dim3(64), 0, ctx->stream, d_points, (u32)N, plan.s, d_table);
+  return launch_check(ctx, "msm_build_tables");
+}
+// window target for the shared-bucket (precomputed) path: adds = n * W(c); bucket reduction ~ 2.8 * max_b once
+inline int choose_window_shared(size_t n) {
+  if (const char* e = getenv("KEAKI_MSM_C_SHARED")) {
+    int c = atoi(e);
+    if (c >= 3 && c <= 24) return c;
+  }
+  double best = 1e300;
+  int bc = 8;
+  for (int c = 8; c <= 23; c++) {
+    MsmPlan p = msm_make_plan(n, c);
+    if ((p.max_b >> PART_SHIFT) > PART_MAX_BINS) continue;
+    double cost = (double)n * p.s.W + 2.8 * (double)p.max_b;
+    if ((double)p.max_b < 131072.0) cost *= 131072.0 / (double)p.max_b;
+    if (cost < best) { best = cost; bc = c; }
+  }
+  return bc;
+}
+inline u32 msm_plan_windows(size_t n, int c) { return msm_make_plan(n, c).s.W; }
 
 }  // namespace keaki_internal
