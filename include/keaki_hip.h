@@ -67,6 +67,11 @@ keaki_status keaki_hip_srs_g1_upload(keaki_hip_ctx* ctx, const uint64_t* points_
 /* wraps caller-owned device memory holding n affine points (not freed by _free) */
 keaki_status keaki_hip_srs_g1_wrap_dev(keaki_hip_ctx* ctx, const void* d_points_aff, size_t n, keaki_hip_srs_g1** out);
 size_t keaki_hip_srs_g1_len(const keaki_hip_srs_g1* srs);
+/* One-time precomputation for a fixed SRS (KZG bases never change): builds the window tables
+ * table[w][i] = 2^(bit offset of window w) * P_i (affine, W x n x 64 bytes of HBM; W = 12..14 for n >= 2^20) so that all
+ * windows of an MSM share ONE bucket set and the per-window reduction / Horner doublings disappear. Later
+ * keaki_hip_msm_g1* calls on this handle with n > len/2 use the tables; results are identical. Optional. */
+keaki_status keaki_hip_srs_g1_precompute(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, size_t* table_bytes_out);
 void keaki_hip_srs_g1_free(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs);
 keaki_status keaki_hip_srs_g2_upload(keaki_hip_ctx* ctx, const uint64_t* points_aff, size_t n, keaki_hip_srs_g2** out);
 keaki_status keaki_hip_srs_g2_wrap_dev(keaki_hip_ctx* ctx, const void* d_points_aff, size_t n, keaki_hip_srs_g2** out);

@@ -134,6 +134,9 @@ KZGSetup KZGSetup::from_powers(std::shared_ptr<Device> dev, std::vector<G1> g1_a
   s.g1_aff_ = std::move(g1_aff);
   s.tau_g2_ = tau_g2;
   s.dev_->check(keaki_hip_srs_g1_upload(s.dev_->ctx(), s.g1_aff_.empty() ? nullptr : s.g1_aff_[0].w.data(), s.g1_aff_.size(), &s.srs_));
+  // The SRS never changes after setup: for production-size setups tabulate [2^(window offset)] tau^i G1 once so that
+  // every later commit/open runs the shared-bucket MSM (W x the SRS in HBM; skipped for toy sizes).
+  if (s.g1_aff_.size() >= (size_t(1) << 16)) s.dev_->check(keaki_hip_srs_g1_precompute(s.dev_->ctx(), s.srs_, nullptr));
   return s;
 }
 

@@ -243,3 +243,27 @@ def test_encap_fixed_base_tables_vs_oracle(oc, py, hip, rand_fr):
     ct3, gt3, _ = hip.encap_batch(np.zeros(8, np.uint64), tau_g2, A[:256], V[:256], Rr[:256], 32)
     ect3, egt3, _ = oc.encap_batch(np.zeros(8, np.uint64), tau_g2, A[:256], V[:256], Rr[:256], 32, threads=8)
     assert np.array_equal(ct3, ect3) and np.array_equal(gt3, egt3)
+
+
+@pytest.mark.parametrize("N", [300, 5000, 1 << 15])
+def test_msm_precomputed_tables(oc, hip, rand_fr, N):
+    """keaki_hip_srs_g1_precompute: shared-bucket path over the window tables gives the same group element as the
+    generic path and the oracle, for full-length and shorter polynomials (zip-truncation) and corner scalars."""
+    _, pts = make_points_g1(oc, hip, N, 900 + N)
+    ints = rand_fr(N, 901 + N)
+    ints[0] = 0; ints[1] = oc.R_MOD - 1; ints[2] = 1; ints[3] = (1 << 253) + 12345; ints[4] = (1 << 200) - 1
+    pts[5] = 0
+    sc = mont(oc, ints)
+    srs = hip.srs_g1_upload(pts)
+    try:
+        plain = jac_to_aff(hip.msm_g1(srs, sc))
+        nbytes = hip.srs_g1_precompute(srs)
+        assert nbytes >= N * 64 * 2
+        for n in (N, N - 1, N // 2 + 1, N // 2, 7):
+            got = jac_to_aff(hip.msm_g1(srs, sc[:n]))
+            assert np.array_equal(got, oc.msm_g1(pts[:n], sc[:n], threads=8)), n
+        assert np.array_equal(jac_to_aff(hip.msm_g1(srs, sc)), plain)
+        z = hip.msm_g1(srs, np.zeros((N, 4), np.uint64))
+        assert not np.any(jac_to_aff(z))
+    finally:
+        srs.free()
