@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--log2n", type=int, default=24, help="log2 of (scalar, point) pairs PER GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="skip the one-time SRS window-table build (generic per-window bucket path)")
-    ap.add_argument("--cpu-log2n", type=int, default=18, help="log2 of the CPU-baseline sample size")
+    ap.add_argument("--cpu-log2n", type=int, default=20, help="log2 of the CPU-baseline sample size")
     args = ap.parse_args()
 
     import torch
