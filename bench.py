@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log2n", type=int, default=24, help="log2 of (scalar, point) pairs PER GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kem-log2n", type=int, default=16, help="log2 of the KEM batch per GPU (second half of the BASELINE metric); 0 disables")
     ap.add_argument("--no-precompute", action="store_true", help="skip the one-time SRS window-table build (generic per-window bucket path)")
     ap.add_argument("--cpu-log2n", type=int, default=20, help="log2 of the CPU-baseline sample size")
     args = ap.parse_args()
@@ -167,6 +168,58 @@ def main():
         elapsed = float(te.item())
     stats = hip.last_msm_stats()
 
+    # ---- second half of the BASELINE metric: batched KEM encapsulations / decapsulations per second -------------------
+    # Items are independent: each rank processes its own batch, no data-path collective (src/vec.rs:63-66, :75-78).
+    kem = None
+    if args.kem_log2n > 0:
+        m = 1 << args.kem_log2n
+        h_a, h_v, h_r = (random_fr_limbs(m, SEED + 31 + 3 * rank), random_fr_limbs(m, SEED + 37 + 5 * rank), random_fr_limbs(m, SEED + 41 + 7 * rank))
+        d_a, d_v, d_r = (torch.from_numpy(x.view(np.int64)).to(dev) for x in (h_a, h_v, h_r))
+        g2_words = []
+        for c in (10857046999023057135944570762232829481370756359578518086990519993285655852781,
+                  11559732032986387107991004021392285783925812861821192530917403151452391805634,
+                  8495653923123431417604973247489272438418190587263600148770280649306958101930,
+                  4082367875863433681332203403145435568316851327593401208105741076214120093531):
+            cm = (c << 256) % 21888242871839275222246405745257275088696311157297823662689037894645226208583
+            g2_words += [(cm >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+        d_g2 = torch.from_numpy(np.array(g2_words, np.uint64).view(np.int64)).to(dev)
+        d_tau = torch.empty(16, dtype=torch.int64, device=dev)
+        hip.g2_mul_batch_dev(d_g2.data_ptr(), 0, d_k.data_ptr(), 1, d_tau.data_ptr())        # [tau]_2 = k_0 * g2
+        d_com = d_pts[0].contiguous()                                                         # a commitment: any G1 point
+        d_ct = torch.empty((m, 16), dtype=torch.int64, device=dev)
+        d_gt = torch.empty((m, 48), dtype=torch.int64, device=dev)
+        d_key = torch.empty((m, 32), dtype=torch.uint8, device=dev)
+        d_gt2 = torch.empty((m, 48), dtype=torch.int64, device=dev)
+        d_key2 = torch.empty((m, 32), dtype=torch.uint8, device=dev)
+
+        def encap():
+            hip.encap_batch_dev(d_com.data_ptr(), d_tau.data_ptr(), d_a.data_ptr(), d_v.data_ptr(), d_r.data_ptr(), m,
+                                d_ct.data_ptr(), d_gt.data_ptr(), d_key.data_ptr(), 32)
+
+        def decap():
+            hip.decap_batch_dev(d_pts.data_ptr(), d_ct.data_ptr(), m, d_gt2.data_ptr(), d_key2.data_ptr(), 32)   # first m SRS points as "proofs"
+
+        rates = []
+        for fn in (encap, decap):
+            fn()
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+            if world > 1:
+                te = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(te, op=dist.ReduceOp.MAX)
+                el = float(te.item())
+            rates.append(2 * m * world / el)
+        kem = {"encaps_per_s": rates[0], "decaps_per_s": rates[1], "batch_per_gpu": m, "msg_len": 32,
+               "note": "whole-job aggregate over all ranks; items sharded by rank, no collective",
+               "algorithmic_bytes_per_encap": 608, "algorithmic_bytes_per_decap": 576}
+        kem_check = (h_a, h_v, h_r, d_com, d_tau, d_ct, d_gt, d_key, d_gt2, d_key2)
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -211,6 +264,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<Fq>", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": ALGO_BYTES_PER_SCALAR_MUL * n,
                      "kernel_ms": avg_bucket_s * 1e3, "msm_total_ms": stats["total_ms"]},
+        "kem": kem,
         "alu": {"bound": "integer issue (v_mad_u64_u32)", "achieved": modmuls / 1e9, "peak": modmul_peak / 1e9, "unit": "G modmul/s",
                 "frac": modmuls / modmul_peak},
     }
@@ -248,6 +302,21 @@ def main():
                       "GPU result on the same sample bit-exact: %s" % (int(np.log2(ns)), bool(np.array_equal(got, ref))),
             "all_cores": {"value": nall / cpu_all_s, "cores": ncores, "sample": "first 2^%d pairs, windows spread over threads" % int(np.log2(nall))},
         }
+        if kem is not None:
+            h_a, h_v, h_r, d_com, d_tau, d_ct, d_gt, d_key, d_gt2, d_key2 = kem_check
+            mc = 32
+            com_h, tau_h = d_com.cpu().numpy().view(np.uint64), d_tau.cpu().numpy().view(np.uint64)
+            t0 = time.perf_counter()
+            ect, egt, ekey = oc.encap_batch(com_h, tau_h, h_a[:mc], h_v[:mc], h_r[:mc], 32, threads=1)
+            ce = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            dgt, dkey = oc.decap_batch(d_pts[:mc].cpu().numpy().view(np.uint64), ect, 32, threads=1)
+            cd = time.perf_counter() - t0
+            ok = (np.array_equal(d_ct[:mc].cpu().numpy().view(np.uint64), ect) and np.array_equal(d_key[:mc].cpu().numpy(), ekey)
+                  and np.array_equal(d_gt[:mc].cpu().numpy().view(np.uint8).reshape(mc, 384), egt)
+                  and np.array_equal(d_gt2[:mc].cpu().numpy().view(np.uint8).reshape(mc, 384), dgt) and np.array_equal(d_key2[:mc].cpu().numpy(), dkey))
+            kem["cpu_baseline"] = {"encaps_per_s": mc / ce, "decaps_per_s": mc / cd, "cores": 1, "kind": "port",
+                                   "sample": "first %d items, CPU restatement of src/kem.rs:13-72; GPU ct/GT/key bytes bit-exact: %s" % (mc, bool(ok))}
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
