@@ -18,6 +18,11 @@
 namespace bn254 {
 
 #define KNOINLINE __device__ __noinline__
+#ifdef KEAKI_PAIRING_INLINE_TOWER
+#define KTOWER __device__ __forceinline__
+#else
+#define KTOWER __device__ __noinline__
+#endif
 
 struct Fq6 { Fq2 c0, c1, c2; };
 struct Fq12 { Fq6 c0, c1; };
@@ -36,7 +41,7 @@ KDEV Fq6 operator-(const Fq6& a) { return {-a.c0, -a.c1, -a.c2}; }
 KDEV Fq6 fq6_mul_v(const Fq6& a) { return {fq2_mul_xi(a.c2), a.c0, a.c1}; }
 KDEV Fq6 fq6_zero() { return {fq2_zero(), fq2_zero(), fq2_zero()}; }
 
-static KNOINLINE void fq6_mul(Fq6* r, const Fq6* a, const Fq6* b) {
+static KTOWER void fq6_mul(Fq6* r, const Fq6* a, const Fq6* b) {
   Fq2 v0 = M2(a->c0, b->c0), v1 = M2(a->c1, b->c1), v2 = M2(a->c2, b->c2);
   Fq2 t0 = fq2_mul_xi(M2(a->c1 + a->c2, b->c1 + b->c2) - v1 - v2) + v0;
   Fq2 t1 = M2(a->c0 + a->c1, b->c0 + b->c1) - v0 - v1 + fq2_mul_xi(v2);
@@ -44,14 +49,14 @@ static KNOINLINE void fq6_mul(Fq6* r, const Fq6* a, const Fq6* b) {
   r->c0 = t0; r->c1 = t1; r->c2 = t2;
 }
 // a * (c0 + c1 v)
-static KNOINLINE void fq6_mul_by_01(Fq6* r, const Fq6* a, const Fq2* c0, const Fq2* c1) {
+static KTOWER void fq6_mul_by_01(Fq6* r, const Fq6* a, const Fq2* c0, const Fq2* c1) {
   Fq2 aa = M2(a->c0, *c0), bb = M2(a->c1, *c1);
   Fq2 t1 = fq2_mul_xi(M2(*c1, a->c1 + a->c2) - bb) + aa;
   Fq2 t3 = M2(*c0, a->c0 + a->c2) - aa + bb;
   Fq2 t2 = M2(*c0 + *c1, a->c0 + a->c1) - aa - bb;
   r->c0 = t1; r->c1 = t2; r->c2 = t3;
 }
-static KNOINLINE void fq6_inv(Fq6* r, const Fq6* a) {
+static KTOWER void fq6_inv(Fq6* r, const Fq6* a) {
   Fq2 t0 = S2(a->c0) - fq2_mul_xi(M2(a->c1, a->c2));
   Fq2 t1 = fq2_mul_xi(S2(a->c2)) - M2(a->c0, a->c1);
   Fq2 t2 = S2(a->c1) - M2(a->c0, a->c2);
@@ -64,7 +69,7 @@ KDEV void fq12_set_one(Fq12* f) {
   f->c0 = fq6_zero(); f->c1 = fq6_zero();
   f->c0.c0.c0 = fq_one();
 }
-static KNOINLINE void fq12_mul(Fq12* r, const Fq12* a, const Fq12* b) {
+static KTOWER void fq12_mul(Fq12* r, const Fq12* a, const Fq12* b) {
   Fq6 t0, t1, m, s0 = a->c0 + a->c1, s1 = b->c0 + b->c1;
   fq6_mul(&t0, &a->c0, &b->c0);
   fq6_mul(&t1, &a->c1, &b->c1);
@@ -72,7 +77,7 @@ static KNOINLINE void fq12_mul(Fq12* r, const Fq12* a, const Fq12* b) {
   r->c1 = m - t0 - t1;
   r->c0 = t0 + fq6_mul_v(t1);
 }
-static KNOINLINE void fq12_sqr(Fq12* r, const Fq12* a) {  // complex squaring: 2 Fq6 products
+static KTOWER void fq12_sqr(Fq12* r, const Fq12* a) {  // complex squaring: 2 Fq6 products
   Fq6 ab, s0 = a->c0 + a->c1, s1 = a->c0 + fq6_mul_v(a->c1), t;
   fq6_mul(&ab, &a->c0, &a->c1);
   fq6_mul(&t, &s0, &s1);
@@ -80,7 +85,7 @@ static KNOINLINE void fq12_sqr(Fq12* r, const Fq12* a) {  // complex squaring: 2
   r->c1 = ab + ab;
 }
 KDEV void fq12_conj(Fq12* r, const Fq12* a) { r->c0 = a->c0; r->c1 = -a->c1; }
-static KNOINLINE void fq12_inv(Fq12* r, const Fq12* a) {
+static KTOWER void fq12_inv(Fq12* r, const Fq12* a) {
   Fq6 n, t, ni;
   fq6_mul(&n, &a->c0, &a->c0);
   fq6_mul(&t, &a->c1, &a->c1);
@@ -91,7 +96,7 @@ static KNOINLINE void fq12_inv(Fq12* r, const Fq12* a) {
   r->c1 = -t;
 }
 // f *= c0 + (d0 + d1 v) w   (13 Fq2 products instead of 18)
-static KNOINLINE void fq12_mul_by_034(Fq12* f, const Fq2* c0, const Fq2* d0, const Fq2* d1) {
+static KTOWER void fq12_mul_by_034(Fq12* f, const Fq2* c0, const Fq2* d0, const Fq2* d1) {
   Fq6 a = {M2(f->c0.c0, *c0), M2(f->c0.c1, *c0), M2(f->c0.c2, *c0)};
   Fq6 b, e, s = f->c0 + f->c1;
   fq6_mul_by_01(&b, &f->c1, d0, d1);
@@ -101,7 +106,7 @@ static KNOINLINE void fq12_mul_by_034(Fq12* f, const Fq2* c0, const Fq2* d0, con
   f->c0 = fq6_mul_v(b) + a;
 }
 // x -> x^(p^k), k = 1, 2, 3
-static KNOINLINE void fq12_frob(Fq12* r, const Fq12* a, int k) {
+static KTOWER void fq12_frob(Fq12* r, const Fq12* a, int k) {
   Fq2 c[6] = {a->c0.c0, a->c1.c0, a->c0.c1, a->c1.c1, a->c0.c2, a->c1.c2};
   Fq2 o[6];
 #pragma unroll 1
@@ -113,7 +118,7 @@ static KNOINLINE void fq12_frob(Fq12* r, const Fq12* a, int k) {
 }
 // Granger-Scott squaring, valid on the cyclotomic subgroup (after the easy part): 9 Fq2 products... as
 // 3 x (1 product + 1 product) pairs
-static KNOINLINE void fq12_cyc_sqr(Fq12* r, const Fq12* a) {
+static KTOWER void fq12_cyc_sqr(Fq12* r, const Fq12* a) {
   const Fq2 r0 = a->c0.c0, r4 = a->c0.c1, r3 = a->c0.c2, r2 = a->c1.c0, r1 = a->c1.c1, r5 = a->c1.c2;
   Fq2 tmp, t0, t1, t2, t3, t4, t5;
   tmp = M2(r0, r1); t0 = M2(r0 + r1, fq2_mul_xi(r1) + r0) - tmp - fq2_mul_xi(tmp); t1 = fq2_dbl(tmp);
@@ -128,7 +133,7 @@ static KNOINLINE void fq12_cyc_sqr(Fq12* r, const Fq12* a) {
   r->c1.c2 = fq2_dbl(t3 + r5) + t3;
 }
 // f^(-z): square-and-multiply over the bits of z with cyclotomic squarings, then conjugate
-static KNOINLINE void fq12_exp_by_neg_z(Fq12* r, const Fq12* f) {
+static KTOWER void fq12_exp_by_neg_z(Fq12* r, const Fq12* f) {
   Fq12 acc = *f;
 #pragma unroll 1
   for (int i = 61; i >= 0; i--) {  // z has 63 bits, top bit handled by acc = f
@@ -143,7 +148,7 @@ static_assert((BN_Z >> 62) == 1, "z must be a 63-bit value");
 struct G2Hom { Fq2 x, y, z; };
 struct Line { Fq2 c0, c1, c2; };  // evaluated as c0 * P.y + (c1 * P.x + c2 v) w
 
-static KNOINLINE void line_double(G2Hom* r, Line* l) {
+static KTOWER void line_double(G2Hom* r, Line* l) {
   Fq2 a = fq2_mul_fq(M2(r->x, r->y), FQ_TWO_INV);
   Fq2 b = S2(r->y), c = S2(r->z);
   Fq2 e = M2(G2_B, fq2_dbl(c) + c);
@@ -158,7 +163,7 @@ static KNOINLINE void line_double(G2Hom* r, Line* l) {
   r->z = M2(b, h);
   l->c0 = -h; l->c1 = fq2_dbl(j) + j; l->c2 = i;
 }
-static KNOINLINE void line_add(G2Hom* r, const Fq2* qx, const Fq2* qy, Line* l) {
+static KTOWER void line_add(G2Hom* r, const Fq2* qx, const Fq2* qy, Line* l) {
   Fq2 theta = r->y - M2(*qy, r->z);
   Fq2 lam = r->x - M2(*qx, r->z);
   Fq2 c = S2(theta), d = S2(lam);
@@ -247,7 +252,7 @@ KDEV void gt_serialize(u32* out96, const Fq12* f) {
 }
 
 // gt_out[i] = serialize(e(P_i, Q_{i*stride})); identity in either slot -> one
-__global__ void __launch_bounds__(64, 2) k_pairing_batch(const G1Aff* __restrict__ ps, const G2Aff* __restrict__ qs, int q_stride, u32 n,
+__global__ void __launch_bounds__(64) k_pairing_batch(const G1Aff* __restrict__ ps, const G2Aff* __restrict__ qs, int q_stride, u32 n,
                                                       u32* __restrict__ gt_out) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

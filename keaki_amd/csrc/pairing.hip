@@ -1,5 +1,6 @@
 // Batched pairing + GT serialisation + BLAKE3 KDF kernels (reference src/kem.rs:30-46,58-69).
 #define KEAKI_FQ2_OUTLINE 1
+#define KEAKI_PAIRING_INLINE_TOWER 1
 #include "internal.h"
 #include "pairing.cuh"
 namespace keaki_internal {
