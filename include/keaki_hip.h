@@ -132,6 +132,12 @@ float keaki_hip_last_msm_total_ms(const keaki_hip_ctx* ctx);
 /* window size (bits) the last MSM used */
 int32_t keaki_hip_last_msm_window_bits(const keaki_hip_ctx* ctx);
 
+/* Test hook: final exponentiation alone. f_mont: n x 12 Fq (Montgomery limbs, order c0.c0.c0 ... c1.c2.c1), the output of a
+ * Miller loop; gt_out: n x 384 bytes, as keaki_hip_pairing_batch would emit. Lets the tests bisect Miller loop vs final exponent. */
+keaki_status keaki_hip_g2_prepare(keaki_hip_ctx* ctx, const uint64_t* g2_aff, uint64_t* lines_out, size_t lines_out_bytes);
+keaki_status keaki_hip_miller_loop_batch(keaki_hip_ctx* ctx, const uint64_t* g1_aff, const uint64_t* g2_aff, size_t n, uint64_t* f_mont_out);
+keaki_status keaki_hip_final_exp_batch(keaki_hip_ctx* ctx, const uint64_t* f_mont, size_t n, uint8_t* gt_out);
+
 /* On-device self-test: runs the hand-scheduled Fq instruction streams (product, add, sub, neg, square and a
  * dependent chain) against the portable template code on `blocks` x 256 lanes x `iters` random and corner-case
  * inputs; *mismatches_out must come back 0. */

@@ -125,7 +125,7 @@ void keaki_hip_ctx_destroy(keaki_hip_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf* b : {&ctx->digits, &ctx->hist, &ctx->offsets, &ctx->cursor, &ctx->sorted, &ctx->buckets, &ctx->partials, &ctx->wsums,
                     &ctx->bsums, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->io_a, &ctx->io_b, &ctx->io_c, &ctx->io_d, &ctx->io_e,
-                    &ctx->fb_scalars, &ctx->fb_g1_gen, &ctx->fb_g2_gen, &ctx->fb_com, &ctx->fb_tau, &ctx->perm})
+                    &ctx->fb_scalars, &ctx->fb_g1_gen, &ctx->fb_g2_gen, &ctx->fb_com, &ctx->fb_tau, &ctx->perm, &ctx->g2gen_lines})
     if (b->p) (void)hipFree(b->p);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -367,7 +367,13 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
     ST_TRY(encap_g1_run(ctx, d_com_aff, d_values, d_r, n, ctx->tmp_a.p));
     ST_TRY(encap_g2_run(ctx, d_tau_g2_aff, d_points, d_r, n, d_ct_out_aff));
   }
-  ST_TRY(pairing_run(ctx, ctx->tmp_a.p, ctx->tmp_c.p, 0, n, gt));
+  // the second pairing slot is the constant generator g2: its line sequence (ark-ec's G2Prepared) is built once per context
+  if (!ctx->g2gen_lines_ready) {
+    ST_TRY(reserve(ctx, ctx->g2gen_lines, g2_prepared_bytes()));
+    ST_TRY(g2_prepare_run(ctx, ctx->tmp_c.p, ctx->g2gen_lines.p));
+    ctx->g2gen_lines_ready = true;
+  }
+  ST_TRY(pairing_run(ctx, ctx->tmp_a.p, ctx->tmp_c.p, 0, n, gt, ctx->g2gen_lines.p));
   if (d_key_out && msg_len) ST_TRY(blake3_gt_run(ctx, gt, n, d_key_out, msg_len));
   return KEAKI_OK;
 }
@@ -434,6 +440,40 @@ keaki_status keaki_hip_decap_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_af
   if (key_out && msg_len) HIP_TRY(ctx, hipMemcpyAsync(key_out, base + off_key, n * msg_len, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   return KEAKI_OK;
+}
+
+// ---- test hook: line table of a fixed Q (MILLER_MAX_LINES x 2 parities x 3 Fq, Montgomery)
+keaki_status keaki_hip_g2_prepare(keaki_hip_ctx* ctx, const uint64_t* g2_aff, uint64_t* lines_out, size_t lines_out_bytes) {
+  CTX_GUARD(ctx);
+  if (!g2_aff || !lines_out || lines_out_bytes < g2_prepared_bytes()) return fail(ctx, KEAKI_ERR_BAD_ARG, "g2_prepare: bad argument");
+  ST_TRY(upload(ctx, ctx->io_a, g2_aff, 128));
+  ST_TRY(reserve(ctx, ctx->io_b, g2_prepared_bytes()));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->io_b.p, 0, g2_prepared_bytes(), ctx->stream));
+  ST_TRY(g2_prepare_run(ctx, ctx->io_a.p, ctx->io_b.p));
+  return download(ctx, lines_out, ctx->io_b.p, g2_prepared_bytes());
+}
+
+// ---- test hook: Miller loop alone (n x 12 Fq Montgomery out)
+keaki_status keaki_hip_miller_loop_batch(keaki_hip_ctx* ctx, const uint64_t* g1_aff, const uint64_t* g2_aff, size_t n, uint64_t* f_mont_out) {
+  CTX_GUARD(ctx);
+  if (n == 0) return KEAKI_OK;
+  if (!g1_aff || !g2_aff || !f_mont_out) return fail(ctx, KEAKI_ERR_BAD_ARG, "miller_loop_batch: null pointer");
+  ST_TRY(upload(ctx, ctx->io_a, g1_aff, n * 64));
+  ST_TRY(upload(ctx, ctx->io_b, g2_aff, n * 128));
+  ST_TRY(reserve(ctx, ctx->io_c, n * 384));
+  ST_TRY(miller_only_run(ctx, ctx->io_a.p, ctx->io_b.p, n, ctx->io_c.p));
+  return download(ctx, f_mont_out, ctx->io_c.p, n * 384);
+}
+
+// ---- test hook: final exponentiation of caller-supplied Miller-loop outputs (n x 12 Fq, Montgomery) -> n x 384 GT bytes
+keaki_status keaki_hip_final_exp_batch(keaki_hip_ctx* ctx, const uint64_t* f_mont, size_t n, uint8_t* gt_out) {
+  CTX_GUARD(ctx);
+  if (n == 0) return KEAKI_OK;
+  if (!f_mont || !gt_out) return fail(ctx, KEAKI_ERR_BAD_ARG, "final_exp_batch: null pointer");
+  ST_TRY(upload(ctx, ctx->io_a, f_mont, n * 384));
+  ST_TRY(reserve(ctx, ctx->io_b, n * 384));
+  ST_TRY(final_exp_only_run(ctx, ctx->io_a.p, n, ctx->io_b.p));
+  return download(ctx, gt_out, ctx->io_b.p, n * 384);
 }
 
 // ---- self-test --------------------------------------------------------------------------------------------

@@ -29,7 +29,8 @@ struct keaki_hip_ctx {
   // grow-only workspaces (all used in stream order)
   keaki_internal::DevBuf digits, hist, offsets, cursor, sorted, buckets, partials, wsums, bsums, tmp_a, tmp_b, tmp_c, io_a, io_b, io_c, io_d, io_e;
   // fixed-base window tables for encapsulate: generator tables are built once per context, the C / [tau]_2 tables per batch
-  keaki_internal::DevBuf fb_scalars, fb_g1_gen, fb_g2_gen, fb_com, fb_tau, perm;
+  keaki_internal::DevBuf fb_scalars, fb_g1_gen, fb_g2_gen, fb_com, fb_tau, perm, g2gen_lines;
+  bool g2gen_lines_ready = false;
   bool fb_ready = false;
   // instrumentation
   bool timing = false;
@@ -69,7 +70,11 @@ keaki_status g1_mul_batch_run(keaki_hip_ctx* ctx, const void* d_pts, int stride,
 keaki_status g2_mul_batch_run(keaki_hip_ctx* ctx, const void* d_pts, int stride, const void* d_scalars, size_t n, void* d_out);
 keaki_status encap_g1_run(keaki_hip_ctx* ctx, const void* d_com, const void* d_values, const void* d_r, size_t n, void* d_out);
 keaki_status encap_g2_run(keaki_hip_ctx* ctx, const void* d_tau_g2, const void* d_points, const void* d_r, size_t n, void* d_out);
-keaki_status pairing_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, int g2_stride, size_t n, void* d_gt);
+keaki_status pairing_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, int g2_stride, size_t n, void* d_gt, const void* d_fixed_lines = nullptr);
+size_t g2_prepared_bytes();
+keaki_status miller_only_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, size_t n, void* d_out);
+keaki_status final_exp_only_run(keaki_hip_ctx* ctx, const void* d_in, size_t n, void* d_gt);
+keaki_status g2_prepare_run(keaki_hip_ctx* ctx, const void* d_q, void* d_lines);   // line sequence of a fixed Q
 keaki_status blake3_gt_run(keaki_hip_ctx* ctx, const void* d_gt, size_t n, void* d_key, size_t msg_len);
 keaki_status g2_generator_to(keaki_hip_ctx* ctx, void* d_dst);  // writes the affine G2 generator (128 B)
 keaki_status g1_generator_to(keaki_hip_ctx* ctx, void* d_dst);  // affine G1 generator (64 B)

@@ -1,4 +1,4 @@
-// Batched BN254 optimal-ate pairing on gfx950: one lane per pairing.
+// Batched BN254 optimal-ate pairing on gfx950: one lane PAIR per pairing.
 //
 // Replaces `E::pairing(p, q)` (reference src/kem.rs:30,58; src/kzg.rs:148; ark-ec 0.4.2 models/bn:
 // G2Prepared line coefficients + multi_miller_loop + final_exponentiation) and
@@ -7,31 +7,107 @@
 // Tower (ark-bn254): Fq2 = Fq[u]/(u^2+1), Fq6 = Fq2[v]/(v^3 - (9+u)), Fq12 = Fq6[w]/(w^2 - v),
 // D-type twist. The reduced pairing value is independent of the Miller-loop addition chain and of
 // subfield scalings of the line functions, so this kernel is free to (a) compute the lines on the
-// fly instead of materialising G2Prepared, (b) use the proper NAF of 6z+2 (22 additions instead of
-// arkworks' 26). The final exponent is arkworks' exactly: (p^12-1)/r * 2z(6z^2+3z+1).
+// fly (or read a table when Q is constant), (b) use the proper NAF of 6z+2 (22 additions instead of
+// arkworks' 26) and a NAF of z in the hard part. The final exponent is arkworks' exactly:
+// (p^12-1)/r * 2z(6z^2+3z+1).
 //
-// Register pressure: an Fq12 is 96 dwords; the Fq2 product and the Fq12-level routines are real
-// (non-inlined) functions so code size stays in the instruction cache.
+// Lane-pair layout: every Fq2 element a0 + a1 u is split over two adjacent lanes -- the even lane
+// holds a0, the odd lane a1 (type Fq2d = "this lane's component"). Consequences:
+//   * Fq2 add/sub/double are ONE Fq operation per lane; an Fq12 is 48 VGPRs per lane, not 96, so the
+//     Miller loop / final exponentiation live in registers instead of a 10 KB/lane scratch stack;
+//   * an Fq2 product is two Fq products per lane (a_self*b_x and a_other*b_y) instead of three
+//     sequential Karatsuba products; a squaring is one;
+//   * the only cross-lane traffic is the partner's component, fetched with a DPP quad-perm
+//     (v_mov_b32_dpp quad_perm:[1,0,3,2]: register-to-register, no LDS);
+//   * both lanes run the SAME instruction stream (component-dependent operands are chosen with
+//     v_cndmask), so there is no divergence; 2n lanes give twice the waves to hide latency.
+// The tower code above Fq2 is written once against the Fq2d primitives.
 #pragma once
 #include "bn254_curve.cuh"
 
 namespace bn254 {
 
 #define KNOINLINE __device__ __noinline__
-#ifdef KEAKI_PAIRING_INLINE_TOWER
 #define KTOWER __device__ __forceinline__
-#else
-#define KTOWER __device__ __noinline__
-#endif
 
-struct Fq6 { Fq2 c0, c1, c2; };
+// ---------------------------------------------------------------------------------------------
+// Fq2d: one component of an Fq2 element per lane
+// ---------------------------------------------------------------------------------------------
+struct Fq2d { Fq v; };
+
+KDEV u32 lane_odd() { return threadIdx.x & 1u; }
+// partner lane's value (lane ^ 1). All 64 lanes of the wave must be active.
+// gfx950 needs two wait states between a VALU write of a VGPR and a DPP read of it. hipcc pads that for instructions it
+// scheduled itself, but the limbs usually come straight out of an inline-asm field stream, which the hazard recogniser does
+// not look into -- so the value is first passed through an `s_nop 1` statement that owns all eight limbs.
+KDEV Fq fq_partner(const Fq& a) {
+  u32 x0 = a.l[0], x1 = a.l[1], x2 = a.l[2], x3 = a.l[3], x4 = a.l[4], x5 = a.l[5], x6 = a.l[6], x7 = a.l[7];
+  asm volatile("s_nop 1" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+  Fq r;
+  r.l[0] = (u32)__builtin_amdgcn_update_dpp(0, (int)x0, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false);
+  r.l[1] = (u32)__builtin_amdgcn_update_dpp(0, (int)x1, 0xB1, 0xF, 0xF, false);
+  r.l[2] = (u32)__builtin_amdgcn_update_dpp(0, (int)x2, 0xB1, 0xF, 0xF, false);
+  r.l[3] = (u32)__builtin_amdgcn_update_dpp(0, (int)x3, 0xB1, 0xF, 0xF, false);
+  r.l[4] = (u32)__builtin_amdgcn_update_dpp(0, (int)x4, 0xB1, 0xF, 0xF, false);
+  r.l[5] = (u32)__builtin_amdgcn_update_dpp(0, (int)x5, 0xB1, 0xF, 0xF, false);
+  r.l[6] = (u32)__builtin_amdgcn_update_dpp(0, (int)x6, 0xB1, 0xF, 0xF, false);
+  r.l[7] = (u32)__builtin_amdgcn_update_dpp(0, (int)x7, 0xB1, 0xF, 0xF, false);
+  return r;
+}
+KDEV Fq fq_select(bool c, const Fq& a, const Fq& b) {  // c ? a : b
+  Fq r;
+#pragma unroll
+  for (int j = 0; j < 8; j++) r.l[j] = c ? a.l[j] : b.l[j];
+  return r;
+}
+
+KDEV Fq2d operator+(const Fq2d& a, const Fq2d& b) { return {a.v + b.v}; }
+KDEV Fq2d operator-(const Fq2d& a, const Fq2d& b) { return {a.v - b.v}; }
+KDEV Fq2d operator-(const Fq2d& a) { return {-a.v}; }
+KDEV Fq2d fq2_dbl(const Fq2d& a) { return {fq_dbl(a.v)}; }
+KDEV Fq2d fq2d_zero() { return {fq_zero()}; }
+KDEV Fq2d fq2d_one() { return {fq_select(lane_odd() != 0, fq_zero(), fq_one())}; }
+KDEV Fq2d fq2_conj(const Fq2d& a) { return {fp_cneg<FqParams>(a.v, lane_odd() != 0)}; }
+KDEV Fq2d fq2_mul_fq(const Fq2d& a, const Fq& k) { return {a.v * k}; }
+// this lane's component of an Fq2 stored as (c0, c1)
+KDEV Fq2d fq2d_load(const Fq2* a) { return {reinterpret_cast<const Fq*>(a)[lane_odd()]}; }
+
+// (a0 + a1 u)(b0 + b1 u):  even lane: a0 b0 - a1 b1 ; odd lane: a1 b0 + a0 b1
+static KNOINLINE Fq2d fq2d_mul(const Fq2d a, const Fq2d b) {
+  const bool odd = lane_odd() != 0;
+  Fq ao = fq_partner(a.v), bo = fq_partner(b.v);
+  // p1 = a_self * (odd ? b_other : b_self) ; p2 = a_other * (odd ? b_self : b_other)
+  Fq p1 = a.v * fq_select(odd, bo, b.v);
+  Fq p2 = ao * fq_select(odd, b.v, bo);
+  return {p1 + fp_cneg<FqParams>(p2, !odd)};
+}
+// (a0 + a1 u)^2:  even lane: (a0 + a1)(a0 - a1) ; odd lane: 2 a0 a1  -- one product per lane
+static KNOINLINE Fq2d fq2d_sqr(const Fq2d a) {
+  const bool odd = lane_odd() != 0;
+  Fq ao = fq_partner(a.v);
+  Fq x = fq_select(odd, ao, a.v + ao);                  // odd: a0      even: a0 + a1
+  Fq y = fq_select(odd, fq_dbl(a.v), a.v - ao);         // odd: 2 a1    even: a0 - a1
+  return {x * y};
+}
+KDEV Fq2d operator*(const Fq2d& a, const Fq2d& b) { return fq2d_mul(a, b); }
+KDEV Fq2d fq2_sqr(const Fq2d& a) { return fq2d_sqr(a); }
+// (9 + u)(a0 + a1 u) = (9 a0 - a1) + (9 a1 + a0) u
+KDEV Fq2d fq2_mul_xi(const Fq2d& a) {
+  Fq t = fq_dbl(fq_dbl(fq_dbl(a.v))) + a.v;   // 9 * self
+  Fq o = fq_partner(a.v);
+  return {t + fp_cneg<FqParams>(o, lane_odd() == 0)};
+}
+// 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + a1^2); the norm inverse is computed redundantly in both lanes
+KDEV Fq2d fq2_inv(const Fq2d& a) {
+  Fq sq = fq_sqr(a.v);
+  Fq n = sq + fq_partner(sq);
+  Fq ni = fq_inv(n);
+  return {fp_cneg<FqParams>(a.v * ni, lane_odd() != 0)};
+}
+
+struct Fq6 { Fq2d c0, c1, c2; };
 struct Fq12 { Fq6 c0, c1; };
 
-// Fq2 product / square are out-of-line functions in this translation unit (KEAKI_FQ2_OUTLINE): the
-// unit of code reuse for the tower
-#ifndef KEAKI_FQ2_OUTLINE
-#error "pairing.cuh expects KEAKI_FQ2_OUTLINE (see pairing.hip)"
-#endif
 #define M2(a, b) ((a) * (b))
 #define S2(a) fq2_sqr((a))
 
@@ -39,35 +115,35 @@ KDEV Fq6 operator+(const Fq6& a, const Fq6& b) { return {a.c0 + b.c0, a.c1 + b.c
 KDEV Fq6 operator-(const Fq6& a, const Fq6& b) { return {a.c0 - b.c0, a.c1 - b.c1, a.c2 - b.c2}; }
 KDEV Fq6 operator-(const Fq6& a) { return {-a.c0, -a.c1, -a.c2}; }
 KDEV Fq6 fq6_mul_v(const Fq6& a) { return {fq2_mul_xi(a.c2), a.c0, a.c1}; }
-KDEV Fq6 fq6_zero() { return {fq2_zero(), fq2_zero(), fq2_zero()}; }
+KDEV Fq6 fq6_zero() { return {fq2d_zero(), fq2d_zero(), fq2d_zero()}; }
 
 static KTOWER void fq6_mul(Fq6* r, const Fq6* a, const Fq6* b) {
-  Fq2 v0 = M2(a->c0, b->c0), v1 = M2(a->c1, b->c1), v2 = M2(a->c2, b->c2);
-  Fq2 t0 = fq2_mul_xi(M2(a->c1 + a->c2, b->c1 + b->c2) - v1 - v2) + v0;
-  Fq2 t1 = M2(a->c0 + a->c1, b->c0 + b->c1) - v0 - v1 + fq2_mul_xi(v2);
-  Fq2 t2 = M2(a->c0 + a->c2, b->c0 + b->c2) - v0 - v2 + v1;
+  Fq2d v0 = M2(a->c0, b->c0), v1 = M2(a->c1, b->c1), v2 = M2(a->c2, b->c2);
+  Fq2d t0 = fq2_mul_xi(M2(a->c1 + a->c2, b->c1 + b->c2) - v1 - v2) + v0;
+  Fq2d t1 = M2(a->c0 + a->c1, b->c0 + b->c1) - v0 - v1 + fq2_mul_xi(v2);
+  Fq2d t2 = M2(a->c0 + a->c2, b->c0 + b->c2) - v0 - v2 + v1;
   r->c0 = t0; r->c1 = t1; r->c2 = t2;
 }
 // a * (c0 + c1 v)
-static KTOWER void fq6_mul_by_01(Fq6* r, const Fq6* a, const Fq2* c0, const Fq2* c1) {
-  Fq2 aa = M2(a->c0, *c0), bb = M2(a->c1, *c1);
-  Fq2 t1 = fq2_mul_xi(M2(*c1, a->c1 + a->c2) - bb) + aa;
-  Fq2 t3 = M2(*c0, a->c0 + a->c2) - aa + bb;
-  Fq2 t2 = M2(*c0 + *c1, a->c0 + a->c1) - aa - bb;
+static KTOWER void fq6_mul_by_01(Fq6* r, const Fq6* a, const Fq2d* c0, const Fq2d* c1) {
+  Fq2d aa = M2(a->c0, *c0), bb = M2(a->c1, *c1);
+  Fq2d t1 = fq2_mul_xi(M2(*c1, a->c1 + a->c2) - bb) + aa;
+  Fq2d t3 = M2(*c0, a->c0 + a->c2) - aa + bb;
+  Fq2d t2 = M2(*c0 + *c1, a->c0 + a->c1) - aa - bb;
   r->c0 = t1; r->c1 = t2; r->c2 = t3;
 }
 static KTOWER void fq6_inv(Fq6* r, const Fq6* a) {
-  Fq2 t0 = S2(a->c0) - fq2_mul_xi(M2(a->c1, a->c2));
-  Fq2 t1 = fq2_mul_xi(S2(a->c2)) - M2(a->c0, a->c1);
-  Fq2 t2 = S2(a->c1) - M2(a->c0, a->c2);
-  Fq2 n = M2(a->c0, t0) + fq2_mul_xi(M2(a->c2, t1) + M2(a->c1, t2));
-  Fq2 ni = fq2_inv(n);
+  Fq2d t0 = S2(a->c0) - fq2_mul_xi(M2(a->c1, a->c2));
+  Fq2d t1 = fq2_mul_xi(S2(a->c2)) - M2(a->c0, a->c1);
+  Fq2d t2 = S2(a->c1) - M2(a->c0, a->c2);
+  Fq2d n = M2(a->c0, t0) + fq2_mul_xi(M2(a->c2, t1) + M2(a->c1, t2));
+  Fq2d ni = fq2_inv(n);
   r->c0 = M2(t0, ni); r->c1 = M2(t1, ni); r->c2 = M2(t2, ni);
 }
 
 KDEV void fq12_set_one(Fq12* f) {
   f->c0 = fq6_zero(); f->c1 = fq6_zero();
-  f->c0.c0.c0 = fq_one();
+  f->c0.c0 = fq2d_one();
 }
 static KTOWER void fq12_mul(Fq12* r, const Fq12* a, const Fq12* b) {
   Fq6 t0, t1, m, s0 = a->c0 + a->c1, s1 = b->c0 + b->c1;
@@ -96,35 +172,34 @@ static KTOWER void fq12_inv(Fq12* r, const Fq12* a) {
   r->c1 = -t;
 }
 // f *= c0 + (d0 + d1 v) w   (13 Fq2 products instead of 18)
-static KTOWER void fq12_mul_by_034(Fq12* f, const Fq2* c0, const Fq2* d0, const Fq2* d1) {
+static KTOWER void fq12_mul_by_034(Fq12* f, const Fq2d* c0, const Fq2d* d0, const Fq2d* d1) {
   Fq6 a = {M2(f->c0.c0, *c0), M2(f->c0.c1, *c0), M2(f->c0.c2, *c0)};
   Fq6 b, e, s = f->c0 + f->c1;
   fq6_mul_by_01(&b, &f->c1, d0, d1);
-  Fq2 cs = *c0 + *d0;
+  Fq2d cs = *c0 + *d0;
   fq6_mul_by_01(&e, &s, &cs, d1);
   f->c1 = e - a - b;
   f->c0 = fq6_mul_v(b) + a;
 }
 // x -> x^(p^k), k = 1, 2, 3
 static KTOWER void fq12_frob(Fq12* r, const Fq12* a, int k) {
-  Fq2 c[6] = {a->c0.c0, a->c1.c0, a->c0.c1, a->c1.c1, a->c0.c2, a->c1.c2};
-  Fq2 o[6];
+  Fq2d c[6] = {a->c0.c0, a->c1.c0, a->c0.c1, a->c1.c1, a->c0.c2, a->c1.c2};
+  Fq2d o[6];
 #pragma unroll 1
   for (int i = 0; i < 6; i++) {
-    Fq2 t = (k & 1) ? fq2_conj(c[i]) : c[i];
-    o[i] = M2(t, FROB_W[k][i]);
+    Fq2d t = (k & 1) ? fq2_conj(c[i]) : c[i];
+    o[i] = M2(t, fq2d_load(&FROB_W[k][i]));
   }
   r->c0.c0 = o[0]; r->c1.c0 = o[1]; r->c0.c1 = o[2]; r->c1.c1 = o[3]; r->c0.c2 = o[4]; r->c1.c2 = o[5];
 }
-// Granger-Scott squaring, valid on the cyclotomic subgroup (after the easy part): 9 Fq2 products... as
-// 3 x (1 product + 1 product) pairs
+// Granger-Scott squaring, valid on the cyclotomic subgroup (after the easy part)
 static KTOWER void fq12_cyc_sqr(Fq12* r, const Fq12* a) {
-  const Fq2 r0 = a->c0.c0, r4 = a->c0.c1, r3 = a->c0.c2, r2 = a->c1.c0, r1 = a->c1.c1, r5 = a->c1.c2;
-  Fq2 tmp, t0, t1, t2, t3, t4, t5;
+  const Fq2d r0 = a->c0.c0, r4 = a->c0.c1, r3 = a->c0.c2, r2 = a->c1.c0, r1 = a->c1.c1, r5 = a->c1.c2;
+  Fq2d tmp, t0, t1, t2, t3, t4, t5;
   tmp = M2(r0, r1); t0 = M2(r0 + r1, fq2_mul_xi(r1) + r0) - tmp - fq2_mul_xi(tmp); t1 = fq2_dbl(tmp);
   tmp = M2(r2, r3); t2 = M2(r2 + r3, fq2_mul_xi(r3) + r2) - tmp - fq2_mul_xi(tmp); t3 = fq2_dbl(tmp);
   tmp = M2(r4, r5); t4 = M2(r4 + r5, fq2_mul_xi(r5) + r4) - tmp - fq2_mul_xi(tmp); t5 = fq2_dbl(tmp);
-  Fq2 x5 = fq2_mul_xi(t5);
+  Fq2d x5 = fq2_mul_xi(t5);
   r->c0.c0 = fq2_dbl(t0 - r0) + t0;
   r->c1.c1 = fq2_dbl(t1 + r1) + t1;
   r->c1.c0 = fq2_dbl(x5 + r2) + x5;
@@ -132,81 +207,102 @@ static KTOWER void fq12_cyc_sqr(Fq12* r, const Fq12* a) {
   r->c0.c1 = fq2_dbl(t2 - r4) + t2;
   r->c1.c2 = fq2_dbl(t3 + r5) + t3;
 }
-// f^(-z): square-and-multiply over the bits of z with cyclotomic squarings, then conjugate
+// f^(-z): signed-digit (NAF) square-and-multiply with cyclotomic squarings -- on the cyclotomic subgroup the
+// inverse is the conjugate, so a -1 digit costs the same as a +1 digit and the NAF has fewer non-zeros than z.
 static KTOWER void fq12_exp_by_neg_z(Fq12* r, const Fq12* f) {
-  Fq12 acc = *f;
+  Fq12 acc = *f, fc;
+  fq12_conj(&fc, f);
 #pragma unroll 1
-  for (int i = 61; i >= 0; i--) {  // z has 63 bits, top bit handled by acc = f
+  for (int i = Z_NAF_LEN - 2; i >= 0; i--) {  // top digit is +1: acc = f
     fq12_cyc_sqr(&acc, &acc);
-    if ((BN_Z >> i) & 1) fq12_mul(&acc, &acc, f);
+    int d = Z_NAF[i];
+    if (d != 0) fq12_mul(&acc, &acc, d > 0 ? f : &fc);
   }
   fq12_conj(r, &acc);
 }
-static_assert((BN_Z >> 62) == 1, "z must be a 63-bit value");
 
 // ---- line functions on the twist, homogeneous projective (same formulas as ark-ec bn/g2.rs) ----
-struct G2Hom { Fq2 x, y, z; };
-struct Line { Fq2 c0, c1, c2; };  // evaluated as c0 * P.y + (c1 * P.x + c2 v) w
+struct G2Hom { Fq2d x, y, z; };
+struct Line { Fq2d c0, c1, c2; };  // evaluated as c0 * P.y + (c1 * P.x + c2 v) w
 
 static KTOWER void line_double(G2Hom* r, Line* l) {
-  Fq2 a = fq2_mul_fq(M2(r->x, r->y), FQ_TWO_INV);
-  Fq2 b = S2(r->y), c = S2(r->z);
-  Fq2 e = M2(G2_B, fq2_dbl(c) + c);
-  Fq2 f = fq2_dbl(e) + e;
-  Fq2 g = fq2_mul_fq(b + f, FQ_TWO_INV);
-  Fq2 h = S2(r->y + r->z) - (b + c);
-  Fq2 i = e - b;
-  Fq2 j = S2(r->x);
-  Fq2 e2 = S2(e);
+  Fq2d a = fq2_mul_fq(M2(r->x, r->y), FQ_TWO_INV);
+  Fq2d b = S2(r->y), c = S2(r->z);
+  Fq2d e = M2(fq2d_load(&G2_B), fq2_dbl(c) + c);
+  Fq2d f = fq2_dbl(e) + e;
+  Fq2d g = fq2_mul_fq(b + f, FQ_TWO_INV);
+  Fq2d h = S2(r->y + r->z) - (b + c);
+  Fq2d i = e - b;
+  Fq2d j = S2(r->x);
+  Fq2d e2 = S2(e);
   r->x = M2(a, b - f);
   r->y = S2(g) - (fq2_dbl(e2) + e2);
   r->z = M2(b, h);
   l->c0 = -h; l->c1 = fq2_dbl(j) + j; l->c2 = i;
 }
-static KTOWER void line_add(G2Hom* r, const Fq2* qx, const Fq2* qy, Line* l) {
-  Fq2 theta = r->y - M2(*qy, r->z);
-  Fq2 lam = r->x - M2(*qx, r->z);
-  Fq2 c = S2(theta), d = S2(lam);
-  Fq2 e = M2(lam, d), f = M2(r->z, c), g = M2(r->x, d);
-  Fq2 h = e + f - fq2_dbl(g);
-  Fq2 ny = M2(theta, g - h) - M2(e, r->y);
+static KTOWER void line_add(G2Hom* r, const Fq2d* qx, const Fq2d* qy, Line* l) {
+  Fq2d theta = r->y - M2(*qy, r->z);
+  Fq2d lam = r->x - M2(*qx, r->z);
+  Fq2d c = S2(theta), d = S2(lam);
+  Fq2d e = M2(lam, d), f = M2(r->z, c), g = M2(r->x, d);
+  Fq2d h = e + f - fq2_dbl(g);
+  Fq2d ny = M2(theta, g - h) - M2(e, r->y);
   r->x = M2(lam, h);
   r->y = ny;
   r->z = M2(r->z, e);
-  l->c0 = lam; l->c1 = -theta; l->c2 = M2(theta, *qx) - M2(lam, *qy);
+  // NOTE: written as 0 - theta on purpose. In this (fully inlined, 512-register) context hipcc 7.2 produced a wrong
+  // value for the unary form `-theta` here and only here, with the asm and the portable negation alike, while the
+  // binary form is correct; the isolated pattern passes the on-device self-test. tests/test_gpu_parity.py pins the whole
+  // line table against the big-int oracle (test_g2_line_table_vs_oracle) so any recurrence is caught.
+  l->c0 = lam; l->c1 = fq2d_zero() - theta; l->c2 = M2(theta, *qx) - M2(lam, *qy);
 }
 KDEV void ell(Fq12* f, const Line* l, const G1Aff* p) {
-  Fq2 c0 = fq2_mul_fq(l->c0, p->y), c1 = fq2_mul_fq(l->c1, p->x);
+  Fq2d c0 = fq2_mul_fq(l->c0, p->y), c1 = fq2_mul_fq(l->c1, p->x);
   fq12_mul_by_034(f, &c0, &c1, &l->c2);
 }
 
-static __device__ void miller_loop(Fq12* f, const G1Aff* p, const G2Aff* q) {
+// Line table of a fixed Q (ark-ec's G2Prepared), per lane parity: lines[li * 2 + parity]
+constexpr int MILLER_MAX_LINES = 96;
+// lines == nullptr: compute the lines on the fly from (qx, qy). lines_out != nullptr: only tabulate them.
+static KTOWER void miller_loop(Fq12* f, const G1Aff* p, const Fq2d* qx, const Fq2d* qy, const Line* __restrict__ lines,
+                                   Line* __restrict__ lines_out) {
+  const u32 par = lane_odd();
   fq12_set_one(f);
-  G2Hom r = {q->x, q->y, fq2_one()};
-  Fq2 nqy = -q->y;
+  G2Hom r = {*qx, *qy, fq2d_one()};
+  Fq2d nqy = -*qy;
   Line l;
+  int li = 0;
 #pragma unroll 1
   for (int i = ATE_LEN - 2; i >= 0; i--) {
-    if (i != ATE_LEN - 2) fq12_sqr(f, f);
-    line_double(&r, &l);
-    ell(f, &l, p);
+    if (i != ATE_LEN - 2 && !lines_out) fq12_sqr(f, f);
+    if (lines) l = lines[li * 2 + par]; else line_double(&r, &l);
+    if (lines_out) lines_out[li * 2 + par] = l; else ell(f, &l, p);
+    li++;
     int d = ATE_NAF[i];
     if (d != 0) {
-      line_add(&r, &q->x, d > 0 ? &q->y : &nqy, &l);
-      ell(f, &l, p);
+      if (lines) l = lines[li * 2 + par]; else line_add(&r, qx, d > 0 ? qy : &nqy, &l);
+      if (lines_out) lines_out[li * 2 + par] = l; else ell(f, &l, p);
+      li++;
     }
   }
   // Q1 = pi(Q), Q2 = -pi^2(Q)
-  Fq2 q1x = M2(fq2_conj(q->x), TWIST_MUL_BY_Q_X), q1y = M2(fq2_conj(q->y), TWIST_MUL_BY_Q_Y);
-  Fq2 q2x = M2(fq2_conj(q1x), TWIST_MUL_BY_Q_X), q2y = -M2(fq2_conj(q1y), TWIST_MUL_BY_Q_Y);
-  line_add(&r, &q1x, &q1y, &l);
-  ell(f, &l, p);
-  line_add(&r, &q2x, &q2y, &l);
-  ell(f, &l, p);
+  if (lines) {
+    l = lines[li * 2 + par]; li++; ell(f, &l, p);
+    l = lines[li * 2 + par]; li++; ell(f, &l, p);
+  } else {
+    Fq2d q1x = M2(fq2_conj(*qx), fq2d_load(&TWIST_MUL_BY_Q_X)), q1y = M2(fq2_conj(*qy), fq2d_load(&TWIST_MUL_BY_Q_Y));
+    Fq2d q2x = M2(fq2_conj(q1x), fq2d_load(&TWIST_MUL_BY_Q_X)), q2y = -M2(fq2_conj(q1y), fq2d_load(&TWIST_MUL_BY_Q_Y));
+    line_add(&r, &q1x, &q1y, &l);
+    if (lines_out) lines_out[li * 2 + par] = l; else ell(f, &l, p);
+    li++;
+    line_add(&r, &q2x, &q2y, &l);
+    if (lines_out) lines_out[li * 2 + par] = l; else ell(f, &l, p);
+    li++;
+  }
 }
 
 // easy part (p^6-1)(p^2+1), hard part = arkworks' Fuentes-Castaneda chain (exponent 2z(6z^2+3z+1)(p^4-p^2+1)/r)
-static __device__ void final_exponentiation(Fq12* out, const Fq12* fin) {
+static KTOWER void final_exponentiation(Fq12* out, const Fq12* fin) {
   Fq12 f1, f2, r, y0, y1, y2, y3, y4, y5, y6, t;
   fq12_conj(&f1, fin);
   fq12_inv(&f2, fin);
@@ -239,33 +335,79 @@ static __device__ void final_exponentiation(Fq12* out, const Fq12* fin) {
   fq12_mul(out, &y15, &y14);
 }
 
-// GT -> 384 canonical little-endian bytes in ark-serialize order (c0.c0.c0 ... c1.c2.c1)
+// GT -> 384 canonical little-endian bytes in ark-serialize order (c0.c0.c0, c0.c0.c1, c0.c1.c0 ... c1.c2.c1):
+// Fq2 coefficient k of the element (k = 0..5 in memory order) fills the 32-byte slots 2k (even lane) and 2k+1 (odd lane).
 KDEV void gt_serialize(u32* out96, const Fq12* f) {
-  const Fq* c = reinterpret_cast<const Fq*>(f);
+  const Fq2d* c = reinterpret_cast<const Fq2d*>(f);
+  const u32 par = lane_odd();
 #pragma unroll 1
-  for (int i = 0; i < 12; i++) {
+  for (int i = 0; i < 6; i++) {
     u32 w[8];
-    fp_from_mont<FqParams>(w, c[i]);
+    fp_from_mont<FqParams>(w, c[i].v);
 #pragma unroll
-    for (int j = 0; j < 8; j++) out96[8 * i + j] = w[j];
+    for (int j = 0; j < 8; j++) out96[8 * (2 * i + par) + j] = w[j];
   }
 }
 
-// gt_out[i] = serialize(e(P_i, Q_{i*stride})); identity in either slot -> one
-__global__ void __launch_bounds__(64) k_pairing_batch(const G1Aff* __restrict__ ps, const G2Aff* __restrict__ qs, int q_stride, u32 n,
-                                                      u32* __restrict__ gt_out) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// gt_out[i] = serialize(e(P_i, Q_{i*stride})); identity in either slot -> one. TWO lanes per item.
+// fixed_lines != nullptr: every item pairs with the same Q whose lines were tabulated by k_g2_prepare (q_stride == 0).
+static __global__ void __launch_bounds__(64, 2) k_pairing_batch(const G1Aff* __restrict__ ps, const G2Aff* __restrict__ qs, int q_stride, u32 n,
+                                                      const Line* __restrict__ fixed_lines, u32* __restrict__ gt_out) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 item = t >> 1;
+  const bool live = item < n;
+  const u32 i = live ? item : (n - 1);   // tail lanes redo the last item: all 64 lanes must stay active for the DPP exchanges
   G1Aff p = ps[i];
-  G2Aff q = qs[(size_t)i * q_stride];
+  const G2Aff* q = qs + (size_t)i * q_stride;
+  Fq2d qx = fq2d_load(&q->x), qy = fq2d_load(&q->y);
+  // identity in either slot (Q = all four components zero, or P = (0,0)): both lanes of the pair agree on `ident`
+  u32 qz = (fq_is_zero(qx.v) && fq_is_zero(qy.v)) ? 1u : 0u;
+  qz &= (u32)__builtin_amdgcn_update_dpp(0, (int)qz, 0xB1, 0xF, 0xF, false);
+  const bool ident = aff_is_inf(p) || qz != 0;
+  // wave-uniform control flow: identity items run the same arithmetic (total on zeros) and discard it
   Fq12 f, e;
-  if (aff_is_inf(p) || aff_is_inf(q)) {
-    fq12_set_one(&e);
-  } else {
-    miller_loop(&f, &p, &q);
-    final_exponentiation(&e, &f);
+  miller_loop(&f, &p, &qx, &qy, fixed_lines, nullptr);
+  final_exponentiation(&e, &f);
+  if (ident) fq12_set_one(&e);
+  if (live) gt_serialize(gt_out + (size_t)96 * i, &e);
+}
+// the line sequence of a fixed Q; every lane pair of the single wave computes the same values, pair 0's layout is the table
+static __global__ void __launch_bounds__(64) k_g2_prepare(const G2Aff* __restrict__ q, Line* __restrict__ lines_out) {
+  Fq12 f;
+  G1Aff dummy = {fq_zero(), fq_zero()};
+  Fq2d qx = fq2d_load(&q->x), qy = fq2d_load(&q->y);
+  miller_loop(&f, &dummy, &qx, &qy, nullptr, lines_out);
+}
+
+// debug / test entry: Miller loop only. out: n x 12 Fq (Montgomery), single-element layout.
+static __global__ void __launch_bounds__(64) k_miller_only(const G1Aff* __restrict__ ps, const G2Aff* __restrict__ qs, u32 n, Fq* __restrict__ out) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 item = t >> 1;
+  const bool live = item < n;
+  const u32 i = live ? item : (n - 1);
+  G1Aff p = ps[i];
+  Fq2d qx = fq2d_load(&qs[i].x), qy = fq2d_load(&qs[i].y);
+  Fq12 f;
+  miller_loop(&f, &p, &qx, &qy, nullptr, nullptr);
+  const Fq2d* c = reinterpret_cast<const Fq2d*>(&f);
+  if (live) {
+#pragma unroll 1
+    for (int k = 0; k < 6; k++) out[(size_t)12 * i + 2 * k + lane_odd()] = c[k].v;
   }
-  gt_serialize(gt_out + (size_t)96 * i, &e);
+}
+// debug / test entry: final exponentiation only. in: n x Fq12 in Montgomery form, single-element layout
+// (c0.c0.c0, c0.c0.c1, ... 12 x Fq); out: n x 384 GT bytes. Two lanes per item.
+static __global__ void __launch_bounds__(64) k_final_exp_only(const Fq* __restrict__ in, u32 n, u32* __restrict__ gt_out) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 item = t >> 1;
+  const bool live = item < n;
+  const u32 i = live ? item : (n - 1);
+  Fq12 f, e;
+  Fq2d* c = reinterpret_cast<Fq2d*>(&f);
+#pragma unroll 1
+  for (int k = 0; k < 6; k++) c[k].v = in[(size_t)12 * i + 2 * k + lane_odd()];
+  final_exponentiation(&e, &f);
+  if (live) gt_serialize(gt_out + (size_t)96 * i, &e);
 }
 
 // ---- BLAKE3 XOF of a 384-byte GT encoding (single chunk, 6 blocks): replaces src/kem.rs:42-46,65-69 ----
@@ -299,7 +441,7 @@ KDEV void b3_compress(u32* out16, const u32* cv, const u32* blk, u64 counter, u3
 #pragma unroll
   for (int i = 0; i < 8; i++) { out16[i] = s[i] ^ s[i + 8]; out16[i + 8] = s[i + 8] ^ cv[i]; }
 }
-__global__ void __launch_bounds__(256) k_blake3_gt_xof(const u32* __restrict__ gt, u32 n, unsigned char* __restrict__ key_out, u32 msg_len) {
+static __global__ void __launch_bounds__(256) k_blake3_gt_xof(const u32* __restrict__ gt, u32 n, unsigned char* __restrict__ key_out, u32 msg_len) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u32* in = gt + (size_t)96 * i;

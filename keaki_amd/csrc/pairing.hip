@@ -1,14 +1,27 @@
 // Batched pairing + GT serialisation + BLAKE3 KDF kernels (reference src/kem.rs:30-46,58-69).
 #define KEAKI_FQ2_OUTLINE 1
-#define KEAKI_PAIRING_INLINE_TOWER 1
 #include "internal.h"
 #include "pairing.cuh"
 namespace keaki_internal {
 using namespace bn254;
-keaki_status pairing_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, int g2_stride, size_t n, void* d_gt) {
-  hipLaunchKernelGGL(k_pairing_batch, dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_g1, (const G2Aff*)d_g2, g2_stride, (u32)n,
-                     (u32*)d_gt);
+keaki_status pairing_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, int g2_stride, size_t n, void* d_gt, const void* d_fixed_lines) {
+  // two lanes per pairing
+  hipLaunchKernelGGL(k_pairing_batch, dim3(cdiv(2 * n, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_g1, (const G2Aff*)d_g2, g2_stride, (u32)n,
+                     (const Line*)d_fixed_lines, (u32*)d_gt);
   return launch_check(ctx, "pairing_batch");
+}
+size_t g2_prepared_bytes() { return (size_t)MILLER_MAX_LINES * 2 * sizeof(Line); }
+keaki_status g2_prepare_run(keaki_hip_ctx* ctx, const void* d_q, void* d_lines) {
+  hipLaunchKernelGGL(k_g2_prepare, dim3(1), dim3(64), 0, ctx->stream, (const G2Aff*)d_q, (Line*)d_lines);
+  return launch_check(ctx, "g2_prepare");
+}
+keaki_status miller_only_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, size_t n, void* d_out) {
+  hipLaunchKernelGGL(k_miller_only, dim3(cdiv(2 * n, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_g1, (const G2Aff*)d_g2, (u32)n, (Fq*)d_out);
+  return launch_check(ctx, "miller_only");
+}
+keaki_status final_exp_only_run(keaki_hip_ctx* ctx, const void* d_in, size_t n, void* d_gt) {
+  hipLaunchKernelGGL(k_final_exp_only, dim3(cdiv(2 * n, 64)), dim3(64), 0, ctx->stream, (const Fq*)d_in, (u32)n, (u32*)d_gt);
+  return launch_check(ctx, "final_exp_only");
 }
 keaki_status blake3_gt_run(keaki_hip_ctx* ctx, const void* d_gt, size_t n, void* d_key, size_t msg_len) {
   hipLaunchKernelGGL(k_blake3_gt_xof, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const u32*)d_gt, (u32)n, (unsigned char*)d_key, (u32)msg_len);

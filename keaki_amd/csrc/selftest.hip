@@ -1,5 +1,5 @@
 // On-device self-test of the hand-scheduled Fq streams against the portable template code.
-#include "bn254_field.cuh"
+#include "pairing.cuh"
 #include "internal.h"
 namespace bn254 {
 using FqRef = Fp<FqParamsRef>;
@@ -48,10 +48,46 @@ __global__ void __launch_bounds__(256) k_selftest_field(u32 seed, u32 iters, uns
   }
   if (bad) atomicAdd(mismatches, bad);
 }
+
+// lane-pair Fq2 primitives (pairing.cuh) against the single-lane Fq2 code
+__global__ void __launch_bounds__(64) k_selftest_fq2d(u32 seed, u32 iters, unsigned long long* mismatches) {
+  u32 pair = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  u32 s = (seed ^ (pair * 0x9E3779B9u)) | 1u;
+  const u32 par = lane_odd();
+  unsigned long long bad = 0;
+  for (u32 it = 0; it < iters; it++) {
+    Fq2 a = {pick(s, 0), pick(s, 0)}, b = {pick(s, 0), pick(s, 0)};   // identical in both lanes of the pair
+    if ((it & 7) == 3) a.c1 = fq_zero();
+    if ((it & 7) == 5) b.c0 = fq_zero();
+    Fq k = pick(s, 0);
+    Fq2d ad = fq2d_load(&a), bd = fq2d_load(&b);
+    auto comp = [&](const Fq2& x) { return par ? x.c1 : x.c0; };
+    bad += !fq_eq((ad * bd).v, comp(a * b));
+    bad += !fq_eq(fq2_sqr(ad).v, comp(fq2_sqr(a)));
+    bad += !fq_eq(fq2_mul_xi(ad).v, comp(fq2_mul_xi(a)));
+    bad += !fq_eq(fq2_conj(ad).v, comp(fq2_conj(a)));
+    bad += !fq_eq(fq2_inv(ad).v, comp(fq2_inv(a)));
+    bad += !fq_eq(fq2_mul_fq(ad, k).v, comp(fq2_mul_fq(a, k)));
+    bad += !fq_eq((ad + bd).v, comp(a + b));
+    bad += !fq_eq((ad - bd).v, comp(a - b));
+    bad += !fq_eq(fq2_dbl(ad).v, comp(fq2_dbl(a)));
+    bad += !fq_eq((-ad).v, comp(-a));
+    bad += !fq_eq(fq2d_one().v, comp(fq2_one()));
+    {  // unary minus right after a subtraction of a product (the line_add shape)
+      Fq2d x = ad - bd * ad;
+      Fq2d n1 = -x, n2 = fq2d_zero() - x;
+      bad += !fq_eq(n1.v, n2.v);
+      Fq2 xs = a - b * a;
+      bad += !fq_eq(n1.v, comp(-xs));
+    }
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
 }  // namespace bn254
 namespace keaki_internal {
 keaki_status selftest_field_run(keaki_hip_ctx* ctx, uint32_t blocks, uint32_t iters, uint32_t seed, void* d_mismatches) {
   hipLaunchKernelGGL(bn254::k_selftest_field, dim3(blocks), dim3(256), 0, ctx->stream, seed, iters, (unsigned long long*)d_mismatches);
+  hipLaunchKernelGGL(bn254::k_selftest_fq2d, dim3(blocks), dim3(64), 0, ctx->stream, seed, iters > 8 ? 8u : iters, (unsigned long long*)d_mismatches);
   return launch_check(ctx, "selftest_field");
 }
 }  // namespace keaki_internal

@@ -23,7 +23,7 @@ EXPORTS = [
     "keaki_hip_g1_mul_batch", "keaki_hip_g2_mul_batch", "keaki_hip_g1_mul_batch_dev", "keaki_hip_g2_mul_batch_dev",
     "keaki_hip_pairing_batch", "keaki_hip_pairing_batch_dev",
     "keaki_hip_encap_batch", "keaki_hip_encap_batch_dev", "keaki_hip_decap_batch", "keaki_hip_decap_batch_dev",
-    "keaki_hip_selftest_field", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
+    "keaki_hip_selftest_field", "keaki_hip_final_exp_batch", "keaki_hip_miller_loop_batch", "keaki_hip_g2_prepare", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
 ]
 
 KEAKI_ERR_TOO_LARGE = -5
@@ -78,6 +78,8 @@ def load_library():
         lib.keaki_hip_decap_batch.argtypes = [vp, vp, vp, sz, vp, vp, sz]
         lib.keaki_hip_decap_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, sz]
         lib.keaki_hip_selftest_field.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+        lib.keaki_hip_final_exp_batch.argtypes = [vp, vp, sz, vp]
+        lib.keaki_hip_miller_loop_batch.argtypes = [vp, vp, vp, sz, vp]
         lib.keaki_hip_set_timing.argtypes = [vp, i32]
         lib.keaki_hip_last_msm_bucket_ms.argtypes = [vp]
         lib.keaki_hip_last_msm_bucket_ms.restype = C.c_float
@@ -234,6 +236,25 @@ class KeakiHip:
 
     def pairing_batch_dev(self, d_g1: int, d_g2: int, stride: int, n: int, d_gt: int):
         self._ck(self.lib.keaki_hip_pairing_batch_dev(self.ctx, C.c_void_p(d_g1), C.c_void_p(d_g2), stride, n, C.c_void_p(d_gt)))
+
+    def g2_prepare(self, g2) -> np.ndarray:
+        """line table of a fixed Q: (96, 2 parities, 3 coefficients, 4 limbs) Montgomery"""
+        q = _np(g2); out = np.zeros(96 * 2 * 3 * 4, np.uint64)
+        self.lib.keaki_hip_g2_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        self._ck(self.lib.keaki_hip_g2_prepare(self.ctx, _ptr(q), _ptr(out), out.nbytes))
+        return out.reshape(96, 2, 3, 4)
+
+    def miller_loop_batch(self, g1, g2) -> np.ndarray:
+        p = _np(g1, 8); q = _np(g2, 16); n = p.shape[0]
+        out = np.zeros((n, 48), np.uint64)
+        self._ck(self.lib.keaki_hip_miller_loop_batch(self.ctx, _ptr(p), _ptr(q), n, _ptr(out)))
+        return out
+
+    def final_exp_batch(self, f_mont) -> np.ndarray:
+        f = _np(f_mont, 48); n = f.shape[0]
+        out = np.zeros((n, 384), np.uint8)
+        self._ck(self.lib.keaki_hip_final_exp_batch(self.ctx, _ptr(f), n, _ptr(out)))
+        return out
 
     # ---- KEM composites
     def encap_batch(self, com, tau_g2, points, values, rs, msg_len: int = 32):

@@ -267,3 +267,47 @@ def test_msm_precomputed_tables(oc, hip, rand_fr, N):
         assert not np.any(jac_to_aff(z))
     finally:
         srs.free()
+
+
+def test_g2_line_table_vs_oracle(oc, py, hip):
+    """Every line coefficient the lane-pair Miller loop tabulates for a fixed Q (the G2Prepared of ark-ec, but along the
+    device's own NAF of 6z+2) against the big-int oracle's line formulas (bn254_py._line_double / _line_add)."""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("devconst", os.path.join(root, "keaki_amd", "csrc", "gen_constants.py"))
+    g = importlib.util.module_from_spec(spec); spec.loader.exec_module(g)
+    naf = g.naf_6z2()
+    _, g2 = oc.generators()
+    for k in (1, 0xC0FFEE):
+        qw = hip.g2_mul_batch(g2, mont(oc, [k]))[0]
+        q = oc.g2_to_ints(qw)[0]
+        r = (q[0], q[1], py.F2_ONE); exp = []
+        negq = py.g2_neg(q)
+        for i in range(len(naf) - 2, -1, -1):
+            r, l = py._line_double(r); exp.append(l)
+            if naf[i]:
+                r, l = py._line_add(r, q if naf[i] == 1 else negq); exp.append(l)
+        q1 = py._mul_by_char(q); q2 = py._mul_by_char(q1); q2 = (q2[0], py.f2_neg(q2[1]))
+        r, l = py._line_add(r, q1); exp.append(l)
+        r, l = py._line_add(r, q2); exp.append(l)
+        tab = hip.g2_prepare(qw)
+        vals = oc.limbs_to_ints(oc.fq_from_mont(tab.reshape(-1, 4)))
+        for li, e in enumerate(exp):
+            got = tuple((vals[(li * 2 + 0) * 3 + c], vals[(li * 2 + 1) * 3 + c]) for c in range(3))
+            assert got == e, (k, li)
+
+
+def test_miller_and_final_exp_stages(oc, hip, rand_fr):
+    """Stage-wise: device final exponentiation of the ORACLE's Miller output, and oracle final exponentiation of the DEVICE's
+    Miller output (the two Miller loops differ by subfield factors only, which the final exponentiation kills)."""
+    g1, g2 = oc.generators()
+    P = hip.g1_mul_batch(g1, mont(oc, rand_fr(5, 71)))
+    Q = hip.g2_mul_batch(g2, mont(oc, rand_fr(5, 72)))
+    exp = oc.pairing_batch(P, Q)
+    f_or = np.stack([oc.miller_loop_raw(P[i], Q[i]) for i in range(5)])
+    assert np.array_equal(hip.final_exp_batch(f_or), exp)
+    f_dev = hip.miller_loop_batch(P, Q)
+    for i in range(5):
+        e = oc.final_exp_raw(f_dev[i])
+        canon = oc.fq_from_mont(e.reshape(-1, 4)).tobytes()
+        assert canon == exp[i].tobytes()
