@@ -125,7 +125,7 @@ void keaki_hip_ctx_destroy(keaki_hip_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf* b : {&ctx->digits, &ctx->hist, &ctx->offsets, &ctx->cursor, &ctx->sorted, &ctx->buckets, &ctx->partials, &ctx->wsums,
                     &ctx->bsums, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->io_a, &ctx->io_b, &ctx->io_c, &ctx->io_d, &ctx->io_e,
-                    &ctx->fb_scalars, &ctx->fb_g1_gen, &ctx->fb_g2_gen, &ctx->fb_com, &ctx->fb_tau, &ctx->perm, &ctx->g2gen_lines})
+                    &ctx->fb_scalars, &ctx->fb_g1_gen, &ctx->fb_g2_gen, &ctx->fb_com, &ctx->fb_tau, &ctx->perm, &ctx->g2gen_lines, &ctx->gt_tab_a, &ctx->gt_tab_b, &ctx->gt_base})
     if (b->p) (void)hipFree(b->p);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -343,29 +343,20 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
   // generator g2 in device memory for the pairing's second slot (src/kem.rs:30 pairs with E::G2Affine::generator())
   ST_TRY(g2_generator_to(ctx, ctx->tmp_c.p));
   const size_t FB = 32 * 256;
-  if (n >= 256) {
+  const bool use_tables = n >= 256;
+  if (use_tables && !ctx->fb_ready) {
     // fixed-base window tables (see ec_batch.cuh): generators once per context, C and [tau]_2 per batch
-    if (!ctx->fb_ready) {
-      ST_TRY(reserve(ctx, ctx->fb_scalars, FB * 32));
-      ST_TRY(reserve(ctx, ctx->fb_g1_gen, FB * G1_AFF_BYTES + G1_AFF_BYTES));
-      ST_TRY(reserve(ctx, ctx->fb_g2_gen, FB * G2_AFF_BYTES));
-      ST_TRY(reserve(ctx, ctx->fb_com, FB * G1_AFF_BYTES));
-      ST_TRY(reserve(ctx, ctx->fb_tau, FB * G2_AFF_BYTES));
-      ST_TRY(fb_table_scalars_run(ctx, ctx->fb_scalars.p));
-      void* g1pt = (char*)ctx->fb_g1_gen.p + FB * G1_AFF_BYTES;   // scratch slot behind the table
-      ST_TRY(g1_generator_to(ctx, g1pt));
-      ST_TRY(g1_fb_table_run(ctx, g1pt, ctx->fb_scalars.p, ctx->fb_g1_gen.p));
-      ST_TRY(g2_fb_table_run(ctx, ctx->tmp_c.p, ctx->fb_scalars.p, ctx->fb_g2_gen.p));
-      ctx->fb_ready = true;
-    }
-    ST_TRY(g1_fb_table_run(ctx, d_com_aff, ctx->fb_scalars.p, ctx->fb_com.p));
-    ST_TRY(g2_fb_table_run(ctx, d_tau_g2_aff, ctx->fb_scalars.p, ctx->fb_tau.p));
-    ST_TRY(encap_g1_fixed_run(ctx, ctx->fb_com.p, ctx->fb_g1_gen.p, d_values, d_r, n, ctx->tmp_a.p));
-    ST_TRY(encap_g2_fixed_run(ctx, ctx->fb_tau.p, ctx->fb_g2_gen.p, d_points, d_r, n, d_ct_out_aff));
-  } else {
-    // small batches: the ladders are cheaper than building two 8192-entry tables
-    ST_TRY(encap_g1_run(ctx, d_com_aff, d_values, d_r, n, ctx->tmp_a.p));
-    ST_TRY(encap_g2_run(ctx, d_tau_g2_aff, d_points, d_r, n, d_ct_out_aff));
+    ST_TRY(reserve(ctx, ctx->fb_scalars, FB * 32));
+    ST_TRY(reserve(ctx, ctx->fb_g1_gen, FB * G1_AFF_BYTES + G1_AFF_BYTES));
+    ST_TRY(reserve(ctx, ctx->fb_g2_gen, FB * G2_AFF_BYTES));
+    ST_TRY(reserve(ctx, ctx->fb_com, FB * G1_AFF_BYTES));
+    ST_TRY(reserve(ctx, ctx->fb_tau, FB * G2_AFF_BYTES));
+    ST_TRY(fb_table_scalars_run(ctx, ctx->fb_scalars.p));
+    void* g1pt = (char*)ctx->fb_g1_gen.p + FB * G1_AFF_BYTES;   // scratch slot behind the table
+    ST_TRY(g1_generator_to(ctx, g1pt));
+    ST_TRY(g1_fb_table_run(ctx, g1pt, ctx->fb_scalars.p, ctx->fb_g1_gen.p));
+    ST_TRY(g2_fb_table_run(ctx, ctx->tmp_c.p, ctx->fb_scalars.p, ctx->fb_g2_gen.p));
+    ctx->fb_ready = true;
   }
   // the second pairing slot is the constant generator g2: its line sequence (ark-ec's G2Prepared) is built once per context
   if (!ctx->g2gen_lines_ready) {
@@ -373,7 +364,48 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
     ST_TRY(g2_prepare_run(ctx, ctx->tmp_c.p, ctx->g2gen_lines.p));
     ctx->g2gen_lines_ready = true;
   }
-  ST_TRY(pairing_run(ctx, ctx->tmp_a.p, ctx->tmp_c.p, 0, n, gt, ctx->g2gen_lines.p));
+  // ciphertexts ct_i = r_i [tau]_2 - (r_i alpha_i) g2
+  if (use_tables) {
+    ST_TRY(g2_fb_table_run(ctx, d_tau_g2_aff, ctx->fb_scalars.p, ctx->fb_tau.p));
+    ST_TRY(encap_g2_fixed_run(ctx, ctx->fb_tau.p, ctx->fb_g2_gen.p, d_points, d_r, n, d_ct_out_aff));
+  } else {
+    ST_TRY(encap_g2_run(ctx, d_tau_g2_aff, d_points, d_r, n, d_ct_out_aff));
+  }
+  const char* gt_env = getenv("KEAKI_ENCAP_GT");
+  const size_t gt_threshold = gt_env ? (size_t)atoll(gt_env) : (size_t)65536;
+  if (n >= gt_threshold) {
+    // large batches: GT_i = A^(r_i) B^(-beta_i r_i) with A = e(C, g2), B = e(g1, g2) (see pairing.cuh): no pairing per item
+    ST_TRY(reserve(ctx, ctx->gt_base, 2 * 384 + G1_AFF_BYTES));
+    char* gb = (char*)ctx->gt_base.p;
+    if (!ctx->gt_b_ready) {
+      ST_TRY(reserve(ctx, ctx->gt_tab_b, gt_table_bytes()));
+      ST_TRY(g1_generator_to(ctx, gb + 768));
+      ST_TRY(pairing_raw_fixed_run(ctx, gb + 768, 1, ctx->g2gen_lines.p, gb + 384));
+      ST_TRY(gt_table_run(ctx, gb + 384, ctx->gt_tab_b.p));
+      ctx->gt_b_ready = true;
+    }
+    // A depends on the commitment only: reuse the table while the caller keeps encrypting to the same commitment
+    uint64_t com_host[8];
+    HIP_TRY(ctx, hipMemcpyAsync(com_host, d_com_aff, 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->gt_a_valid || memcmp(com_host, ctx->gt_a_com, 64) != 0) {
+      ST_TRY(reserve(ctx, ctx->gt_tab_a, gt_table_bytes()));
+      ST_TRY(pairing_raw_fixed_run(ctx, d_com_aff, 1, ctx->g2gen_lines.p, gb));
+      ST_TRY(gt_table_run(ctx, gb, ctx->gt_tab_a.p));
+      memcpy(ctx->gt_a_com, com_host, 64);
+      ctx->gt_a_valid = true;
+    }
+    ST_TRY(gt_encap_exp_run(ctx, ctx->gt_tab_a.p, ctx->gt_tab_b.p, d_values, d_r, n, gt));
+  } else {
+    // per-item pairing e(r_i (C - beta_i g1), g2) with the tabulated lines of g2
+    if (use_tables) {
+      ST_TRY(g1_fb_table_run(ctx, d_com_aff, ctx->fb_scalars.p, ctx->fb_com.p));
+      ST_TRY(encap_g1_fixed_run(ctx, ctx->fb_com.p, ctx->fb_g1_gen.p, d_values, d_r, n, ctx->tmp_a.p));
+    } else {
+      ST_TRY(encap_g1_run(ctx, d_com_aff, d_values, d_r, n, ctx->tmp_a.p));
+    }
+    ST_TRY(pairing_run(ctx, ctx->tmp_a.p, ctx->tmp_c.p, 0, n, gt, ctx->g2gen_lines.p));
+  }
   if (d_key_out && msg_len) ST_TRY(blake3_gt_run(ctx, gt, n, d_key_out, msg_len));
   return KEAKI_OK;
 }

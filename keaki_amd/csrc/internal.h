@@ -29,7 +29,10 @@ struct keaki_hip_ctx {
   // grow-only workspaces (all used in stream order)
   keaki_internal::DevBuf digits, hist, offsets, cursor, sorted, buckets, partials, wsums, bsums, tmp_a, tmp_b, tmp_c, io_a, io_b, io_c, io_d, io_e;
   // fixed-base window tables for encapsulate: generator tables are built once per context, the C / [tau]_2 tables per batch
-  keaki_internal::DevBuf fb_scalars, fb_g1_gen, fb_g2_gen, fb_com, fb_tau, perm, g2gen_lines;
+  keaki_internal::DevBuf fb_scalars, fb_g1_gen, fb_g2_gen, fb_com, fb_tau, perm, g2gen_lines, gt_tab_a, gt_tab_b, gt_base;
+  bool gt_b_ready = false;
+  bool gt_a_valid = false;
+  uint64_t gt_a_com[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // commitment the cached A-table belongs to
   bool g2gen_lines_ready = false;
   bool fb_ready = false;
   // instrumentation
@@ -72,6 +75,10 @@ keaki_status encap_g1_run(keaki_hip_ctx* ctx, const void* d_com, const void* d_v
 keaki_status encap_g2_run(keaki_hip_ctx* ctx, const void* d_tau_g2, const void* d_points, const void* d_r, size_t n, void* d_out);
 keaki_status pairing_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, int g2_stride, size_t n, void* d_gt, const void* d_fixed_lines = nullptr);
 size_t g2_prepared_bytes();
+keaki_status pairing_raw_fixed_run(keaki_hip_ctx* ctx, const void* d_g1, size_t n, const void* d_lines, void* d_out);
+size_t gt_table_bytes();
+keaki_status gt_table_run(keaki_hip_ctx* ctx, const void* d_base, void* d_table);
+keaki_status gt_encap_exp_run(keaki_hip_ctx* ctx, const void* d_tab_a, const void* d_tab_b, const void* d_betas, const void* d_rs, size_t n, void* d_gt);
 keaki_status miller_only_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, size_t n, void* d_out);
 keaki_status final_exp_only_run(keaki_hip_ctx* ctx, const void* d_in, size_t n, void* d_gt);
 keaki_status g2_prepare_run(keaki_hip_ctx* ctx, const void* d_q, void* d_lines);   // line sequence of a fixed Q

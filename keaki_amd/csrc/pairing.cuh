@@ -379,6 +379,97 @@ static __global__ void __launch_bounds__(64) k_g2_prepare(const G2Aff* __restric
   miller_loop(&f, &dummy, &qx, &qy, nullptr, lines_out);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Encapsulation at scale: no pairing per item. In the loop of src/vec.rs:63-66 the commitment C is the same for every
+// item, so by bilinearity
+//     e(r (C - beta g1), g2) = A^r * B^(-beta r),      A = e(C, g2),  B = e(g1, g2)
+// with A, B FIXED for the batch: two fixed-base exponentiations in GT with 8-bit window tables T[j][d] = base^(d 2^(8j))
+// (32 x 256 Fq12 entries per base) = at most 64 Fq12 products per item instead of a Miller loop + final exponentiation
+// (~5x fewer Fq products). The value -- hence the serialised bytes and the key -- is identical.
+// GT elements are stored in the lane-pair order: 12 Fq per element, slot 2k + parity = Fq2 coefficient k, component parity
+// (which is also ark-serialize's coefficient order).
+// ---------------------------------------------------------------------------------------------
+constexpr u32 GT_WINDOWS = 32, GT_ENTRIES = 256;
+
+KDEV void gt_load(Fq12* f, const Fq* __restrict__ src) {
+  Fq2d* c = reinterpret_cast<Fq2d*>(f);
+  const u32 par = lane_odd();
+#pragma unroll
+  for (int k = 0; k < 6; k++) c[k].v = src[2 * k + par];
+}
+KDEV void gt_store(Fq* __restrict__ dst, const Fq12* f) {
+  const Fq2d* c = reinterpret_cast<const Fq2d*>(f);
+  const u32 par = lane_odd();
+#pragma unroll
+  for (int k = 0; k < 6; k++) dst[2 * k + par] = c[k].v;
+}
+// out[i] = e(P_i, Q_fixed) as a raw GT element (12 Fq, Montgomery). Lines of the fixed Q are given. Two lanes per item.
+static __global__ void __launch_bounds__(64, 2) k_pairing_raw_fixed(const G1Aff* __restrict__ ps, u32 n, const Line* __restrict__ fixed_lines,
+                                                                   Fq* __restrict__ out) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 item = t >> 1;
+  const bool live = item < n;
+  const u32 i = live ? item : (n - 1);
+  G1Aff p = ps[i];
+  Fq2d dummy = fq2d_zero();
+  Fq12 f, e;
+  miller_loop(&f, &p, &dummy, &dummy, fixed_lines, nullptr);
+  final_exponentiation(&e, &f);
+  if (aff_is_inf(p)) fq12_set_one(&e);
+  if (live) gt_store(out + (size_t)12 * i, &e);
+}
+// table[(j * 256 + d)] = base^(d * 2^(8 j)).  Step 1: one wave, lane pair j holds base^(2^(8j)) (8 j cyclotomic squarings).
+static __global__ void __launch_bounds__(64, 2) k_gt_table_bases(const Fq* __restrict__ base, Fq* __restrict__ table) {
+  const u32 j = threadIdx.x >> 1;   // 32 pairs
+  Fq12 x;
+  gt_load(&x, base);
+#pragma unroll 1
+  for (u32 s = 0; s < 8 * (GT_WINDOWS - 1); s++) {
+    if (s < 8 * j) fq12_cyc_sqr(&x, &x);       // pair-uniform predicate: both lanes of a pair take the same side
+  }
+  gt_store(table + (size_t)(j * GT_ENTRIES + 1) * 12, &x);
+}
+// Step 2: pair (j, d), d >= 2: table[j][d] = table[j][1]^d by square-and-multiply; d = 0 -> one (never multiplied in, kept for clarity)
+static __global__ void __launch_bounds__(64, 2) k_gt_table_fill(Fq* __restrict__ table) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 pairi = t >> 1;                   // 0 .. 32*256-1
+  const u32 j = pairi >> 8, d = pairi & 255u;
+  Fq12 b, acc;
+  gt_load(&b, table + (size_t)(j * GT_ENTRIES + 1) * 12);
+  fq12_set_one(&acc);
+#pragma unroll 1
+  for (int bit = 7; bit >= 0; bit--) {
+    fq12_cyc_sqr(&acc, &acc);                 // squaring one is one: harmless before the first set bit
+    if ((d >> bit) & 1u) fq12_mul(&acc, &acc, &b);
+  }
+  if (d != 1) gt_store(table + (size_t)(j * GT_ENTRIES + d) * 12, &acc);
+}
+// gt_out[i] = serialize(A^(r_i) * B^(-(r_i * beta_i)))   (tables of A and B). Two lanes per item.
+static __global__ void __launch_bounds__(64, 2) k_gt_encap_exp(const Fq* __restrict__ tab_a, const Fq* __restrict__ tab_b, const Fr* __restrict__ betas,
+                                                              const Fr* __restrict__ rs, u32 n, u32* __restrict__ gt_out) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 item = t >> 1;
+  const bool live = item < n;
+  const u32 i = live ? item : (n - 1);
+  Fr r = rs[i];
+  Fr m = fp_neg<FrParams>(fp_mul<FrParams>(r, betas[i]));
+  u32 u[8], v[8];
+  fp_from_mont<FrParams>(u, r);
+  fp_from_mont<FrParams>(v, m);
+  Fq12 acc, e;
+  fq12_set_one(&acc);
+#pragma unroll 1
+  for (u32 j = 0; j < GT_WINDOWS; j++) {
+    u32 da = u[0] & 255u, db = v[0] & 255u;
+#pragma unroll
+    for (int w = 0; w < 7; w++) { u[w] = (u[w] >> 8) | (u[w + 1] << 24); v[w] = (v[w] >> 8) | (v[w + 1] << 24); }
+    u[7] >>= 8; v[7] >>= 8;
+    if (da) { gt_load(&e, tab_a + (size_t)(j * GT_ENTRIES + da) * 12); fq12_mul(&acc, &acc, &e); }
+    if (db) { gt_load(&e, tab_b + (size_t)(j * GT_ENTRIES + db) * 12); fq12_mul(&acc, &acc, &e); }
+  }
+  if (live) gt_serialize(gt_out + (size_t)96 * i, &acc);
+}
+
 // debug / test entry: Miller loop only. out: n x 12 Fq (Montgomery), single-element layout.
 static __global__ void __launch_bounds__(64) k_miller_only(const G1Aff* __restrict__ ps, const G2Aff* __restrict__ qs, u32 n, Fq* __restrict__ out) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -15,6 +15,22 @@ keaki_status g2_prepare_run(keaki_hip_ctx* ctx, const void* d_q, void* d_lines) 
   hipLaunchKernelGGL(k_g2_prepare, dim3(1), dim3(64), 0, ctx->stream, (const G2Aff*)d_q, (Line*)d_lines);
   return launch_check(ctx, "g2_prepare");
 }
+keaki_status pairing_raw_fixed_run(keaki_hip_ctx* ctx, const void* d_g1, size_t n, const void* d_lines, void* d_out) {
+  hipLaunchKernelGGL(k_pairing_raw_fixed, dim3(cdiv(2 * n, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_g1, (u32)n, (const Line*)d_lines, (Fq*)d_out);
+  return launch_check(ctx, "pairing_raw_fixed");
+}
+size_t gt_table_bytes() { return (size_t)GT_WINDOWS * GT_ENTRIES * 12 * sizeof(Fq); }
+// d_table[j][d] = base^(d 2^(8j)); d_base: 12 Fq
+keaki_status gt_table_run(keaki_hip_ctx* ctx, const void* d_base, void* d_table) {
+  hipLaunchKernelGGL(k_gt_table_bases, dim3(1), dim3(64), 0, ctx->stream, (const Fq*)d_base, (Fq*)d_table);
+  hipLaunchKernelGGL(k_gt_table_fill, dim3(cdiv(2 * GT_WINDOWS * GT_ENTRIES, 64)), dim3(64), 0, ctx->stream, (Fq*)d_table);
+  return launch_check(ctx, "gt_table");
+}
+keaki_status gt_encap_exp_run(keaki_hip_ctx* ctx, const void* d_tab_a, const void* d_tab_b, const void* d_betas, const void* d_rs, size_t n, void* d_gt) {
+  hipLaunchKernelGGL(k_gt_encap_exp, dim3(cdiv(2 * n, 64)), dim3(64), 0, ctx->stream, (const Fq*)d_tab_a, (const Fq*)d_tab_b, (const Fr*)d_betas,
+                     (const Fr*)d_rs, (u32)n, (u32*)d_gt);
+  return launch_check(ctx, "gt_encap_exp");
+}
 keaki_status miller_only_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, size_t n, void* d_out) {
   hipLaunchKernelGGL(k_miller_only, dim3(cdiv(2 * n, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_g1, (const G2Aff*)d_g2, (u32)n, (Fq*)d_out);
   return launch_check(ctx, "miller_only");

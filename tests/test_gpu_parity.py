@@ -311,3 +311,34 @@ def test_miller_and_final_exp_stages(oc, hip, rand_fr):
         e = oc.final_exp_raw(f_dev[i])
         canon = oc.fq_from_mont(e.reshape(-1, 4)).tobytes()
         assert canon == exp[i].tobytes()
+
+
+def test_encap_gt_fixed_base_path_vs_oracle(oc, py, hip, rand_fr, monkeypatch):
+    """Large batches compute GT_i = A^(r_i) * B^(-beta_i r_i) with A = e(C, g2), B = e(g1, g2) (fixed-base GT tables) instead of
+    one pairing per item. Forced here with a low threshold; the bytes must equal the oracle's serial e(r(C - beta g1), g2)."""
+    monkeypatch.setenv("KEAKI_ENCAP_GT", "64")
+    g1, g2 = oc.generators()
+    n = 300
+    tau, c0, c1 = rand_fr(3, 81)
+    tau_g2 = hip.g2_mul_batch(g2, mont(oc, [tau]))[0]
+    a, v, r = rand_fr(n, 82), rand_fr(n, 83), rand_fr(n, 84)
+    v[0] = 0; r[1] = 1; r[2] = py.R - 1; v[3] = py.R - 1; r[4] = 0; v[5] = 1; r[5] = 255; r[6] = 256; r[7] = (1 << 248) + 5
+    A, V, Rr = mont(oc, a), mont(oc, v), mont(oc, r)
+    for c in (c0, c1):     # two commitments: exercises the per-commitment table cache
+        com = hip.g1_mul_batch(g1, mont(oc, [c]))[0]
+        for _ in range(2):
+            ct, gt, key = hip.encap_batch(com, tau_g2, A, V, Rr, 32)
+            ect, egt, ekey = oc.encap_batch(com, tau_g2, A, V, Rr, 32, threads=8)
+            assert np.array_equal(ct, ect) and np.array_equal(gt, egt) and np.array_equal(key, ekey)
+    # identity commitment: A = 1
+    z = np.zeros(8, np.uint64)
+    ct, gt, _ = hip.encap_batch(z, tau_g2, A[:128], V[:128], Rr[:128], 32)
+    ect, egt, _ = oc.encap_batch(z, tau_g2, A[:128], V[:128], Rr[:128], 32, threads=8)
+    assert np.array_equal(ct, ect) and np.array_equal(gt, egt)
+    # and the per-item pairing path agrees with it
+    monkeypatch.setenv("KEAKI_ENCAP_GT", "1000000000")
+    com = hip.g1_mul_batch(g1, mont(oc, [c0]))[0]
+    ct2, gt2, _ = hip.encap_batch(com, tau_g2, A, V, Rr, 32)
+    monkeypatch.setenv("KEAKI_ENCAP_GT", "64")
+    ct3, gt3, _ = hip.encap_batch(com, tau_g2, A, V, Rr, 32)
+    assert np.array_equal(gt2, gt3) and np.array_equal(ct2, ct3)
