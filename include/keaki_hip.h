@@ -91,6 +91,15 @@ keaki_status keaki_hip_msm_g2_dev(keaki_hip_ctx* ctx, const keaki_hip_srs_g2* sr
 keaki_status keaki_hip_g1_sum_dev(keaki_hip_ctx* ctx, const void* d_points_jac, size_t k, void* d_out_jac);
 keaki_status keaki_hip_g1_sum(keaki_hip_ctx* ctx, const uint64_t* points_jac, size_t k, uint64_t* out_jac);
 
+/* ---- FK23 batch openings: replaces kzg::open_fk (src/kzg.rs:157-203; caller src/vec.rs:40) ------------------------------
+ * All d = 2^log2d opening proofs of the polynomial p (d coefficients) at the d-th roots of unity, in O(d log d) group operations
+ * (three G1 FFTs + 2d scalar-mults on the GPU). The scalar-field inputs are prepared by the caller (keaki's own host-side work):
+ *   hat_a[2d]     = DFT_2d(0, ..., 0, p_0, ..., p_{d-1}) * (2d)^-1        (the 1/2d of the inverse transform folded in)
+ *   tw_2d[d]      = omega_2d^k,  tw_2d_inv[d] = omega_2d^-k   (k < d),    tw_d[d/2] = omega_d^k   (k < d/2)
+ * where omega_N is ark-poly's Radix2EvaluationDomain generator of order N. Uses srs[0..d). proofs_out_aff: d affine points. */
+keaki_status keaki_hip_open_fk(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, uint32_t log2d, const uint64_t* hat_a, const uint64_t* tw_2d,
+                               const uint64_t* tw_2d_inv, const uint64_t* tw_d, uint64_t* proofs_out_aff);
+
 /* ---- batched scalar multiplication: replaces `.mul(scalar)` (src/kem.rs:22,30,36,37; src/kzg.rs:57,60,135,144)
  * out[i] = scalars[i] * points[i]   (point_stride = 1) or scalars[i] * points[0] (point_stride = 0).
  * points affine in, affine out. */

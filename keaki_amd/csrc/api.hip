@@ -474,6 +474,27 @@ keaki_status keaki_hip_decap_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_af
   return KEAKI_OK;
 }
 
+// ---- FK23 batch openings: replaces kzg::open_fk (src/kzg.rs:157-203) ----------------------------------------------------------
+keaki_status keaki_hip_open_fk(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, uint32_t log2d, const uint64_t* hat_a, const uint64_t* tw_2d,
+                               const uint64_t* tw_2d_inv, const uint64_t* tw_d, uint64_t* proofs_out_aff) {
+  CTX_GUARD(ctx);
+  if (!srs || !hat_a || !tw_2d || !tw_2d_inv || (!tw_d && log2d > 0) || !proofs_out_aff || log2d > 27) return fail(ctx, KEAKI_ERR_BAD_ARG, "open_fk: bad argument");
+  const size_t d = (size_t)1 << log2d;
+  if (d > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "open_fk: %zu coefficients but the SRS holds %zu points", d, srs->n);
+  // one staging buffer: hat_a (2d Fr) | tw_2d (d) | tw_2d_inv (d) | tw_d (d/2) | work (2d Jacobian) | proofs (d affine)
+  const size_t o_ha = 0, o_t1 = o_ha + 2 * d * 32, o_t2 = o_t1 + d * 32, o_t3 = o_t2 + d * 32, o_w = o_t3 + (d / 2 + 1) * 32, o_p = o_w + 2 * d * 96,
+               total = o_p + d * 64;
+  ST_TRY(reserve(ctx, ctx->io_d, total));
+  char* b = (char*)ctx->io_d.p;
+  hipStream_t st = ctx->stream;
+  HIP_TRY(ctx, hipMemcpyAsync(b + o_ha, hat_a, 2 * d * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(b + o_t1, tw_2d, d * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(b + o_t2, tw_2d_inv, d * 32, hipMemcpyHostToDevice, st));
+  if (d >= 2) HIP_TRY(ctx, hipMemcpyAsync(b + o_t3, tw_d, (d / 2) * 32, hipMemcpyHostToDevice, st));
+  ST_TRY(open_fk_run(ctx, srs->d, log2d, b + o_ha, b + o_t1, b + o_t2, b + o_t3, b + o_w, b + o_p));
+  return download(ctx, proofs_out_aff, b + o_p, d * 64);
+}
+
 // ---- test hook: line table of a fixed Q (MILLER_MAX_LINES x 2 parities x 3 Fq, Montgomery)
 keaki_status keaki_hip_g2_prepare(keaki_hip_ctx* ctx, const uint64_t* g2_aff, uint64_t* lines_out, size_t lines_out_bytes) {
   CTX_GUARD(ctx);

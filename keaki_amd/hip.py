@@ -23,7 +23,7 @@ EXPORTS = [
     "keaki_hip_g1_mul_batch", "keaki_hip_g2_mul_batch", "keaki_hip_g1_mul_batch_dev", "keaki_hip_g2_mul_batch_dev",
     "keaki_hip_pairing_batch", "keaki_hip_pairing_batch_dev",
     "keaki_hip_encap_batch", "keaki_hip_encap_batch_dev", "keaki_hip_decap_batch", "keaki_hip_decap_batch_dev",
-    "keaki_hip_selftest_field", "keaki_hip_final_exp_batch", "keaki_hip_miller_loop_batch", "keaki_hip_g2_prepare", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
+    "keaki_hip_selftest_field", "keaki_hip_open_fk", "keaki_hip_final_exp_batch", "keaki_hip_miller_loop_batch", "keaki_hip_g2_prepare", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
 ]
 
 KEAKI_ERR_TOO_LARGE = -5
@@ -78,6 +78,7 @@ def load_library():
         lib.keaki_hip_decap_batch.argtypes = [vp, vp, vp, sz, vp, vp, sz]
         lib.keaki_hip_decap_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, sz]
         lib.keaki_hip_selftest_field.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+        lib.keaki_hip_open_fk.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp, vp]
         lib.keaki_hip_final_exp_batch.argtypes = [vp, vp, sz, vp]
         lib.keaki_hip_miller_loop_batch.argtypes = [vp, vp, vp, sz, vp]
         lib.keaki_hip_set_timing.argtypes = [vp, i32]
@@ -254,6 +255,13 @@ class KeakiHip:
         f = _np(f_mont, 48); n = f.shape[0]
         out = np.zeros((n, 384), np.uint8)
         self._ck(self.lib.keaki_hip_final_exp_batch(self.ctx, _ptr(f), n, _ptr(out)))
+        return out
+
+    def open_fk(self, srs: "SrsG1", log2d: int, hat_a, tw_2d, tw_2d_inv, tw_d) -> np.ndarray:
+        d = 1 << log2d
+        ha = _np(hat_a, 4); t1 = _np(tw_2d, 4); t2 = _np(tw_2d_inv, 4); t3 = _np(tw_d, 4) if d >= 2 else np.zeros((1, 4), np.uint64)
+        out = np.zeros((d, 8), np.uint64)
+        self._ck(self.lib.keaki_hip_open_fk(self.ctx, srs.handle, log2d, _ptr(ha), _ptr(t1), _ptr(t2), _ptr(t3), _ptr(out)))
         return out
 
     # ---- KEM composites

@@ -206,8 +206,30 @@ Result<bool> verify(const KZGSetup& setup, const G1& commitment, const Fr& point
 }
 
 Result<std::vector<G1>> open_fk(const KZGSetup& setup, const std::vector<Fr>& p, size_t domain_size) {
-  vec::Radix2Domain d = vec::Radix2Domain::create(domain_size);
-  std::vector<Fr> el = d.elements();
+  const size_t d = p.size();
+  const bool pow2 = d >= 1 && (d & (d - 1)) == 0;
+  if (pow2 && domain_size == d && d <= setup.g1_pow().size()) {
+    // FK23 (src/kzg.rs:157-203): the three group FFTs and the 2d scalar-mults run on the GPU (keaki_hip_open_fk); the host
+    // prepares the scalar-field side exactly as the reference does with ark-poly: hat_a = DFT_2d(0,..,0,p), twiddles.
+    unsigned log2d = 0;
+    while ((size_t(1) << log2d) < d) log2d++;
+    vec::Radix2Domain d2 = vec::Radix2Domain::create(2 * d);
+    std::vector<Fr> a(2 * d);
+    for (size_t i = 0; i < d; i++) a[d + i] = p[i];
+    std::vector<Fr> hat_a = d2.fft(a);
+    for (auto& x : hat_a) x = x * d2.size_inv;            // the 1/(2d) of the inverse transform, folded into the pointwise factor
+    std::vector<Fr> tw(d), twi(d), twd(d / 2 + 1);
+    Fr w = Fr::one(), wi = Fr::one();
+    for (size_t k = 0; k < d; k++) { tw[k] = w; twi[k] = wi; w = w * d2.group_gen; wi = wi * d2.group_gen_inv; }
+    for (size_t k = 0; k < d / 2; k++) twd[k] = tw[2 * k];  // omega_d = omega_2d^2
+    std::vector<G1> out(d);
+    const Device& dev = *setup.device();
+    dev.check(keaki_hip_open_fk(dev.ctx(), setup.srs(), log2d, hat_a[0].l, tw[0].l, twi[0].l, twd[0].l, out[0].w.data()));
+    return Result<std::vector<G1>>::Ok(std::move(out));
+  }
+  // shapes FK23 does not cover (the reference would panic on them): one opening per root of unity
+  vec::Radix2Domain dd = vec::Radix2Domain::create(domain_size);
+  std::vector<Fr> el = dd.elements();
   std::vector<G1> out;
   out.reserve(el.size());
   for (const Fr& z : el) {

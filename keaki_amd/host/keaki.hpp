@@ -128,8 +128,8 @@ class KZGSetup {
 Result<G1> commit(const KZGSetup& setup, const DensePolynomial& p);                          // src/kzg.rs:89-101
 Result<G1> open(const KZGSetup& setup, const DensePolynomial& p, const Fr& point);           // src/kzg.rs:104-124
 Result<bool> verify(const KZGSetup& setup, const G1& commitment, const Fr& point, const Fr& value, const G1& proof);  // :127-151
-// all openings at the roots of unity of a size-d domain (src/kzg.rs:157-203). Round 1: O(d^2) via
-// per-point `open`; the FK23 G1-FFT version is the "next" row.
+// all openings at the roots of unity of a size-d domain (src/kzg.rs:157-203): FK23 -- three G1 FFTs + 2d scalar-mults on
+// the GPU (keaki_hip_open_fk) when p.size() == domain_size is a power of two; per-point `open` otherwise.
 Result<std::vector<G1>> open_fk(const KZGSetup& setup, const std::vector<Fr>& p, size_t domain_size);
 
 }  // namespace kzg

@@ -536,6 +536,34 @@ def poly_quotient(coeffs, z):
 def kzg_open(g1_pow, coeffs, z):
     return kzg_commit(g1_pow, poly_quotient(coeffs, z))
 
+def fr_root_of_unity(n):
+    """ark-poly Radix2EvaluationDomain generator of order n (n a power of two <= 2^28): 5^((r-1)/2^28) ^ (2^28 / n)"""
+    w = pow(5, (R - 1) >> 28, R)
+    return pow(w, (1 << 28) // n, R)
+
+def kzg_open_fk(g1_pow, p):
+    """src/kzg.rs:157-203 restated literally (naive O(d^2) DFTs): FK23 all-openings at the d-th roots of unity, d = len(p)."""
+    d = len(p)
+    n2 = 2 * d
+    w2 = fr_root_of_unity(n2)
+    s = [g1_pow[d - 1 - i] for i in range(d)] + [None] * d
+    a = [0] * d + [c % R for c in p]
+    def g_dft(v, w):
+        out = []
+        for j in range(len(v)):
+            acc = None
+            for i, pt in enumerate(v):
+                acc = g1_add(acc, g1_mul(pt, pow(w, i * j, R)))
+            out.append(acc)
+        return out
+    hat_s = g_dft(s, w2)
+    hat_a = [sum(a[i] * pow(w2, i * j, R) for i in range(n2)) % R for j in range(n2)]
+    hat_h = [g1_mul(hat_s[i], hat_a[i]) for i in range(n2)]
+    inv = pow(n2, -1, R)
+    h_prime = [g1_mul(x, inv) for x in g_dft(hat_h, pow(w2, -1, R))]
+    h = h_prime[:d]
+    return g_dft(h, fr_root_of_unity(d) if d > 1 else 1)
+
 def kzg_verify(tau_g2, commitment, point, value, proof):
     """src/kzg.rs:127-151: e(C - [v]_1, g2) == e(proof, [tau]_2 - [point]_2)."""
     lhs = pairing(g1_add(commitment, g1_neg(g1_mul(G1_GEN, value))), G2_GEN)

@@ -195,3 +195,48 @@ def test_vec_encrypt_matches_serial_reference_loop(K, oc, py):
     serial = [K.encrypt(rng_b, s, com, pts[i], vals[i], msgs[i]) for i in range(n)]
     for b, c in zip(batched, serial):
         assert np.array_equal(b[0], c[0]) and b[1] == c[1]
+
+
+def test_open_fk_gpu_vs_oracle_and_per_point_open(K, oc, py):
+    """FK23 on the GPU (three G1 FFTs + 2d scalar-mults): against the oracle's literal restatement at d = 8 and against per-point
+    `open` + `verify` at d = 64 (the relation the reference asserts in src/kzg.rs:470-505)."""
+    rng = K.Rng(21)
+    secret = rng.fr_rand()
+    s = K.KZGSetup.setup(secret, 64)
+    tau = canon(oc, secret)[0]
+    g1p, _ = py.kzg_setup(tau, 8)
+    coeffs = [3, 1, 4, 1, 5, 9, 2, 6]
+    p8 = np.stack([K.fr(c) for c in coeffs])
+    got = oc.g1_to_ints(K.open_fk(s, p8, 8))
+    assert got == py.kzg_open_fk(g1p, coeffs)
+    # d = 64, random coefficients, including zero and top-heavy ones
+    p64 = np.stack([rng.fr_rand() for _ in range(64)])
+    p64[3] = 0
+    proofs = K.open_fk(s, p64, 64)
+    el = K.domain_elements(64)
+    com = K.commit(s, p64)
+    for i in (0, 1, 2, 31, 32, 63):
+        assert np.array_equal(proofs[i], K.open(s, p64, el[i]))
+        assert K.verify(s, com, el[i], K.poly_evaluate(p64, el[i]), proofs[i])
+    # d = 1 and d = 2 corner shapes
+    assert np.array_equal(K.open_fk(s, p64[:1], 1)[0], K.open(s, p64[:1], K.domain_elements(1)[0]))
+    pr2 = K.open_fk(s, p64[:2], 2)
+    el2 = K.domain_elements(2)
+    assert all(np.array_equal(pr2[i], K.open(s, p64[:2], el2[i])) for i in range(2))
+
+
+def test_laconic_ot_larger(K):
+    """tests/laconic_ot.rs flow at N_CHOICES = 255 (domain 256): vec_commit now runs FK23 on the GPU."""
+    N = 255
+    rng = K.Rng(22)
+    s = K.KZGSetup.setup(rng.fr_rand(), 256)
+    np_rng = np.random.default_rng(22)
+    bits = [int(b) for b in np_rng.integers(0, 2, N)]
+    commitment, proofs = K.vec_commit(rng, s, np.stack([K.fr(b) for b in bits]))
+    sets = [[np_rng.bytes(32) for _ in range(N)] for _ in range(2)]
+    el = K.domain_elements(N + K.PADDING_LEN)
+    ct0 = K.vec_encrypt(rng, s, commitment, el, np.stack([K.fr(0)] * N), sets[0])
+    ct1 = K.vec_encrypt(rng, s, commitment, el, np.stack([K.fr(1)] * N), sets[1])
+    chosen = [ct0[i] if bits[i] == 0 else ct1[i] for i in range(N)]
+    got = K.vec_decrypt(s, proofs, chosen)
+    assert all(got[i] == sets[bits[i]][i] for i in range(N))

@@ -222,3 +222,15 @@ def test_c_oracle_msm_g2_and_edges(oc, py):
     assert oc.g1_on_curve(base[0]) and oc.g2_on_curve(pts[0])
     bad = base[0].copy(); bad[0] ^= np.uint64(1)
     assert not oc.g1_on_curve(bad)
+
+
+def test_kzg_open_fk_restatement(py):
+    """src/kzg.rs:470-505 on BN254: FK23 proofs (literal restatement of src/kzg.rs:157-203) == per-point open, d = 4, SRS 16."""
+    g1p, tau_g2 = py.kzg_setup(987654321987654321, 16)
+    p = [1, 2, 3, 4]
+    fk = py.kzg_open_fk(g1p, p)
+    w = py.fr_root_of_unity(4)
+    pts = [pow(w, i, py.R) for i in range(4)]
+    assert fk == [py.kzg_open(g1p, p, z) for z in pts]
+    com = py.kzg_commit(g1p, p)
+    assert py.kzg_verify(tau_g2, com, pts[1], py.poly_eval(p, pts[1]), fk[1])
