@@ -325,6 +325,53 @@ static __global__ void __launch_bounds__(256) k_cnt_scatter(const u32* __restric
   }
 }
 
+
+// ---- heavy buckets ----------------------------------------------------------------------------------------------------
+// Structured scalars (0/1 coefficients, repeated values) can put millions of points into ONE bucket; a single lane would
+// need minutes for it. Buckets come size-sorted (perm[0] is the largest), so the first HEAVY_MAX entries of perm are
+// examined by a 2-D grid: block (b, s) accumulates slice s of bucket perm[b] with 256 lanes if that bucket holds at least
+// HEAVY_MIN points (otherwise it exits at once), k_msm_heavy_combine folds the slices, and k_msm_accumulate skips those
+// buckets. Uniformly random scalars never trigger it (buckets hold tens to hundreds of points).
+constexpr u32 HEAVY_MIN = 8192, HEAVY_MAX = 256, HEAVY_SLICES = 32;
+template <class F>
+__global__ void __launch_bounds__(256) k_msm_heavy(const Aff<F>* __restrict__ points, const u32* __restrict__ sorted, const u32* __restrict__ offsets,
+                                                   const u32* __restrict__ counts, const u32* __restrict__ perm, u32 nbuckets_total,
+                                                   Xyzz<F>* __restrict__ slices) {
+  __shared__ Xyzz<F> sh[256];
+  const u32 b = blockIdx.x, sl = blockIdx.y;
+  if (b >= nbuckets_total) return;
+  const u32 t = perm[b];
+  const u32 cnt = counts[t];
+  if (cnt < HEAVY_MIN) return;          // block-uniform
+  const u32 start = offsets[t];
+  const u32 per = (cnt + HEAVY_SLICES - 1) / HEAVY_SLICES;
+  const u32 lo = sl * per, hi = min(cnt, lo + per);
+  Xyzz<F> acc = xyzz_inf<F>();
+  for (u32 k = lo + threadIdx.x; k < hi; k += 256) {
+    u32 e = sorted[start + k];
+    Aff<F> p = points[e & 0x7FFFFFFFu];
+    acc = xyzz_add_mixed(acc, aff_cneg(p, (e >> 31) != 0));
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (u32 o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) slices[(size_t)b * HEAVY_SLICES + sl] = sh[0];
+}
+template <class F>
+__global__ void __launch_bounds__(64) k_msm_heavy_combine(const u32* __restrict__ counts, const u32* __restrict__ perm, u32 nbuckets_total,
+                                                          const Xyzz<F>* __restrict__ slices, Xyzz<F>* __restrict__ buckets) {
+  u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= HEAVY_MAX || b >= nbuckets_total) return;
+  const u32 t = perm[b];
+  if (counts[t] < HEAVY_MIN) return;
+  Xyzz<F> acc = xyzz_inf<F>();
+  for (u32 sl = 0; sl < HEAVY_SLICES; sl++) acc = xyzz_add(acc, slices[(size_t)b * HEAVY_SLICES + sl]);
+  buckets[t] = acc;
+}
+
 // ---- K4: bucket accumulation (dominant kernel) ----------------------------------------------------
 template <class F>
 __global__ void __launch_bounds__(256) k_msm_accumulate(const Aff<F>* __restrict__ points, const u32* __restrict__ sorted,
@@ -334,6 +381,7 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const Aff<F>* __restrict
   if (lane >= nbuckets_total) return;
   u32 t = perm[lane];
   u32 start = offsets[t], cnt = counts[t];
+  if (lane < HEAVY_MAX && cnt >= HEAVY_MIN) return;   // done by k_msm_heavy / k_msm_heavy_combine
   Xyzz<F> acc = xyzz_inf<F>();
   for (u32 k = 0; k < cnt; k++) {
     u32 e = sorted[start + k];

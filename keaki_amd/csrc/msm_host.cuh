@@ -113,6 +113,13 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   hipLaunchKernelGGL((k_msm_accumulate<F>), dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
                      (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
   ST_TRY(launch_check(ctx, "msm_accumulate"));
+  // heavy buckets (structured scalars only; the blocks exit immediately otherwise)
+  ST_TRY(reserve(ctx, ctx->heavy, (size_t)HEAVY_MAX * HEAVY_SLICES * sizeof(Xyzz<F>)));
+  hipLaunchKernelGGL((k_msm_heavy<F>), dim3(HEAVY_MAX, HEAVY_SLICES), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
+                     (const u32*)hist, (const u32*)perm, (u32)nb, (Xyzz<F>*)ctx->heavy.p);
+  hipLaunchKernelGGL((k_msm_heavy_combine<F>), dim3(cdiv(HEAVY_MAX, 64)), dim3(64), 0, st, (const u32*)hist, (const u32*)perm, (u32)nb,
+                     (const Xyzz<F>*)ctx->heavy.p, buckets);
+  ST_TRY(launch_check(ctx, "msm_heavy"));
   if (ctx->timing) (void)hipEventRecord(ctx->ev[2], st);
   hipLaunchKernelGGL((k_msm_reduce<F>), dim3(cdiv((size_t)rs.W * chunks, 64)), dim3(64), 0, st, (const Xyzz<F>*)buckets, rs, L, chunks, partials);
   // chunk partials -> (at most 128 per window) -> window sums

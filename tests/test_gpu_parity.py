@@ -342,3 +342,32 @@ def test_encap_gt_fixed_base_path_vs_oracle(oc, py, hip, rand_fr, monkeypatch):
     monkeypatch.setenv("KEAKI_ENCAP_GT", "64")
     ct3, gt3, _ = hip.encap_batch(com, tau_g2, A, V, Rr, 32)
     assert np.array_equal(gt2, gt3) and np.array_equal(ct2, ct3)
+
+
+def test_msm_structured_scalars_heavy_buckets(oc, hip, rand_fr):
+    """0/1 and repeated coefficients put tens of thousands of points into single buckets (the heavy-bucket path: sliced
+    accumulation by whole workgroups). Checked via the O(n) identity MSM(s, k_i G) == (sum s_i k_i) G, with and without tables."""
+    n = 1 << 17
+    g1, _ = oc.generators()
+    rng = np.random.default_rng(17)
+    k = rng.integers(0, 2**63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+    k[:, 3] &= np.uint64((1 << 60) - 1)
+    pts = hip.g1_mul_batch(g1, k)
+    one = oc.fr_to_mont(oc.ints_to_limbs([1]))[0]
+    seven = oc.fr_to_mont(oc.ints_to_limbs([7]))[0]
+    rnd = mont(oc, rand_fr(1, 99))[0]
+    cases = {"bits": np.where(rng.integers(0, 2, n)[:, None] == 1, one[None, :], np.zeros((1, 4), np.uint64)).astype(np.uint64),
+             "all_ones": np.repeat(one[None, :], n, 0), "all_equal_random": np.repeat(rnd[None, :], n, 0),
+             "two_values": np.where(rng.integers(0, 2, n)[:, None] == 1, seven[None, :], rnd[None, :]).astype(np.uint64)}
+    srs = hip.srs_g1_upload(pts)
+    try:
+        for tables in (False, True):
+            if tables:
+                hip.srs_g1_precompute(srs)
+            for name, sc in cases.items():
+                sc = np.ascontiguousarray(sc)
+                got = jac_to_aff(hip.msm_g1(srs, sc))
+                exp = oc.g1_mul_batch(g1, oc.fr_dot(sc, k).reshape(1, 4))[0]
+                assert np.array_equal(got, exp), (name, tables)
+    finally:
+        srs.free()
