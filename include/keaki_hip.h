@@ -96,8 +96,9 @@ keaki_status keaki_hip_g1_sum(keaki_hip_ctx* ctx, const uint64_t* points_jac, si
  * (three G1 FFTs + 2d scalar-mults on the GPU). The scalar-field inputs are prepared by the caller (keaki's own host-side work):
  *   hat_a[2d]     = DFT_2d(0, ..., 0, p_0, ..., p_{d-1}) * (2d)^-1        (the 1/2d of the inverse transform folded in)
  *   tw_2d[d]      = omega_2d^k,  tw_2d_inv[d] = omega_2d^-k   (k < d),    tw_d[d/2] = omega_d^k   (k < d/2)
- * where omega_N is ark-poly's Radix2EvaluationDomain generator of order N. Uses srs[0..d). proofs_out_aff: d affine points. */
-keaki_status keaki_hip_open_fk(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, uint32_t log2d, const uint64_t* hat_a, const uint64_t* tw_2d,
+ * where omega_N is ark-poly's Radix2EvaluationDomain generator of order N. Uses srs[0..d). proofs_out_aff: d affine points.
+ * The SRS-only transform hat_s = DFT_2d(reversed SRS) is computed on the first call for a given d and cached in the handle. */
+keaki_status keaki_hip_open_fk(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32_t log2d, const uint64_t* hat_a, const uint64_t* tw_2d,
                                const uint64_t* tw_2d_inv, const uint64_t* tw_d, uint64_t* proofs_out_aff);
 
 /* ---- batched scalar multiplication: replaces `.mul(scalar)` (src/kem.rs:22,30,36,37; src/kzg.rs:57,60,135,144)

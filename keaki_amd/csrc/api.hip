@@ -13,6 +13,9 @@ struct keaki_hip_srs_g1 {
   void* table = nullptr;
   size_t table_bytes = 0;
   int c_table = 0;
+  // FK23: hat_s = DFT_2d(reversed SRS) for the last requested d (2d Jacobian points), reused by later keaki_hip_open_fk calls
+  void* fk_hat_s = nullptr;
+  int fk_log2d = -1;
 };
 struct keaki_hip_srs_g2 {
   const void* d = nullptr;
@@ -175,6 +178,7 @@ void keaki_hip_srs_g1_free(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs) {
   if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
   if (srs->owned && srs->d) (void)hipFree((void*)srs->d);
   if (srs->table) (void)hipFree(srs->table);
+  if (srs->fk_hat_s) (void)hipFree(srs->fk_hat_s);
   delete srs;
 }
 keaki_status keaki_hip_srs_g1_precompute(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, size_t* table_bytes_out) {
@@ -475,7 +479,7 @@ keaki_status keaki_hip_decap_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_af
 }
 
 // ---- FK23 batch openings: replaces kzg::open_fk (src/kzg.rs:157-203) ----------------------------------------------------------
-keaki_status keaki_hip_open_fk(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, uint32_t log2d, const uint64_t* hat_a, const uint64_t* tw_2d,
+keaki_status keaki_hip_open_fk(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32_t log2d, const uint64_t* hat_a, const uint64_t* tw_2d,
                                const uint64_t* tw_2d_inv, const uint64_t* tw_d, uint64_t* proofs_out_aff) {
   CTX_GUARD(ctx);
   if (!srs || !hat_a || !tw_2d || !tw_2d_inv || (!tw_d && log2d > 0) || !proofs_out_aff || log2d > 27) return fail(ctx, KEAKI_ERR_BAD_ARG, "open_fk: bad argument");
@@ -491,7 +495,13 @@ keaki_status keaki_hip_open_fk(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, 
   HIP_TRY(ctx, hipMemcpyAsync(b + o_t1, tw_2d, d * 32, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(b + o_t2, tw_2d_inv, d * 32, hipMemcpyHostToDevice, st));
   if (d >= 2) HIP_TRY(ctx, hipMemcpyAsync(b + o_t3, tw_d, (d / 2) * 32, hipMemcpyHostToDevice, st));
-  ST_TRY(open_fk_run(ctx, srs->d, log2d, b + o_ha, b + o_t1, b + o_t2, b + o_t3, b + o_w, b + o_p));
+  if (srs->fk_log2d != (int)log2d) {
+    if (srs->fk_hat_s) { HIP_TRY(ctx, hipStreamSynchronize(st)); (void)hipFree(srs->fk_hat_s); srs->fk_hat_s = nullptr; srs->fk_log2d = -1; }
+    HIP_TRY(ctx, hipMalloc(&srs->fk_hat_s, 2 * d * 96));
+    ST_TRY(fk_hat_s_run(ctx, srs->d, log2d, b + o_t1, srs->fk_hat_s));
+    srs->fk_log2d = (int)log2d;
+  }
+  ST_TRY(open_fk_run(ctx, srs->fk_hat_s, log2d, b + o_ha, b + o_t2, b + o_t3, b + o_w, b + o_p));
   return download(ctx, proofs_out_aff, b + o_p, d * 64);
 }
 

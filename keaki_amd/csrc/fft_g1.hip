@@ -4,8 +4,8 @@
 // (`domain_2d.fft(&s)`, `domain_2d.ifft(&hat_h)`, `domain_d.fft(&h)`) and 2d scalar multiplications (`hat_s[i].mul(hat_a[i])`,
 // :189-191). Here:
 //   S[i] = [tau^(d-1-i)]_1 (i < d), identity (i >= d)            k_fk_load          (SRS reversed, src/kzg.rs:166-174)
-//   S <- DFT_2d(S)                                               k_bitrev + k_g1_fft_stage x log2(2d)
-//   S[i] <- hat_a[i] * S[i]                                      k_g1_mul_jac       (hat_a = DFT_2d(0..0, p) / 2d, from the host)
+//   hat_s <- DFT_2d(S)                                           k_bitrev + k_g1_fft_stage x log2(2d); cached per (SRS, d)
+//   S[i] <- hat_a[i] * hat_s[i]                                  k_g1_mul_jac_oop   (hat_a = DFT_2d(0..0, p) / 2d, from the host)
 //   S <- DFT_2d^-1(S) (scaling folded into hat_a); h = S[0..d]   same kernels with inverse twiddles
 //   proofs <- DFT_d(h), normalised to affine                     k_g1_fft_stage x log2(d), k_g1_jac_to_aff
 // A butterfly is one scalar multiplication of a Jacobian point by a twiddle factor plus an add and a subtract; one lane
@@ -92,15 +92,27 @@ static keaki_status g1_fft(keaki_hip_ctx* ctx, G1Jac* a, u32 log2n, const Fr* tw
   return launch_check(ctx, "g1_fft");
 }
 
-// d = 2^log2d openings. d_work: 2d Jacobian points. d_hat_a: 2d Fr (already divided by 2d). d_tw2d / d_tw2d_inv: d Fr each
-// (omega_2d^k, omega_2d^-k); d_twd: d/2 Fr (omega_d^k). Output: d affine proofs.
-keaki_status open_fk_run(keaki_hip_ctx* ctx, const void* d_srs, u32 log2d, const void* d_hat_a, const void* d_tw2d, const void* d_tw2d_inv,
-                         const void* d_twd, void* d_work, void* d_proofs_aff) {
+// out[i] = s[i] * in[i] (out-of-place pointwise product; in = cached hat_s)
+static __global__ void __launch_bounds__(64) k_g1_mul_jac_oop(const G1Jac* __restrict__ in, const Fr* __restrict__ s, u32 n, G1Jac* __restrict__ out) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = jac_scalar_mul(in[i], s[i]);
+}
+
+// hat_s = DFT_2d(reversed SRS padded with identities): depends on the SRS only, so it is computed once per (SRS, d) and cached.
+keaki_status fk_hat_s_run(keaki_hip_ctx* ctx, const void* d_srs, u32 log2d, const void* d_tw2d, void* d_hat_s) {
+  const u32 d = 1u << log2d;
+  G1Jac* s = (G1Jac*)d_hat_s;
+  hipLaunchKernelGGL(k_fk_load, dim3(cdiv(2 * d, 256)), dim3(256), 0, ctx->stream, (const G1Aff*)d_srs, d, s);
+  return g1_fft(ctx, s, log2d + 1, (const Fr*)d_tw2d);
+}
+// d = 2^log2d openings from the cached hat_s. d_work: 2d Jacobian points. d_hat_a: 2d Fr (already divided by 2d).
+// d_tw2d_inv: d Fr (omega_2d^-k); d_twd: d/2 Fr (omega_d^k). Output: d affine proofs.
+keaki_status open_fk_run(keaki_hip_ctx* ctx, const void* d_hat_s, u32 log2d, const void* d_hat_a, const void* d_tw2d_inv, const void* d_twd,
+                         void* d_work, void* d_proofs_aff) {
   const u32 d = 1u << log2d;
   G1Jac* s = (G1Jac*)d_work;
-  hipLaunchKernelGGL(k_fk_load, dim3(cdiv(2 * d, 256)), dim3(256), 0, ctx->stream, (const G1Aff*)d_srs, d, s);
-  ST_TRY(g1_fft(ctx, s, log2d + 1, (const Fr*)d_tw2d));
-  hipLaunchKernelGGL(k_g1_mul_jac, dim3(cdiv(2 * d, 64)), dim3(64), 0, ctx->stream, s, (const Fr*)d_hat_a, 2 * d);
+  hipLaunchKernelGGL(k_g1_mul_jac_oop, dim3(cdiv(2 * d, 64)), dim3(64), 0, ctx->stream, (const G1Jac*)d_hat_s, (const Fr*)d_hat_a, 2 * d, s);
   ST_TRY(g1_fft(ctx, s, log2d + 1, (const Fr*)d_tw2d_inv));
   if (log2d > 0) ST_TRY(g1_fft(ctx, s, log2d, (const Fr*)d_twd));
   hipLaunchKernelGGL(k_g1_jac_to_aff, dim3(cdiv(d, 64)), dim3(64), 0, ctx->stream, (const G1Jac*)s, d, (G1Aff*)d_proofs_aff);

@@ -90,8 +90,9 @@ keaki_status g1_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void*
 keaki_status g2_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void* d_table_scalars, void* d_table);
 keaki_status encap_g1_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, const void* d_tab_b, const void* d_xs, const void* d_rs, size_t n, void* d_out);
 keaki_status encap_g2_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, const void* d_tab_b, const void* d_xs, const void* d_rs, size_t n, void* d_out);
-keaki_status open_fk_run(keaki_hip_ctx* ctx, const void* d_srs, uint32_t log2d, const void* d_hat_a, const void* d_tw2d, const void* d_tw2d_inv,
-                         const void* d_twd, void* d_work, void* d_proofs_aff);
+keaki_status fk_hat_s_run(keaki_hip_ctx* ctx, const void* d_srs, uint32_t log2d, const void* d_tw2d, void* d_hat_s);
+keaki_status open_fk_run(keaki_hip_ctx* ctx, const void* d_hat_s, uint32_t log2d, const void* d_hat_a, const void* d_tw2d_inv, const void* d_twd,
+                         void* d_work, void* d_proofs_aff);
 keaki_status selftest_field_run(keaki_hip_ctx* ctx, uint32_t blocks, uint32_t iters, uint32_t seed, void* d_mismatches);
 
 }  // namespace keaki_internal

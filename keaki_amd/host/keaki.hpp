@@ -116,7 +116,7 @@ class KZGSetup {
   const std::vector<G1>& g1_aff() const { return g1_aff_; }
   const G2& tau_g2() const { return tau_g2_; }
   const std::shared_ptr<Device>& device() const { return dev_; }
-  const keaki_hip_srs_g1* srs() const { return srs_; }
+  keaki_hip_srs_g1* srs() const { return srs_; }
  private:
   KZGSetup() {}
   std::shared_ptr<Device> dev_;
