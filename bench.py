@@ -223,8 +223,9 @@ def main():
         kem_check = (h_a, h_v, h_r, d_com, d_tau, d_ct, d_gt, d_key, d_gt2, d_key2)
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        # wait for rank 0 (CPU baseline + JSON line) so the process group is torn down together
+        dist.barrier()
+        dist.destroy_process_group()
         return
 
     total_units = n * world * args.steps
@@ -319,8 +320,9 @@ def main():
                   and np.array_equal(d_gt2[:mc].cpu().numpy().view(np.uint8).reshape(mc, 384), dgt) and np.array_equal(d_key2[:mc].cpu().numpy(), dkey))
             kem["cpu_baseline"] = {"encaps_per_s": mc / ce, "decaps_per_s": mc / cd, "cores": 1, "kind": "port",
                                    "sample": "first %d items, CPU restatement of src/kem.rs:13-72; GPU ct/GT/key bytes bit-exact: %s" % (mc, bool(ok))}
-    print(json.dumps(result))
+    print(json.dumps(result), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
