@@ -101,6 +101,15 @@ keaki_status keaki_hip_g1_sum(keaki_hip_ctx* ctx, const uint64_t* points_jac, si
 keaki_status keaki_hip_open_fk(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32_t log2d, const uint64_t* hat_a, const uint64_t* tw_2d,
                                const uint64_t* tw_2d_inv, const uint64_t* tw_d, uint64_t* proofs_out_aff);
 
+/* Same, from the coefficients themselves: hat_a and all twiddle tables are derived on the device (row f-4 of the scope table), the
+ * caller passes only omega_2d (the order-2d root of ark-poly's Radix2EvaluationDomain), its inverse and (2d)^-1. */
+keaki_status keaki_hip_open_fk_poly(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32_t log2d, const uint64_t* coeffs, const uint64_t* omega_2d,
+                                    const uint64_t* omega_2d_inv, const uint64_t* inv_2d, uint64_t* proofs_out_aff);
+/* Scalar-field DFT on the device: replaces ark-poly `domain.fft` / `domain.ifft` over Fr (src/vec.rs:36-37, src/kzg.rs:185).
+ * data: n = 2^log2n Fr, transformed in place: out[j] = sum_i in[i] omega^(ij), then multiplied by *scale_or_null if given
+ * (pass omega^-1 and n^-1 for the inverse transform). */
+keaki_status keaki_hip_fr_fft(keaki_hip_ctx* ctx, uint64_t* data, uint32_t log2n, const uint64_t* omega, const uint64_t* scale_or_null);
+
 /* ---- batched scalar multiplication: replaces `.mul(scalar)` (src/kem.rs:22,30,36,37; src/kzg.rs:57,60,135,144)
  * out[i] = scalars[i] * points[i]   (point_stride = 1) or scalars[i] * points[0] (point_stride = 0).
  * points affine in, affine out. */

@@ -505,6 +505,32 @@ keaki_status keaki_hip_open_fk(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32
   return download(ctx, proofs_out_aff, b + o_p, d * 64);
 }
 
+// FK23 from the coefficients: twiddles and hat_a are derived on the device (row f-4)
+keaki_status keaki_hip_open_fk_poly(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32_t log2d, const uint64_t* coeffs, const uint64_t* omega_2d,
+                                    const uint64_t* omega_2d_inv, const uint64_t* inv_2d, uint64_t* proofs_out_aff) {
+  CTX_GUARD(ctx);
+  if (!srs || !coeffs || !omega_2d || !omega_2d_inv || !inv_2d || !proofs_out_aff || log2d > 27) return fail(ctx, KEAKI_ERR_BAD_ARG, "open_fk_poly: bad argument");
+  const size_t d = (size_t)1 << log2d;
+  if (d > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "open_fk: %zu coefficients but the SRS holds %zu points", d, srs->n);
+  const size_t o_p = 0, o_fr = o_p + d * 32, o_g = o_fr + (4 * d + d / 2 + 2) * 32, o_out = o_g + 2 * d * 96, total = o_out + d * 64;
+  ST_TRY(reserve(ctx, ctx->io_d, total));
+  char* b = (char*)ctx->io_d.p;
+  HIP_TRY(ctx, hipMemcpyAsync(b + o_p, coeffs, d * 32, hipMemcpyHostToDevice, ctx->stream));
+  ST_TRY(open_fk_poly_run(ctx, srs->d, &srs->fk_hat_s, &srs->fk_log2d, log2d, b + o_p, omega_2d, omega_2d_inv, inv_2d, b + o_fr, b + o_g, b + o_out));
+  return download(ctx, proofs_out_aff, b + o_out, d * 64);
+}
+// In-place scalar-field DFT of n = 2^log2n elements with the order-n root `omega`, then an optional scaling (the 1/n of an inverse transform).
+keaki_status keaki_hip_fr_fft(keaki_hip_ctx* ctx, uint64_t* data, uint32_t log2n, const uint64_t* omega, const uint64_t* scale_or_null) {
+  CTX_GUARD(ctx);
+  if (!data || !omega || log2n > 28) return fail(ctx, KEAKI_ERR_BAD_ARG, "fr_fft: bad argument");
+  const size_t n = (size_t)1 << log2n;
+  ST_TRY(reserve(ctx, ctx->io_d, n * 32 + (n / 2 + 1) * 32));
+  char* b = (char*)ctx->io_d.p;
+  HIP_TRY(ctx, hipMemcpyAsync(b, data, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  ST_TRY(fr_fft_run(ctx, b, log2n, omega, scale_or_null, b + n * 32));
+  return download(ctx, data, b, n * 32);
+}
+
 // ---- test hook: line table of a fixed Q (MILLER_MAX_LINES x 2 parities x 3 Fq, Montgomery)
 keaki_status keaki_hip_g2_prepare(keaki_hip_ctx* ctx, const uint64_t* g2_aff, uint64_t* lines_out, size_t lines_out_bytes) {
   CTX_GUARD(ctx);

@@ -79,6 +79,51 @@ static __global__ void __launch_bounds__(64) k_g1_jac_to_aff(const G1Jac* __rest
   out[i] = jac_to_aff(a[i]);
 }
 
+
+// ---- scalar-field (Fr) FFT on the device: row f-4 (the host-side ark-poly work of src/kzg.rs:182-185 and src/vec.rs:36-37) --------
+KDEV Fr fr_mul(const Fr& a, const Fr& b) { return fp_mul<FrParams>(a, b); }
+// out[k] = omega^k, k < n   (square-and-multiply per lane; n <= 2^27)
+static __global__ void __launch_bounds__(256) k_fr_powers(Fr omega, u32 n, Fr* __restrict__ out) {
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  Fr acc = fp_one<FrParams>(), b = omega;
+  for (u32 e = k; e; e >>= 1) {
+    if (e & 1u) acc = fr_mul(acc, b);
+    b = fr_mul(b, b);
+  }
+  out[k] = acc;
+}
+static __global__ void __launch_bounds__(256) k_fr_bitrev(Fr* __restrict__ a, u32 log2n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (1u << log2n)) return;
+  u32 r = log2n ? (__brev(i) >> (32 - log2n)) : 0u;
+  if (i < r) { Fr t = a[i]; a[i] = a[r]; a[r] = t; }
+}
+// tw[k * tw_stride] = root^k for the transform's own root of order n
+static __global__ void __launch_bounds__(256) k_fr_fft_stage(Fr* __restrict__ a, const Fr* __restrict__ tw, u32 tw_stride, u32 n, u32 len) {
+  u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n / 2) return;
+  u32 half = len >> 1;
+  u32 j = b % half, i0 = (b / half) * len + j, i1 = i0 + half;
+  Fr u = a[i0], v = fr_mul(a[i1], tw[(size_t)j * (n / len) * tw_stride]);
+  a[i0] = fp_add<FrParams>(u, v);
+  a[i1] = fp_sub<FrParams>(u, v);
+}
+static __global__ void __launch_bounds__(256) k_fr_scale(Fr* __restrict__ a, Fr s, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = fr_mul(a[i], s);
+}
+// a2[i] = 0 (i < d), p[i - d] (d <= i < 2d)
+static __global__ void __launch_bounds__(256) k_fk_pad(const Fr* __restrict__ p, u32 d, Fr* __restrict__ a2) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * d) return;
+  a2[i] = i < d ? fp_zero<FrParams>() : p[i - d];
+}
+static __global__ void __launch_bounds__(256) k_fr_stride2(const Fr* __restrict__ in, u32 n_out, Fr* __restrict__ out) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_out) out[i] = in[2 * (size_t)i];
+}
+
 }  // namespace bn254
 
 namespace keaki_internal {
@@ -117,6 +162,58 @@ keaki_status open_fk_run(keaki_hip_ctx* ctx, const void* d_hat_s, u32 log2d, con
   if (log2d > 0) ST_TRY(g1_fft(ctx, s, log2d, (const Fr*)d_twd));
   hipLaunchKernelGGL(k_g1_jac_to_aff, dim3(cdiv(d, 64)), dim3(64), 0, ctx->stream, (const G1Jac*)s, d, (G1Aff*)d_proofs_aff);
   return launch_check(ctx, "open_fk");
+}
+
+
+// in-place DFT of n = 2^log2n Fr elements with the given twiddle table (tw[k * tw_stride] = root^k, k < n/2)
+static keaki_status fr_fft(keaki_hip_ctx* ctx, Fr* a, u32 log2n, const Fr* tw, u32 tw_stride) {
+  const u32 n = 1u << log2n;
+  hipLaunchKernelGGL(k_fr_bitrev, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, a, log2n);
+  for (u32 len = 2; len <= n; len <<= 1)
+    hipLaunchKernelGGL(k_fr_fft_stage, dim3(cdiv(n / 2 ? n / 2 : 1, 256)), dim3(256), 0, ctx->stream, a, tw, tw_stride, n, len);
+  return launch_check(ctx, "fr_fft");
+}
+// generic scalar-field transform: d_data (n Fr) <- DFT with root `omega` (order n), then optionally * scale. d_tw: scratch for n/2 Fr.
+keaki_status fr_fft_run(keaki_hip_ctx* ctx, void* d_data, u32 log2n, const uint64_t* omega, const uint64_t* scale_or_null, void* d_tw) {
+  const u32 n = 1u << log2n;
+  Fr w, s;
+  memcpy(&w, omega, 32);
+  if (n >= 2) {
+    hipLaunchKernelGGL(k_fr_powers, dim3(cdiv(n / 2, 256)), dim3(256), 0, ctx->stream, w, n / 2, (Fr*)d_tw);
+    ST_TRY(fr_fft(ctx, (Fr*)d_data, log2n, (const Fr*)d_tw, 1));
+  }
+  if (scale_or_null) {
+    memcpy(&s, scale_or_null, 32);
+    hipLaunchKernelGGL(k_fr_scale, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (Fr*)d_data, s, n);
+  }
+  return launch_check(ctx, "fr_fft_run");
+}
+// FK23 from the polynomial itself: everything (twiddles, hat_a) is derived on the device from three scalars.
+// d_p: d Fr coefficients. d_fr_work: room for (2d + d + d + d/2 + 1) Fr. d_g_work: 2d Jacobian points. Output: d affine proofs.
+keaki_status open_fk_poly_run(keaki_hip_ctx* ctx, const void* d_srs, void** hat_s_cache, int* hat_s_log2d, u32 log2d, const void* d_p,
+                              const uint64_t* omega_2d, const uint64_t* omega_2d_inv, const uint64_t* inv_2d, void* d_fr_work, void* d_g_work,
+                              void* d_proofs_aff) {
+  const u32 d = 1u << log2d;
+  Fr w, wi, s;
+  memcpy(&w, omega_2d, 32); memcpy(&wi, omega_2d_inv, 32); memcpy(&s, inv_2d, 32);
+  Fr* hat_a = (Fr*)d_fr_work;
+  Fr* tw = hat_a + 2 * (size_t)d;       // omega_2d^k,  k < d
+  Fr* twi = tw + d;                      // omega_2d^-k, k < d
+  Fr* twd = twi + d;                     // omega_d^k,   k < d/2
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(k_fr_powers, dim3(cdiv(d, 256)), dim3(256), 0, st, w, d, tw);
+  hipLaunchKernelGGL(k_fr_powers, dim3(cdiv(d, 256)), dim3(256), 0, st, wi, d, twi);
+  if (d >= 2) hipLaunchKernelGGL(k_fr_stride2, dim3(cdiv(d / 2, 256)), dim3(256), 0, st, (const Fr*)tw, d / 2, twd);
+  hipLaunchKernelGGL(k_fk_pad, dim3(cdiv(2 * d, 256)), dim3(256), 0, st, (const Fr*)d_p, d, hat_a);
+  ST_TRY(fr_fft(ctx, hat_a, log2d + 1, tw, 1));
+  hipLaunchKernelGGL(k_fr_scale, dim3(cdiv(2 * d, 256)), dim3(256), 0, st, hat_a, s, 2 * d);
+  if (*hat_s_log2d != (int)log2d) {
+    if (*hat_s_cache) { HIP_TRY(ctx, hipStreamSynchronize(st)); (void)hipFree(*hat_s_cache); *hat_s_cache = nullptr; *hat_s_log2d = -1; }
+    HIP_TRY(ctx, hipMalloc(hat_s_cache, 2 * (size_t)d * sizeof(G1Jac)));
+    ST_TRY(fk_hat_s_run(ctx, d_srs, log2d, tw, *hat_s_cache));
+    *hat_s_log2d = (int)log2d;
+  }
+  return open_fk_run(ctx, *hat_s_cache, log2d, hat_a, twi, twd, d_g_work, d_proofs_aff);
 }
 
 }  // namespace keaki_internal

@@ -23,7 +23,7 @@ EXPORTS = [
     "keaki_hip_g1_mul_batch", "keaki_hip_g2_mul_batch", "keaki_hip_g1_mul_batch_dev", "keaki_hip_g2_mul_batch_dev",
     "keaki_hip_pairing_batch", "keaki_hip_pairing_batch_dev",
     "keaki_hip_encap_batch", "keaki_hip_encap_batch_dev", "keaki_hip_decap_batch", "keaki_hip_decap_batch_dev",
-    "keaki_hip_selftest_field", "keaki_hip_open_fk", "keaki_hip_final_exp_batch", "keaki_hip_miller_loop_batch", "keaki_hip_g2_prepare", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
+    "keaki_hip_selftest_field", "keaki_hip_open_fk", "keaki_hip_open_fk_poly", "keaki_hip_fr_fft", "keaki_hip_final_exp_batch", "keaki_hip_miller_loop_batch", "keaki_hip_g2_prepare", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
 ]
 
 KEAKI_ERR_TOO_LARGE = -5
@@ -79,6 +79,8 @@ def load_library():
         lib.keaki_hip_decap_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, sz]
         lib.keaki_hip_selftest_field.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
         lib.keaki_hip_open_fk.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp, vp]
+        lib.keaki_hip_open_fk_poly.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp, vp]
+        lib.keaki_hip_fr_fft.argtypes = [vp, vp, C.c_uint32, vp, vp]
         lib.keaki_hip_final_exp_batch.argtypes = [vp, vp, sz, vp]
         lib.keaki_hip_miller_loop_batch.argtypes = [vp, vp, vp, sz, vp]
         lib.keaki_hip_set_timing.argtypes = [vp, i32]
@@ -257,11 +259,25 @@ class KeakiHip:
         self._ck(self.lib.keaki_hip_final_exp_batch(self.ctx, _ptr(f), n, _ptr(out)))
         return out
 
+    def fr_fft(self, data, log2n: int, omega, scale=None) -> np.ndarray:
+        a = _np(data, 4).copy()
+        assert a.shape[0] == 1 << log2n
+        self._ck(self.lib.keaki_hip_fr_fft(self.ctx, _ptr(a), log2n, _ptr(_np(omega)), _ptr(_np(scale)) if scale is not None else None))
+        return a
+
     def open_fk(self, srs: "SrsG1", log2d: int, hat_a, tw_2d, tw_2d_inv, tw_d) -> np.ndarray:
         d = 1 << log2d
         ha = _np(hat_a, 4); t1 = _np(tw_2d, 4); t2 = _np(tw_2d_inv, 4); t3 = _np(tw_d, 4) if d >= 2 else np.zeros((1, 4), np.uint64)
         out = np.zeros((d, 8), np.uint64)
         self._ck(self.lib.keaki_hip_open_fk(self.ctx, srs.handle, log2d, _ptr(ha), _ptr(t1), _ptr(t2), _ptr(t3), _ptr(out)))
+        return out
+
+    def open_fk_poly(self, srs: "SrsG1", log2d: int, coeffs, omega_2d, omega_2d_inv, inv_2d) -> np.ndarray:
+        d = 1 << log2d
+        p = _np(coeffs, 4)
+        assert p.shape[0] == d
+        out = np.zeros((d, 8), np.uint64)
+        self._ck(self.lib.keaki_hip_open_fk_poly(self.ctx, srs.handle, log2d, _ptr(p), _ptr(_np(omega_2d)), _ptr(_np(omega_2d_inv)), _ptr(_np(inv_2d)), _ptr(out)))
         return out
 
     # ---- KEM composites

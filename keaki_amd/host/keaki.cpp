@@ -209,22 +209,14 @@ Result<std::vector<G1>> open_fk(const KZGSetup& setup, const std::vector<Fr>& p,
   const size_t d = p.size();
   const bool pow2 = d >= 1 && (d & (d - 1)) == 0;
   if (pow2 && domain_size == d && d <= setup.g1_pow().size()) {
-    // FK23 (src/kzg.rs:157-203): the three group FFTs and the 2d scalar-mults run on the GPU (keaki_hip_open_fk); the host
-    // prepares the scalar-field side exactly as the reference does with ark-poly: hat_a = DFT_2d(0,..,0,p), twiddles.
+    // FK23 (src/kzg.rs:157-203): the scalar-field DFT, the three group FFTs and the 2d scalar-mults all run on the GPU.
     unsigned log2d = 0;
     while ((size_t(1) << log2d) < d) log2d++;
+    // hat_a = DFT_2d(0,..,0,p) / 2d and every twiddle table are derived on the device from omega_2d (keaki_hip_open_fk_poly)
     vec::Radix2Domain d2 = vec::Radix2Domain::create(2 * d);
-    std::vector<Fr> a(2 * d);
-    for (size_t i = 0; i < d; i++) a[d + i] = p[i];
-    std::vector<Fr> hat_a = d2.fft(a);
-    for (auto& x : hat_a) x = x * d2.size_inv;            // the 1/(2d) of the inverse transform, folded into the pointwise factor
-    std::vector<Fr> tw(d), twi(d), twd(d / 2 + 1);
-    Fr w = Fr::one(), wi = Fr::one();
-    for (size_t k = 0; k < d; k++) { tw[k] = w; twi[k] = wi; w = w * d2.group_gen; wi = wi * d2.group_gen_inv; }
-    for (size_t k = 0; k < d / 2; k++) twd[k] = tw[2 * k];  // omega_d = omega_2d^2
     std::vector<G1> out(d);
     const Device& dev = *setup.device();
-    dev.check(keaki_hip_open_fk(dev.ctx(), setup.srs(), log2d, hat_a[0].l, tw[0].l, twi[0].l, twd[0].l, out[0].w.data()));
+    dev.check(keaki_hip_open_fk_poly(dev.ctx(), setup.srs(), log2d, p[0].l, d2.group_gen.l, d2.group_gen_inv.l, d2.size_inv.l, out[0].w.data()));
     return Result<std::vector<G1>>::Ok(std::move(out));
   }
   // shapes FK23 does not cover (the reference would panic on them): one opening per root of unity
@@ -329,7 +321,16 @@ std::pair<G1, std::vector<G1>> vec_commit(Rng& rng, const kzg::KZGSetup& setup, 
   std::vector<Fr> padded(v);
   padded.push_back(fr_rand(rng));                    // src/vec.rs:31-33
   Radix2Domain domain = Radix2Domain::create(d);     // :36
-  std::vector<Fr> p_coeff = domain.ifft(padded);     // :37
+  std::vector<Fr> p_coeff;
+  if (d >= (size_t(1) << 12)) {                      // :37 on the device for large domains (keaki_hip_fr_fft), same values
+    p_coeff = std::move(padded);
+    p_coeff.resize(domain.size);
+    unsigned log_size = 0;
+    while ((size_t(1) << log_size) < domain.size) log_size++;
+    setup.device()->check(keaki_hip_fr_fft(setup.device()->ctx(), p_coeff[0].l, log_size, domain.group_gen_inv.l, domain.size_inv.l));
+  } else {
+    p_coeff = domain.ifft(padded);
+  }
   std::vector<G1> proofs = kzg::open_fk(setup, p_coeff, domain.size).unwrap();  // :40
   DensePolynomial dense = p_coeff;
   while (!dense.empty() && dense.back().is_zero()) dense.pop_back();  // from_coefficients_vec trims

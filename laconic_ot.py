@@ -3,7 +3,7 @@
 
     python laconic_ot.py --log2n 16          # N_CHOICES = 2^16 receiver bits, 2 x 32-byte messages per bit
 
-Receiver::new  -> vec_commit : pad with one random scalar, iFFT to coefficients (host), FK23 openings (GPU G1 FFTs), commit (GPU MSM)
+Receiver::new  -> vec_commit : pad with one random scalar, iFFT to coefficients (GPU Fr FFT), FK23 openings (GPU Fr + G1 FFTs), commit (GPU MSM)
 Sender::send   -> 2 x vec_encrypt : one batched GPU encapsulation per message set (fixed-base GT path), XOR on host
 Receiver::receive -> vec_decrypt : one batched GPU decapsulation (one pairing per item), XOR on host
 Prints the same three phase timings the reference test prints (tests/laconic_ot.rs:148,176,188) as one JSON line and checks

@@ -240,3 +240,18 @@ def test_laconic_ot_larger(K):
     chosen = [ct0[i] if bits[i] == 0 else ct1[i] for i in range(N)]
     got = K.vec_decrypt(s, proofs, chosen)
     assert all(got[i] == sets[bits[i]][i] for i in range(N))
+
+
+def test_vec_commit_device_fft_branch(K, oc, py):
+    """Domain 4096: vec_commit takes the device iFFT (keaki_hip_fr_fft) + FK23-from-coefficients route; the commitment opens to
+    the committed bits at the domain elements (src/vec.rs:26-49 contract) and p_coeff matches a host-side interpolation check."""
+    N = 4095
+    rng = K.Rng(31)
+    s = K.KZGSetup.setup(rng.fr_rand(), 4096)
+    np_rng = np.random.default_rng(31)
+    bits = [int(b) for b in np_rng.integers(0, 2, N)]
+    commitment, proofs = K.vec_commit(rng, s, np.stack([K.fr(b) for b in bits]))
+    el = K.domain_elements(N + K.PADDING_LEN)
+    for i in (0, 1, 2, 2047, 2048, 4094):
+        assert K.verify(s, commitment, el[i], K.fr(bits[i]), proofs[i])
+        assert not K.verify(s, commitment, el[i], K.fr(1 - bits[i]), proofs[i])

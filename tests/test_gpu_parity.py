@@ -371,3 +371,70 @@ def test_msm_structured_scalars_heavy_buckets(oc, hip, rand_fr):
                 assert np.array_equal(got, exp), (name, tables)
     finally:
         srs.free()
+
+
+def _fr_ints(oc, mont_limbs):
+    return oc.limbs_to_ints(oc.fr_from_mont(np.asarray(mont_limbs).reshape(-1, 4)))
+
+
+@pytest.mark.parametrize("log2n", [0, 1, 2, 5])
+def test_fr_fft_vs_naive_dft(oc, py, hip, rand_fr, log2n):
+    """Device scalar-field DFT (row f-4; ark-poly domain.fft / ifft over Fr) against the O(n^2) definition with ark-poly's root."""
+    n = 1 << log2n
+    a = rand_fr(n, 700 + log2n)
+    if n > 2:
+        a[1] = 0
+        a[2] = py.R - 1
+    w = py.fr_root_of_unity(n)
+    got = _fr_ints(oc, hip.fr_fft(mont(oc, a), log2n, mont(oc, [w])[0]))
+    assert got == [sum(a[i] * pow(w, i * j, py.R) for i in range(n)) % py.R for j in range(n)]
+    # inverse transform with the 1/n scaling folded in returns the input
+    back = hip.fr_fft(mont(oc, got), log2n, mont(oc, [pow(w, -1, py.R)])[0], mont(oc, [pow(n, -1, py.R)])[0])
+    assert _fr_ints(oc, back) == a
+
+
+def test_fr_fft_large_round_trip_and_spot_values(oc, py, hip, rand_fr):
+    """2^16 elements: forward then inverse is the identity; X[0] = sum a_i, X[n/2] = sum (-1)^i a_i, one random bin by Horner."""
+    log2n, n = 16, 1 << 16
+    a = rand_fr(n, 716)
+    am = mont(oc, a)
+    w = py.fr_root_of_unity(n)
+    X = hip.fr_fft(am, log2n, mont(oc, [w])[0])
+    Xi = _fr_ints(oc, X)
+    assert Xi[0] == sum(a) % py.R
+    assert Xi[n // 2] == sum(v if i % 2 == 0 else -v for i, v in enumerate(a)) % py.R
+    j = 12345
+    wj, acc = pow(w, j, py.R), 0
+    for v in reversed(a):
+        acc = (acc * wj + v) % py.R
+    assert Xi[j] == acc
+    back = hip.fr_fft(X, log2n, mont(oc, [pow(w, -1, py.R)])[0], mont(oc, [pow(n, -1, py.R)])[0])
+    assert np.array_equal(back, am)
+
+
+@pytest.mark.parametrize("log2d", [0, 1, 3, 6])
+def test_open_fk_poly_matches_explicit_twiddle_entry(oc, py, hip, rand_fr, log2d):
+    """keaki_hip_open_fk_poly (hat_a and twiddles derived on the device) == keaki_hip_open_fk fed with host-computed
+    hat_a / twiddles, and == the oracle's literal FK23 at d <= 8."""
+    d = 1 << log2d
+    ks, pts = make_points_g1(oc, hip, max(d, 2), 800 + log2d)      # any points serve as an "SRS" for the linear-algebra identity
+    p = rand_fr(d, 810 + log2d)
+    w2 = py.fr_root_of_unity(2 * d)
+    w2i, inv = pow(w2, -1, py.R), pow(2 * d, -1, py.R)
+    a = [0] * d + p
+    hat_a = [sum(a[i] * pow(w2, i * j, py.R) for i in range(2 * d)) * inv % py.R for j in range(2 * d)]
+    tw = [pow(w2, k, py.R) for k in range(d)]
+    twi = [pow(w2i, k, py.R) for k in range(d)]
+    twd = [tw[2 * k] for k in range(d // 2)] or [1]
+    srs_a, srs_b = hip.srs_g1_upload(pts), hip.srs_g1_upload(pts)
+    try:
+        explicit = hip.open_fk(srs_a, log2d, mont(oc, hat_a), mont(oc, tw), mont(oc, twi), mont(oc, twd))
+        poly = hip.open_fk_poly(srs_b, log2d, mont(oc, p), mont(oc, [w2])[0], mont(oc, [w2i])[0], mont(oc, [inv])[0])
+        assert np.array_equal(explicit, poly)
+        if d <= 8:
+            g1p = oc.g1_to_ints(pts)
+            assert oc.g1_to_ints(poly) == py.kzg_open_fk(g1p[:d], p)
+        # second call reuses the cached hat_s
+        assert np.array_equal(hip.open_fk_poly(srs_b, log2d, mont(oc, p), mont(oc, [w2])[0], mont(oc, [w2i])[0], mont(oc, [inv])[0]), poly)
+    finally:
+        srs_a.free(); srs_b.free()
