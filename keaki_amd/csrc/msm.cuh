@@ -71,9 +71,10 @@ inline MsmPlan msm_make_plan(size_t n, int c_target) {
 // code = bucket (= |d| - 1) | sign << 31. Signed rule for windows below the top: coef in [0, 2^wd];
 // coef > 2^(wd-1) -> digit coef - 2^wd with carry 1 (coef == 2^wd is digit 0 with carry 1).
 template <class Emit>
-KDEV void msm_for_each_digit(const Fr& k, const MsmShape& s, Emit emit) {
+KDEV void msm_for_each_digit_canon(const u32 (&canon)[8], const MsmShape& s, Emit emit) {
   u32 v[8];
-  fp_from_mont<FrParams>(v, k);
+#pragma unroll
+  for (int j = 0; j < 8; j++) v[j] = canon[j];
   u32 carry = 0;
   for (u32 w = 0; w < s.W; w++) {
     const u32 wd = msm_width(s, w);
@@ -95,102 +96,177 @@ KDEV void msm_for_each_digit(const Fr& k, const MsmShape& s, Emit emit) {
   }
 }
 
-// ---- LDS-staged two-pass radix partition of the (bucket, point) pairs -------------------------------
-// Global bucket id g = w * B + bucket. Pass 1 partitions all n*W pairs by the coarse key g >> PART_SHIFT
-// (per-workgroup histograms and cursors live in LDS; the only global traffic is coalesced reads and
-// short contiguous runs of 8-byte writes). Pass 2 gives each coarse bin to one workgroup, which
-// histograms / scans / scatters its <= 2^PART_SHIFT fine buckets entirely in LDS and emits the final
-// bucket-ordered index stream plus the per-bucket offsets and counts. No global atomics anywhere.
-constexpr u32 PART_SHIFT = 12;
-constexpr u32 PART_FINE = 1u << PART_SHIFT;
-constexpr u32 PART_TILE = 1024;       // scalars per workgroup in pass 1
-constexpr u32 PART_MAX_BINS = 8192;   // coarse bins (LDS: 32 KB of counters)
+template <class Emit>
+KDEV void msm_for_each_digit(const Fr& k, const MsmShape& s, Emit emit) {
+  u32 v[8];
+  fp_from_mont<FrParams>(v, k);
+  msm_for_each_digit_canon(v, s, emit);
+}
+
+// ---- two-pass radix partition of the (bucket, point) pairs, every tile sorted in LDS before it is written ----------
+// Global bucket id g = w * B + bucket (shared-bucket mode: g = bucket). Pass 1 partitions all n*W pairs by the coarse key
+// g >> shift: a workgroup stages the <= P1_CAP pairs of its tile of scalars in LDS (160 KB per workgroup on gfx950), counting-
+// sorts them there by coarse bin and writes every (bin, workgroup) cell as one contiguous run. Pass 2 gives each coarse bin
+// to one workgroup: a histogram of the bin's 2^shift fine buckets fixes the per-bucket offsets, then P2_CAP pairs at a time
+// are counting-sorted in LDS and every bucket's share of the chunk is written as one run (16 lanes per bucket). Output: the
+// bucket-ordered index stream plus per-bucket offsets and counts. No global atomics; writes are runs, not single words
+// (scattered 4- and 8-byte stores had cost 3x / 7x write amplification in HBM).
+constexpr u32 P1_THREADS = 1024;
+constexpr u32 P1_CAP = 16384;          // pairs staged per pass-1 tile (8 B each = 128 KB of LDS)
+constexpr u32 PART_MAX_BINS = 2048;    // coarse bins
+constexpr u32 P2_THREADS = 1024;
+constexpr u32 P2_CAP = 32768;          // payloads staged per pass-2 chunk (4 B each = 128 KB of LDS)
+constexpr u32 PART_MAX_FINE_SHIFT = 11;
+constexpr u32 PART_MAX_FINE = 1u << PART_MAX_FINE_SHIFT;
 
 struct PartShape {
-  u32 nbins;    // coarse bins = ceil(W * B / PART_FINE)
-  u32 nwg;      // pass-1 workgroups = ceil(n / PART_TILE)
+  u32 nbins;    // coarse bins = ceil(total buckets >> shift)
+  u32 nwg;      // pass-1 workgroups = ceil(n / tile)
+  u32 shift;    // fine bits: a coarse bin covers 2^shift buckets
+  u32 tile;     // scalars per pass-1 workgroup (<= P1_THREADS, tile * W <= P1_CAP)
 };
+inline bool part_make_shape(size_t n, u32 W, size_t nb, PartShape* ps, int shift_override = -1) {
+  u32 lg = 0;
+  while (((size_t)1 << lg) < nb) lg++;
+  int shift = (int)(lg + 1) / 2 + 1;              // fine side one bit wider than the coarse side (4-byte vs 8-byte runs)
+  if (shift_override >= 0) shift = shift_override;
+  if (shift > (int)PART_MAX_FINE_SHIFT) shift = PART_MAX_FINE_SHIFT;
+  if (shift < 0) shift = 0;
+  while ((int)lg - shift > 11 && shift < (int)PART_MAX_FINE_SHIFT) shift++;
+  ps->shift = (u32)shift;
+  ps->nbins = (u32)((nb + ((size_t)1 << shift) - 1) >> shift);
+  u32 tile = W ? P1_CAP / W : P1_THREADS;
+  if (tile > P1_THREADS) tile = P1_THREADS;
+  if (tile == 0) return false;
+  ps->tile = tile;
+  ps->nwg = (u32)((n + tile - 1) / tile);
+  return ps->nbins >= 1 && ps->nbins <= PART_MAX_BINS;
+}
+
+// exclusive scan, in place, of a[0..len) in LDS, len <= 2 * blockDim.x = 2048; returns the total. Whole workgroup calls it.
+__device__ __forceinline__ u32 lds_exclusive_scan(u32* a, u32 len, u32* wsum) {
+  const u32 t = threadIdx.x, lane = t & 63, wid = t >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  u32 x0 = 2 * t < len ? a[2 * t] : 0u, x1 = 2 * t + 1 < len ? a[2 * t + 1] : 0u;
+  u32 sum = x0 + x1, x = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { u32 y = __shfl_up(x, o, 64); if (lane >= (u32)o) x += y; }
+  if (lane == 63) wsum[wid] = x;
+  __syncthreads();
+  u32 base = 0, tot = 0;
+  for (u32 k = 0; k < nw; k++) { u32 sv = wsum[k]; if (k < wid) base += sv; tot += sv; }
+  u32 ex = base + x - sum;
+  if (2 * t < len) a[2 * t] = ex;
+  if (2 * t + 1 < len) a[2 * t + 1] = ex + x0;
+  __syncthreads();
+  return tot;
+}
 
 // pass 1a: counts[bin * nwg + wg]
-static __global__ void __launch_bounds__(256) k_part_count(const Fr* __restrict__ scalars, MsmShape s, PartShape ps, u32* __restrict__ counts) {
-  extern __shared__ u32 lds_hist[];
-  for (u32 b = threadIdx.x; b < ps.nbins; b += 256) lds_hist[b] = 0;
+static __global__ void __launch_bounds__(P1_THREADS) k_part_count(const Fr* __restrict__ scalars, MsmShape s, PartShape ps, u32* __restrict__ counts) {
+  __shared__ u32 hist[PART_MAX_BINS];
+  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) hist[b] = 0;
   __syncthreads();
-  const u32 base = blockIdx.x * PART_TILE;
-  for (u32 t = threadIdx.x; t < PART_TILE; t += 256) {
-    u32 i = base + t;
-    if (i < s.n) {
-      msm_for_each_digit(scalars[i], s, [&](u32 w, u32 code) {
-        u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
-        atomicAdd(&lds_hist[g >> PART_SHIFT], 1u);
-      });
-    }
+  const u32 i = blockIdx.x * ps.tile + threadIdx.x;
+  if (threadIdx.x < ps.tile && i < s.n) {
+    msm_for_each_digit(scalars[i], s, [&](u32 w, u32 code) {
+      u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
+      atomicAdd(&hist[g >> ps.shift], 1u);
+    });
   }
   __syncthreads();
-  for (u32 b = threadIdx.x; b < ps.nbins; b += 256) counts[(size_t)b * ps.nwg + blockIdx.x] = lds_hist[b];
+  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) counts[(size_t)b * ps.nwg + blockIdx.x] = hist[b];
 }
-// pass 1b: entries[pos] = fine (PART_SHIFT bits) << 32 | sign << 31 | point index
-static __global__ void __launch_bounds__(256) k_part_scatter(const Fr* __restrict__ scalars, MsmShape s, PartShape ps,
-                                                             const u32* __restrict__ offsets, u64* __restrict__ entries) {
-  extern __shared__ u32 lds_cur[];
-  for (u32 b = threadIdx.x; b < ps.nbins; b += 256) lds_cur[b] = offsets[(size_t)b * ps.nwg + blockIdx.x];
+// pass 1b: entries[pos] = bucket id g << 32 | sign << 31 | point (table row) index
+static __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const Fr* __restrict__ scalars, MsmShape s, PartShape ps,
+                                                                    const u32* __restrict__ offsets, u64* __restrict__ entries) {
+  __shared__ u64 ent[P1_CAP];
+  __shared__ u32 cur[PART_MAX_BINS];
+  __shared__ u32 goff[PART_MAX_BINS];
+  __shared__ u32 wsum[P1_THREADS / 64];
+  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) { cur[b] = 0; goff[b] = offsets[(size_t)b * ps.nwg + blockIdx.x]; }
   __syncthreads();
-  const u32 base = blockIdx.x * PART_TILE;
-  for (u32 t = threadIdx.x; t < PART_TILE; t += 256) {
-    u32 i = base + t;
-    if (i < s.n) {
-      msm_for_each_digit(scalars[i], s, [&](u32 w, u32 code) {
-        u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
-        u32 pos = atomicAdd(&lds_cur[g >> PART_SHIFT], 1u);
-        entries[pos] = ((u64)(g & (PART_FINE - 1)) << 32) | (code & 0x80000000u) | (i + w * s.stride);
-      });
-    }
+  const u32 i = blockIdx.x * ps.tile + threadIdx.x;
+  const bool act = threadIdx.x < ps.tile && i < s.n;
+  u32 k[8];                                                  // canonical scalar, kept for the second digit walk
+  if (act) {
+    fp_from_mont<FrParams>(k, scalars[i]);
+    msm_for_each_digit_canon(k, s, [&](u32 w, u32 code) {
+      u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
+      atomicAdd(&cur[g >> ps.shift], 1u);
+    });
+  }
+  const u32 m = lds_exclusive_scan(cur, ps.nbins, wsum);     // cur[b] = start of bin b inside the tile
+  if (act) {
+    msm_for_each_digit_canon(k, s, [&](u32 w, u32 code) {
+      u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
+      u32 pos = atomicAdd(&cur[g >> ps.shift], 1u);           // afterwards cur[b] = end of bin b = start of bin b + 1
+      ent[pos] = ((u64)g << 32) | (code & 0x80000000u) | (i + w * s.stride);
+    });
+  }
+  __syncthreads();
+  for (u32 q = threadIdx.x; q < m; q += P1_THREADS) {
+    u64 v = ent[q];
+    u32 b = (u32)(v >> 32) >> ps.shift;
+    u32 st = b ? cur[b - 1] : 0u;
+    entries[goff[b] + (q - st)] = v;
   }
 }
 // grand total of entries = exclusive offset of the last (bin, workgroup) cell + its count
 static __global__ void k_part_total(const u32* __restrict__ counts, const u32* __restrict__ offsets, u32 ncounts, u32* __restrict__ total) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *total = offsets[ncounts - 1] + counts[ncounts - 1];
 }
-// pass 2: one workgroup per coarse bin. bin b covers global buckets [b * PART_FINE, (b+1) * PART_FINE).
-constexpr u32 PF_THREADS = 1024, PF_PER = PART_FINE / PF_THREADS;
-static __global__ void __launch_bounds__(PF_THREADS) k_part_fine(const u64* __restrict__ entries, const u32* __restrict__ offsets, PartShape ps,
+// pass 2: one workgroup per coarse bin. bin b covers global buckets [b << shift, (b + 1) << shift).
+static __global__ void __launch_bounds__(P2_THREADS) k_part_fine(const u64* __restrict__ entries, const u32* __restrict__ offsets, PartShape ps,
                                                                  const u32* __restrict__ total_ptr, u32 nbuckets_total, u32* __restrict__ bucket_offsets,
                                                                  u32* __restrict__ bucket_counts, u32* __restrict__ sorted) {
-  __shared__ u32 hist[PART_FINE];
-  __shared__ u32 wsum[PF_THREADS / 64];
-  const u32 bin = blockIdx.x;
+  __shared__ u32 pay[P2_CAP];
+  __shared__ u32 hist[PART_MAX_FINE];
+  __shared__ u32 cursor[PART_MAX_FINE];
+  __shared__ u32 wsum[P2_THREADS / 64];
+  const u32 bin = blockIdx.x, nf = 1u << ps.shift, mask = nf - 1u, t = threadIdx.x;
   const u32 lo = offsets[(size_t)bin * ps.nwg];
   const u32 hi = (bin + 1 < ps.nbins) ? offsets[(size_t)(bin + 1) * ps.nwg] : *total_ptr;
-  for (u32 f = threadIdx.x; f < PART_FINE; f += PF_THREADS) hist[f] = 0;
+  const u32 m = hi - lo;
+  // whole-bin histogram -> per-bucket counts and offsets
+  for (u32 f = t; f < nf; f += P2_THREADS) hist[f] = 0;
   __syncthreads();
-  for (u32 e = lo + threadIdx.x; e < hi; e += PF_THREADS) atomicAdd(&hist[(u32)(entries[e] >> 32)], 1u);
+  for (u32 q = t; q < m; q += P2_THREADS) atomicAdd(&hist[(u32)(entries[lo + q] >> 32) & mask], 1u);
   __syncthreads();
-  // exclusive scan of hist (PF_PER counters per thread), in place; counts kept in registers
-  u32 cnt[PF_PER];
-  u32 sum = 0;
-#pragma unroll
-  for (u32 k = 0; k < PF_PER; k++) { cnt[k] = hist[threadIdx.x * PF_PER + k]; sum += cnt[k]; }
-  u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6, x = sum;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { u32 y = __shfl_up(x, o, 64); if (lane >= (u32)o) x += y; }
-  if (lane == 63) wsum[wid] = x;
-  __syncthreads();
-  u32 wbase = 0;
-  for (u32 k = 0; k < wid; k++) wbase += wsum[k];
-  u32 ex = lo + wbase + x - sum;
-#pragma unroll
-  for (u32 k = 0; k < PF_PER; k++) {
-    u32 f = threadIdx.x * PF_PER + k;
-    u32 g = bin * PART_FINE + f;
-    hist[f] = ex;                      // becomes the running cursor of bucket f
-    if (g < nbuckets_total) { bucket_offsets[g] = ex; bucket_counts[g] = cnt[k]; }
-    ex += cnt[k];
+  const u32 c0 = 2 * t < nf ? hist[2 * t] : 0u, c1 = 2 * t + 1 < nf ? hist[2 * t + 1] : 0u;
+  lds_exclusive_scan(hist, nf, wsum);
+  {
+    const u32 g0 = (bin << ps.shift) + 2 * t;
+    if (2 * t < nf) { cursor[2 * t] = hist[2 * t]; if (g0 < nbuckets_total) { bucket_offsets[g0] = lo + hist[2 * t]; bucket_counts[g0] = c0; } }
+    if (2 * t + 1 < nf) { cursor[2 * t + 1] = hist[2 * t + 1]; if (g0 + 1 < nbuckets_total) { bucket_offsets[g0 + 1] = lo + hist[2 * t + 1]; bucket_counts[g0 + 1] = c1; } }
   }
   __syncthreads();
-  for (u32 e = lo + threadIdx.x; e < hi; e += PF_THREADS) {
-    u64 v = entries[e];
-    u32 pos = atomicAdd(&hist[(u32)(v >> 32)], 1u);
-    sorted[pos] = (u32)v;
+  for (u32 cb = 0; cb < m; cb += P2_CAP) {
+    const u32 mc = m - cb < P2_CAP ? m - cb : P2_CAP;
+    const u64* src = entries + lo + cb;
+    if (m > P2_CAP) {                               // a single chunk reuses the whole-bin scan that is already in hist
+      for (u32 f = t; f < nf; f += P2_THREADS) hist[f] = 0;
+      __syncthreads();
+      for (u32 q = t; q < mc; q += P2_THREADS) atomicAdd(&hist[(u32)(src[q] >> 32) & mask], 1u);
+      lds_exclusive_scan(hist, nf, wsum);
+    }
+    for (u32 q = t; q < mc; q += P2_THREADS) {
+      u64 v = src[q];
+      u32 pos = atomicAdd(&hist[(u32)(v >> 32) & mask], 1u);   // afterwards hist[f] = end of bucket f inside the chunk
+      pay[pos] = (u32)v;
+    }
+    __syncthreads();
+    if (m <= P2_CAP) {                              // the chunk is the bin: the LDS image is the output
+      for (u32 q = t; q < mc; q += P2_THREADS) sorted[lo + q] = pay[q];
+      return;
+    }
+    for (u32 f = t >> 4; f < nf; f += P2_THREADS / 16) {       // 16 lanes per bucket: one run per (bucket, chunk)
+      u32 st = f ? hist[f - 1] : 0u, len = hist[f] - st, gb = lo + cursor[f];
+      for (u32 j = t & 15; j < len; j += 16) sorted[gb + j] = pay[st + j];
+    }
+    __syncthreads();
+    for (u32 f = t; f < nf; f += P2_THREADS) cursor[f] += hist[f] - (f ? hist[f - 1] : 0u);
+    __syncthreads();
   }
 }
 

@@ -73,9 +73,10 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
     return launch_check(ctx, "msm_final");
   }
   PartShape ps;
-  ps.nbins = cdiv(nb, PART_FINE);
-  ps.nwg = cdiv(n, PART_TILE);
-  if (ps.nbins > PART_MAX_BINS) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: %u coarse bins exceed the LDS budget (window too large)", ps.nbins);
+  int shift_override = -1;
+  if (const char* e = getenv("KEAKI_PART_SHIFT")) shift_override = atoi(e);
+  if (!part_make_shape(n, s.W, nb, &ps, shift_override))
+    return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: %zu buckets / %u windows exceed the partition's LDS budget (window too large)", nb, s.W);
   const size_t ncounts = (size_t)ps.nbins * ps.nwg;
   if (ncounts >= 4294967295ull) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: partition table too large");
   ST_TRY(reserve(ctx, ctx->digits, n * s.W * 8));      // coarse-partitioned (fine | sign | index) entries
@@ -90,14 +91,13 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   u32 *pcounts = (u32*)ctx->cursor.p, *poffsets = pcounts + ncounts;
   Xyzz<F>* buckets = (Xyzz<F>*)ctx->buckets.p;
   Xyzz<F>* partials = (Xyzz<F>*)ctx->partials.p;
-  const size_t lds = (size_t)ps.nbins * 4;
-  hipLaunchKernelGGL(k_part_count, dim3(ps.nwg), dim3(256), lds, st, (const Fr*)d_scalars, s, ps, pcounts);
+  hipLaunchKernelGGL(k_part_count, dim3(ps.nwg), dim3(P1_THREADS), 0, st, (const Fr*)d_scalars, s, ps, pcounts);
   ST_TRY(launch_check(ctx, "part_count"));
   ST_TRY(device_scan(ctx, pcounts, (u32)ncounts, poffsets));
-  hipLaunchKernelGGL(k_part_scatter, dim3(ps.nwg), dim3(256), lds, st, (const Fr*)d_scalars, s, ps, (const u32*)poffsets, entries);
+  hipLaunchKernelGGL(k_part_scatter, dim3(ps.nwg), dim3(P1_THREADS), 0, st, (const Fr*)d_scalars, s, ps, (const u32*)poffsets, entries);
   ST_TRY(launch_check(ctx, "part_scatter"));
   hipLaunchKernelGGL(k_part_total, dim3(1), dim3(64), 0, st, (const u32*)pcounts, (const u32*)poffsets, (u32)ncounts, poffsets + ncounts);
-  hipLaunchKernelGGL(k_part_fine, dim3(ps.nbins), dim3(PF_THREADS), 0, st, (const u64*)entries, (const u32*)poffsets, ps, (const u32*)(poffsets + ncounts),
+  hipLaunchKernelGGL(k_part_fine, dim3(ps.nbins), dim3(P2_THREADS), 0, st, (const u64*)entries, (const u32*)poffsets, ps, (const u32*)(poffsets + ncounts),
                      (u32)nb, offsets, hist, sorted);
   ST_TRY(launch_check(ctx, "part_fine"));
   // bucket schedule: descending size
@@ -159,7 +159,7 @@ inline int choose_window_shared(size_t n) {
   int bc = 8;
   for (int c = 8; c <= 23; c++) {
     MsmPlan p = msm_make_plan(n, c);
-    if ((p.max_b >> PART_SHIFT) > PART_MAX_BINS) continue;
+    if (p.max_b > ((size_t)PART_MAX_BINS << PART_MAX_FINE_SHIFT)) continue;
     double cost = (double)n * p.s.W + 2.8 * (double)p.max_b;
     if ((double)p.max_b < 131072.0) cost *= 131072.0 / (double)p.max_b;
     if (cost < best) { best = cost; bc = c; }
