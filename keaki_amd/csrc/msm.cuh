@@ -17,6 +17,7 @@
 // commutative, so the affine result is bit-identical run to run.
 #pragma once
 #include "bn254_curve.cuh"
+#include "fq29.cuh"
 
 namespace bn254 {
 
@@ -465,6 +466,63 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const Aff<F>* __restrict
     acc = xyzz_add_mixed(acc, aff_cneg(p, (e >> 31) != 0));
   }
   buckets[t] = acc;
+}
+
+// G1 bucket accumulation in the 9 x 29-bit lazy representation (fq29.cuh): same schedule and memory traffic as the generic
+// kernel above, ~2450 instead of ~3200 issues per mixed addition. Table / SRS rows stay in the saturated 2^256 form (the
+// 2^261 form is the same integer shifted by 5 bits); buckets are written back saturated and canonical.
+// Value bounds (multiples of p; measured maxima in brackets): X < 9.4 [8.7], Y < 3.6 [3.1], ZZ, ZZZ < 1.4; P = U2 - X + 16p < 17.4;
+// R = S2 - Y + 4p < 5.3; every product of those stays < 3p.
+static __global__ void __launch_bounds__(256) k_msm_accumulate_g1_u29(const Aff<Fq>* __restrict__ points, const u32* __restrict__ sorted,
+                                                                      const u32* __restrict__ offsets, const u32* __restrict__ counts,
+                                                                      const u32* __restrict__ perm, u32 nbuckets_total, Xyzz<Fq>* __restrict__ buckets) {
+  u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane >= nbuckets_total) return;
+  u32 t = perm[lane];
+  u32 start = offsets[t], cnt = counts[t];
+  if (lane < HEAVY_MAX && cnt >= HEAVY_MIN) return;   // done by k_msm_heavy / k_msm_heavy_combine
+  U29 X1, Y1, ZZ, ZZZ;
+  bool empty = true;
+  for (u32 k = 0; k < cnt; k++) {
+    u32 e = sorted[start + k];
+    Aff<Fq> q = points[e & 0x7FFFFFFFu];
+    if (aff_is_inf(q)) continue;
+    q.y = f_cneg(q.y, (e >> 31) != 0);
+    const U29 X2 = u29_from_sat_shift5(q.x.l), Y2 = u29_from_sat_shift5(q.y.l);
+    if (empty) {
+      X1 = u29_mul(X2, u29_one());
+      Y1 = u29_mul(Y2, u29_one());
+      ZZ = u29_one();
+      ZZZ = u29_one();
+      empty = false;
+      continue;
+    }
+    const U29 U2 = u29_mul(X2, ZZ), S2 = u29_mul(Y2, ZZZ);
+    const U29 P = u29_sub(U2, X1, Q29::K16), R = u29_sub(S2, Y1, Q29::K4);
+    if (u29_maybe_zero(P)) {            // 18 in 2^29 for unrelated points; exact test only then
+      if (u29_is_zero(P)) {
+        if (u29_is_zero(R)) {           // same point: double it in the saturated arithmetic, re-enter
+          Xyzz<Fq> d = xyzz_dbl_aff(q);
+          X1 = u29_from_fq(d.x); Y1 = u29_from_fq(d.y); ZZ = u29_from_fq(d.zz); ZZZ = u29_from_fq(d.zzz);
+        } else {
+          empty = true;                 // opposite points
+        }
+        continue;
+      }
+    }
+    const U29 PP = u29_sqr(P), PPP = u29_mul(P, PP), Q = u29_mul(X1, PP);
+    const U29 X3 = u29_sub3(u29_sqr(R), PPP, Q);
+    const U29 T = u29_sub(Q, X3, Q29::K16);
+    Y1 = u29_sub(u29_mul(R, T), u29_mul(Y1, PPP), Q29::K2);
+    X1 = X3;
+    ZZ = u29_mul(ZZ, PP);
+    ZZZ = u29_mul(ZZZ, PPP);
+  }
+  Xyzz<Fq> out = xyzz_inf<Fq>();
+  if (!empty) {
+    out.x = u29_to_fq(X1); out.y = u29_to_fq(Y1); out.zz = u29_to_fq(ZZ); out.zzz = u29_to_fq(ZZZ);
+  }
+  buckets[t] = out;
 }
 
 // ---- K5: per-window weighted sum, chunked ----------------------------------------------------------

@@ -1,6 +1,7 @@
 // Host-side driver of the MSM pipeline (workspace sizing, window choice, kernel sequence), written
 // once and instantiated for G1 (msm_g1.hip) and G2 (msm_g2.hip).
 #pragma once
+#include <type_traits>
 #include "internal.h"
 #include "msm.cuh"
 
@@ -110,8 +111,17 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   hipLaunchKernelGGL(k_cnt_scatter, dim3(cdiv(nb, 1024)), dim3(256), 0, st, (const u32*)hist, (u32)nb, gstart, perm);
   ST_TRY(launch_check(ctx, "cnt_sort"));
   if (ctx->timing) (void)hipEventRecord(ctx->ev[1], st);
-  hipLaunchKernelGGL((k_msm_accumulate<F>), dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
-                     (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
+  bool u29 = false;
+  if constexpr (std::is_same<F, Fq>::value) {
+    static const bool use_u29 = !(getenv("KEAKI_ACC_U29") && atoi(getenv("KEAKI_ACC_U29")) == 0);   // A/B switch for profiling
+    u29 = use_u29;
+    if (u29)
+      hipLaunchKernelGGL(k_msm_accumulate_g1_u29, dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
+                         (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
+  }
+  if (!u29)
+    hipLaunchKernelGGL((k_msm_accumulate<F>), dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
+                       (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
   ST_TRY(launch_check(ctx, "msm_accumulate"));
   // heavy buckets (structured scalars only; the blocks exit immediately otherwise)
   ST_TRY(reserve(ctx, ctx->heavy, (size_t)HEAVY_MAX * HEAVY_SLICES * sizeof(Xyzz<F>)));

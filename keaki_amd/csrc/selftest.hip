@@ -1,5 +1,6 @@
 // On-device self-test of the hand-scheduled Fq streams against the portable template code.
 #include "pairing.cuh"
+#include "fq29.cuh"
 #include "internal.h"
 namespace bn254 {
 using FqRef = Fp<FqParamsRef>;
@@ -83,11 +84,49 @@ __global__ void __launch_bounds__(64) k_selftest_fq2d(u32 seed, u32 iters, unsig
   }
   if (bad) atomicAdd(mismatches, bad);
 }
+
+// 9 x 29-bit lazy arithmetic (fq29.cuh) against the saturated streams: every result is brought back with u29_to_fq
+__global__ void __launch_bounds__(256) k_selftest_u29(u32 seed, u32 iters, unsigned long long* mismatches) {
+  u32 s = (seed ^ (blockIdx.x * 0x9E3779B9u) ^ (threadIdx.x * 0xC2B2AE35u)) | 1u;
+  unsigned long long bad = 0;
+  for (u32 it = 0; it < iters; it++) {
+    u32 sh = mix(s);
+    Fq a = pick(s, (sh & 15) < 6 ? (sh & 15) : 0), b = pick(s, ((sh >> 4) & 15) < 6 ? ((sh >> 4) & 15) : 0), c = pick(s, 0), d = pick(s, 0);
+    // entry by the free 5-bit shift (value < 32p) and by the reducing entry (< 2p)
+    U29 al = u29_from_sat_shift5(a.l), bl = u29_from_sat_shift5(b.l);
+    U29 ar = u29_from_fq(a), br = u29_from_fq(b), cr = u29_from_fq(c), dr = u29_from_fq(d);
+    bad += !fq_eq(u29_to_fq(ar), a);
+    bad += !fq_eq(u29_to_fq(al), a);
+    bad += !fq_eq(u29_to_fq(u29_mul(al, br)), a * b);           // table coordinate x accumulator coordinate
+    bad += !fq_eq(u29_to_fq(u29_mul(ar, br)), a * b);
+    bad += !fq_eq(u29_to_fq(u29_sqr(ar)), fq_sqr(a));
+    // differences at every bias, then used as product operands (the shapes of the mixed addition)
+    U29 p16 = u29_sub(ar, br, Q29::K16), p4 = u29_sub(ar, br, Q29::K4), p2 = u29_sub(ar, br, Q29::K2);
+    bad += !fq_eq(u29_to_fq(p16), a - b);
+    bad += !fq_eq(u29_to_fq(p4), a - b);
+    bad += !fq_eq(u29_to_fq(p2), a - b);
+    bad += !fq_eq(u29_to_fq(u29_sqr(p16)), fq_sqr(a - b));
+    bad += !fq_eq(u29_to_fq(u29_mul(p16, u29_sqr(p16))), (a - b) * fq_sqr(a - b));
+    U29 x3 = u29_sub3(ar, br, cr);
+    bad += !fq_eq(u29_to_fq(x3), a - b - c - c);
+    U29 t = u29_sub(dr, x3, Q29::K16);
+    bad += !fq_eq(u29_to_fq(u29_mul(p4, t)), (a - b) * (d - (a - b - c - c)));
+    // zero filter and exact zero test
+    U29 z = u29_sub(ar, ar, Q29::K16);
+    bad += !u29_maybe_zero(z);
+    bad += !u29_is_zero(z);
+    bad += u29_is_zero(p16) != fq_eq(a, b);
+    bad += (fq_eq(a, b) && !u29_maybe_zero(p16));
+    bad += u29_is_zero(ar) != fq_is_zero(a);
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
 }  // namespace bn254
 namespace keaki_internal {
 keaki_status selftest_field_run(keaki_hip_ctx* ctx, uint32_t blocks, uint32_t iters, uint32_t seed, void* d_mismatches) {
   hipLaunchKernelGGL(bn254::k_selftest_field, dim3(blocks), dim3(256), 0, ctx->stream, seed, iters, (unsigned long long*)d_mismatches);
   hipLaunchKernelGGL(bn254::k_selftest_fq2d, dim3(blocks), dim3(64), 0, ctx->stream, seed, iters > 8 ? 8u : iters, (unsigned long long*)d_mismatches);
+  hipLaunchKernelGGL(bn254::k_selftest_u29, dim3(blocks), dim3(256), 0, ctx->stream, seed, iters, (unsigned long long*)d_mismatches);
   return launch_check(ctx, "selftest_field");
 }
 }  // namespace keaki_internal
