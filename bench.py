@@ -233,10 +233,12 @@ def main():
     avg_bucket_s = float(np.mean(bucket_ms)) * 1e-3
     achieved_gbs = ALGO_BYTES_PER_SCALAR_MUL * n / avg_bucket_s / 1e9
     windows = (254 + stats["window_bits"] - 1) // stats["window_bits"]
-    # integer roofline: one XYZZ mixed add = 8M + 2S = 10 Montgomery products; measured issue rate of
-    # v_mad_u64_u32 / v_add on gfx950 is 1 wave-instruction per ~4.3 cycles per SIMD (profiles/r01_ubench_int_gfx950.txt);
-    # the hand-scheduled 8x32-bit Montgomery product is ~300 issues (128 mad + 8 mul_lo + 127 carry counts + slide/reduce).
-    modmul_peak = 1024 * 2.4e9 / 4.3 * 64 / 300.0
+    # integer roofline: one XYZZ mixed add = 8M + 2S = 10 Montgomery products. Measured issue rate of v_mad_u64_u32 / 32-bit
+    # VALU on gfx950: 1 wave-instruction per ~4.3 cycles per SIMD (profiles/r01_ubench_int_gfx950.txt). The common path of one
+    # mixed addition in k_msm_accumulate_g1_u29 (9 x 29-bit lazy limbs, fq29.cuh) is 2567 instructions in the shipped ISA
+    # (1710 v_mad_u64_u32: 8 x 162 + 2 x 126 + the 9 m_k p_0 of each product; the rest slides, masks, carries, loads).
+    ISSUES_PER_MIXED_ADD = 2567.0
+    modmul_peak = 1024 * 2.4e9 / 4.3 * 64 / ISSUES_PER_MIXED_ADD * 10.0
     modmuls = 10.0 * n * windows / avg_bucket_s
     # HBM traffic of the dominant kernel from PMC counters (separate rocprofv3 --pmc passes, committed under profiles/)
     traffic = None
@@ -258,18 +260,18 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u32x8 Montgomery (256-bit modular integer)",
+        "dtype": "u32 limbs, 256-bit Montgomery modular integer (9 x 29-bit lazy limbs in the bucket kernel, 8 x 32 elsewhere)",
         "data": "synthetic: scalars uniform in [0,r) (SplitMix64), points k_i*G generated on device",
         "config": {"workload": "2^%d-point BN254 G1 Pippenger MSM per GPU, SRS + scalars resident in HBM%s" % (
             args.log2n, "" if world == 1 else "; %d chunks, RCCL all-gather of 96-B partial sums + %d EC adds" % (world, world - 1)),
             "points_per_gpu": n, "window_bits": stats["window_bits"], "windows": windows, "setup_s": round(gen_s, 2),
                    "srs_window_tables_bytes": table_bytes},
-        "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate<Fq>", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate_g1_u29", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": ALGO_BYTES_PER_SCALAR_MUL * n,
                      "kernel_ms": avg_bucket_s * 1e3, "msm_total_ms": stats["total_ms"]},
         "kem": kem,
         "alu": {"bound": "integer issue (v_mad_u64_u32)", "achieved": modmuls / 1e9, "peak": modmul_peak / 1e9, "unit": "G modmul/s",
-                "frac": modmuls / modmul_peak},
+                "frac": modmuls / modmul_peak, "issues_per_mixed_add": ISSUES_PER_MIXED_ADD},
     }
 
     # ---- correctness of what was timed + CPU baseline (oracle = checker only) ------------------------
