@@ -154,6 +154,14 @@ KDEV U29 u29_sub(const U29& a, const U29& b, const u32 (&K)[9]) {
   for (int i = 0; i < 9; i++) t.l[i] = a.l[i] - b.l[i] + K[i];
   return u29_carry(t);
 }
+// the same without the carry pass: limbs below 2^31. Allowed as ONE operand of a product whose other operand is carried, as
+// the subtrahend of a difference biased by 2^31, and into u29_to_sat; never squared.
+KDEV U29 u29_sub_raw(const U29& a, const U29& b, const u32 (&K)[9]) {
+  U29 t;
+#pragma unroll
+  for (int i = 0; i < 9; i++) t.l[i] = a.l[i] - b.l[i] + K[i];
+  return t;
+}
 // a - b - 2c + 8p  (bias 2^31)
 KDEV U29 u29_sub3(const U29& a, const U29& b, const U29& c) {
   U29 t;

@@ -498,7 +498,7 @@ static __global__ void __launch_bounds__(256) k_msm_accumulate_g1_u29(const Aff<
       continue;
     }
     const U29 U2 = u29_mul(X2, ZZ), S2 = u29_mul(Y2, ZZZ);
-    const U29 P = u29_sub(U2, X1, Q29::K16), R = u29_sub(S2, Y1, Q29::K4);
+    const U29 P = u29_sub(U2, X1, Q29::K16), R = u29_sub(S2, Y1, Q29::K4W);   // Y1 is kept uncarried (limbs < 2^31)
     if (u29_maybe_zero(P)) {            // 18 in 2^29 for unrelated points; exact test only then
       if (u29_is_zero(P)) {
         if (u29_is_zero(R)) {           // same point: double it in the saturated arithmetic, re-enter
@@ -512,8 +512,8 @@ static __global__ void __launch_bounds__(256) k_msm_accumulate_g1_u29(const Aff<
     }
     const U29 PP = u29_sqr(P), PPP = u29_mul(P, PP), Q = u29_mul(X1, PP);
     const U29 X3 = u29_sub3(u29_sqr(R), PPP, Q);
-    const U29 T = u29_sub(Q, X3, Q29::K16);
-    Y1 = u29_sub(u29_mul(R, T), u29_mul(Y1, PPP), Q29::K2);
+    const U29 T = u29_sub_raw(Q, X3, Q29::K16);                                 // only multiplied by the carried R
+    Y1 = u29_sub_raw(u29_mul(R, T), u29_mul(Y1, PPP), Q29::K2);
     X1 = X3;
     ZZ = u29_mul(ZZ, PP);
     ZZZ = u29_mul(ZZZ, PPP);

@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256) k_selftest_u29(u32 seed, u32 iters, unsig
     u32 sh = mix(s);
     Fq a = pick(s, (sh & 15) < 6 ? (sh & 15) : 0), b = pick(s, ((sh >> 4) & 15) < 6 ? ((sh >> 4) & 15) : 0), c = pick(s, 0), d = pick(s, 0);
     // entry by the free 5-bit shift (value < 32p) and by the reducing entry (< 2p)
-    U29 al = u29_from_sat_shift5(a.l), bl = u29_from_sat_shift5(b.l);
+    U29 al = u29_from_sat_shift5(a.l);
     U29 ar = u29_from_fq(a), br = u29_from_fq(b), cr = u29_from_fq(c), dr = u29_from_fq(d);
     bad += !fq_eq(u29_to_fq(ar), a);
     bad += !fq_eq(u29_to_fq(al), a);
@@ -109,8 +109,14 @@ __global__ void __launch_bounds__(256) k_selftest_u29(u32 seed, u32 iters, unsig
     bad += !fq_eq(u29_to_fq(u29_mul(p16, u29_sqr(p16))), (a - b) * fq_sqr(a - b));
     U29 x3 = u29_sub3(ar, br, cr);
     bad += !fq_eq(u29_to_fq(x3), a - b - c - c);
-    U29 t = u29_sub(dr, x3, Q29::K16);
+    U29 t = u29_sub_raw(dr, x3, Q29::K16);
     bad += !fq_eq(u29_to_fq(u29_mul(p4, t)), (a - b) * (d - (a - b - c - c)));
+    {  // uncarried difference as subtrahend (bias 2^31), as a factor, and on the way out
+      U29 y = u29_sub_raw(u29_mul(ar, br), u29_mul(cr, dr), Q29::K2);
+      bad += !fq_eq(u29_to_fq(y), a * b - c * d);
+      bad += !fq_eq(u29_to_fq(u29_sub(ar, y, Q29::K4W)), a - (a * b - c * d));
+      bad += !fq_eq(u29_to_fq(u29_mul(y, br)), (a * b - c * d) * b);
+    }
     // zero filter and exact zero test
     U29 z = u29_sub(ar, ar, Q29::K16);
     bad += !u29_maybe_zero(z);
