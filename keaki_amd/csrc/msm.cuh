@@ -18,6 +18,7 @@
 #pragma once
 #include "bn254_curve.cuh"
 #include "fq29.cuh"
+#include "xyzz29.cuh"
 
 namespace bn254 {
 
@@ -536,67 +537,77 @@ __global__ void __launch_bounds__(64) k_msm_reduce(const Xyzz<F>* __restrict__ b
   u32 lo = t * L;
   const u32 Bw = msm_nbuckets(s, w);
   const Xyzz<F>* bk = buckets + msm_bucket_base(s, w);
-  Xyzz<F> run = xyzz_inf<F>(), ws = xyzz_inf<F>();
+  typedef TailOps<F> O;
+  typename O::P run = O::inf(), ws = O::inf();
   for (u32 j = L; j-- > 0;) {
     if (lo + j < Bw) {
-      run = xyzz_add(run, bk[lo + j]);
-      ws = xyzz_add(ws, run);
+      run = O::add(run, O::load(bk[lo + j]));
+      ws = O::add(ws, run);
     }
   }
   // ws += lo * run   (lo < 2^c), MSB-first double-and-add
   if (lo != 0 && lo < Bw) {
-    Xyzz<F> m = xyzz_inf<F>();
+    typename O::P m = O::inf();
     for (int b = 31 - __clz(lo); b >= 0; b--) {
-      m = xyzz_dbl(m);
-      if ((lo >> b) & 1) m = xyzz_add(m, run);
+      m = O::dbl(m);
+      if ((lo >> b) & 1) m = O::add(m, run);
     }
-    ws = xyzz_add(ws, m);
+    ws = O::add(ws, m);
   }
-  partials[g] = ws;
+  partials[g] = O::store(ws);
 }
 
 // ---- K5b: sum groups of G consecutive chunk partials of each window (keeps K6a's serial part short) -------------
 template <class F>
 __global__ void __launch_bounds__(64) k_msm_partial_groups(const Xyzz<F>* __restrict__ in, u32 chunks_in, u32 G, u32 chunks_out,
                                                            Xyzz<F>* __restrict__ out) {
-  __shared__ Xyzz<F> sh[64];
+  typedef TailOps<F> O;
+  __shared__ typename O::P sh[64];
   u32 w = blockIdx.y, x = blockIdx.x, l = threadIdx.x;
-  Xyzz<F> acc = xyzz_inf<F>();
-  for (u32 t = x * G + l; t < (x + 1) * G && t < chunks_in; t += 64) acc = xyzz_add(acc, in[(size_t)w * chunks_in + t]);
+  typename O::P acc = O::inf();
+  for (u32 t = x * G + l; t < (x + 1) * G && t < chunks_in; t += 64) acc = O::add(acc, O::load(in[(size_t)w * chunks_in + t]));
   sh[l] = acc;
   __syncthreads();
   for (u32 o = 32; o > 0; o >>= 1) {
-    if (l < o) sh[l] = xyzz_add(sh[l], sh[l + o]);
+    if (l < o) sh[l] = O::add(sh[l], sh[l + o]);
     __syncthreads();
   }
-  if (l == 0) out[(size_t)w * chunks_out + x] = sh[0];
+  if (l == 0) out[(size_t)w * chunks_out + x] = O::store(sh[0]);
 }
 
 // ---- K6a: sum the chunk partials of each window, then scale by 2^(w c) ---------------------------------
 template <class F>
 __global__ void __launch_bounds__(64) k_msm_window_finish(const Xyzz<F>* __restrict__ partials, MsmShape s, u32 chunks_per_window,
                                                           Xyzz<F>* __restrict__ window_sums) {
-  __shared__ Xyzz<F> sh[64];
+  typedef TailOps<F> O;
+  __shared__ typename O::P sh[64];
   u32 w = blockIdx.x, l = threadIdx.x;
-  Xyzz<F> acc = xyzz_inf<F>();
-  for (u32 t = l; t < chunks_per_window; t += 64) acc = xyzz_add(acc, partials[(size_t)w * chunks_per_window + t]);
+  typename O::P acc = O::inf();
+  for (u32 t = l; t < chunks_per_window; t += 64) acc = O::add(acc, O::load(partials[(size_t)w * chunks_per_window + t]));
   sh[l] = acc;
   __syncthreads();
   for (u32 o = 32; o > 0; o >>= 1) {
-    if (l < o) sh[l] = xyzz_add(sh[l], sh[l + o]);
+    if (l < o) sh[l] = O::add(sh[l], sh[l + o]);
     __syncthreads();
   }
   if (l == 0) {
-    Xyzz<F> r = sh[0];
-    for (u32 k = 0, nd = msm_bit_offset(s, w); k < nd; k++) r = xyzz_dbl(r);
-    window_sums[w] = r;
+    typename O::P r = sh[0];
+    for (u32 k = 0, nd = msm_bit_offset(s, w); k < nd; k++) r = O::dbl(r);
+    window_sums[w] = O::store(r);
   }
 }
 
 // write a point as normalised Jacobian (x, y, 1) / (1, 1, 0)
+template <class F> KDEV Aff<F> xyzz_to_aff_tail(const Xyzz<F>& p) { return xyzz_to_aff(p); }
+template <> KDEV Aff<Fq> xyzz_to_aff_tail<Fq>(const Xyzz<Fq>& p) {   // single lane: the binary-GCD inverse instead of the Fermat ladder
+  if (xyzz_is_inf(p)) return aff_inf<Fq>();
+  Fq izzz = fq_inv_xgcd(p.zzz);
+  Fq izz = fq_sqr(izzz) * fq_sqr(p.zz);
+  return {p.x * izz, p.y * izzz};
+}
 template <class F>
 KDEV void store_norm_jac(F* out, const Xyzz<F>& p) {
-  Aff<F> a = xyzz_to_aff(p);
+  Aff<F> a = xyzz_to_aff_tail(p);
   if (xyzz_is_inf(p)) {
     out[0] = f_one<F>(); out[1] = f_one<F>(); out[2] = f_zero<F>();
   } else {

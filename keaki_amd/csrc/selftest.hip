@@ -1,6 +1,7 @@
 // On-device self-test of the hand-scheduled Fq streams against the portable template code.
 #include "pairing.cuh"
 #include "fq29.cuh"
+#include "xyzz29.cuh"
 #include "internal.h"
 namespace bn254 {
 using FqRef = Fp<FqParamsRef>;
@@ -42,6 +43,7 @@ __global__ void __launch_bounds__(256) k_selftest_field(u32 seed, u32 iters, uns
     bad += !same(a - b, fp_sub<FqParamsRef>(ar, br));
     bad += !same(-a, fp_neg<FqParamsRef>(ar));
     bad += !same(fq_sqr(a), fp_mul<FqParamsRef>(ar, ar));
+    if ((it & 15) == 0) bad += !fq_eq(fq_inv_xgcd(a), fq_inv(a));     // binary-GCD inverse == Fermat ladder (incl. 0, p-1, tiny values)
     // dependent chain (exercises back-to-back streams)
     chain = chain * a + b - chain * chain;
     chain_ref = fp_sub<FqParamsRef>(fp_add<FqParamsRef>(fp_mul<FqParamsRef>(chain_ref, ar), br), fp_mul<FqParamsRef>(chain_ref, chain_ref));
@@ -127,11 +129,47 @@ __global__ void __launch_bounds__(256) k_selftest_u29(u32 seed, u32 iters, unsig
   }
   if (bad) atomicAdd(mismatches, bad);
 }
+
+// XYZZ addition / doubling in the 29-bit representation (xyzz29.cuh) against the saturated formulas, projectively compared
+KDEV bool xyzz_same(const Xyzz<Fq>& a, const Xyzz<Fq>& b) {
+  if (xyzz_is_inf(a) || xyzz_is_inf(b)) return xyzz_is_inf(a) && xyzz_is_inf(b);
+  return fq_eq(a.x * b.zz, b.x * a.zz) && fq_eq(a.y * b.zzz, b.y * a.zzz);
+}
+__global__ void __launch_bounds__(64) k_selftest_x29(u32 seed, u32 iters, unsigned long long* mismatches) {
+  u32 s = (seed ^ ((blockIdx.x * 64 + threadIdx.x) * 0x9E3779B9u)) | 1u;
+  unsigned long long bad = 0;
+  const Aff<Fq> g = {G1_GEN_X, G1_GEN_Y};
+  Xyzz<Fq> p = xyzz_from_aff(g), q = xyzz_dbl_aff(g);
+  for (u32 it = 0; it < iters; it++) {
+    u32 r = mix(s);
+    // walk two pseudo-random multiples of the generator with the saturated arithmetic
+    p = (r & 1) ? xyzz_add(xyzz_dbl(p), q) : xyzz_add_mixed(xyzz_dbl(p), g);
+    q = (r & 2) ? xyzz_add(q, p) : xyzz_dbl(q);
+    const X29 pl = x29_load(p), ql = x29_load(q);
+    bad += !xyzz_same(x29_store(x29_add(pl, ql)), xyzz_add(p, q));
+    bad += !xyzz_same(x29_store(x29_dbl(pl)), xyzz_dbl(p));
+    bad += !xyzz_same(x29_store(x29_add(pl, pl)), xyzz_dbl(p));                            // equal inputs -> doubling branch
+    bad += !xyzz_is_inf(x29_store(x29_add(pl, x29_load(xyzz_neg(p)))));                    // opposite inputs -> infinity
+    bad += !xyzz_same(x29_store(x29_add(x29_inf(), ql)), q);
+    bad += !xyzz_same(x29_store(x29_add(ql, x29_load(xyzz_inf<Fq>()))), q);
+    // chains stay inside the working form: (p + q) + 2p + q
+    bad += !xyzz_same(x29_store(x29_add(x29_add(x29_add(pl, ql), x29_dbl(pl)), ql)), xyzz_add(xyzz_add(xyzz_add(p, q), xyzz_dbl(p)), q));
+    bad += !xyzz_same(x29_store(x29_dbl(x29_dbl(x29_dbl(ql)))), xyzz_dbl(xyzz_dbl(xyzz_dbl(q))));
+    // stored coordinates are canonical
+    Xyzz<Fq> st = x29_store(x29_add(pl, ql));
+    u32 t[8];
+    for (int j = 0; j < 8; j++) t[j] = st.x.l[j];
+    fp_reduce_once<FqParamsRef>(t);
+    for (int j = 0; j < 8; j++) bad += (t[j] != st.x.l[j]);
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
 }  // namespace bn254
 namespace keaki_internal {
 keaki_status selftest_field_run(keaki_hip_ctx* ctx, uint32_t blocks, uint32_t iters, uint32_t seed, void* d_mismatches) {
   hipLaunchKernelGGL(bn254::k_selftest_field, dim3(blocks), dim3(256), 0, ctx->stream, seed, iters, (unsigned long long*)d_mismatches);
   hipLaunchKernelGGL(bn254::k_selftest_fq2d, dim3(blocks), dim3(64), 0, ctx->stream, seed, iters > 8 ? 8u : iters, (unsigned long long*)d_mismatches);
+  hipLaunchKernelGGL(bn254::k_selftest_x29, dim3(blocks > 64 ? 64 : blocks), dim3(64), 0, ctx->stream, seed, iters > 16 ? 16u : iters, (unsigned long long*)d_mismatches);
   hipLaunchKernelGGL(bn254::k_selftest_u29, dim3(blocks), dim3(256), 0, ctx->stream, seed, iters, (unsigned long long*)d_mismatches);
   return launch_check(ctx, "selftest_field");
 }
