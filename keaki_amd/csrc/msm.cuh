@@ -164,8 +164,9 @@ __device__ __forceinline__ u32 lds_exclusive_scan(u32* a, u32 len, u32* wsum) {
   return tot;
 }
 
-// pass 1a: counts[bin * nwg + wg]
-static __global__ void __launch_bounds__(P1_THREADS) k_part_count(const Fr* __restrict__ scalars, MsmShape s, PartShape ps, u32* __restrict__ counts) {
+// pass 1a: counts[bin * nwg + wg] (the order of the global scan) and counts_t[wg * nbins + bin] (read back, coalesced, by pass 1b)
+static __global__ void __launch_bounds__(P1_THREADS) k_part_count(const Fr* __restrict__ scalars, MsmShape s, PartShape ps, u32* __restrict__ counts,
+                                                                  u32* __restrict__ counts_t) {
   __shared__ u32 hist[PART_MAX_BINS];
   for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) hist[b] = 0;
   __syncthreads();
@@ -177,30 +178,32 @@ static __global__ void __launch_bounds__(P1_THREADS) k_part_count(const Fr* __re
     });
   }
   __syncthreads();
-  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) counts[(size_t)b * ps.nwg + blockIdx.x] = hist[b];
+  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) {
+    u32 c = hist[b];
+    counts[(size_t)b * ps.nwg + blockIdx.x] = c;
+    counts_t[(size_t)blockIdx.x * ps.nbins + b] = c;
+  }
 }
 // pass 1b: entries[pos] = bucket id g << 32 | sign << 31 | point (table row) index
 static __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const Fr* __restrict__ scalars, MsmShape s, PartShape ps,
-                                                                    const u32* __restrict__ offsets, u64* __restrict__ entries) {
+                                                                    const u32* __restrict__ offsets, const u32* __restrict__ counts_t,
+                                                                    u64* __restrict__ entries) {
   __shared__ u64 ent[P1_CAP];
   __shared__ u32 cur[PART_MAX_BINS];
   __shared__ u32 goff[PART_MAX_BINS];
   __shared__ u32 wsum[P1_THREADS / 64];
-  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) { cur[b] = 0; goff[b] = offsets[(size_t)b * ps.nwg + blockIdx.x]; }
-  __syncthreads();
+  // the tile's histogram was made by pass 1a: no second digit walk for it
+  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) {
+    cur[b] = counts_t[(size_t)blockIdx.x * ps.nbins + b];
+    goff[b] = offsets[(size_t)b * ps.nwg + blockIdx.x];
+  }
   const u32 i = blockIdx.x * ps.tile + threadIdx.x;
   const bool act = threadIdx.x < ps.tile && i < s.n;
-  u32 k[8];                                                  // canonical scalar, kept for the second digit walk
-  if (act) {
-    fp_from_mont<FrParams>(k, scalars[i]);
-    msm_for_each_digit_canon(k, s, [&](u32 w, u32 code) {
-      u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
-      atomicAdd(&cur[g >> ps.shift], 1u);
-    });
-  }
+  Fr k;
+  if (act) k = scalars[i];
   const u32 m = lds_exclusive_scan(cur, ps.nbins, wsum);     // cur[b] = start of bin b inside the tile
   if (act) {
-    msm_for_each_digit_canon(k, s, [&](u32 w, u32 code) {
+    msm_for_each_digit(k, s, [&](u32 w, u32 code) {
       u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
       u32 pos = atomicAdd(&cur[g >> ps.shift], 1u);           // afterwards cur[b] = end of bin b = start of bin b + 1
       ent[pos] = ((u64)g << 32) | (code & 0x80000000u) | (i + w * s.stride);
@@ -243,19 +246,26 @@ static __global__ void __launch_bounds__(P2_THREADS) k_part_fine(const u64* __re
     if (2 * t + 1 < nf) { cursor[2 * t + 1] = hist[2 * t + 1]; if (g0 + 1 < nbuckets_total) { bucket_offsets[g0 + 1] = lo + hist[2 * t + 1]; bucket_counts[g0 + 1] = c1; } }
   }
   __syncthreads();
+  constexpr u32 PER = P2_CAP / P2_THREADS;
   for (u32 cb = 0; cb < m; cb += P2_CAP) {
     const u32 mc = m - cb < P2_CAP ? m - cb : P2_CAP;
     const u64* src = entries + lo + cb;
+    u64 e[PER];                                     // the chunk stays in registers between the two LDS phases
+#pragma unroll
+    for (u32 k = 0; k < PER; k++) { u32 q = k * P2_THREADS + t; e[k] = q < mc ? src[q] : 0ull; }
     if (m > P2_CAP) {                               // a single chunk reuses the whole-bin scan that is already in hist
       for (u32 f = t; f < nf; f += P2_THREADS) hist[f] = 0;
       __syncthreads();
-      for (u32 q = t; q < mc; q += P2_THREADS) atomicAdd(&hist[(u32)(src[q] >> 32) & mask], 1u);
+#pragma unroll
+      for (u32 k = 0; k < PER; k++) if (k * P2_THREADS + t < mc) atomicAdd(&hist[(u32)(e[k] >> 32) & mask], 1u);
       lds_exclusive_scan(hist, nf, wsum);
     }
-    for (u32 q = t; q < mc; q += P2_THREADS) {
-      u64 v = src[q];
-      u32 pos = atomicAdd(&hist[(u32)(v >> 32) & mask], 1u);   // afterwards hist[f] = end of bucket f inside the chunk
-      pay[pos] = (u32)v;
+#pragma unroll
+    for (u32 k = 0; k < PER; k++) {
+      if (k * P2_THREADS + t < mc) {
+        u32 pos = atomicAdd(&hist[(u32)(e[k] >> 32) & mask], 1u);   // afterwards hist[f] = end of bucket f inside the chunk
+        pay[pos] = (u32)e[k];
+      }
     }
     __syncthreads();
     if (m <= P2_CAP) {                              // the chunk is the bin: the LDS image is the output

@@ -85,18 +85,18 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   ST_TRY(reserve(ctx, ctx->sorted, n * s.W * 4));
   ST_TRY(reserve(ctx, ctx->hist, nb * 4));             // per-bucket counts
   ST_TRY(reserve(ctx, ctx->offsets, nb * 4));          // per-bucket start offsets
-  ST_TRY(reserve(ctx, ctx->cursor, (ncounts * 2 + 4) * 4));  // [counts | exclusive scan] of the (bin, workgroup) table
+  ST_TRY(reserve(ctx, ctx->cursor, (ncounts * 3 + 4) * 4));  // [counts | exclusive scan | total | counts, workgroup-major] of the (bin, workgroup) table
   ST_TRY(reserve(ctx, ctx->buckets, nb * sizeof(Xyzz<F>)));
   ST_TRY(reserve(ctx, ctx->partials, ((size_t)rs.W * chunks + (size_t)rs.W * 256) * sizeof(Xyzz<F>)));
   u64* entries = (u64*)ctx->digits.p;
   u32 *sorted = (u32*)ctx->sorted.p, *hist = (u32*)ctx->hist.p, *offsets = (u32*)ctx->offsets.p;
-  u32 *pcounts = (u32*)ctx->cursor.p, *poffsets = pcounts + ncounts;
+  u32 *pcounts = (u32*)ctx->cursor.p, *poffsets = pcounts + ncounts, *pcounts_t = poffsets + ncounts + 4;
   Xyzz<F>* buckets = (Xyzz<F>*)ctx->buckets.p;
   Xyzz<F>* partials = (Xyzz<F>*)ctx->partials.p;
-  hipLaunchKernelGGL(k_part_count, dim3(ps.nwg), dim3(P1_THREADS), 0, st, (const Fr*)d_scalars, s, ps, pcounts);
+  hipLaunchKernelGGL(k_part_count, dim3(ps.nwg), dim3(P1_THREADS), 0, st, (const Fr*)d_scalars, s, ps, pcounts, pcounts_t);
   ST_TRY(launch_check(ctx, "part_count"));
   ST_TRY(device_scan(ctx, pcounts, (u32)ncounts, poffsets));
-  hipLaunchKernelGGL(k_part_scatter, dim3(ps.nwg), dim3(P1_THREADS), 0, st, (const Fr*)d_scalars, s, ps, (const u32*)poffsets, entries);
+  hipLaunchKernelGGL(k_part_scatter, dim3(ps.nwg), dim3(P1_THREADS), 0, st, (const Fr*)d_scalars, s, ps, (const u32*)poffsets, (const u32*)pcounts_t, entries);
   ST_TRY(launch_check(ctx, "part_scatter"));
   hipLaunchKernelGGL(k_part_total, dim3(1), dim3(64), 0, st, (const u32*)pcounts, (const u32*)poffsets, (u32)ncounts, poffsets + ncounts);
   hipLaunchKernelGGL(k_part_fine, dim3(ps.nbins), dim3(P2_THREADS), 0, st, (const u64*)entries, (const u32*)poffsets, ps, (const u32*)(poffsets + ncounts),
