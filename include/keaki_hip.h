@@ -110,6 +110,14 @@ keaki_status keaki_hip_open_fk_poly(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, u
  * (pass omega^-1 and n^-1 for the inverse transform). */
 keaki_status keaki_hip_fr_fft(keaki_hip_ctx* ctx, uint64_t* data, uint32_t log2n, const uint64_t* omega, const uint64_t* scale_or_null);
 
+/* ---- SRS ingest (scope row f-3) -----------------------------------------------------------------------------------------
+ * The reference reads .ptau points with `deserialize_uncompressed_unchecked` (src/kzg/ptau.rs:266,314): no curve check at all.
+ * A snarkjs .ptau stores coordinates as Montgomery limbs, which is this ABI's point layout, so sections 2 and 3 are uploaded
+ * verbatim (keaki_hip_srs_g1_upload) and checked on the device: the number of points with y^2 != x^3 + b (b = 3 on G1,
+ * 3/(9+u) on the twist; (0,0) = identity passes) and the index of the first one (UINT64_MAX if none; may be NULL). */
+keaki_status keaki_hip_srs_g1_check(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, uint64_t* n_off_curve, uint64_t* first_off_curve);
+keaki_status keaki_hip_g2_check(keaki_hip_ctx* ctx, const uint64_t* points_aff, size_t n, uint64_t* n_off_curve, uint64_t* first_off_curve);
+
 /* ---- batched scalar multiplication: replaces `.mul(scalar)` (src/kem.rs:22,30,36,37; src/kzg.rs:57,60,135,144)
  * out[i] = scalars[i] * points[i]   (point_stride = 1) or scalars[i] * points[0] (point_stride = 0).
  * points affine in, affine out. */

@@ -565,6 +565,30 @@ keaki_status keaki_hip_final_exp_batch(keaki_hip_ctx* ctx, const uint64_t* f_mon
   return download(ctx, gt_out, ctx->io_b.p, n * 384);
 }
 
+// ---- SRS ingest: on-curve check (row f-3) ------------------------------------------------------------------------
+static keaki_status curve_check_common(keaki_hip_ctx* ctx, bool g2, const void* d_pts, size_t n, uint64_t* n_off_curve, uint64_t* first_off_curve) {
+  ST_TRY(reserve(ctx, ctx->io_e, 16));
+  const uint64_t init[2] = {0, ~0ull};
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->io_e.p, init, 16, hipMemcpyHostToDevice, ctx->stream));
+  if (n) ST_TRY(g2 ? g2_curve_check_run(ctx, d_pts, n, ctx->io_e.p) : g1_curve_check_run(ctx, d_pts, n, ctx->io_e.p));
+  uint64_t res[2];
+  ST_TRY(download(ctx, res, ctx->io_e.p, 16));
+  *n_off_curve = res[0];
+  if (first_off_curve) *first_off_curve = res[1];
+  return KEAKI_OK;
+}
+keaki_status keaki_hip_srs_g1_check(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, uint64_t* n_off_curve, uint64_t* first_off_curve) {
+  CTX_GUARD(ctx);
+  if (!srs || !n_off_curve) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g1_check: null pointer");
+  return curve_check_common(ctx, false, srs->d, srs->n, n_off_curve, first_off_curve);
+}
+keaki_status keaki_hip_g2_check(keaki_hip_ctx* ctx, const uint64_t* points_aff, size_t n, uint64_t* n_off_curve, uint64_t* first_off_curve) {
+  CTX_GUARD(ctx);
+  if (!n_off_curve || (n && !points_aff)) return fail(ctx, KEAKI_ERR_BAD_ARG, "g2_check: null pointer");
+  ST_TRY(upload(ctx, ctx->io_a, points_aff, n * 128));
+  return curve_check_common(ctx, true, ctx->io_a.p, n, n_off_curve, first_off_curve);
+}
+
 // ---- self-test --------------------------------------------------------------------------------------------
 keaki_status keaki_hip_selftest_field(keaki_hip_ctx* ctx, uint32_t blocks, uint32_t iters, uint32_t seed, uint64_t* mismatches_out) {
   CTX_GUARD(ctx);

@@ -131,4 +131,26 @@ __global__ void __launch_bounds__(64) k_encap_fixed(const Aff<F>* __restrict__ t
   out[i] = xyzz_to_aff(acc);
 }
 
+
+// ---- on-curve check of affine points (SRS ingest, reference src/kzg/ptau.rs:266,314 deserialises *unchecked*) ----------------
+// counts points with y^2 != x^3 + b; (0, 0) is the identity and passes. b = 3 on G1, 3/(9+u) on the twist.
+KDEV Fq curve_b(const Fq*) {
+  Fq three = fq_one();
+  three = three + three + three;
+  return three;
+}
+KDEV Fq2 curve_b(const Fq2*) { return G2_B; }
+template <class F>
+__global__ void __launch_bounds__(256) k_curve_check(const Aff<F>* __restrict__ pts, u32 n, unsigned long long* __restrict__ bad,
+                                                     unsigned long long* __restrict__ first_bad) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff<F> p = pts[i];
+  if (aff_is_inf(p)) return;
+  F lhs = f_sqr(p.y), rhs = f_sqr(p.x) * p.x + curve_b((const F*)nullptr);
+  if (!f_eq(lhs, rhs)) {
+    atomicAdd(bad, 1ull);
+    atomicMin(first_bad, (unsigned long long)i);
+  }
+}
 }  // namespace bn254

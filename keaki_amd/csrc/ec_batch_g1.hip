@@ -33,4 +33,9 @@ keaki_status encap_g1_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, const v
                      (const Fr*)d_rs, (u32)n, (G1Aff*)d_out);
   return launch_check(ctx, "encap_g1_fixed");
 }
+keaki_status g1_curve_check_run(keaki_hip_ctx* ctx, const void* d_pts, size_t n, void* d_bad2) {
+  hipLaunchKernelGGL((k_curve_check<Fq>), dim3(cdiv(n ? n : 1, 256)), dim3(256), 0, ctx->stream, (const G1Aff*)d_pts, (u32)n,
+                     (unsigned long long*)d_bad2, (unsigned long long*)d_bad2 + 1);
+  return launch_check(ctx, "g1_curve_check");
+}
 }  // namespace keaki_internal

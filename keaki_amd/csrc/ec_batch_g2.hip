@@ -30,4 +30,9 @@ keaki_status encap_g2_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, const v
                      (const Fr*)d_rs, (u32)n, (G2Aff*)d_out);
   return launch_check(ctx, "encap_g2_fixed");
 }
+keaki_status g2_curve_check_run(keaki_hip_ctx* ctx, const void* d_pts, size_t n, void* d_bad2) {
+  hipLaunchKernelGGL((k_curve_check<Fq2>), dim3(cdiv(n ? n : 1, 256)), dim3(256), 0, ctx->stream, (const G2Aff*)d_pts, (u32)n,
+                     (unsigned long long*)d_bad2, (unsigned long long*)d_bad2 + 1);
+  return launch_check(ctx, "g2_curve_check");
+}
 }  // namespace keaki_internal

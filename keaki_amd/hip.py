@@ -23,7 +23,7 @@ EXPORTS = [
     "keaki_hip_g1_mul_batch", "keaki_hip_g2_mul_batch", "keaki_hip_g1_mul_batch_dev", "keaki_hip_g2_mul_batch_dev",
     "keaki_hip_pairing_batch", "keaki_hip_pairing_batch_dev",
     "keaki_hip_encap_batch", "keaki_hip_encap_batch_dev", "keaki_hip_decap_batch", "keaki_hip_decap_batch_dev",
-    "keaki_hip_selftest_field", "keaki_hip_open_fk", "keaki_hip_open_fk_poly", "keaki_hip_fr_fft", "keaki_hip_final_exp_batch", "keaki_hip_miller_loop_batch", "keaki_hip_g2_prepare", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
+    "keaki_hip_selftest_field", "keaki_hip_open_fk", "keaki_hip_open_fk_poly", "keaki_hip_fr_fft", "keaki_hip_srs_g1_check", "keaki_hip_g2_check", "keaki_hip_final_exp_batch", "keaki_hip_miller_loop_batch", "keaki_hip_g2_prepare", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
 ]
 
 KEAKI_ERR_TOO_LARGE = -5
@@ -81,6 +81,8 @@ def load_library():
         lib.keaki_hip_open_fk.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp, vp]
         lib.keaki_hip_open_fk_poly.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp, vp]
         lib.keaki_hip_fr_fft.argtypes = [vp, vp, C.c_uint32, vp, vp]
+        lib.keaki_hip_srs_g1_check.argtypes = [vp, vp, vp, vp]
+        lib.keaki_hip_g2_check.argtypes = [vp, vp, C.c_size_t, vp, vp]
         lib.keaki_hip_final_exp_batch.argtypes = [vp, vp, sz, vp]
         lib.keaki_hip_miller_loop_batch.argtypes = [vp, vp, vp, sz, vp]
         lib.keaki_hip_set_timing.argtypes = [vp, i32]
@@ -258,6 +260,18 @@ class KeakiHip:
         out = np.zeros((n, 384), np.uint8)
         self._ck(self.lib.keaki_hip_final_exp_batch(self.ctx, _ptr(f), n, _ptr(out)))
         return out
+
+    def srs_g1_check(self, srs: "SrsG1"):
+        """-> (number of off-curve points, index of the first or None)"""
+        bad, first = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self.lib.keaki_hip_srs_g1_check(self.ctx, srs.handle, C.byref(bad), C.byref(first)))
+        return bad.value, (None if bad.value == 0 else first.value)
+
+    def g2_check(self, points):
+        pts = _np(points, 16)
+        bad, first = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self.lib.keaki_hip_g2_check(self.ctx, _ptr(pts), pts.shape[0], C.byref(bad), C.byref(first)))
+        return bad.value, (None if bad.value == 0 else first.value)
 
     def fr_fft(self, data, log2n: int, omega, scale=None) -> np.ndarray:
         a = _np(data, 4).copy()

@@ -1,10 +1,12 @@
 // Flat C front-end of the C++ host mirror (keaki.hpp) so the pytest harness and other FFI users can
 // drive kzg / kem / enc / vec exactly as the reference's tests do. Errors: 0 ok, 1 = KZGError
 // (degree/max written to err_out[2]), negative = HipError status; message via keaki_host_last_error().
+#include <algorithm>
 #include <cstring>
 #include <string>
 
 #include "keaki.hpp"
+#include "ptau.hpp"
 
 using namespace keaki;
 
@@ -90,6 +92,64 @@ int keaki_host_setup_from_powers(int device, const uint64_t* g1_aff, size_t n, c
     std::vector<G1> pts(n);
     for (size_t i = 0; i < n; i++) pts[i] = g1_of(g1_aff + 8 * i);
     *out = new Setup{dev, kzg::KZGSetup::from_powers(dev, std::move(pts), g2_of(tau_g2))};
+    return 0;
+  });
+}
+// ---- .ptau ingest (src/kzg/ptau.rs, src/kzg.rs:33-52). Status 2 = SetupFileError: kind / payload in err_out[3], text via last_error.
+static int file_err(const ptau::SetupFileError& e, uint64_t* err_out) {
+  if (err_out) { err_out[0] = (uint64_t)e.kind; err_out[1] = e.a; err_out[2] = e.b; }
+  g_err = e.to_string();
+  return 2;
+}
+// parse only (no GPU): header (modulus bytes up to mod_cap, power, ceremony power), section table, and the point counts; with
+// g1_out / g2_out non-null the limbs of sections 2 / 3 are copied out (call once with nulls for the counts)
+int keaki_host_ptau_parse(const char* path, uint8_t* modulus_out, size_t mod_cap, uint32_t* mod_len, uint32_t* power, uint32_t* ceremony_power,
+                          uint64_t* sections_out /* 11 x (id, size, position) */, size_t* file_len, size_t* n_g1, size_t* n_g2, uint64_t* g1_out,
+                          uint64_t* g2_out, uint64_t* err_out) {
+  return guard([&] {
+    auto data = ptau::load(path);
+    if (!data.ok) return file_err(data.error, err_out);
+    if (file_len) *file_len = data.value.size();
+    auto md = ptau::verify_metadata(data.value);
+    if (!md.ok) return file_err(md.error, err_out);
+    auto secs = ptau::parse_sections(data.value);
+    if (!secs.ok) return file_err(secs.error, err_out);
+    if (sections_out) for (size_t i = 0; i < ptau::N_SECTIONS; i++) {
+      sections_out[3 * i] = secs.value.sections[i].id; sections_out[3 * i + 1] = secs.value.sections[i].size; sections_out[3 * i + 2] = secs.value.sections[i].position;
+    }
+    auto hdr = ptau::parse_header(data.value, secs.value);
+    if (!hdr.ok) return file_err(hdr.error, err_out);
+    if (mod_len) *mod_len = (uint32_t)hdr.value.field_modulus.size();
+    if (modulus_out) memcpy(modulus_out, hdr.value.field_modulus.data(), std::min(mod_cap, hdr.value.field_modulus.size()));
+    if (power) *power = hdr.value.power;
+    if (ceremony_power) *ceremony_power = hdr.value.ceremony_power;
+    auto g1 = ptau::parse_tau_g1(data.value, secs.value, hdr.value.power);
+    if (!g1.ok) return file_err(g1.error, err_out);
+    auto g2 = ptau::parse_tau_g2(data.value, secs.value, hdr.value.power);
+    if (!g2.ok) return file_err(g2.error, err_out);
+    if (n_g1) *n_g1 = g1.value.size();
+    if (n_g2) *n_g2 = g2.value.size();
+    if (g1_out) for (size_t i = 0; i < g1.value.size(); i++) memcpy(g1_out + 8 * i, g1.value[i].w.data(), 64);
+    if (g2_out) for (size_t i = 0; i < g2.value.size(); i++) memcpy(g2_out + 16 * i, g2.value[i].w.data(), 128);
+    return 0;
+  });
+}
+int keaki_host_ptau_section_info(const uint8_t* header12, size_t offset, uint64_t* out3, uint64_t* err_out) {
+  return guard([&] {
+    auto si = ptau::section_info_from_data(header12, offset);
+    if (!si.ok) return file_err(si.error, err_out);
+    out3[0] = si.value.id; out3[1] = si.value.size; out3[2] = si.value.position;
+    return 0;
+  });
+}
+int keaki_host_ptau_section_index(uint8_t id) { return ptau::section_index(id); }
+// KZGSetup::new_from_file
+int keaki_host_setup_from_file(int device, const char* path, void** out, uint64_t* err_out) {
+  return guard([&] {
+    auto dev = std::make_shared<Device>(device);
+    auto r = kzg::new_from_file(dev, path);
+    if (!r.ok) return file_err(r.error, err_out);
+    *out = new Setup{dev, std::move(*r.setup)};
     return 0;
   });
 }

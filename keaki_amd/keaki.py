@@ -31,6 +31,19 @@ class KeakiHostError(RuntimeError):
     pass
 
 
+class SetupFileError(Exception):
+    """SetupFileError -- src/kzg/ptau.rs:360-376 (+ OffCurve, Truncated: what the reference does not detect / panics on)"""
+    KINDS = ["ElementSizeMismatch", "EmptySection", "FileError", "InvalidFileType", "InvalidNumberOfSections", "ParseError",
+             "UnknownSection", "OffCurve", "Truncated"]
+
+    def __init__(self, kind: int, a: int, b: int, text: str):
+        super().__init__(text)
+        self.kind, self.a, self.b = self.KINDS[kind], a, b
+
+    def __eq__(self, other):
+        return isinstance(other, SetupFileError) and (self.kind, self.a, self.b) == (other.kind, other.a, other.b)
+
+
 def _lib():
     global _LIB
     if _LIB is None:
@@ -66,6 +79,8 @@ def _ck(st, err=None):
         return
     if st == 1 and err is not None:
         raise KZGError(int(err[0]), int(err[1]))
+    if st == 2 and err is not None:
+        raise SetupFileError(int(err[0]), int(err[1]), int(err[2]), _lib().keaki_host_last_error().decode())
     raise KeakiHostError(f"status {st}: {_lib().keaki_host_last_error().decode()}")
 
 
@@ -135,6 +150,33 @@ def fft(coeffs, domain_min) -> np.ndarray:
 
 
 # ---- kzg --------------------------------------------------------------------------------------
+def ptau_parse(path: str) -> dict:
+    """get_powers_from_file (src/kzg/ptau.rs:347-358) without a GPU: header, section table, and the limbs of sections 2 and 3."""
+    lib = _lib()
+    err = np.zeros(3, np.uint64)
+    mod = np.zeros(64, np.uint8); mod_len = C.c_uint32(); power = C.c_uint32(); cer = C.c_uint32()
+    secs = np.zeros((11, 3), np.uint64); flen = C.c_size_t(); n1 = C.c_size_t(); n2 = C.c_size_t()
+    args = [os.fsencode(path), _p(mod), C.c_size_t(64), C.byref(mod_len), C.byref(power), C.byref(cer), _p(secs), C.byref(flen), C.byref(n1), C.byref(n2)]
+    _ck(lib.keaki_host_ptau_parse(*args, None, None, _p(err)), err)
+    g1 = np.zeros((n1.value, 8), np.uint64); g2 = np.zeros((n2.value, 16), np.uint64)
+    _ck(lib.keaki_host_ptau_parse(*args, _p(g1), _p(g2), _p(err)), err)
+    return {"file_len": flen.value, "field_modulus": bytes(mod[:mod_len.value]), "power": power.value, "ceremony_power": cer.value,
+            "sections": [tuple(int(v) for v in r) for r in secs], "tau_g1": g1, "tau_g2": g2}
+
+
+def ptau_section_info(header12: bytes, offset: int):
+    """SectionInfo::new_from_data (src/kzg/ptau.rs:169-182) -> (id, size, position)"""
+    out = np.zeros(3, np.uint64); err = np.zeros(3, np.uint64)
+    buf = np.frombuffer(bytes(header12), np.uint8).copy()
+    _ck(_lib().keaki_host_ptau_section_info(_p(buf), C.c_size_t(offset), _p(out), _p(err)), err)
+    return tuple(int(v) for v in out)
+
+
+def ptau_section_index(section_id: int) -> int:
+    """SectionId::try_from + section_index (src/kzg/ptau.rs:54-90); -1 = UnknownSection"""
+    return _lib().keaki_host_ptau_section_index(C.c_uint8(section_id))
+
+
 class KZGSetup:
     def __init__(self, handle):
         self.h = handle
@@ -149,6 +191,13 @@ class KZGSetup:
     def from_powers(g1_aff, tau_g2, device: int = 0) -> "KZGSetup":
         pts = _u64(g1_aff, 8); h = C.c_void_p()
         _ck(_lib().keaki_host_setup_from_powers(device, _p(pts), C.c_size_t(pts.shape[0]), _p(_u64(tau_g2)), C.byref(h)))
+        return KZGSetup(h)
+
+    @staticmethod
+    def new_from_file(path: str, device: int = 0) -> "KZGSetup":
+        """KZGSetup::new_from_file (src/kzg.rs:33-52): sections 2 / 3 of a snarkjs .ptau uploaded verbatim, curve-checked on the GPU"""
+        h = C.c_void_p(); err = np.zeros(3, np.uint64)
+        _ck(_lib().keaki_host_setup_from_file(device, os.fsencode(path), C.byref(h), _p(err)), err)
         return KZGSetup(h)
 
     def g1_pow(self) -> np.ndarray:

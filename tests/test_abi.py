@@ -104,7 +104,7 @@ def test_host_mirror_library_loads():
     lib = ctypes.CDLL(os.path.join(ROOT, "keaki_amd", "libkeaki_host.so"))
     for s in ["keaki_host_setup", "keaki_host_commit", "keaki_host_open", "keaki_host_verify", "keaki_host_open_fk", "keaki_host_encapsulate",
               "keaki_host_decapsulate", "keaki_host_encrypt", "keaki_host_decrypt", "keaki_host_vec_commit", "keaki_host_vec_encrypt",
-              "keaki_host_vec_decrypt"]:
+              "keaki_host_vec_decrypt", "keaki_host_setup_from_file", "keaki_host_ptau_parse", "keaki_host_ptau_section_info"]:
         assert hasattr(lib, s), s
 
 

@@ -255,3 +255,42 @@ def test_vec_commit_device_fft_branch(K, oc, py):
     for i in (0, 1, 2, 2047, 2048, 4094):
         assert K.verify(s, commitment, el[i], K.fr(bits[i]), proofs[i])
         assert not K.verify(s, commitment, el[i], K.fr(1 - bits[i]), proofs[i])
+
+
+def test_new_from_file_ptau_fixture(K, oc, py, tmp_path):
+    """KZGSetup::new_from_file (src/kzg.rs:33-52) on the reference's own fixture: sections 2 / 3 are uploaded verbatim (the bytes are
+    Montgomery limbs), both are curve-checked on the GPU, tau_g2 = second point of section 3. Then commit / open / verify with that
+    SRS (3 powers) against the oracle, and the pairing relation of a real ceremony: e(tau G1, g2) == e(g1, tau G2)."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ppot_0080_01.ptau.test")
+    s = K.KZGSetup.new_from_file(path)
+    pts = py.ptau_points(open(path, "rb").read())
+    assert oc.g1_to_ints(s.g1_pow()) == pts["tau_g1"] and len(pts["tau_g1"]) == 3
+    assert oc.g2_to_ints(s.tau_g2())[0] == pts["tau_g2"][1]
+    coeffs = [5, -7, 11]
+    p = np.stack([K.fr(c) for c in coeffs])
+    com = K.commit(s, p)
+    assert oc.g1_to_ints(com)[0] == py.kzg_commit(pts["tau_g1"], [c % py.R for c in coeffs])
+    z = K.fr(3)
+    proof = K.open(s, p, z)
+    assert K.verify(s, com, z, K.poly_evaluate(p, z), proof)          # holds only if tau_g2 really is [tau]_2 of the same tau
+    assert not K.verify(s, com, z, K.fr(1), proof)
+    with pytest.raises(K.KZGError):                                       # 4 coefficients > 3 powers
+        K.commit(s, np.stack([K.fr(1)] * 4))
+    # a flipped coordinate byte: the reference would accept the file; here the device check names the section and the index
+    blob = bytearray(open(path, "rb").read())
+    d = K.ptau_parse(path)
+    g1_pos, g2_pos = d["sections"][1][2], d["sections"][2][2]
+    bad = bytearray(blob); bad[g1_pos + 64 * 2 + 5] ^= 0x40             # x of tau^2 G1
+    f1 = tmp_path / "bad_g1.ptau"; f1.write_bytes(bytes(bad))
+    with pytest.raises(K.SetupFileError) as e:
+        K.KZGSetup.new_from_file(str(f1))
+    assert e.value.kind == "OffCurve" and (e.value.a, e.value.b) == (1, 2) and "tauG1" in str(e.value)
+    bad = bytearray(blob); bad[g2_pos + 128 + 70] ^= 0x01               # y.c0 of tau G2
+    f2 = tmp_path / "bad_g2.ptau"; f2.write_bytes(bytes(bad))
+    with pytest.raises(K.SetupFileError) as e:
+        K.KZGSetup.new_from_file(str(f2))
+    assert e.value.kind == "OffCurve" and (e.value.a, e.value.b) == (1, 1) and "tauG2" in str(e.value)
+    with pytest.raises(K.SetupFileError) as e:
+        K.KZGSetup.new_from_file(str(tmp_path / "nope.ptau"))
+    assert e.value.kind == "FileError"

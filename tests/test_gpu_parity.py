@@ -438,3 +438,29 @@ def test_open_fk_poly_matches_explicit_twiddle_entry(oc, py, hip, rand_fr, log2d
         assert np.array_equal(hip.open_fk_poly(srs_b, log2d, mont(oc, p), mont(oc, [w2])[0], mont(oc, [w2i])[0], mont(oc, [inv])[0]), poly)
     finally:
         srs_a.free(); srs_b.free()
+
+
+def test_curve_checks(oc, py, hip, rand_fr):
+    """keaki_hip_srs_g1_check / keaki_hip_g2_check (SRS ingest, row f-3): valid multiples of the generators and the identity pass;
+    every corrupted point is counted and the first index is reported."""
+    g1, g2 = oc.generators()
+    n = 3000
+    pts = hip.g1_mul_batch(g1, mont(oc, rand_fr(n, 901)))
+    pts[17] = 0                                     # identity
+    srs = hip.srs_g1_upload(pts)
+    try:
+        assert hip.srs_g1_check(srs) == (0, None)
+    finally:
+        srs.free()
+    bad = pts.copy()
+    bad[5, 0] ^= np.uint64(2); bad[2999, 7] ^= np.uint64(1 << 40); bad[100, 4:8] = bad[101, 4:8]     # x, y limb, y of another point
+    srs = hip.srs_g1_upload(bad)
+    try:
+        assert hip.srs_g1_check(srs) == (3, 5)
+    finally:
+        srs.free()
+    q = hip.g2_mul_batch(g2, mont(oc, rand_fr(500, 902)))
+    assert hip.g2_check(q) == (0, None)
+    qb = q.copy(); qb[499, 3] ^= np.uint64(8); qb[250, 12] ^= np.uint64(1)
+    assert hip.g2_check(qb) == (2, 250)
+    assert hip.g2_check(np.zeros((0, 16), np.uint64)) == (0, None)
