@@ -110,6 +110,15 @@ keaki_status keaki_hip_open_fk_poly(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, u
  * (pass omega^-1 and n^-1 for the inverse transform). */
 keaki_status keaki_hip_fr_fft(keaki_hip_ctx* ctx, uint64_t* data, uint32_t log2n, const uint64_t* omega, const uint64_t* scale_or_null);
 
+/* ---- KZG `open` in one call (scope row f-4) -------------------------------------------------------------------------
+ * Replaces the body of `open` (reference src/kzg.rs:104-124): value = p(point) and proof = commit(q), q = (p - p(point)) / (x - point),
+ * with the synthetic division done on the device (blockwise Horner recurrence) right in front of the MSM, so the n - 1 quotient
+ * coefficients never exist on the host. coeffs: n Fr, low degree first, trailing zeros already trimmed as ark-poly's
+ * DensePolynomial does. n - 1 must not exceed the SRS length (KEAKI_ERR_TOO_LARGE; the caller raises PolynomialTooLarge first,
+ * src/kzg.rs:113-118). proof_out_jac: u64[12] normalised Jacobian; value_out: u64[4] or NULL. */
+keaki_status keaki_hip_kzg_open(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, const uint64_t* coeffs, size_t n, const uint64_t* point,
+                                uint64_t* proof_out_jac, uint64_t* value_out);
+
 /* ---- SRS ingest (scope row f-3) -----------------------------------------------------------------------------------------
  * The reference reads .ptau points with `deserialize_uncompressed_unchecked` (src/kzg/ptau.rs:266,314): no curve check at all.
  * A snarkjs .ptau stores coordinates as Montgomery limbs, which is this ABI's point layout, so sections 2 and 3 are uploaded

@@ -565,6 +565,27 @@ keaki_status keaki_hip_final_exp_batch(keaki_hip_ctx* ctx, const uint64_t* f_mon
   return download(ctx, gt_out, ctx->io_b.p, n * 384);
 }
 
+// ---- KZG open on the device (row f-4): value = p(z), proof = commit((p - p(z)) / (x - z)) ------------------------------------------
+keaki_status keaki_hip_kzg_open(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, const uint64_t* coeffs, size_t n, const uint64_t* point,
+                                uint64_t* proof_out_jac, uint64_t* value_out) {
+  CTX_GUARD(ctx);
+  if (!srs || !point || !proof_out_jac || (n && !coeffs)) return fail(ctx, KEAKI_ERR_BAD_ARG, "kzg_open: null pointer");
+  if (n && n - 1 > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", n - 1, srs->n);
+  const size_t nq = n ? n - 1 : 0;
+  const size_t o_q = 0, o_v = o_q + (nq + 1) * 32, o_w = o_v + 32, total = o_w + (2 * (n / 255 + 8) + 8) * 32;
+  ST_TRY(upload(ctx, ctx->io_a, coeffs, n * 32));
+  ST_TRY(reserve(ctx, ctx->io_c, total));
+  ST_TRY(reserve(ctx, ctx->io_b, 96));
+  char* b = (char*)ctx->io_c.p;
+  HIP_TRY(ctx, hipMemsetAsync(b + o_v, 0, 32, ctx->stream));                     // the zero polynomial evaluates to 0
+  if (n) ST_TRY(open_quotient_run(ctx, ctx->io_a.p, n, point, b + o_q, b + o_v, b + o_w));
+  ST_TRY(msm_g1_run(ctx, srs->d, srs->n, b + o_q, nq, ctx->io_b.p, srs->table, srs->c_table));
+  ST_TRY(download(ctx, proof_out_jac, ctx->io_b.p, 96));
+  if (value_out) ST_TRY(download(ctx, value_out, b + o_v, 32));
+  resolve_timing(ctx);
+  return KEAKI_OK;
+}
+
 // ---- SRS ingest: on-curve check (row f-3) ------------------------------------------------------------------------
 static keaki_status curve_check_common(keaki_hip_ctx* ctx, bool g2, const void* d_pts, size_t n, uint64_t* n_off_curve, uint64_t* first_off_curve) {
   ST_TRY(reserve(ctx, ctx->io_e, 16));

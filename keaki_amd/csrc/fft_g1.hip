@@ -124,6 +124,48 @@ static __global__ void __launch_bounds__(256) k_fr_stride2(const Fr* __restrict_
   if (i < n_out) out[i] = in[2 * (size_t)i];
 }
 
+// ---- synthetic division by (x - z) on the device: the quotient of `open` (src/kzg.rs:109-120), row f-4 ------------------------
+// Q_i = sum_{j >= i} c_j z^(j-i)  (Q_0 = p(z), quotient coefficient q_i = Q_(i+1)) obeys Q_i = c_i + z Q_(i+1): a linear recurrence,
+// evaluated blockwise. Level k works on a^k (a^0 = c, a^(k+1) = the block values of level k) with multiplier w_k = z^(L^k):
+//   up:   H_b = sum_{t < L} a[bL + t] w^t                       (one lane per block, Horner from the top of the block)
+//   top:  all suffix values of the last level by one lane
+//   down: a lane re-runs its block from the carry Q_((b+1)L) supplied by the level above and writes every Q of the block
+constexpr u32 HORNER_L = 256;
+static __global__ void k_fr_pow_chain(Fr z, u32 levels, Fr* __restrict__ w) {      // w[k] = z^(256^k)
+  if (threadIdx.x || blockIdx.x) return;
+  Fr x = z;
+  for (u32 k = 0; k < levels; k++) {
+    w[k] = x;
+    for (int s = 0; s < 8; s++) x = fr_mul(x, x);
+  }
+}
+static __global__ void __launch_bounds__(64) k_fr_horner_up(const Fr* __restrict__ a, u32 m, const Fr* __restrict__ wp, Fr* __restrict__ H) {
+  u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 lo = b * HORNER_L;
+  if (lo >= m) return;
+  u32 hi = min(m, lo + HORNER_L);
+  const Fr w = *wp;
+  Fr h = a[hi - 1];
+  for (u32 k = hi - 1; k-- > lo;) h = fp_add<FrParams>(fr_mul(h, w), a[k]);
+  H[b] = h;
+}
+// q_up[b] = suffix value at the start of block b of this level (nullptr at the top level: nothing above). out[k - shift] = Q_k;
+// with shift = 1 (level 0) Q_0 goes to *value_out instead.
+static __global__ void __launch_bounds__(64) k_fr_horner_down(const Fr* __restrict__ a, u32 m, const Fr* __restrict__ wp, const Fr* __restrict__ q_up,
+                                                              u32 nblocks, Fr* __restrict__ out, u32 shift, Fr* __restrict__ value_out) {
+  u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 lo = b * HORNER_L;
+  if (lo >= m) return;
+  u32 hi = min(m, lo + HORNER_L);
+  const Fr w = *wp;
+  Fr carry = (q_up && b + 1 < nblocks) ? q_up[b + 1] : fp_zero<FrParams>();
+  for (u32 k = hi; k-- > lo;) {
+    carry = fp_add<FrParams>(fr_mul(carry, w), a[k]);
+    if (k >= shift) out[k - shift] = carry;
+    else if (value_out) *value_out = carry;
+  }
+}
+
 }  // namespace bn254
 
 namespace keaki_internal {
@@ -214,6 +256,39 @@ keaki_status open_fk_poly_run(keaki_hip_ctx* ctx, const void* d_srs, void** hat_
     *hat_s_log2d = (int)log2d;
   }
   return open_fk_run(ctx, *hat_s_cache, log2d, hat_a, twi, twd, d_g_work, d_proofs_aff);
+}
+
+
+// d_c: n coefficients (Fr). d_q: n - 1 quotient coefficients out (n >= 1; n == 1: nothing written). d_value: p(z) out (1 Fr).
+// d_work: room for 2 * (n / 255 + 8) + 8 Fr.
+keaki_status open_quotient_run(keaki_hip_ctx* ctx, const void* d_c, size_t n, const uint64_t* z, void* d_q, void* d_value, void* d_work) {
+  hipStream_t st = ctx->stream;
+  Fr zz;
+  memcpy(&zz, z, 32);
+  // level sizes
+  u32 m[8];
+  u32 levels = 0;
+  for (size_t cur = n;; cur = (cur + HORNER_L - 1) / HORNER_L) { m[levels++] = (u32)cur; if (cur <= HORNER_L || levels == 8) break; }
+  Fr* w = (Fr*)d_work;                       // w[k], k < levels
+  Fr* base = w + 8;
+  // a[k]: level arrays (a[0] = coefficients), Q[k]: suffix values of level k >= 1
+  const Fr* a[8]; Fr* Q[8];
+  a[0] = (const Fr*)d_c; Q[0] = nullptr;
+  Fr* p = base;
+  for (u32 k = 1; k < levels; k++) { a[k] = p; p += m[k]; }
+  for (u32 k = 1; k < levels; k++) { Q[k] = p; p += m[k]; }
+  hipLaunchKernelGGL(k_fr_pow_chain, dim3(1), dim3(1), 0, st, zz, levels, w);
+  for (u32 k = 0; k + 1 < levels; k++)
+    hipLaunchKernelGGL(k_fr_horner_up, dim3(cdiv(m[k + 1], 64)), dim3(64), 0, st, a[k], m[k], (const Fr*)(w + k), (Fr*)a[k + 1]);
+  for (u32 k = levels; k-- > 0;) {
+    const Fr* q_up = (k + 1 < levels) ? Q[k + 1] : nullptr;
+    const u32 nblocks = cdiv(m[k], HORNER_L);
+    if (k == 0)
+      hipLaunchKernelGGL(k_fr_horner_down, dim3(cdiv(nblocks, 64)), dim3(64), 0, st, a[0], m[0], (const Fr*)w, q_up, nblocks, (Fr*)d_q, 1u, (Fr*)d_value);
+    else
+      hipLaunchKernelGGL(k_fr_horner_down, dim3(cdiv(nblocks, 64)), dim3(64), 0, st, a[k], m[k], (const Fr*)(w + k), q_up, nblocks, Q[k], 0u, (Fr*)nullptr);
+  }
+  return launch_check(ctx, "open_quotient");
 }
 
 }  // namespace keaki_internal

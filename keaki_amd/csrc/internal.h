@@ -92,6 +92,7 @@ keaki_status encap_g1_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, const v
 keaki_status encap_g2_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, const void* d_tab_b, const void* d_xs, const void* d_rs, size_t n, void* d_out);
 keaki_status g1_curve_check_run(keaki_hip_ctx* ctx, const void* d_pts, size_t n, void* d_bad2);   // d_bad2: u64 count, u64 first index
 keaki_status g2_curve_check_run(keaki_hip_ctx* ctx, const void* d_pts, size_t n, void* d_bad2);
+keaki_status open_quotient_run(keaki_hip_ctx* ctx, const void* d_c, size_t n, const uint64_t* z, void* d_q, void* d_value, void* d_work);
 keaki_status fr_fft_run(keaki_hip_ctx* ctx, void* d_data, uint32_t log2n, const uint64_t* omega, const uint64_t* scale_or_null, void* d_tw);
 keaki_status open_fk_poly_run(keaki_hip_ctx* ctx, const void* d_srs, void** hat_s_cache, int* hat_s_log2d, uint32_t log2d, const void* d_p,
                               const uint64_t* omega_2d, const uint64_t* omega_2d_inv, const uint64_t* inv_2d, void* d_fr_work, void* d_g_work,

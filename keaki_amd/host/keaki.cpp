@@ -165,17 +165,16 @@ Result<G1> commit(const KZGSetup& setup, const DensePolynomial& p) {
 static void trim(DensePolynomial& p) { while (!p.empty() && p.back().is_zero()) p.pop_back(); }
 
 Result<G1> open(const KZGSetup& setup, const DensePolynomial& p_in, const Fr& point) {
-  // quotient (p(x) - p(point)) / (x - point): the Horner intermediates are its coefficients
+  // quotient (p(x) - p(point)) / (x - point) and its commitment in one device call (keaki_hip_kzg_open: blockwise Horner recurrence
+  // in front of the MSM). The quotient has p.len() - 1 coefficients and its leading one is p's, so it needs no trimming.
   DensePolynomial p = p_in;
   trim(p);
-  DensePolynomial q;
-  if (p.size() > 1) {
-    q.resize(p.size() - 1);
-    Fr acc = Fr::zero();
-    for (size_t i = p.size() - 1; i >= 1; i--) { acc = acc * point + p[i]; q[i - 1] = acc; }
-  }
-  trim(q);
-  return commit(setup, q);
+  const size_t qlen = p.size() > 1 ? p.size() - 1 : 0;
+  if (qlen > setup.g1_pow().size())                       // the commit inside open fails with the QUOTIENT's length (src/kzg.rs:123,91-96)
+    return Result<G1>::Err(KZGError{KZGError::PolynomialTooLarge, qlen, setup.g1_pow().size()});
+  uint64_t jac[12];
+  setup.device()->check(keaki_hip_kzg_open(setup.device()->ctx(), setup.srs(), p.empty() ? nullptr : p[0].l, p.size(), point.l, jac, nullptr));
+  return Result<G1>::Ok(jac_to_g1(jac));
 }
 
 Result<bool> verify(const KZGSetup& setup, const G1& commitment, const Fr& point, const Fr& value, const G1& proof) {

@@ -464,3 +464,34 @@ def test_curve_checks(oc, py, hip, rand_fr):
     qb = q.copy(); qb[499, 3] ^= np.uint64(8); qb[250, 12] ^= np.uint64(1)
     assert hip.g2_check(qb) == (2, 250)
     assert hip.g2_check(np.zeros((0, 16), np.uint64)) == (0, None)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 255, 256, 257, 5000, 70000])
+def test_kzg_open_quotient_on_device(oc, py, hip, rand_fr, n):
+    """keaki_hip_kzg_open (row f-4): p(z) and the commitment of (p - p(z)) / (x - z), the quotient made on the device by the blockwise
+    Horner recurrence (block 256: sizes around one, two and three levels). Against the oracle's Horner quotient + MSM."""
+    N = max(n, 2)
+    ks, pts = make_points_g1(oc, hip, N, 950)
+    c = rand_fr(n, 951 + n)
+    if n > 4:
+        c[1] = 0; c[n // 2] = 0
+    z = rand_fr(1, 960 + n)[0]
+    srs = hip.srs_g1_upload(pts)
+    try:
+        proof, val = hip.kzg_open(srs, mont(oc, c), mont(oc, [z])[0])
+        assert _fr_ints(oc, val)[0] == (py.poly_eval(c, z) if n else 0)
+        q = py.poly_quotient(c, z) if n > 1 else []
+        assert len(q) == max(n - 1, 0)
+        exp = oc.msm_g1(pts[:len(q)], mont(oc, q)) if q else None
+        got = jac_to_aff(proof)
+        if q:
+            assert np.array_equal(got, exp)
+        else:
+            assert not np.any(got)
+        # z = 0: the quotient is a shift
+        proof0, val0 = hip.kzg_open(srs, mont(oc, c), mont(oc, [0])[0])
+        assert _fr_ints(oc, val0)[0] == (c[0] if n else 0)
+        if n > 1:
+            assert np.array_equal(jac_to_aff(proof0), oc.msm_g1(pts[:n - 1], mont(oc, c[1:])))
+    finally:
+        srs.free()
