@@ -370,7 +370,15 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
   }
   // ciphertexts ct_i = r_i [tau]_2 - (r_i alpha_i) g2
   if (use_tables) {
-    ST_TRY(g2_fb_table_run(ctx, d_tau_g2_aff, ctx->fb_scalars.p, ctx->fb_tau.p));
+    // [tau]_2 belongs to the setup, not to the batch: rebuild its window table (8192 G2 scalar-mults, ~4 ms) only when it changes
+    uint64_t tau_host[16];
+    HIP_TRY(ctx, hipMemcpyAsync(tau_host, d_tau_g2_aff, 128, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->fb_tau_valid || memcmp(tau_host, ctx->fb_tau_pt, 128) != 0) {
+      ST_TRY(g2_fb_table_run(ctx, d_tau_g2_aff, ctx->fb_scalars.p, ctx->fb_tau.p));
+      memcpy(ctx->fb_tau_pt, tau_host, 128);
+      ctx->fb_tau_valid = true;
+    }
     ST_TRY(encap_g2_fixed_run(ctx, ctx->fb_tau.p, ctx->fb_g2_gen.p, d_points, d_r, n, d_ct_out_aff));
   } else {
     ST_TRY(encap_g2_run(ctx, d_tau_g2_aff, d_points, d_r, n, d_ct_out_aff));

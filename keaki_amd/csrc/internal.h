@@ -32,6 +32,8 @@ struct keaki_hip_ctx {
   keaki_internal::DevBuf fb_scalars, fb_g1_gen, fb_g2_gen, fb_com, fb_tau, perm, g2gen_lines, gt_tab_a, gt_tab_b, gt_base, heavy;
   bool gt_b_ready = false;
   bool gt_a_valid = false;
+  bool fb_tau_valid = false;          // window table of [tau]_2 (encap ciphertext side) is for this point
+  uint64_t fb_tau_pt[16] = {};
   uint64_t gt_a_com[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // commitment the cached A-table belongs to
   bool g2gen_lines_ready = false;
   bool fb_ready = false;

@@ -243,6 +243,13 @@ def test_encap_fixed_base_tables_vs_oracle(oc, py, hip, rand_fr):
     ct3, gt3, _ = hip.encap_batch(np.zeros(8, np.uint64), tau_g2, A[:256], V[:256], Rr[:256], 32)
     ect3, egt3, _ = oc.encap_batch(np.zeros(8, np.uint64), tau_g2, A[:256], V[:256], Rr[:256], 32, threads=8)
     assert np.array_equal(ct3, ect3) and np.array_equal(gt3, egt3)
+    # the [tau]_2 window table is cached per context: another setup's tau must rebuild it, and coming back must rebuild it again
+    tau_b = hip.g2_mul_batch(g2, mont(oc, [rand_fr(1, 65)[0]]))[0]
+    ct4, gt4, _ = hip.encap_batch(com, tau_b, A[:256], V[:256], Rr[:256], 32)
+    ect4, egt4, _ = oc.encap_batch(com, tau_b, A[:256], V[:256], Rr[:256], 32, threads=8)
+    assert np.array_equal(ct4, ect4) and np.array_equal(gt4, egt4) and not np.array_equal(ct4, ct[:256])
+    ct5, _, _ = hip.encap_batch(com, tau_g2, A[:256], V[:256], Rr[:256], 32)
+    assert np.array_equal(ct5, ct[:256])
 
 
 @pytest.mark.parametrize("N", [300, 5000, 1 << 15])
