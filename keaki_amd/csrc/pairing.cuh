@@ -383,13 +383,14 @@ static __global__ void __launch_bounds__(64) k_g2_prepare(const G2Aff* __restric
 // Encapsulation at scale: no pairing per item. In the loop of src/vec.rs:63-66 the commitment C is the same for every
 // item, so by bilinearity
 //     e(r (C - beta g1), g2) = A^r * B^(-beta r),      A = e(C, g2),  B = e(g1, g2)
-// with A, B FIXED for the batch: two fixed-base exponentiations in GT with 8-bit window tables T[j][d] = base^(d 2^(8j))
-// (32 x 256 Fq12 entries per base) = at most 64 Fq12 products per item instead of a Miller loop + final exponentiation
-// (~5x fewer Fq products). The value -- hence the serialised bytes and the key -- is identical.
+// with A, B FIXED for the batch: two fixed-base exponentiations in GT with SIGNED 13-bit window tables T[j][d] = base^(d 2^(13j)),
+// d = 1..4096 (20 x 4096 Fq12 entries = 31.5 MB per base). A and B are outputs of the final exponentiation, i.e. unitary, so
+// base^(-d) is the conjugate of T[j][d]: at most 40 Fq12 products per item instead of a Miller loop + final exponentiation
+// (~8x fewer Fq products; 8-bit unsigned windows needed 64). The value -- hence the serialised bytes and the key -- is identical.
 // GT elements are stored in the lane-pair order: 12 Fq per element, slot 2k + parity = Fq2 coefficient k, component parity
 // (which is also ark-serialize's coefficient order).
 // ---------------------------------------------------------------------------------------------
-constexpr u32 GT_WINDOWS = 32, GT_ENTRIES = 256;
+constexpr u32 GT_WB = 13, GT_WINDOWS = 20, GT_HALF = 1u << (GT_WB - 1), GT_ENTRIES = GT_HALF + 1;   // entry d in [1, 4096]; slot 0 unused
 
 KDEV void gt_load(Fq12* f, const Fq* __restrict__ src) {
   Fq2d* c = reinterpret_cast<Fq2d*>(f);
@@ -418,31 +419,31 @@ static __global__ void __launch_bounds__(64, 2) k_pairing_raw_fixed(const G1Aff*
   if (aff_is_inf(p)) fq12_set_one(&e);
   if (live) gt_store(out + (size_t)12 * i, &e);
 }
-// table[(j * 256 + d)] = base^(d * 2^(8 j)).  Step 1: one wave, lane pair j holds base^(2^(8j)) (8 j cyclotomic squarings).
+// table[j * GT_ENTRIES + d] = base^(d 2^(13 j)).  Step 1: one lane pair walks the chain base^(2^s), s < 13 * 20, and drops
+// base^(2^s) into slot 2^(s mod 13) of window s / 13 (the powers of two of every window).
 static __global__ void __launch_bounds__(64, 2) k_gt_table_bases(const Fq* __restrict__ base, Fq* __restrict__ table) {
-  const u32 j = threadIdx.x >> 1;   // 32 pairs
+  if (threadIdx.x >= 2) return;
   Fq12 x;
   gt_load(&x, base);
 #pragma unroll 1
-  for (u32 s = 0; s < 8 * (GT_WINDOWS - 1); s++) {
-    if (s < 8 * j) fq12_cyc_sqr(&x, &x);       // pair-uniform predicate: both lanes of a pair take the same side
+  for (u32 s = 0; s < GT_WB * GT_WINDOWS; s++) {
+    gt_store(table + ((size_t)(s / GT_WB) * GT_ENTRIES + (1u << (s % GT_WB))) * 12, &x);
+    fq12_cyc_sqr(&x, &x);
   }
-  gt_store(table + (size_t)(j * GT_ENTRIES + 1) * 12, &x);
 }
-// Step 2: pair (j, d), d >= 2: table[j][d] = table[j][1]^d by square-and-multiply; d = 0 -> one (never multiplied in, kept for clarity)
-static __global__ void __launch_bounds__(64, 2) k_gt_table_fill(Fq* __restrict__ table) {
+// Step 2, level L = 1 .. GT_WB - 2: table[j][2^L + x] = table[j][2^L] * table[j][x], 1 <= x < 2^L (all known from the levels below)
+static __global__ void __launch_bounds__(64, 2) k_gt_table_fill(Fq* __restrict__ table, u32 L) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  const u32 pairi = t >> 1;                   // 0 .. 32*256-1
-  const u32 j = pairi >> 8, d = pairi & 255u;
-  Fq12 b, acc;
-  gt_load(&b, table + (size_t)(j * GT_ENTRIES + 1) * 12);
-  fq12_set_one(&acc);
-#pragma unroll 1
-  for (int bit = 7; bit >= 0; bit--) {
-    fq12_cyc_sqr(&acc, &acc);                 // squaring one is one: harmless before the first set bit
-    if ((d >> bit) & 1u) fq12_mul(&acc, &acc, &b);
-  }
-  if (d != 1) gt_store(table + (size_t)(j * GT_ENTRIES + d) * 12, &acc);
+  const u32 pairi = t >> 1;
+  const u32 per = (1u << L) - 1u;                    // entries of this level per window
+  const bool live = pairi < GT_WINDOWS * per;
+  const u32 pi = live ? pairi : 0u;
+  const u32 j = pi / per, x = 1u + pi % per;
+  Fq12 a, b;
+  gt_load(&a, table + ((size_t)j * GT_ENTRIES + (1u << L)) * 12);
+  gt_load(&b, table + ((size_t)j * GT_ENTRIES + x) * 12);
+  fq12_mul(&a, &a, &b);
+  if (live) gt_store(table + ((size_t)j * GT_ENTRIES + (1u << L) + x) * 12, &a);
 }
 // gt_out[i] = serialize(A^(r_i) * B^(-(r_i * beta_i)))   (tables of A and B). Two lanes per item.
 static __global__ void __launch_bounds__(64, 2) k_gt_encap_exp(const Fq* __restrict__ tab_a, const Fq* __restrict__ tab_b, const Fr* __restrict__ betas,
@@ -458,14 +459,28 @@ static __global__ void __launch_bounds__(64, 2) k_gt_encap_exp(const Fq* __restr
   fp_from_mont<FrParams>(v, m);
   Fq12 acc, e;
   fq12_set_one(&acc);
+  u32 ca = 0, cb = 0;                                // signed-digit carries
 #pragma unroll 1
   for (u32 j = 0; j < GT_WINDOWS; j++) {
-    u32 da = u[0] & 255u, db = v[0] & 255u;
+    u32 da = (u[0] & (2u * GT_HALF - 1u)) + ca, db = (v[0] & (2u * GT_HALF - 1u)) + cb;
 #pragma unroll
-    for (int w = 0; w < 7; w++) { u[w] = (u[w] >> 8) | (u[w + 1] << 24); v[w] = (v[w] >> 8) | (v[w + 1] << 24); }
-    u[7] >>= 8; v[7] >>= 8;
-    if (da) { gt_load(&e, tab_a + (size_t)(j * GT_ENTRIES + da) * 12); fq12_mul(&acc, &acc, &e); }
-    if (db) { gt_load(&e, tab_b + (size_t)(j * GT_ENTRIES + db) * 12); fq12_mul(&acc, &acc, &e); }
+    for (int w = 0; w < 7; w++) { u[w] = (u[w] >> GT_WB) | (u[w + 1] << (32 - GT_WB)); v[w] = (v[w] >> GT_WB) | (v[w + 1] << (32 - GT_WB)); }
+    u[7] >>= GT_WB; v[7] >>= GT_WB;
+    // digit in (-2^12, 2^12]: above the half, take d - 2^13 and carry (2^13 itself becomes digit 0 with a carry)
+    const bool na = da > GT_HALF, nb = db > GT_HALF;
+    ca = na ? 1u : 0u; cb = nb ? 1u : 0u;
+    if (na) da = 2u * GT_HALF - da;
+    if (nb) db = 2u * GT_HALF - db;
+    if (da) {
+      gt_load(&e, tab_a + ((size_t)j * GT_ENTRIES + da) * 12);
+      if (na) fq12_conj(&e, &e);                      // unitary: inverse = conjugate
+      fq12_mul(&acc, &acc, &e);
+    }
+    if (db) {
+      gt_load(&e, tab_b + ((size_t)j * GT_ENTRIES + db) * 12);
+      if (nb) fq12_conj(&e, &e);
+      fq12_mul(&acc, &acc, &e);
+    }
   }
   if (live) gt_serialize(gt_out + (size_t)96 * i, &acc);
 }

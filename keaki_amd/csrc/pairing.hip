@@ -20,10 +20,11 @@ keaki_status pairing_raw_fixed_run(keaki_hip_ctx* ctx, const void* d_g1, size_t 
   return launch_check(ctx, "pairing_raw_fixed");
 }
 size_t gt_table_bytes() { return (size_t)GT_WINDOWS * GT_ENTRIES * 12 * sizeof(Fq); }
-// d_table[j][d] = base^(d 2^(8j)); d_base: 12 Fq
+// d_table[j][d] = base^(d 2^(13j)), d = 1..4096; d_base: 12 Fq
 keaki_status gt_table_run(keaki_hip_ctx* ctx, const void* d_base, void* d_table) {
   hipLaunchKernelGGL(k_gt_table_bases, dim3(1), dim3(64), 0, ctx->stream, (const Fq*)d_base, (Fq*)d_table);
-  hipLaunchKernelGGL(k_gt_table_fill, dim3(cdiv(2 * GT_WINDOWS * GT_ENTRIES, 64)), dim3(64), 0, ctx->stream, (Fq*)d_table);
+  for (u32 L = 1; L + 2 <= GT_WB; L++)
+    hipLaunchKernelGGL(k_gt_table_fill, dim3(cdiv(2 * GT_WINDOWS * ((1u << L) - 1u), 64)), dim3(64), 0, ctx->stream, (Fq*)d_table, L);
   return launch_check(ctx, "gt_table");
 }
 keaki_status gt_encap_exp_run(keaki_hip_ctx* ctx, const void* d_tab_a, const void* d_tab_b, const void* d_betas, const void* d_rs, size_t n, void* d_gt) {

@@ -330,6 +330,10 @@ def test_encap_gt_fixed_base_path_vs_oracle(oc, py, hip, rand_fr, monkeypatch):
     tau_g2 = hip.g2_mul_batch(g2, mont(oc, [tau]))[0]
     a, v, r = rand_fr(n, 82), rand_fr(n, 83), rand_fr(n, 84)
     v[0] = 0; r[1] = 1; r[2] = py.R - 1; v[3] = py.R - 1; r[4] = 0; v[5] = 1; r[5] = 255; r[6] = 256; r[7] = (1 << 248) + 5
+    # signed 13-bit window corners: digit exactly 2^12 (kept), 2^12 + 1 (negative, carry), all-ones windows (2^13 after the carry -> 0),
+    # a run of carries through every window, the largest exponent below 2^253
+    r[8] = 1 << 12; r[9] = (1 << 12) + 1; r[10] = (1 << 13) - 1; r[11] = (1 << 26) - 1; r[12] = (1 << 253) - 1; v[12] = 1
+    r[13] = sum(((1 << 12) + 1) << (13 * j) for j in range(19)); r[14] = (1 << 13); r[15] = (1 << 13) + (1 << 12)
     A, V, Rr = mont(oc, a), mont(oc, v), mont(oc, r)
     for c in (c0, c1):     # two commitments: exercises the per-commitment table cache
         com = hip.g1_mul_batch(g1, mont(oc, [c]))[0]
