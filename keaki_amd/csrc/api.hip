@@ -346,7 +346,7 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
   if (!gt) { ST_TRY(reserve(ctx, ctx->tmp_b, n * 384)); gt = ctx->tmp_b.p; }
   // generator g2 in device memory for the pairing's second slot (src/kem.rs:30 pairs with E::G2Affine::generator())
   ST_TRY(g2_generator_to(ctx, ctx->tmp_c.p));
-  const size_t FB = 32 * 256;
+  const size_t FB = fb_table_entries();
   const bool use_tables = n >= 256;
   if (use_tables && !ctx->fb_ready) {
     // fixed-base window tables (see ec_batch.cuh): generators once per context, C and [tau]_2 per batch
@@ -370,7 +370,7 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
   }
   // ciphertexts ct_i = r_i [tau]_2 - (r_i alpha_i) g2
   if (use_tables) {
-    // [tau]_2 belongs to the setup, not to the batch: rebuild its window table (8192 G2 scalar-mults, ~4 ms) only when it changes
+    // [tau]_2 belongs to the setup, not to the batch: rebuild its window table (82 K G2 scalar-mults) only when it changes
     uint64_t tau_host[16];
     HIP_TRY(ctx, hipMemcpyAsync(tau_host, d_tau_g2_aff, 128, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -72,44 +72,60 @@ static __global__ void __launch_bounds__(64) k_encap_g2(const G2Aff* __restrict_
 // bases: g1, g2 (generators), C (the commitment) and [tau]_2. So
 //     r (C - beta g1)       = r C + (-(r beta)) g1          (src/kem.rs:22,30)
 //     r ([tau]_2 - alpha g2) = r [tau]_2 + (-(r alpha)) g2   (src/kem.rs:36-37)
-// are sums of two FIXED-base multiples: with 8-bit window tables T[j][d] = d 2^(8j) B (32 x 256
-// affine entries per base, built once per batch by k_mul_batch) each costs 32 mixed additions and
+// are sums of two FIXED-base multiples: with signed 13-bit window tables T[j][d] = d 2^(13j) B, d = 1..4096 (20 x 4097
+// affine entries per base, built by k_mul_batch; negative digits negate y) each costs at most 20 mixed additions and
 // no doublings, instead of a 254-step double-and-add ladder per scalar-mult.
 // ------------------------------------------------------------------------------------------------
-constexpr u32 FB_WINDOWS = 32, FB_ENTRIES = 256;
+constexpr u32 FB_WB = 13, FB_WINDOWS = 20, FB_HALF = 1u << (FB_WB - 1), FB_ENTRIES = FB_HALF + 1;   // signed digits: entry d in [1, 4096]
 
-// scalars[j * 256 + d] = Montgomery(d * 2^(8j)) (0 when the value is >= r: never indexed, scalars are < r)
+// scalars[j * FB_ENTRIES + d] = Montgomery(d * 2^(13 j) mod r)
 static __global__ void __launch_bounds__(256) k_fb_table_scalars(Fr* __restrict__ out) {
-  u32 j = blockIdx.x, d = threadIdx.x;
+  u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= FB_WINDOWS * FB_ENTRIES) return;
+  u32 j = idx / FB_ENTRIES, d = idx % FB_ENTRIES;
   u32 v[8];
 #pragma unroll
   for (int t = 0; t < 8; t++) v[t] = 0;
-  u32 bit = 8 * j;
+  const u32 bit = FB_WB * j, word = bit >> 5;
+  const u64 sh = (u64)d << (bit & 31);               // 13 + 31 bits: two words
 #pragma unroll
-  for (int t = 0; t < 8; t++) if ((bit >> 5) == (u32)t) v[t] = d << (bit & 31);   // 8-bit window never straddles a word
-  // >= r ?
-  bool ge = true;
-#pragma unroll
-  for (int t = 7; t >= 0; t--) {
-    if (v[t] != FrParams::MOD[t]) { ge = v[t] > FrParams::MOD[t]; break; }
+  for (int t = 0; t < 8; t++) {
+    if (word == (u32)t) v[t] = (u32)sh;
+    if (word + 1 == (u32)t) v[t] = (u32)(sh >> 32);
   }
-  if (ge) {
+  if (word == 7 && (sh >> 32) != 0) {                // beyond 256 bits: never indexed (the top digit is at most 2^7 + 1)
 #pragma unroll
     for (int t = 0; t < 8; t++) v[t] = 0;
   }
-  out[j * FB_ENTRIES + d] = fp_to_mont<FrParams>(v);
+  // reduce mod r: with signed digits the top term d 2^247 alone may exceed r although the whole sum is below it
+  for (int rounds = 0; rounds < 6; rounds++) {
+    bool ge = true;
+#pragma unroll
+    for (int t = 7; t >= 0; t--) {
+      if (v[t] != FrParams::MOD[t]) { ge = v[t] > FrParams::MOD[t]; break; }
+    }
+    if (!ge) break;
+    u64 b = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) { u64 dd = (u64)v[t] - FrParams::MOD[t] - b; v[t] = (u32)dd; b = (dd >> 32) & 1u; }
+  }
+  out[idx] = fp_to_mont<FrParams>(v);
 }
 
-// acc += T[j][byte_j(k)] for all windows; k canonical (consumed)
+// acc += sign_j * T[j][|digit_j(k)|] for all windows, signed 13-bit digits in (-2^12, 2^12]; k canonical (consumed)
 template <class F>
 KDEV Xyzz<F> fb_accumulate(Xyzz<F> acc, const Aff<F>* __restrict__ table, u32* v) {
+  u32 carry = 0;
 #pragma unroll 1
   for (u32 j = 0; j < FB_WINDOWS; j++) {
-    u32 d = v[0] & 255u;
+    u32 d = (v[0] & (2u * FB_HALF - 1u)) + carry;
 #pragma unroll
-    for (int t = 0; t < 7; t++) v[t] = (v[t] >> 8) | (v[t + 1] << 24);
-    v[7] >>= 8;
-    if (d) acc = xyzz_add_mixed(acc, table[j * FB_ENTRIES + d]);
+    for (int t = 0; t < 7; t++) v[t] = (v[t] >> FB_WB) | (v[t + 1] << (32 - FB_WB));
+    v[7] >>= FB_WB;
+    const bool neg = d > FB_HALF;                    // d - 2^13 and a carry (2^13 itself: digit 0, carry 1)
+    carry = neg ? 1u : 0u;
+    if (neg) d = 2u * FB_HALF - d;
+    if (d) acc = xyzz_add_mixed(acc, aff_cneg(table[j * FB_ENTRIES + d], neg));
   }
   return acc;
 }

@@ -14,7 +14,7 @@ keaki_status encap_g1_run(keaki_hip_ctx* ctx, const void* d_com, const void* d_v
   return launch_check(ctx, "encap_g1");
 }
 keaki_status fb_table_scalars_run(keaki_hip_ctx* ctx, void* d_scalars) {
-  hipLaunchKernelGGL(k_fb_table_scalars, dim3(FB_WINDOWS), dim3(FB_ENTRIES), 0, ctx->stream, (Fr*)d_scalars);
+  hipLaunchKernelGGL(k_fb_table_scalars, dim3(cdiv(FB_WINDOWS * FB_ENTRIES, 256)), dim3(256), 0, ctx->stream, (Fr*)d_scalars);
   return launch_check(ctx, "fb_table_scalars");
 }
 keaki_status g1_generator_to(keaki_hip_ctx* ctx, void* d_dst) {
@@ -22,7 +22,7 @@ keaki_status g1_generator_to(keaki_hip_ctx* ctx, void* d_dst) {
   HIP_TRY(ctx, hipMemcpyFromSymbolAsync((char*)d_dst + sizeof(Fq), HIP_SYMBOL(G1_GEN_Y), sizeof(Fq), 0, hipMemcpyDeviceToDevice, ctx->stream));
   return KEAKI_OK;
 }
-// table[j*256+d] = d 2^(8j) * base   (8192 affine entries)
+// table[j * FB_ENTRIES + d] = d 2^(13 j) * base   (20 x 4097 affine entries)
 keaki_status g1_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void* d_table_scalars, void* d_table) {
   hipLaunchKernelGGL((k_mul_batch<Fq>), dim3(cdiv(FB_WINDOWS * FB_ENTRIES, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_base, 0,
                      (const Fr*)d_table_scalars, FB_WINDOWS * FB_ENTRIES, (G1Aff*)d_table);
@@ -38,4 +38,5 @@ keaki_status g1_curve_check_run(keaki_hip_ctx* ctx, const void* d_pts, size_t n,
                      (unsigned long long*)d_bad2, (unsigned long long*)d_bad2 + 1);
   return launch_check(ctx, "g1_curve_check");
 }
+size_t fb_table_entries() { return (size_t)FB_WINDOWS * FB_ENTRIES; }
 }  // namespace keaki_internal

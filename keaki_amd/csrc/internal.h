@@ -87,6 +87,7 @@ keaki_status g2_prepare_run(keaki_hip_ctx* ctx, const void* d_q, void* d_lines);
 keaki_status blake3_gt_run(keaki_hip_ctx* ctx, const void* d_gt, size_t n, void* d_key, size_t msg_len);
 keaki_status g2_generator_to(keaki_hip_ctx* ctx, void* d_dst);  // writes the affine G2 generator (128 B)
 keaki_status g1_generator_to(keaki_hip_ctx* ctx, void* d_dst);  // affine G1 generator (64 B)
+size_t fb_table_entries();                                                                     // window-table entries per base
 keaki_status fb_table_scalars_run(keaki_hip_ctx* ctx, void* d_scalars);                       // 8192 Fr: d * 2^(8j)
 keaki_status g1_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void* d_table_scalars, void* d_table);
 keaki_status g2_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void* d_table_scalars, void* d_table);

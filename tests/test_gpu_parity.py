@@ -232,6 +232,9 @@ def test_encap_fixed_base_tables_vs_oracle(oc, py, hip, rand_fr):
     tau_g2 = hip.g2_mul_batch(g2, mont(oc, [tau]))[0]
     a, v, r = rand_fr(n, 62), rand_fr(n, 63), rand_fr(n, 64)
     a[0] = 0; v[1] = 0; r[2] = 1; r[3] = py.R - 1; a[4] = py.R - 1; v[5] = 1; r[6] = 255; r[7] = 256; r[8] = (1 << 248)
+    # signed 13-bit window corners (digit 2^12, 2^12 + 1, all-ones windows, carries through every window, top digit + carry >= r / 2^247)
+    r[9] = 1 << 12; r[10] = (1 << 12) + 1; r[11] = (1 << 13) - 1; r[12] = (1 << 26) - 1; r[13] = (1 << 253) - 1; a[13] = 1
+    r[14] = sum(((1 << 12) + 1) << (13 * j) for j in range(19)); r[15] = py.R - 2; a[15] = 1; r[16] = (96 << 247) + (1 << 246)
     A, V, Rr = mont(oc, a), mont(oc, v), mont(oc, r)
     ct, gt, key = hip.encap_batch(com, tau_g2, A, V, Rr, 32)
     ect, egt, ekey = oc.encap_batch(com, tau_g2, A, V, Rr, 32, threads=8)
