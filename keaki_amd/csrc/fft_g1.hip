@@ -11,32 +11,13 @@
 // A butterfly is one scalar multiplication of a Jacobian point by a twiddle factor plus an add and a subtract; one lane
 // per butterfly, N/2 lanes per stage. Twiddle tables (omega^k, k < N/2) come from the host (scalar-field work stays there).
 #include "ec_batch.cuh"
+#include "jac29.cuh"
 #include "internal.h"
 
 namespace bn254 {
 
-// k * P for a Jacobian P (full Jacobian additions), MSB first. k: Montgomery Fr.
-KDEV G1Jac jac_scalar_mul(const G1Jac& p, const Fr& k_mont) {
-  u32 v[8];
-  fp_from_mont<FrParams>(v, k_mont);
-  G1Jac acc = jac_inf<Fq>();
-  if (jac_is_inf(p)) return acc;
-#pragma unroll
-  for (int s = 0; s < 2; s++) {   // the two top bits of a 254-bit scalar are zero
-#pragma unroll
-    for (int j = 7; j > 0; j--) v[j] = (v[j] << 1) | (v[j - 1] >> 31);
-    v[0] <<= 1;
-  }
-#pragma unroll 1
-  for (int i = 0; i < 254; i++) {
-    acc = jac_dbl(acc);
-    if (v[7] >> 31) acc = jac_add(acc, p);
-#pragma unroll
-    for (int j = 7; j > 0; j--) v[j] = (v[j] << 1) | (v[j - 1] >> 31);
-    v[0] <<= 1;
-  }
-  return acc;
-}
+// k * P for a Jacobian P: NAF ladder in the 29-bit lazy arithmetic (jac29.cuh). k: Montgomery Fr.
+KDEV G1Jac jac_scalar_mul(const G1Jac& p, const Fr& k_mont) { return jac_scalar_mul_u29(p, k_mont); }
 KDEV bool fr_is_one(const Fr& a) {
   u32 o = 0;
 #pragma unroll

@@ -2,6 +2,8 @@
 #include "pairing.cuh"
 #include "fq29.cuh"
 #include "xyzz29.cuh"
+#include "jac29.cuh"
+#include "ec_batch.cuh"
 #include "internal.h"
 namespace bn254 {
 using FqRef = Fp<FqParamsRef>;
@@ -164,11 +166,36 @@ __global__ void __launch_bounds__(64) k_selftest_x29(u32 seed, u32 iters, unsign
   }
   if (bad) atomicAdd(mismatches, bad);
 }
+
+// NAF ladder in the 29-bit Jacobian arithmetic (jac29.cuh) against the saturated double-and-add of ec_batch.cuh
+__global__ void __launch_bounds__(64) k_selftest_j29(u32 seed, u32 iters, unsigned long long* mismatches) {
+  u32 s = (seed ^ ((blockIdx.x * 64 + threadIdx.x) * 0x9E3779B9u)) | 1u;
+  unsigned long long bad = 0;
+  const Aff<Fq> g = {G1_GEN_X, G1_GEN_Y};
+  Jac<Fq> p = jac_from_aff(g);
+  for (u32 it = 0; it < iters; it++) {
+    Fr k;
+    for (int j = 0; j < 8; j++) k.l[j] = mix(s);
+    k.l[7] &= 0x1FFFFFFFu;                              // < 2^253 < r: a valid Montgomery residue of some scalar
+    u32 sh = mix(s) & 7;
+    if (sh == 0) { for (int j = 0; j < 8; j++) k.l[j] = 0; }                       // 0
+    if (sh == 1) { for (int j = 0; j < 8; j++) k.l[j] = FrParams::ONE[j]; }        // 1
+    if (sh == 2) { for (int j = 0; j < 8; j++) k.l[j] = FrParams::MOD[j]; k.l[0] -= 1; Fr one = fp_one<FrParams>(); k = fp_neg<FrParams>(one); }  // r - 1
+    Jac<Fq> a = jac_scalar_mul_u29(p, k);
+    Aff<Fq> ref = jac_to_aff(scalar_mul(jac_to_aff(p), k));
+    Aff<Fq> got = jac_to_aff(a);
+    bad += !(fq_eq(got.x, ref.x) && fq_eq(got.y, ref.y));
+    bad += !jac_is_inf(jac_scalar_mul_u29(jac_inf<Fq>(), k));
+    p = jac_is_inf(a) ? jac_dbl(p) : jac_add(a, p);      // next base: some other multiple, non-trivial Z
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
 }  // namespace bn254
 namespace keaki_internal {
 keaki_status selftest_field_run(keaki_hip_ctx* ctx, uint32_t blocks, uint32_t iters, uint32_t seed, void* d_mismatches) {
   hipLaunchKernelGGL(bn254::k_selftest_field, dim3(blocks), dim3(256), 0, ctx->stream, seed, iters, (unsigned long long*)d_mismatches);
   hipLaunchKernelGGL(bn254::k_selftest_fq2d, dim3(blocks), dim3(64), 0, ctx->stream, seed, iters > 8 ? 8u : iters, (unsigned long long*)d_mismatches);
+  hipLaunchKernelGGL(bn254::k_selftest_j29, dim3(blocks > 16 ? 16 : blocks), dim3(64), 0, ctx->stream, seed, iters > 4 ? 4u : iters, (unsigned long long*)d_mismatches);
   hipLaunchKernelGGL(bn254::k_selftest_x29, dim3(blocks > 64 ? 64 : blocks), dim3(64), 0, ctx->stream, seed, iters > 16 ? 16u : iters, (unsigned long long*)d_mismatches);
   hipLaunchKernelGGL(bn254::k_selftest_u29, dim3(blocks), dim3(256), 0, ctx->stream, seed, iters, (unsigned long long*)d_mismatches);
   return launch_check(ctx, "selftest_field");

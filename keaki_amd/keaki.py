@@ -297,6 +297,26 @@ def vec_encrypt(rng: Rng, setup: KZGSetup, com, points, values, messages):
     return [(g2[i].copy(), body[i * ml:(i + 1) * ml].tobytes()) for i in range(n)]
 
 
+def vec_encrypt_arrays(rng: Rng, setup: KZGSetup, com, points, values, messages: np.ndarray):
+    """vec_encrypt on contiguous arrays (n equal-length messages as an (n, len) uint8 array) -> (ct G2 points (n, 16) u64,
+    ct bodies (n, len) u8): the same call without a Python object per item."""
+    msgs = np.ascontiguousarray(messages, dtype=np.uint8)
+    n, ml = msgs.shape
+    pts = np.ascontiguousarray(_u64(points, 4)[:n]); vals = np.ascontiguousarray(_u64(values, 4)[:n])
+    g2 = np.zeros((n, 16), np.uint64); body = np.zeros((n, max(ml, 1)), np.uint8)
+    _ck(_lib().keaki_host_vec_encrypt(rng.h, setup.h, _p(_u64(com)), _p(pts), _p(vals), _p(msgs), C.c_size_t(n), C.c_size_t(ml), _p(g2), _p(body)))
+    return g2, body[:, :ml]
+
+
+def vec_decrypt_arrays(setup: KZGSetup, proofs, ct_g2: np.ndarray, ct_body: np.ndarray) -> np.ndarray:
+    body = np.ascontiguousarray(ct_body, dtype=np.uint8)
+    n, ml = body.shape
+    pr = np.ascontiguousarray(_u64(proofs, 8)[:n]); g2 = np.ascontiguousarray(_u64(ct_g2, 16)[:n])
+    out = np.zeros((n, max(ml, 1)), np.uint8)
+    _ck(_lib().keaki_host_vec_decrypt(setup.h, _p(pr), _p(g2), _p(body), C.c_size_t(n), C.c_size_t(ml), _p(out)))
+    return out[:, :ml]
+
+
 def vec_decrypt(setup: KZGSetup, proofs, cts):
     n = len(cts); ml = len(cts[0][1]) if n else 0
     pr = np.ascontiguousarray(_u64(proofs, 8)[:n])
