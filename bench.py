@@ -235,9 +235,10 @@ def main():
     windows = (254 + stats["window_bits"] - 1) // stats["window_bits"]
     # integer roofline: one XYZZ mixed add = 8M + 2S = 10 Montgomery products. Measured issue rate of v_mad_u64_u32 / 32-bit
     # VALU on gfx950: 1 wave-instruction per ~4.3 cycles per SIMD (profiles/r01_ubench_int_gfx950.txt). The common path of one
-    # mixed addition in k_msm_accumulate_g1_u29 (9 x 29-bit lazy limbs, fq29.cuh) is 2567 instructions in the shipped ISA
-    # (1710 v_mad_u64_u32: 8 x 162 + 2 x 126 + the 9 m_k p_0 of each product; the rest slides, masks, carries, loads).
-    ISSUES_PER_MIXED_ADD = 2567.0
+    # mixed addition in k_msm_accumulate_g1_u29 (9 x 29-bit lazy limbs, fq29.cuh) is 2416 instructions in the shipped ISA
+    # (1629 v_mad_u64_u32: 6 x 162 + 2 x 126 + one 243-multiply-add dual product R T + (2p - Y) PPP + U2/S2; the rest slides,
+    # masks, carries, loads; the two basic blocks of the loop body, rare-path zero test included).
+    ISSUES_PER_MIXED_ADD = 2416.0
     modmul_peak = 1024 * 2.4e9 / 4.3 * 64 / ISSUES_PER_MIXED_ADD * 10.0
     modmuls = 10.0 * n * windows / avg_bucket_s
     # HBM traffic of the dominant kernel from PMC counters (separate rocprofv3 --pmc passes, committed under profiles/)

@@ -137,6 +137,12 @@ KDEV U29 u29_sqr(const U29& a) {
   u29_sqr_asm(r.l, a.l);
   return r;
 }
+// (a b + c d) / 2^261 with one reduction (limb bounds: see fq29_asm.cuh)
+KDEV U29 u29_mul2(const U29& a, const U29& b, const U29& c, const U29& d) {
+  U29 r;
+  u29_mul2_asm(r.l, a.l, b.l, c.l, d.l);
+  return r;
+}
 
 // one parallel carry pass: limbs 0..7 back below 2^29 + 8 (inputs: any u32 limbs), value unchanged
 KDEV U29 u29_carry(const U29& x) {

@@ -21,7 +21,7 @@ ACC = "v[126:127]"
 ACC_LO, ACC_HI = "v126", "v127"
 
 
-def block(square):
+def block(square, dual=False):
     ops = []          # (constraint, expr) in operand order
     index = {}
 
@@ -37,6 +37,8 @@ def block(square):
     nout = len(ops)
     A = [op(("a", i), '"v"', "a[%d]" % i) for i in range(9)]
     B = A if square else [op(("b", i), '"v"', "b[%d]" % i) for i in range(9)]
+    Cc = [op(("c", i), '"v"', "c[%d]" % i) for i in range(9)] if dual else None
+    Dd = [op(("e", i), '"v"', "d[%d]" % i) for i in range(9)] if dual else None
     P = [op(("p", i), '"s"', "Q29::MOD[%d]" % i) for i in range(9)]
     INV = op(("inv",), '"s"', "Q29::INV")
     L = []
@@ -58,6 +60,9 @@ def block(square):
         else:
             for i in range(lo_i, min(k, 8) + 1):
                 terms.append((A[i], B[k - i]))
+            if dual:
+                for i in range(lo_i, min(k, 8) + 1):
+                    terms.append((Cc[i], Dd[k - i]))
         for i in range(lo_i, min(k, 9)):          # m_i p_{k-i}, i < k
             if k - i <= 8:
                 terms.append((R[i], P[k - i]))
@@ -82,9 +87,13 @@ def block(square):
     return '  asm("%s"\n      : %s\n      : %s\n      : "vcc", "%s", "%s");' % (body, outs, ins, ACC_LO, ACC_HI), len(L), nmad
 
 
-def emit(name, square):
-    stmt, n, nmad = block(square)
-    if square:
+def emit(name, square, dual=False):
+    stmt, n, nmad = block(square, dual)
+    if dual:
+        print("// r = (a b + c d) / 2^261 (lazy): two products, ONE reduction. Limbs: a, b, d at most 2^29 + 8, c at most 1.5 * 2^30 (columns stay"
+              " below 45 * 2^58). %d instructions, %d v_mad_u64_u32." % (n, nmad))
+        print("KDEV void %s(u32* __restrict__ r, const u32* __restrict__ a, const u32* __restrict__ b, const u32* __restrict__ c, const u32* __restrict__ d) {" % name)
+    elif square:
         print("// r = a^2 / 2^261 (lazy). Limbs of a at most 2^29 + 8. %d instructions, %d v_mad_u64_u32." % (n, nmad))
         print("KDEV void %s(u32* __restrict__ r, const u32* __restrict__ a) {" % name)
         print("  u32 d[8];")
@@ -101,6 +110,7 @@ def main():
     print("namespace bn254 {")
     emit("u29_mul_asm", False)
     emit("u29_sqr_asm", True)
+    emit("u29_mul2_asm", False, True)
     print("}  // namespace bn254")
 
 

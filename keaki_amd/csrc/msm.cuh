@@ -117,7 +117,8 @@ constexpr u32 P1_THREADS = 1024;
 constexpr u32 P1_CAP = 16384;          // pairs staged per pass-1 tile (8 B each = 128 KB of LDS)
 constexpr u32 PART_MAX_BINS = 2048;    // coarse bins
 constexpr u32 P2_THREADS = 1024;
-constexpr u32 P2_CAP = 32768;          // payloads staged per pass-2 chunk (4 B each = 128 KB of LDS)
+constexpr u32 P2_CAP_BIG = 32768;      // payloads staged per pass-2 chunk (4 B each = 128 KB of LDS: one workgroup per CU)
+constexpr u32 P2_CAP_SMALL = 15360;    // 60 KB: two workgroups per CU, their phases overlap
 constexpr u32 PART_MAX_FINE_SHIFT = 11;
 constexpr u32 PART_MAX_FINE = 1u << PART_MAX_FINE_SHIFT;
 
@@ -222,6 +223,7 @@ static __global__ void k_part_total(const u32* __restrict__ counts, const u32* _
   if (threadIdx.x == 0 && blockIdx.x == 0) *total = offsets[ncounts - 1] + counts[ncounts - 1];
 }
 // pass 2: one workgroup per coarse bin. bin b covers global buckets [b << shift, (b + 1) << shift).
+template <u32 P2_CAP>
 static __global__ void __launch_bounds__(P2_THREADS) k_part_fine(const u64* __restrict__ entries, const u32* __restrict__ offsets, PartShape ps,
                                                                  const u32* __restrict__ total_ptr, u32 nbuckets_total, u32* __restrict__ bucket_offsets,
                                                                  u32* __restrict__ bucket_counts, u32* __restrict__ sorted) {
@@ -482,8 +484,8 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const Aff<F>* __restrict
 // G1 bucket accumulation in the 9 x 29-bit lazy representation (fq29.cuh): same schedule and memory traffic as the generic
 // kernel above, ~2450 instead of ~3200 issues per mixed addition. Table / SRS rows stay in the saturated 2^256 form (the
 // 2^261 form is the same integer shifted by 5 bits); buckets are written back saturated and canonical.
-// Value bounds (multiples of p; measured maxima in brackets): X < 9.4 [8.7], Y < 3.6 [3.1], ZZ, ZZZ < 1.4; P = U2 - X + 16p < 17.4;
-// R = S2 - Y + 4p < 5.3; every product of those stays < 3p.
+// Value bounds (multiples of p; measured maxima in brackets): X < 9.4 [8.7], Y < 1.6 [1.4], ZZ, ZZZ < 1.4; P = U2 - X + 16p < 17.4;
+// R = S2 - Y + 4p < 5.3 [4.9]; every product of those stays < 3p.
 static __global__ void __launch_bounds__(256) k_msm_accumulate_g1_u29(const Aff<Fq>* __restrict__ points, const u32* __restrict__ sorted,
                                                                       const u32* __restrict__ offsets, const u32* __restrict__ counts,
                                                                       const u32* __restrict__ perm, u32 nbuckets_total, Xyzz<Fq>* __restrict__ buckets) {
@@ -509,7 +511,7 @@ static __global__ void __launch_bounds__(256) k_msm_accumulate_g1_u29(const Aff<
       continue;
     }
     const U29 U2 = u29_mul(X2, ZZ), S2 = u29_mul(Y2, ZZZ);
-    const U29 P = u29_sub(U2, X1, Q29::K16), R = u29_sub(S2, Y1, Q29::K4W);   // Y1 is kept uncarried (limbs < 2^31)
+    const U29 P = u29_sub(U2, X1, Q29::K16), R = u29_sub(S2, Y1, Q29::K4);
     if (u29_maybe_zero(P)) {            // 18 in 2^29 for unrelated points; exact test only then
       if (u29_is_zero(P)) {
         if (u29_is_zero(R)) {           // same point: double it in the saturated arithmetic, re-enter
@@ -523,8 +525,12 @@ static __global__ void __launch_bounds__(256) k_msm_accumulate_g1_u29(const Aff<
     }
     const U29 PP = u29_sqr(P), PPP = u29_mul(P, PP), Q = u29_mul(X1, PP);
     const U29 X3 = u29_sub3(u29_sqr(R), PPP, Q);
-    const U29 T = u29_sub_raw(Q, X3, Q29::K16);                                 // only multiplied by the carried R
-    Y1 = u29_sub_raw(u29_mul(R, T), u29_mul(Y1, PPP), Q29::K2);
+    const U29 T = u29_sub(Q, X3, Q29::K16);
+    // Y3 = R T - Y1 PPP as ONE double-width column pass with a single reduction: R T + (2p - Y1) PPP  (Y1 < 1.6p, limbs exact)
+    U29 NY1;
+#pragma unroll
+    for (int i = 0; i < 9; i++) NY1.l[i] = Q29::K2[i] - Y1.l[i];
+    Y1 = u29_mul2(R, T, NY1, PPP);
     X1 = X3;
     ZZ = u29_mul(ZZ, PP);
     ZZZ = u29_mul(ZZZ, PPP);

@@ -99,8 +99,13 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   hipLaunchKernelGGL(k_part_scatter, dim3(ps.nwg), dim3(P1_THREADS), 0, st, (const Fr*)d_scalars, s, ps, (const u32*)poffsets, (const u32*)pcounts_t, entries);
   ST_TRY(launch_check(ctx, "part_scatter"));
   hipLaunchKernelGGL(k_part_total, dim3(1), dim3(64), 0, st, (const u32*)pcounts, (const u32*)poffsets, (u32)ncounts, poffsets + ncounts);
-  hipLaunchKernelGGL(k_part_fine, dim3(ps.nbins), dim3(P2_THREADS), 0, st, (const u64*)entries, (const u32*)poffsets, ps, (const u32*)(poffsets + ncounts),
-                     (u32)nb, offsets, hist, sorted);
+  static const bool p2_small = getenv("KEAKI_P2_SMALL") && atoi(getenv("KEAKI_P2_SMALL")) != 0;
+  if (p2_small)
+    hipLaunchKernelGGL((k_part_fine<P2_CAP_SMALL>), dim3(ps.nbins), dim3(P2_THREADS), 0, st, (const u64*)entries, (const u32*)poffsets, ps,
+                       (const u32*)(poffsets + ncounts), (u32)nb, offsets, hist, sorted);
+  else
+    hipLaunchKernelGGL((k_part_fine<P2_CAP_BIG>), dim3(ps.nbins), dim3(P2_THREADS), 0, st, (const u64*)entries, (const u32*)poffsets, ps,
+                       (const u32*)(poffsets + ncounts), (u32)nb, offsets, hist, sorted);
   ST_TRY(launch_check(ctx, "part_fine"));
   // bucket schedule: descending size
   ST_TRY(reserve(ctx, ctx->perm, nb * 4 + 2 * CNT_BINS * 4));

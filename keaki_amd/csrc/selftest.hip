@@ -104,6 +104,10 @@ __global__ void __launch_bounds__(256) k_selftest_u29(u32 seed, u32 iters, unsig
     bad += !fq_eq(u29_to_fq(u29_mul(al, br)), a * b);           // table coordinate x accumulator coordinate
     bad += !fq_eq(u29_to_fq(u29_mul(ar, br)), a * b);
     bad += !fq_eq(u29_to_fq(u29_sqr(ar)), fq_sqr(a));
+    {  // the asm streams against the portable statements of the same column algorithm, limb for limb
+      U29 m1 = u29_mul(al, br), m2 = u29_mul_ref(al, br), s1 = u29_sqr(ar), s2 = u29_sqr_ref(ar);
+      for (int j = 0; j < 9; j++) bad += (m1.l[j] != m2.l[j]) + (s1.l[j] != s2.l[j]);
+    }
     // differences at every bias, then used as product operands (the shapes of the mixed addition)
     U29 p16 = u29_sub(ar, br, Q29::K16), p4 = u29_sub(ar, br, Q29::K4), p2 = u29_sub(ar, br, Q29::K2);
     bad += !fq_eq(u29_to_fq(p16), a - b);
@@ -120,6 +124,11 @@ __global__ void __launch_bounds__(256) k_selftest_u29(u32 seed, u32 iters, unsig
       bad += !fq_eq(u29_to_fq(y), a * b - c * d);
       bad += !fq_eq(u29_to_fq(u29_sub(ar, y, Q29::K4W)), a - (a * b - c * d));
       bad += !fq_eq(u29_to_fq(u29_mul(y, br)), (a * b - c * d) * b);
+    }
+    {  // the dual product of the mixed addition: (a b + (2p - c) d) / R with one reduction == a b - c d
+      U29 nc;
+      for (int j = 0; j < 9; j++) nc.l[j] = Q29::K2[j] - cr.l[j];
+      bad += !fq_eq(u29_to_fq(u29_mul2(p4, u29_sub(dr, x3, Q29::K16), nc, br)), (a - b) * (d - (a - b - c - c)) - c * b);
     }
     // zero filter and exact zero test
     U29 z = u29_sub(ar, ar, Q29::K16);
