@@ -50,6 +50,20 @@ KDEV U29 u29_from_sat_shift5(const u32* x) {
   return r;
 }
 
+// limbs of x itself (no shift): the integer of a saturated residue cut into 29-bit limbs (limb 8 = bits 232..255)
+KDEV U29 u29_from_sat_plain(const u32* x) {
+  U29 r;
+  r.l[0] = x[0] & Q29::MASK;
+#pragma unroll
+  for (int i = 1; i < 9; i++) {
+    const int s = 29 * i, w = s >> 5, o = s & 31;
+    u32 lo = x[w], hi = (w + 1 < 8) ? x[w + 1] : 0u;
+    u32 v = o ? __builtin_amdgcn_alignbit(hi, lo, o) : lo;
+    r.l[i] = (i < 8) ? (v & Q29::MASK) : v;
+  }
+  return r;
+}
+
 // slide the 64-bit column accumulator down one limb
 KDEV void u29_slide(u32& lo, u32& hi) {
   lo = __builtin_amdgcn_alignbit(hi, lo, 29);
@@ -178,9 +192,8 @@ KDEV U29 u29_sub3(const U29& a, const U29& b, const U29& c) {
 // cheap necessary condition for x == 0 (mod p) when x < 18p and limb 0 is exact (after u29_carry): x = k p => l[0] * p^-1 = k
 KDEV bool u29_maybe_zero(const U29& x) { return ((x.l[0] * Q29::PINV) & Q29::MASK) <= 17u; }
 
-// 2^261-form lazy value -> canonical saturated 2^256-form residue (8 x 32)
-KDEV void u29_to_sat(u32* out, const U29& a) {
-  U29 t = u29_mul(a, u29_const(Q29::R256));   // == value * 2^256 (mod p), < 2p, limbs exact
+// t < 2p with exact limbs (a product's output) -> the canonical integer below p, packed into 8 x 32 bits
+KDEV void u29_pack_canonical(u32* out, const U29& t) {
   // d = t - p with a signed ripple; keep t when it borrows
   u32 d[9];
   int carry = 0;
@@ -202,6 +215,10 @@ KDEV void u29_to_sat(u32* out, const U29& a) {
     if (q + 2 < 10 && 58 - o < 32) w |= (u64)v[q + 2] << 58;
     out[j] = (u32)(w >> o);
   }
+}
+// 2^261-form lazy value -> canonical saturated 2^256-form residue (8 x 32)
+KDEV void u29_to_sat(u32* out, const U29& a) {
+  u29_pack_canonical(out, u29_mul(a, u29_const(Q29::R256)));   // == value * 2^256 (mod p), < 2p, limbs exact
 }
 KDEV Fq u29_to_fq(const U29& a) {
   Fq r;

@@ -11,14 +11,16 @@ Why one statement: hipcc's own schedule of the portable loops splits every colum
 instructions); and with one statement per column it puts a wait state behind every statement (on gfx940+ it must assume that
 an asm block ends in a partial-register write, the "dst_sel forwarding" hazard) -- 24 dead issue slots per product. The halves
 of a 64-bit asm operand cannot be named inside the string, so the accumulator is a fixed VGPR pair declared as clobbered
-(v[126:127]: inside the allocation of every kernel that uses these streams, so it costs no occupancy).
+(v[54:55]: inside the allocation of every kernel that uses these streams, so it costs no occupancy, and in a
+caller-saved block of the AMDGPU calling convention, so a non-inlined function that contains a stream -- fq2d_mul in pairing.cuh --
+need not save and restore it; v[126:127] cost two AGPR spill slots there and with them the second wave per SIMD).
 m_k lives in the register of result limb k (m_k is last read in column k + 8, limb k is produced in column k + 9).
 Hazards: every VGPR dependency in the block is interlocked by the hardware; VCC is written and never read.
 
     python keaki_amd/csrc/gen_fq29_asm.py > keaki_amd/csrc/fq29_asm.cuh
 """
-ACC = "v[126:127]"
-ACC_LO, ACC_HI = "v126", "v127"
+ACC = "v[54:55]"
+ACC_LO, ACC_HI = "v54", "v55"
 
 
 def block(square, dual=False):

@@ -24,6 +24,7 @@
 // The tower code above Fq2 is written once against the Fq2d primitives.
 #pragma once
 #include "bn254_curve.cuh"
+#include "fq29.cuh"
 
 namespace bn254 {
 
@@ -73,13 +74,24 @@ KDEV Fq2d fq2_mul_fq(const Fq2d& a, const Fq& k) { return {a.v * k}; }
 KDEV Fq2d fq2d_load(const Fq2* a) { return {reinterpret_cast<const Fq*>(a)[lane_odd()]}; }
 
 // (a0 + a1 u)(b0 + b1 u):  even lane: a0 b0 - a1 b1 ; odd lane: a1 b0 + a0 b1
+// Both products of a lane go through ONE double-width column pass with a single Montgomery reduction, in the 9 x 29-bit limbs of
+// fq29.cuh (no carry instructions): the saturated operands are cut into limbs on the way in -- the left factors shifted by 5 bits,
+// which turns the 2^256 Montgomery form into the 2^261 one the stream reduces by -- and the result (< 1.6p) is brought back to
+// the canonical saturated residue, so nothing above this function changes. The even lane's subtraction is (64p - 32 a1) b1.
+// ~1,700 SIMD-cycles instead of ~2,550 for two saturated products and a modular addition.
 static KNOINLINE Fq2d fq2d_mul(const Fq2d a, const Fq2d b) {
   const bool odd = lane_odd() != 0;
   Fq ao = fq_partner(a.v), bo = fq_partner(b.v);
-  // p1 = a_self * (odd ? b_other : b_self) ; p2 = a_other * (odd ? b_self : b_other)
-  Fq p1 = a.v * fq_select(odd, bo, b.v);
-  Fq p2 = ao * fq_select(odd, b.v, bo);
-  return {p1 + fp_cneg<FqParams>(p2, !odd)};
+  // self * X + (+-)other * Y :  X = odd ? b_other : b_self ;  Y = odd ? b_self : b_other ; sign: even -, odd +
+  const Fq X = fq_select(odd, bo, b.v), Y = fq_select(odd, b.v, bo);
+  const U29 A1 = u29_from_sat_shift5(a.v.l), B1 = u29_from_sat_plain(X.l), D = u29_from_sat_plain(Y.l);
+  U29 C = u29_from_sat_shift5(ao.l);
+#pragma unroll
+  for (int i = 0; i < 9; i++) C.l[i] = odd ? C.l[i] : Q29::K64[i] - C.l[i];       // 64p - 32 a1 > 0 in every limb (32p would underflow the
+                                                                                    // top limb for a1 near p); limbs below 1.5 * 2^30
+  Fq2d r;
+  u29_pack_canonical(r.v.l, u29_mul2(A1, B1, C, D));
+  return r;
 }
 // (a0 + a1 u)^2:  even lane: (a0 + a1)(a0 - a1) ; odd lane: 2 a0 a1  -- one product per lane
 static KNOINLINE Fq2d fq2d_sqr(const Fq2d a) {
