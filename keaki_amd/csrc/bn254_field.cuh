@@ -34,6 +34,7 @@ struct alignas(16) Fq2 {
 }  // namespace bn254
 
 #include "bn254_constants.cuh"
+#include "fq29_core.cuh"
 
 namespace bn254 {
 
@@ -322,10 +323,20 @@ KDEV Fq2 fq2_zero() { return {fq_zero(), fq_zero()}; }
 KDEV Fq2 fq2_one() { return {fq_one(), fq_zero()}; }
 KDEV bool fq2_is_zero(const Fq2& a) { return fq_is_zero(a.c0) && fq_is_zero(a.c1); }
 KDEV bool fq2_eq(const Fq2& a, const Fq2& b) { return fq_eq(a.c0, b.c0) && fq_eq(a.c1, b.c1); }
-KDEV Fq2 fq2_mul_inl(const Fq2& a, const Fq2& b) {  // Karatsuba: 3 Fq products
-  Fq t0 = a.c0 * b.c0, t1 = a.c1 * b.c1;
-  Fq t2 = (a.c0 + a.c1) * (b.c0 + b.c1);
-  return {t0 - t1, t2 - t0 - t1};
+// Each component is ONE dual product in the 9 x 29-bit limbs of fq29_core.cuh -- two products sharing a single Montgomery
+// reduction, no carry instructions: c0 = a0 b0 + (64p - 32 a1) b1, c1 = a0 b1 + a1 b0. The left factors enter shifted by 5 bits
+// (2^256 -> 2^261 Montgomery form), results come back as canonical saturated residues. ~770 instructions against ~1020 for the
+// Karatsuba form on the saturated streams (3 products + 5 modular additions).
+KDEV Fq2 fq2_mul_inl(const Fq2& a, const Fq2& b) {
+  const U29 A0 = u29_from_sat_shift5(a.c0.l), A1 = u29_from_sat_shift5(a.c1.l);
+  const U29 B0 = u29_from_sat_plain(b.c0.l), B1 = u29_from_sat_plain(b.c1.l);
+  U29 NA1;
+#pragma unroll
+  for (int i = 0; i < 9; i++) NA1.l[i] = Fq29Params::K64[i] - A1.l[i];
+  Fq2 r;
+  u29_pack_canonical(r.c0.l, u29_mul2(A0, B0, NA1, B1));
+  u29_pack_canonical(r.c1.l, u29_mul2(A0, B1, A1, B0));
+  return r;
 }
 KDEV Fq2 fq2_sqr_inl(const Fq2& a) {  // (a0+a1)(a0-a1) + 2 a0 a1 u
   Fq m = a.c0 * a.c1;

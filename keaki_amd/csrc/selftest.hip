@@ -46,6 +46,12 @@ __global__ void __launch_bounds__(256) k_selftest_field(u32 seed, u32 iters, uns
     bad += !same(-a, fp_neg<FqParamsRef>(ar));
     bad += !same(fq_sqr(a), fp_mul<FqParamsRef>(ar, ar));
     if ((it & 15) == 0) bad += !fq_eq(fq_inv_xgcd(a), fq_inv(a));     // binary-GCD inverse == Fermat ladder (incl. 0, p-1, tiny values)
+    {  // Fq2 product (one dual 29-bit product per component) against the Karatsuba form on the saturated streams
+      Fq2 x = {a, b}, y = {chain, pick(s, (sh >> 8) & 7)};
+      Fq t0 = x.c0 * y.c0, t1 = x.c1 * y.c1, t2 = (x.c0 + x.c1) * (y.c0 + y.c1);
+      Fq2 z = fq2_mul_inl(x, y);
+      bad += !fq_eq(z.c0, t0 - t1) + !fq_eq(z.c1, t2 - t0 - t1);
+    }
     // dependent chain (exercises back-to-back streams)
     chain = chain * a + b - chain * chain;
     chain_ref = fp_sub<FqParamsRef>(fp_add<FqParamsRef>(fp_mul<FqParamsRef>(chain_ref, ar), br), fp_mul<FqParamsRef>(chain_ref, chain_ref));
