@@ -5,13 +5,14 @@
 // occur inside the loops of src/vec.rs:63-66.
 #pragma once
 #include "bn254_curve.cuh"
+#include "jac29.cuh"
 
 namespace bn254 {
 
 // k * P, k given as Montgomery Fr. MSB-first; the 256-bit scalar is shifted left one bit per step so
 // register indices stay static.
 template <class F>
-KDEV Jac<F> scalar_mul(const Aff<F>& p, const Fr& k_mont) {
+KDEV Jac<F> scalar_mul_sat(const Aff<F>& p, const Fr& k_mont) {
   u32 v[8];
   fp_from_mont<FrParams>(v, k_mont);
   Jac<F> acc = jac_inf<F>();
@@ -33,6 +34,10 @@ KDEV Jac<F> scalar_mul(const Aff<F>& p, const Fr& k_mont) {
   }
   return acc;
 }
+
+// G2 (and the reference ladder of the self-test): the saturated double-and-add above. G1: the NAF ladder in 29-bit limbs (jac29.cuh).
+template <class F> KDEV Jac<F> scalar_mul(const Aff<F>& p, const Fr& k_mont) { return scalar_mul_sat(p, k_mont); }
+KDEV Jac<Fq> scalar_mul(const Aff<Fq>& p, const Fr& k_mont) { return jac_scalar_mul_u29(jac_from_aff(p), k_mont); }
 
 template <class F>
 __global__ void __launch_bounds__(64) k_mul_batch(const Aff<F>* __restrict__ pts, int stride, const Fr* __restrict__ scalars, u32 n,

@@ -38,11 +38,20 @@ KDEV J29 j29_dbl(const J29& p) {
   r.z = u29_scale(u29_mul(p.y, p.z), 2);
   return r;
 }
-// a + (X2, Y2, Z2) with Z2Z2 = Z2^2, Z2cu = Z2^3; never the doubling / cancellation case (caller's invariant)
-KDEV J29 j29_add(const J29& a, const U29& X2, const U29& Y2, const U29& Z2, const U29& Z2Z2, const U29& Z2cu) {
+// a + (X2, Y2, Z2) with Z2Z2 = Z2^2, Z2cu = Z2^3. special: 0 = ordinary sum (returned), 1 = the two points are equal (the caller doubles),
+// 2 = they are opposite (the sum is the identity). In a ladder k P with k < r that only happens for k = r - 2 (running multiple -P,
+// last digit -1), but it costs three instructions to notice (zero filter of fq29_core.cuh).
+KDEV J29 j29_add(const J29& a, const U29& X2, const U29& Y2, const U29& Z2, const U29& Z2Z2, const U29& Z2cu, int& special) {
   const U29 Z1Z1 = u29_sqr(a.z), U1 = u29_mul(a.x, Z2Z2), U2 = u29_mul(X2, Z1Z1), S1 = u29_mul(a.y, Z2cu);
   const U29 S2 = u29_mul(Y2, u29_mul(a.z, Z1Z1));
   const U29 H = u29_sub(U2, U1, Q29::K2);
+  special = 0;
+  if (u29_maybe_zero(H)) {
+    if (u29_is_zero(H)) {
+      special = u29_is_zero(u29_sub(S2, S1, Q29::K2)) ? 1 : 2;
+      return a;
+    }
+  }
   const U29 I = u29_scale(u29_sqr(H), 4), J = u29_mul(H, I);
   U29 t;
 #pragma unroll
@@ -89,7 +98,10 @@ KDEV Jac<Fq> jac_scalar_mul_u29(const Jac<Fq>& p, const Fr& k_mont) {
         acc.x = X2; acc.y = neg ? Y2n : Y2; acc.z = Z2;
         empty = false;
       } else {
-        acc = j29_add(acc, X2, neg ? Y2n : Y2, Z2, Z2Z2, Z2cu);
+        int special;
+        acc = j29_add(acc, X2, neg ? Y2n : Y2, Z2, Z2Z2, Z2cu, special);
+        if (special == 1) acc = j29_dbl(acc);
+        if (special == 2) empty = true;
       }
     }
   }

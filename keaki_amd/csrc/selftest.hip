@@ -195,9 +195,10 @@ __global__ void __launch_bounds__(64) k_selftest_j29(u32 seed, u32 iters, unsign
     u32 sh = mix(s) & 7;
     if (sh == 0) { for (int j = 0; j < 8; j++) k.l[j] = 0; }                       // 0
     if (sh == 1) { for (int j = 0; j < 8; j++) k.l[j] = FrParams::ONE[j]; }        // 1
-    if (sh == 2) { for (int j = 0; j < 8; j++) k.l[j] = FrParams::MOD[j]; k.l[0] -= 1; Fr one = fp_one<FrParams>(); k = fp_neg<FrParams>(one); }  // r - 1
+    if (sh == 2) { Fr one = fp_one<FrParams>(); k = fp_neg<FrParams>(one); }                       // r - 1
+    if (sh == 3) { Fr one = fp_one<FrParams>(); k = fp_neg<FrParams>(fp_add<FrParams>(one, one)); }  // r - 2: the ladder's last addition is a doubling
     Jac<Fq> a = jac_scalar_mul_u29(p, k);
-    Aff<Fq> ref = jac_to_aff(scalar_mul(jac_to_aff(p), k));
+    Aff<Fq> ref = jac_to_aff(scalar_mul_sat(jac_to_aff(p), k));
     Aff<Fq> got = jac_to_aff(a);
     bad += !(fq_eq(got.x, ref.x) && fq_eq(got.y, ref.y));
     bad += !jac_is_inf(jac_scalar_mul_u29(jac_inf<Fq>(), k));
