@@ -226,6 +226,7 @@ KDEV Fp<P> fp_to_mont(const u32* canon) {
 // (k_selftest_field) compares the streams with, through FqParamsRef.
 // ---------------------------------------------------------------------------------------------
 struct FqParamsRef : FqParams {};   // same constants, but takes the portable template path
+struct FrParamsRef : FrParams {};
 }  // namespace bn254
 #ifndef KEAKI_PORTABLE_FIELD
 #include "bn254_field_asm.cuh"
@@ -234,6 +235,7 @@ template <> KDEV Fq fp_mul<FqParams>(const Fq& a, const Fq& b) { Fq r; fq_mul_as
 template <> KDEV Fq fp_add<FqParams>(const Fq& a, const Fq& b) { Fq r; fq_add_asm(r.l, a.l, b.l); return r; }
 template <> KDEV Fq fp_sub<FqParams>(const Fq& a, const Fq& b) { Fq r; fq_sub_asm(r.l, a.l, b.l); return r; }
 template <> KDEV Fq fp_neg<FqParams>(const Fq& a) { Fq r; fq_neg_asm(r.l, a.l); return r; }
+template <> KDEV void fp_from_mont<FrParams>(u32* out, const Fr& a) { fr_from_mont_asm(out, a.l); }   // the MSM's digit extraction
 }  // namespace bn254
 #endif
 namespace bn254 {

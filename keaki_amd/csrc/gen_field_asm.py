@@ -148,6 +148,55 @@ def emit_neg():
     print("}")
 
 
+def emit_redc(params, name):
+    """x / 2^256 mod the modulus of `params` (Montgomery -> canonical integer, ark-ff into_bigint), ONE asm block: the MSM's digit
+    extraction runs it once per scalar per pass and hipcc's schedule of the portable loop is ~450 instructions (250 of them v_mov).
+    Accumulator v[52:53] + overflow counter v54: fixed registers of a caller-saved block, declared as clobbers."""
+    ACC, LO, HI, OVF = "v[52:53]", "v52", "v53", "v54"
+    ops = []
+    idx = {}
+    def op(key, cons, expr):
+        if key not in idx:
+            idx[key] = len(ops); ops.append((cons, expr))
+        return "%%%d" % idx[key]
+    T = [op(("t", i), '"=&v"', "t[%d]" % i) for i in range(8)]       # m_k lives in t[k] until result limb k is produced (column k + 8)
+    nout = len(ops)
+    X = [op(("x", i), '"v"', "x[%d]" % i) for i in range(8)]
+    P = [op(("p", i), '"s"', "%s::MOD[%d]" % (params, i)) for i in range(8)]
+    INV = op(("inv",), '"s"', "%s::INV" % params)
+    L = ["v_mov_b32 %s, 0" % LO, "v_mov_b32 %s, 0" % HI, "v_mov_b32 %s, 0" % OVF]
+    def mad(a, b):
+        L.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (ACC, a, b, ACC))
+        L.append("v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (OVF, OVF))
+    def slide():
+        L.append("v_mov_b32 %s, %s" % (LO, HI)); L.append("v_mov_b32 %s, %s" % (HI, OVF)); L.append("v_mov_b32 %s, 0" % OVF)
+    for k in range(8):
+        L.append("v_add_co_u32_e32 %s, vcc, %s, %s" % (LO, X[k], LO))          # acc < 2^34 after a slide: cannot leave 64 bits
+        L.append("v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (HI, HI))
+        for i in range(k):
+            mad(T[i], P[k - i])
+        L.append("v_mul_lo_u32 %s, %s, %s" % (T[k], LO, INV))
+        mad(T[k], P[0])
+        slide()
+    res = []
+    for k in range(8, 15):
+        for i in range(k - 7, 8):
+            mad(T[i], P[k - i])
+        # result limb k - 8 may overwrite m_(k-8): last read in column k - 1 ... but m_(k-8) p_(8)? no: p has 8 limbs, m_i is read up to column i + 7
+        L.append("v_mov_b32 %s, %s" % (T[k - 8], LO))
+        slide()
+    L.append("v_mov_b32 %s, %s" % (T[7], LO))
+    body = "\\n\\t".join(L)
+    print("// r = x / 2^256 mod p(%s), canonical. %d instructions." % (params, len(L) + 16))
+    print("KDEV void %s(u32* __restrict__ r, const u32* __restrict__ x) {" % name)
+    print("  u32 t[8];")
+    print('  asm("%s"\n      : %s\n      : %s\n      : "vcc", "%s", "%s", "%s");' % (body, ", ".join("%s(%s)" % o for o in ops[:nout]),
+          ", ".join("%s(%s)" % o for o in ops[nout:]), LO, HI, OVF))
+    print("  fp_reduce_once<%s>(t);" % params)
+    print("#pragma unroll\n  for (int j = 0; j < 8; j++) r[j] = t[j];")
+    print("}")
+
+
 def main():
     print("// GENERATED by keaki_amd/csrc/gen_field_asm.py -- do not edit.")
     print("// Hand-scheduled gfx950 streams for Fq (BN254 base field): see the generator's header for the design.")
@@ -158,6 +207,7 @@ def main():
     emit_add()
     emit_sub()
     emit_neg()
+    emit_redc("FrParams", "fr_from_mont_asm")
     print("}  // namespace bn254")
 
 

@@ -52,6 +52,18 @@ __global__ void __launch_bounds__(256) k_selftest_field(u32 seed, u32 iters, uns
       Fq2 z = fq2_mul_inl(x, y);
       bad += !fq_eq(z.c0, t0 - t1) + !fq_eq(z.c1, t2 - t0 - t1);
     }
+    {  // Montgomery -> canonical of a scalar (fr_from_mont_asm) against the portable loop
+      Fr x; Fp<FrParamsRef> xr;
+      for (int j = 0; j < 8; j++) x.l[j] = mix(s);
+      x.l[7] &= 0x1FFFFFFFu;                                       // < 2^253 < r
+      if ((sh & 0x300) == 0x100) { for (int j = 0; j < 8; j++) x.l[j] = FrParams::MOD[j]; x.l[0] -= 1; }
+      if ((sh & 0x300) == 0x200) { for (int j = 0; j < 8; j++) x.l[j] = (j == 0); }
+      for (int j = 0; j < 8; j++) xr.l[j] = x.l[j];
+      u32 c1[8], c2[8];
+      fp_from_mont<FrParams>(c1, x);
+      fp_from_mont<FrParamsRef>(c2, xr);
+      for (int j = 0; j < 8; j++) bad += (c1[j] != c2[j]);
+    }
     // dependent chain (exercises back-to-back streams)
     chain = chain * a + b - chain * chain;
     chain_ref = fp_sub<FqParamsRef>(fp_add<FqParamsRef>(fp_mul<FqParamsRef>(chain_ref, ar), br), fp_mul<FqParamsRef>(chain_ref, chain_ref));
