@@ -346,20 +346,23 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
   if (!gt) { ST_TRY(reserve(ctx, ctx->tmp_b, n * 384)); gt = ctx->tmp_b.p; }
   // generator g2 in device memory for the pairing's second slot (src/kem.rs:30 pairs with E::G2Affine::generator())
   ST_TRY(g2_generator_to(ctx, ctx->tmp_c.p));
-  const size_t FB = fb_table_entries();
+  // window widths of the fixed-base tables: 16 bits for bases that outlive a batch (generators: per context, [tau]_2: per setup),
+  // 13 bits for the commitment's table (rebuilt per batch in the per-item-pairing path)
+  constexpr uint32_t FB_WB_LONG = 16, FB_WB_BATCH = 13;
+  const size_t FBL = fb_table_entries(FB_WB_LONG), FBS = fb_table_entries(FB_WB_BATCH);
   const bool use_tables = n >= 256;
   if (use_tables && !ctx->fb_ready) {
-    // fixed-base window tables (see ec_batch.cuh): generators once per context, C and [tau]_2 per batch
-    ST_TRY(reserve(ctx, ctx->fb_scalars, FB * 32));
-    ST_TRY(reserve(ctx, ctx->fb_g1_gen, FB * G1_AFF_BYTES + G1_AFF_BYTES));
-    ST_TRY(reserve(ctx, ctx->fb_g2_gen, FB * G2_AFF_BYTES));
-    ST_TRY(reserve(ctx, ctx->fb_com, FB * G1_AFF_BYTES));
-    ST_TRY(reserve(ctx, ctx->fb_tau, FB * G2_AFF_BYTES));
-    ST_TRY(fb_table_scalars_run(ctx, ctx->fb_scalars.p));
-    void* g1pt = (char*)ctx->fb_g1_gen.p + FB * G1_AFF_BYTES;   // scratch slot behind the table
+    ST_TRY(reserve(ctx, ctx->fb_scalars, (FBL + FBS) * 32));                        // [16-bit scalars | 13-bit scalars]
+    ST_TRY(reserve(ctx, ctx->fb_g1_gen, FBL * G1_AFF_BYTES + G1_AFF_BYTES));
+    ST_TRY(reserve(ctx, ctx->fb_g2_gen, FBL * G2_AFF_BYTES));
+    ST_TRY(reserve(ctx, ctx->fb_com, FBS * G1_AFF_BYTES));
+    ST_TRY(reserve(ctx, ctx->fb_tau, FBL * G2_AFF_BYTES));
+    ST_TRY(fb_table_scalars_run(ctx, ctx->fb_scalars.p, FB_WB_LONG));
+    ST_TRY(fb_table_scalars_run(ctx, (char*)ctx->fb_scalars.p + FBL * 32, FB_WB_BATCH));
+    void* g1pt = (char*)ctx->fb_g1_gen.p + FBL * G1_AFF_BYTES;   // scratch slot behind the table
     ST_TRY(g1_generator_to(ctx, g1pt));
-    ST_TRY(g1_fb_table_run(ctx, g1pt, ctx->fb_scalars.p, ctx->fb_g1_gen.p));
-    ST_TRY(g2_fb_table_run(ctx, ctx->tmp_c.p, ctx->fb_scalars.p, ctx->fb_g2_gen.p));
+    ST_TRY(g1_fb_table_run(ctx, g1pt, ctx->fb_scalars.p, ctx->fb_g1_gen.p, FB_WB_LONG));
+    ST_TRY(g2_fb_table_run(ctx, ctx->tmp_c.p, ctx->fb_scalars.p, ctx->fb_g2_gen.p, FB_WB_LONG));
     ctx->fb_ready = true;
   }
   // the second pairing slot is the constant generator g2: its line sequence (ark-ec's G2Prepared) is built once per context
@@ -375,14 +378,17 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
     HIP_TRY(ctx, hipMemcpyAsync(tau_host, d_tau_g2_aff, 128, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (!ctx->fb_tau_valid || memcmp(tau_host, ctx->fb_tau_pt, 128) != 0) {
-      ST_TRY(g2_fb_table_run(ctx, d_tau_g2_aff, ctx->fb_scalars.p, ctx->fb_tau.p));
+      ST_TRY(g2_fb_table_run(ctx, d_tau_g2_aff, ctx->fb_scalars.p, ctx->fb_tau.p, FB_WB_LONG));
       memcpy(ctx->fb_tau_pt, tau_host, 128);
       ctx->fb_tau_valid = true;
     }
-    ST_TRY(encap_g2_fixed_run(ctx, ctx->fb_tau.p, ctx->fb_g2_gen.p, d_points, d_r, n, d_ct_out_aff));
+    ST_TRY(encap_g2_fixed_run(ctx, ctx->fb_tau.p, FB_WB_LONG, ctx->fb_g2_gen.p, FB_WB_LONG, d_points, d_r, n, d_ct_out_aff));
   } else {
     ST_TRY(encap_g2_run(ctx, d_tau_g2_aff, d_points, d_r, n, d_ct_out_aff));
   }
+  // window widths of the GT tables: the constant B = e(g1, g2) is tabulated once per context (16 bits: 16 products per item, 201 MB), A = e(C, g2)
+  // per commitment (13 bits: 20 products per item, 31.5 MB, ~12 ms to build)
+  constexpr uint32_t GT_WB_CONST = 16, GT_WB_PER_COMMITMENT = 13;
   const char* gt_env = getenv("KEAKI_ENCAP_GT");
   const size_t gt_threshold = gt_env ? (size_t)atoll(gt_env) : (size_t)65536;
   if (n >= gt_threshold) {
@@ -390,10 +396,10 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
     ST_TRY(reserve(ctx, ctx->gt_base, 2 * 384 + G1_AFF_BYTES));
     char* gb = (char*)ctx->gt_base.p;
     if (!ctx->gt_b_ready) {
-      ST_TRY(reserve(ctx, ctx->gt_tab_b, gt_table_bytes()));
+      ST_TRY(reserve(ctx, ctx->gt_tab_b, gt_table_bytes(GT_WB_CONST)));
       ST_TRY(g1_generator_to(ctx, gb + 768));
       ST_TRY(pairing_raw_fixed_run(ctx, gb + 768, 1, ctx->g2gen_lines.p, gb + 384));
-      ST_TRY(gt_table_run(ctx, gb + 384, ctx->gt_tab_b.p));
+      ST_TRY(gt_table_run(ctx, gb + 384, ctx->gt_tab_b.p, GT_WB_CONST));
       ctx->gt_b_ready = true;
     }
     // A depends on the commitment only: reuse the table while the caller keeps encrypting to the same commitment
@@ -401,18 +407,18 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
     HIP_TRY(ctx, hipMemcpyAsync(com_host, d_com_aff, 64, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (!ctx->gt_a_valid || memcmp(com_host, ctx->gt_a_com, 64) != 0) {
-      ST_TRY(reserve(ctx, ctx->gt_tab_a, gt_table_bytes()));
+      ST_TRY(reserve(ctx, ctx->gt_tab_a, gt_table_bytes(GT_WB_PER_COMMITMENT)));
       ST_TRY(pairing_raw_fixed_run(ctx, d_com_aff, 1, ctx->g2gen_lines.p, gb));
-      ST_TRY(gt_table_run(ctx, gb, ctx->gt_tab_a.p));
+      ST_TRY(gt_table_run(ctx, gb, ctx->gt_tab_a.p, GT_WB_PER_COMMITMENT));
       memcpy(ctx->gt_a_com, com_host, 64);
       ctx->gt_a_valid = true;
     }
-    ST_TRY(gt_encap_exp_run(ctx, ctx->gt_tab_a.p, ctx->gt_tab_b.p, d_values, d_r, n, gt));
+    ST_TRY(gt_encap_exp_run(ctx, ctx->gt_tab_a.p, GT_WB_PER_COMMITMENT, ctx->gt_tab_b.p, GT_WB_CONST, d_values, d_r, n, gt));
   } else {
     // per-item pairing e(r_i (C - beta_i g1), g2) with the tabulated lines of g2
     if (use_tables) {
-      ST_TRY(g1_fb_table_run(ctx, d_com_aff, ctx->fb_scalars.p, ctx->fb_com.p));
-      ST_TRY(encap_g1_fixed_run(ctx, ctx->fb_com.p, ctx->fb_g1_gen.p, d_values, d_r, n, ctx->tmp_a.p));
+      ST_TRY(g1_fb_table_run(ctx, d_com_aff, (char*)ctx->fb_scalars.p + FBL * 32, ctx->fb_com.p, FB_WB_BATCH));
+      ST_TRY(encap_g1_fixed_run(ctx, ctx->fb_com.p, FB_WB_BATCH, ctx->fb_g1_gen.p, FB_WB_LONG, d_values, d_r, n, ctx->tmp_a.p));
     } else {
       ST_TRY(encap_g1_run(ctx, d_com_aff, d_values, d_r, n, ctx->tmp_a.p));
     }

@@ -81,28 +81,31 @@ static __global__ void __launch_bounds__(64) k_encap_g2(const G2Aff* __restrict_
 // affine entries per base, built by k_mul_batch; negative digits negate y) each costs at most 20 mixed additions and
 // no doublings, instead of a 254-step double-and-add ladder per scalar-mult.
 // ------------------------------------------------------------------------------------------------
-constexpr u32 FB_WB = 13, FB_WINDOWS = 20, FB_HALF = 1u << (FB_WB - 1), FB_ENTRIES = FB_HALF + 1;   // signed digits: entry d in [1, 4096]
+// window width per table: 16 bits (16 windows x 32768 entries) for bases that outlive a batch (the generators: per context; [tau]_2: per
+// setup), 13 bits (20 x 4096) for the commitment's table, rebuilt per batch. entries = 2^(wb-1) + 1 slots per window, slot 0 unused.
+struct FbShape { u32 wb, windows, entries; };
+__host__ __device__ inline FbShape fb_shape(u32 wb) { return {wb, (254u + wb - 1u) / wb + ((254u % wb) == 0u ? 1u : 0u), (1u << (wb - 1)) + 1u}; }
 
-// scalars[j * FB_ENTRIES + d] = Montgomery(d * 2^(13 j) mod r)
-static __global__ void __launch_bounds__(256) k_fb_table_scalars(Fr* __restrict__ out) {
+// scalars[j * entries + d] = Montgomery(d * 2^(wb j) mod r)
+static __global__ void __launch_bounds__(256) k_fb_table_scalars(Fr* __restrict__ out, FbShape g) {
   u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= FB_WINDOWS * FB_ENTRIES) return;
-  u32 j = idx / FB_ENTRIES, d = idx % FB_ENTRIES;
+  if (idx >= g.windows * g.entries) return;
+  u32 j = idx / g.entries, d = idx % g.entries;
   u32 v[8];
 #pragma unroll
   for (int t = 0; t < 8; t++) v[t] = 0;
-  const u32 bit = FB_WB * j, word = bit >> 5;
-  const u64 sh = (u64)d << (bit & 31);               // 13 + 31 bits: two words
+  const u32 bit = g.wb * j, word = bit >> 5;
+  const u64 sh = (u64)d << (bit & 31);               // at most 16 + 31 bits: two words
 #pragma unroll
   for (int t = 0; t < 8; t++) {
     if (word == (u32)t) v[t] = (u32)sh;
     if (word + 1 == (u32)t) v[t] = (u32)(sh >> 32);
   }
-  if (word == 7 && (sh >> 32) != 0) {                // beyond 256 bits: never indexed (the top digit is at most 2^7 + 1)
+  if (word == 7 && (sh >> 32) != 0) {                // beyond 256 bits: never indexed (the top digit is small)
 #pragma unroll
     for (int t = 0; t < 8; t++) v[t] = 0;
   }
-  // reduce mod r: with signed digits the top term d 2^247 alone may exceed r although the whole sum is below it
+  // reduce mod r: with signed digits the top term d 2^(wb (windows-1)) alone may exceed r although the whole sum is below it
   for (int rounds = 0; rounds < 6; rounds++) {
     bool ge = true;
 #pragma unroll
@@ -117,27 +120,28 @@ static __global__ void __launch_bounds__(256) k_fb_table_scalars(Fr* __restrict_
   out[idx] = fp_to_mont<FrParams>(v);
 }
 
-// acc += sign_j * T[j][|digit_j(k)|] for all windows, signed 13-bit digits in (-2^12, 2^12]; k canonical (consumed)
+// acc += sign_j * T[j][|digit_j(k)|] for all windows, signed wb-bit digits in (-2^(wb-1), 2^(wb-1)]; k canonical (consumed)
 template <class F>
-KDEV Xyzz<F> fb_accumulate(Xyzz<F> acc, const Aff<F>* __restrict__ table, u32* v) {
+KDEV Xyzz<F> fb_accumulate(Xyzz<F> acc, const Aff<F>* __restrict__ table, FbShape g, u32* v) {
   u32 carry = 0;
+  const u32 half = 1u << (g.wb - 1);
 #pragma unroll 1
-  for (u32 j = 0; j < FB_WINDOWS; j++) {
-    u32 d = (v[0] & (2u * FB_HALF - 1u)) + carry;
+  for (u32 j = 0; j < g.windows; j++) {
+    u32 d = (v[0] & (2u * half - 1u)) + carry;
 #pragma unroll
-    for (int t = 0; t < 7; t++) v[t] = (v[t] >> FB_WB) | (v[t + 1] << (32 - FB_WB));
-    v[7] >>= FB_WB;
-    const bool neg = d > FB_HALF;                    // d - 2^13 and a carry (2^13 itself: digit 0, carry 1)
+    for (int t = 0; t < 7; t++) v[t] = (v[t] >> g.wb) | (v[t + 1] << (32u - g.wb));
+    v[7] >>= g.wb;
+    const bool neg = d > half;                       // d - 2^wb and a carry (2^wb itself: digit 0, carry 1)
     carry = neg ? 1u : 0u;
-    if (neg) d = 2u * FB_HALF - d;
-    if (d) acc = xyzz_add_mixed(acc, aff_cneg(table[j * FB_ENTRIES + d], neg));
+    if (neg) d = 2u * half - d;
+    if (d) acc = xyzz_add_mixed(acc, aff_cneg(table[(size_t)j * g.entries + d], neg));
   }
   return acc;
 }
 
 // out[i] = r_i * BaseA + (-(r_i * x_i)) * BaseB   with tables for BaseA (C or [tau]_2) and BaseB (g1 or g2)
 template <class F>
-__global__ void __launch_bounds__(64) k_encap_fixed(const Aff<F>* __restrict__ tab_a, const Aff<F>* __restrict__ tab_b,
+__global__ void __launch_bounds__(64) k_encap_fixed(const Aff<F>* __restrict__ tab_a, FbShape ga, const Aff<F>* __restrict__ tab_b, FbShape gb,
                                                     const Fr* __restrict__ xs, const Fr* __restrict__ rs, u32 n, Aff<F>* __restrict__ out) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -147,8 +151,8 @@ __global__ void __launch_bounds__(64) k_encap_fixed(const Aff<F>* __restrict__ t
   fp_from_mont<FrParams>(u, r);
   fp_from_mont<FrParams>(v, t);
   Xyzz<F> acc = xyzz_inf<F>();
-  acc = fb_accumulate(acc, tab_a, u);
-  acc = fb_accumulate(acc, tab_b, v);
+  acc = fb_accumulate(acc, tab_a, ga, u);
+  acc = fb_accumulate(acc, tab_b, gb, v);
   out[i] = xyzz_to_aff(acc);
 }
 

@@ -13,8 +13,9 @@ keaki_status encap_g1_run(keaki_hip_ctx* ctx, const void* d_com, const void* d_v
                      (G1Aff*)d_out);
   return launch_check(ctx, "encap_g1");
 }
-keaki_status fb_table_scalars_run(keaki_hip_ctx* ctx, void* d_scalars) {
-  hipLaunchKernelGGL(k_fb_table_scalars, dim3(cdiv(FB_WINDOWS * FB_ENTRIES, 256)), dim3(256), 0, ctx->stream, (Fr*)d_scalars);
+keaki_status fb_table_scalars_run(keaki_hip_ctx* ctx, void* d_scalars, uint32_t wb) {
+  const FbShape g = fb_shape(wb);
+  hipLaunchKernelGGL(k_fb_table_scalars, dim3(cdiv(g.windows * g.entries, 256)), dim3(256), 0, ctx->stream, (Fr*)d_scalars, g);
   return launch_check(ctx, "fb_table_scalars");
 }
 keaki_status g1_generator_to(keaki_hip_ctx* ctx, void* d_dst) {
@@ -22,14 +23,17 @@ keaki_status g1_generator_to(keaki_hip_ctx* ctx, void* d_dst) {
   HIP_TRY(ctx, hipMemcpyFromSymbolAsync((char*)d_dst + sizeof(Fq), HIP_SYMBOL(G1_GEN_Y), sizeof(Fq), 0, hipMemcpyDeviceToDevice, ctx->stream));
   return KEAKI_OK;
 }
-// table[j * FB_ENTRIES + d] = d 2^(13 j) * base   (20 x 4097 affine entries)
-keaki_status g1_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void* d_table_scalars, void* d_table) {
-  hipLaunchKernelGGL((k_mul_batch<Fq>), dim3(cdiv(FB_WINDOWS * FB_ENTRIES, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_base, 0,
-                     (const Fr*)d_table_scalars, FB_WINDOWS * FB_ENTRIES, (G1Aff*)d_table);
+// table[j * entries + d] = d 2^(wb j) * base
+keaki_status g1_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void* d_table_scalars, void* d_table, uint32_t wb) {
+  const u32 cnt = (u32)fb_table_entries(wb);
+  hipLaunchKernelGGL((k_mul_batch<Fq>), dim3(cdiv(cnt, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_base, 0, (const Fr*)d_table_scalars, cnt,
+                     (G1Aff*)d_table);
   return launch_check(ctx, "g1_fb_table");
 }
-keaki_status encap_g1_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, const void* d_tab_b, const void* d_xs, const void* d_rs, size_t n, void* d_out) {
-  hipLaunchKernelGGL((k_encap_fixed<Fq>), dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_tab_a, (const G1Aff*)d_tab_b, (const Fr*)d_xs,
+keaki_status encap_g1_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t wb_a, const void* d_tab_b, uint32_t wb_b, const void* d_xs,
+                                const void* d_rs, size_t n, void* d_out) {
+  hipLaunchKernelGGL((k_encap_fixed<Fq>), dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_tab_a, fb_shape(wb_a), (const G1Aff*)d_tab_b,
+                     fb_shape(wb_b), (const Fr*)d_xs,
                      (const Fr*)d_rs, (u32)n, (G1Aff*)d_out);
   return launch_check(ctx, "encap_g1_fixed");
 }
@@ -38,5 +42,5 @@ keaki_status g1_curve_check_run(keaki_hip_ctx* ctx, const void* d_pts, size_t n,
                      (unsigned long long*)d_bad2, (unsigned long long*)d_bad2 + 1);
   return launch_check(ctx, "g1_curve_check");
 }
-size_t fb_table_entries() { return (size_t)FB_WINDOWS * FB_ENTRIES; }
+size_t fb_table_entries(uint32_t wb) { FbShape g = fb_shape(wb); return (size_t)g.windows * g.entries; }
 }  // namespace keaki_internal

@@ -20,14 +20,16 @@ keaki_status g2_generator_to(keaki_hip_ctx* ctx, void* d_dst) {
   return KEAKI_OK;
 }
 // table[j*256+d] = d 2^(8j) * base   (8192 affine entries)
-keaki_status g2_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void* d_table_scalars, void* d_table) {
-  hipLaunchKernelGGL((k_mul_batch<Fq2>), dim3(cdiv(FB_WINDOWS * FB_ENTRIES, 64)), dim3(64), 0, ctx->stream, (const G2Aff*)d_base, 0,
-                     (const Fr*)d_table_scalars, FB_WINDOWS * FB_ENTRIES, (G2Aff*)d_table);
+keaki_status g2_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void* d_table_scalars, void* d_table, uint32_t wb) {
+  const u32 cnt = (u32)fb_table_entries(wb);
+  hipLaunchKernelGGL((k_mul_batch<Fq2>), dim3(cdiv(cnt, 64)), dim3(64), 0, ctx->stream, (const G2Aff*)d_base, 0, (const Fr*)d_table_scalars, cnt,
+                     (G2Aff*)d_table);
   return launch_check(ctx, "g2_fb_table");
 }
-keaki_status encap_g2_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, const void* d_tab_b, const void* d_xs, const void* d_rs, size_t n, void* d_out) {
-  hipLaunchKernelGGL((k_encap_fixed<Fq2>), dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, (const G2Aff*)d_tab_a, (const G2Aff*)d_tab_b, (const Fr*)d_xs,
-                     (const Fr*)d_rs, (u32)n, (G2Aff*)d_out);
+keaki_status encap_g2_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t wb_a, const void* d_tab_b, uint32_t wb_b, const void* d_xs,
+                                const void* d_rs, size_t n, void* d_out) {
+  hipLaunchKernelGGL((k_encap_fixed<Fq2>), dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, (const G2Aff*)d_tab_a, fb_shape(wb_a), (const G2Aff*)d_tab_b,
+                     fb_shape(wb_b), (const Fr*)d_xs, (const Fr*)d_rs, (u32)n, (G2Aff*)d_out);
   return launch_check(ctx, "encap_g2_fixed");
 }
 keaki_status g2_curve_check_run(keaki_hip_ctx* ctx, const void* d_pts, size_t n, void* d_bad2) {

@@ -78,21 +78,22 @@ keaki_status encap_g2_run(keaki_hip_ctx* ctx, const void* d_tau_g2, const void* 
 keaki_status pairing_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, int g2_stride, size_t n, void* d_gt, const void* d_fixed_lines = nullptr);
 size_t g2_prepared_bytes();
 keaki_status pairing_raw_fixed_run(keaki_hip_ctx* ctx, const void* d_g1, size_t n, const void* d_lines, void* d_out);
-size_t gt_table_bytes();
-keaki_status gt_table_run(keaki_hip_ctx* ctx, const void* d_base, void* d_table);
-keaki_status gt_encap_exp_run(keaki_hip_ctx* ctx, const void* d_tab_a, const void* d_tab_b, const void* d_betas, const void* d_rs, size_t n, void* d_gt);
+size_t gt_table_bytes(uint32_t wb);
+keaki_status gt_table_run(keaki_hip_ctx* ctx, const void* d_base, void* d_table, uint32_t wb);
+keaki_status gt_encap_exp_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t wb_a, const void* d_tab_b, uint32_t wb_b, const void* d_betas,
+                              const void* d_rs, size_t n, void* d_gt);
 keaki_status miller_only_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, size_t n, void* d_out);
 keaki_status final_exp_only_run(keaki_hip_ctx* ctx, const void* d_in, size_t n, void* d_gt);
 keaki_status g2_prepare_run(keaki_hip_ctx* ctx, const void* d_q, void* d_lines);   // line sequence of a fixed Q
 keaki_status blake3_gt_run(keaki_hip_ctx* ctx, const void* d_gt, size_t n, void* d_key, size_t msg_len);
 keaki_status g2_generator_to(keaki_hip_ctx* ctx, void* d_dst);  // writes the affine G2 generator (128 B)
 keaki_status g1_generator_to(keaki_hip_ctx* ctx, void* d_dst);  // affine G1 generator (64 B)
-size_t fb_table_entries();                                                                     // window-table entries per base
-keaki_status fb_table_scalars_run(keaki_hip_ctx* ctx, void* d_scalars);                       // 8192 Fr: d * 2^(8j)
-keaki_status g1_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void* d_table_scalars, void* d_table);
-keaki_status g2_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void* d_table_scalars, void* d_table);
-keaki_status encap_g1_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, const void* d_tab_b, const void* d_xs, const void* d_rs, size_t n, void* d_out);
-keaki_status encap_g2_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, const void* d_tab_b, const void* d_xs, const void* d_rs, size_t n, void* d_out);
+size_t fb_table_entries(uint32_t wb);                                                          // window-table entries per base at window width wb
+keaki_status fb_table_scalars_run(keaki_hip_ctx* ctx, void* d_scalars, uint32_t wb);          // d * 2^(wb j) mod r
+keaki_status g1_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void* d_table_scalars, void* d_table, uint32_t wb);
+keaki_status g2_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void* d_table_scalars, void* d_table, uint32_t wb);
+keaki_status encap_g1_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t wb_a, const void* d_tab_b, uint32_t wb_b, const void* d_xs, const void* d_rs, size_t n, void* d_out);
+keaki_status encap_g2_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t wb_a, const void* d_tab_b, uint32_t wb_b, const void* d_xs, const void* d_rs, size_t n, void* d_out);
 keaki_status g1_curve_check_run(keaki_hip_ctx* ctx, const void* d_pts, size_t n, void* d_bad2);   // d_bad2: u64 count, u64 first index
 keaki_status g2_curve_check_run(keaki_hip_ctx* ctx, const void* d_pts, size_t n, void* d_bad2);
 keaki_status open_quotient_run(keaki_hip_ctx* ctx, const void* d_c, size_t n, const uint64_t* z, void* d_q, void* d_value, void* d_work);

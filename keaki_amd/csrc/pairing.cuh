@@ -402,7 +402,10 @@ static __global__ void __launch_bounds__(64) k_g2_prepare(const G2Aff* __restric
 // GT elements are stored in the lane-pair order: 12 Fq per element, slot 2k + parity = Fq2 coefficient k, component parity
 // (which is also ark-serialize's coefficient order).
 // ---------------------------------------------------------------------------------------------
-constexpr u32 GT_WB = 13, GT_WINDOWS = 20, GT_HALF = 1u << (GT_WB - 1), GT_ENTRIES = GT_HALF + 1;   // entry d in [1, 4096]; slot 0 unused
+// window width per table: 13 bits (20 windows x 4096 entries, 31.5 MB) for A = e(C, g2), rebuilt per commitment; 16 bits (16 x 32768,
+// 201 MB) for the constant B = e(g1, g2), built once per context. entries = 2^(wb-1) + 1 slots per window, slot 0 unused.
+struct GtShape { u32 wb, windows, entries; };
+__host__ __device__ inline GtShape gt_shape(u32 wb) { return {wb, (254u + wb - 1u) / wb + ((254u % wb) == 0u ? 1u : 0u), (1u << (wb - 1)) + 1u}; }
 
 KDEV void gt_load(Fq12* f, const Fq* __restrict__ src) {
   Fq2d* c = reinterpret_cast<Fq2d*>(f);
@@ -431,35 +434,57 @@ static __global__ void __launch_bounds__(64, 2) k_pairing_raw_fixed(const G1Aff*
   if (aff_is_inf(p)) fq12_set_one(&e);
   if (live) gt_store(out + (size_t)12 * i, &e);
 }
-// table[j * GT_ENTRIES + d] = base^(d 2^(13 j)).  Step 1: one lane pair walks the chain base^(2^s), s < 13 * 20, and drops
-// base^(2^s) into slot 2^(s mod 13) of window s / 13 (the powers of two of every window).
-static __global__ void __launch_bounds__(64, 2) k_gt_table_bases(const Fq* __restrict__ base, Fq* __restrict__ table) {
+// table[j * entries + d] = base^(d 2^(wb j)).  Step 1: one lane pair walks the chain base^(2^s), s < wb * windows, and drops
+// base^(2^s) into slot 2^(s mod wb) of window s / wb (the powers of two of every window).
+static __global__ void __launch_bounds__(64, 2) k_gt_table_bases(const Fq* __restrict__ base, Fq* __restrict__ table, GtShape g) {
   if (threadIdx.x >= 2) return;
   Fq12 x;
   gt_load(&x, base);
 #pragma unroll 1
-  for (u32 s = 0; s < GT_WB * GT_WINDOWS; s++) {
-    gt_store(table + ((size_t)(s / GT_WB) * GT_ENTRIES + (1u << (s % GT_WB))) * 12, &x);
+  for (u32 s = 0; s < g.wb * g.windows; s++) {
+    gt_store(table + ((size_t)(s / g.wb) * g.entries + (1u << (s % g.wb))) * 12, &x);
     fq12_cyc_sqr(&x, &x);
   }
 }
-// Step 2, level L = 1 .. GT_WB - 2: table[j][2^L + x] = table[j][2^L] * table[j][x], 1 <= x < 2^L (all known from the levels below)
-static __global__ void __launch_bounds__(64, 2) k_gt_table_fill(Fq* __restrict__ table, u32 L) {
+// Step 2, level L = 1 .. wb - 2: table[j][2^L + x] = table[j][2^L] * table[j][x], 1 <= x < 2^L (all known from the levels below)
+static __global__ void __launch_bounds__(64, 2) k_gt_table_fill(Fq* __restrict__ table, u32 L, GtShape g) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 pairi = t >> 1;
   const u32 per = (1u << L) - 1u;                    // entries of this level per window
-  const bool live = pairi < GT_WINDOWS * per;
+  const bool live = pairi < g.windows * per;
   const u32 pi = live ? pairi : 0u;
   const u32 j = pi / per, x = 1u + pi % per;
   Fq12 a, b;
-  gt_load(&a, table + ((size_t)j * GT_ENTRIES + (1u << L)) * 12);
-  gt_load(&b, table + ((size_t)j * GT_ENTRIES + x) * 12);
+  gt_load(&a, table + ((size_t)j * g.entries + (1u << L)) * 12);
+  gt_load(&b, table + ((size_t)j * g.entries + x) * 12);
   fq12_mul(&a, &a, &b);
-  if (live) gt_store(table + ((size_t)j * GT_ENTRIES + (1u << L) + x) * 12, &a);
+  if (live) gt_store(table + ((size_t)j * g.entries + (1u << L) + x) * 12, &a);
+}
+// acc *= base^k from the signed-window table of `base` (k canonical, consumed): digits in (-2^(wb-1), 2^(wb-1)], a digit above the half
+// becomes d - 2^wb with a carry (2^wb itself: digit 0, carry 1); a negative digit multiplies by the conjugate (unitary: inverse = conjugate)
+static KTOWER void gt_table_exp(Fq12* acc, const Fq* __restrict__ tab, GtShape g, u32* k) {
+  Fq12 e;
+  u32 carry = 0;
+  const u32 half = 1u << (g.wb - 1);
+#pragma unroll 1
+  for (u32 j = 0; j < g.windows; j++) {
+    u32 d = (k[0] & (2u * half - 1u)) + carry;
+#pragma unroll
+    for (int w = 0; w < 7; w++) k[w] = (k[w] >> g.wb) | (k[w + 1] << (32u - g.wb));
+    k[7] >>= g.wb;
+    const bool neg = d > half;
+    carry = neg ? 1u : 0u;
+    if (neg) d = 2u * half - d;
+    if (d) {
+      gt_load(&e, tab + ((size_t)j * g.entries + d) * 12);
+      if (neg) fq12_conj(&e, &e);
+      fq12_mul(acc, acc, &e);
+    }
+  }
 }
 // gt_out[i] = serialize(A^(r_i) * B^(-(r_i * beta_i)))   (tables of A and B). Two lanes per item.
-static __global__ void __launch_bounds__(64, 2) k_gt_encap_exp(const Fq* __restrict__ tab_a, const Fq* __restrict__ tab_b, const Fr* __restrict__ betas,
-                                                              const Fr* __restrict__ rs, u32 n, u32* __restrict__ gt_out) {
+static __global__ void __launch_bounds__(64, 2) k_gt_encap_exp(const Fq* __restrict__ tab_a, GtShape ga, const Fq* __restrict__ tab_b, GtShape gb,
+                                                              const Fr* __restrict__ betas, const Fr* __restrict__ rs, u32 n, u32* __restrict__ gt_out) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 item = t >> 1;
   const bool live = item < n;
@@ -469,31 +494,10 @@ static __global__ void __launch_bounds__(64, 2) k_gt_encap_exp(const Fq* __restr
   u32 u[8], v[8];
   fp_from_mont<FrParams>(u, r);
   fp_from_mont<FrParams>(v, m);
-  Fq12 acc, e;
+  Fq12 acc;
   fq12_set_one(&acc);
-  u32 ca = 0, cb = 0;                                // signed-digit carries
-#pragma unroll 1
-  for (u32 j = 0; j < GT_WINDOWS; j++) {
-    u32 da = (u[0] & (2u * GT_HALF - 1u)) + ca, db = (v[0] & (2u * GT_HALF - 1u)) + cb;
-#pragma unroll
-    for (int w = 0; w < 7; w++) { u[w] = (u[w] >> GT_WB) | (u[w + 1] << (32 - GT_WB)); v[w] = (v[w] >> GT_WB) | (v[w + 1] << (32 - GT_WB)); }
-    u[7] >>= GT_WB; v[7] >>= GT_WB;
-    // digit in (-2^12, 2^12]: above the half, take d - 2^13 and carry (2^13 itself becomes digit 0 with a carry)
-    const bool na = da > GT_HALF, nb = db > GT_HALF;
-    ca = na ? 1u : 0u; cb = nb ? 1u : 0u;
-    if (na) da = 2u * GT_HALF - da;
-    if (nb) db = 2u * GT_HALF - db;
-    if (da) {
-      gt_load(&e, tab_a + ((size_t)j * GT_ENTRIES + da) * 12);
-      if (na) fq12_conj(&e, &e);                      // unitary: inverse = conjugate
-      fq12_mul(&acc, &acc, &e);
-    }
-    if (db) {
-      gt_load(&e, tab_b + ((size_t)j * GT_ENTRIES + db) * 12);
-      if (nb) fq12_conj(&e, &e);
-      fq12_mul(&acc, &acc, &e);
-    }
-  }
+  gt_table_exp(&acc, tab_a, ga, u);
+  gt_table_exp(&acc, tab_b, gb, v);
   if (live) gt_serialize(gt_out + (size_t)96 * i, &acc);
 }
 

@@ -19,17 +19,19 @@ keaki_status pairing_raw_fixed_run(keaki_hip_ctx* ctx, const void* d_g1, size_t 
   hipLaunchKernelGGL(k_pairing_raw_fixed, dim3(cdiv(2 * n, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_g1, (u32)n, (const Line*)d_lines, (Fq*)d_out);
   return launch_check(ctx, "pairing_raw_fixed");
 }
-size_t gt_table_bytes() { return (size_t)GT_WINDOWS * GT_ENTRIES * 12 * sizeof(Fq); }
-// d_table[j][d] = base^(d 2^(13j)), d = 1..4096; d_base: 12 Fq
-keaki_status gt_table_run(keaki_hip_ctx* ctx, const void* d_base, void* d_table) {
-  hipLaunchKernelGGL(k_gt_table_bases, dim3(1), dim3(64), 0, ctx->stream, (const Fq*)d_base, (Fq*)d_table);
-  for (u32 L = 1; L + 2 <= GT_WB; L++)
-    hipLaunchKernelGGL(k_gt_table_fill, dim3(cdiv(2 * GT_WINDOWS * ((1u << L) - 1u), 64)), dim3(64), 0, ctx->stream, (Fq*)d_table, L);
+size_t gt_table_bytes(uint32_t wb) { GtShape g = gt_shape(wb); return (size_t)g.windows * g.entries * 12 * sizeof(Fq); }
+// d_table[j][d] = base^(d 2^(wb j)), d = 1 .. 2^(wb-1); d_base: 12 Fq
+keaki_status gt_table_run(keaki_hip_ctx* ctx, const void* d_base, void* d_table, uint32_t wb) {
+  const GtShape g = gt_shape(wb);
+  hipLaunchKernelGGL(k_gt_table_bases, dim3(1), dim3(64), 0, ctx->stream, (const Fq*)d_base, (Fq*)d_table, g);
+  for (u32 L = 1; L + 2 <= g.wb; L++)
+    hipLaunchKernelGGL(k_gt_table_fill, dim3(cdiv(2 * g.windows * ((1u << L) - 1u), 64)), dim3(64), 0, ctx->stream, (Fq*)d_table, L, g);
   return launch_check(ctx, "gt_table");
 }
-keaki_status gt_encap_exp_run(keaki_hip_ctx* ctx, const void* d_tab_a, const void* d_tab_b, const void* d_betas, const void* d_rs, size_t n, void* d_gt) {
-  hipLaunchKernelGGL(k_gt_encap_exp, dim3(cdiv(2 * n, 64)), dim3(64), 0, ctx->stream, (const Fq*)d_tab_a, (const Fq*)d_tab_b, (const Fr*)d_betas,
-                     (const Fr*)d_rs, (u32)n, (u32*)d_gt);
+keaki_status gt_encap_exp_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t wb_a, const void* d_tab_b, uint32_t wb_b, const void* d_betas,
+                              const void* d_rs, size_t n, void* d_gt) {
+  hipLaunchKernelGGL(k_gt_encap_exp, dim3(cdiv(2 * n, 64)), dim3(64), 0, ctx->stream, (const Fq*)d_tab_a, gt_shape(wb_a), (const Fq*)d_tab_b, gt_shape(wb_b),
+                     (const Fr*)d_betas, (const Fr*)d_rs, (u32)n, (u32*)d_gt);
   return launch_check(ctx, "gt_encap_exp");
 }
 keaki_status miller_only_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, size_t n, void* d_out) {
