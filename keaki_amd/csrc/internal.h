@@ -104,6 +104,7 @@ keaki_status open_fk_poly_run(keaki_hip_ctx* ctx, const void* d_srs, void** hat_
 keaki_status fk_hat_s_run(keaki_hip_ctx* ctx, const void* d_srs, uint32_t log2d, const void* d_tw2d, void* d_hat_s);
 keaki_status open_fk_run(keaki_hip_ctx* ctx, const void* d_hat_s, uint32_t log2d, const void* d_hat_a, const void* d_tw2d_inv, const void* d_twd,
                          void* d_work, void* d_proofs_aff);
+keaki_status selftest_u29_run(keaki_hip_ctx* ctx, uint32_t blocks, uint32_t iters, uint32_t seed, void* d_mismatches);
 keaki_status selftest_field_run(keaki_hip_ctx* ctx, uint32_t blocks, uint32_t iters, uint32_t seed, void* d_mismatches);
 
 }  // namespace keaki_internal
