@@ -219,16 +219,24 @@ static KTOWER void fq12_cyc_sqr(Fq12* r, const Fq12* a) {
   r->c0.c1 = fq2_dbl(t2 - r4) + t2;
   r->c1.c2 = fq2_dbl(t3 + r5) + t3;
 }
-// f^(-z): signed-digit (NAF) square-and-multiply with cyclotomic squarings -- on the cyclotomic subgroup the
-// inverse is the conjugate, so a -1 digit costs the same as a +1 digit and the NAF has fewer non-zeros than z.
+// f^(-z): width-3 NAF square-and-multiply with cyclotomic squarings -- on the cyclotomic subgroup the inverse is the conjugate, so
+// negative digits are free; digits +-1, +-3 need f and f^3 (one cyclotomic squaring + one product up front) and leave 17 products in
+// the loop instead of the 23 of the plain NAF (z has 28 one bits).
 static KTOWER void fq12_exp_by_neg_z(Fq12* r, const Fq12* f) {
-  Fq12 acc = *f, fc;
-  fq12_conj(&fc, f);
+  Fq12 f3, acc, t;
+  fq12_cyc_sqr(&t, f);
+  fq12_mul(&f3, &t, f);
+  const int top = Z_WNAF3[Z_WNAF3_LEN - 1];      // +1 or +3
+  acc = top == 3 ? f3 : *f;
 #pragma unroll 1
-  for (int i = Z_NAF_LEN - 2; i >= 0; i--) {  // top digit is +1: acc = f
+  for (int i = Z_WNAF3_LEN - 2; i >= 0; i--) {
     fq12_cyc_sqr(&acc, &acc);
-    int d = Z_NAF[i];
-    if (d != 0) fq12_mul(&acc, &acc, d > 0 ? f : &fc);
+    const int d = Z_WNAF3[i];
+    if (d != 0) {
+      t = (d == 3 || d == -3) ? f3 : *f;
+      if (d < 0) fq12_conj(&t, &t);
+      fq12_mul(&acc, &acc, &t);
+    }
   }
   fq12_conj(r, &acc);
 }
