@@ -105,6 +105,9 @@ keaki_status keaki_hip_open_fk(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32
  * caller passes only omega_2d (the order-2d root of ark-poly's Radix2EvaluationDomain), its inverse and (2d)^-1. */
 keaki_status keaki_hip_open_fk_poly(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32_t log2d, const uint64_t* coeffs, const uint64_t* omega_2d,
                                     const uint64_t* omega_2d_inv, const uint64_t* inv_2d, uint64_t* proofs_out_aff);
+/* Optional, setup time: tabulate hat_s = DFT_2d of the reversed SRS (src/kzg.rs:166-179) for the domain size d = 2^log2d, so that the
+ * first keaki_hip_open_fk[_poly] with this d does not pay for it (it depends on the SRS only; the calls cache it on first use anyway). */
+keaki_status keaki_hip_srs_g1_precompute_fk(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32_t log2d, const uint64_t* omega_2d);
 /* Scalar-field DFT on the device: replaces ark-poly `domain.fft` / `domain.ifft` over Fr (src/vec.rs:36-37, src/kzg.rs:185).
  * data: n = 2^log2n Fr, transformed in place: out[j] = sum_i in[i] omega^(ij), then multiplied by *scale_or_null if given
  * (pass omega^-1 and n^-1 for the inverse transform). */

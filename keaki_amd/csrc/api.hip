@@ -533,6 +533,17 @@ keaki_status keaki_hip_open_fk_poly(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, u
   ST_TRY(open_fk_poly_run(ctx, srs->d, &srs->fk_hat_s, &srs->fk_log2d, log2d, b + o_p, omega_2d, omega_2d_inv, inv_2d, b + o_fr, b + o_g, b + o_out));
   return download(ctx, proofs_out_aff, b + o_out, d * 64);
 }
+// hat_s = DFT_2d(reversed SRS) for later open_fk calls with this d: setup-time work (the FK23 analogue of keaki_hip_srs_g1_precompute)
+keaki_status keaki_hip_srs_g1_precompute_fk(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32_t log2d, const uint64_t* omega_2d) {
+  CTX_GUARD(ctx);
+  if (!srs || !omega_2d || log2d > 27) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g1_precompute_fk: bad argument");
+  const size_t d = (size_t)1 << log2d;
+  if (d > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "open_fk: %zu coefficients but the SRS holds %zu points", d, srs->n);
+  ST_TRY(reserve(ctx, ctx->io_d, d * 32));
+  ST_TRY(fk_precompute_run(ctx, srs->d, &srs->fk_hat_s, &srs->fk_log2d, log2d, omega_2d, ctx->io_d.p));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // setup-time call: return when the table exists
+  return KEAKI_OK;
+}
 // In-place scalar-field DFT of n = 2^log2n elements with the order-n root `omega`, then an optional scaling (the 1/n of an inverse transform).
 keaki_status keaki_hip_fr_fft(keaki_hip_ctx* ctx, uint64_t* data, uint32_t log2n, const uint64_t* omega, const uint64_t* scale_or_null) {
   CTX_GUARD(ctx);

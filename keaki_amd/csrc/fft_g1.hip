@@ -239,6 +239,21 @@ keaki_status open_fk_poly_run(keaki_hip_ctx* ctx, const void* d_srs, void** hat_
   return open_fk_run(ctx, *hat_s_cache, log2d, hat_a, twi, twd, d_g_work, d_proofs_aff);
 }
 
+// hat_s = DFT_2d(reversed SRS) ahead of time (it depends on the SRS and d only): setup-time work like the MSM window tables
+keaki_status fk_precompute_run(keaki_hip_ctx* ctx, const void* d_srs, void** hat_s_cache, int* hat_s_log2d, u32 log2d, const uint64_t* omega_2d,
+                               void* d_tw_work) {
+  const u32 d = 1u << log2d;
+  if (*hat_s_log2d == (int)log2d) return KEAKI_OK;
+  Fr w;
+  memcpy(&w, omega_2d, 32);
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(k_fr_powers, dim3(cdiv(d, 256)), dim3(256), 0, st, w, d, (Fr*)d_tw_work);
+  if (*hat_s_cache) { HIP_TRY(ctx, hipStreamSynchronize(st)); (void)hipFree(*hat_s_cache); *hat_s_cache = nullptr; *hat_s_log2d = -1; }
+  HIP_TRY(ctx, hipMalloc(hat_s_cache, 2 * (size_t)d * sizeof(G1Jac)));
+  ST_TRY(fk_hat_s_run(ctx, d_srs, log2d, d_tw_work, *hat_s_cache));
+  *hat_s_log2d = (int)log2d;
+  return KEAKI_OK;
+}
 
 // d_c: n coefficients (Fr). d_q: n - 1 quotient coefficients out (n >= 1; n == 1: nothing written). d_value: p(z) out (1 Fr).
 // d_work: room for 2 * (n / 255 + 8) + 8 Fr.

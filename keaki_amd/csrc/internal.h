@@ -101,6 +101,8 @@ keaki_status fr_fft_run(keaki_hip_ctx* ctx, void* d_data, uint32_t log2n, const 
 keaki_status open_fk_poly_run(keaki_hip_ctx* ctx, const void* d_srs, void** hat_s_cache, int* hat_s_log2d, uint32_t log2d, const void* d_p,
                               const uint64_t* omega_2d, const uint64_t* omega_2d_inv, const uint64_t* inv_2d, void* d_fr_work, void* d_g_work,
                               void* d_proofs_aff);
+keaki_status fk_precompute_run(keaki_hip_ctx* ctx, const void* d_srs, void** hat_s_cache, int* hat_s_log2d, uint32_t log2d, const uint64_t* omega_2d,
+                               void* d_tw_work);
 keaki_status fk_hat_s_run(keaki_hip_ctx* ctx, const void* d_srs, uint32_t log2d, const void* d_tw2d, void* d_hat_s);
 keaki_status open_fk_run(keaki_hip_ctx* ctx, const void* d_hat_s, uint32_t log2d, const void* d_hat_a, const void* d_tw2d_inv, const void* d_twd,
                          void* d_work, void* d_proofs_aff);

@@ -23,7 +23,7 @@ EXPORTS = [
     "keaki_hip_g1_mul_batch", "keaki_hip_g2_mul_batch", "keaki_hip_g1_mul_batch_dev", "keaki_hip_g2_mul_batch_dev",
     "keaki_hip_pairing_batch", "keaki_hip_pairing_batch_dev",
     "keaki_hip_encap_batch", "keaki_hip_encap_batch_dev", "keaki_hip_decap_batch", "keaki_hip_decap_batch_dev",
-    "keaki_hip_selftest_field", "keaki_hip_open_fk", "keaki_hip_open_fk_poly", "keaki_hip_fr_fft", "keaki_hip_srs_g1_check", "keaki_hip_g2_check", "keaki_hip_kzg_open", "keaki_hip_final_exp_batch", "keaki_hip_miller_loop_batch", "keaki_hip_g2_prepare", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
+    "keaki_hip_selftest_field", "keaki_hip_open_fk", "keaki_hip_open_fk_poly", "keaki_hip_srs_g1_precompute_fk", "keaki_hip_fr_fft", "keaki_hip_srs_g1_check", "keaki_hip_g2_check", "keaki_hip_kzg_open", "keaki_hip_final_exp_batch", "keaki_hip_miller_loop_batch", "keaki_hip_g2_prepare", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
 ]
 
 KEAKI_ERR_TOO_LARGE = -5
@@ -81,6 +81,7 @@ def load_library():
         lib.keaki_hip_open_fk.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp, vp]
         lib.keaki_hip_open_fk_poly.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp, vp]
         lib.keaki_hip_fr_fft.argtypes = [vp, vp, C.c_uint32, vp, vp]
+        lib.keaki_hip_srs_g1_precompute_fk.argtypes = [vp, vp, C.c_uint32, vp]
         lib.keaki_hip_srs_g1_check.argtypes = [vp, vp, vp, vp]
         lib.keaki_hip_kzg_open.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp]
         lib.keaki_hip_g2_check.argtypes = [vp, vp, C.c_size_t, vp, vp]

@@ -204,6 +204,14 @@ Result<bool> verify(const KZGSetup& setup, const G1& commitment, const Fr& point
   return Result<bool>::Ok(memcmp(gt, gt + 384, 384) == 0);
 }
 
+void precompute_open_fk(const KZGSetup& setup, size_t d) {
+  if (d < 1 || (d & (d - 1)) != 0 || d > setup.g1_pow().size()) return;   // open_fk falls back to per-point openings for such shapes
+  unsigned log2d = 0;
+  while ((size_t(1) << log2d) < d) log2d++;
+  vec::Radix2Domain d2 = vec::Radix2Domain::create(2 * d);
+  setup.device()->check(keaki_hip_srs_g1_precompute_fk(setup.device()->ctx(), setup.srs(), log2d, d2.group_gen.l));
+}
+
 Result<std::vector<G1>> open_fk(const KZGSetup& setup, const std::vector<Fr>& p, size_t domain_size) {
   const size_t d = p.size();
   const bool pow2 = d >= 1 && (d & (d - 1)) == 0;

@@ -131,6 +131,8 @@ Result<bool> verify(const KZGSetup& setup, const G1& commitment, const Fr& point
 // all openings at the roots of unity of a size-d domain (src/kzg.rs:157-203): FK23 -- three G1 FFTs + 2d scalar-mults on
 // the GPU (keaki_hip_open_fk) when p.size() == domain_size is a power of two; per-point `open` otherwise.
 Result<std::vector<G1>> open_fk(const KZGSetup& setup, const std::vector<Fr>& p, size_t domain_size);
+// setup-time: tabulate the SRS-only part of open_fk (hat_s) for power-of-two domain size d, so the first open_fk does not pay for it
+void precompute_open_fk(const KZGSetup& setup, size_t domain_size);
 
 }  // namespace kzg
 

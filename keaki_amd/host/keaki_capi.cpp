@@ -178,6 +178,9 @@ int keaki_host_verify(void* s, const uint64_t* com, const uint64_t* point, const
     *out_ok = r.value ? 1 : 0; return 0;
   });
 }
+int keaki_host_precompute_open_fk(void* s, size_t domain_size) {
+  return guard([&] { kzg::precompute_open_fk(((Setup*)s)->s, domain_size); return 0; });
+}
 int keaki_host_open_fk(void* s, const uint64_t* coeffs, size_t n, size_t domain_size, uint64_t* out_g1s, uint64_t* err_out) {
   return guard([&] {
     auto r = kzg::open_fk(((Setup*)s)->s, frs_of(coeffs, n), domain_size);

@@ -244,6 +244,11 @@ def verify(setup: KZGSetup, commitment, point, value, proof) -> bool:
     return bool(ok.value)
 
 
+def precompute_open_fk(setup: "KZGSetup", domain_size: int) -> None:
+    """setup-time: the SRS-only transform of FK23 (hat_s) for this domain size"""
+    _ck(_lib().keaki_host_precompute_open_fk(setup.h, C.c_size_t(domain_size)))
+
+
 def open_fk(setup: KZGSetup, p, domain_size: int) -> np.ndarray:
     c = _u64(p, 4); size = _lib().keaki_host_domain(domain_size, None)
     out = np.zeros((size, 8), np.uint64); err = np.zeros(2, np.uint64)

@@ -35,6 +35,7 @@ def main():
     while setup_degree < n + K.PADDING_LEN:
         setup_degree <<= 1
     s = K.KZGSetup.setup(rng.fr_rand(), setup_degree)      # SETUP_DEGREE: the domain of n+1 evaluations
+    K.precompute_open_fk(s, setup_degree)                  # SRS-only part of the FK23 openings, like the MSM window tables
     t_setup = time.time() - t0
     np_rng = np.random.default_rng(7)
     bits = np_rng.integers(0, 2, n)

@@ -218,6 +218,12 @@ def test_open_fk_gpu_vs_oracle_and_per_point_open(K, oc, py):
     for i in (0, 1, 2, 31, 32, 63):
         assert np.array_equal(proofs[i], K.open(s, p64, el[i]))
         assert K.verify(s, com, el[i], K.poly_evaluate(p64, el[i]), proofs[i])
+    # setup-time precomputation of the SRS-only transform gives the same proofs (and another domain size afterwards still works)
+    s2 = K.KZGSetup.setup(secret, 64)
+    K.precompute_open_fk(s2, 64)
+    assert np.array_equal(K.open_fk(s2, p64, 64), proofs)
+    assert np.array_equal(K.open_fk(s2, p8, 8), K.open_fk(s, p8, 8))
+    K.precompute_open_fk(s2, 48)          # not a power of two: ignored, open_fk falls back to per-point openings there
     # d = 1 and d = 2 corner shapes
     assert np.array_equal(K.open_fk(s, p64[:1], 1)[0], K.open(s, p64[:1], K.domain_elements(1)[0]))
     pr2 = K.open_fk(s, p64[:2], 2)
