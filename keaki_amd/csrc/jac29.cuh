@@ -1,6 +1,7 @@
 // Jacobian scalar multiplication of BN254 G1 points in the 9 x 29-bit lazy representation (fq29.cuh): the inner loop of the FK23
 // butterflies (fft_g1.hip; reference src/kzg.rs:182-200 = ark-poly group FFTs, every butterfly one `Group * ScalarField`).
-// Left-to-right NAF (digit_i = bit_(i+1)(3k) - bit_(i+1)(k): ~85 additions for 254 doublings, no table), doubling dbl-2009-l with
+// GLV split k = k1 + k2 lambda (128-bit halves, phi(P) = (beta X, Y, Z) costs one product), two interleaved left-to-right NAFs
+// (digit_i = bit_(i+1)(3k) - bit_(i+1)(k): ~86 additions for 129 doublings, no table), doubling dbl-2009-l with
 // D = 4 X Y^2 taken as a product (keeps every value small), addition add-2007-bl with the addend's Z^2, Z^3 precomputed.
 // Value bounds (multiples of p) on the running point: X < 17.6, Y < 19.3, Z < 3.4; the addend is below 1.2 (u29_from_fq). A limb-exact
 // model with 64-bit overflow assertions ran full 254-bit multiplications before this was written; test: k_selftest_j29 and the
@@ -66,17 +67,94 @@ KDEV J29 j29_add(const J29& a, const U29& X2, const U29& Y2, const U29& Z2, cons
   return r;
 }
 
-// k * P, P Jacobian (saturated, any Z), k a Montgomery Fr below r. P of prime order or infinity.
-KDEV Jac<Fq> jac_scalar_mul_u29(const Jac<Fq>& p, const Fr& k_mont) {
-  if (jac_is_inf(p)) return jac_inf<Fq>();
-  u32 k[8], h[8];
-  fp_from_mont<FrParams>(k, k_mont);
-  {  // h = 3 k (< 2^256)
+// ---- GLV: k = k1 + k2 lambda (mod r), |k1|, |k2| < 2^127, phi(x, y) = (beta x, y) = lambda (x, y) ------------------------------
+// Babai rounding on the short basis (a1, b1), (a2, b2): c_i = (k g_i) >> 256, k1 = k - c1 a1 - c2 a2, k2 = -c1 b1 - c2 b2, all computed
+// modulo 2^160 (the results fit 128 signed bits). out: magnitudes (5 words, top word 0) and signs.
+KDEV void glv_mul_acc(u64* col, const u32* x, int xn, const u32* y, int yn) {   // col[i + j] += x[i] y[j], 32-bit columns with 64-bit sums (lazy carries)
+#pragma unroll
+  for (int i = 0; i < xn; i++)
+#pragma unroll
+    for (int j = 0; j < yn; j++) {
+      const u64 p = (u64)x[i] * y[j];
+      col[i + j] += (u32)p;
+      col[i + j + 1] += p >> 32;
+    }
+}
+KDEV void glv_decompose(const u32* k, u32* k1, bool& neg1, u32* k2, bool& neg2) {
+  u32 c1[3], c2[5];
+  {  // c1 = (k g1) >> 256  (< 2^65), c2 = (k g2) >> 256  (< 2^129)
+    u64 col[14];
+#pragma unroll
+    for (int i = 0; i < 14; i++) col[i] = 0;
+    glv_mul_acc(col, k, 8, GlvParams::G1, 3);
     u64 c = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) { c += 3ull * k[j]; h[j] = (u32)c; c >>= 32; }
+    for (int i = 0; i < 11; i++) { c += col[i]; if (i >= 8) c1[i - 8] = (u32)c; c >>= 32; }
+#pragma unroll
+    for (int i = 0; i < 14; i++) col[i] = 0;
+    glv_mul_acc(col, k, 8, GlvParams::G2, 5);
+    c = 0;
+#pragma unroll
+    for (int i = 0; i < 13; i++) { c += col[i]; if (i >= 8) c2[i - 8] = (u32)c; c >>= 32; }
+  }
+  // t = c1 a1 + c2 a2, s = c1 (-b1), u = c2 b2 (b2 = a1), each modulo 2^160
+  u32 t[5], s[5], uu[5];
+  {
+    u64 col[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) col[i] = 0;
+    glv_mul_acc(col, c1, 3, GlvParams::A1, 2);
+    glv_mul_acc(col, c2, 5, GlvParams::A2, 4);
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { c += col[i]; t[i] = (u32)c; c >>= 32; }
+#pragma unroll
+    for (int i = 0; i < 10; i++) col[i] = 0;
+    glv_mul_acc(col, c1, 3, GlvParams::NB1, 4);
+    c = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { c += col[i]; s[i] = (u32)c; c >>= 32; }
+#pragma unroll
+    for (int i = 0; i < 10; i++) col[i] = 0;
+    glv_mul_acc(col, c2, 5, GlvParams::A1, 2);
+    c = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { c += col[i]; uu[i] = (u32)c; c >>= 32; }
+  }
+  // k1 = k - t, k2 = s - u  (mod 2^160, two's complement), then sign / magnitude
+  long long b = 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) { long long d = (long long)k[i] - t[i] + b; k1[i] = (u32)d; b = d >> 32; }
+  b = 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) { long long d = (long long)s[i] - uu[i] + b; k2[i] = (u32)d; b = d >> 32; }
+  neg1 = (k1[4] >> 31) != 0;
+  neg2 = (k2[4] >> 31) != 0;
+  {
+    u64 c = neg1 ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { c += neg1 ? (u32)~k1[i] : k1[i]; k1[i] = (u32)c; c >>= 32; }
+    c = neg2 ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { c += neg2 ? (u32)~k2[i] : k2[i]; k2[i] = (u32)c; c >>= 32; }
+  }
+}
+
+// k * P, P Jacobian (saturated, any Z), k a Montgomery Fr below r. P of prime order or infinity.
+// GLV: k P = k1 P + k2 phi(P) with 128-bit k1, k2: 129 doublings and two interleaved NAFs (~86 additions) instead of 254 doublings + 85.
+KDEV Jac<Fq> jac_scalar_mul_u29(const Jac<Fq>& p, const Fr& k_mont) {
+  if (jac_is_inf(p)) return jac_inf<Fq>();
+  u32 k[8], k1[5], k2[5], h1[5], h2[5];
+  bool neg1, neg2;
+  fp_from_mont<FrParams>(k, k_mont);
+  glv_decompose(k, k1, neg1, k2, neg2);
+  {  // h = 3 k (< 2^130)
+    u64 c = 0, d = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) { c += 3ull * k1[j]; h1[j] = (u32)c; c >>= 32; d += 3ull * k2[j]; h2[j] = (u32)d; d >>= 32; }
   }
   const U29 X2 = u29_from_fq(p.x), Y2 = u29_from_fq(p.y), Z2 = u29_from_fq(p.z);
+  const U29 X2b = u29_mul(X2, u29_const(GlvParams::BETA29));          // phi(P) = (beta X, Y, Z)
   const U29 Z2Z2 = u29_sqr(Z2), Z2cu = u29_mul(Z2, Z2Z2);
   U29 zero;
 #pragma unroll
@@ -86,22 +164,30 @@ KDEV Jac<Fq> jac_scalar_mul_u29(const Jac<Fq>& p, const Fr& k_mont) {
   acc.x = X2; acc.y = Y2; acc.z = Z2;
   bool empty = true;
 #pragma unroll 1
-  for (int it = 0; it < 255; it++) {
-    const u32 hb = h[7] >> 31, kb = k[7] >> 31;
+  for (int it = 0; it < 130; it++) {            // NAF digit i = 129 - it: bit i + 1 of h minus bit i + 1 of k, words hold bits 0 .. 159
+    const int bit = 130 - it;                   // i + 1
+    const u32 w = (u32)bit >> 5, sft = (u32)bit & 31u;
+    u32 hb1 = 0, kb1 = 0, hb2 = 0, kb2 = 0;
 #pragma unroll
-    for (int j = 7; j > 0; j--) { h[j] = (h[j] << 1) | (h[j - 1] >> 31); k[j] = (k[j] << 1) | (k[j - 1] >> 31); }
-    h[0] <<= 1; k[0] <<= 1;
+    for (int j = 0; j < 5; j++) {
+      if (w == (u32)j) { hb1 = (h1[j] >> sft) & 1u; kb1 = (k1[j] >> sft) & 1u; hb2 = (h2[j] >> sft) & 1u; kb2 = (k2[j] >> sft) & 1u; }
+    }
     if (!empty) acc = j29_dbl(acc);
-    if (hb != kb) {
-      const bool neg = kb != 0;                         // digit = hb - kb
-      if (empty) {
-        acc.x = X2; acc.y = neg ? Y2n : Y2; acc.z = Z2;
-        empty = false;
-      } else {
-        int special;
-        acc = j29_add(acc, X2, neg ? Y2n : Y2, Z2, Z2Z2, Z2cu, special);
-        if (special == 1) acc = j29_dbl(acc);
-        if (special == 2) empty = true;
+#pragma unroll
+    for (int which = 0; which < 2; which++) {
+      const u32 hb = which ? hb2 : hb1, kb = which ? kb2 : kb1;
+      if (hb != kb) {
+        const bool neg = (kb != 0) != (which ? neg2 : neg1);          // digit sign times the sign of k_i
+        const U29& AX = which ? X2b : X2;
+        if (empty) {
+          acc.x = AX; acc.y = neg ? Y2n : Y2; acc.z = Z2;
+          empty = false;
+        } else {
+          int special;
+          acc = j29_add(acc, AX, neg ? Y2n : Y2, Z2, Z2Z2, Z2cu, special);
+          if (special == 1) acc = j29_dbl(acc);
+          if (special == 2) empty = true;
+        }
       }
     }
   }

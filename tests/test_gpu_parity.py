@@ -25,7 +25,10 @@ def make_points_g1(oc, hip, n, seed):
 
 def test_g1_mul_batch_vs_oracle(oc, py, hip, rand_fr):
     g1, _ = oc.generators()
-    ks = rand_fr(26, 11) + [0, 1, 2, 3, py.R - 1, py.R - 2, py.R - 3, (py.R - 1) // 2, (py.R + 1) // 2]   # r - 2: the NAF ladder ends in a doubling
+    lam = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd       # GLV eigenvalue: decompositions with k1 or k2 zero / tiny / negative
+    ks = rand_fr(40, 11) + [0, 1, 2, 3, py.R - 1, py.R - 2, py.R - 3, (py.R - 1) // 2, (py.R + 1) // 2,   # r - 2: the NAF ladder ends in a doubling
+                            lam, lam + 1, lam - 1, py.R - lam, 2 * lam % py.R, (lam * lam) % py.R, 1 << 127, (1 << 128) - 1, 1 << 128, (1 << 253) + 5,
+                            9931322734385697763, 147946756881789319010696353538189108491, 147946756881789319000765030803803410728]
     km = mont(oc, ks)
     got = hip.g1_mul_batch(g1, km)
     exp = oc.g1_mul_batch(g1, km)
