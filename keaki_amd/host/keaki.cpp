@@ -368,6 +368,23 @@ std::vector<enc::Ciphertext> vec_encrypt(Rng& rng, const kzg::KZGSetup& setup, c
   return out;
 }
 
+// The same two loops on contiguous buffers of n equal-length messages: identical draws and bytes, no per-item containers (what an FFI
+// caller with 2^20 items wants).
+void vec_encrypt_flat(Rng& rng, const kzg::KZGSetup& setup, const G1& com, const Fr* points, const Fr* values, const uint8_t* msgs, size_t n,
+                      size_t msg_len, uint64_t* ct_g2_out, uint8_t* ct_msg_out) {
+  if (!n) return;
+  std::vector<Fr> rs(n);
+  for (size_t i = 0; i < n; i++) rs[i] = fr_rand(rng);        // one r per item, in index order (src/vec.rs:63-66 -> src/kem.rs:26)
+  setup.device()->check(keaki_hip_encap_batch(setup.device()->ctx(), com.w.data(), setup.tau_g2().w.data(), points[0].l, values[0].l, rs[0].l, n,
+                                              ct_g2_out, nullptr, msg_len ? ct_msg_out : nullptr, msg_len));
+  for (size_t i = 0; i < n * msg_len; i++) ct_msg_out[i] ^= msgs[i];                                          // src/enc.rs:32-36
+}
+void vec_decrypt_flat(const kzg::KZGSetup& setup, const uint64_t* proofs, const uint64_t* ct_g2, const uint8_t* ct_msgs, size_t n, size_t msg_len,
+                      uint8_t* msgs_out) {
+  if (!n || !msg_len) return;
+  setup.device()->check(keaki_hip_decap_batch(setup.device()->ctx(), proofs, ct_g2, n, nullptr, msgs_out, msg_len));
+  for (size_t i = 0; i < n * msg_len; i++) msgs_out[i] ^= ct_msgs[i];                                         // src/enc.rs:48-52
+}
 std::vector<std::vector<uint8_t>> vec_decrypt(const kzg::KZGSetup& setup, const std::vector<G1>& proofs,
                                               const std::vector<const enc::Ciphertext*>& cts) {
   size_t n = cts.size();
@@ -377,8 +394,8 @@ std::vector<std::vector<uint8_t>> vec_decrypt(const kzg::KZGSetup& setup, const 
   for (auto* c : cts) max_len = std::max(max_len, c->second.size());
   std::vector<uint64_t> pr(8 * n), ct(16 * n);
   for (size_t i = 0; i < n; i++) { memcpy(&pr[8 * i], proofs[i].w.data(), 64); memcpy(&ct[16 * i], cts[i]->first.w.data(), 128); }
-  std::vector<uint8_t> key(n * std::max<size_t>(max_len, 1)), gt(n * 384);
-  setup.device()->check(keaki_hip_decap_batch(setup.device()->ctx(), pr.data(), ct.data(), n, gt.data(), key.data(), max_len));
+  std::vector<uint8_t> key(n * std::max<size_t>(max_len, 1));
+  setup.device()->check(keaki_hip_decap_batch(setup.device()->ctx(), pr.data(), ct.data(), n, nullptr, key.data(), max_len));   // keys only: no 384 B/item GT download
   for (size_t i = 0; i < n; i++) {
     out[i].resize(cts[i]->second.size());
     for (size_t j = 0; j < out[i].size(); j++) out[i][j] = key[i * max_len + j] ^ cts[i]->second[j];

@@ -165,6 +165,10 @@ std::pair<G1, std::vector<G1>> vec_commit(Rng& rng, const kzg::KZGSetup& setup, 
 std::vector<enc::Ciphertext> vec_encrypt(Rng& rng, const kzg::KZGSetup& setup, const G1& com, const std::vector<Fr>& points,
                                          const std::vector<Fr>& values, const std::vector<std::vector<uint8_t>>& messages);
 // src/vec.rs:72-81
+void vec_encrypt_flat(Rng& rng, const kzg::KZGSetup& setup, const G1& com, const Fr* points, const Fr* values, const uint8_t* msgs, size_t n,
+                      size_t msg_len, uint64_t* ct_g2_out, uint8_t* ct_msg_out);
+void vec_decrypt_flat(const kzg::KZGSetup& setup, const uint64_t* proofs, const uint64_t* ct_g2, const uint8_t* ct_msgs, size_t n, size_t msg_len,
+                      uint8_t* msgs_out);
 std::vector<std::vector<uint8_t>> vec_decrypt(const kzg::KZGSetup& setup, const std::vector<G1>& proofs,
                                               const std::vector<const enc::Ciphertext*>& cts);
 }  // namespace vec

@@ -235,25 +235,16 @@ int keaki_host_vec_commit(void* rng, void* s, const uint64_t* v, size_t n, uint6
 int keaki_host_vec_encrypt(void* rng, void* s, const uint64_t* com, const uint64_t* points, const uint64_t* values, const uint8_t* msgs,
                            size_t n, size_t msg_len, uint64_t* ct_g2_out, uint8_t* ct_msg_out) {
   return guard([&] {
-    std::vector<std::vector<uint8_t>> m(n);
-    for (size_t i = 0; i < n; i++) m[i].assign(msgs + i * msg_len, msgs + (i + 1) * msg_len);
-    auto c = vec::vec_encrypt(*(Rng*)rng, ((Setup*)s)->s, g1_of(com), frs_of(points, n), frs_of(values, n), m);
-    for (size_t i = 0; i < n; i++) { memcpy(ct_g2_out + 16 * i, c[i].first.w.data(), 128); if (msg_len) memcpy(ct_msg_out + i * msg_len, c[i].second.data(), msg_len); }
+    static_assert(sizeof(Fr) == 32, "Fr is four u64 limbs");
+    vec::vec_encrypt_flat(*(Rng*)rng, ((Setup*)s)->s, g1_of(com), reinterpret_cast<const Fr*>(points), reinterpret_cast<const Fr*>(values), msgs, n, msg_len,
+                          ct_g2_out, ct_msg_out);
     return 0;
   });
 }
 int keaki_host_vec_decrypt(void* s, const uint64_t* proofs, const uint64_t* ct_g2, const uint8_t* ct_msgs, size_t n, size_t msg_len,
                            uint8_t* msgs_out) {
   return guard([&] {
-    std::vector<enc::Ciphertext> cts(n);
-    std::vector<const enc::Ciphertext*> ptrs(n);
-    std::vector<G1> pr(n);
-    for (size_t i = 0; i < n; i++) {
-      cts[i] = {g2_of(ct_g2 + 16 * i), std::vector<uint8_t>(ct_msgs + i * msg_len, ct_msgs + (i + 1) * msg_len)};
-      ptrs[i] = &cts[i]; pr[i] = g1_of(proofs + 8 * i);
-    }
-    auto m = vec::vec_decrypt(((Setup*)s)->s, pr, ptrs);
-    for (size_t i = 0; i < n; i++) if (msg_len) memcpy(msgs_out + i * msg_len, m[i].data(), msg_len);
+    vec::vec_decrypt_flat(((Setup*)s)->s, proofs, ct_g2, ct_msgs, n, msg_len, msgs_out);
     return 0;
   });
 }
