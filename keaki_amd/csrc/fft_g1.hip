@@ -36,13 +36,19 @@ static __global__ void __launch_bounds__(256) k_bitrev_jac(G1Jac* __restrict__ a
   u32 r = __brev(i) >> (32 - log2n);
   if (i < r) { G1Jac t = a[i]; a[i] = a[r]; a[r] = t; }
 }
-// stage with butterfly span `len`: for block b and j < len/2: (u, v) = (a[i], w^j a[i + len/2]), w = omega^(n/len)
+// stage with butterfly span `len`: for block blk and j < len/2: (u, v) = (a[i], w^j a[i + len/2]), w = omega^(n/len).
+// Lane order: while a stage still has at least 64 blocks, consecutive lanes take the SAME j in different blocks, so a wave shares one
+// twiddle and the ladder's digit branches are wave-uniform (with one twiddle per lane every iteration of every wave pays for both
+// additions: 258 instead of ~86 per scalar multiplication). The last six stages have fewer blocks than a wave has lanes.
 static __global__ void __launch_bounds__(64) k_g1_fft_stage(G1Jac* __restrict__ a, const Fr* __restrict__ tw, u32 n, u32 len) {
   u32 b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n / 2) return;
-  u32 half = len >> 1;
-  u32 j = b % half, i0 = (b / half) * len + j, i1 = i0 + half;
-  Fr w = tw[(size_t)j * (n / len)];
+  const u32 half = len >> 1, nblocks = n / len;
+  u32 j, blk;
+  if (nblocks >= 64) { blk = b % nblocks; j = b / nblocks; }
+  else { j = b % half; blk = b / half; }
+  const u32 i0 = blk * len + j, i1 = i0 + half;
+  Fr w = tw[(size_t)j * nblocks];
   G1Jac u = a[i0], v = a[i1];
   if (!fr_is_one(w)) v = jac_scalar_mul(v, w);
   a[i0] = jac_add(u, v);
