@@ -1,7 +1,6 @@
 // Jacobian scalar multiplication of BN254 G1 points in the 9 x 29-bit lazy representation (fq29.cuh): the inner loop of the FK23
 // butterflies (fft_g1.hip; reference src/kzg.rs:182-200 = ark-poly group FFTs, every butterfly one `Group * ScalarField`).
-// GLV split k = k1 + k2 lambda (128-bit halves, phi(P) = (beta X, Y, Z) costs one product), two interleaved left-to-right NAFs
-// (digit_i = bit_(i+1)(3k) - bit_(i+1)(k): ~86 additions for 129 doublings, no table), doubling dbl-2009-l with
+// GLV split k = k1 + k2 lambda (128-bit halves, phi(P) = (beta X, Y, Z)), fixed signed 4-bit windows over one table of 8 multiples, doubling dbl-2009-l with
 // D = 4 X Y^2 taken as a product (keeps every value small), addition add-2007-bl with the addend's Z^2, Z^3 precomputed.
 // Value bounds (multiples of p) on the running point: X < 17.6, Y < 19.3, Z < 3.4; the addend is below 1.2 (u29_from_fq). A limb-exact
 // model with 64-bit overflow assertions ran full 254-bit multiplications before this was written; test: k_selftest_j29 and the
@@ -140,51 +139,89 @@ KDEV void glv_decompose(const u32* k, u32* k1, bool& neg1, u32* k2, bool& neg2) 
   }
 }
 
+// general Jacobian + Jacobian in the lazy arithmetic (the addend comes from a table: its Z^2, Z^3 are stored with it)
+struct J29T {            // table entry: multiple m P with everything an addition needs, and beta X for phi(m P)
+  U29 x, xb, y, z, zz, zcu;
+};
 // k * P, P Jacobian (saturated, any Z), k a Montgomery Fr below r. P of prime order or infinity.
-// GLV: k P = k1 P + k2 phi(P) with 128-bit k1, k2: 129 doublings and two interleaved NAFs (~86 additions) instead of 254 doublings + 85.
+// GLV split k = k1 + k2 lambda (128-bit halves), then fixed signed 4-bit windows on both halves over ONE table {1..8} P (phi of an entry
+// is the same entry with beta X): 33 windows x (4 doublings + 2 additions) = 129 doublings + 66 additions + 11 table operations. Every
+// lane of a wave does the same work whatever its scalar -- a NAF ladder with per-lane scalars executes its addition in nearly every
+// iteration (some lane always has a non-zero digit): 258 additions. The table lives in private memory (per-lane index).
 KDEV Jac<Fq> jac_scalar_mul_u29(const Jac<Fq>& p, const Fr& k_mont) {
   if (jac_is_inf(p)) return jac_inf<Fq>();
-  u32 k[8], k1[5], k2[5], h1[5], h2[5];
+  u32 k[8], k1[5], k2[5];
   bool neg1, neg2;
   fp_from_mont<FrParams>(k, k_mont);
   glv_decompose(k, k1, neg1, k2, neg2);
-  {  // h = 3 k (< 2^130)
-    u64 c = 0, d = 0;
-#pragma unroll
-    for (int j = 0; j < 5; j++) { c += 3ull * k1[j]; h1[j] = (u32)c; c >>= 32; d += 3ull * k2[j]; h2[j] = (u32)d; d >>= 32; }
+  // table T[m - 1] = m P, m = 1..8
+  J29T T[8];
+  const U29 beta = u29_const(GlvParams::BETA29);
+  {
+    J29 m1;
+    m1.x = u29_from_fq(p.x); m1.y = u29_from_fq(p.y); m1.z = u29_from_fq(p.z);
+    auto put = [&](int idx, const J29& q) {
+      T[idx].x = q.x; T[idx].y = q.y; T[idx].z = q.z;
+      T[idx].xb = u29_mul(q.x, beta);
+      T[idx].zz = u29_sqr(q.z);
+      T[idx].zcu = u29_mul(q.z, T[idx].zz);
+    };
+    put(0, m1);
+    int special;
+    const J29 m2 = j29_dbl(m1);                                                                put(1, m2);
+    const J29 m3 = j29_add(m2, T[0].x, T[0].y, T[0].z, T[0].zz, T[0].zcu, special);            put(2, m3);
+    const J29 m4 = j29_dbl(m2);                                                                put(3, m4);
+    const J29 m5 = j29_add(m4, T[0].x, T[0].y, T[0].z, T[0].zz, T[0].zcu, special);            put(4, m5);
+    const J29 m6 = j29_dbl(m3);                                                                put(5, m6);
+    const J29 m7 = j29_add(m6, T[0].x, T[0].y, T[0].z, T[0].zz, T[0].zcu, special);            put(6, m7);
+    const J29 m8 = j29_dbl(m4);                                                                put(7, m8);
   }
-  const U29 X2 = u29_from_fq(p.x), Y2 = u29_from_fq(p.y), Z2 = u29_from_fq(p.z);
-  const U29 X2b = u29_mul(X2, u29_const(GlvParams::BETA29));          // phi(P) = (beta X, Y, Z)
-  const U29 Z2Z2 = u29_sqr(Z2), Z2cu = u29_mul(Z2, Z2Z2);
   U29 zero;
 #pragma unroll
   for (int i = 0; i < 9; i++) zero.l[i] = 0;
-  const U29 Y2n = u29_sub(zero, Y2, Q29::K2);
+  // signed digits d_j in [-8, 8] of |k1|, |k2| (bits 4j .. 4j+3 plus carry), top down: j = 32 .. 0  (|k_i| < 2^127: digit 32 is the carry)
+  u32 dig1[5], dig2[5], car = 0;                // digits packed 8 per word as 4-bit magnitudes | sign flags kept apart
+  u32 sg1[2] = {0, 0}, sg2[2] = {0, 0};
+#pragma unroll
+  for (int w = 0; w < 5; w++) { dig1[w] = 0; dig2[w] = 0; }
+  car = 0;
+#pragma unroll 1
+  for (int j = 0; j < 33; j++) {
+    u32 d = ((j < 32) ? ((k1[j >> 3] >> ((j & 7) * 4)) & 15u) : 0u) + car;
+    car = d > 8u ? 1u : 0u;
+    const u32 mag = car ? 16u - d : d;
+    dig1[j >> 3] |= mag << ((j & 7) * 4);
+    sg1[j >> 5] |= car << (j & 31);
+  }
+  car = 0;
+#pragma unroll 1
+  for (int j = 0; j < 33; j++) {
+    u32 d = ((j < 32) ? ((k2[j >> 3] >> ((j & 7) * 4)) & 15u) : 0u) + car;
+    car = d > 8u ? 1u : 0u;
+    const u32 mag = car ? 16u - d : d;
+    dig2[j >> 3] |= mag << ((j & 7) * 4);
+    sg2[j >> 5] |= car << (j & 31);
+  }
   J29 acc;
-  acc.x = X2; acc.y = Y2; acc.z = Z2;
+  acc.x = zero; acc.y = zero; acc.z = zero;
   bool empty = true;
 #pragma unroll 1
-  for (int it = 0; it < 130; it++) {            // NAF digit i = 129 - it: bit i + 1 of h minus bit i + 1 of k, words hold bits 0 .. 159
-    const int bit = 130 - it;                   // i + 1
-    const u32 w = (u32)bit >> 5, sft = (u32)bit & 31u;
-    u32 hb1 = 0, kb1 = 0, hb2 = 0, kb2 = 0;
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      if (w == (u32)j) { hb1 = (h1[j] >> sft) & 1u; kb1 = (k1[j] >> sft) & 1u; hb2 = (h2[j] >> sft) & 1u; kb2 = (k2[j] >> sft) & 1u; }
-    }
-    if (!empty) acc = j29_dbl(acc);
-#pragma unroll
+  for (int j = 32; j >= 0; j--) {
+    if (!empty) { acc = j29_dbl(acc); acc = j29_dbl(acc); acc = j29_dbl(acc); acc = j29_dbl(acc); }
+#pragma unroll 1
     for (int which = 0; which < 2; which++) {
-      const u32 hb = which ? hb2 : hb1, kb = which ? kb2 : kb1;
-      if (hb != kb) {
-        const bool neg = (kb != 0) != (which ? neg2 : neg1);          // digit sign times the sign of k_i
-        const U29& AX = which ? X2b : X2;
+      const u32 mag = ((which ? dig2[j >> 3] : dig1[j >> 3]) >> ((j & 7) * 4)) & 15u;
+      if (mag) {
+        const bool neg = (((which ? sg2[j >> 5] : sg1[j >> 5]) >> (j & 31)) & 1u) != (which ? neg2 : neg1);
+        const J29T& e = T[mag - 1];
+        const U29 ex = which ? e.xb : e.x;
+        const U29 ey = neg ? u29_sub(zero, e.y, Q29::K32) : e.y;
         if (empty) {
-          acc.x = AX; acc.y = neg ? Y2n : Y2; acc.z = Z2;
+          acc.x = ex; acc.y = ey; acc.z = e.z;
           empty = false;
         } else {
           int special;
-          acc = j29_add(acc, AX, neg ? Y2n : Y2, Z2, Z2Z2, Z2cu, special);
+          acc = j29_add(acc, ex, ey, e.z, e.zz, e.zcu, special);
           if (special == 1) acc = j29_dbl(acc);
           if (special == 2) empty = true;
         }
