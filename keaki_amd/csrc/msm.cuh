@@ -19,6 +19,7 @@
 #include "bn254_curve.cuh"
 #include "fq29.cuh"
 #include "xyzz29.cuh"
+#include "jac29.cuh"
 
 namespace bn254 {
 
@@ -655,6 +656,52 @@ __global__ void __launch_bounds__(64) k_msm_build_tables(const Aff<F>* __restric
     for (u32 d = msm_width(s, w - 1); d > 0; d--) j = jac_dbl(j);
     p = jac_to_aff(j);
     table[(size_t)w * N + i] = p;
+  }
+}
+
+// G1 version of the table build in the 29-bit lazy arithmetic with ONE inversion per point instead of one per window: the lane keeps
+// the running Jacobian multiple (never renormalised), parks X and Y of every window in the table slot, keeps the W - 1 Z's in
+// registers, inverts their product once and walks back (the partial products of the Z's are recomputed: ~W^2/2 products, nothing
+// against the W - 1 Fermat ladders of ~380 products each that the generic kernel spends).
+constexpr u32 TABLE_MAX_W = 16;
+static __global__ void __launch_bounds__(64) k_msm_build_tables_g1(const Aff<Fq>* __restrict__ points, u32 N, MsmShape s, Aff<Fq>* __restrict__ table) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const Aff<Fq> p = points[i];
+  table[i] = p;
+  if (aff_is_inf(p)) {                             // every multiple of the identity is the identity
+    for (u32 w = 1; w < s.W; w++) table[(size_t)w * N + i] = p;
+    return;
+  }
+  J29 j;
+  j.x = u29_from_fq(p.x); j.y = u29_from_fq(p.y); j.z = u29_one();
+  U29 zs[TABLE_MAX_W];
+  U29 prod = u29_one();
+#pragma unroll 1
+  for (u32 w = 1; w < s.W; w++) {
+    for (u32 d = msm_width(s, w - 1); d > 0; d--) j = j29_dbl(j);
+    Aff<Fq> tmp = {u29_to_fq(j.x), u29_to_fq(j.y)};       // Jacobian X, Y parked in the slot
+    table[(size_t)w * N + i] = tmp;
+#pragma unroll
+    for (u32 k = 1; k < TABLE_MAX_W; k++) if (k == w) zs[k] = j.z;
+    prod = u29_mul(prod, j.z);
+  }
+  // 1 / (Z_1 ... Z_(W-1))
+  U29 tinv = u29_from_fq(fq_inv(u29_to_fq(prod)));
+#pragma unroll 1
+  for (u32 w = s.W - 1; w >= 1; w--) {
+    U29 pre = u29_one(), zw = u29_one();
+#pragma unroll
+    for (u32 k = 1; k < TABLE_MAX_W; k++) {
+      if (k < w) pre = u29_mul(pre, zs[k]);
+      if (k == w) zw = zs[k];
+    }
+    const U29 zinv = u29_mul(tinv, pre);            // 1 / Z_w
+    tinv = u29_mul(tinv, zw);                        // 1 / (Z_1 ... Z_(w-1))
+    const U29 zi2 = u29_sqr(zinv), zi3 = u29_mul(zi2, zinv);
+    const Aff<Fq> jxy = table[(size_t)w * N + i];
+    Aff<Fq> a = {u29_to_fq(u29_mul(u29_from_sat_shift5(jxy.x.l), zi2)), u29_to_fq(u29_mul(u29_from_sat_shift5(jxy.y.l), zi3))};
+    table[(size_t)w * N + i] = a;
   }
 }
 

@@ -164,6 +164,14 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
 template <class F>
 keaki_status msm_build_tables(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t N, int c_table, Aff<F>* d_table) {
   MsmPlan plan = msm_make_plan(N, c_table);
+  bool done = false;
+  if constexpr (std::is_same<F, Fq>::value) {
+    if (plan.s.W <= TABLE_MAX_W) {
+      hipLaunchKernelGGL(k_msm_build_tables_g1, dim3(cdiv(N, 64)), dim3(64), 0, ctx->stream, d_points, (u32)N, plan.s, d_table);
+      done = true;
+    }
+  }
+  if (!done)
   hipLaunchKernelGGL((k_msm_build_tables<F>), dim3(cdiv(N, 64)), dim3(64), 0, ctx->stream, d_points, (u32)N, plan.s, d_table);
   return launch_check(ctx, "msm_build_tables");
 }
