@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""G2 MSM timing (scope row K4): 2^k points generated on the device, scalars uniform. python bench_tools/bench_msm_g2.py 18"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import random_fr_limbs, SEED
+from keaki_amd.hip import KeakiHip
+hip = KeakiHip(0)
+P_MOD = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+mont = lambda v: [((v << 256) % P_MOD >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+G2 = ((10857046999023057135944570762232829481370756359578518086990519993285655852781, 11559732032986387107991004021392285783925812861821192530917403151452391805634), (8495653923123431417604973247489272438418190587263600148770280649306958101930, 4082367875863433681332203403145435568316851327593401208105741076214120093531))
+g2 = np.array(mont(G2[0][0]) + mont(G2[0][1]) + mont(G2[1][0]) + mont(G2[1][1]), np.uint64)
+for log2n in [int(x) for x in sys.argv[1:]] or [16, 18]:
+    n = 1 << log2n
+    pts = hip.g2_mul_batch(g2, random_fr_limbs(n, SEED + 1))
+    sc = random_fr_limbs(n, SEED + 2)
+    srs = hip.srs_g2_upload(pts)
+    hip.msm_g2(srs, sc)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        hip.msm_g2(srs, sc)
+    dt = (time.perf_counter() - t0) / 3
+    print("G2 MSM 2^%d: %.2f ms incl. %d MB scalar upload (%.2e scalar-mults/s)" % (log2n, dt * 1e3, n * 32 >> 20, n / dt), flush=True)
+    srs.free()
