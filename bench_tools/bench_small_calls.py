@@ -1,0 +1,13 @@
+import sys, time
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from keaki_amd import keaki as K
+rng = K.Rng(1)
+s = K.KZGSetup.setup(rng.fr_rand(), 1024)
+p = np.stack([rng.fr_rand() for _ in range(1000)])
+com = K.commit(s, p); z = rng.fr_rand(); pr = K.open(s, p, z); v = K.poly_evaluate(p, z)
+assert K.verify(s, com, z, v, pr)
+for name, fn in (("commit(1000)", lambda: K.commit(s, p)), ("open(1000)", lambda: K.open(s, p, z)), ("verify", lambda: K.verify(s, com, z, v, pr))):
+    fn(); t0 = time.perf_counter()
+    for _ in range(5): fn()
+    print(name, "%.2f ms" % ((time.perf_counter() - t0) / 5 * 1e3))

@@ -122,6 +122,15 @@ keaki_status keaki_hip_fr_fft(keaki_hip_ctx* ctx, uint64_t* data, uint32_t log2n
 keaki_status keaki_hip_kzg_open(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, const uint64_t* coeffs, size_t n, const uint64_t* point,
                                 uint64_t* proof_out_jac, uint64_t* value_out);
 
+/* ---- KZG `verify` in one call -------------------------------------------------------------------------------------
+ * Replaces the body of `verify` (reference src/kzg.rs:127-146): e(com - value g1, g2) == e(proof, [tau]_2 - point g2).
+ * Evaluated as e(com - value g1 + point proof, g2) == e(proof, [tau]_2): the same predicate by bilinearity, with both second
+ * slots fixed per setup, so no G2 arithmetic runs and both Miller loops read tabulated lines (the table of [tau]_2 is cached
+ * in the context until a different [tau]_2 is passed). com_aff, proof_aff: u64[8] affine G1 ((0,0) = identity);
+ * tau_g2_aff: u64[16]; point, value: u64[4] Fr. *ok_out = 1 when the equation holds, else 0. */
+keaki_status keaki_hip_kzg_verify(keaki_hip_ctx* ctx, const uint64_t* com_aff, const uint64_t* tau_g2_aff, const uint64_t* point,
+                                  const uint64_t* value, const uint64_t* proof_aff, int32_t* ok_out);
+
 /* ---- SRS ingest (scope row f-3) -----------------------------------------------------------------------------------------
  * The reference reads .ptau points with `deserialize_uncompressed_unchecked` (src/kzg/ptau.rs:266,314): no curve check at all.
  * A snarkjs .ptau stores coordinates as Montgomery limbs, which is this ABI's point layout, so sections 2 and 3 are uploaded

@@ -128,7 +128,7 @@ void keaki_hip_ctx_destroy(keaki_hip_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf* b : {&ctx->digits, &ctx->hist, &ctx->offsets, &ctx->cursor, &ctx->sorted, &ctx->buckets, &ctx->partials, &ctx->wsums,
                     &ctx->bsums, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->io_a, &ctx->io_b, &ctx->io_c, &ctx->io_d, &ctx->io_e,
-                    &ctx->fb_scalars, &ctx->fb_g1_gen, &ctx->fb_g2_gen, &ctx->fb_com, &ctx->fb_tau, &ctx->perm, &ctx->g2gen_lines, &ctx->gt_tab_a, &ctx->gt_tab_b, &ctx->gt_base, &ctx->heavy})
+                    &ctx->fb_scalars, &ctx->fb_g1_gen, &ctx->fb_g2_gen, &ctx->fb_com, &ctx->fb_tau, &ctx->perm, &ctx->g2gen_lines, &ctx->gt_tab_a, &ctx->gt_tab_b, &ctx->gt_base, &ctx->heavy, &ctx->verify_lines, &ctx->verify_io})
     if (b->p) (void)hipFree(b->p);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -608,6 +608,44 @@ keaki_status keaki_hip_kzg_open(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs,
   ST_TRY(download(ctx, proof_out_jac, ctx->io_b.p, 96));
   if (value_out) ST_TRY(download(ctx, value_out, b + o_v, 32));
   resolve_timing(ctx);
+  return KEAKI_OK;
+}
+
+// ---- KZG verify -----------------------------------------------------------------------------------------------------
+keaki_status keaki_hip_kzg_verify(keaki_hip_ctx* ctx, const uint64_t* com_aff, const uint64_t* tau_g2_aff, const uint64_t* point,
+                                  const uint64_t* value, const uint64_t* proof_aff, int32_t* ok_out) {
+  CTX_GUARD(ctx);
+  if (!com_aff || !tau_g2_aff || !point || !value || !proof_aff || !ok_out) return fail(ctx, KEAKI_ERR_BAD_ARG, "kzg_verify: null pointer");
+  // io block: [g2 128 | tau_g2 128 | com 64 | proof 64 | value 32 | point 32 | pairing inputs 128 | gt 768]
+  constexpr size_t O_Q = 0, O_IN = 256, O_P = O_IN + 192, O_GT = O_P + 128, IO_BYTES = O_GT + 768;
+  const size_t LB = g2_prepared_bytes();
+  if (!ctx->verify_lines.p) {
+    ST_TRY(reserve(ctx, ctx->verify_lines, 2 * LB));
+    ST_TRY(reserve(ctx, ctx->verify_io, IO_BYTES));
+    ST_TRY(g2_generator_to(ctx, (char*)ctx->verify_io.p + O_Q));
+    ST_TRY(g2_prepare_run(ctx, (char*)ctx->verify_io.p + O_Q, ctx->verify_lines.p));
+    ctx->verify_tau_valid = false;
+  }
+  char* io = (char*)ctx->verify_io.p;
+  if (!ctx->verify_tau_valid || memcmp(ctx->verify_tau_pt, tau_g2_aff, 128) != 0) {
+    ctx->verify_tau_valid = false;
+    HIP_TRY(ctx, hipMemcpyAsync(io + O_Q + 128, tau_g2_aff, 128, hipMemcpyHostToDevice, ctx->stream));
+    ST_TRY(g2_prepare_run(ctx, io + O_Q + 128, (char*)ctx->verify_lines.p + LB));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                              // tau_g2_aff is the caller's memory
+    memcpy(ctx->verify_tau_pt, tau_g2_aff, 128);
+    ctx->verify_tau_valid = true;
+  }
+  uint64_t in[24];
+  memcpy(in, com_aff, 64);
+  memcpy(in + 8, proof_aff, 64);
+  memcpy(in + 16, value, 32);
+  memcpy(in + 20, point, 32);
+  HIP_TRY(ctx, hipMemcpyAsync(io + O_IN, in, 192, hipMemcpyHostToDevice, ctx->stream));
+  ST_TRY(verify_combine_run(ctx, io + O_IN, io + O_IN + 64, io + O_IN + 128, io + O_IN + 160, io + O_P));
+  ST_TRY(pairing_run(ctx, io + O_P, io + O_Q, 1, 2, io + O_GT, ctx->verify_lines.p, g2_prepared_lines()));
+  uint8_t gt[768];
+  ST_TRY(download(ctx, gt, io + O_GT, 768));                                       // synchronises: `in` stays alive until here
+  *ok_out = memcmp(gt, gt + 384, 384) == 0 ? 1 : 0;
   return KEAKI_OK;
 }
 

@@ -59,6 +59,28 @@ static __global__ void __launch_bounds__(64) k_encap_g1(const G1Aff* __restrict_
   G1Aff cb = jac_to_aff(jac_add_mixed(t, *com));
   out[i] = jac_to_aff(scalar_mul(cb, rs[i]));
 }
+// kzg verify, G1 side: out2 = [com - value g1 + point proof, proof]   (affine). src/kzg.rs:135-143 checks
+//   e(com - value g1, g2) == e(proof, [tau]_2 - point g2); moving point * proof across by bilinearity gives
+//   e(com - value g1 + point proof, g2) == e(proof, [tau]_2), the same predicate with both second slots FIXED per setup.
+// lanes 0 and 1 run the two scalar mults in lockstep (same ladder, different base and scalar); lane 0 combines.
+static __global__ void __launch_bounds__(64) k_verify_combine(const G1Aff* __restrict__ com, const G1Aff* __restrict__ proof,
+                                                       const Fr* __restrict__ value, const Fr* __restrict__ point, G1Aff* __restrict__ out2) {
+  __shared__ G1Jac sh;
+  const u32 t = threadIdx.x;
+  if (t >= 2) return;
+  G1Aff g = {G1_GEN_X, G1_GEN_Y};
+  G1Aff base = t == 0 ? g : *proof;
+  Fr k = t == 0 ? *value : *point;
+  G1Jac m = scalar_mul(base, k);
+  if (t == 0) m.y = -m.y;
+  if (t == 1) sh = m;
+  __syncthreads();
+  if (t == 0) {
+    m = jac_add(m, sh);
+    out2[0] = jac_to_aff(jac_add_mixed(m, *com));
+    out2[1] = *proof;
+  }
+}
 // encapsulate, G2 side (src/kem.rs:36-37): ct[i] = r[i] * (tau_g2 - points[i] * g2)   (affine)
 static __global__ void __launch_bounds__(64) k_encap_g2(const G2Aff* __restrict__ tau_g2, const Fr* __restrict__ points, const Fr* __restrict__ rs,
                                                  u32 n, G2Aff* __restrict__ out) {

@@ -13,6 +13,11 @@ keaki_status encap_g1_run(keaki_hip_ctx* ctx, const void* d_com, const void* d_v
                      (G1Aff*)d_out);
   return launch_check(ctx, "encap_g1");
 }
+keaki_status verify_combine_run(keaki_hip_ctx* ctx, const void* d_com, const void* d_proof, const void* d_value, const void* d_point, void* d_out2) {
+  hipLaunchKernelGGL(k_verify_combine, dim3(1), dim3(64), 0, ctx->stream, (const G1Aff*)d_com, (const G1Aff*)d_proof, (const Fr*)d_value,
+                     (const Fr*)d_point, (G1Aff*)d_out2);
+  return launch_check(ctx, "verify_combine");
+}
 keaki_status fb_table_scalars_run(keaki_hip_ctx* ctx, void* d_scalars, uint32_t wb) {
   const FbShape g = fb_shape(wb);
   hipLaunchKernelGGL(k_fb_table_scalars, dim3(cdiv(g.windows * g.entries, 256)), dim3(256), 0, ctx->stream, (Fr*)d_scalars, g);

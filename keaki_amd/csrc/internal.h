@@ -32,6 +32,9 @@ struct keaki_hip_ctx {
   keaki_internal::DevBuf fb_scalars, fb_g1_gen, fb_g2_gen, fb_com, fb_tau, perm, g2gen_lines, gt_tab_a, gt_tab_b, gt_base, heavy;
   bool gt_b_ready = false;
   bool gt_a_valid = false;
+  keaki_internal::DevBuf verify_lines, verify_io;   // kzg verify: [lines of g2 | lines of [tau]_2], small in/out block
+  bool verify_tau_valid = false;
+  uint64_t verify_tau_pt[16] = {};
   bool fb_tau_valid = false;          // window table of [tau]_2 (encap ciphertext side) is for this point
   uint64_t fb_tau_pt[16] = {};
   uint64_t gt_a_com[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // commitment the cached A-table belongs to
@@ -75,7 +78,10 @@ keaki_status g1_mul_batch_run(keaki_hip_ctx* ctx, const void* d_pts, int stride,
 keaki_status g2_mul_batch_run(keaki_hip_ctx* ctx, const void* d_pts, int stride, const void* d_scalars, size_t n, void* d_out);
 keaki_status encap_g1_run(keaki_hip_ctx* ctx, const void* d_com, const void* d_values, const void* d_r, size_t n, void* d_out);
 keaki_status encap_g2_run(keaki_hip_ctx* ctx, const void* d_tau_g2, const void* d_points, const void* d_r, size_t n, void* d_out);
-keaki_status pairing_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, int g2_stride, size_t n, void* d_gt, const void* d_fixed_lines = nullptr);
+keaki_status pairing_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, int g2_stride, size_t n, void* d_gt, const void* d_fixed_lines = nullptr,
+                         uint32_t lines_stride = 0);
+uint32_t g2_prepared_lines();                 // Line entries of one table
+keaki_status verify_combine_run(keaki_hip_ctx* ctx, const void* d_com, const void* d_proof, const void* d_value, const void* d_point, void* d_out2);
 size_t g2_prepared_bytes();
 keaki_status pairing_raw_fixed_run(keaki_hip_ctx* ctx, const void* d_g1, size_t n, const void* d_lines, void* d_out);
 size_t gt_table_bytes(uint32_t wb);

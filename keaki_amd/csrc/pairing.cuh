@@ -370,9 +370,10 @@ KDEV void gt_serialize(u32* out96, const Fq12* f) {
 }
 
 // gt_out[i] = serialize(e(P_i, Q_{i*stride})); identity in either slot -> one. TWO lanes per item.
-// fixed_lines != nullptr: every item pairs with the same Q whose lines were tabulated by k_g2_prepare (q_stride == 0).
+// fixed_lines != nullptr: the second slots are fixed points whose lines were tabulated by k_g2_prepare -- one table for every item
+// (lines_stride == 0, q_stride == 0) or table i * lines_stride for item i (kzg verify: g2 and [tau]_2).
 static __global__ void __launch_bounds__(64, 2) k_pairing_batch(const G1Aff* __restrict__ ps, const G2Aff* __restrict__ qs, int q_stride, u32 n,
-                                                      const Line* __restrict__ fixed_lines, u32* __restrict__ gt_out) {
+                                                      const Line* __restrict__ fixed_lines, u32 lines_stride, u32* __restrict__ gt_out) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 item = t >> 1;
   const bool live = item < n;
@@ -386,7 +387,7 @@ static __global__ void __launch_bounds__(64, 2) k_pairing_batch(const G1Aff* __r
   const bool ident = aff_is_inf(p) || qz != 0;
   // wave-uniform control flow: identity items run the same arithmetic (total on zeros) and discard it
   Fq12 f, e;
-  miller_loop(&f, &p, &qx, &qy, fixed_lines, nullptr);
+  miller_loop(&f, &p, &qx, &qy, fixed_lines ? fixed_lines + (size_t)i * lines_stride : nullptr, nullptr);
   final_exponentiation(&e, &f);
   if (ident) fq12_set_one(&e);
   if (live) gt_serialize(gt_out + (size_t)96 * i, &e);

@@ -4,12 +4,14 @@
 #include "pairing.cuh"
 namespace keaki_internal {
 using namespace bn254;
-keaki_status pairing_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, int g2_stride, size_t n, void* d_gt, const void* d_fixed_lines) {
+keaki_status pairing_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, int g2_stride, size_t n, void* d_gt, const void* d_fixed_lines,
+                         uint32_t lines_stride) {
   // two lanes per pairing
   hipLaunchKernelGGL(k_pairing_batch, dim3(cdiv(2 * n, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_g1, (const G2Aff*)d_g2, g2_stride, (u32)n,
-                     (const Line*)d_fixed_lines, (u32*)d_gt);
+                     (const Line*)d_fixed_lines, lines_stride, (u32*)d_gt);
   return launch_check(ctx, "pairing_batch");
 }
+uint32_t g2_prepared_lines() { return (uint32_t)MILLER_MAX_LINES * 2; }
 size_t g2_prepared_bytes() { return (size_t)MILLER_MAX_LINES * 2 * sizeof(Line); }
 keaki_status g2_prepare_run(keaki_hip_ctx* ctx, const void* d_q, void* d_lines) {
   hipLaunchKernelGGL(k_g2_prepare, dim3(1), dim3(64), 0, ctx->stream, (const G2Aff*)d_q, (Line*)d_lines);

@@ -23,7 +23,7 @@ EXPORTS = [
     "keaki_hip_g1_mul_batch", "keaki_hip_g2_mul_batch", "keaki_hip_g1_mul_batch_dev", "keaki_hip_g2_mul_batch_dev",
     "keaki_hip_pairing_batch", "keaki_hip_pairing_batch_dev",
     "keaki_hip_encap_batch", "keaki_hip_encap_batch_dev", "keaki_hip_decap_batch", "keaki_hip_decap_batch_dev",
-    "keaki_hip_selftest_field", "keaki_hip_open_fk", "keaki_hip_open_fk_poly", "keaki_hip_srs_g1_precompute_fk", "keaki_hip_fr_fft", "keaki_hip_srs_g1_check", "keaki_hip_g2_check", "keaki_hip_kzg_open", "keaki_hip_final_exp_batch", "keaki_hip_miller_loop_batch", "keaki_hip_g2_prepare", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
+    "keaki_hip_selftest_field", "keaki_hip_open_fk", "keaki_hip_open_fk_poly", "keaki_hip_srs_g1_precompute_fk", "keaki_hip_fr_fft", "keaki_hip_srs_g1_check", "keaki_hip_g2_check", "keaki_hip_kzg_open", "keaki_hip_kzg_verify", "keaki_hip_final_exp_batch", "keaki_hip_miller_loop_batch", "keaki_hip_g2_prepare", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
 ]
 
 KEAKI_ERR_TOO_LARGE = -5
@@ -85,6 +85,7 @@ def load_library():
         lib.keaki_hip_srs_g1_check.argtypes = [vp, vp, vp, vp]
         lib.keaki_hip_kzg_open.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp]
         lib.keaki_hip_g2_check.argtypes = [vp, vp, C.c_size_t, vp, vp]
+        lib.keaki_hip_kzg_verify.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int32)]
         lib.keaki_hip_final_exp_batch.argtypes = [vp, vp, sz, vp]
         lib.keaki_hip_miller_loop_batch.argtypes = [vp, vp, vp, sz, vp]
         lib.keaki_hip_set_timing.argtypes = [vp, i32]
@@ -269,6 +270,13 @@ class KeakiHip:
         out = np.zeros(12, np.uint64); val = np.zeros(4, np.uint64)
         self._ck(self.lib.keaki_hip_kzg_open(self.ctx, srs.handle, _ptr(c) if c.shape[0] else None, c.shape[0], _ptr(_np(point)), _ptr(out), _ptr(val)))
         return out, val
+
+    def kzg_verify(self, com_aff, tau_g2_aff, point, value, proof_aff) -> bool:
+        """src/kzg.rs:127-146 on the device (affine Montgomery points, Montgomery Fr)"""
+        ok = C.c_int32(0)
+        self._ck(self.lib.keaki_hip_kzg_verify(self.ctx, _ptr(_np(com_aff)), _ptr(_np(tau_g2_aff)), _ptr(_np(point)), _ptr(_np(value)),
+                                               _ptr(_np(proof_aff)), C.byref(ok)))
+        return bool(ok.value)
 
     def srs_g1_check(self, srs: "SrsG1"):
         """-> (number of off-curve points, index of the first or None)"""

@@ -110,12 +110,6 @@ G1 jac_to_g1(const uint64_t j[12]) {
   if (j[8] | j[9] | j[10] | j[11]) memcpy(r.w.data(), j, 64);
   return r;
 }
-G2 jac_to_g2(const uint64_t j[24]) {
-  G2 r; bool nz = false;
-  for (int i = 16; i < 24; i++) nz |= j[i] != 0;
-  if (nz) memcpy(r.w.data(), j, 128);
-  return r;
-}
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ kzg
@@ -178,30 +172,11 @@ Result<G1> open(const KZGSetup& setup, const DensePolynomial& p_in, const Fr& po
 }
 
 Result<bool> verify(const KZGSetup& setup, const G1& commitment, const Fr& point, const Fr& value, const G1& proof) {
+  // src/kzg.rs:127-146; the device evaluates e(C - value g1 + point proof, g2) == e(proof, [tau]_2) (include/keaki_hip.h)
   const Device& dev = *setup.device();
-  // lhs point: commitment - value * g1  = MSM([commitment, g1], [1, -value]);  rhs: tau_g2 - point * g2
-  G1 g1 = g1_generator(); G2 g2 = g2_generator(dev);
-  uint64_t p2[16]; memcpy(p2, commitment.w.data(), 64); memcpy(p2 + 8, g1.w.data(), 64);
-  Fr sc[2] = {Fr::one(), -value};
-  keaki_hip_srs_g1* s1 = nullptr; uint64_t j1[12];
-  dev.check(keaki_hip_srs_g1_upload(dev.ctx(), p2, 2, &s1));
-  int st = keaki_hip_msm_g1(dev.ctx(), s1, sc[0].l, 2, j1);
-  keaki_hip_srs_g1_free(dev.ctx(), s1);
-  dev.check(st);
-  uint64_t q2[32]; memcpy(q2, setup.tau_g2().w.data(), 128); memcpy(q2 + 16, g2.w.data(), 128);
-  Fr sc2[2] = {Fr::one(), -point};
-  keaki_hip_srs_g2* s2 = nullptr; uint64_t j2[24];
-  dev.check(keaki_hip_srs_g2_upload(dev.ctx(), q2, 2, &s2));
-  st = keaki_hip_msm_g2(dev.ctx(), s2, sc2[0].l, 2, j2);
-  keaki_hip_srs_g2_free(dev.ctx(), s2);
-  dev.check(st);
-  G1 lhs = jac_to_g1(j1); G2 rhs = jac_to_g2(j2);
-  uint64_t ps[16], qs[32];
-  memcpy(ps, lhs.w.data(), 64); memcpy(ps + 8, proof.w.data(), 64);
-  memcpy(qs, g2.w.data(), 128); memcpy(qs + 16, rhs.w.data(), 128);
-  uint8_t gt[2 * 384];
-  dev.check(keaki_hip_pairing_batch(dev.ctx(), ps, qs, 1, 2, gt));
-  return Result<bool>::Ok(memcmp(gt, gt + 384, 384) == 0);
+  int32_t ok = 0;
+  dev.check(keaki_hip_kzg_verify(dev.ctx(), commitment.w.data(), setup.tau_g2().w.data(), point.l, value.l, proof.w.data(), &ok));
+  return Result<bool>::Ok(ok != 0);
 }
 
 void precompute_open_fk(const KZGSetup& setup, size_t d) {

@@ -87,6 +87,45 @@ def test_kzg_open_and_verify_matrix(K, oc, py):
     assert not K.verify(s, K.commit(s, q), point, value, proof)       # wrong commitment
 
 
+def test_kzg_verify_edges_and_setup_switch(K, oc, py):
+    """keaki_hip_kzg_verify evaluates e(C - v g1 + z proof, g2) == e(proof, [tau]_2) with cached line tables: identity proof /
+    commitment (constant and zero polynomial), alternating setups (the [tau]_2 table must follow), booleans == the oracle's
+    src/kzg.rs:127-146 restatement."""
+    rng = K.Rng(50)
+    sec_a, sec_b = rng.fr_rand(), rng.fr_rand()
+    sa, sb = K.KZGSetup.setup(sec_a, 8), K.KZGSetup.setup(sec_b, 8)
+    z = rng.fr_rand()
+    const = np.stack([K.fr(7)])
+    com, proof = K.commit(sa, const), K.open(sa, const, z)
+    assert not np.any(proof)                                          # quotient of a constant is empty: identity proof
+    assert K.verify(sa, com, z, K.fr(7), proof)
+    assert not K.verify(sa, com, z, K.fr(8), proof)
+    zero_pt = np.zeros(8, np.uint64)
+    assert K.verify(sa, zero_pt, z, K.fr(0), zero_pt)                 # zero polynomial: everything is the identity
+    assert not K.verify(sa, zero_pt, z, K.fr(1), zero_pt)
+    p = np.stack([K.fr(c) for c in POLY])
+    v = K.poly_evaluate(p, z)
+    ca, pa = K.commit(sa, p), K.open(sa, p, z)
+    cb, pb = K.commit(sb, p), K.open(sb, p, z)
+    for _ in range(2):                                                # a, b, a, b: the cached [tau]_2 lines switch every call
+        assert K.verify(sa, ca, z, v, pa)
+        assert K.verify(sb, cb, z, v, pb)
+        assert not K.verify(sa, cb, z, v, pb)
+        assert not K.verify(sb, ca, z, v, pa)
+    # point = 0 and value = 0 corners
+    z0 = K.fr(0)
+    assert K.verify(sa, ca, z0, K.poly_evaluate(p, z0), K.open(sa, p, z0))
+    root = np.stack([K.fr(c) for c in [-6, 1, 1]])                    # (x - 2)(x + 3): value 0 at x = 2
+    assert K.verify(sa, K.commit(sa, root), K.fr(2), K.fr(0), K.open(sa, root, K.fr(2)))
+    assert not K.verify(sa, K.commit(sa, root), K.fr(3), K.fr(0), K.open(sa, root, K.fr(3)))
+    # booleans against the oracle on the same integers
+    tau, zi, vi = canon(oc, sec_a)[0], canon(oc, z)[0], canon(oc, v)[0]
+    _, tau_g2 = py.kzg_setup(tau, 8)
+    ci, pi = oc.g1_to_ints(ca)[0], oc.g1_to_ints(pa)[0]
+    assert py.kzg_verify(tau_g2, ci, zi, vi, pi) is True
+    assert py.kzg_verify(tau_g2, ci, zi, (vi + 1) % py.R, pi) is False and not K.verify(sa, ca, z, K.fr_add(v, K.fr(1)), pa)
+
+
 def test_kzg_open_fk(K):
     """src/kzg.rs:470-505: open_fk proofs == open at each root of unity (d = 4, SRS 16)."""
     rng = K.Rng(6)
