@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised cross-check of encap_batch / decap_batch against the CPU oracle over batch sizes that hit every path (ladder < 256 <= fixed-base
-tables; per-item pairing vs the GT fixed-base path, forced with KEAKI_ENCAP_GT).  python bench_tools/fuzz_kem.py"""
+tables; per-item pairing vs the GT fixed-base path, forced with KEAKI_ENCAP_GT).  python bench_tools/fuzz_kem.py [rounds [seed]]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,18 +11,21 @@ from keaki_amd.hip import KeakiHip
 hip = KeakiHip(0)
 mont = lambda ints: oc.fr_to_mont(oc.ints_to_limbs(ints))
 g1, g2 = oc.generators()
-rng = np.random.default_rng(7)
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+rng = np.random.default_rng(seed)
+S0 = 0 if seed == 7 else seed * 100003
 bad = 0
-for it in range(16):
+for it in range(rounds):
     os.environ["KEAKI_ENCAP_GT"] = "64" if it % 2 else "1000000000"
-    n = int(rng.integers(1, 700)) if it % 4 else [1, 255, 256, 257][it // 4]
-    tau, c0 = rand_fr_ints(2, 100 + it)
+    n = int(rng.integers(1, 700)) if it % 4 else [1, 255, 256, 257][(it // 4) % 4]
+    tau, c0 = rand_fr_ints(2, S0 + 100 + it)
     com = hip.g1_mul_batch(g1, mont([c0]))[0]; tau_g2 = hip.g2_mul_batch(g2, mont([tau]))[0]
-    A, V, Rr = mont(rand_fr_ints(n, 200 + it)), mont(rand_fr_ints(n, 300 + it)), mont(rand_fr_ints(n, 400 + it))
+    A, V, Rr = mont(rand_fr_ints(n, S0 + 200 + it)), mont(rand_fr_ints(n, S0 + 300 + it)), mont(rand_fr_ints(n, S0 + 400 + it))
     ml = int(rng.integers(1, 100))
     ct, gt, key = hip.encap_batch(com, tau_g2, A, V, Rr, ml)
     ect, egt, ekey = oc.encap_batch(com, tau_g2, A, V, Rr, ml, threads=8)
-    proofs = hip.g1_mul_batch(g1, mont(rand_fr_ints(n, 500 + it)))
+    proofs = hip.g1_mul_batch(g1, mont(rand_fr_ints(n, S0 + 500 + it)))
     dgt, dkey = hip.decap_batch(proofs, ct, ml)
     egt2, ekey2 = oc.decap_batch(proofs, ect, ml, threads=8)
     ok = all(np.array_equal(a, b) for a, b in ((ct, ect), (gt, egt), (key, ekey), (dgt, egt2), (dkey, ekey2)))

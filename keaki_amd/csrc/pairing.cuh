@@ -511,7 +511,7 @@ static __global__ void __launch_bounds__(64, 2) k_gt_encap_exp(const Fq* __restr
 }
 
 // debug / test entry: Miller loop only. out: n x 12 Fq (Montgomery), single-element layout.
-static __global__ void __launch_bounds__(64) k_miller_only(const G1Aff* __restrict__ ps, const G2Aff* __restrict__ qs, u32 n, Fq* __restrict__ out) {
+static __global__ void __launch_bounds__(64, 2) k_miller_only(const G1Aff* __restrict__ ps, const G2Aff* __restrict__ qs, u32 n, Fq* __restrict__ out) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 item = t >> 1;
   const bool live = item < n;
@@ -528,7 +528,7 @@ static __global__ void __launch_bounds__(64) k_miller_only(const G1Aff* __restri
 }
 // debug / test entry: final exponentiation only. in: n x Fq12 in Montgomery form, single-element layout
 // (c0.c0.c0, c0.c0.c1, ... 12 x Fq); out: n x 384 GT bytes. Two lanes per item.
-static __global__ void __launch_bounds__(64) k_final_exp_only(const Fq* __restrict__ in, u32 n, u32* __restrict__ gt_out) {
+static __global__ void __launch_bounds__(64, 2) k_final_exp_only(const Fq* __restrict__ in, u32 n, u32* __restrict__ gt_out) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 item = t >> 1;
   const bool live = item < n;
