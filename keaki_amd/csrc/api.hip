@@ -332,6 +332,18 @@ keaki_status keaki_hip_pairing_batch(keaki_hip_ctx* ctx, const uint64_t* g1_aff,
   return download(ctx, gt_out, ctx->io_c.p, n * 384);
 }
 
+// signed-window table of e(P, g2) for a G1 point P in device memory: the powers of two e(P, g2)^(2^s) = e(2^s P, g2) come from one
+// pairing launch over the doubling chain of P (latency of one pairing), the rest of every window by products (pairing.cuh)
+static keaki_status gt_table_of(keaki_hip_ctx* ctx, const void* d_p_aff, void* d_table, uint32_t wb) {
+  char* gb = (char*)ctx->gt_base.p;
+  const uint32_t cnt = gt_table_powers(wb);
+  void* pts = gb + G1_AFF_BYTES;
+  void* pows = gb + G1_AFF_BYTES + 320 * G1_AFF_BYTES;
+  ST_TRY(g1_pow2_chain_run(ctx, d_p_aff, cnt, pts));
+  ST_TRY(pairing_raw_fixed_run(ctx, pts, cnt, ctx->g2gen_lines.p, pows));
+  return gt_table_run(ctx, pows, d_table, wb);
+}
+
 // ---- KEM composites ------------------------------------------------------------------------------------------
 keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff, const void* d_tau_g2_aff, const void* d_points,
                                        const void* d_values, const void* d_r, size_t n, void* d_ct_out_aff, void* d_gt_out, void* d_key_out,
@@ -387,19 +399,18 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
     ST_TRY(encap_g2_run(ctx, d_tau_g2_aff, d_points, d_r, n, d_ct_out_aff));
   }
   // window widths of the GT tables: the constant B = e(g1, g2) is tabulated once per context (16 bits: 16 products per item, 201 MB), A = e(C, g2)
-  // per commitment (13 bits: 20 products per item, 31.5 MB, ~12 ms to build)
+  // per commitment (13 bits: 20 products per item, 31.5 MB, ~8.6 ms to build: the latency of one pairing launch + the fills)
   constexpr uint32_t GT_WB_CONST = 16, GT_WB_PER_COMMITMENT = 13;
   const char* gt_env = getenv("KEAKI_ENCAP_GT");
   const size_t gt_threshold = gt_env ? (size_t)atoll(gt_env) : (size_t)65536;
   if (n >= gt_threshold) {
     // large batches: GT_i = A^(r_i) B^(-beta_i r_i) with A = e(C, g2), B = e(g1, g2) (see pairing.cuh): no pairing per item
-    ST_TRY(reserve(ctx, ctx->gt_base, 2 * 384 + G1_AFF_BYTES));
+    ST_TRY(reserve(ctx, ctx->gt_base, G1_AFF_BYTES + 320 * (G1_AFF_BYTES + 384)));   // a point | 2^s multiples | their pairings
     char* gb = (char*)ctx->gt_base.p;
     if (!ctx->gt_b_ready) {
       ST_TRY(reserve(ctx, ctx->gt_tab_b, gt_table_bytes(GT_WB_CONST)));
-      ST_TRY(g1_generator_to(ctx, gb + 768));
-      ST_TRY(pairing_raw_fixed_run(ctx, gb + 768, 1, ctx->g2gen_lines.p, gb + 384));
-      ST_TRY(gt_table_run(ctx, gb + 384, ctx->gt_tab_b.p, GT_WB_CONST));
+      ST_TRY(g1_generator_to(ctx, gb));
+      ST_TRY(gt_table_of(ctx, gb, ctx->gt_tab_b.p, GT_WB_CONST));
       ctx->gt_b_ready = true;
     }
     // A depends on the commitment only: reuse the table while the caller keeps encrypting to the same commitment
@@ -408,8 +419,7 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (!ctx->gt_a_valid || memcmp(com_host, ctx->gt_a_com, 64) != 0) {
       ST_TRY(reserve(ctx, ctx->gt_tab_a, gt_table_bytes(GT_WB_PER_COMMITMENT)));
-      ST_TRY(pairing_raw_fixed_run(ctx, d_com_aff, 1, ctx->g2gen_lines.p, gb));
-      ST_TRY(gt_table_run(ctx, gb, ctx->gt_tab_a.p, GT_WB_PER_COMMITMENT));
+      ST_TRY(gt_table_of(ctx, d_com_aff, ctx->gt_tab_a.p, GT_WB_PER_COMMITMENT));
       memcpy(ctx->gt_a_com, com_host, 64);
       ctx->gt_a_valid = true;
     }

@@ -443,17 +443,13 @@ static __global__ void __launch_bounds__(64, 2) k_pairing_raw_fixed(const G1Aff*
   if (aff_is_inf(p)) fq12_set_one(&e);
   if (live) gt_store(out + (size_t)12 * i, &e);
 }
-// table[j * entries + d] = base^(d 2^(wb j)).  Step 1: one lane pair walks the chain base^(2^s), s < wb * windows, and drops
-// base^(2^s) into slot 2^(s mod wb) of window s / wb (the powers of two of every window).
-static __global__ void __launch_bounds__(64, 2) k_gt_table_bases(const Fq* __restrict__ base, Fq* __restrict__ table, GtShape g) {
-  if (threadIdx.x >= 2) return;
-  Fq12 x;
-  gt_load(&x, base);
-#pragma unroll 1
-  for (u32 s = 0; s < g.wb * g.windows; s++) {
-    gt_store(table + ((size_t)(s / g.wb) * g.entries + (1u << (s % g.wb))) * 12, &x);
-    fq12_cyc_sqr(&x, &x);
-  }
+// table[j * entries + d] = base^(d 2^(wb j)).  Step 1: the powers of two base^(2^s), s < wb * windows (pows[s]: 12 Fq each, from
+// k_pairing_raw_fixed over the multiples 2^s P of k_g1_pow2_chain -- base = e(P, Q)) go to slot 2^(s mod wb) of window s / wb.
+static __global__ void __launch_bounds__(256) k_gt_table_scatter(const Fq* __restrict__ pows, Fq* __restrict__ table, GtShape g) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= g.wb * g.windows * 12) return;
+  const u32 s = t / 12, c = t % 12;
+  table[((size_t)(s / g.wb) * g.entries + (1u << (s % g.wb))) * 12 + c] = pows[(size_t)s * 12 + c];
 }
 // Step 2, level L = 1 .. wb - 2: table[j][2^L + x] = table[j][2^L] * table[j][x], 1 <= x < 2^L (all known from the levels below)
 static __global__ void __launch_bounds__(64, 2) k_gt_table_fill(Fq* __restrict__ table, u32 L, GtShape g) {

@@ -22,10 +22,11 @@ keaki_status pairing_raw_fixed_run(keaki_hip_ctx* ctx, const void* d_g1, size_t 
   return launch_check(ctx, "pairing_raw_fixed");
 }
 size_t gt_table_bytes(uint32_t wb) { GtShape g = gt_shape(wb); return (size_t)g.windows * g.entries * 12 * sizeof(Fq); }
-// d_table[j][d] = base^(d 2^(wb j)), d = 1 .. 2^(wb-1); d_base: 12 Fq
-keaki_status gt_table_run(keaki_hip_ctx* ctx, const void* d_base, void* d_table, uint32_t wb) {
+uint32_t gt_table_powers(uint32_t wb) { GtShape g = gt_shape(wb); return g.wb * g.windows; }
+// d_table[j][d] = base^(d 2^(wb j)), d = 1 .. 2^(wb-1), base = e(P, Q): d_pows = e(2^s P, Q), s < gt_table_powers(wb), 12 Fq each
+keaki_status gt_table_run(keaki_hip_ctx* ctx, const void* d_pows, void* d_table, uint32_t wb) {
   const GtShape g = gt_shape(wb);
-  hipLaunchKernelGGL(k_gt_table_bases, dim3(1), dim3(64), 0, ctx->stream, (const Fq*)d_base, (Fq*)d_table, g);
+  hipLaunchKernelGGL(k_gt_table_scatter, dim3(cdiv(g.wb * g.windows * 12, 256)), dim3(256), 0, ctx->stream, (const Fq*)d_pows, (Fq*)d_table, g);
   for (u32 L = 1; L + 2 <= g.wb; L++)
     hipLaunchKernelGGL(k_gt_table_fill, dim3(cdiv(2 * g.windows * ((1u << L) - 1u), 64)), dim3(64), 0, ctx->stream, (Fq*)d_table, L, g);
   return launch_check(ctx, "gt_table");
