@@ -82,7 +82,8 @@ def main():
 
     out = {}
     for name, fn, ab in (("encaps_fresh_commitment", encap_fresh, ALGO_BYTES_ENCAP), ("encaps", encap, ALGO_BYTES_ENCAP), ("decaps", decap, ALGO_BYTES_DECAP)):
-        for _ in range(args.warmup):
+        # steady state of `encaps` = same commitment as the call before: the SECOND call to a commitment fills its wider GT table (0.5 ms, once)
+        for _ in range(max(args.warmup, 2) if name == "encaps" else args.warmup):
             fn()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()

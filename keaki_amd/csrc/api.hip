@@ -398,9 +398,13 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
   } else {
     ST_TRY(encap_g2_run(ctx, d_tau_g2_aff, d_points, d_r, n, d_ct_out_aff));
   }
-  // window widths of the GT tables: the constant B = e(g1, g2) is tabulated once per context (16 bits: 16 products per item, 201 MB), A = e(C, g2)
-  // per commitment (13 bits: 20 products per item, 31.5 MB, ~8.6 ms to build: the latency of one pairing launch + the fills)
-  constexpr uint32_t GT_WB_CONST = 16, GT_WB_PER_COMMITMENT = 13;
+  // window widths of the GT tables. The constant B = e(g1, g2) is tabulated once per context: 20-bit windows (13 products per item, 2.6 GB;
+  // KEAKI_GT_WB_B picks another width). A = e(C, g2) per commitment: 13 bits on first sight (20 products per item, 31.5 MB, ~8.6 ms to
+  // build: the latency of one pairing launch + the fills); when the SAME commitment comes back, its 16-bit table (16 products, 201 MB) is
+  // filled from the powers of two still lying in gt_base (0.5 ms, no pairing).
+  constexpr uint32_t GT_WB_A_FIRST = 13, GT_WB_A_REPEAT = 16;
+  const char* wbb_env = getenv("KEAKI_GT_WB_B");
+  const uint32_t wb_b_req = wbb_env ? (uint32_t)atoi(wbb_env) : 20u;
   const char* gt_env = getenv("KEAKI_ENCAP_GT");
   const size_t gt_threshold = gt_env ? (size_t)atoll(gt_env) : (size_t)65536;
   if (n >= gt_threshold) {
@@ -408,22 +412,32 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
     ST_TRY(reserve(ctx, ctx->gt_base, G1_AFF_BYTES + 320 * (G1_AFF_BYTES + 384)));   // a point | 2^s multiples | their pairings
     char* gb = (char*)ctx->gt_base.p;
     if (!ctx->gt_b_ready) {
-      ST_TRY(reserve(ctx, ctx->gt_tab_b, gt_table_bytes(GT_WB_CONST)));
+      if (wb_b_req < 8 || wb_b_req > 22 || gt_table_powers(wb_b_req) > 320) return fail(ctx, KEAKI_ERR_BAD_ARG, "KEAKI_GT_WB_B=%u out of range", wb_b_req);
+      ctx->gt_b_wb = wb_b_req;
+      ST_TRY(reserve(ctx, ctx->gt_tab_b, gt_table_bytes(ctx->gt_b_wb)));
       ST_TRY(g1_generator_to(ctx, gb));
-      ST_TRY(gt_table_of(ctx, gb, ctx->gt_tab_b.p, GT_WB_CONST));
+      ST_TRY(gt_table_of(ctx, gb, ctx->gt_tab_b.p, ctx->gt_b_wb));
       ctx->gt_b_ready = true;
+      ctx->gt_a_valid = false;                    // gt_base now holds B's powers
     }
     // A depends on the commitment only: reuse the table while the caller keeps encrypting to the same commitment
     uint64_t com_host[8];
     HIP_TRY(ctx, hipMemcpyAsync(com_host, d_com_aff, 64, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (!ctx->gt_a_valid || memcmp(com_host, ctx->gt_a_com, 64) != 0) {
-      ST_TRY(reserve(ctx, ctx->gt_tab_a, gt_table_bytes(GT_WB_PER_COMMITMENT)));
-      ST_TRY(gt_table_of(ctx, d_com_aff, ctx->gt_tab_a.p, GT_WB_PER_COMMITMENT));
+      ctx->gt_a_valid = false;
+      ST_TRY(reserve(ctx, ctx->gt_tab_a, gt_table_bytes(GT_WB_A_REPEAT)));
+      ST_TRY(gt_table_of(ctx, d_com_aff, ctx->gt_tab_a.p, GT_WB_A_FIRST));
       memcpy(ctx->gt_a_com, com_host, 64);
+      ctx->gt_a_wb = GT_WB_A_FIRST;
       ctx->gt_a_valid = true;
+    } else if (ctx->gt_a_wb != GT_WB_A_REPEAT) {
+      // same commitment again: the powers A^(2^s), s < 260, of the first build cover the 256 the wider table needs
+      ST_TRY(gt_table_run(ctx, gb + G1_AFF_BYTES + 320 * G1_AFF_BYTES, ctx->gt_tab_a.p, GT_WB_A_REPEAT));
+      static_assert(GT_WB_A_REPEAT == 16 && GT_WB_A_FIRST == 13, "the power count of the first table must cover the second");
+      ctx->gt_a_wb = GT_WB_A_REPEAT;
     }
-    ST_TRY(gt_encap_exp_run(ctx, ctx->gt_tab_a.p, GT_WB_PER_COMMITMENT, ctx->gt_tab_b.p, GT_WB_CONST, d_values, d_r, n, gt));
+    ST_TRY(gt_encap_exp_run(ctx, ctx->gt_tab_a.p, ctx->gt_a_wb, ctx->gt_tab_b.p, ctx->gt_b_wb, d_values, d_r, n, gt));
   } else {
     // per-item pairing e(r_i (C - beta_i g1), g2) with the tabulated lines of g2
     if (use_tables) {

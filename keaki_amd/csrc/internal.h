@@ -32,6 +32,7 @@ struct keaki_hip_ctx {
   keaki_internal::DevBuf fb_scalars, fb_g1_gen, fb_g2_gen, fb_com, fb_tau, perm, g2gen_lines, gt_tab_a, gt_tab_b, gt_base, heavy;
   bool gt_b_ready = false;
   bool gt_a_valid = false;
+  uint32_t gt_a_wb = 0, gt_b_wb = 0;      // window widths of the GT tables in gt_tab_a / gt_tab_b
   keaki_internal::DevBuf verify_lines, verify_io;   // kzg verify: [lines of g2 | lines of [tau]_2], small in/out block
   bool verify_tau_valid = false;
   uint64_t verify_tau_pt[16] = {};

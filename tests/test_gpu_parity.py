@@ -340,8 +340,12 @@ def test_encap_gt_fixed_base_path_vs_oracle(oc, py, hip, rand_fr, monkeypatch):
     # a run of carries through every window, the largest exponent below 2^253
     r[8] = 1 << 12; r[9] = (1 << 12) + 1; r[10] = (1 << 13) - 1; r[11] = (1 << 26) - 1; r[12] = (1 << 253) - 1; v[12] = 1
     r[13] = sum(((1 << 12) + 1) << (13 * j) for j in range(19)); r[14] = (1 << 13); r[15] = (1 << 13) + (1 << 12)
+    # the same corners for the 16-bit table A gets when its commitment repeats, and for the 20-bit table of B (exponent -(r beta): r = 1)
+    r[16] = 1 << 15; r[17] = (1 << 15) + 1; r[18] = (1 << 16) - 1; r[19] = sum(((1 << 15) + 1) << (16 * j) for j in range(15))
+    for k, e in enumerate([1 << 19, (1 << 19) + 1, (1 << 20) - 1, sum(((1 << 19) + 1) << (20 * j) for j in range(12)), (1 << 253) + 12345]):
+        r[20 + k] = 1; v[20 + k] = py.R - e
     A, V, Rr = mont(oc, a), mont(oc, v), mont(oc, r)
-    for c in (c0, c1):     # two commitments: exercises the per-commitment table cache
+    for c in (c0, c1):     # two commitments, twice each: the per-commitment cache, first the 13-bit table of A, then its 16-bit one
         com = hip.g1_mul_batch(g1, mont(oc, [c]))[0]
         for _ in range(2):
             ct, gt, key = hip.encap_batch(com, tau_g2, A, V, Rr, 32)
