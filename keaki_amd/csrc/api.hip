@@ -414,7 +414,13 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
     if (!ctx->gt_b_ready) {
       if (wb_b_req < 8 || wb_b_req > 22 || gt_table_powers(wb_b_req) > 320) return fail(ctx, KEAKI_ERR_BAD_ARG, "KEAKI_GT_WB_B=%u out of range", wb_b_req);
       ctx->gt_b_wb = wb_b_req;
-      ST_TRY(reserve(ctx, ctx->gt_tab_b, gt_table_bytes(ctx->gt_b_wb)));
+      keaki_status st_b = reserve(ctx, ctx->gt_tab_b, gt_table_bytes(ctx->gt_b_wb));
+      if (st_b == KEAKI_ERR_OOM && ctx->gt_b_wb > 16) {          // no room for the wide table: the 16-bit one is 201 MB
+        (void)hipGetLastError();
+        ctx->gt_b_wb = 16;
+        st_b = reserve(ctx, ctx->gt_tab_b, gt_table_bytes(ctx->gt_b_wb));
+      }
+      ST_TRY(st_b);
       ST_TRY(g1_generator_to(ctx, gb));
       ST_TRY(gt_table_of(ctx, gb, ctx->gt_tab_b.p, ctx->gt_b_wb));
       ctx->gt_b_ready = true;

@@ -365,6 +365,31 @@ def test_encap_gt_fixed_base_path_vs_oracle(oc, py, hip, rand_fr, monkeypatch):
     assert np.array_equal(gt2, gt3) and np.array_equal(ct2, ct3)
 
 
+@pytest.mark.parametrize("wb", [16, 11])
+def test_encap_gt_path_other_window_widths(oc, py, rand_fr, monkeypatch, wb):
+    """The constant-base GT table at another window width (16 bits is what a context falls back to when the 2.6 GB 20-bit table does not
+    fit; 11 leaves a 1-bit top window): own context, since the table is built once per context."""
+    from keaki_amd.hip import KeakiHip
+    monkeypatch.setenv("KEAKI_ENCAP_GT", "64")
+    monkeypatch.setenv("KEAKI_GT_WB_B", str(wb))
+    h = KeakiHip(0)
+    try:
+        g1, g2 = oc.generators()
+        n = 96
+        tau, c0 = rand_fr(2, 181)
+        tau_g2 = h.g2_mul_batch(g2, mont(oc, [tau]))[0]
+        com = h.g1_mul_batch(g1, mont(oc, [c0]))[0]
+        a, v, r = rand_fr(n, 182), rand_fr(n, 183), rand_fr(n, 184)
+        r[0] = 1; v[0] = py.R - ((1 << (wb - 1)) + 1); r[1] = 1; v[1] = py.R - ((1 << wb) - 1); r[2] = 1; v[2] = 1     # exponent of B: 2^(wb-1)+1, 2^wb-1, r-1
+        A, V, Rr = mont(oc, a), mont(oc, v), mont(oc, r)
+        ect, egt, ekey = oc.encap_batch(com, tau_g2, A, V, Rr, 32, threads=8)
+        for _ in range(2):
+            ct, gt, key = h.encap_batch(com, tau_g2, A, V, Rr, 32)
+            assert np.array_equal(ct, ect) and np.array_equal(gt, egt) and np.array_equal(key, ekey)
+    finally:
+        h.close()
+
+
 def test_msm_structured_scalars_heavy_buckets(oc, hip, rand_fr):
     """0/1 and repeated coefficients put tens of thousands of points into single buckets (the heavy-bucket path: sliced
     accumulation by whole workgroups). Checked via the O(n) identity MSM(s, k_i G) == (sum s_i k_i) G, with and without tables."""
