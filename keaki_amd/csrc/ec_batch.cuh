@@ -188,8 +188,8 @@ KDEV Xyzz<F> fb_accumulate(Xyzz<F> acc, const Aff<F>* __restrict__ table, FbShap
 }
 
 // out[i] = r_i * BaseA + (-(r_i * x_i)) * BaseB   with tables for BaseA (C or [tau]_2) and BaseB (g1 or g2)
-template <class F>
-__global__ void __launch_bounds__(64) k_encap_fixed(const Aff<F>* __restrict__ tab_a, FbShape ga, const Aff<F>* __restrict__ tab_b, FbShape gb,
+template <class F, int OCC>
+__global__ void __launch_bounds__(64, OCC) k_encap_fixed(const Aff<F>* __restrict__ tab_a, FbShape ga, const Aff<F>* __restrict__ tab_b, FbShape gb,
                                                     const Fr* __restrict__ xs, const Fr* __restrict__ rs, u32 n, Aff<F>* __restrict__ out) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

@@ -42,7 +42,7 @@ keaki_status g1_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void*
 }
 keaki_status encap_g1_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t wb_a, const void* d_tab_b, uint32_t wb_b, const void* d_xs,
                                 const void* d_rs, size_t n, void* d_out) {
-  hipLaunchKernelGGL((k_encap_fixed<Fq>), dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_tab_a, fb_shape(wb_a), (const G1Aff*)d_tab_b,
+  hipLaunchKernelGGL((k_encap_fixed<Fq, 1>), dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_tab_a, fb_shape(wb_a), (const G1Aff*)d_tab_b,
                      fb_shape(wb_b), (const Fr*)d_xs,
                      (const Fr*)d_rs, (u32)n, (G1Aff*)d_out);
   return launch_check(ctx, "encap_g1_fixed");
