@@ -79,16 +79,27 @@ KDEV Fq2d fq2d_load(const Fq2* a) { return {reinterpret_cast<const Fq*>(a)[lane_
 // which turns the 2^256 Montgomery form into the 2^261 one the stream reduces by -- and the result (< 1.6p) is brought back to
 // the canonical saturated residue, so nothing above this function changes. The even lane's subtraction is (64p - 32 a1) b1.
 // ~1,700 SIMD-cycles instead of ~2,550 for two saturated products and a modular addition.
+// partner lane's limbs of a value this kernel's own (compiler-scheduled) instructions produced: the hazard recogniser pads the DPP reads itself
+KDEV U29 u29_partner(const U29& a) {
+  U29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = (u32)__builtin_amdgcn_update_dpp(0, (int)a.l[i], 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false);
+  return r;
+}
 static KNOINLINE Fq2d fq2d_mul(const Fq2d a, const Fq2d b) {
   const bool odd = lane_odd() != 0;
-  Fq ao = fq_partner(a.v), bo = fq_partner(b.v);
+  // every lane cuts its OWN two operands into limbs and fetches the partner's limbs (18 DPP moves) instead of fetching the saturated words and
+  // cutting four operands
+  const U29 A1 = u29_from_sat_shift5(a.v.l), Bs = u29_from_sat_plain(b.v.l);
+  const U29 Ao = u29_partner(A1), Bo = u29_partner(Bs);
   // self * X + (+-)other * Y :  X = odd ? b_other : b_self ;  Y = odd ? b_self : b_other ; sign: even -, odd +
-  const Fq X = fq_select(odd, bo, b.v), Y = fq_select(odd, b.v, bo);
-  const U29 A1 = u29_from_sat_shift5(a.v.l), B1 = u29_from_sat_plain(X.l), D = u29_from_sat_plain(Y.l);
-  U29 C = u29_from_sat_shift5(ao.l);
+  U29 B1, D, C;
 #pragma unroll
-  for (int i = 0; i < 9; i++) C.l[i] = odd ? C.l[i] : Q29::K64[i] - C.l[i];       // 64p - 32 a1 > 0 in every limb (32p would underflow the
-                                                                                    // top limb for a1 near p); limbs below 1.5 * 2^30
+  for (int i = 0; i < 9; i++) {
+    B1.l[i] = odd ? Bo.l[i] : Bs.l[i];
+    D.l[i] = odd ? Bs.l[i] : Bo.l[i];
+    C.l[i] = odd ? Ao.l[i] : Q29::K64[i] - Ao.l[i];           // 64p - 32 a1 > 0 in every limb (32p would underflow the top limb for a1 near p);
+  }                                                           // limbs below 1.5 * 2^30
   Fq2d r;
   u29_pack_canonical(r.v.l, u29_mul2(A1, B1, C, D));
   return r;
