@@ -194,28 +194,22 @@ KDEV U29 u29_sub3(const U29& a, const U29& b, const U29& c) {
 KDEV bool u29_maybe_zero(const U29& x) { return ((x.l[0] * Q29::PINV) & Q29::MASK) <= 17u; }
 
 // t < 2p with exact limbs (a product's output) -> the canonical integer below p, packed into 8 x 32 bits
+KDEV void fq_cond_sub_p_asm(u32* __restrict__ r, const u32* __restrict__ t);   // bn254_field_asm.cuh (included after this file)
 KDEV void u29_pack_canonical(u32* out, const U29& t) {
-  // d = t - p with a signed ripple; keep t when it borrows
-  u32 d[9];
-  int carry = 0;
+  // pack the (exact) limbs into 8 x 32 bits first -- 2p < 2^255 fits -- then ONE conditional subtraction on the hardware borrow chain
+  // (16 instructions); a signed ripple over nine 29-bit limbs costs 45
+  u32 v[10], w[8];
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
-    int s = (int)t.l[i] - (int)Q29::MOD[i] + carry;
-    d[i] = (i < 8) ? ((u32)s & Q29::MASK) : (u32)s;
-    carry = s >> 29;
-  }
-  const bool keep = (int)d[8] < 0;
-  u32 v[10];
-#pragma unroll
-  for (int i = 0; i < 9; i++) v[i] = keep ? t.l[i] : d[i];
+  for (int i = 0; i < 9; i++) v[i] = t.l[i];
   v[9] = 0;
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const int s = 32 * j, q = s / 29, o = s % 29;
-    u64 w = ((u64)v[q + 1] << 29) | v[q];
-    if (q + 2 < 10 && 58 - o < 32) w |= (u64)v[q + 2] << 58;
-    out[j] = (u32)(w >> o);
+    u64 x = ((u64)v[q + 1] << 29) | v[q];
+    if (q + 2 < 10 && 58 - o < 32) x |= (u64)v[q + 2] << 58;
+    w[j] = (u32)(x >> o);
   }
+  fq_cond_sub_p_asm(out, w);
 }
 // 2^261-form lazy value -> canonical saturated 2^256-form residue (8 x 32)
 KDEV void u29_to_sat(u32* out, const U29& a) {

@@ -45,14 +45,14 @@ KDEV Fq fq_partner(const Fq& a) {
   u32 x0 = a.l[0], x1 = a.l[1], x2 = a.l[2], x3 = a.l[3], x4 = a.l[4], x5 = a.l[5], x6 = a.l[6], x7 = a.l[7];
   asm volatile("s_nop 1" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
   Fq r;
-  r.l[0] = (u32)__builtin_amdgcn_update_dpp(0, (int)x0, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false);
-  r.l[1] = (u32)__builtin_amdgcn_update_dpp(0, (int)x1, 0xB1, 0xF, 0xF, false);
-  r.l[2] = (u32)__builtin_amdgcn_update_dpp(0, (int)x2, 0xB1, 0xF, 0xF, false);
-  r.l[3] = (u32)__builtin_amdgcn_update_dpp(0, (int)x3, 0xB1, 0xF, 0xF, false);
-  r.l[4] = (u32)__builtin_amdgcn_update_dpp(0, (int)x4, 0xB1, 0xF, 0xF, false);
-  r.l[5] = (u32)__builtin_amdgcn_update_dpp(0, (int)x5, 0xB1, 0xF, 0xF, false);
-  r.l[6] = (u32)__builtin_amdgcn_update_dpp(0, (int)x6, 0xB1, 0xF, 0xF, false);
-  r.l[7] = (u32)__builtin_amdgcn_update_dpp(0, (int)x7, 0xB1, 0xF, 0xF, false);
+  r.l[0] = (u32)__builtin_amdgcn_update_dpp(0, (int)x0, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, true);
+  r.l[1] = (u32)__builtin_amdgcn_update_dpp(0, (int)x1, 0xB1, 0xF, 0xF, true);
+  r.l[2] = (u32)__builtin_amdgcn_update_dpp(0, (int)x2, 0xB1, 0xF, 0xF, true);
+  r.l[3] = (u32)__builtin_amdgcn_update_dpp(0, (int)x3, 0xB1, 0xF, 0xF, true);
+  r.l[4] = (u32)__builtin_amdgcn_update_dpp(0, (int)x4, 0xB1, 0xF, 0xF, true);
+  r.l[5] = (u32)__builtin_amdgcn_update_dpp(0, (int)x5, 0xB1, 0xF, 0xF, true);
+  r.l[6] = (u32)__builtin_amdgcn_update_dpp(0, (int)x6, 0xB1, 0xF, 0xF, true);
+  r.l[7] = (u32)__builtin_amdgcn_update_dpp(0, (int)x7, 0xB1, 0xF, 0xF, true);
   return r;
 }
 KDEV Fq fq_select(bool c, const Fq& a, const Fq& b) {  // c ? a : b
@@ -79,29 +79,27 @@ KDEV Fq2d fq2d_load(const Fq2* a) { return {reinterpret_cast<const Fq*>(a)[lane_
 // which turns the 2^256 Montgomery form into the 2^261 one the stream reduces by -- and the result (< 1.6p) is brought back to
 // the canonical saturated residue, so nothing above this function changes. The even lane's subtraction is (64p - 32 a1) b1.
 // ~1,700 SIMD-cycles instead of ~2,550 for two saturated products and a modular addition.
-// partner lane's limbs of a value this kernel's own (compiler-scheduled) instructions produced: the hazard recogniser pads the DPP reads itself
-KDEV U29 u29_partner(const U29& a) {
+// limbs of a value this kernel's own (compiler-scheduled) instructions produced, fetched across the lane pair: the hazard recogniser pads
+// the DPP reads itself. CTRL = quad_perm: 0xB1 [1,0,3,2] the partner's value, 0xA0 [0,0,2,2] the even lane's, 0xF5 [1,1,3,3] the odd lane's.
+template <int CTRL>
+KDEV U29 u29_quad(const U29& a) {
   U29 r;
 #pragma unroll
-  for (int i = 0; i < 9; i++) r.l[i] = (u32)__builtin_amdgcn_update_dpp(0, (int)a.l[i], 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false);
+  for (int i = 0; i < 9; i++) r.l[i] = (u32)__builtin_amdgcn_update_dpp(0, (int)a.l[i], CTRL, 0xF, 0xF, true);
   return r;
 }
 static KNOINLINE Fq2d fq2d_mul(const Fq2d a, const Fq2d b) {
   const bool odd = lane_odd() != 0;
-  // every lane cuts its OWN two operands into limbs and fetches the partner's limbs (18 DPP moves) instead of fetching the saturated words and
-  // cutting four operands
+  // every lane cuts its OWN two operands into limbs and fetches limbs over DPP (27 moves) instead of fetching the saturated words and cutting
+  // four operands. even lane: a0 b0 + (64p - 32 a1) b1, odd lane: a1 b0 + a0 b1 -- the right factors are b0 and b1 in BOTH lanes
   const U29 A1 = u29_from_sat_shift5(a.v.l), Bs = u29_from_sat_plain(b.v.l);
-  const U29 Ao = u29_partner(A1), Bo = u29_partner(Bs);
-  // self * X + (+-)other * Y :  X = odd ? b_other : b_self ;  Y = odd ? b_self : b_other ; sign: even -, odd +
-  U29 B1, D, C;
+  const U29 Ao = u29_quad<0xB1>(A1), B0 = u29_quad<0xA0>(Bs), B1 = u29_quad<0xF5>(Bs);
+  U29 C;
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
-    B1.l[i] = odd ? Bo.l[i] : Bs.l[i];
-    D.l[i] = odd ? Bs.l[i] : Bo.l[i];
-    C.l[i] = odd ? Ao.l[i] : Q29::K64[i] - Ao.l[i];           // 64p - 32 a1 > 0 in every limb (32p would underflow the top limb for a1 near p);
-  }                                                           // limbs below 1.5 * 2^30
+  for (int i = 0; i < 9; i++) C.l[i] = odd ? Ao.l[i] : Q29::K64[i] - Ao.l[i];   // 64p - 32 a1 > 0 in every limb (32p would underflow the top limb for
+                                                                                 // a1 near p); limbs below 1.5 * 2^30
   Fq2d r;
-  u29_pack_canonical(r.v.l, u29_mul2(A1, B1, C, D));
+  u29_pack_canonical(r.v.l, u29_mul2(A1, B0, C, B1));
   return r;
 }
 // (a0 + a1 u)^2:  even lane: (a0 + a1)(a0 - a1) ; odd lane: 2 a0 a1  -- one product per lane
@@ -394,7 +392,7 @@ static __global__ void __launch_bounds__(64, 2) k_pairing_batch(const G1Aff* __r
   Fq2d qx = fq2d_load(&q->x), qy = fq2d_load(&q->y);
   // identity in either slot (Q = all four components zero, or P = (0,0)): both lanes of the pair agree on `ident`
   u32 qz = (fq_is_zero(qx.v) && fq_is_zero(qy.v)) ? 1u : 0u;
-  qz &= (u32)__builtin_amdgcn_update_dpp(0, (int)qz, 0xB1, 0xF, 0xF, false);
+  qz &= (u32)__builtin_amdgcn_update_dpp(0, (int)qz, 0xB1, 0xF, 0xF, true);
   const bool ident = aff_is_inf(p) || qz != 0;
   // wave-uniform control flow: identity items run the same arithmetic (total on zeros) and discard it
   Fq12 f, e;
