@@ -97,16 +97,21 @@ def emit_cond_sub():
 
 
 def emit_add():
-    print("// r = a + b mod p")
+    print("// r = a + b mod p   (one statement: the sum, the trial subtraction and the selection; a + b < 2p < 2^255, no carry out of 256 bits)")
     print("KDEV void fq_add_asm(u32* __restrict__ r, const u32* __restrict__ a, const u32* __restrict__ b) {")
     print("  u32 t[8];")
-    lines = ["v_add_co_u32_e32 %0, vcc, %8, %16"]
+    lines = ["v_add_co_u32_e32 %8, vcc, %16, %24"]
     for j in range(1, 8):
-        lines.append("v_addc_co_u32_e32 %%%d, vcc, %%%d, %%%d, vcc" % (j, 8 + j, 16 + j))
-    outs = ", ".join('"=&v"(t[%d])' % j for j in range(8))
-    ins = ", ".join('"v"(a[%d])' % j for j in range(8)) + ", " + ", ".join('"v"(b[%d])' % j for j in range(8))
+        lines.append("v_addc_co_u32_e32 %%%d, vcc, %%%d, %%%d, vcc" % (8 + j, 16 + j, 24 + j))
+    lines.append("v_subrev_co_u32_e32 %0, vcc, %32, %8")
+    for j in range(1, 8):
+        lines.append("v_subbrev_co_u32_e32 %%%d, vcc, %%%d, %%%d, vcc" % (j, 32 + j, 8 + j))
+    for j in range(8):
+        lines.append("v_cndmask_b32_e32 %%%d, %%%d, %%%d, vcc" % (j, j, 8 + j))   # borrow -> keep the sum
+    outs = ", ".join('"=&v"(r[%d])' % j for j in range(8)) + ", " + ", ".join('"=&v"(t[%d])' % j for j in range(8))
+    ins = ", ".join('"v"(a[%d])' % j for j in range(8)) + ", " + ", ".join('"v"(b[%d])' % j for j in range(8)) + ", " + \
+        ", ".join('"v"(FqParams::MOD[%d])' % j for j in range(8))
     print('  asm("%s"\n      : %s\n      : %s\n      : "vcc");' % (SEP.join(lines), outs, ins))
-    print("  fq_cond_sub_p_asm(r, t);   // a + b < 2p < 2^255: no carry out of 256 bits")
     print("}")
 
 
