@@ -102,13 +102,26 @@ static KNOINLINE Fq2d fq2d_mul(const Fq2d a, const Fq2d b) {
   u29_pack_canonical(r.v.l, u29_mul2(A1, B0, C, B1));
   return r;
 }
-// (a0 + a1 u)^2:  even lane: (a0 + a1)(a0 - a1) ; odd lane: 2 a0 a1  -- one product per lane
+// (a0 + a1 u)^2:  even lane: (a0 + a1)(a0 - a1) ; odd lane: 2 a0 a1  -- one product per lane, in the 29-bit limbs: the sum and the doubling are
+// lazy limb operations (no reduction), only the difference a0 - a1 is a saturated modular subtraction. The factor 2^5 that turns the 2^256
+// Montgomery form into the 2^261 one rides on the second factor. even: (a0 + a1) < 2p times 32 (a0 - a1 mod p) < 32p; odd: a0 < p times
+// 64 a1 < 64p: products below 64 p^2, results below 1.4p; one factor has exact limbs, the other limbs below 2^30.
+// 162 v_mad_u64_u32 in 383 instructions instead of 128 + 148 carry instructions in 444.
 static KNOINLINE Fq2d fq2d_sqr(const Fq2d a) {
   const bool odd = lane_odd() != 0;
-  Fq ao = fq_partner(a.v);
-  Fq x = fq_select(odd, ao, a.v + ao);                  // odd: a0      even: a0 + a1
-  Fq y = fq_select(odd, fq_dbl(a.v), a.v - ao);         // odd: 2 a1    even: a0 - a1
-  return {x * y};
+  const Fq ao = fq_partner(a.v);
+  const Fq d = a.v - ao;                                    // used by the even lane: a0 - a1
+  const U29 As = u29_from_sat_plain(a.v.l), Ao = u29_quad<0xB1>(As);
+  const U29 A5 = u29_from_sat_shift5(a.v.l), D5 = u29_from_sat_shift5(d.l);
+  U29 x, y;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    x.l[i] = odd ? Ao.l[i] : As.l[i] + Ao.l[i];
+    y.l[i] = odd ? 2u * A5.l[i] : D5.l[i];
+  }
+  Fq2d r;
+  u29_pack_canonical(r.v.l, u29_mul(x, y));
+  return r;
 }
 KDEV Fq2d operator*(const Fq2d& a, const Fq2d& b) { return fq2d_mul(a, b); }
 KDEV Fq2d fq2_sqr(const Fq2d& a) { return fq2d_sqr(a); }
