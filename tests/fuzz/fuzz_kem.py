@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Randomised cross-check of encap_batch / decap_batch against the CPU oracle over batch sizes that hit every path (ladder < 256 <= fixed-base
-tables; per-item pairing vs the GT fixed-base path, forced with KEAKI_ENCAP_GT).  python bench_tools/fuzz_kem.py [rounds [seed]]"""
+tables; per-item pairing vs the GT fixed-base path, forced with KEAKI_ENCAP_GT).  python tests/fuzz/fuzz_kem.py [rounds [seed]]"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle as oc
 from conftest import rand_fr_ints

@@ -2,10 +2,10 @@
 """Random SEQUENCES of C-ABI calls on ONE context, every result checked against the CPU oracle: MSMs on two SRSs (one with window tables),
 encap / decap batches on both GT paths with commitments that repeat or change, kzg_open, kzg_verify with two setups, pairing batches.
 The per-feature tests exercise each call alone; this one is after state that leaks between calls (grow-only scratch buffers, cached tables
-of [tau]_2 / A / B, cached line tables).   python bench_tools/fuzz_mixed.py [rounds [seed]]"""
+of [tau]_2 / A / B, cached line tables).   python tests/fuzz/fuzz_mixed.py [rounds [seed]]"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle as oc
 from conftest_helpers import rand_fr_ints, R_MOD

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the MSM pipeline against the CPU oracle: random sizes (also just around tile / chunk boundaries), with and
-without window tables, random / sparse / repeated scalars, some identity points.  python bench_tools/fuzz_msm.py [rounds [seed]]"""
+without window tables, random / sparse / repeated scalars, some identity points.  python tests/fuzz/fuzz_msm.py [rounds [seed]]"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle as oc
 from conftest import rand_fr_ints
