@@ -512,6 +512,33 @@ def test_curve_checks(oc, py, hip, rand_fr):
     assert hip.g2_check(np.zeros((0, 16), np.uint64)) == (0, None)
 
 
+def test_kzg_verify_abi_degenerate_left_point(oc, py, hip, rand_fr):
+    """keaki_hip_kzg_verify evaluates e(C - v g1 + z proof, g2) == e(proof, [tau]_2). Inputs chosen so that the left point is the IDENTITY
+    (C = v g1 - z proof): the reference's equation e(C - v g1, g2) == e(proof, [tau]_2 - z g2) then reads e(proof, [tau]_2) == 1, false for
+    proof != O and true for proof == O; plus an honest opening and the oracle's verdict on the same integers."""
+    g1, g2 = oc.generators()
+    tau, v, z, k = rand_fr(4, 4242)
+    tau_g2 = hip.g2_mul_batch(g2, mont(oc, [tau]))[0]
+    G = py.G1_GEN
+    proof_i = py.g1_mul(G, k)
+    com_i = py.g1_add(py.g1_mul(G, v), py.g1_neg(py.g1_mul(proof_i, z)))
+    com, proof = oc.g1_from_ints([com_i])[0], oc.g1_from_ints([proof_i])[0]
+    zm, vm = mont(oc, [z])[0], mont(oc, [v])[0]
+    assert hip.kzg_verify(com, tau_g2, zm, vm, proof) is False
+    assert py.kzg_verify(py.g2_mul(py.G2_GEN, tau), com_i, z, v, proof_i) is False
+    zero = np.zeros(8, np.uint64)
+    com0 = oc.g1_from_ints([py.g1_mul(G, v)])[0]                     # proof = O, C = v g1: both sides are 1
+    assert hip.kzg_verify(com0, tau_g2, zm, vm, zero) is True
+    # an honest opening of p(x) = c0 + c1 x: proof = c1 g1, C = (c0 + c1 tau) g1, value = c0 + c1 z
+    c0, c1 = rand_fr(2, 4243)
+    comh = oc.g1_from_ints([py.g1_mul(G, (c0 + c1 * tau) % py.R)])[0]
+    prh = oc.g1_from_ints([py.g1_mul(G, c1)])[0]
+    val = (c0 + c1 * z) % py.R
+    assert hip.kzg_verify(comh, tau_g2, zm, mont(oc, [val])[0], prh) is True
+    assert hip.kzg_verify(comh, tau_g2, zm, mont(oc, [(val + 1) % py.R])[0], prh) is False
+    assert hip.kzg_verify(comh, tau_g2, mont(oc, [(z + 1) % py.R])[0], mont(oc, [val])[0], prh) is False
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 255, 256, 257, 5000, 70000])
 def test_kzg_open_quotient_on_device(oc, py, hip, rand_fr, n):
     """keaki_hip_kzg_open (row f-4): p(z) and the commitment of (p - p(z)) / (x - z), the quotient made on the device by the blockwise
