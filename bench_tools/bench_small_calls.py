@@ -11,3 +11,10 @@ for name, fn in (("commit(1000)", lambda: K.commit(s, p)), ("open(1000)", lambda
     fn(); t0 = time.perf_counter()
     for _ in range(5): fn()
     print(name, "%.2f ms" % ((time.perf_counter() - t0) / 5 * 1e3))
+# single KEM calls (src/kem.rs:13-50, 55-72 with n = 1)
+ct, key = K.encapsulate(rng, s, com, z, v, 32)
+assert K.decapsulate(s, pr, ct, 32) == key
+for name, fn in (("encapsulate", lambda: K.encapsulate(rng, s, com, z, v, 32)), ("decapsulate", lambda: K.decapsulate(s, pr, ct, 32))):
+    fn(); t0 = time.perf_counter()
+    for _ in range(5): fn()
+    print(name, "%.2f ms" % ((time.perf_counter() - t0) / 5 * 1e3))

@@ -107,17 +107,6 @@ static __global__ void __launch_bounds__(320) k_g1_pow2_chain(const G1Aff* __res
     out[t] = jac_to_aff(q);
   }
 }
-// encapsulate, G2 side (src/kem.rs:36-37): ct[i] = r[i] * (tau_g2 - points[i] * g2)   (affine)
-static __global__ void __launch_bounds__(64) k_encap_g2(const G2Aff* __restrict__ tau_g2, const Fr* __restrict__ points, const Fr* __restrict__ rs,
-                                                 u32 n, G2Aff* __restrict__ out) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  G2Aff g = {G2_GEN_X, G2_GEN_Y};
-  G2Jac t = scalar_mul(g, points[i]);
-  t.y = -t.y;
-  G2Aff ta = jac_to_aff(jac_add_mixed(t, *tau_g2));
-  out[i] = jac_to_aff(scalar_mul(ta, rs[i]));
-}
 
 
 // ------------------------------------------------------------------------------------------------

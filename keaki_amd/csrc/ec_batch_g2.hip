@@ -10,11 +10,6 @@ keaki_status g2_mul_batch_run(keaki_hip_ctx* ctx, const void* d_pts, int stride,
                      (G2Aff*)d_out);
   return launch_check(ctx, "g2_mul_batch");
 }
-keaki_status encap_g2_run(keaki_hip_ctx* ctx, const void* d_tau_g2, const void* d_points, const void* d_r, size_t n, void* d_out) {
-  hipLaunchKernelGGL(k_encap_g2, dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, (const G2Aff*)d_tau_g2, (const Fr*)d_points, (const Fr*)d_r, (u32)n,
-                     (G2Aff*)d_out);
-  return launch_check(ctx, "encap_g2");
-}
 keaki_status g2_generator_to(keaki_hip_ctx* ctx, void* d_dst) {
   HIP_TRY(ctx, hipMemcpyFromSymbolAsync(d_dst, HIP_SYMBOL(G2_GEN_X), sizeof(Fq2), 0, hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyFromSymbolAsync((char*)d_dst + sizeof(Fq2), HIP_SYMBOL(G2_GEN_Y), sizeof(Fq2), 0, hipMemcpyDeviceToDevice, ctx->stream));

@@ -41,6 +41,9 @@ struct keaki_hip_ctx {
   uint64_t gt_a_com[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // commitment the cached A-table belongs to
   bool g2gen_lines_ready = false;
   bool fb_ready = false;
+  keaki_internal::DevBuf fbs_scalars, fbs_g2_gen, fbs_tau;     // small (8-bit) tables of g2 and [tau]_2 for batches below 256 items
+  bool fbs_ready = false, fbs_tau_valid = false;
+  uint64_t fbs_tau_pt[16] = {};
   // instrumentation
   bool timing = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -78,7 +81,6 @@ keaki_status g1_sum_run(keaki_hip_ctx* ctx, const void* d_points_jac, size_t k, 
 keaki_status g1_mul_batch_run(keaki_hip_ctx* ctx, const void* d_pts, int stride, const void* d_scalars, size_t n, void* d_out);
 keaki_status g2_mul_batch_run(keaki_hip_ctx* ctx, const void* d_pts, int stride, const void* d_scalars, size_t n, void* d_out);
 keaki_status encap_g1_run(keaki_hip_ctx* ctx, const void* d_com, const void* d_values, const void* d_r, size_t n, void* d_out);
-keaki_status encap_g2_run(keaki_hip_ctx* ctx, const void* d_tau_g2, const void* d_points, const void* d_r, size_t n, void* d_out);
 keaki_status pairing_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, int g2_stride, size_t n, void* d_gt, const void* d_fixed_lines = nullptr,
                          uint32_t lines_stride = 0);
 uint32_t g2_prepared_lines();                 // Line entries of one table
