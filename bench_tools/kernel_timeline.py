@@ -3,7 +3,8 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_part_count" in r["Kernel_Name"] or "k_msm_digits" in r["Kernel_Name"]]
+key = sys.argv[2] if len(sys.argv) > 2 else "k_part_count"
+idx = [i for i, r in enumerate(rows) if key in r["Kernel_Name"]]
 start = idx[-1] if idx else max(0, len(rows) - 30)
 t0 = int(rows[start]["Start_Timestamp"])
 for r in rows[start:]:

@@ -32,6 +32,9 @@ struct keaki_hip_ctx {
   keaki_internal::DevBuf fb_scalars, fb_g1_gen, fb_g2_gen, fb_com, fb_tau, perm, g2gen_lines, gt_tab_a, gt_tab_b, gt_base, heavy;
   bool gt_b_ready = false;
   bool gt_a_valid = false;
+  bool gt_b_fallback = false;             // the wide table of B did not fit once: stay at 16 bits
+  uint64_t seen_com[8] = {};              // commitment of the last encap call and how many consecutive calls carried it
+  uint32_t seen_com_runs = 0;
   uint32_t gt_a_wb = 0, gt_b_wb = 0;      // window widths of the GT tables in gt_tab_a / gt_tab_b
   keaki_internal::DevBuf verify_lines, verify_io;   // kzg verify: [lines of g2 | lines of [tau]_2], small in/out block
   bool verify_tau_valid = false;

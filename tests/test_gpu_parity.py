@@ -365,6 +365,30 @@ def test_encap_gt_fixed_base_path_vs_oracle(oc, py, hip, rand_fr, monkeypatch):
     assert np.array_equal(gt2, gt3) and np.array_equal(ct2, ct3)
 
 
+def test_encap_small_calls_switch_to_gt_path_when_commitment_repeats(oc, py, rand_fr, monkeypatch):
+    """Without KEAKI_ENCAP_GT the third consecutive call with one commitment (any batch size) builds the tables of A = e(C, g2) and B and
+    takes the GT fixed-base path; later calls reuse them, a different commitment goes back to the per-item path. Own context (the policy is
+    per context); every call against the oracle."""
+    from keaki_amd.hip import KeakiHip
+    monkeypatch.delenv("KEAKI_ENCAP_GT", raising=False)
+    monkeypatch.delenv("KEAKI_GT_WB_B", raising=False)
+    h = KeakiHip(0)
+    try:
+        g1, g2 = oc.generators()
+        tau, c0, c1 = rand_fr(3, 281)
+        tau_g2 = h.g2_mul_batch(g2, mont(oc, [tau]))[0]
+        coms = [h.g1_mul_batch(g1, mont(oc, [c]))[0] for c in (c0, c1)]
+        seq = [0, 0, 0, 0, 0, 1, 0, 0, 1, 1, 1, 1]          # which commitment; the GT path starts at calls 3 and (table cached) 7, 8, and 12
+        for it, ci in enumerate(seq):
+            n = [1, 1, 1, 2, 37, 1, 1, 300, 1, 5, 1, 1][it]
+            A, V, Rr = (mont(oc, rand_fr(n, 290 + 3 * it + k)) for k in range(3))
+            ct, gt, key = h.encap_batch(coms[ci], tau_g2, A, V, Rr, 32)
+            ect, egt, ekey = oc.encap_batch(coms[ci], tau_g2, A, V, Rr, 32, threads=8)
+            assert np.array_equal(ct, ect) and np.array_equal(gt, egt) and np.array_equal(key, ekey), "call %d" % it
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize("wb", [16, 11])
 def test_encap_gt_path_other_window_widths(oc, py, rand_fr, monkeypatch, wb):
     """The constant-base GT table at another window width (16 bits is what a context falls back to when the 2.6 GB 20-bit table does not
