@@ -385,6 +385,17 @@ def test_encap_small_calls_switch_to_gt_path_when_commitment_repeats(oc, py, ran
             ct, gt, key = h.encap_batch(coms[ci], tau_g2, A, V, Rr, 32)
             ect, egt, ekey = oc.encap_batch(coms[ci], tau_g2, A, V, Rr, 32, threads=8)
             assert np.array_equal(ct, ect) and np.array_equal(gt, egt) and np.array_equal(key, ekey), "call %d" % it
+        # a context that built the 16-bit table of B for small calls widens it (and rebuilds A) when a large batch comes: sample against the oracle
+        n = 65536
+        rng = np.random.default_rng(5)
+        base = mont(oc, rand_fr(64, 400))
+        A, V, Rr = (base[rng.integers(0, 64, n)] for _ in range(3))
+        ct, gt, key = h.encap_batch(coms[1], tau_g2, A, V, Rr, 32)
+        idx = np.array([0, 1, 777, 40000, n - 1])
+        ect, egt, ekey = oc.encap_batch(coms[1], tau_g2, A[idx], V[idx], Rr[idx], 32, threads=8)
+        assert np.array_equal(ct[idx], ect) and np.array_equal(gt[idx], egt) and np.array_equal(key[idx], ekey)
+        ct2, gt2, key2 = h.encap_batch(coms[1], tau_g2, A[:300], V[:300], Rr[:300], 32)          # and small batches keep using the wide tables
+        assert np.array_equal(ct2, ct[:300]) and np.array_equal(gt2, gt[:300]) and np.array_equal(key2, key[:300])
     finally:
         h.close()
 
