@@ -125,11 +125,14 @@ constexpr u32 PART_MAX_FINE = 1u << PART_MAX_FINE_SHIFT;
 
 struct PartShape {
   u32 nbins;    // coarse bins = ceil(total buckets >> shift)
-  u32 nwg;      // pass-1 workgroups = ceil(n / tile)
+  u32 nwg;      // pass-1 workgroups = ceil(ntiles / sub)
   u32 shift;    // fine bits: a coarse bin covers 2^shift buckets
-  u32 tile;     // scalars per pass-1 workgroup (<= P1_THREADS, tile * W <= P1_CAP)
+  u32 tile;     // scalars per pass-1 tile (<= P1_THREADS, tile * W <= P1_CAP)
+  u32 ntiles;   // ceil(n / tile)
+  u32 sub;      // consecutive tiles per workgroup: the (bin, workgroup) table -- written bin-major, scanned, read back with a stride of nwg words --
+                // shrinks by this factor; the per-tile histograms stay (workgroup-major, contiguous)
 };
-inline bool part_make_shape(size_t n, u32 W, size_t nb, PartShape* ps, int shift_override = -1) {
+inline bool part_make_shape(size_t n, u32 W, size_t nb, PartShape* ps, int shift_override = -1, u32 sub_max = 8) {
   u32 lg = 0;
   while (((size_t)1 << lg) < nb) lg++;
   int shift = (int)(lg + 1) / 2 + 1;              // fine side one bit wider than the coarse side (4-byte vs 8-byte runs)
@@ -143,7 +146,12 @@ inline bool part_make_shape(size_t n, u32 W, size_t nb, PartShape* ps, int shift
   if (tile > P1_THREADS) tile = P1_THREADS;
   if (tile == 0) return false;
   ps->tile = tile;
-  ps->nwg = (u32)((n + tile - 1) / tile);
+  ps->ntiles = (u32)((n + tile - 1) / tile);
+  u32 sub = ps->ntiles / 1024u;                   // keep >= 1024 workgroups (4 per CU) when the input allows
+  if (sub > sub_max) sub = sub_max;
+  if (sub < 1) sub = 1;
+  ps->sub = sub;
+  ps->nwg = (ps->ntiles + sub - 1) / sub;
   return ps->nbins >= 1 && ps->nbins <= PART_MAX_BINS;
 }
 
@@ -166,25 +174,34 @@ __device__ __forceinline__ u32 lds_exclusive_scan(u32* a, u32 len, u32* wsum) {
   return tot;
 }
 
-// pass 1a: counts[bin * nwg + wg] (the order of the global scan) and counts_t[wg * nbins + bin] (read back, coalesced, by pass 1b)
+// pass 1a: counts[bin * nwg + wg] (the order of the global scan; one cell per bin and WORKGROUP = ps.sub consecutive tiles) and
+// counts_t[tile * nbins + bin] (per tile; read back, coalesced, by pass 1b)
 static __global__ void __launch_bounds__(P1_THREADS) k_part_count(const Fr* __restrict__ scalars, MsmShape s, PartShape ps, u32* __restrict__ counts,
                                                                   u32* __restrict__ counts_t) {
   __shared__ u32 hist[PART_MAX_BINS];
-  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) hist[b] = 0;
-  __syncthreads();
-  const u32 i = blockIdx.x * ps.tile + threadIdx.x;
-  if (threadIdx.x < ps.tile && i < s.n) {
-    msm_for_each_digit(scalars[i], s, [&](u32 w, u32 code) {
-      u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
-      atomicAdd(&hist[g >> ps.shift], 1u);
-    });
+  __shared__ u32 tot[PART_MAX_BINS];
+  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) tot[b] = 0;      // bin b is always handled by the same lane: no race on tot
+  for (u32 t = 0; t < ps.sub; t++) {
+    const u32 tile = blockIdx.x * ps.sub + t;
+    if (tile >= ps.ntiles) break;
+    for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) hist[b] = 0;
+    __syncthreads();
+    const u32 i = tile * ps.tile + threadIdx.x;
+    if (threadIdx.x < ps.tile && i < s.n) {
+      msm_for_each_digit(scalars[i], s, [&](u32 w, u32 code) {
+        u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
+        atomicAdd(&hist[g >> ps.shift], 1u);
+      });
+    }
+    __syncthreads();
+    for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) {
+      u32 c = hist[b];
+      counts_t[(size_t)tile * ps.nbins + b] = c;
+      tot[b] += c;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) {
-    u32 c = hist[b];
-    counts[(size_t)b * ps.nwg + blockIdx.x] = c;
-    counts_t[(size_t)blockIdx.x * ps.nbins + b] = c;
-  }
+  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) counts[(size_t)b * ps.nwg + blockIdx.x] = tot[b];
 }
 // pass 1b: entries[pos] = bucket id g << 32 | sign << 31 | point (table row) index
 static __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const Fr* __restrict__ scalars, MsmShape s, PartShape ps,
@@ -194,29 +211,42 @@ static __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const Fr* __
   __shared__ u32 cur[PART_MAX_BINS];
   __shared__ u32 goff[PART_MAX_BINS];
   __shared__ u32 wsum[P1_THREADS / 64];
-  // the tile's histogram was made by pass 1a: no second digit walk for it
-  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) {
-    cur[b] = counts_t[(size_t)blockIdx.x * ps.nbins + b];
-    goff[b] = offsets[(size_t)b * ps.nwg + blockIdx.x];
-  }
-  const u32 i = blockIdx.x * ps.tile + threadIdx.x;
-  const bool act = threadIdx.x < ps.tile && i < s.n;
-  Fr k;
-  if (act) k = scalars[i];
-  const u32 m = lds_exclusive_scan(cur, ps.nbins, wsum);     // cur[b] = start of bin b inside the tile
-  if (act) {
-    msm_for_each_digit(k, s, [&](u32 w, u32 code) {
-      u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
-      u32 pos = atomicAdd(&cur[g >> ps.shift], 1u);           // afterwards cur[b] = end of bin b = start of bin b + 1
-      ent[pos] = ((u64)g << 32) | (code & 0x80000000u) | (i + w * s.stride);
-    });
-  }
-  __syncthreads();
-  for (u32 q = threadIdx.x; q < m; q += P1_THREADS) {
-    u64 v = ent[q];
-    u32 b = (u32)(v >> 32) >> ps.shift;
-    u32 st = b ? cur[b - 1] : 0u;
-    entries[goff[b] + (q - st)] = v;
+  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) goff[b] = offsets[(size_t)b * ps.nwg + blockIdx.x];
+  for (u32 t = 0; t < ps.sub; t++) {
+    const u32 tile = blockIdx.x * ps.sub + t;
+    if (tile >= ps.ntiles) break;
+    // the tile's histogram was made by pass 1a: no second digit walk for it
+    for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) cur[b] = counts_t[(size_t)tile * ps.nbins + b];
+    const u32 i = tile * ps.tile + threadIdx.x;
+    const bool act = threadIdx.x < ps.tile && i < s.n;
+    Fr k;
+    if (act) k = scalars[i];
+    const u32 m = lds_exclusive_scan(cur, ps.nbins, wsum);     // cur[b] = start of bin b inside the tile
+    if (act) {
+      msm_for_each_digit(k, s, [&](u32 w, u32 code) {
+        u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
+        u32 pos = atomicAdd(&cur[g >> ps.shift], 1u);           // afterwards cur[b] = end of bin b = start of bin b + 1
+        ent[pos] = ((u64)g << 32) | (code & 0x80000000u) | (i + w * s.stride);
+      });
+    }
+    __syncthreads();
+    for (u32 q = threadIdx.x; q < m; q += P1_THREADS) {
+      u64 v = ent[q];
+      u32 b = (u32)(v >> 32) >> ps.shift;
+      u32 st = b ? cur[b - 1] : 0u;
+      entries[goff[b] + (q - st)] = v;
+    }
+    __syncthreads();
+    if (t + 1 < ps.sub) {                                       // the next tile of this workgroup continues every bin's run
+      u32 add0 = 0, add1 = 0;
+      const u32 b0 = threadIdx.x, b1 = threadIdx.x + P1_THREADS;
+      if (b0 < ps.nbins) add0 = cur[b0] - (b0 ? cur[b0 - 1] : 0u);
+      if (b1 < ps.nbins) add1 = cur[b1] - cur[b1 - 1];
+      __syncthreads();
+      if (b0 < ps.nbins) goff[b0] += add0;
+      if (b1 < ps.nbins) goff[b1] += add1;
+      __syncthreads();
+    }
   }
 }
 // grand total of entries = exclusive offset of the last (bin, workgroup) cell + its count

@@ -79,7 +79,8 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   PartShape ps;
   int shift_override = -1;
   if (const char* e = getenv("KEAKI_PART_SHIFT")) shift_override = atoi(e);
-  if (!part_make_shape(n, s.W, nb, &ps, shift_override))
+  static const u32 sub_max = getenv("KEAKI_P1_SUB") ? (u32)atoi(getenv("KEAKI_P1_SUB")) : 8u;
+  if (!part_make_shape(n, s.W, nb, &ps, shift_override, sub_max ? sub_max : 1u))
     return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: %zu buckets / %u windows exceed the partition's LDS budget (window too large)", nb, s.W);
   const size_t ncounts = (size_t)ps.nbins * ps.nwg;
   if (ncounts >= 4294967295ull) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: partition table too large");
@@ -87,7 +88,7 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   ST_TRY(reserve(ctx, ctx->sorted, n * s.W * 4));
   ST_TRY(reserve(ctx, ctx->hist, nb * 4));             // per-bucket counts
   ST_TRY(reserve(ctx, ctx->offsets, nb * 4));          // per-bucket start offsets
-  ST_TRY(reserve(ctx, ctx->cursor, (ncounts * 3 + 4) * 4));  // [counts | exclusive scan | total | counts, workgroup-major] of the (bin, workgroup) table
+  ST_TRY(reserve(ctx, ctx->cursor, (ncounts * 2 + 4 + (size_t)ps.nbins * ps.ntiles) * 4));  // [counts | exclusive scan | total] of the (bin, workgroup) table | per-tile counts, tile-major
   ST_TRY(reserve(ctx, ctx->buckets, nb * sizeof(Xyzz<F>)));
   ST_TRY(reserve(ctx, ctx->partials, ((size_t)rs.W * chunks + (size_t)rs.W * 256) * sizeof(Xyzz<F>)));
   u64* entries = (u64*)ctx->digits.p;
