@@ -174,34 +174,32 @@ __device__ __forceinline__ u32 lds_exclusive_scan(u32* a, u32 len, u32* wsum) {
   return tot;
 }
 
-// pass 1a: counts[bin * nwg + wg] (the order of the global scan; one cell per bin and WORKGROUP = ps.sub consecutive tiles) and
-// counts_t[tile * nbins + bin] (per tile; read back, coalesced, by pass 1b)
-static __global__ void __launch_bounds__(P1_THREADS) k_part_count(const Fr* __restrict__ scalars, MsmShape s, PartShape ps, u32* __restrict__ counts,
-                                                                  u32* __restrict__ counts_t) {
+// pass 1a: counts_t[tile * nbins + bin], one workgroup per tile (contiguous rows; read back, coalesced, by pass 1b) ...
+static __global__ void __launch_bounds__(P1_THREADS) k_part_count(const Fr* __restrict__ scalars, MsmShape s, PartShape ps, u32* __restrict__ counts_t) {
   __shared__ u32 hist[PART_MAX_BINS];
-  __shared__ u32 tot[PART_MAX_BINS];
-  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) tot[b] = 0;      // bin b is always handled by the same lane: no race on tot
-  for (u32 t = 0; t < ps.sub; t++) {
-    const u32 tile = blockIdx.x * ps.sub + t;
-    if (tile >= ps.ntiles) break;
-    for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) hist[b] = 0;
-    __syncthreads();
-    const u32 i = tile * ps.tile + threadIdx.x;
-    if (threadIdx.x < ps.tile && i < s.n) {
-      msm_for_each_digit(scalars[i], s, [&](u32 w, u32 code) {
-        u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
-        atomicAdd(&hist[g >> ps.shift], 1u);
-      });
-    }
-    __syncthreads();
-    for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) {
-      u32 c = hist[b];
-      counts_t[(size_t)tile * ps.nbins + b] = c;
-      tot[b] += c;
-    }
-    __syncthreads();
+  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) hist[b] = 0;
+  __syncthreads();
+  const u32 i = blockIdx.x * ps.tile + threadIdx.x;
+  if (threadIdx.x < ps.tile && i < s.n) {
+    msm_for_each_digit(scalars[i], s, [&](u32 w, u32 code) {
+      u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
+      atomicAdd(&hist[g >> ps.shift], 1u);
+    });
   }
-  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) counts[(size_t)b * ps.nwg + blockIdx.x] = tot[b];
+  __syncthreads();
+  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) counts_t[(size_t)blockIdx.x * ps.nbins + b] = hist[b];
+}
+// ... and counts[bin * nwg + wg] (the order of the global scan): one cell per bin and pass-1b WORKGROUP = ps.sub consecutive tiles
+static __global__ void __launch_bounds__(256) k_part_supercount(const u32* __restrict__ counts_t, PartShape ps, u32* __restrict__ counts) {
+  const u32 wg = blockIdx.y;
+  const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= ps.nbins) return;
+  u32 tot = 0;
+  for (u32 t = 0; t < ps.sub; t++) {
+    const u32 tile = wg * ps.sub + t;
+    if (tile < ps.ntiles) tot += counts_t[(size_t)tile * ps.nbins + b];
+  }
+  counts[(size_t)b * ps.nwg + wg] = tot;
 }
 // pass 1b: entries[pos] = bucket id g << 32 | sign << 31 | point (table row) index
 static __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const Fr* __restrict__ scalars, MsmShape s, PartShape ps,

@@ -96,7 +96,8 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   u32 *pcounts = (u32*)ctx->cursor.p, *poffsets = pcounts + ncounts, *pcounts_t = poffsets + ncounts + 4;
   Xyzz<F>* buckets = (Xyzz<F>*)ctx->buckets.p;
   Xyzz<F>* partials = (Xyzz<F>*)ctx->partials.p;
-  hipLaunchKernelGGL(k_part_count, dim3(ps.nwg), dim3(P1_THREADS), 0, st, (const Fr*)d_scalars, s, ps, pcounts, pcounts_t);
+  hipLaunchKernelGGL(k_part_count, dim3(ps.ntiles), dim3(P1_THREADS), 0, st, (const Fr*)d_scalars, s, ps, pcounts_t);
+  hipLaunchKernelGGL(k_part_supercount, dim3(cdiv(ps.nbins, 256), ps.nwg), dim3(256), 0, st, (const u32*)pcounts_t, ps, pcounts);
   ST_TRY(launch_check(ctx, "part_count"));
   ST_TRY(device_scan(ctx, pcounts, (u32)ncounts, poffsets));
   hipLaunchKernelGGL(k_part_scatter, dim3(ps.nwg), dim3(P1_THREADS), 0, st, (const Fr*)d_scalars, s, ps, (const u32*)poffsets, (const u32*)pcounts_t, entries);
