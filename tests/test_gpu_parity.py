@@ -603,3 +603,52 @@ def test_kzg_open_quotient_on_device(oc, py, hip, rand_fr, n):
             assert np.array_equal(jac_to_aff(proof0), oc.msm_g1(pts[:n - 1], mont(oc, c[1:])))
     finally:
         srs.free()
+
+
+def test_concurrent_host_threads_one_context_and_two(oc, hip, rand_fr):
+    """The ABI serialises calls on one context (a mutex per context) and contexts are independent: four host threads -- two on the shared
+    context, two on contexts of their own -- run MSMs, pairings and encapsulations at the same time (ctypes releases the GIL); every result
+    against the oracle values computed beforehand."""
+    import threading
+    from keaki_amd.hip import KeakiHip
+    g1, g2 = oc.generators()
+    n = 3000
+    pts = hip.g1_mul_batch(g1, mont(oc, rand_fr(n, 7001)))
+    jobs = []
+    for k in range(4):
+        sc = mont(oc, rand_fr(n, 7010 + k))
+        P = hip.g1_mul_batch(g1, mont(oc, rand_fr(8, 7020 + k)))
+        Q = hip.g2_mul_batch(g2, mont(oc, rand_fr(8, 7030 + k)))
+        com = hip.g1_mul_batch(g1, mont(oc, rand_fr(1, 7040 + k)))[0]
+        tau_g2 = hip.g2_mul_batch(g2, mont(oc, rand_fr(1, 7050 + k)))[0]
+        A, V, Rr = (mont(oc, rand_fr(40, 7060 + 3 * k + j)) for j in range(3))
+        jobs.append({"sc": sc, "P": P, "Q": Q, "com": com, "tau": tau_g2, "A": A, "V": V, "R": Rr,
+                     "msm": oc.msm_g1(pts, sc, threads=8), "gt": oc.pairing_batch(P, Q, threads=8),
+                     "enc": oc.encap_batch(com, tau_g2, A, V, Rr, 32, threads=8)})
+    own = [KeakiHip(0), KeakiHip(0)]
+    ctxs = [hip, hip, own[0], own[1]]
+    errors = []
+
+    def work(k):
+        try:
+            h, j = ctxs[k], jobs[k]
+            srs = h.srs_g1_upload(pts)
+            try:
+                for _ in range(3):
+                    assert np.array_equal(jac_to_aff(h.msm_g1(srs, j["sc"])), j["msm"]), "msm"
+                    assert np.array_equal(h.pairing_batch(j["P"], j["Q"]), j["gt"]), "pairing"
+                    ct, gt, key = h.encap_batch(j["com"], j["tau"], j["A"], j["V"], j["R"], 32)
+                    assert np.array_equal(ct, j["enc"][0]) and np.array_equal(gt, j["enc"][1]) and np.array_equal(key, j["enc"][2]), "encap"
+            finally:
+                srs.free()
+        except Exception as e:                       # noqa: BLE001 -- reported by the main thread
+            errors.append("thread %d: %r" % (k, e))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for h in own:
+        h.close()
+    assert not errors, errors
