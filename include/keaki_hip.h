@@ -27,8 +27,11 @@
  *  - A ctx is bound to one GPU. Multi-GPU = one ctx (one process) per GPU: each rank runs
  *    msm on its contiguous chunk of (scalar, point) pairs, the 96-byte partial sums are exchanged
  *    with RCCL all-gather by the caller, and keaki_hip_g1_sum_dev adds them.
- *  - Thread-safety: a ctx serialises calls internally (one mutex); use one ctx per host thread for
- *    concurrency.
+ *  - Thread-safety: a ctx serialises calls internally (one recursive mutex, held from the first staging
+ *    copy of a host-pointer call to its last download, so the shared staging buffers belong to one
+ *    call at a time); calls from several host threads on one ctx are safe and run one after another.
+ *    Use one ctx per host thread for concurrency. Handles (keaki_hip_srs_*) must not be freed while
+ *    another thread still uses them.
  */
 #ifndef KEAKI_HIP_H
 #define KEAKI_HIP_H
@@ -55,7 +58,14 @@ typedef struct keaki_hip_srs_g1 keaki_hip_srs_g1; /* device-resident [tau^i]_1, 
 typedef struct keaki_hip_srs_g2 keaki_hip_srs_g2; /* device-resident G2 bases, affine  */
 
 /* ---- context ------------------------------------------------------------------------------- */
-/* device: HIP device ordinal. stream: a hipStream_t to enqueue on, or NULL for a private stream. */
+/* device: HIP device ordinal. stream: the hipStream_t every call of this ctx enqueues on:
+ *   KEAKI_HIP_STREAM_PRIVATE  (NULL)  the ctx creates its own NON-BLOCKING stream: unordered against the caller's streams AND against the
+ *                                      legacy default stream -- order *_dev calls with keaki_hip_synchronize or events;
+ *   KEAKI_HIP_STREAM_LEGACY   (= hipStreamLegacy)  the legacy default ("null") stream of the device, which a NULL handle cannot name here;
+ *   any other value                    a stream the caller created (e.g. the handle of a torch.cuda.Stream): *_dev calls are then ordered
+ *                                      with everything else the caller enqueues there (RCCL collectives, copies). */
+#define KEAKI_HIP_STREAM_PRIVATE ((void*)0)
+#define KEAKI_HIP_STREAM_LEGACY ((void*)1)
 keaki_status keaki_hip_ctx_create(int32_t device, void* stream, keaki_hip_ctx** out);
 void keaki_hip_ctx_destroy(keaki_hip_ctx* ctx);
 const char* keaki_hip_last_error(const keaki_hip_ctx* ctx); /* ctx may be NULL: last create error */
@@ -66,6 +76,10 @@ const char* keaki_hip_version(void);
 keaki_status keaki_hip_srs_g1_upload(keaki_hip_ctx* ctx, const uint64_t* points_aff, size_t n, keaki_hip_srs_g1** out);
 /* wraps caller-owned device memory holding n affine points (not freed by _free) */
 keaki_status keaki_hip_srs_g1_wrap_dev(keaki_hip_ctx* ctx, const void* d_points_aff, size_t n, keaki_hip_srs_g1** out);
+/* non-owning view of points [offset, offset + n) of `srs` (which must outlive it): the contiguous chunk one rank owns when commit's MSM
+ * (src/kzg.rs:98) is sharded by point range over several GPUs; free it with keaki_hip_srs_g1_free. keaki_hip_srs_g1_precompute on
+ * the view tabulates the chunk only. */
+keaki_status keaki_hip_srs_g1_slice(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, size_t offset, size_t n, keaki_hip_srs_g1** out);
 size_t keaki_hip_srs_g1_len(const keaki_hip_srs_g1* srs);
 /* One-time precomputation for a fixed SRS (KZG bases never change): builds the window tables
  * table[w][i] = 2^(bit offset of window w) * P_i (affine, W x n x 64 bytes of HBM; W = 12..14 for n >= 2^20) so that all

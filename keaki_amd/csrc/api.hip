@@ -40,6 +40,19 @@ keaki_status fail(keaki_hip_ctx* ctx, keaki_status code, const char* fmt, ...) {
   return code;
 }
 
+keaki_status dev_alloc(keaki_hip_ctx* ctx, void** p, size_t bytes) {
+  if (const char* lim = getenv("KEAKI_TEST_ALLOC_LIMIT")) {
+    if (bytes > (size_t)strtoull(lim, nullptr, 10))
+      return fail(ctx, KEAKI_ERR_OOM, "allocation of %zu bytes refused by KEAKI_TEST_ALLOC_LIMIT=%s", bytes, lim);
+  }
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(ctx, e == hipErrorOutOfMemory ? KEAKI_ERR_OOM : KEAKI_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+  }
+  return KEAKI_OK;
+}
+
 keaki_status reserve(keaki_hip_ctx* ctx, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap) return KEAKI_OK;
   if (b.p) {
@@ -49,7 +62,7 @@ keaki_status reserve(keaki_hip_ctx* ctx, DevBuf& b, size_t bytes) {
     b.p = nullptr; b.cap = 0;
   }
   size_t want = bytes + bytes / 8 + 256;
-  HIP_TRY(ctx, hipMalloc(&b.p, want));
+  ST_TRY(dev_alloc(ctx, &b.p, want));
   b.cap = want;
   return KEAKI_OK;
 }
@@ -86,7 +99,7 @@ keaki_status download(keaki_hip_ctx* ctx, void* host, const void* dev, size_t by
 
 #define CTX_GUARD(ctx)                                \
   if (!(ctx)) return KEAKI_ERR_BAD_ARG;               \
-  std::lock_guard<std::mutex> lock_((ctx)->mu);       \
+  std::lock_guard<std::recursive_mutex> lock_((ctx)->mu);       \
   if (hipSetDevice((ctx)->device) != hipSuccess) return fail(ctx, KEAKI_ERR_HIP, "hipSetDevice(%d) failed", (ctx)->device)
 
 }  // namespace
@@ -170,6 +183,14 @@ keaki_status keaki_hip_srs_g1_wrap_dev(keaki_hip_ctx* ctx, const void* d_points_
   CTX_GUARD(ctx);
   if (!out || (n && !d_points_aff)) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g1_wrap_dev: null pointer");
   *out = new keaki_hip_srs_g1{d_points_aff, n, false};
+  return KEAKI_OK;
+}
+// non-owning view of points [offset, offset + n) of an uploaded SRS: the chunk a rank owns when an MSM is sharded by point range
+keaki_status keaki_hip_srs_g1_slice(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, size_t offset, size_t n, keaki_hip_srs_g1** out) {
+  CTX_GUARD(ctx);
+  if (!srs || !out) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g1_slice: null pointer");
+  if (offset > srs->n || n > srs->n - offset) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g1_slice: [%zu, %zu) is outside the %zu points of the SRS", offset, offset + n, srs->n);
+  *out = new keaki_hip_srs_g1{(const char*)srs->d + offset * G1_AFF_BYTES, n, false};
   return KEAKI_OK;
 }
 size_t keaki_hip_srs_g1_len(const keaki_hip_srs_g1* srs) { return srs ? srs->n : 0; }
@@ -282,30 +303,24 @@ keaki_status keaki_hip_g2_mul_batch_dev(keaki_hip_ctx* ctx, const void* d_points
 }
 keaki_status keaki_hip_g1_mul_batch(keaki_hip_ctx* ctx, const uint64_t* points_aff, int32_t point_stride, const uint64_t* scalars, size_t n,
                                     uint64_t* out_aff) {
-  {
-    CTX_GUARD(ctx);
-    if (n == 0) return KEAKI_OK;
-    if (!points_aff || !scalars || !out_aff || (point_stride != 0 && point_stride != 1)) return fail(ctx, KEAKI_ERR_BAD_ARG, "g1_mul_batch: bad argument");
-    ST_TRY(upload(ctx, ctx->io_a, points_aff, (point_stride ? n : 1) * 64));
-    ST_TRY(upload(ctx, ctx->io_b, scalars, n * 32));
-    ST_TRY(reserve(ctx, ctx->io_c, n * 64));
-  }
+  CTX_GUARD(ctx);                 // held across stage -> kernel -> download: io_a/io_b/io_c belong to this call until it returns
+  if (n == 0) return KEAKI_OK;
+  if (!points_aff || !scalars || !out_aff || (point_stride != 0 && point_stride != 1)) return fail(ctx, KEAKI_ERR_BAD_ARG, "g1_mul_batch: bad argument");
+  ST_TRY(upload(ctx, ctx->io_a, points_aff, (point_stride ? n : 1) * 64));
+  ST_TRY(upload(ctx, ctx->io_b, scalars, n * 32));
+  ST_TRY(reserve(ctx, ctx->io_c, n * 64));
   ST_TRY(keaki_hip_g1_mul_batch_dev(ctx, ctx->io_a.p, point_stride, ctx->io_b.p, n, ctx->io_c.p));
-  CTX_GUARD(ctx);
   return download(ctx, out_aff, ctx->io_c.p, n * 64);
 }
 keaki_status keaki_hip_g2_mul_batch(keaki_hip_ctx* ctx, const uint64_t* points_aff, int32_t point_stride, const uint64_t* scalars, size_t n,
                                     uint64_t* out_aff) {
-  {
-    CTX_GUARD(ctx);
-    if (n == 0) return KEAKI_OK;
-    if (!points_aff || !scalars || !out_aff || (point_stride != 0 && point_stride != 1)) return fail(ctx, KEAKI_ERR_BAD_ARG, "g2_mul_batch: bad argument");
-    ST_TRY(upload(ctx, ctx->io_a, points_aff, (point_stride ? n : 1) * 128));
-    ST_TRY(upload(ctx, ctx->io_b, scalars, n * 32));
-    ST_TRY(reserve(ctx, ctx->io_c, n * 128));
-  }
+  CTX_GUARD(ctx);                 // held across stage -> kernel -> download: io_a/io_b/io_c belong to this call until it returns
+  if (n == 0) return KEAKI_OK;
+  if (!points_aff || !scalars || !out_aff || (point_stride != 0 && point_stride != 1)) return fail(ctx, KEAKI_ERR_BAD_ARG, "g2_mul_batch: bad argument");
+  ST_TRY(upload(ctx, ctx->io_a, points_aff, (point_stride ? n : 1) * 128));
+  ST_TRY(upload(ctx, ctx->io_b, scalars, n * 32));
+  ST_TRY(reserve(ctx, ctx->io_c, n * 128));
   ST_TRY(keaki_hip_g2_mul_batch_dev(ctx, ctx->io_a.p, point_stride, ctx->io_b.p, n, ctx->io_c.p));
-  CTX_GUARD(ctx);
   return download(ctx, out_aff, ctx->io_c.p, n * 128);
 }
 
@@ -319,16 +334,13 @@ keaki_status keaki_hip_pairing_batch_dev(keaki_hip_ctx* ctx, const void* d_g1_af
 }
 keaki_status keaki_hip_pairing_batch(keaki_hip_ctx* ctx, const uint64_t* g1_aff, const uint64_t* g2_aff, int32_t g2_stride, size_t n,
                                      uint8_t* gt_out) {
-  {
-    CTX_GUARD(ctx);
-    if (n == 0) return KEAKI_OK;
-    if (!g1_aff || !g2_aff || !gt_out || (g2_stride != 0 && g2_stride != 1)) return fail(ctx, KEAKI_ERR_BAD_ARG, "pairing_batch: bad argument");
-    ST_TRY(upload(ctx, ctx->io_a, g1_aff, n * 64));
-    ST_TRY(upload(ctx, ctx->io_b, g2_aff, (g2_stride ? n : 1) * 128));
-    ST_TRY(reserve(ctx, ctx->io_c, n * 384));
-  }
-  ST_TRY(keaki_hip_pairing_batch_dev(ctx, ctx->io_a.p, ctx->io_b.p, g2_stride, n, ctx->io_c.p));
   CTX_GUARD(ctx);
+  if (n == 0) return KEAKI_OK;
+  if (!g1_aff || !g2_aff || !gt_out || (g2_stride != 0 && g2_stride != 1)) return fail(ctx, KEAKI_ERR_BAD_ARG, "pairing_batch: bad argument");
+  ST_TRY(upload(ctx, ctx->io_a, g1_aff, n * 64));
+  ST_TRY(upload(ctx, ctx->io_b, g2_aff, (g2_stride ? n : 1) * 128));
+  ST_TRY(reserve(ctx, ctx->io_c, n * 384));
+  ST_TRY(keaki_hip_pairing_batch_dev(ctx, ctx->io_a.p, ctx->io_b.p, g2_stride, n, ctx->io_c.p));
   return download(ctx, gt_out, ctx->io_c.p, n * 384);
 }
 
@@ -509,28 +521,22 @@ keaki_status keaki_hip_decap_batch_dev(keaki_hip_ctx* ctx, const void* d_proofs_
 keaki_status keaki_hip_encap_batch(keaki_hip_ctx* ctx, const uint64_t* com_aff, const uint64_t* tau_g2_aff, const uint64_t* points,
                                    const uint64_t* values, const uint64_t* r, size_t n, uint64_t* ct_out_aff, uint8_t* gt_out, uint8_t* key_out,
                                    size_t msg_len) {
-  size_t off_tau, off_pts, off_val, off_r, off_ct, off_gt, off_key, total;
-  {
-    CTX_GUARD(ctx);
-    if (n == 0) return KEAKI_OK;
-    if (!com_aff || !tau_g2_aff || !points || !values || !r || !ct_out_aff || (!gt_out && !key_out) || msg_len > 65536)
-      return fail(ctx, KEAKI_ERR_BAD_ARG, "encap_batch: bad argument");
-    off_tau = 64; off_pts = off_tau + 128; off_val = off_pts + n * 32; off_r = off_val + n * 32; off_ct = off_r + n * 32;
-    off_gt = off_ct + n * 128; off_key = off_gt + n * 384; total = off_key + n * msg_len + 16;
-    ST_TRY(reserve(ctx, ctx->io_a, total));
-    char* base = (char*)ctx->io_a.p;
-    hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(base, com_aff, 64, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(base + off_tau, tau_g2_aff, 128, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(base + off_pts, points, n * 32, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(base + off_val, values, n * 32, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(base + off_r, r, n * 32, hipMemcpyHostToDevice, st));
-  }
+  CTX_GUARD(ctx);                 // one lock from staging to the last download (the *_dev call below re-enters it)
+  if (n == 0) return KEAKI_OK;
+  if (!com_aff || !tau_g2_aff || !points || !values || !r || !ct_out_aff || (!gt_out && !key_out) || msg_len > 65536)
+    return fail(ctx, KEAKI_ERR_BAD_ARG, "encap_batch: bad argument");
+  const size_t off_tau = 64, off_pts = off_tau + 128, off_val = off_pts + n * 32, off_r = off_val + n * 32, off_ct = off_r + n * 32,
+               off_gt = off_ct + n * 128, off_key = off_gt + n * 384, total = off_key + n * msg_len + 16;
+  ST_TRY(reserve(ctx, ctx->io_a, total));
   char* base = (char*)ctx->io_a.p;
+  hipStream_t st = ctx->stream;
+  HIP_TRY(ctx, hipMemcpyAsync(base, com_aff, 64, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(base + off_tau, tau_g2_aff, 128, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(base + off_pts, points, n * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(base + off_val, values, n * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(base + off_r, r, n * 32, hipMemcpyHostToDevice, st));
   ST_TRY(keaki_hip_encap_batch_dev(ctx, base, base + off_tau, base + off_pts, base + off_val, base + off_r, n, base + off_ct, base + off_gt,
                                    key_out ? base + off_key : nullptr, msg_len));
-  CTX_GUARD(ctx);
-  hipStream_t st = ctx->stream;
   HIP_TRY(ctx, hipMemcpyAsync(ct_out_aff, base + off_ct, n * 128, hipMemcpyDeviceToHost, st));
   if (gt_out) HIP_TRY(ctx, hipMemcpyAsync(gt_out, base + off_gt, n * 384, hipMemcpyDeviceToHost, st));
   if (key_out && msg_len) HIP_TRY(ctx, hipMemcpyAsync(key_out, base + off_key, n * msg_len, hipMemcpyDeviceToHost, st));
@@ -539,21 +545,16 @@ keaki_status keaki_hip_encap_batch(keaki_hip_ctx* ctx, const uint64_t* com_aff, 
 }
 keaki_status keaki_hip_decap_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_aff, const uint64_t* cts_aff, size_t n, uint8_t* gt_out,
                                    uint8_t* key_out, size_t msg_len) {
-  size_t off_ct, off_gt, off_key, total;
-  {
-    CTX_GUARD(ctx);
-    if (n == 0) return KEAKI_OK;
-    if (!proofs_aff || !cts_aff || (!gt_out && !key_out) || msg_len > 65536) return fail(ctx, KEAKI_ERR_BAD_ARG, "decap_batch: bad argument");
-    off_ct = n * 64; off_gt = off_ct + n * 128; off_key = off_gt + n * 384; total = off_key + n * msg_len + 16;
-    ST_TRY(reserve(ctx, ctx->io_a, total));
-    char* base = (char*)ctx->io_a.p;
-    HIP_TRY(ctx, hipMemcpyAsync(base, proofs_aff, n * 64, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(base + off_ct, cts_aff, n * 128, hipMemcpyHostToDevice, ctx->stream));
-  }
-  char* base = (char*)ctx->io_a.p;
-  ST_TRY(keaki_hip_decap_batch_dev(ctx, base, base + off_ct, n, base + off_gt, key_out ? base + off_key : nullptr, msg_len));
   CTX_GUARD(ctx);
+  if (n == 0) return KEAKI_OK;
+  if (!proofs_aff || !cts_aff || (!gt_out && !key_out) || msg_len > 65536) return fail(ctx, KEAKI_ERR_BAD_ARG, "decap_batch: bad argument");
+  const size_t off_ct = n * 64, off_gt = off_ct + n * 128, off_key = off_gt + n * 384, total = off_key + n * msg_len + 16;
+  ST_TRY(reserve(ctx, ctx->io_a, total));
+  char* base = (char*)ctx->io_a.p;
   hipStream_t st = ctx->stream;
+  HIP_TRY(ctx, hipMemcpyAsync(base, proofs_aff, n * 64, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(base + off_ct, cts_aff, n * 128, hipMemcpyHostToDevice, st));
+  ST_TRY(keaki_hip_decap_batch_dev(ctx, base, base + off_ct, n, base + off_gt, key_out ? base + off_key : nullptr, msg_len));
   if (gt_out) HIP_TRY(ctx, hipMemcpyAsync(gt_out, base + off_gt, n * 384, hipMemcpyDeviceToHost, st));
   if (key_out && msg_len) HIP_TRY(ctx, hipMemcpyAsync(key_out, base + off_key, n * msg_len, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -687,12 +688,13 @@ keaki_status keaki_hip_kzg_verify(keaki_hip_ctx* ctx, const uint64_t* com_aff, c
   // io block: [g2 128 | tau_g2 128 | com 64 | proof 64 | value 32 | point 32 | pairing inputs 128 | gt 768]
   constexpr size_t O_Q = 0, O_IN = 256, O_P = O_IN + 192, O_GT = O_P + 128, IO_BYTES = O_GT + 768;
   const size_t LB = g2_prepared_bytes();
-  if (!ctx->verify_lines.p) {
+  if (!ctx->verify_ready) {
+    ctx->verify_tau_valid = false;
     ST_TRY(reserve(ctx, ctx->verify_lines, 2 * LB));
     ST_TRY(reserve(ctx, ctx->verify_io, IO_BYTES));
     ST_TRY(g2_generator_to(ctx, (char*)ctx->verify_io.p + O_Q));
     ST_TRY(g2_prepare_run(ctx, (char*)ctx->verify_io.p + O_Q, ctx->verify_lines.p));
-    ctx->verify_tau_valid = false;
+    ctx->verify_ready = true;               // only after every step succeeded (a failed init is retried by the next call)
   }
   char* io = (char*)ctx->verify_io.p;
   if (!ctx->verify_tau_valid || memcmp(ctx->verify_tau_pt, tau_g2_aff, 128) != 0) {

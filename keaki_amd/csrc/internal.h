@@ -24,7 +24,7 @@ struct keaki_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  std::mutex mu;
+  std::recursive_mutex mu;   // recursive: host-pointer entry points hold it across stage -> *_dev -> download
   std::string err;
   // grow-only workspaces (all used in stream order)
   keaki_internal::DevBuf digits, hist, offsets, cursor, sorted, buckets, partials, wsums, bsums, tmp_a, tmp_b, tmp_c, io_a, io_b, io_c, io_d, io_e;
@@ -37,6 +37,7 @@ struct keaki_hip_ctx {
   uint32_t seen_com_runs = 0;
   uint32_t gt_a_wb = 0, gt_b_wb = 0;      // window widths of the GT tables in gt_tab_a / gt_tab_b
   keaki_internal::DevBuf verify_lines, verify_io;   // kzg verify: [lines of g2 | lines of [tau]_2], small in/out block
+  bool verify_ready = false;              // set only after every init step of kzg verify succeeded
   bool verify_tau_valid = false;
   uint64_t verify_tau_pt[16] = {};
   bool fb_tau_valid = false;          // window table of [tau]_2 (encap ciphertext side) is for this point
@@ -59,6 +60,9 @@ namespace keaki_internal {
 
 keaki_status fail(keaki_hip_ctx* ctx, keaki_status code, const char* fmt, ...);
 keaki_status reserve(keaki_hip_ctx* ctx, DevBuf& b, size_t bytes);
+// hipMalloc behind the library's one allocation gate. KEAKI_TEST_ALLOC_LIMIT=<bytes> (tests only) makes every single allocation above
+// that size fail with KEAKI_ERR_OOM, which is how the optional-memory fallbacks (SRS window tables, the wide GT table) are exercised.
+keaki_status dev_alloc(keaki_hip_ctx* ctx, void** p, size_t bytes);
 keaki_status launch_check(keaki_hip_ctx* ctx, const char* what);
 inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
 

@@ -395,14 +395,39 @@ static __global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(const u32* _
 // by size (counting sort on min(count, CNT_BINS-1), largest first) gives every wave equal trip counts
 // and starts the heaviest buckets first. perm[t] = bucket handled by global lane t.
 constexpr u32 CNT_BINS = 1024;
-static __global__ void __launch_bounds__(256) k_cnt_hist(const u32* __restrict__ counts, u32 nb, u32* __restrict__ ghist) {
+// Heavy buckets (see below) are found here, BY COUNT, while the counts are being read anyway: every bucket with >= HEAVY_MIN points
+// takes a slot in hv->bucket[] and a contiguous range of ceil(count / HEAVY_SLICE) slice ids.
+constexpr u32 HEAVY_MIN = 8192, HEAVY_SLICE = 16384;
+struct HeavyList {
+  u32 n;            // heavy buckets found
+  u32 nslices;      // slice ids handed out
+};
+// capacities (host side, msm_host.cuh): cap = pairs / HEAVY_MIN + 1 >= the number of buckets that can hold HEAVY_MIN pairs, and
+// slice_cap = cap + pairs / HEAVY_SLICE + 1 >= sum of ceil(count / HEAVY_SLICE) over them: neither can overflow; the bounds checks
+// in the kernels are belt and braces.
+static __global__ void __launch_bounds__(256) k_cnt_hist(const u32* __restrict__ counts, u32 nb, u32* __restrict__ ghist, HeavyList* __restrict__ hv,
+                                                         u32 hv_cap, u32 hv_slice_cap, u32* __restrict__ hv_bucket, u32* __restrict__ hv_first,
+                                                         u32* __restrict__ hv_owner) {
   __shared__ u32 h[CNT_BINS];
   for (u32 b = threadIdx.x; b < CNT_BINS; b += 256) h[b] = 0;
   __syncthreads();
   const u32 base = blockIdx.x * 1024;
   for (u32 t = threadIdx.x; t < 1024; t += 256) {
     u32 g = base + t;
-    if (g < nb) { u32 c = counts[g]; atomicAdd(&h[c < CNT_BINS - 1 ? c : CNT_BINS - 1], 1u); }
+    if (g < nb) {
+      u32 c = counts[g];
+      atomicAdd(&h[c < CNT_BINS - 1 ? c : CNT_BINS - 1], 1u);
+      if (c >= HEAVY_MIN) {
+        const u32 nsl = (c + HEAVY_SLICE - 1) / HEAVY_SLICE;
+        const u32 slot = atomicAdd(&hv->n, 1u);
+        if (slot < hv_cap) {
+          const u32 first = atomicAdd(&hv->nslices, nsl);
+          hv_bucket[slot] = g;
+          hv_first[slot] = first;
+          for (u32 k = 0; k < nsl && first + k < hv_slice_cap; k++) hv_owner[first + k] = slot;
+        }
+      }
+    }
   }
   __syncthreads();
   for (u32 b = threadIdx.x; b < CNT_BINS; b += 256) if (h[b]) atomicAdd(&ghist[b], h[b]);
@@ -447,49 +472,64 @@ static __global__ void __launch_bounds__(256) k_cnt_scatter(const u32* __restric
 
 // ---- heavy buckets ----------------------------------------------------------------------------------------------------
 // Structured scalars (0/1 coefficients, repeated values) can put millions of points into ONE bucket; a single lane would
-// need minutes for it. Buckets come size-sorted (perm[0] is the largest), so the first HEAVY_MAX entries of perm are
-// examined by a 2-D grid: block (b, s) accumulates slice s of bucket perm[b] with 256 lanes if that bucket holds at least
-// HEAVY_MIN points (otherwise it exits at once), k_msm_heavy_combine folds the slices, and k_msm_accumulate skips those
-// buckets. Uniformly random scalars never trigger it (buckets hold tens to hundreds of points).
-constexpr u32 HEAVY_MIN = 8192, HEAVY_MAX = 256, HEAVY_SLICES = 32;
+// need minutes for it. Every bucket with >= HEAVY_MIN points (found by k_cnt_hist, by count -- NOT by its place in the size order:
+// the size sort clamps at CNT_BINS - 1, so thousands of mid-size buckets can stand in front of a huge one) is cut into slices of
+// HEAVY_SLICE points; a fixed grid of workgroups walks the slice list, 256 lanes per slice + an LDS tree; k_msm_heavy_combine folds
+// the slices of each bucket (one wave per bucket), and k_msm_accumulate* skip those buckets. Uniformly random scalars never trigger
+// it (buckets hold tens to hundreds of points): the grids then exit after one load.
+constexpr u32 HEAVY_GRID = 2048, HEAVY_COMBINE_GRID = 512;
 template <class F>
 __global__ void __launch_bounds__(256) k_msm_heavy(const Aff<F>* __restrict__ points, const u32* __restrict__ sorted, const u32* __restrict__ offsets,
-                                                   const u32* __restrict__ counts, const u32* __restrict__ perm, u32 nbuckets_total,
+                                                   const u32* __restrict__ counts, const HeavyList* __restrict__ hv, u32 hv_slice_cap,
+                                                   const u32* __restrict__ hv_bucket, const u32* __restrict__ hv_first, const u32* __restrict__ hv_owner,
                                                    Xyzz<F>* __restrict__ slices) {
   __shared__ Xyzz<F> sh[256];
-  const u32 b = blockIdx.x, sl = blockIdx.y;
-  if (b >= nbuckets_total) return;
-  const u32 t = perm[b];
-  const u32 cnt = counts[t];
-  if (cnt < HEAVY_MIN) return;          // block-uniform
-  const u32 start = offsets[t];
-  const u32 per = (cnt + HEAVY_SLICES - 1) / HEAVY_SLICES;
-  const u32 lo = sl * per, hi = min(cnt, lo + per);
-  Xyzz<F> acc = xyzz_inf<F>();
-  for (u32 k = lo + threadIdx.x; k < hi; k += 256) {
-    u32 e = sorted[start + k];
-    Aff<F> p = points[e & 0x7FFFFFFFu];
-    acc = xyzz_add_mixed(acc, aff_cneg(p, (e >> 31) != 0));
-  }
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  for (u32 o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], sh[threadIdx.x + o]);
+  const u32 total = min(hv->nslices, hv_slice_cap);
+  for (u32 sid = blockIdx.x; sid < total; sid += gridDim.x) {        // block-uniform
+    const u32 slot = hv_owner[sid];
+    const u32 t = hv_bucket[slot];
+    const u32 cnt = counts[t], start = offsets[t];
+    const u32 lo = (sid - hv_first[slot]) * HEAVY_SLICE, hi = min(cnt, lo + HEAVY_SLICE);
+    Xyzz<F> acc = xyzz_inf<F>();
+    for (u32 k = lo + threadIdx.x; k < hi; k += 256) {
+      u32 e = sorted[start + k];
+      Aff<F> p = points[e & 0x7FFFFFFFu];
+      acc = xyzz_add_mixed(acc, aff_cneg(p, (e >> 31) != 0));
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (u32 o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], sh[threadIdx.x + o]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) slices[sid] = sh[0];
     __syncthreads();
   }
-  if (threadIdx.x == 0) slices[(size_t)b * HEAVY_SLICES + sl] = sh[0];
 }
 template <class F>
-__global__ void __launch_bounds__(64) k_msm_heavy_combine(const u32* __restrict__ counts, const u32* __restrict__ perm, u32 nbuckets_total,
+__global__ void __launch_bounds__(64) k_msm_heavy_combine(const u32* __restrict__ counts, const HeavyList* __restrict__ hv, u32 hv_cap, u32 hv_slice_cap,
+                                                          const u32* __restrict__ hv_bucket, const u32* __restrict__ hv_first,
                                                           const Xyzz<F>* __restrict__ slices, Xyzz<F>* __restrict__ buckets) {
-  u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= HEAVY_MAX || b >= nbuckets_total) return;
-  const u32 t = perm[b];
-  if (counts[t] < HEAVY_MIN) return;
-  Xyzz<F> acc = xyzz_inf<F>();
-  for (u32 sl = 0; sl < HEAVY_SLICES; sl++) acc = xyzz_add(acc, slices[(size_t)b * HEAVY_SLICES + sl]);
-  buckets[t] = acc;
+  __shared__ Xyzz<F> sh[64];
+  const u32 nh = min(hv->n, hv_cap);
+  for (u32 slot = blockIdx.x; slot < nh; slot += gridDim.x) {
+    const u32 t = hv_bucket[slot], first = hv_first[slot];
+    const u32 nsl = (counts[t] + HEAVY_SLICE - 1) / HEAVY_SLICE;
+    Xyzz<F> acc = xyzz_inf<F>();
+    for (u32 k = threadIdx.x; k < nsl; k += 64)
+      if (first + k < hv_slice_cap) acc = xyzz_add(acc, slices[first + k]);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (u32 o = 32; o > 0; o >>= 1) {
+      if (threadIdx.x < o) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], sh[threadIdx.x + o]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) buckets[t] = sh[0];
+    __syncthreads();
+  }
 }
+// the ordinary bucket kernels leave these buckets to the heavy path
+KDEV bool msm_bucket_is_heavy(u32 cnt) { return cnt >= HEAVY_MIN; }
 
 // ---- K4: bucket accumulation (dominant kernel) ----------------------------------------------------
 template <class F>
@@ -500,7 +540,7 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const Aff<F>* __restrict
   if (lane >= nbuckets_total) return;
   u32 t = perm[lane];
   u32 start = offsets[t], cnt = counts[t];
-  if (lane < HEAVY_MAX && cnt >= HEAVY_MIN) return;   // done by k_msm_heavy / k_msm_heavy_combine
+  if (msm_bucket_is_heavy(cnt)) return;   // done by k_msm_heavy / k_msm_heavy_combine
   Xyzz<F> acc = xyzz_inf<F>();
   for (u32 k = 0; k < cnt; k++) {
     u32 e = sorted[start + k];
@@ -522,7 +562,7 @@ static __global__ void __launch_bounds__(256) k_msm_accumulate_g1_u29(const Aff<
   if (lane >= nbuckets_total) return;
   u32 t = perm[lane];
   u32 start = offsets[t], cnt = counts[t];
-  if (lane < HEAVY_MAX && cnt >= HEAVY_MIN) return;   // done by k_msm_heavy / k_msm_heavy_combine
+  if (msm_bucket_is_heavy(cnt)) return;   // done by k_msm_heavy / k_msm_heavy_combine
   U29 X1, Y1, ZZ, ZZZ;
   bool empty = true;
   for (u32 k = 0; k < cnt; k++) {

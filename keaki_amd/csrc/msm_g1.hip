@@ -9,7 +9,7 @@ keaki_status msm_g1_precompute_run(keaki_hip_ctx* ctx, const void* d_points, siz
   const int c = choose_window_shared(N);
   const size_t bytes = (size_t)msm_plan_windows(N, c) * N * sizeof(G1Aff);
   void* t = nullptr;
-  HIP_TRY(ctx, hipMalloc(&t, bytes ? bytes : 64));
+  ST_TRY(dev_alloc(ctx, &t, bytes ? bytes : 64));
   keaki_status st = msm_build_tables<Fq>(ctx, (const G1Aff*)d_points, N, c, (G1Aff*)t);
   if (st != KEAKI_OK) { (void)hipFree(t); return st; }
   *c_table_out = c; *table_bytes_out = bytes; *d_table_out = t;

@@ -20,6 +20,7 @@ inline int choose_window(size_t n) {
   int bc = 3;
   for (int c = 3; c <= 22; c++) {
     MsmPlan p = msm_make_plan(n, c);
+    if (p.nb > ((size_t)PART_MAX_BINS << PART_MAX_FINE_SHIFT)) continue;      // the two-pass partition addresses 2048 x 2048 buckets
     double cost = (double)n * p.s.W + 2.8 * (double)p.nb;
     if ((double)p.nb < 131072.0) cost *= 131072.0 / (double)p.nb;   // too few buckets cannot fill 256 CUs
     if (cost < best) { best = cost; bc = c; }
@@ -112,11 +113,20 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
                        (const u32*)(poffsets + ncounts), (u32)nb, offsets, hist, sorted);
   ST_TRY(launch_check(ctx, "part_fine"));
   // bucket schedule: descending size
-  ST_TRY(reserve(ctx, ctx->perm, nb * 4 + 2 * CNT_BINS * 4));
+  ST_TRY(reserve(ctx, ctx->perm, nb * 4 + 2 * CNT_BINS * 4 + sizeof(HeavyList)));
   u32* perm = (u32*)ctx->perm.p;
-  u32 *ghist = perm + nb, *gstart = ghist + CNT_BINS;
-  HIP_TRY(ctx, hipMemsetAsync(ghist, 0, CNT_BINS * 4, st));
-  hipLaunchKernelGGL(k_cnt_hist, dim3(cdiv(nb, 1024)), dim3(256), 0, st, (const u32*)hist, (u32)nb, ghist);
+  u32 *gstart = perm + nb, *ghist = gstart + CNT_BINS;
+  HeavyList* hv = (HeavyList*)(ghist + CNT_BINS);                        // right behind the histogram: one memset clears both
+  HIP_TRY(ctx, hipMemsetAsync(ghist, 0, CNT_BINS * 4 + sizeof(HeavyList), st));
+  // heavy-bucket list: [bucket[cap] | first[cap] | owner[slice_cap]] then the slice sums
+  const size_t total_pairs = n * (size_t)s.W;
+  const u32 hv_cap = (u32)(total_pairs / HEAVY_MIN + 1), hv_slice_cap = (u32)(hv_cap + total_pairs / HEAVY_SLICE + 1);
+  const size_t hv_hdr = ((2 * (size_t)hv_cap + hv_slice_cap) * 4 + 255) & ~(size_t)255;
+  ST_TRY(reserve(ctx, ctx->heavy, hv_hdr + (size_t)hv_slice_cap * sizeof(Xyzz<F>)));
+  u32 *hv_bucket = (u32*)ctx->heavy.p, *hv_first = hv_bucket + hv_cap, *hv_owner = hv_first + hv_cap;
+  Xyzz<F>* hv_slices = (Xyzz<F>*)((char*)ctx->heavy.p + hv_hdr);
+  hipLaunchKernelGGL(k_cnt_hist, dim3(cdiv(nb, 1024)), dim3(256), 0, st, (const u32*)hist, (u32)nb, ghist, hv, hv_cap, hv_slice_cap, hv_bucket, hv_first,
+                     hv_owner);
   hipLaunchKernelGGL(k_cnt_offsets, dim3(1), dim3(CNT_BINS), 0, st, (const u32*)ghist, gstart);
   hipLaunchKernelGGL(k_cnt_scatter, dim3(cdiv(nb, 1024)), dim3(256), 0, st, (const u32*)hist, (u32)nb, gstart, perm);
   ST_TRY(launch_check(ctx, "cnt_sort"));
@@ -133,12 +143,11 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
     hipLaunchKernelGGL((k_msm_accumulate<F>), dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
                        (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
   ST_TRY(launch_check(ctx, "msm_accumulate"));
-  // heavy buckets (structured scalars only; the blocks exit immediately otherwise)
-  ST_TRY(reserve(ctx, ctx->heavy, (size_t)HEAVY_MAX * HEAVY_SLICES * sizeof(Xyzz<F>)));
-  hipLaunchKernelGGL((k_msm_heavy<F>), dim3(HEAVY_MAX, HEAVY_SLICES), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
-                     (const u32*)hist, (const u32*)perm, (u32)nb, (Xyzz<F>*)ctx->heavy.p);
-  hipLaunchKernelGGL((k_msm_heavy_combine<F>), dim3(cdiv(HEAVY_MAX, 64)), dim3(64), 0, st, (const u32*)hist, (const u32*)perm, (u32)nb,
-                     (const Xyzz<F>*)ctx->heavy.p, buckets);
+  // heavy buckets (structured scalars only; the grids exit after one load otherwise)
+  hipLaunchKernelGGL((k_msm_heavy<F>), dim3(HEAVY_GRID), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets, (const u32*)hist,
+                     (const HeavyList*)hv, hv_slice_cap, (const u32*)hv_bucket, (const u32*)hv_first, (const u32*)hv_owner, hv_slices);
+  hipLaunchKernelGGL((k_msm_heavy_combine<F>), dim3(HEAVY_COMBINE_GRID), dim3(64), 0, st, (const u32*)hist, (const HeavyList*)hv, hv_cap, hv_slice_cap,
+                     (const u32*)hv_bucket, (const u32*)hv_first, (const Xyzz<F>*)hv_slices, buckets);
   ST_TRY(launch_check(ctx, "msm_heavy"));
   if (ctx->timing) (void)hipEventRecord(ctx->ev[2], st);
   hipLaunchKernelGGL((k_msm_reduce<F>), dim3(cdiv((size_t)rs.W * chunks, 64)), dim3(64), 0, st, (const Xyzz<F>*)buckets, rs, L, chunks, partials);

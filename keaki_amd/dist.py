@@ -1,34 +1,149 @@
-"""Multi-GPU sharding of the MSM: one process per GPU, contiguous point-chunks, ONE exchange step.
+"""Multi-GPU layer: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on a GPU node, "gloo" in the CPU tests
+and wherever several ranks share one GPU). Nothing here computes: the group arithmetic is the C ABI's, this module decides WHO
+computes WHAT and moves the 96-byte partial sums.
 
-The MSM  sum_i s_i P_i  shards by (scalar, point) chunk: rank q owns pairs [lo_q, hi_q), runs a complete
-Pippenger on them and produces one 96-byte normalised-Jacobian partial sum. EC addition is not an RCCL
-reduction operator, so the "reduce" is an all-gather of the world_size partials (torch.distributed,
-backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests) followed by world_size-1 EC adds
-on every rank (keaki_hip_g1_sum_dev). The message is 96 B per rank: latency-bound, bandwidth-irrelevant.
-Batched encapsulation / decapsulation shard by item with no collective at all.
+What shards how:
+
+* kzg::commit's MSM (reference src/kzg.rs:98) -- by contiguous (scalar, point) chunk. Rank q holds SRS points [lo_q, hi_q) (and the
+  window tables of that chunk only), runs a complete Pippenger on them and emits one normalised-Jacobian partial; ONE exchange step:
+  an all-gather of the world_size partials (EC addition is not an RCCL reduction operator), then world_size - 1 EC additions on
+  every rank (keaki_hip_g1_sum[_dev]). 96 bytes per rank: latency-bound, xGMI bandwidth is irrelevant.
+* vec_encrypt / vec_decrypt (src/vec.rs:63-66, :75-78) -- by item, no collective. Every rank draws the WHOLE stream of r values so that
+  the ciphertexts equal the single-process ones.
+* kzg::open_fk (FK23, src/kzg.rs:157-203) inside vec_commit -- REPLICATED: every rank computes all proofs (its group FFTs would need
+  an all-to-all of 96-byte points; not built). Only the commit MSM of vec_commit is sharded.
 """
 from __future__ import annotations
 
+import numpy as np
+
 
 def chunk_bounds(n_total: int, world: int, rank: int):
-    """contiguous chunk [lo, hi) of rank `rank`; sizes differ by at most one"""
+    """contiguous chunk [lo, hi) of rank `rank`; sizes differ by at most one (keaki::dist::Shard::bounds)"""
     base, rem = divmod(n_total, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def sharded_msm(partial_fn, all_gather_fn, sum_fn, world: int):
-    """partial_fn() -> this rank's partial (12 words); all_gather_fn(partial) -> (world, 12) on every rank;
-    sum_fn(all_partials) -> the full MSM result (12 words). With world == 1 the partial is the result."""
-    part = partial_fn()
-    if world == 1:
-        return part
-    return sum_fn(all_gather_fn(part))
+class Shard:
+    """This process's place in the job. world == 1 needs no process group at all."""
+
+    def __init__(self, rank: int = 0, world: int = 1, dist_module=None):
+        self.rank, self.world, self.dist = rank, world, dist_module
+        if world > 1 and dist_module is None:
+            raise ValueError("world > 1 needs the initialised torch.distributed module")
+
+    @classmethod
+    def from_env(cls):
+        """under torch.distributed.run: uses the default process group if one is initialised"""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return cls(dist.get_rank(), dist.get_world_size(), dist)
+        return cls()
+
+    def bounds(self, n: int):
+        return chunk_bounds(n, self.world, self.rank)
+
+    def all_gather_rows(self, row):
+        """row: 1-D torch int64 tensor (on the device for RCCL, anywhere for gloo) -> (world, len) tensor holding every rank's row,
+        on the device `row` lives on. THE exchange step of the sharded MSM."""
+        import torch
+        if self.world == 1:
+            return row.reshape(1, -1)
+        backend = self.dist.get_backend()
+        if backend == "nccl":
+            out = torch.empty((self.world, row.numel()), dtype=row.dtype, device=row.device)
+            self.dist.all_gather_into_tensor(out.view(-1), row.contiguous())       # ordered on the current stream
+            return out
+        host = row.detach().cpu().contiguous()                                     # .cpu() waits for the producer on the current stream
+        out = torch.empty((self.world, host.numel()), dtype=host.dtype)
+        self.dist.all_gather_into_tensor(out.view(-1), host)
+        return out.to(row.device)
+
+    def all_gather_np(self, words: np.ndarray) -> np.ndarray:
+        """host variant: u64[k] per rank -> (world, k)"""
+        import torch
+        if self.world == 1:
+            return words.reshape(1, -1).copy()
+        t = torch.from_numpy(np.ascontiguousarray(words).view(np.int64))
+        if self.dist.get_backend() == "nccl":
+            t = t.cuda()
+        return self.all_gather_rows(t).cpu().numpy().view(np.uint64)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
 
 
-def torch_all_gather(dist_module, out_buf):
-    """all-gather closure over a preallocated (world, 12) int64 tensor (device tensor on the GPU box)"""
-    def fn(part):
-        dist_module.all_gather_into_tensor(out_buf.view(-1), part)
-        return out_buf
-    return fn
+class ShardedMsm:
+    """One rank's chunk of a G1 MSM whose (scalar, point) pairs live in HBM: the configuration of BASELINE configs 2-4.
+
+        sm = ShardedMsm(hip, shard, d_points_chunk_ptr, n_chunk)    # the rank's points, already resident (SRS upload = setup time)
+        sm.precompute()                                             # optional window tables of the chunk
+        out = sm.run(d_scalars_chunk_ptr)                           # device tensor of 12 words: the FULL sum, on every rank
+
+    `hip` must have been created on the stream torch uses (KeakiHip(device, torch.cuda.current_stream().cuda_stream)) so that the
+    MSM, the RCCL all-gather and the final additions are ordered without host synchronisation."""
+
+    def __init__(self, hip, shard: Shard, d_points_ptr: int, n_chunk: int, torch_device=None):
+        import torch
+        self.hip, self.shard, self.n = hip, shard, n_chunk
+        self.srs = hip.srs_g1_wrap_dev(d_points_ptr, n_chunk)
+        dev = torch_device if torch_device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.part = torch.zeros(12, dtype=torch.int64, device=dev)
+        self.out = torch.zeros(12, dtype=torch.int64, device=dev)
+        self.table_bytes = 0
+        self._all = None
+
+    def precompute(self) -> int:
+        self.table_bytes = self.hip.srs_g1_precompute(self.srs)
+        return self.table_bytes
+
+    def run_partial(self, d_scalars_ptr: int, n: int | None = None):
+        self.hip.msm_g1_dev(self.srs, d_scalars_ptr, self.n if n is None else n, self.part.data_ptr())
+        return self.part
+
+    def combine(self):
+        """all-gather the partials, add them: afterwards self.out holds the whole MSM on every rank"""
+        if self.shard.world == 1:
+            return self.part
+        self._all = self.shard.all_gather_rows(self.part)
+        self.hip.g1_sum_dev(self._all.data_ptr(), self.shard.world, self.out.data_ptr())
+        return self.out
+
+    def run(self, d_scalars_ptr: int, n: int | None = None):
+        self.run_partial(d_scalars_ptr, n)
+        return self.combine()
+
+    def close(self):
+        if self.srs is not None:
+            self.srs.free()
+            self.srs = None
+
+
+# ---- the host-mirror flow (keaki_amd/keaki.py) sharded: what laconic_ot.py --gpus N runs -----------------------------------------------
+def sharded_commit(K, setup, p, shard: Shard) -> np.ndarray:
+    """kzg::commit with the MSM split by point range over the ranks; every rank returns the same affine commitment"""
+    part = K.commit_partial(setup, p, shard.rank, shard.world)
+    return K.commit_combine(setup, shard.all_gather_np(part))
+
+
+def sharded_vec_commit(K, rng, setup, v, shard: Shard):
+    """vec_commit (src/vec.rs:22-49): padding draw, iFFT and FK23 openings replicated on every rank (same rng seed -> same values),
+    the commit MSM sharded by point range, one all-gather. Returns (commitment, proofs) on every rank."""
+    part, proofs = K.vec_commit_partial(rng, setup, v, shard.rank, shard.world)
+    return K.commit_combine(setup, shard.all_gather_np(part)), proofs
+
+
+def sharded_vec_encrypt(K, rng, setup, com, points, values, messages, shard: Shard):
+    """this rank's item range of vec_encrypt -> ((lo, hi), ct G2 points, ct bodies); no collective"""
+    n = np.asarray(messages).shape[0]
+    g2, body = K.vec_encrypt_arrays_shard(rng, setup, com, points, values, messages, shard.rank, shard.world)
+    return shard.bounds(n), g2, body
+
+
+def sharded_vec_decrypt(K, setup, proofs, ct_g2, ct_body, shard: Shard):
+    """this rank's item range of vec_decrypt -> ((lo, hi), messages); no collective"""
+    n = np.asarray(ct_body).shape[0]
+    lo, hi = shard.bounds(n)
+    return (lo, hi), K.vec_decrypt_arrays(setup, proofs[lo:hi], ct_g2[lo:hi], ct_body[lo:hi])

@@ -16,7 +16,7 @@ _LIB = None
 
 EXPORTS = [
     "keaki_hip_ctx_create", "keaki_hip_ctx_destroy", "keaki_hip_last_error", "keaki_hip_synchronize", "keaki_hip_version",
-    "keaki_hip_srs_g1_upload", "keaki_hip_srs_g1_wrap_dev", "keaki_hip_srs_g1_len", "keaki_hip_srs_g1_precompute", "keaki_hip_srs_g1_free",
+    "keaki_hip_srs_g1_upload", "keaki_hip_srs_g1_wrap_dev", "keaki_hip_srs_g1_slice", "keaki_hip_srs_g1_len", "keaki_hip_srs_g1_precompute", "keaki_hip_srs_g1_free",
     "keaki_hip_srs_g2_upload", "keaki_hip_srs_g2_wrap_dev", "keaki_hip_srs_g2_free",
     "keaki_hip_msm_g1", "keaki_hip_msm_g1_dev", "keaki_hip_msm_g2", "keaki_hip_msm_g2_dev",
     "keaki_hip_g1_sum_dev", "keaki_hip_g1_sum",
@@ -67,6 +67,7 @@ def load_library():
             getattr(lib, f"keaki_hip_{g}_mul_batch").argtypes = [vp, vp, i32, vp, sz, vp]
             getattr(lib, f"keaki_hip_{g}_mul_batch_dev").argtypes = [vp, vp, i32, vp, sz, vp]
         lib.keaki_hip_srs_g1_precompute.argtypes = [vp, vp, C.POINTER(C.c_size_t)]
+        lib.keaki_hip_srs_g1_slice.argtypes = [vp, vp, sz, sz, C.POINTER(vp)]
         lib.keaki_hip_srs_g1_len.argtypes = [vp]
         lib.keaki_hip_srs_g1_len.restype = sz
         lib.keaki_hip_g1_sum.argtypes = [vp, vp, sz, vp]
@@ -129,10 +130,16 @@ class SrsG2(SrsG1):
 class KeakiHip:
     """One context = one GPU (one process per GPU in multi-GPU runs)."""
 
+    STREAM_LEGACY = 1          # KEAKI_HIP_STREAM_LEGACY: the device's legacy default stream (torch's default stream has handle 0 = this one)
+
     def __init__(self, device: int = 0, stream: int | None = None):
+        """stream: None -> private non-blocking stream (order *_dev calls with synchronize()); 0 or STREAM_LEGACY -> the legacy default
+        stream (what `torch.cuda.current_stream().cuda_stream` == 0 means); else a hipStream_t handle, e.g. torch.cuda.Stream().cuda_stream."""
         self.lib = load_library()
         ctx = C.c_void_p()
-        st = self.lib.keaki_hip_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(ctx))
+        if stream is not None and stream == 0:
+            stream = self.STREAM_LEGACY
+        st = self.lib.keaki_hip_ctx_create(device, C.c_void_p(stream) if stream is not None else None, C.byref(ctx))
         if st != 0:
             raise KeakiHipError(st, self.lib.keaki_hip_last_error(None).decode())
         self.ctx = ctx
@@ -178,6 +185,12 @@ class KeakiHip:
     def srs_g1_wrap_dev(self, dptr: int, n: int) -> SrsG1:
         h = C.c_void_p()
         self._ck(self.lib.keaki_hip_srs_g1_wrap_dev(self.ctx, C.c_void_p(dptr), n, C.byref(h)))
+        return SrsG1(self, h, n)
+
+    def srs_g1_slice(self, srs: SrsG1, offset: int, n: int) -> SrsG1:
+        """non-owning view of points [offset, offset + n): one rank's chunk of a sharded MSM"""
+        h = C.c_void_p()
+        self._ck(self.lib.keaki_hip_srs_g1_slice(self.ctx, srs.handle, offset, n, C.byref(h)))
         return SrsG1(self, h, n)
 
     def srs_g2_upload(self, points) -> SrsG2:

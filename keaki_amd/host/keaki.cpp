@@ -120,8 +120,32 @@ std::string KZGError::to_string() const {
   return "Can't commit to polynomial: polynomial has degree " + std::to_string(degree) + " but max degree is " + std::to_string(max_degree);
 }
 
-KZGSetup::~KZGSetup() { if (srs_ && dev_) keaki_hip_srs_g1_free(dev_->ctx(), srs_); }
-KZGSetup::KZGSetup(KZGSetup&& o) noexcept : dev_(std::move(o.dev_)), g1_aff_(std::move(o.g1_aff_)), tau_g2_(o.tau_g2_), srs_(o.srs_) { o.srs_ = nullptr; }
+KZGSetup::~KZGSetup() {
+  if (chunk_ && dev_) keaki_hip_srs_g1_free(dev_->ctx(), chunk_);
+  if (srs_ && dev_) keaki_hip_srs_g1_free(dev_->ctx(), srs_);
+}
+KZGSetup::KZGSetup(KZGSetup&& o) noexcept
+    : dev_(std::move(o.dev_)), g1_aff_(std::move(o.g1_aff_)), tau_g2_(o.tau_g2_), srs_(o.srs_), tables_(o.tables_), chunk_(o.chunk_),
+      chunk_lo_(o.chunk_lo_), chunk_hi_(o.chunk_hi_) {
+  o.srs_ = nullptr; o.chunk_ = nullptr;
+}
+
+// window tables are an optimisation: when they do not fit (KEAKI_ERR_OOM) the handle keeps working through the generic path
+static bool try_precompute(const Device& dev, keaki_hip_srs_g1* srs) {
+  const int st = keaki_hip_srs_g1_precompute(dev.ctx(), srs, nullptr);
+  if (st == KEAKI_ERR_OOM) return false;
+  dev.check(st);
+  return true;
+}
+
+keaki_hip_srs_g1* KZGSetup::chunk_srs(size_t lo, size_t hi) const {
+  if (chunk_ && chunk_lo_ == lo && chunk_hi_ == hi) return chunk_;
+  if (chunk_) { keaki_hip_srs_g1_free(dev_->ctx(), chunk_); chunk_ = nullptr; }
+  dev_->check(keaki_hip_srs_g1_slice(dev_->ctx(), srs_, lo, hi - lo, &chunk_));
+  chunk_lo_ = lo; chunk_hi_ = hi;
+  if (tables_ && hi > lo) (void)try_precompute(*dev_, chunk_);
+  return chunk_;
+}
 
 KZGSetup KZGSetup::from_powers(std::shared_ptr<Device> dev, std::vector<G1> g1_aff, const G2& tau_g2) {
   KZGSetup s;
@@ -134,7 +158,7 @@ KZGSetup KZGSetup::from_powers(std::shared_ptr<Device> dev, std::vector<G1> g1_a
   // without (the per-window sums need ~250 serial doublings). KEAKI_PRECOMPUTE_MIN raises the smallest SRS that gets tables.
   const char* pm = getenv("KEAKI_PRECOMPUTE_MIN");
   const size_t pre_min = pm ? (size_t)atoll(pm) : (size_t)1;
-  if (s.g1_aff_.size() >= pre_min) s.dev_->check(keaki_hip_srs_g1_precompute(s.dev_->ctx(), s.srs_, nullptr));
+  if (s.g1_aff_.size() >= pre_min) s.tables_ = try_precompute(*s.dev_, s.srs_);
   return s;
 }
 
@@ -302,7 +326,8 @@ std::vector<Fr> Radix2Domain::ifft(std::vector<Fr> e) const {
   return e;
 }
 
-std::pair<G1, std::vector<G1>> vec_commit(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v) {
+// src/vec.rs:27-44: everything of vec_commit in front of the final commit -> (coefficients as a DensePolynomial, proofs)
+std::pair<DensePolynomial, std::vector<G1>> vec_commit_openings(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v) {
   size_t d = v.size() + PADDING_LEN;
   std::vector<Fr> padded(v);
   padded.push_back(fr_rand(rng));                    // src/vec.rs:31-33
@@ -318,10 +343,14 @@ std::pair<G1, std::vector<G1>> vec_commit(Rng& rng, const kzg::KZGSetup& setup, 
     p_coeff = domain.ifft(padded);
   }
   std::vector<G1> proofs = kzg::open_fk(setup, p_coeff, domain.size).unwrap();  // :40
-  DensePolynomial dense = p_coeff;
+  DensePolynomial dense = std::move(p_coeff);
   while (!dense.empty() && dense.back().is_zero()) dense.pop_back();  // from_coefficients_vec trims
-  G1 com = kzg::commit(setup, dense).unwrap();       // :46
-  return {com, proofs};
+  return {std::move(dense), std::move(proofs)};
+}
+std::pair<G1, std::vector<G1>> vec_commit(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v) {
+  auto cp = vec_commit_openings(rng, setup, v);
+  G1 com = kzg::commit(setup, cp.first).unwrap();    // :46
+  return {com, std::move(cp.second)};
 }
 
 std::vector<enc::Ciphertext> vec_encrypt(Rng& rng, const kzg::KZGSetup& setup, const G1& com, const std::vector<Fr>& points,
@@ -383,4 +412,50 @@ std::vector<std::vector<uint8_t>> vec_decrypt(const kzg::KZGSetup& setup, const 
 }
 
 }  // namespace vec
+
+// ------------------------------------------------------------------------------------------------ dist
+namespace dist {
+
+std::pair<size_t, size_t> Shard::bounds(size_t n) const {
+  const size_t base = n / world, rem = n % world;
+  const size_t lo = rank * base + std::min(rank, rem);
+  return {lo, lo + base + (rank < rem ? 1 : 0)};
+}
+
+kzg::Result<Partial> commit_partial(const kzg::KZGSetup& setup, const DensePolynomial& p, const Shard& sh) {
+  const size_t len = setup.g1_pow().size();
+  if (p.size() > len) return kzg::Result<Partial>::Err(kzg::KZGError{kzg::KZGError::PolynomialTooLarge, p.size(), len});
+  // the ranges follow the SRS, not the polynomial: a rank's window tables are built once per setup and serve every polynomial
+  auto b = sh.bounds(len);
+  const size_t lo = std::min(b.first, p.size()), hi = std::min(b.second, p.size());
+  Partial out;
+  setup.device()->check(keaki_hip_msm_g1(setup.device()->ctx(), setup.chunk_srs(b.first, b.second), hi > lo ? p[lo].l : nullptr, hi - lo, out.data()));
+  return kzg::Result<Partial>::Ok(out);
+}
+
+std::pair<Partial, std::vector<G1>> vec_commit_partial(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v, const Shard& sh) {
+  auto cp = vec::vec_commit_openings(rng, setup, v);                 // replicated on every rank: same rng stream, same values
+  return {commit_partial(setup, cp.first, sh).unwrap(), std::move(cp.second)};
+}
+
+G1 commit_combine(const kzg::KZGSetup& setup, const Partial* partials, size_t world) {
+  uint64_t jac[12];
+  setup.device()->check(keaki_hip_g1_sum(setup.device()->ctx(), world ? partials[0].data() : nullptr, world, jac));
+  return jac_to_g1(jac);
+}
+
+void vec_encrypt_flat_shard(Rng& rng, const kzg::KZGSetup& setup, const G1& com, const Fr* points, const Fr* values, const uint8_t* msgs, size_t n,
+                            size_t msg_len, const Shard& sh, uint64_t* ct_g2_out, uint8_t* ct_msg_out) {
+  if (!n) return;
+  std::vector<Fr> rs(n);
+  for (size_t i = 0; i < n; i++) rs[i] = fr_rand(rng);        // the whole stream, as the serial loop would draw it (src/vec.rs:63-66 -> src/kem.rs:26)
+  auto b = sh.bounds(n);
+  const size_t lo = b.first, m = b.second - b.first;
+  if (!m) return;
+  setup.device()->check(keaki_hip_encap_batch(setup.device()->ctx(), com.w.data(), setup.tau_g2().w.data(), points[lo].l, values[lo].l, rs[lo].l, m,
+                                              ct_g2_out, nullptr, msg_len ? ct_msg_out : nullptr, msg_len));
+  for (size_t i = 0; i < m * msg_len; i++) ct_msg_out[i] ^= msgs[lo * msg_len + i];
+}
+
+}  // namespace dist
 }  // namespace keaki

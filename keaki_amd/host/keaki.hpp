@@ -117,12 +117,19 @@ class KZGSetup {
   const G2& tau_g2() const { return tau_g2_; }
   const std::shared_ptr<Device>& device() const { return dev_; }
   keaki_hip_srs_g1* srs() const { return srs_; }
+  // false when the optional window tables of the SRS did not fit in HBM: commit / open then run the generic per-window MSM (same results)
+  bool has_window_tables() const { return tables_; }
+  // this rank's chunk [lo, hi) of the SRS as a handle of its own, with its own window tables (built on first use; see keaki::dist)
+  keaki_hip_srs_g1* chunk_srs(size_t lo, size_t hi) const;
  private:
   KZGSetup() {}
   std::shared_ptr<Device> dev_;
   std::vector<G1> g1_aff_;
   G2 tau_g2_;
   keaki_hip_srs_g1* srs_ = nullptr;  // device-resident copy of g1_aff, uploaded once
+  bool tables_ = false;
+  mutable keaki_hip_srs_g1* chunk_ = nullptr;
+  mutable size_t chunk_lo_ = 0, chunk_hi_ = 0;
 };
 
 Result<G1> commit(const KZGSetup& setup, const DensePolynomial& p);                          // src/kzg.rs:89-101
@@ -161,6 +168,8 @@ struct Radix2Domain {
 };
 // src/vec.rs:22-49
 std::pair<G1, std::vector<G1>> vec_commit(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v);
+// lines :27-44 of it (padding draw, iFFT, open_fk): the dense coefficient vector and the proofs, without the final commit
+std::pair<DensePolynomial, std::vector<G1>> vec_commit_openings(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v);
 // src/vec.rs:52-69: one Fr::rand per item in index order, then ONE batched GPU call for all items
 std::vector<enc::Ciphertext> vec_encrypt(Rng& rng, const kzg::KZGSetup& setup, const G1& com, const std::vector<Fr>& points,
                                          const std::vector<Fr>& values, const std::vector<std::vector<uint8_t>>& messages);
@@ -172,5 +181,30 @@ void vec_decrypt_flat(const kzg::KZGSetup& setup, const uint64_t* proofs, const 
 std::vector<std::vector<uint8_t>> vec_decrypt(const kzg::KZGSetup& setup, const std::vector<G1>& proofs,
                                               const std::vector<const enc::Ciphertext*>& cts);
 }  // namespace vec
+
+// ---- one process per GPU: the same calls with the work split over `world` ranks ------------------------------------------------------
+// commit's MSM (src/kzg.rs:98) shards by contiguous coefficient / point range: every rank runs a complete Pippenger on its range and
+// emits one 96-byte normalised-Jacobian partial; the CALLER exchanges the partials (RCCL all-gather in the harness, any transport
+// in an application: the library never opens a connection) and every rank adds them. EC addition is exact, so the affine result equals
+// the single-GPU one bit for bit. The loops of vec_encrypt / vec_decrypt (src/vec.rs:63-66, :75-78) shard by item, no exchange at all.
+namespace dist {
+struct Shard {
+  size_t rank = 0, world = 1;
+  // contiguous range of rank `rank` out of n units; sizes differ by at most one
+  std::pair<size_t, size_t> bounds(size_t n) const;
+};
+using Partial = std::array<uint64_t, 12>;   // normalised Jacobian (x, y, 1) or (1, 1, 0)
+// this rank's share of kzg::commit: sum over i in bounds(setup.len) and i < p.size() of p[i] [tau^i]_1. Same error as commit.
+kzg::Result<Partial> commit_partial(const kzg::KZGSetup& setup, const DensePolynomial& p, const Shard& sh);
+// vec_commit with the final commit (src/vec.rs:46) left as this rank's partial. Padding draw, iFFT and the FK23 openings are REPLICATED:
+// every rank runs them with the same rng stream and gets the same proofs (the group FFTs of FK23 are not sharded).
+std::pair<Partial, std::vector<G1>> vec_commit_partial(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v, const Shard& sh);
+// the sum of all ranks' partials (in any order)
+G1 commit_combine(const kzg::KZGSetup& setup, const Partial* partials, size_t world);
+// vec_encrypt_flat for the items in bounds(n) only: draws ALL n values of r in index order (so every rank's stream, and therefore every
+// ciphertext, equals the single-process call's) and writes (hi - lo) ciphertexts
+void vec_encrypt_flat_shard(Rng& rng, const kzg::KZGSetup& setup, const G1& com, const Fr* points, const Fr* values, const uint8_t* msgs, size_t n,
+                            size_t msg_len, const Shard& sh, uint64_t* ct_g2_out, uint8_t* ct_msg_out);
+}  // namespace dist
 
 }  // namespace keaki

@@ -249,4 +249,39 @@ int keaki_host_vec_decrypt(void* s, const uint64_t* proofs, const uint64_t* ct_g
   });
 }
 
+// ---- keaki::dist: one process per GPU (rank / world), the exchange of the 96-byte partials is the caller's ------------------------
+int keaki_host_setup_has_tables(void* s) { return ((Setup*)s)->s.has_window_tables() ? 1 : 0; }
+int keaki_host_commit_partial(void* s, const uint64_t* coeffs, size_t n, size_t rank, size_t world, uint64_t* out_jac12, uint64_t* err_out) {
+  return guard([&] {
+    auto r = dist::commit_partial(((Setup*)s)->s, frs_of(coeffs, n), dist::Shard{rank, world});
+    if (!r.ok) return kzg_err(r.error, err_out);
+    memcpy(out_jac12, r.value.data(), 96); return 0;
+  });
+}
+// vec_commit with the commit left as this rank's partial; proofs_out sized with keaki_host_domain(n + 1)
+int keaki_host_vec_commit_partial(void* rng, void* s, const uint64_t* v, size_t n, size_t rank, size_t world, uint64_t* out_jac12, uint64_t* proofs_out) {
+  return guard([&] {
+    auto r = dist::vec_commit_partial(*(Rng*)rng, ((Setup*)s)->s, frs_of(v, n), dist::Shard{rank, world});
+    memcpy(out_jac12, r.first.data(), 96);
+    for (size_t i = 0; i < r.second.size(); i++) memcpy(proofs_out + 8 * i, r.second[i].w.data(), 64);
+    return 0;
+  });
+}
+int keaki_host_commit_combine(void* s, const uint64_t* partials_jac12, size_t world, uint64_t* out_g1) {
+  return guard([&] {
+    static_assert(sizeof(dist::Partial) == 96, "a partial is twelve u64 words");
+    G1 g = dist::commit_combine(((Setup*)s)->s, reinterpret_cast<const dist::Partial*>(partials_jac12), world);
+    memcpy(out_g1, g.w.data(), 64); return 0;
+  });
+}
+// vec_encrypt for the items of rank `rank` only (outputs sized for that rank's hi - lo items)
+int keaki_host_vec_encrypt_shard(void* rng, void* s, const uint64_t* com, const uint64_t* points, const uint64_t* values, const uint8_t* msgs,
+                                 size_t n, size_t msg_len, size_t rank, size_t world, uint64_t* ct_g2_out, uint8_t* ct_msg_out) {
+  return guard([&] {
+    dist::vec_encrypt_flat_shard(*(Rng*)rng, ((Setup*)s)->s, g1_of(com), reinterpret_cast<const Fr*>(points), reinterpret_cast<const Fr*>(values), msgs, n,
+                                 msg_len, dist::Shard{rank, world}, ct_g2_out, ct_msg_out);
+    return 0;
+  });
+}
+
 }  // extern "C"

@@ -214,6 +214,10 @@ class KZGSetup:
         _lib().keaki_host_setup_tau_g2(self.h, _p(out))
         return out
 
+    def has_window_tables(self) -> bool:
+        """False when the optional SRS window tables did not fit in HBM (commit / open then take the generic MSM path)"""
+        return bool(_lib().keaki_host_setup_has_tables(self.h))
+
     def close(self):
         if self.h:
             _lib().keaki_host_setup_free(self.h)
@@ -330,3 +334,40 @@ def vec_decrypt(setup: KZGSetup, proofs, cts):
     out = np.zeros(max(n * ml, 1), np.uint8)
     _ck(_lib().keaki_host_vec_decrypt(setup.h, _p(pr), _p(g2), _p(body), C.c_size_t(n), C.c_size_t(ml), _p(out)))
     return [out[i * ml:(i + 1) * ml].tobytes() for i in range(n)]
+
+
+# ---- keaki::dist (host/keaki.hpp): one process per GPU; the exchange of the 96-byte partials is the caller's (keaki_amd/dist.py) --------
+def commit_partial(setup: KZGSetup, p, rank: int, world: int) -> np.ndarray:
+    """this rank's share of kzg::commit: the MSM over its contiguous range of the SRS -> normalised Jacobian u64[12]"""
+    c = _u64(p, 4); out = np.zeros(12, np.uint64); err = np.zeros(2, np.uint64)
+    _ck(_lib().keaki_host_commit_partial(setup.h, _p(c), C.c_size_t(c.shape[0]), C.c_size_t(rank), C.c_size_t(world), _p(out), _p(err)), err)
+    return out
+
+
+def vec_commit_partial(rng: Rng, setup: KZGSetup, v, rank: int, world: int):
+    """vec_commit with the final commit left as this rank's partial -> (partial u64[12], proofs); see keaki::dist::vec_commit_partial"""
+    v = _u64(v, 4); n = v.shape[0]
+    size = _lib().keaki_host_domain(n + PADDING_LEN, None)
+    part = np.zeros(12, np.uint64); proofs = np.zeros((size, 8), np.uint64)
+    _ck(_lib().keaki_host_vec_commit_partial(rng.h, setup.h, _p(v), C.c_size_t(n), C.c_size_t(rank), C.c_size_t(world), _p(part), _p(proofs)))
+    return part, proofs
+
+
+def commit_combine(setup: KZGSetup, partials) -> np.ndarray:
+    pr = _u64(partials, 12); out = np.zeros(8, np.uint64)
+    _ck(_lib().keaki_host_commit_combine(setup.h, _p(pr), C.c_size_t(pr.shape[0]), _p(out)))
+    return out
+
+
+def vec_encrypt_arrays_shard(rng: Rng, setup: KZGSetup, com, points, values, messages: np.ndarray, rank: int, world: int):
+    """vec_encrypt_arrays for the items of rank `rank` only: consumes the rng exactly as the full call does (one r per item of the WHOLE
+    vector, in index order), returns the ciphertexts of this rank's contiguous item range"""
+    from .dist import chunk_bounds
+    msgs = np.ascontiguousarray(messages, dtype=np.uint8)
+    n, ml = msgs.shape
+    lo, hi = chunk_bounds(n, world, rank)
+    pts = np.ascontiguousarray(_u64(points, 4)[:n]); vals = np.ascontiguousarray(_u64(values, 4)[:n])
+    g2 = np.zeros((hi - lo, 16), np.uint64); body = np.zeros((hi - lo, max(ml, 1)), np.uint8)
+    _ck(_lib().keaki_host_vec_encrypt_shard(rng.h, setup.h, _p(_u64(com)), _p(pts), _p(vals), _p(msgs), C.c_size_t(n), C.c_size_t(ml),
+                                           C.c_size_t(rank), C.c_size_t(world), _p(g2), _p(body)))
+    return g2, body[:, :ml]

@@ -1,13 +1,23 @@
 #!/usr/bin/env python3
-"""Laconic OT end-to-end on one MI355X -- the reference's integration flow (tests/laconic_ot.rs:15-200) at any size.
+"""Laconic OT end-to-end -- the reference's integration flow (tests/laconic_ot.rs:15-200) at any size, on 1..N GPUs.
 
-    python laconic_ot.py --log2n 16          # N_CHOICES = 2^16 receiver bits, 2 x 32-byte messages per bit
+    python laconic_ot.py --log2n 16                      # N_CHOICES = 2^16 receiver bits, 2 x 32-byte messages per bit, one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        laconic_ot.py --gpus N --log2n 20                # BASELINE config 5: one rank per GPU (RCCL)
 
 Receiver::new  -> vec_commit : pad with one random scalar, iFFT to coefficients (GPU Fr FFT), FK23 openings (GPU Fr + G1 FFTs), commit (GPU MSM)
 Sender::send   -> 2 x vec_encrypt : one batched GPU encapsulation per message set (fixed-base GT path), XOR on host
 Receiver::receive -> vec_decrypt : one batched GPU decapsulation (one pairing per item), XOR on host
-Prints the same three phase timings the reference test prints (tests/laconic_ot.rs:148,176,188) as one JSON line and checks
-that every decrypted message is the chosen one.
+
+With N ranks (keaki_amd/dist.py; host side keaki::dist in keaki_amd/host/keaki.hpp):
+  * every rank builds the same setup (same secret) and holds the whole SRS (2^21 points = 128 MiB);
+  * vec_commit: padding draw, iFFT and the FK23 openings are REPLICATED (every rank computes all proofs; the group FFTs are not
+    sharded), the commit MSM is sharded by point range: one all-gather of 96-byte partials + N - 1 EC additions;
+  * vec_encrypt / vec_decrypt: sharded by item, NO collective; every rank draws the whole stream of r so that the ciphertexts are the
+    single-process ones. Rank q decrypts the items it encrypted, so nothing moves between ranks; the recovered messages are checked
+    on the rank that holds them and the verdicts are combined at the end (one all-gather of a flag).
+Prints the same three phase timings the reference test prints (tests/laconic_ot.rs:148,176,188) as one JSON line (rank 0; the MAX over
+ranks of every phase) and checks that every decrypted message is the chosen one. Exit code 1 otherwise.
 """
 import argparse
 import json
@@ -25,17 +35,50 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2n", type=int, default=10)
     ap.add_argument("--value-bytes", type=int, default=32)   # VALUE_BYTES (tests/laconic_ot.rs:124)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo lets several ranks share one GPU (1-GPU box)")
+    ap.add_argument("--check-single", action="store_true",
+                    help="rank 0 also runs the un-sharded calls with the same seeds and compares commitment and ciphertexts bit for bit")
     args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("laconic_ot.py --gpus N with N > 1 must be launched through torch.distributed.run (one rank per GPU)")
     from keaki_amd import keaki as K
+    from keaki_amd.dist import Shard, sharded_vec_commit, sharded_vec_encrypt, sharded_vec_decrypt
+    dist = None
+    device = 0
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        ndev = torch.cuda.device_count()          # does not initialise the GPU
+        if ndev == 0:
+            raise SystemExit("laconic_ot.py needs an MI355X (there is no CPU fallback)")
+        if args.backend == "nccl" and world > ndev:
+            raise SystemExit("%d ranks but %d GPUs: RCCL needs one GPU per rank (use --backend gloo to share a GPU)" % (world, ndev))
+        device = local_rank % ndev
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    shard = Shard(rank, world, dist)
+
+    def phase_max(t):
+        return float(shard.all_gather_np(np.array([np.float64(t)]).view(np.uint64)).view(np.float64).max())
+
     n = 1 << args.log2n
     vb = args.value_bytes
-    rng = K.Rng(2024)
+    rng = K.Rng(2024)                              # the same stream on every rank: setup secret, padding, r values
     t0 = time.time()
     setup_degree = 1
     while setup_degree < n + K.PADDING_LEN:
         setup_degree <<= 1
-    s = K.KZGSetup.setup(rng.fr_rand(), setup_degree)      # SETUP_DEGREE: the domain of n+1 evaluations
+    s = K.KZGSetup.setup(rng.fr_rand(), setup_degree, device)      # SETUP_DEGREE: the domain of n+1 evaluations
     K.precompute_open_fk(s, setup_degree)                  # SRS-only part of the FK23 openings, like the MSM window tables
+    shard.barrier()
     t_setup = time.time() - t0
     np_rng = np.random.default_rng(7)
     bits = np_rng.integers(0, 2, n)
@@ -43,30 +86,53 @@ def main():
     choices = np.where(bits[:, None] == 0, zero[None, :], one[None, :]).astype(np.uint64)
 
     t0 = time.time()
-    commitment, proofs = K.vec_commit(rng, s, choices)      # Receiver::new
-    t_receiver_new = time.time() - t0
+    commitment, proofs = sharded_vec_commit(K, rng, s, choices, shard)      # Receiver::new
+    t_receiver_new = phase_max(time.time() - t0)
 
     sets = [np_rng.integers(0, 256, size=(n, vb), dtype=np.uint8) for _ in range(2)]
     elements = K.domain_elements(n + K.PADDING_LEN)
     t0 = time.time()
     zeros, ones = np.repeat(zero[None, :], n, 0), np.repeat(one[None, :], n, 0)
-    g2_0, body_0 = K.vec_encrypt_arrays(rng, s, commitment, elements, zeros, sets[0])     # Sender::send: encrypt set b to "bit i == b"
-    g2_1, body_1 = K.vec_encrypt_arrays(rng, s, commitment, elements, ones, sets[1])
-    t_sender_send = time.time() - t0
+    (lo, hi), g2_0, body_0 = sharded_vec_encrypt(K, rng, s, commitment, elements, zeros, sets[0], shard)     # Sender::send: set b to "bit i == b"
+    _, g2_1, body_1 = sharded_vec_encrypt(K, rng, s, commitment, elements, ones, sets[1], shard)
+    t_sender_send = phase_max(time.time() - t0)
 
     t0 = time.time()
-    pick = bits[:, None] == 0                                                              # Receiver::receive
-    got = K.vec_decrypt_arrays(s, proofs, np.where(pick, g2_0, g2_1), np.where(pick, body_0, body_1))
-    t_receive = time.time() - t0
-    ok = bool(np.array_equal(got, np.where(pick, sets[0], sets[1])))
+    pick = bits[lo:hi, None] == 0                                                              # Receiver::receive, this rank's items
+    got = K.vec_decrypt_arrays(s, proofs[lo:hi], np.where(pick, g2_0, g2_1), np.where(pick, body_0, body_1))
+    t_receive = phase_max(time.time() - t0)
+    ok = bool(np.array_equal(got, np.where(pick, sets[0][lo:hi], sets[1][lo:hi])))
     # the receiver must NOT be able to read the other message: decrypting the unchosen ciphertext gives something else
-    other = K.vec_decrypt_arrays(s, proofs[:256], np.where(pick, g2_1, g2_0)[:256], np.where(pick, body_1, body_0)[:256])
-    ok = ok and not np.array_equal(other, np.where(pick, sets[1], sets[0])[:256])
-    print(json.dumps({"flow": "laconic_ot", "n_choices": n, "value_bytes": vb, "setup_s": round(t_setup, 3),
-                      "receiver_new_s": round(t_receiver_new, 3), "sender_send_s": round(t_sender_send, 3),
-                      "receiver_receive_s": round(t_receive, 3), "all_messages_recovered": bool(ok),
-                      "note": "wall-clock through the C++ host mirror (contiguous arrays in, arrays out); GPU work: FK23 + MSM / 2n encaps / n decaps"}))
-    if not ok:
+    m = min(256, hi - lo)
+    if m:
+        other = K.vec_decrypt_arrays(s, proofs[lo:lo + m], np.where(pick, g2_1, g2_0)[:m], np.where(pick, body_1, body_0)[:m])
+        ok = ok and not np.array_equal(other, np.where(pick, sets[1][lo:hi], sets[0][lo:hi])[:m])
+    single = None
+    if args.check_single and rank == 0:
+        # the un-sharded calls with the same seeds: commitment, proofs and this rank's ciphertexts must be the same bytes
+        rng1 = K.Rng(2024)
+        rng1.fr_rand()                                                                         # the setup secret
+        com1, proofs1 = K.vec_commit(rng1, s, choices)
+        a0, b0 = K.vec_encrypt_arrays(rng1, s, com1, elements, zeros, sets[0])
+        a1, b1 = K.vec_encrypt_arrays(rng1, s, com1, elements, ones, sets[1])
+        single = bool(np.array_equal(com1, commitment) and np.array_equal(proofs1, proofs) and np.array_equal(a0[lo:hi], g2_0)
+                      and np.array_equal(b0[lo:hi], body_0) and np.array_equal(a1[lo:hi], g2_1) and np.array_equal(b1[lo:hi], body_1))
+        ok = ok and single
+    all_ok = bool(shard.all_gather_np(np.array([1 if ok else 0], np.uint64)).min() == 1)
+    if rank == 0:
+        print(json.dumps({"flow": "laconic_ot", "n_choices": n, "value_bytes": vb, "n_gpus": world, "ranks_seen": shard.world,
+                          "backend": args.backend if world > 1 else None, "setup_s": round(t_setup, 3),
+                          "receiver_new_s": round(t_receiver_new, 3), "sender_send_s": round(t_sender_send, 3),
+                          "receiver_receive_s": round(t_receive, 3), "all_messages_recovered": all_ok,
+                          "sharded_equals_single_process": single,
+                          "sharding": None if world == 1 else "commit MSM by point range (1 all-gather of 96-B partials); FK23 openings replicated on "
+                                                              "every rank; encaps / decaps by item, no collective",
+                          "note": "wall-clock through the C++ host mirror (contiguous arrays in, arrays out), max over ranks per phase; "
+                                  "GPU work: FK23 + MSM / 2n encaps / n decaps"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not all_ok:
         raise SystemExit(1)
 
 

@@ -13,6 +13,60 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _run(cmd, timeout):
+    import subprocess
+    try:
+        p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout, text=True)
+        return p.returncode, p.stdout
+    except subprocess.TimeoutExpired as e:
+        return -9, "TIMEOUT after %ds\n%s" % (timeout, (e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or ""))
+
+
+@pytest.fixture(scope="session", autouse=True)
+def multirank_runs(request, tmp_path_factory):
+    """The multi-process jobs of tests/test_gpu_world2.py. Session-scoped and autouse so that they are launched FIRST, while this
+    process has not touched the GPU yet (a process that has initialised the GPU must not fork + exec on this pool); every rank is a
+    fresh interpreter. Does nothing unless a test of that module is selected (i.e. `-m gpu` on the GPU box)."""
+    if not any("test_gpu_world2" in it.nodeid for it in request.session.items):
+        yield {}
+        return
+    import subprocess
+    py_exe = sys.executable
+    out = {}
+    port = 29400 + os.getpid() % 500
+    # (1) two ranks of the MSM composition test on GPU 0, exchange over gloo
+    d = str(tmp_path_factory.mktemp("world2_msm"))
+    n_total = (1 << 16) + 3
+    procs = [subprocess.Popen([py_exe, os.path.join(ROOT, "tests", "multirank", "msm_rank.py"), str(q), "2", str(port), str(n_total), d],
+                              cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for q in range(2)]
+    logs, rcs = [], []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+            o = "TIMEOUT\n" + (o or "")
+        logs.append(o); rcs.append(p.returncode)
+    out["msm"] = {"rc": rcs, "log": "\n---- rank ----\n".join(logs), "dir": d, "n_total": n_total}
+    launch = [py_exe, "-m", "torch.distributed.run", "--nnodes=1", "--master-addr", "127.0.0.1"]
+    # (2) bench.py at world 2 (gloo, both ranks on GPU 0): weak line + strong block (2^19 total) + KEM block, small sizes
+    rc, log = _run(launch + ["--nproc-per-node", "2", "--master-port", str(port + 1), "bench.py", "--gpus", "2", "--backend", "gloo", "--log2n", "18",
+                             "--kem-log2n", "10", "--steps", "3", "--warmup", "1", "--cpu-log2n", "14", "--strong-log2n", "19"], 1500)
+    out["bench"] = {"rc": rc, "log": log}
+    # (3) laconic_ot.py at world 2
+    rc, log = _run(launch + ["--nproc-per-node", "2", "--master-port", str(port + 2), "laconic_ot.py", "--gpus", "2", "--backend", "gloo", "--log2n", "9",
+                             "--check-single"], 1500)
+    out["laconic"] = {"rc": rc, "log": log}
+    # (4) the driver's launch line at N = 1
+    rc, log = _run(launch + ["--nproc-per-node", "1", "--master-port", str(port + 3), "bench.py", "--gpus", "1", "--log2n", "18", "--kem-log2n", "10",
+                             "--steps", "2", "--warmup", "1", "--cpu-log2n", "14"], 1500)
+    out["bench1"] = {"rc": rc, "log": log}
+    rc, log = _run(launch + ["--nproc-per-node", "1", "--master-port", str(port + 4), "laconic_ot.py", "--gpus", "1", "--log2n", "9"], 1500)
+    out["laconic1"] = {"rc": rc, "log": log}
+    yield out
+
+
 @pytest.fixture(scope="session")
 def oc():
     """C oracle (ctypes) -- the checker, never the thing under test."""

@@ -1,0 +1,76 @@
+"""N > 1 on real hardware with ONE GPU: two ranks share GPU 0 (each its own keaki context and stream), exchange over gloo. The jobs
+are launched by the session fixture `multirank_runs` (tests/conftest.py) BEFORE anything in the pytest process touches the GPU; the
+tests here only read what the ranks left behind and compare it with the oracle. Covers VERDICT r01 'next' items 1(d) and 4:
+  * keaki_hip_msm_g1_dev -> all-gather of 96-byte partials -> keaki_hip_g1_sum_dev composed across two processes, three steps with
+    different scalars, one rank with window tables and one without;
+  * bench.py --gpus 2 (weak line + strong block + KEM block, full-size checks over both ranks);
+  * laconic_ot.py --gpus 2: sharded commit, item-sharded vec_encrypt / vec_decrypt, bytes equal to the single-process calls."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _json_line(text):
+    for line in reversed(text.strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    raise AssertionError("no JSON line in output:\n" + text[-2000:])
+
+
+def test_world2_hip_msm_allgather_sum_vs_oracle(multirank_runs, oc):
+    run = multirank_runs["msm"]
+    assert run["rc"] == [0, 0], run["log"]
+    from bench import random_fr_limbs
+    from keaki_amd.hip import jac_to_affine_words
+    n_total = run["n_total"]
+    r = [np.load(os.path.join(run["dir"], "rank%d.npz" % q)) for q in range(2)]
+    assert int(r[0]["lo"]) == 0 and int(r[0]["hi"]) == int(r[1]["lo"]) and int(r[1]["hi"]) == n_total
+    assert int(r[0]["table_bytes"]) > 0 and int(r[1]["table_bytes"]) == 0
+    k_all = random_fr_limbs(n_total, 0xA11CE)
+    g1, _ = oc.generators()
+    pts = oc.g1_mul_batch(g1, k_all, threads=os.cpu_count() or 1)                 # the whole instance, on the CPU
+    for q in range(2):
+        assert np.array_equal(r[q]["pts_head"], pts[int(r[q]["lo"]):int(r[q]["lo"]) + 64])
+    for step in range(3):
+        s_all = random_fr_limbs(n_total, 0xB0B + step)
+        exp = oc.msm_g1(pts, s_all, threads=os.cpu_count() or 1)
+        for q in range(2):
+            assert np.array_equal(jac_to_affine_words(r[q]["results"][step]), exp), (step, q)
+            lo, hi = int(r[q]["lo"]), int(r[q]["hi"])
+            assert np.array_equal(jac_to_affine_words(r[q]["partials"][step]), oc.msm_g1(pts[lo:hi], s_all[lo:hi], threads=8)), (step, q)
+
+
+def test_world2_bench_line(multirank_runs):
+    run = multirank_runs["bench"]
+    assert run["rc"] == 0, run["log"][-3000:]
+    j = _json_line(run["log"])
+    assert j["n_gpus"] == 2 and j["config"]["ranks_seen"] == 2 and j["scaling"] == "weak"
+    assert j["value"] and j["value"] > 0
+    assert j["checks"]["full_size_check"] is True and j["checks"]["sample_bit_exact"] is True and j["checks"]["kem_bit_exact"] is True
+    assert j["config"]["exchange_ms"] is not None
+    st = j["strong"]
+    assert st["ranks_seen"] == 2 and st["points_per_gpu"] * 2 == st["total_points"] and st["full_size_check"] is True
+    assert j["roofline"]["frac"] > 0 and j["cpu_baseline"]["value"] > 0
+
+
+def test_world2_laconic_ot(multirank_runs):
+    run = multirank_runs["laconic"]
+    assert run["rc"] == 0, run["log"][-3000:]
+    j = _json_line(run["log"])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2
+    assert j["all_messages_recovered"] is True and j["sharded_equals_single_process"] is True
+
+
+def test_world1_under_torchrun(multirank_runs):
+    """the launch line of the driver at N = 1 (torch.distributed.run with one rank): bench.py and laconic_ot.py"""
+    for name in ("bench1", "laconic1"):
+        run = multirank_runs[name]
+        assert run["rc"] == 0, run["log"][-3000:]
+        j = _json_line(run["log"])
+        assert j["n_gpus"] == 1
+    assert _json_line(multirank_runs["bench1"]["log"])["checks"]["full_size_check"] is True
+    assert _json_line(multirank_runs["laconic1"]["log"])["all_messages_recovered"] is True
