@@ -139,6 +139,7 @@ static bool try_precompute(const Device& dev, keaki_hip_srs_g1* srs) {
 }
 
 keaki_hip_srs_g1* KZGSetup::chunk_srs(size_t lo, size_t hi) const {
+  if (lo == 0 && hi == g1_aff_.size()) return srs_;            // one rank: the chunk is the SRS, its tables are there already
   if (chunk_ && chunk_lo_ == lo && chunk_hi_ == hi) return chunk_;
   if (chunk_) { keaki_hip_srs_g1_free(dev_->ctx(), chunk_); chunk_ = nullptr; }
   dev_->check(keaki_hip_srs_g1_slice(dev_->ctx(), srs_, lo, hi - lo, &chunk_));
@@ -420,6 +421,11 @@ std::pair<size_t, size_t> Shard::bounds(size_t n) const {
   const size_t base = n / world, rem = n % world;
   const size_t lo = rank * base + std::min(rank, rem);
   return {lo, lo + base + (rank < rem ? 1 : 0)};
+}
+
+void prepare(const kzg::KZGSetup& setup, const Shard& sh) {
+  auto b = sh.bounds(setup.g1_pow().size());
+  (void)setup.chunk_srs(b.first, b.second);
 }
 
 kzg::Result<Partial> commit_partial(const kzg::KZGSetup& setup, const DensePolynomial& p, const Shard& sh) {

@@ -194,6 +194,8 @@ struct Shard {
   std::pair<size_t, size_t> bounds(size_t n) const;
 };
 using Partial = std::array<uint64_t, 12>;   // normalised Jacobian (x, y, 1) or (1, 1, 0)
+// setup-time: this rank's SRS chunk as a handle of its own with its window tables (commit_partial would build them on first use)
+void prepare(const kzg::KZGSetup& setup, const Shard& sh);
 // this rank's share of kzg::commit: sum over i in bounds(setup.len) and i < p.size() of p[i] [tau^i]_1. Same error as commit.
 kzg::Result<Partial> commit_partial(const kzg::KZGSetup& setup, const DensePolynomial& p, const Shard& sh);
 // vec_commit with the final commit (src/vec.rs:46) left as this rank's partial. Padding draw, iFFT and the FK23 openings are REPLICATED:

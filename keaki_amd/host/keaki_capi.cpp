@@ -250,6 +250,9 @@ int keaki_host_vec_decrypt(void* s, const uint64_t* proofs, const uint64_t* ct_g
 }
 
 // ---- keaki::dist: one process per GPU (rank / world), the exchange of the 96-byte partials is the caller's ------------------------
+int keaki_host_prepare_shard(void* s, size_t rank, size_t world) {
+  return guard([&] { dist::prepare(((Setup*)s)->s, dist::Shard{rank, world}); return 0; });
+}
 int keaki_host_setup_has_tables(void* s) { return ((Setup*)s)->s.has_window_tables() ? 1 : 0; }
 int keaki_host_commit_partial(void* s, const uint64_t* coeffs, size_t n, size_t rank, size_t world, uint64_t* out_jac12, uint64_t* err_out) {
   return guard([&] {

@@ -337,6 +337,11 @@ def vec_decrypt(setup: KZGSetup, proofs, cts):
 
 
 # ---- keaki::dist (host/keaki.hpp): one process per GPU; the exchange of the 96-byte partials is the caller's (keaki_amd/dist.py) --------
+def prepare_shard(setup: KZGSetup, rank: int, world: int) -> None:
+    """setup-time: window tables of this rank's SRS chunk (commit_partial would build them on first use)"""
+    _ck(_lib().keaki_host_prepare_shard(setup.h, C.c_size_t(rank), C.c_size_t(world)))
+
+
 def commit_partial(setup: KZGSetup, p, rank: int, world: int) -> np.ndarray:
     """this rank's share of kzg::commit: the MSM over its contiguous range of the SRS -> normalised Jacobian u64[12]"""
     c = _u64(p, 4); out = np.zeros(12, np.uint64); err = np.zeros(2, np.uint64)

@@ -78,6 +78,7 @@ def main():
         setup_degree <<= 1
     s = K.KZGSetup.setup(rng.fr_rand(), setup_degree, device)      # SETUP_DEGREE: the domain of n+1 evaluations
     K.precompute_open_fk(s, setup_degree)                  # SRS-only part of the FK23 openings, like the MSM window tables
+    K.prepare_shard(s, rank, world)                        # window tables of this rank's SRS chunk (N > 1)
     shard.barrier()
     t_setup = time.time() - t0
     np_rng = np.random.default_rng(7)

@@ -1,0 +1,344 @@
+//! `hip` feature of keaki: the BN254 hot path on an AMD MI355X through `libkeaki_hip.so` (crate `keaki-hip-sys`).
+//!
+//! keaki's public functions stay generic over `E: Pairing`. For `E = ark_bn254::Bn254` the arkworks calls that carry the cost --
+//! `msm_unchecked` (src/kzg.rs:98), `E::pairing` + `serialize_uncompressed` + BLAKE3 (src/kem.rs:30-46, :58-69), the scalar
+//! multiplications of `encapsulate` (src/kem.rs:22,30,36,37), the group FFTs of `open_fk` (src/kzg.rs:157-203) -- are replaced by one
+//! call each into the C ABI. Every other curve keeps the arkworks path. Nothing here does arithmetic: field elements cross the boundary
+//! as the Montgomery limbs ark-ff already holds (`Fp.0.0`), points as affine (x, y) with (0, 0) for the identity.
+//!
+//! NOT compiled in the image this was written in (no Rust toolchain there); `rust/README.md` says how to build and what to run.
+#![cfg(feature = "hip")]
+
+use ark_bn254::{Bn254, Fq, Fq2, Fr, G1Affine, G1Projective, G2Affine, G2Projective};
+use ark_ec::{pairing::Pairing, CurveGroup};
+use ark_ff::{BigInt, Zero};
+use core::any::TypeId;
+use keaki_hip_sys as sys;
+use std::{
+    ffi::CStr,
+    sync::{Arc, OnceLock},
+};
+
+// ark-ff 0.4.2: Fp<MontBackend<_, 4>, 4> is `Fp(BigInt<4>, PhantomData)`, BigInt<4> is `BigInt([u64; 4])`: 32 bytes of Montgomery
+// limbs. The slices of scalars are handed to the library in place; these asserts (and `Device::self_check`) guard the assumption.
+const _: () = assert!(core::mem::size_of::<Fr>() == 32 && core::mem::align_of::<Fr>() == 8);
+const _: () = assert!(core::mem::size_of::<Fq>() == 32);
+
+/// GT as `serialize_uncompressed` writes it (12 x 32 canonical little-endian bytes).
+pub const GT_BYTES: usize = 384;
+
+// ------------------------------------------------------------------------------------------------ device
+/// One GPU context for the process (`KEAKI_HIP_DEVICE` picks the ordinal, default 0). The C ABI serialises calls on a context
+/// internally, so sharing it between threads is sound.
+pub struct Device {
+    ctx: *mut sys::keaki_hip_ctx,
+}
+unsafe impl Send for Device {}
+unsafe impl Sync for Device {}
+
+impl Device {
+    pub fn global() -> &'static Device {
+        static DEV: OnceLock<Device> = OnceLock::new();
+        DEV.get_or_init(|| {
+            let ordinal = std::env::var("KEAKI_HIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0i32);
+            let mut ctx = core::ptr::null_mut();
+            let st = unsafe { sys::keaki_hip_ctx_create(ordinal, sys::KEAKI_HIP_STREAM_PRIVATE, &mut ctx) };
+            if st != sys::KEAKI_OK {
+                // the feature was asked for: fail loudly instead of silently computing on the CPU
+                let msg = unsafe { CStr::from_ptr(sys::keaki_hip_last_error(core::ptr::null())) }.to_string_lossy().into_owned();
+                panic!("keaki `hip` feature: cannot create a context on device {ordinal}: {msg} (status {st})");
+            }
+            let dev = Device { ctx };
+            dev.self_check();
+            dev
+        })
+    }
+
+    fn check(&self, st: sys::keaki_status, what: &str) {
+        if st != sys::KEAKI_OK {
+            let msg = unsafe { CStr::from_ptr(sys::keaki_hip_last_error(self.ctx)) }.to_string_lossy().into_owned();
+            panic!("libkeaki_hip: {what} failed with status {st}: {msg}");
+        }
+    }
+
+    /// 1 * G1 through the library must be arkworks' generator: catches a layout mismatch (limb order, Montgomery radix) at start-up.
+    fn self_check(&self) {
+        use ark_ec::AffineRepr;
+        let g = G1Affine::generator();
+        let one = Fr::from(1u64);
+        let mut out = [0u64; 8];
+        let st = unsafe { sys::keaki_hip_g1_mul_batch(self.ctx, g1_words(&g).as_ptr(), 0, fr_ptr(core::slice::from_ref(&one)), 1, out.as_mut_ptr()) };
+        self.check(st, "self-check g1_mul_batch");
+        assert_eq!(g1_from_words(&out), g, "libkeaki_hip and ark-ff disagree on the limb layout");
+    }
+}
+
+impl Drop for Device {
+    fn drop(&mut self) {
+        unsafe { sys::keaki_hip_ctx_destroy(self.ctx) }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ layout (no arithmetic)
+fn fr_ptr(s: &[Fr]) -> *const u64 {
+    s.as_ptr() as *const u64
+}
+fn fq_words(x: &Fq) -> [u64; 4] {
+    x.0 .0
+}
+fn fq_from_words(w: &[u64]) -> Fq {
+    Fq::new_unchecked(BigInt::new([w[0], w[1], w[2], w[3]])) // limbs are already Montgomery residues
+}
+/// arkworks' `Affine { x, y, infinity }` is repr(Rust): write the fields explicitly; identity = all-zero words
+pub fn g1_words(p: &G1Affine) -> [u64; 8] {
+    let mut w = [0u64; 8];
+    if !p.infinity {
+        w[..4].copy_from_slice(&fq_words(&p.x));
+        w[4..].copy_from_slice(&fq_words(&p.y));
+    }
+    w
+}
+pub fn g2_words(p: &G2Affine) -> [u64; 16] {
+    let mut w = [0u64; 16];
+    if !p.infinity {
+        w[..4].copy_from_slice(&fq_words(&p.x.c0));
+        w[4..8].copy_from_slice(&fq_words(&p.x.c1));
+        w[8..12].copy_from_slice(&fq_words(&p.y.c0));
+        w[12..].copy_from_slice(&fq_words(&p.y.c1));
+    }
+    w
+}
+pub fn g1_from_words(w: &[u64]) -> G1Affine {
+    if w[..8].iter().all(|&x| x == 0) {
+        return G1Affine::identity();
+    }
+    G1Affine::new_unchecked(fq_from_words(&w[..4]), fq_from_words(&w[4..8]))
+}
+pub fn g2_from_words(w: &[u64]) -> G2Affine {
+    if w[..16].iter().all(|&x| x == 0) {
+        return G2Affine::identity();
+    }
+    G2Affine::new_unchecked(
+        Fq2::new(fq_from_words(&w[..4]), fq_from_words(&w[4..8])),
+        Fq2::new(fq_from_words(&w[8..12]), fq_from_words(&w[12..16])),
+    )
+}
+/// normalised Jacobian (x, y, 1) or (1, 1, 0) as the MSM entry points return it
+fn g1_from_jac(w: &[u64; 12]) -> G1Projective {
+    if w[8..].iter().all(|&x| x == 0) {
+        return G1Projective::zero();
+    }
+    g1_from_words(&w[..8]).into()
+}
+
+// ------------------------------------------------------------------------------------------------ the SRS on the device
+/// `KZGSetup::g1_aff` resident in HBM (uploaded once, with the window tables of the fixed bases).
+pub struct HipSrs {
+    srs: *mut sys::keaki_hip_srs_g1,
+    len: usize,
+}
+unsafe impl Send for HipSrs {}
+unsafe impl Sync for HipSrs {}
+
+impl HipSrs {
+    pub fn upload(g1_aff: &[G1Affine]) -> Self {
+        let dev = Device::global();
+        let words: Vec<u64> = g1_aff.iter().flat_map(|p| g1_words(p)).collect();
+        let mut srs = core::ptr::null_mut();
+        dev.check(unsafe { sys::keaki_hip_srs_g1_upload(dev.ctx, words.as_ptr(), g1_aff.len(), &mut srs) }, "srs_g1_upload");
+        // optional memory: without room for the tables the handle keeps working through the generic MSM path
+        let st = unsafe { sys::keaki_hip_srs_g1_precompute(dev.ctx, srs, core::ptr::null_mut()) };
+        if st != sys::KEAKI_ERR_OOM {
+            dev.check(st, "srs_g1_precompute");
+        }
+        HipSrs { srs, len: g1_aff.len() }
+    }
+    pub fn len(&self) -> usize {
+        self.len
+    }
+    pub fn is_empty(&self) -> bool {
+        self.len == 0
+    }
+}
+impl Drop for HipSrs {
+    fn drop(&mut self) {
+        unsafe { sys::keaki_hip_srs_g1_free(Device::global().ctx, self.srs) }
+    }
+}
+
+/// Lazily uploaded device copy of a `KZGSetup`'s SRS. A field of `KZGSetup` under the feature; invisible to its derived traits.
+#[derive(Default)]
+pub struct SetupCache(OnceLock<Arc<HipSrs>>);
+impl SetupCache {
+    fn get(&self, g1_aff: &[G1Affine]) -> &Arc<HipSrs> {
+        self.0.get_or_init(|| Arc::new(HipSrs::upload(g1_aff)))
+    }
+}
+impl Clone for SetupCache {
+    fn clone(&self) -> Self {
+        let c = SetupCache::default();
+        if let Some(a) = self.0.get() {
+            let _ = c.0.set(a.clone());
+        }
+        c
+    }
+}
+impl core::fmt::Debug for SetupCache {
+    fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result {
+        write!(f, "SetupCache(uploaded: {})", self.0.get().is_some())
+    }
+}
+impl PartialEq for SetupCache {
+    fn eq(&self, _: &Self) -> bool {
+        true // a cache: equal setups are equal whether or not they have been uploaded
+    }
+}
+impl Eq for SetupCache {}
+
+// ------------------------------------------------------------------------------------------------ BN254 entry points
+pub fn commit(srs: &HipSrs, coeffs: &[Fr]) -> G1Projective {
+    let dev = Device::global();
+    let mut out = [0u64; 12];
+    dev.check(unsafe { sys::keaki_hip_msm_g1(dev.ctx, srs.srs, fr_ptr(coeffs), coeffs.len(), out.as_mut_ptr()) }, "msm_g1");
+    g1_from_jac(&out)
+}
+
+/// `open`: quotient and its commitment in one device call. `coeffs` = the polynomial with trailing zeros trimmed (DensePolynomial).
+pub fn open(srs: &HipSrs, coeffs: &[Fr], point: &Fr) -> G1Projective {
+    let dev = Device::global();
+    let mut out = [0u64; 12];
+    dev.check(
+        unsafe { sys::keaki_hip_kzg_open(dev.ctx, srs.srs, fr_ptr(coeffs), coeffs.len(), fr_ptr(core::slice::from_ref(point)), out.as_mut_ptr(), core::ptr::null_mut()) },
+        "kzg_open",
+    );
+    g1_from_jac(&out)
+}
+
+pub fn verify(commitment: &G1Projective, tau_g2: &G2Projective, point: &Fr, value: &Fr, proof: &G1Projective) -> bool {
+    let dev = Device::global();
+    let (c, t, p) = (g1_words(&commitment.into_affine()), g2_words(&tau_g2.into_affine()), g1_words(&proof.into_affine()));
+    let mut ok = 0i32;
+    dev.check(
+        unsafe {
+            sys::keaki_hip_kzg_verify(dev.ctx, c.as_ptr(), t.as_ptr(), fr_ptr(core::slice::from_ref(point)), fr_ptr(core::slice::from_ref(value)), p.as_ptr(), &mut ok)
+        },
+        "kzg_verify",
+    );
+    ok != 0
+}
+
+/// FK23: all `d = coeffs.len()` openings at the d-th roots of unity (d a power of two, d <= srs.len()). `omega_2d`, `omega_2d_inv`,
+/// `inv_2d` = `group_gen`, `group_gen_inv`, `size_inv` of `Radix2EvaluationDomain::new(2 d)`.
+pub fn open_fk(srs: &HipSrs, coeffs: &[Fr], omega_2d: &Fr, omega_2d_inv: &Fr, inv_2d: &Fr) -> Vec<G1Projective> {
+    let dev = Device::global();
+    let d = coeffs.len();
+    assert!(d.is_power_of_two() && d <= srs.len());
+    let mut out = vec![0u64; 8 * d];
+    dev.check(
+        unsafe {
+            sys::keaki_hip_open_fk_poly(
+                dev.ctx, srs.srs, d.trailing_zeros(), fr_ptr(coeffs), fr_ptr(core::slice::from_ref(omega_2d)),
+                fr_ptr(core::slice::from_ref(omega_2d_inv)), fr_ptr(core::slice::from_ref(inv_2d)), out.as_mut_ptr(),
+            )
+        },
+        "open_fk_poly",
+    );
+    out.chunks_exact(8).map(|w| g1_from_words(w).into()).collect()
+}
+
+/// The loop body of `vec_encrypt` (src/vec.rs:63-66 -> src/enc.rs:19-40 -> src/kem.rs:13-50) for all items at once: the SAME commitment
+/// and setup for every item, `rs[i]` drawn by the caller in index order. Returns the ciphertext points and `n * msg_len` key bytes.
+pub fn encap_batch(commitment: &G1Projective, tau_g2: &G2Projective, points: &[Fr], values: &[Fr], rs: &[Fr], msg_len: usize) -> (Vec<G2Projective>, Vec<u8>) {
+    let dev = Device::global();
+    let n = points.len();
+    assert!(values.len() >= n && rs.len() == n);
+    let (c, t) = (g1_words(&commitment.into_affine()), g2_words(&tau_g2.into_affine()));
+    let mut ct = vec![0u64; 16 * n];
+    let mut gt = vec![0u8; if msg_len == 0 { GT_BYTES * n } else { 0 }];
+    let mut key = vec![0u8; n * msg_len];
+    dev.check(
+        unsafe {
+            sys::keaki_hip_encap_batch(
+                dev.ctx, c.as_ptr(), t.as_ptr(), fr_ptr(points), fr_ptr(values), fr_ptr(rs), n, ct.as_mut_ptr(),
+                if msg_len == 0 { gt.as_mut_ptr() } else { core::ptr::null_mut() },
+                if msg_len == 0 { core::ptr::null_mut() } else { key.as_mut_ptr() },
+                msg_len,
+            )
+        },
+        "encap_batch",
+    );
+    (ct.chunks_exact(16).map(|w| g2_from_words(w).into()).collect(), key)
+}
+
+/// The loop body of `vec_decrypt` (src/vec.rs:75-78 -> src/kem.rs:55-72): `n * msg_len` key bytes.
+pub fn decap_batch(proofs: &[G1Projective], cts: &[G2Projective], msg_len: usize) -> Vec<u8> {
+    let dev = Device::global();
+    let n = cts.len();
+    if n == 0 || msg_len == 0 {
+        return Vec::new();
+    }
+    let p: Vec<u64> = G1Projective::normalize_batch(&proofs[..n]).iter().flat_map(|a| g1_words(a)).collect();
+    let q: Vec<u64> = G2Projective::normalize_batch(cts).iter().flat_map(|a| g2_words(a)).collect();
+    let mut key = vec![0u8; n * msg_len];
+    dev.check(
+        unsafe { sys::keaki_hip_decap_batch(dev.ctx, p.as_ptr(), q.as_ptr(), n, core::ptr::null_mut(), key.as_mut_ptr(), msg_len) },
+        "decap_batch",
+    );
+    key
+}
+
+/// `serialize_uncompressed(E::pairing(p, q))` for a batch (tests and callers that want GT itself).
+pub fn pairing_bytes(ps: &[G1Affine], qs: &[G2Affine]) -> Vec<u8> {
+    let dev = Device::global();
+    let n = ps.len();
+    assert_eq!(qs.len(), n);
+    let p: Vec<u64> = ps.iter().flat_map(|a| g1_words(a)).collect();
+    let q: Vec<u64> = qs.iter().flat_map(|a| g2_words(a)).collect();
+    let mut gt = vec![0u8; GT_BYTES * n];
+    dev.check(unsafe { sys::keaki_hip_pairing_batch(dev.ctx, p.as_ptr(), q.as_ptr(), 1, n, gt.as_mut_ptr()) }, "pairing_batch");
+    gt
+}
+
+/// `domain.ifft` of src/vec.rs:37 on the device: `data.len()` = the domain size (power of two), padded by the caller.
+pub fn fr_ifft_in_place(data: &mut [Fr], group_gen_inv: &Fr, size_inv: &Fr) {
+    let dev = Device::global();
+    assert!(data.len().is_power_of_two());
+    dev.check(
+        unsafe {
+            sys::keaki_hip_fr_fft(dev.ctx, data.as_mut_ptr() as *mut u64, data.len().trailing_zeros(), fr_ptr(core::slice::from_ref(group_gen_inv)), fr_ptr(core::slice::from_ref(size_inv)))
+        },
+        "fr_fft",
+    );
+}
+
+// ------------------------------------------------------------------------------------------------ dispatch from the generic functions
+/// `true` when the generic parameter is BN254 and the feature is not switched off at run time (`KEAKI_HIP=off`).
+pub fn active<E: Pairing>() -> bool {
+    TypeId::of::<E>() == TypeId::of::<Bn254>() && std::env::var("KEAKI_HIP").map(|v| v != "off").unwrap_or(true)
+}
+
+/// Reinterpret `&A` as `&B` when they are the same type. The callers have established `E == Bn254`, which makes `E::G1` and
+/// `G1Projective` (etc.) one type; TypeId re-checks it, so a wrong call panics instead of transmuting.
+pub fn same<A: 'static, B: 'static>(a: &A) -> &B {
+    assert_eq!(TypeId::of::<A>(), TypeId::of::<B>());
+    unsafe { &*(a as *const A as *const B) }
+}
+pub fn same_slice<A: 'static, B: 'static>(a: &[A]) -> &[B] {
+    assert_eq!(TypeId::of::<A>(), TypeId::of::<B>());
+    unsafe { core::slice::from_raw_parts(a.as_ptr() as *const B, a.len()) }
+}
+pub fn same_owned<A: 'static, B: 'static>(a: A) -> B {
+    assert_eq!(TypeId::of::<A>(), TypeId::of::<B>());
+    let a = core::mem::ManuallyDrop::new(a);
+    unsafe { core::ptr::read(&*a as *const A as *const B) }
+}
+pub fn same_vec<A: 'static, B: 'static>(v: Vec<A>) -> Vec<B> {
+    assert_eq!(TypeId::of::<A>(), TypeId::of::<B>());
+    let mut v = core::mem::ManuallyDrop::new(v);
+    unsafe { Vec::from_raw_parts(v.as_mut_ptr() as *mut B, v.len(), v.capacity()) }
+}
+
+/// The device copy of a setup's SRS (uploaded on first use).
+pub fn srs_of<'a, E: Pairing>(cache: &'a SetupCache, g1_aff: &[E::G1Affine]) -> &'a HipSrs {
+    cache.get(same_slice::<E::G1Affine, G1Affine>(g1_aff))
+}

@@ -1,0 +1,200 @@
+//! Parity of the `hip` feature against arkworks itself -- the check that cannot run in the image the MI355X backend was built in
+//! (no Rust toolchain there), and the one that closes its "parity unpinned" residual: the absolute GT value (final-exponent multiple,
+//! tower basis, serialisation order) and therefore every KEM key.
+//!
+//!     KEAKI_HIP_LIB_DIR=/path/to/keaki_amd cargo test --release --features hip --test hip_parity -- --nocapture
+//!
+//! The constants below are tests/golden/bn254_vectors.json of the MI355X tree (made by its CPU oracle): if arkworks disagrees with
+//! them, the ORACLE is wrong; if the GPU disagrees with arkworks, the kernels are.
+#![cfg(feature = "hip")]
+
+use ark_bn254::{Bn254, Fq, Fq2, Fr, G1Affine, G1Projective, G2Affine, G2Projective};
+use ark_ec::{pairing::Pairing, AffineRepr, CurveGroup, VariableBaseMSM};
+use ark_ff::PrimeField;
+use ark_poly::{univariate::DensePolynomial, DenseUVPolynomial, EvaluationDomain, Radix2EvaluationDomain};
+use ark_serialize::CanonicalSerialize;
+use ark_std::{ops::Mul, test_rng, UniformRand};
+use keaki::{
+    hip,
+    kem::{decapsulate, encapsulate},
+    kzg::{commit, open, open_fk, verify, KZGSetup},
+    vec::{vec_commit, vec_decrypt, vec_encrypt},
+};
+
+/// serialize_uncompressed(e(G1, G2)) according to the oracle (sha-256 e109983de6d3ff0d8d4e1236dd4d91d2a313d7e7a22e3a15062b6759ad70331c)
+const GT_OF_GENERATORS_HEX: &str = concat!(
+    "950e879d73631f5eb5788589eb5f7ef8d63e0a28de1ba00dfe4ca9ed3f252b264a8afb8eb4349db466ed1809ea4d7c39",
+    "bdab7938821f1b0a00a295c72c2de002e01dbdfd0254134efcb1ec877395d25f937719b344adb1a58d129be2d6f2a913"
+    "2b16a16e8ab030b130e69c69bd20b4c45986e6744a98314b5c1a0f50faa90b04dbaf9ef8aeeee3f50be31c210b598f47",
+    "52f073987f9d35be8f6770d83f2ffc0af0d18dd9d2dbcdf943825acc12a7a9ddca45e629d962c6bd64908c3930a5541c"
+    "fe2924dcc5580d5cef7a4bfdec90a91b59926f850d4a7923c01a5a5dbf0f5c094a2b9fb9d415820fa6b40c59bb9eade9",
+    "c953407b0fc11da350a9d872cad6d3142974ca385854afdf5f583c04231adc5957c8914b6b20dc89660ed7c3bbe7c01d"
+    "972be2d53ecdb27a1bcc16ac610db95aa7d237c8ff55a898cb88645a0e32530b23d7ebf5dafdd79b0f9c2ac4ba07ce18",
+    "d3d16cf36e47916c4cae5d08d3afa813972c769e8514533e380c9443b3e1ee5c96fa3a0a73f301b626454721527bf900"
+);
+
+// one KEM vector of the oracle (canonical decimal integers): tau, commitment C, point alpha, value beta, randomness r
+const KEM_TAU: &str = "16108486810683800910316471678634637090532684621664899853843559589009028751094";
+const KEM_COM: [&str; 2] = ["8301085058852846531532799415381687432237323807022128681561952933606273730036", "21492297623070018767944304975622711585455352824125049729415138778289051475193"];
+const KEM_POINT: &str = "18421418035183923608318714001760815819998638789739981746722599328348178616250";
+const KEM_VALUE: &str = "19796525744667426349873518466399876375687502633323377217699839780345057951712";
+const KEM_R: &str = "9222778255153844183597133810292204042513128492245322607305955548628659646598";
+const KEM_GT_HEX: &str = concat!(
+    "b5951694bedc946d0cb033071ebccb74905604a0b0c5a66cda9c8ec0b2e10c0a549140177daa327d0e89b4f21beafb13",
+    "b29e86fd6d4e1f2a87eff1c5cd622409115543ce297d946d44217ccb7af716346077588ce8f2c449f7e37a0bb676e31f"
+    "c496512b3851851460add03bf4f0abcfbc7d63b0cafcb3b0fd90b1bf7b6ef62d430e57ebde40785394be150e2dd1ad2f",
+    "94f51e4a6131bacd70d51a03f43d162db1e54bca000e2298bb3470421d549bcb6e356d30cff97fb72c80eb17972f4406"
+    "4a47cee237e27b4bfa0f2104b2cdf7c36c40387931f6ef4210dcfb5f69f46c18f60fda3398158fd95ac72daf927a92ae",
+    "c4344361f53c9614b9d2e3cd1605bd2e24fd3035cbddcb02f6339450936132ccf6de676e86110e5f7332d2fd8c32812f"
+    "7cc69690d85e3b2294297f5e83e878d20c8088a6d5a3a057f6e2ad4948a24d27b3b8f2912973c67d62718db3ee083c6e",
+    "d2b7cf4b311016dff36b1e9057fd2217042a0c386d65cf3816ee890850be5aff54630b783984b079925b4d6ffdca7100"
+);
+const KEM_KEY_HEX: &str = "e7f29112b1833c5614ca4457b23f10fce69eabfb19695af33781b81007d8c244";
+
+fn fr(s: &str) -> Fr {
+    Fr::from_le_bytes_mod_order(&num_le(s))
+}
+fn fq(s: &str) -> Fq {
+    Fq::from_le_bytes_mod_order(&num_le(s))
+}
+/// decimal string -> little-endian bytes (schoolbook; the test has no bignum dependency)
+fn num_le(s: &str) -> Vec<u8> {
+    let mut out = vec![0u8; 32];
+    for ch in s.bytes() {
+        let mut carry = (ch - b'0') as u32;
+        for b in out.iter_mut() {
+            let v = (*b as u32) * 10 + carry;
+            *b = v as u8;
+            carry = v >> 8;
+        }
+    }
+    out
+}
+fn hex(b: &[u8]) -> String {
+    b.iter().map(|x| format!("{x:02x}")).collect()
+}
+fn gt_bytes(p: G1Affine, q: G2Affine) -> Vec<u8> {
+    let mut b = Vec::new();
+    Bn254::pairing(p, q).serialize_uncompressed(&mut b).unwrap();
+    b
+}
+/// a rand::Rng that replays fixed values of Fr::rand: 4 x next_u64 per draw = the limbs of the Montgomery representation
+struct Replay(Vec<u64>, usize);
+impl Replay {
+    fn of(values: &[Fr]) -> Self {
+        Replay(values.iter().flat_map(|v| v.0 .0).collect(), 0)
+    }
+}
+impl rand::RngCore for Replay {
+    fn next_u32(&mut self) -> u32 {
+        self.next_u64() as u32
+    }
+    fn next_u64(&mut self) -> u64 {
+        self.1 += 1;
+        self.0[self.1 - 1]
+    }
+    fn fill_bytes(&mut self, dest: &mut [u8]) {
+        for c in dest.chunks_mut(8) {
+            let v = self.next_u64().to_le_bytes();
+            c.copy_from_slice(&v[..c.len()]);
+        }
+    }
+    fn try_fill_bytes(&mut self, dest: &mut [u8]) -> Result<(), rand::Error> {
+        self.fill_bytes(dest);
+        Ok(())
+    }
+}
+
+#[test]
+fn gt_of_generators_arkworks_oracle_gpu() {
+    let ark = gt_bytes(G1Affine::generator(), G2Affine::generator());
+    assert_eq!(hex(&ark), GT_OF_GENERATORS_HEX, "arkworks disagrees with the oracle's golden vector: the oracle's GT convention is wrong");
+    let gpu = hip::pairing_bytes(&[G1Affine::generator()], &[G2Affine::generator()]);
+    assert_eq!(gpu, ark, "GPU pairing bytes differ from arkworks");
+}
+
+#[test]
+fn pairing_batch_matches_arkworks_on_random_points() {
+    let rng = &mut test_rng();
+    let n = 64;
+    let ps: Vec<G1Affine> = (0..n).map(|_| G1Affine::generator().mul(Fr::rand(rng)).into_affine()).collect();
+    let mut qs: Vec<G2Affine> = (0..n).map(|_| G2Affine::generator().mul(Fr::rand(rng)).into_affine()).collect();
+    qs[3] = G2Affine::identity(); // identity in a slot -> GT one
+    let gpu = hip::pairing_bytes(&ps, &qs);
+    for i in 0..n {
+        assert_eq!(&gpu[384 * i..384 * (i + 1)], &gt_bytes(ps[i], qs[i])[..], "item {i}");
+    }
+}
+
+#[test]
+fn msm_commit_open_verify_match_arkworks() {
+    let rng = &mut test_rng();
+    for &n in &[1usize, 2, 33, 129, 1 << 12] {
+        let setup = KZGSetup::<Bn254>::setup(Fr::rand(rng), n);
+        let p = DensePolynomial::from_coefficients_vec((0..n).map(|_| Fr::rand(rng)).collect());
+        let gpu = commit(&setup, &p).unwrap(); // hip path
+        let cpu = <G1Projective as VariableBaseMSM>::msm_unchecked(setup.g1_aff(), &p.coeffs);
+        assert_eq!(gpu.into_affine(), cpu.into_affine(), "commit n={n}");
+        let z = Fr::rand(rng);
+        let proof = open(&setup, &p, &z).unwrap(); // hip path: device quotient + MSM
+        std::env::set_var("KEAKI_HIP", "off");
+        let proof_cpu = open(&setup, &p, &z).unwrap(); // arkworks path
+        std::env::remove_var("KEAKI_HIP");
+        assert_eq!(proof.into_affine(), proof_cpu.into_affine(), "open n={n}");
+        use ark_poly::Polynomial;
+        let v = p.evaluate(&z);
+        assert!(verify(&setup, gpu, z, v, proof).unwrap());
+        assert!(!verify(&setup, gpu, z, v + Fr::from(1u64), proof).unwrap());
+    }
+}
+
+#[test]
+fn kem_vector_of_the_oracle_arkworks_and_gpu() {
+    let tau = fr(KEM_TAU);
+    let setup = KZGSetup::<Bn254>::setup(tau, 8);
+    let com: G1Projective = G1Affine::new(fq(KEM_COM[0]), fq(KEM_COM[1])).into();
+    let (point, value, r) = (fr(KEM_POINT), fr(KEM_VALUE), fr(KEM_R));
+    // arkworks path with r replayed
+    std::env::set_var("KEAKI_HIP", "off");
+    let (ct_cpu, key_cpu) = encapsulate::<Bn254>(&mut Replay::of(&[r]), &setup, com, point, value, 32);
+    std::env::remove_var("KEAKI_HIP");
+    assert_eq!(hex(&key_cpu), KEM_KEY_HEX, "arkworks disagrees with the oracle's KEM key");
+    let secret = gt_bytes((com - G1Affine::generator().mul(value)).mul(r).into_affine(), G2Affine::generator());
+    assert_eq!(hex(&secret), KEM_GT_HEX);
+    // GPU path, same r
+    let (ct_gpu, key_gpu) = encapsulate::<Bn254>(&mut Replay::of(&[r]), &setup, com, point, value, 32);
+    assert_eq!(ct_gpu.into_affine(), ct_cpu.into_affine());
+    assert_eq!(key_gpu, key_cpu);
+}
+
+#[test]
+fn vec_flow_matches_serial_arkworks_loop() {
+    // Laconic-OT shaped: vec_commit, vec_encrypt to "value i == b", vec_decrypt; GPU path and arkworks path from the same rng seed
+    let n = 15usize; // domain 16
+    let run = |hip_on: bool| {
+        if !hip_on {
+            std::env::set_var("KEAKI_HIP", "off");
+        }
+        let rng = &mut test_rng();
+        let setup = KZGSetup::<Bn254>::setup(Fr::rand(rng), 16);
+        let v: Vec<Fr> = (0..n).map(|i| Fr::from((i % 2) as u64)).collect();
+        let (com, proofs) = vec_commit(rng, &setup, &v).unwrap();
+        let dom = Radix2EvaluationDomain::<Fr>::new(n + 1).unwrap();
+        let points: Vec<Fr> = dom.elements().collect();
+        let msgs: Vec<Vec<u8>> = (0..n).map(|i| vec![i as u8; 1 + (i % 5) * 7]).collect(); // ragged lengths
+        let refs: Vec<&[u8]> = msgs.iter().map(|m| m.as_slice()).collect();
+        let cts = vec_encrypt(rng, &setup, com, &points, &v, &refs);
+        let ct_refs: Vec<_> = cts.iter().collect();
+        let dec = vec_decrypt::<Bn254>(&proofs, &ct_refs);
+        std::env::remove_var("KEAKI_HIP");
+        (com.into_affine(), G1Projective::normalize_batch(&proofs), cts.iter().map(|c| (c.0.into_affine(), c.1.clone())).collect::<Vec<_>>(), dec, msgs)
+    };
+    let (c1, p1, e1, d1, m1) = run(true);
+    let (c0, p0, e0, d0, _) = run(false);
+    assert_eq!(c1, c0);
+    assert_eq!(p1, p0, "FK23 proofs");
+    assert_eq!(e1, e0, "ciphertexts");
+    assert_eq!(d1, d0);
+    assert_eq!(d1, m1, "messages recovered");
+    let _ = (open_fk::<Bn254>, decapsulate::<Bn254>, Fq2::new(Fq::from(0u64), Fq::from(0u64)), G2Projective::default());
+}

@@ -1,0 +1,128 @@
+"""CPU suite: the Rust side of the boundary (rust/) against the C header -- the check that would have caught a declaration with a
+missing parameter. No Rust toolchain is needed: the `extern "C"` block is parsed as text.
+  * every function of include/keaki_hip.h is declared in rust/keaki-hip-sys/src/lib.rs, and nothing else is;
+  * same parameter count, same width / pointer-ness per parameter, same return type;
+  * the glue module and the patch only call symbols that are declared;
+  * the patch applies cleanly to the reference sources (when /root/reference is present: not on the GPU box)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RUST = os.path.join(ROOT, "rust")
+
+
+def _strip_c_comments(t):
+    return re.sub(r"/\*.*?\*/", "", t, flags=re.S)
+
+
+def c_functions():
+    hdr = _strip_c_comments(open(os.path.join(ROOT, "include", "keaki_hip.h")).read())
+    out = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(keaki_hip_\w+)\s*\(([^;{]*?)\)\s*;", hdr):
+        ret, name, params = m.group(1).strip(), m.group(2), m.group(3).strip()
+        plist = [] if params in ("", "void") else [p.strip() for p in params.split(",")]
+        out[name] = (ret, plist)
+    return out
+
+
+def rust_functions():
+    src = open(os.path.join(RUST, "keaki-hip-sys", "src", "lib.rs")).read()
+    src = re.sub(r"//.*", "", src)
+    block = re.search(r'extern\s+"C"\s*\{(.*)\}', src, flags=re.S).group(1)
+    out = {}
+    for m in re.finditer(r"pub\s+fn\s+(\w+)\s*\((.*?)\)\s*(?:->\s*([^;]+?))?\s*;", block, flags=re.S):
+        name, params, ret = m.group(1), m.group(2).strip(), (m.group(3) or "()").strip()
+        plist = [p.strip() for p in params.split(",") if p.strip()]
+        out[name] = (ret, [p.split(":", 1)[1].strip() for p in plist])
+    return out
+
+
+def c_class(t):
+    """(is_pointer, pointee / scalar class)"""
+    t = re.sub(r"\bconst\b", "", t)
+    t = re.sub(r"\b[a-z_]\w*$", "", t.strip()) if not t.strip().endswith("*") else t      # drop the parameter name
+    t = t.strip()
+    stars = t.count("*")
+    base = t.replace("*", "").strip()
+    scalar = {"int32_t": "i32", "uint32_t": "u32", "size_t": "usize", "uint64_t": "u64", "uint8_t": "u8", "float": "f32", "void": "void", "char": "c_char",
+              "keaki_status": "i32", "keaki_hip_ctx": "ctx", "keaki_hip_srs_g1": "srs_g1", "keaki_hip_srs_g2": "srs_g2"}[base]
+    return stars, scalar
+
+
+def rust_class(t):
+    t = t.strip()
+    stars = len(re.findall(r"\*(?:const|mut)", t))
+    base = re.sub(r"\*(?:const|mut)\s*", "", t).strip()
+    scalar = {"i32": "i32", "u32": "u32", "usize": "usize", "u64": "u64", "u8": "u8", "f32": "f32", "c_void": "void", "c_char": "c_char", "keaki_status": "i32",
+              "keaki_hip_ctx": "ctx", "keaki_hip_srs_g1": "srs_g1", "keaki_hip_srs_g2": "srs_g2", "()": "void"}[base]
+    return stars, scalar
+
+
+def test_sys_crate_declares_exactly_the_header():
+    c, r = c_functions(), rust_functions()
+    assert len(c) >= 45
+    assert sorted(c) == sorted(r), (sorted(set(c) - set(r)), sorted(set(r) - set(c)))
+    for name in c:
+        cret, cparams = c[name]
+        rret, rparams = r[name]
+        assert len(cparams) == len(rparams), "%s: %d parameters in the header, %d in Rust" % (name, len(cparams), len(rparams))
+        for i, (cp, rp) in enumerate(zip(cparams, rparams)):
+            assert c_class(cp) == rust_class(rp), "%s parameter %d: C `%s` vs Rust `%s`" % (name, i, cp, rp)
+        assert c_class(cret + " x" if not cret.endswith("*") else cret) == rust_class(rret), "%s return: C `%s` vs Rust `%s`" % (name, cret, rret)
+
+
+def test_const_pointers_agree():
+    """*const on the Rust side exactly where the header says const (a shim that takes *mut for an input invites aliasing bugs)"""
+    c, r = c_functions(), rust_functions()
+    for name in c:
+        for cp, rp in zip(c[name][1], r[name][1]):
+            if "*" in cp and cp.count("*") == 1:
+                assert ("const" in cp) == rp.startswith("*const"), "%s: C `%s` vs Rust `%s`" % (name, cp, rp)
+
+
+def test_glue_calls_only_declared_symbols():
+    declared = set(rust_functions())
+    for rel in ("keaki/src/hip.rs", "keaki/tests/hip_parity.rs", "keaki/keaki-hip.patch"):
+        text = open(os.path.join(RUST, rel)).read()
+        used = set(re.findall(r"\b(keaki_hip_\w+)\b", text)) - {"keaki_hip_sys", "keaki_hip_ctx", "keaki_hip_srs_g1", "keaki_hip_srs_g2"}
+        assert used <= declared, (rel, sorted(used - declared))
+    glue = open(os.path.join(RUST, "keaki", "src", "hip.rs")).read()
+    for sym in ("keaki_hip_msm_g1", "keaki_hip_kzg_open", "keaki_hip_kzg_verify", "keaki_hip_open_fk_poly", "keaki_hip_encap_batch", "keaki_hip_decap_batch",
+                "keaki_hip_pairing_batch", "keaki_hip_srs_g1_upload", "keaki_hip_srs_g1_precompute"):
+        assert sym in glue
+    # the precompute call passes three arguments (the declaration VERDICT r01 found wrong had two)
+    assert re.search(r"keaki_hip_srs_g1_precompute\(\s*dev\.ctx,\s*srs,\s*core::ptr::null_mut\(\)\s*\)", glue)
+
+
+def test_patch_touches_the_cited_call_sites_and_applies():
+    patch = open(os.path.join(RUST, "keaki", "keaki-hip.patch")).read()
+    for f in ("Cargo.toml", "src/lib.rs", "src/kzg.rs", "src/kem.rs", "src/vec.rs"):
+        assert "+++ b/%s" % f in patch
+    for needle in ("crate::hip::commit", "crate::hip::open(", "crate::hip::verify", "crate::hip::open_fk", "crate::hip::encap_batch", "crate::hip::decap_batch",
+                   'hip = ["dep:keaki-hip-sys"'):
+        assert needle in patch, needle
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "src")):
+        pytest.skip("reference sources not present (GPU box)")
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        shutil.copy(os.path.join(ref, "Cargo.toml"), td)
+        shutil.copytree(os.path.join(ref, "src"), os.path.join(td, "src"))
+        p = subprocess.run(["patch", "-p1", "--dry-run", "-i", os.path.join(RUST, "keaki", "keaki-hip.patch")], cwd=td, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
+        assert p.returncode == 0, p.stdout
+
+
+def test_parity_constants_are_the_golden_vectors():
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "bn254_vectors.json")))
+    t = open(os.path.join(RUST, "keaki", "tests", "hip_parity.rs")).read()
+    join = lambda name: "".join(re.findall(r'"([0-9a-f]+)"', re.search(name + r": &str = concat!\((.*?)\);", t, flags=re.S).group(1)))
+    assert join("GT_OF_GENERATORS_HEX") == g["pairing"][0]["gt_hex"] and g["pairing"][0]["a"] == "1" and g["pairing"][0]["b"] == "1"
+    assert join("KEM_GT_HEX") == g["kem"]["gt_hex"]
+    assert g["kem"]["key_hex"] in t and g["kem"]["r"] in t and g["kem"]["tau"] in t
+    assert "e109983de6d3ff0d8d4e1236dd4d91d2a313d7e7a22e3a15062b6759ad70331c" == g["pairing"][0]["gt_sha256"]
