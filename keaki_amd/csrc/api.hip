@@ -141,7 +141,7 @@ void keaki_hip_ctx_destroy(keaki_hip_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf* b : {&ctx->digits, &ctx->hist, &ctx->offsets, &ctx->cursor, &ctx->sorted, &ctx->buckets, &ctx->partials, &ctx->wsums,
                     &ctx->bsums, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->io_a, &ctx->io_b, &ctx->io_c, &ctx->io_d, &ctx->io_e,
-                    &ctx->fb_scalars, &ctx->fb_g1_gen, &ctx->fb_g2_gen, &ctx->fb_com, &ctx->fb_tau, &ctx->perm, &ctx->g2gen_lines, &ctx->gt_tab_a, &ctx->gt_tab_b, &ctx->gt_base, &ctx->heavy, &ctx->verify_lines, &ctx->verify_io, &ctx->fbs_scalars, &ctx->fbs_g2_gen, &ctx->fbs_tau})
+                    &ctx->fb_scalars, &ctx->fb_g1_gen, &ctx->fb_g2_gen, &ctx->fb_com, &ctx->fb_tau, &ctx->perm, &ctx->g2gen_lines, &ctx->gt_tab_a, &ctx->gt_tab_b, &ctx->gt_base, &ctx->heavy, &ctx->pair_ws, &ctx->verify_lines, &ctx->verify_io, &ctx->fbs_scalars, &ctx->fbs_g2_gen, &ctx->fbs_tau})
     if (b->p) (void)hipFree(b->p);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -633,7 +633,10 @@ keaki_status keaki_hip_g2_prepare(keaki_hip_ctx* ctx, const uint64_t* g2_aff, ui
   ST_TRY(reserve(ctx, ctx->io_b, g2_prepared_bytes()));
   HIP_TRY(ctx, hipMemsetAsync(ctx->io_b.p, 0, g2_prepared_bytes(), ctx->stream));
   ST_TRY(g2_prepare_run(ctx, ctx->io_a.p, ctx->io_b.p));
-  return download(ctx, lines_out, ctx->io_b.p, g2_prepared_bytes());
+  ST_TRY(reserve(ctx, ctx->io_c, g2_prepared_bytes()));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->io_c.p, 0, g2_prepared_bytes(), ctx->stream));
+  ST_TRY(lines_to256_run(ctx, ctx->io_b.p, ctx->io_c.p));
+  return download(ctx, lines_out, ctx->io_c.p, g2_prepared_bytes());
 }
 
 // ---- test hook: Miller loop alone (n x 12 Fq Montgomery out)

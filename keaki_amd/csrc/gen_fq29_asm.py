@@ -23,7 +23,8 @@ ACC = "v[54:55]"
 ACC_LO, ACC_HI = "v54", "v55"
 
 
-def block(square, dual=False):
+def block(square, dual=False, nprod=None):
+    """nprod (2..6): r = (a0 b0 + a1 b1 + ... ) / 2^261, operands a[k*9+i], b[k*9+i]; overrides `dual`"""
     ops = []          # (constraint, expr) in operand order
     index = {}
 
@@ -37,10 +38,15 @@ def block(square, dual=False):
     R = [op(("r", i), '"=&v"', "r[%d]" % i) for i in range(9)]
     D = [op(("d", i), '"=&v"', "d[%d]" % i) for i in range(8)] if square else None
     nout = len(ops)
-    A = [op(("a", i), '"v"', "a[%d]" % i) for i in range(9)]
-    B = A if square else [op(("b", i), '"v"', "b[%d]" % i) for i in range(9)]
-    Cc = [op(("c", i), '"v"', "c[%d]" % i) for i in range(9)] if dual else None
-    Dd = [op(("e", i), '"v"', "d[%d]" % i) for i in range(9)] if dual else None
+    if nprod:
+        AN = [[op(("a", k, i), '"v"', "a%d[%d]" % (k, i)) for i in range(9)] for k in range(nprod)]
+        BN = [[op(("b", k, i), '"v"', "b%d[%d]" % (k, i)) for i in range(9)] for k in range(nprod)]
+        A = B = Cc = Dd = None
+    else:
+        A = [op(("a", i), '"v"', "a[%d]" % i) for i in range(9)]
+        B = A if square else [op(("b", i), '"v"', "b[%d]" % i) for i in range(9)]
+        Cc = [op(("c", i), '"v"', "c[%d]" % i) for i in range(9)] if dual else None
+        Dd = [op(("e", i), '"v"', "d[%d]" % i) for i in range(9)] if dual else None
     P = [op(("p", i), '"s"', "Q29::MOD[%d]" % i) for i in range(9)]
     INV = op(("inv",), '"s"', "Q29::INV")
     L = []
@@ -59,6 +65,10 @@ def block(square, dual=False):
                 terms.append((D[i], A[j]))
             if k % 2 == 0:
                 terms.append((A[k // 2], A[k // 2]))
+        elif nprod:
+            for q in range(nprod):
+                for i in range(lo_i, min(k, 8) + 1):
+                    terms.append((AN[q][i], BN[q][k - i]))
         else:
             for i in range(lo_i, min(k, 8) + 1):
                 terms.append((A[i], B[k - i]))
@@ -106,13 +116,30 @@ def emit(name, square, dual=False):
     print("}")
 
 
+def emit_dot(nprod):
+    stmt, n, nmad = block(False, False, nprod)
+    print("// r = (sum_k a_k b_k) / 2^261 (lazy), k < %d: %d products, ONE reduction. All limbs at most 2^29 + 8 (a column holds %d products of < 2^58 + ..."
+          " and stays below 2^64). %d instructions, %d v_mad_u64_u32." % (nprod, nprod, 9 * nprod + 9, n, nmad))
+    args = ", ".join("const u32* __restrict__ a%d, const u32* __restrict__ b%d" % (k, k) for k in range(nprod))
+    print("KDEV void u29_dot%d_asm(u32* __restrict__ r, %s) {" % (nprod, args))
+    print(stmt)
+    print("}")
+
+
 def main():
-    print("// GENERATED by keaki_amd/csrc/gen_fq29_asm.py -- do not edit.")
+    import sys
+    dots = len(sys.argv) > 1 and sys.argv[1] == "--dots"
+    print("// GENERATED by keaki_amd/csrc/gen_fq29_asm.py%s -- do not edit." % (" --dots" if dots else ""))
     print("#pragma once")
     print("namespace bn254 {")
-    emit("u29_mul_asm", False)
-    emit("u29_sqr_asm", True)
-    emit("u29_mul2_asm", False, True)
+    if dots:
+        # the multi-product streams of the pairing tower (pair261.cuh): python gen_fq29_asm.py --dots > fq29_dot_asm.cuh
+        for nprod in (3, 4, 6):
+            emit_dot(nprod)
+    else:
+        emit("u29_mul_asm", False)
+        emit("u29_sqr_asm", True)
+        emit("u29_mul2_asm", False, True)
     print("}  // namespace bn254")
 
 

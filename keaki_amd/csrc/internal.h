@@ -36,6 +36,7 @@ struct keaki_hip_ctx {
   uint64_t seen_com[8] = {};              // commitment of the last encap call and how many consecutive calls carried it
   uint32_t seen_com_runs = 0;
   uint32_t gt_a_wb = 0, gt_b_wb = 0;      // window widths of the GT tables in gt_tab_a / gt_tab_b
+  keaki_internal::DevBuf pair_ws;                   // per-item slots of the final exponentiation (pairing.cuh)
   keaki_internal::DevBuf verify_lines, verify_io;   // kzg verify: [lines of g2 | lines of [tau]_2], small in/out block
   bool verify_ready = false;              // set only after every init step of kzg verify succeeded
   bool verify_tau_valid = false;
@@ -102,7 +103,8 @@ keaki_status gt_encap_exp_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t 
                               const void* d_rs, size_t n, void* d_gt);
 keaki_status miller_only_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, size_t n, void* d_out);
 keaki_status final_exp_only_run(keaki_hip_ctx* ctx, const void* d_in, size_t n, void* d_gt);
-keaki_status g2_prepare_run(keaki_hip_ctx* ctx, const void* d_q, void* d_lines);   // line sequence of a fixed Q
+keaki_status g2_prepare_run(keaki_hip_ctx* ctx, const void* d_q, void* d_lines);   // line sequence of a fixed Q (2^261 form: internal)
+keaki_status lines_to256_run(keaki_hip_ctx* ctx, const void* d_lines261, void* d_lines256);   // the same table in the ABI's 2^256 form (test hook)
 keaki_status blake3_gt_run(keaki_hip_ctx* ctx, const void* d_gt, size_t n, void* d_key, size_t msg_len);
 keaki_status g2_generator_to(keaki_hip_ctx* ctx, void* d_dst);  // writes the affine G2 generator (128 B)
 keaki_status g1_generator_to(keaki_hip_ctx* ctx, void* d_dst);  // affine G1 generator (64 B)

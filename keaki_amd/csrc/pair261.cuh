@@ -1,0 +1,355 @@
+// Fq2 / Fq6 / Fq12 tower of the BN254 pairing for gfx950, one lane PAIR per element, residues in the 2^261 Montgomery form.
+//
+// Replaces what `E::pairing` runs inside ark-ec 0.4.2 (models/bn: Fp12 arithmetic under multi_miller_loop and
+// final_exponentiation; reference call sites src/kem.rs:30,58, src/kzg.rs:148). Tower as ark-bn254: Fq2 = Fq[u]/(u^2+1),
+// Fq6 = Fq2[v]/(v^3 - (9+u)), Fq12 = Fq6[w]/(w^2 - v).
+//
+// Lane-pair layout (as round 1): an Fq2 element a0 + a1 u lives in two adjacent lanes -- even lane a0, odd lane a1 (type Fq2d =
+// "this lane's component", 8 x 32-bit canonical words). Additions are one Fq operation per lane; the partner's component arrives
+// by DPP quad_perm (register to register); both lanes run the same instruction stream.
+//
+// What is new in round 2 -- where the instructions went, and how they were removed:
+//   * Radix. Everything in this file is a residue x 2^261 mod p, the radix the 9 x 29-bit product streams of fq29_asm.cuh reduce
+//     by, so no operand needs the 5-bit shift that bridged from the 2^256 form (and multiplied its bound by 32). Inputs are
+//     converted once at kernel entry (to261), GT leaves through the same from-Montgomery product it always needed.
+//   * Lazy reduction ACROSS products (Aranha et al., "Faster explicit formulas for computing pairings over ordinary curves",
+//     restated for the column streams): an output coefficient that is a sum of up to three Fq2 products -- every coefficient of an Fq6
+//     product written out by the schoolbook rule, of the sparse line product, of an Fq4 squaring -- is ONE stream of up to six Fq
+//     products with ONE Montgomery reduction (u29_dot6_asm: 567 v_mad_u64_u32 in 610 instructions; a column holds 63 terms below
+//     2^58, the budget of a 64-bit accumulator). The Karatsuba forms of round 1 needed fewer multiply-adds (6 x 243 per Fq6 product
+//     against 3 x 567) but ~27 saturated additions (25 instructions each), two multiplications by 9+u (143 each) and a limb cut +
+//     pack round trip per product around them: 3,540 instructions per Fq6 product then, ~2,500 now.
+//   * Operands are cut into limbs ONCE per tower operation (not once per product), the partner exchange is done on the limbs once,
+//     the multiplication by 9+u is applied to limbs (xi_limbs: shifts and adds, one carry pass) and the sign of the even lane's
+//     -a1 b1 term is carried by the y operand (2p - y1), prepared once per operand.
+// Value bounds (multiples of p) and limb classes are stated at every helper; the streams' budget is: every limb <= 2^29 + 8.
+#pragma once
+#include "bn254_curve.cuh"
+#include "fq29.cuh"
+#include "fq29_dot_asm.cuh"
+#include "pair261_constants.cuh"
+
+namespace bn254 {
+namespace p261 {
+
+#define KNOINLINE __device__ __noinline__
+#define KTOWER __device__ __forceinline__
+
+struct Fq2d { Fq v; };   // this lane's component; canonical (< p), 2^261-form
+struct Fq6 { Fq2d c0, c1, c2; };
+struct Fq12 { Fq6 c0, c1; };
+
+KDEV u32 lane_odd() { return threadIdx.x & 1u; }
+
+// ---- lane-pair exchange ---------------------------------------------------------------------------------------------------------
+// gfx950 needs two wait states between a VALU write of a VGPR and a DPP read of it. hipcc pads that for instructions it scheduled
+// itself but does not look into inline-asm streams: a value that comes straight out of a stream passes through a fence first.
+KDEV void fence8(u32 (&x)[8]) {
+  asm volatile("s_nop 1" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+}
+KDEV void fence9(U29& x) {
+  asm volatile("s_nop 1" : "+v"(x.l[0]), "+v"(x.l[1]), "+v"(x.l[2]), "+v"(x.l[3]), "+v"(x.l[4]), "+v"(x.l[5]), "+v"(x.l[6]), "+v"(x.l[7]), "+v"(x.l[8]));
+}
+// CTRL = quad_perm: 0xB1 [1,0,3,2] the partner's value, 0xA0 [0,0,2,2] the even lane's, 0xF5 [1,1,3,3] the odd lane's. All 64 lanes active.
+// The moves are kept as moves: hipcc's DPP combiner likes to fold a v_mov_b32_dpp into the VALU instruction that consumes it, and for
+// `own - partner(own)` it produced  v_subrev_u32_dpp v0, v0, v0 quad_perm:[1,0,3,2]  -- DPP operand and plain operand in the SAME
+// register -- which gives wrong values on gfx950 (found with bench_tools/dbg/dbg_pair.hip: every variant of fq2d_sqr with that
+// instruction failed in the even lanes, the variant whose partner limbs pass through an asm statement is correct).
+// The empty statement below owns the nine results, so nothing is folded; the streams need the limbs in registers of their own anyway.
+template <int CTRL>
+KDEV U29 quad(const U29& a) {
+  U29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = (u32)__builtin_amdgcn_update_dpp(0, (int)a.l[i], CTRL, 0xF, 0xF, true);
+  asm volatile("" : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7]), "+v"(r.l[8]));
+  return r;
+}
+KDEV Fq fq_partner(const Fq& a) {        // safe for stream outputs (fenced)
+  Fq t = a, r;
+  fence8(t.l);
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.l[i] = (u32)__builtin_amdgcn_update_dpp(0, (int)t.l[i], 0xB1, 0xF, 0xF, true);
+  asm volatile("" : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7]));   // no DPP folding (see quad)
+  return r;
+}
+KDEV Fq fq_select(bool c, const Fq& a, const Fq& b) {  // c ? a : b
+  Fq r;
+#pragma unroll
+  for (int j = 0; j < 8; j++) r.l[j] = c ? a.l[j] : b.l[j];
+  return r;
+}
+
+// ---- limbs <-> words -----------------------------------------------------------------------------------------------------------
+KDEV U29 cut(const Fq& a) { return u29_from_sat_plain(a.l); }                       // exact limbs (< 2^29), value = the residue (< p)
+KDEV Fq pack(const U29& t) { Fq r; u29_pack_canonical(r.l, t); return r; }          // t: exact limbs, value < 2p  ->  canonical words
+KDEV U29 carry(const U29& x) { return u29_carry(x); }                               // any u32 limbs -> limbs <= 2^29 + 7, same value
+
+// ---- Fq in the 2^261 form (one lane) --------------------------------------------------------------------------------------------
+KDEV Fq fq_mul261(const Fq& a, const Fq& b) { return pack(u29_mul(cut(a), cut(b))); }
+KDEV Fq fq_sqr261(const Fq& a) { return pack(u29_sqr(cut(a))); }
+KDEV Fq to261(const Fq& a256) { return pack(u29_mul(cut(a256), u29_const(Conv::C266))); }     // x 2^256 -> x 2^261
+KDEV Fq to256(const Fq& a261) { return pack(u29_mul(cut(a261), u29_const(Q29::R256))); }      // x 2^261 -> x 2^256
+KDEV void canon_words(u32* out8, const Fq& a261) { u29_pack_canonical(out8, u29_mul(cut(a261), u29_const(Conv::PLAIN_ONE))); }   // -> x itself
+// a^(p-2): 254 squarings + ~127 products in the lazy limbs (every intermediate < 2p). Once per pairing (easy part of the final exponentiation).
+static KNOINLINE Fq fq_inv261(const Fq a) {
+  const U29 base = cut(a);
+  U29 acc = u29_const(Q29::ONE);
+  for (int i = 253; i >= 0; i--) {
+    acc = u29_sqr(acc);
+    if ((FQ_PM2[i >> 5] >> (i & 31)) & 1) acc = u29_mul(acc, base);
+  }
+  return pack(acc);
+}
+
+// ---- Fq2d: saturated front (same interface as round 1) ---------------------------------------------------------------------------
+KDEV Fq2d operator+(const Fq2d& a, const Fq2d& b) { return {a.v + b.v}; }
+KDEV Fq2d operator-(const Fq2d& a, const Fq2d& b) { return {a.v - b.v}; }
+KDEV Fq2d fq2_neg(const Fq2d& a) { return {fq_zero() - a.v}; }      // binary form on purpose: see DESIGN.md section 4.3 (the `-theta` note)
+KDEV Fq2d fq2_dbl(const Fq2d& a) { return {fq_dbl(a.v)}; }
+KDEV Fq2d fq2d_zero() { return {fq_zero()}; }
+KDEV Fq2d fq2d_one() { return {fq_select(lane_odd() != 0, fq_zero(), ONE)}; }
+KDEV Fq2d fq2_conj(const Fq2d& a) { return {fp_cneg<FqParams>(a.v, lane_odd() != 0)}; }
+KDEV Fq2d fq2d_load(const Fq2* a) { return {reinterpret_cast<const Fq*>(a)[lane_odd()]}; }    // this lane's component of a constant (c0, c1)
+KDEV Fq2d fq2_mul_fq(const Fq2d& a, const Fq& k) { return {fq_mul261(a.v, k)}; }
+
+// ---- product operands in limb form ---------------------------------------------------------------------------------------------
+// x side: this lane's component and the partner's (limbs <= 2^29 + 8)
+struct XF { U29 s, o; };
+// y side: the real component's limbs (in BOTH lanes) and the imaginary component's -- in even lanes NEGATED (K p - y1), so that the one
+// stream  x.s y.y0 + x.o y.y1  is  a0 b0 - a1 b1  in the even lane and  a1 b0 + a0 b1  in the odd lane. Limbs <= 2^29 + 8.
+struct YF { U29 y0, y1; };
+
+KDEV XF x_of(const U29& own) { return {own, quad<0xB1>(own)}; }
+// K: a multiple of p not below the bound of the imaginary component, limbs biased by 2^30 (Q29::K2 / K4 / K16 / K32)
+KDEV YF y_of(const U29& own, const u32 (&K)[9]) {
+  const bool odd = lane_odd() != 0;
+  YF r;
+  r.y0 = quad<0xA0>(own);
+  const U29 y1 = quad<0xF5>(own);
+  U29 n;
+#pragma unroll
+  for (int i = 0; i < 9; i++) n.l[i] = K[i] - y1.l[i];
+  n = carry(n);
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.y1.l[i] = odd ? y1.l[i] : n.l[i];
+  return r;
+}
+// This lane's component of (9 + u)(a0 + a1 u) = (9 a0 - a1) + (9 a1 + a0) u from limbs: even 9 a + (K p - o), odd 9 a + o.
+// a: EXACT limbs (< 2^29: a cut or a stream output), o: the partner's limbs, K >= bound of o. 9 a_i = ((a_i << 3) & MASK) + a_i with the
+// three bits shifted out carried into the next limb, so no intermediate exceeds 32 bits. Result: limbs <= 2^29 + 8, value < (9 + K) p.
+KDEV U29 xi_limbs(const U29& a, const U29& o, const u32 (&K)[9]) {
+  const bool odd = lane_odd() != 0;
+  U29 t;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const u32 add = odd ? o.l[i] : K[i] - o.l[i];
+    const u32 lo8 = (i < 8) ? ((a.l[i] << 3) & Q29::MASK) : (a.l[i] << 3);
+    t.l[i] = lo8 + a.l[i] + add + (i ? (a.l[i - 1] >> 26) : 0u);
+  }
+  return carry(t);
+}
+
+// one Fq2 product, two, three: (sum of the Fq2 products)'s component of this lane, exact limbs, value < 2p for the operand bounds used here
+KDEV U29 dot1(const XF& x0, const YF& y0) { return u29_mul2(x0.s, y0.y0, x0.o, y0.y1); }
+KDEV U29 dot2(const XF& x0, const YF& y0, const XF& x1, const YF& y1) {
+  U29 r;
+  u29_dot4_asm(r.l, x0.s.l, y0.y0.l, x0.o.l, y0.y1.l, x1.s.l, y1.y0.l, x1.o.l, y1.y1.l);
+  return r;
+}
+KDEV U29 dot3(const XF& x0, const YF& y0, const XF& x1, const YF& y1, const XF& x2, const YF& y2) {
+  U29 r;
+  u29_dot6_asm(r.l, x0.s.l, y0.y0.l, x0.o.l, y0.y1.l, x1.s.l, y1.y0.l, x1.o.l, y1.y1.l, x2.s.l, y2.y0.l, x2.o.l, y2.y1.l);
+  return r;
+}
+
+// ---- single Fq2 product / square (line functions, Frobenius, inversions) -------------------------------------------------------
+// (a0 + a1 u)(b0 + b1 u): even lane a0 b0 + a1 (2p - b1), odd lane a1 b0 + a0 b1: one dual stream, one reduction. Bound (1 + 2)/169 + 1.
+static KNOINLINE Fq2d fq2d_mul(const Fq2d a, const Fq2d b) {
+  return {pack(dot1(x_of(cut(a.v)), y_of(cut(b.v), Q29::K2)))};
+}
+// (a0 + a1 u)^2: even lane (a0 + a1)(a0 - a1), odd lane 2 a0 a1 -- one product per lane. x = a0 + a1 (limbs <= 2^30) | a0;  y = a0 - a1 + 2p | 2 a1
+static KNOINLINE Fq2d fq2d_sqr(const Fq2d a) {
+  const bool odd = lane_odd() != 0;
+  const U29 A = cut(a.v), O = quad<0xB1>(A);
+  U29 x, y;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    x.l[i] = odd ? O.l[i] : A.l[i] + O.l[i];
+    y.l[i] = odd ? 2u * A.l[i] : A.l[i] - O.l[i] + Q29::K2[i];
+  }
+  return {pack(u29_mul(x, carry(y)))};       // u29_mul: one side up to 2^30 + 16, the other carried. Bound (2 * 3)/169 + 1.
+}
+KDEV Fq2d operator*(const Fq2d& a, const Fq2d& b) { return fq2d_mul(a, b); }
+KDEV Fq2d fq2_sqr(const Fq2d& a) { return fq2d_sqr(a); }
+// (9 + u) a in the saturated words (only where a single value is needed outside a product)
+KDEV Fq2d fq2_mul_xi(const Fq2d& a) {
+  Fq t = fq_dbl(fq_dbl(fq_dbl(a.v))) + a.v;   // 9 * self
+  Fq o = fq_partner(a.v);
+  return {t + fp_cneg<FqParams>(o, lane_odd() == 0)};
+}
+// 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + a1^2); the norm's inverse is computed redundantly in both lanes
+KDEV Fq2d fq2_inv(const Fq2d& a) {
+  Fq sq = fq_sqr261(a.v);
+  Fq n = sq + fq_partner(sq);
+  Fq ni = fq_inv261(n);
+  return {fp_cneg<FqParams>(fq_mul261(a.v, ni), lane_odd() != 0)};
+}
+
+#define M2(a, b) ((a) * (b))
+#define S2(a) fq2_sqr((a))
+
+// ---- Fq6 ------------------------------------------------------------------------------------------------------------------------
+KDEV Fq6 operator+(const Fq6& a, const Fq6& b) { return {a.c0 + b.c0, a.c1 + b.c1, a.c2 + b.c2}; }
+KDEV Fq6 operator-(const Fq6& a, const Fq6& b) { return {a.c0 - b.c0, a.c1 - b.c1, a.c2 - b.c2}; }
+KDEV Fq6 fq6_neg(const Fq6& a) { return {fq2_neg(a.c0), fq2_neg(a.c1), fq2_neg(a.c2)}; }
+KDEV Fq6 fq6_mul_v(const Fq6& a) { return {fq2_mul_xi(a.c2), a.c0, a.c1}; }
+KDEV Fq6 fq6_zero() { return {fq2d_zero(), fq2d_zero(), fq2d_zero()}; }
+
+// (a0 + a1 v + a2 v^2)(b0 + b1 v + b2 v^2), v^3 = xi, written out:
+//   c0 = a0 b0 + (xi a1) b2 + (xi a2) b1      c1 = a0 b1 + a1 b0 + (xi a2) b2      c2 = a0 b2 + a1 b1 + a2 b0
+// three streams of six Fq products. Bounds: plain term 1*1 + 1*2 = 3, xi term 11 + 22 = 33: c0 < (69/169 + 1) p.
+static KTOWER void fq6_mul(Fq6* r, const Fq6* a, const Fq6* b) {
+  const XF x0 = x_of(cut(a->c0.v)), x1 = x_of(cut(a->c1.v)), x2 = x_of(cut(a->c2.v));
+  const XF xx1 = x_of(xi_limbs(x1.s, x1.o, Q29::K2)), xx2 = x_of(xi_limbs(x2.s, x2.o, Q29::K2));
+  const YF y0 = y_of(cut(b->c0.v), Q29::K2), y1 = y_of(cut(b->c1.v), Q29::K2), y2 = y_of(cut(b->c2.v), Q29::K2);
+  const Fq c0 = pack(dot3(x0, y0, xx1, y2, xx2, y1));
+  const Fq c1 = pack(dot3(x0, y1, x1, y0, xx2, y2));
+  const Fq c2 = pack(dot3(x0, y2, x1, y1, x2, y0));
+  r->c0.v = c0; r->c1.v = c1; r->c2.v = c2;
+}
+static KTOWER void fq6_inv(Fq6* r, const Fq6* a) {
+  Fq2d t0 = S2(a->c0) - fq2_mul_xi(M2(a->c1, a->c2));
+  Fq2d t1 = fq2_mul_xi(S2(a->c2)) - M2(a->c0, a->c1);
+  Fq2d t2 = S2(a->c1) - M2(a->c0, a->c2);
+  Fq2d n = M2(a->c0, t0) + fq2_mul_xi(M2(a->c2, t1) + M2(a->c1, t2));
+  Fq2d ni = fq2_inv(n);
+  r->c0 = M2(t0, ni); r->c1 = M2(t1, ni); r->c2 = M2(t2, ni);
+}
+
+// ---- Fq12 -----------------------------------------------------------------------------------------------------------------------
+KDEV void fq12_set_one(Fq12* f) {
+  f->c0 = fq6_zero(); f->c1 = fq6_zero();
+  f->c0.c0 = fq2d_one();
+}
+KDEV void fq12_conj(Fq12* r, const Fq12* a) { r->c0 = a->c0; r->c1 = fq6_neg(a->c1); }
+// Karatsuba over Fq6: three Fq6 products through ONE instance of fq6_mul (the loop counter is wave-uniform: the operand choice is
+// scalar control flow, not per-lane selects)
+static KTOWER void fq12_mul(Fq12* r, const Fq12* a, const Fq12* b) {
+  Fq6 t0, t1, m;
+#pragma unroll 1
+  for (int k = 0; k < 3; k++) {
+    Fq6 x, y, z;
+    if (k == 0) { x = a->c0; y = b->c0; }
+    else if (k == 1) { x = a->c1; y = b->c1; }
+    else { x = a->c0 + a->c1; y = b->c0 + b->c1; }
+    fq6_mul(&z, &x, &y);
+    if (k == 0) t0 = z; else if (k == 1) t1 = z; else m = z;
+  }
+  r->c1 = m - t0 - t1;
+  r->c0 = t0 + fq6_mul_v(t1);
+}
+// complex squaring: a0 a1 and (a0 + a1)(a0 + v a1)
+static KTOWER void fq12_sqr(Fq12* r, const Fq12* a) {
+  Fq6 ab, t;
+#pragma unroll 1
+  for (int k = 0; k < 2; k++) {
+    Fq6 x, y, z;
+    if (k == 0) { x = a->c0; y = a->c1; }
+    else { x = a->c0 + a->c1; y = a->c0 + fq6_mul_v(a->c1); }
+    fq6_mul(&z, &x, &y);
+    if (k == 0) ab = z; else t = z;
+  }
+  r->c0 = t - ab - fq6_mul_v(ab);
+  r->c1 = ab + ab;
+}
+static KTOWER void fq12_inv(Fq12* r, const Fq12* a) {
+  Fq6 n0, n1, ni, r0, r1;
+#pragma unroll 1
+  for (int k = 0; k < 2; k++) {
+    Fq6 x = k ? a->c1 : a->c0, z;
+    fq6_mul(&z, &x, &x);
+    if (k == 0) n0 = z; else n1 = z;
+  }
+  Fq6 n = n0 - fq6_mul_v(n1);
+  fq6_inv(&ni, &n);
+#pragma unroll 1
+  for (int k = 0; k < 2; k++) {
+    Fq6 x = k ? a->c1 : a->c0, z;
+    fq6_mul(&z, &x, &ni);
+    if (k == 0) r0 = z; else r1 = z;
+  }
+  r->c0 = r0;
+  r->c1 = fq6_neg(r1);
+}
+// x -> x^(p^k), k = 1, 2, 3
+static KTOWER void fq12_frob(Fq12* r, const Fq12* a, int k) {
+  Fq2d c[6] = {a->c0.c0, a->c1.c0, a->c0.c1, a->c1.c1, a->c0.c2, a->c1.c2};
+  Fq2d o[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    Fq2d t = (k & 1) ? fq2_conj(c[i]) : c[i];
+    o[i] = M2(t, fq2d_load(&FROB_W[k][i]));
+  }
+  r->c0.c0 = o[0]; r->c1.c0 = o[1]; r->c0.c1 = o[2]; r->c1.c1 = o[3]; r->c0.c2 = o[4]; r->c1.c2 = o[5];
+}
+
+// Granger-Scott squaring on the cyclotomic subgroup: three Fq4 squarings (x + y s)^2 = (x^2 + xi y^2) + 2 x y s, each as
+//   t0 = x x + (xi y) y   one stream of four Fq products      (bound 3 + 33)
+//   t1 = (2x) y           one dual stream                      (bound 2 + 4)
+// then the linear recombination in the saturated words.
+KDEV void fq4_sqr(Fq2d* t0, Fq2d* t1, const Fq2d& x, const Fq2d& y) {
+  const XF xx = x_of(cut(x.v)), xy = x_of(cut(y.v));
+  const XF xxy = x_of(xi_limbs(xy.s, xy.o, Q29::K2));
+  const YF yx = y_of(xx.s, Q29::K2), yy = y_of(xy.s, Q29::K2);
+  XF x2;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { x2.s.l[i] = 2u * xx.s.l[i]; x2.o.l[i] = 2u * xx.o.l[i]; }      // limbs < 2^30: within the dual stream's budget
+  t0->v = pack(dot2(xx, yx, xxy, yy));
+  t1->v = pack(dot1(x2, yy));
+}
+static KTOWER void fq12_cyc_sqr(Fq12* r, const Fq12* a) {
+  const Fq2d r0 = a->c0.c0, r4 = a->c0.c1, r3 = a->c0.c2, r2 = a->c1.c0, r1 = a->c1.c1, r5 = a->c1.c2;
+  Fq2d t0, t1, t2, t3, t4, t5;
+#pragma unroll 1
+  for (int k = 0; k < 3; k++) {
+    Fq2d x, y, u, w;
+    if (k == 0) { x = r0; y = r1; } else if (k == 1) { x = r2; y = r3; } else { x = r4; y = r5; }
+    fq4_sqr(&u, &w, x, y);
+    if (k == 0) { t0 = u; t1 = w; } else if (k == 1) { t2 = u; t3 = w; } else { t4 = u; t5 = w; }
+  }
+  Fq2d x5 = fq2_mul_xi(t5);
+  r->c0.c0 = fq2_dbl(t0 - r0) + t0;
+  r->c1.c1 = fq2_dbl(t1 + r1) + t1;
+  r->c1.c0 = fq2_dbl(x5 + r2) + x5;
+  r->c0.c2 = fq2_dbl(t4 - r3) + t4;
+  r->c0.c1 = fq2_dbl(t2 - r4) + t2;
+  r->c1.c2 = fq2_dbl(t3 + r5) + t3;
+}
+
+// ---- the sparse line product: f *= c0 + (d0 + d1 v) w ---------------------------------------------------------------------------
+// f = (a0 + a1 v + a2 v^2) + (e0 + e1 v + e2 v^2) w. With w^2 = v, v^3 = xi:
+//   r0.c0 = a0 c0 + e1 (xi d1) + e2 (xi d0)     r0.c1 = a1 c0 + e0 d0 + e2 (xi d1)     r0.c2 = a2 c0 + e0 d1 + e1 d0
+//   r1.c0 = e0 c0 + a0 d0 + a2 (xi d1)          r1.c1 = e1 c0 + a0 d1 + a1 d0          r1.c2 = e2 c0 + a1 d1 + a2 d0
+// six streams of six Fq products; the multiplications by xi sit on the line's side (two per line instead of one per product).
+// The line's coefficients arrive as LIMBS of this lane's component: c0, d0 exact and < 2p (outputs of the products by P's coordinates),
+// d1 exact and < p. Bounds: f's coefficients 1; terms c0: 2 + 2, d0: 2 + 2, d1: 1 + 2, xi d1 (< 11p, negated 16p): 27, xi d0 (< 22p, 32p): 54.
+static KTOWER void fq12_mul_by_034_limbs(Fq12* f, U29 c0, U29 d0, const U29& d1, bool fence_c0_d0) {
+  if (fence_c0_d0) { fence9(c0); fence9(d0); }
+  const U29 c0o = quad<0xB1>(c0), d0o = quad<0xB1>(d0), d1o = quad<0xB1>(d1);
+  (void)c0o;
+  const YF yc0 = y_of(c0, Q29::K2), yd0 = y_of(d0, Q29::K2), yd1 = y_of(d1, Q29::K2);
+  const YF yxd0 = y_of(xi_limbs(d0, d0o, Q29::K4), Q29::K32), yxd1 = y_of(xi_limbs(d1, d1o, Q29::K2), Q29::K16);
+  const XF a0 = x_of(cut(f->c0.c0.v)), a1 = x_of(cut(f->c0.c1.v)), a2 = x_of(cut(f->c0.c2.v));
+  const XF e0 = x_of(cut(f->c1.c0.v)), e1 = x_of(cut(f->c1.c1.v)), e2 = x_of(cut(f->c1.c2.v));
+  const Fq r00 = pack(dot3(a0, yc0, e1, yxd1, e2, yxd0));
+  const Fq r01 = pack(dot3(a1, yc0, e0, yd0, e2, yxd1));
+  const Fq r02 = pack(dot3(a2, yc0, e0, yd1, e1, yd0));
+  const Fq r10 = pack(dot3(e0, yc0, a0, yd0, a2, yxd1));
+  const Fq r11 = pack(dot3(e1, yc0, a0, yd1, a1, yd0));
+  const Fq r12 = pack(dot3(e2, yc0, a1, yd1, a2, yd0));
+  f->c0.c0.v = r00; f->c0.c1.v = r01; f->c0.c2.v = r02;
+  f->c1.c0.v = r10; f->c1.c1.v = r11; f->c1.c2.v = r12;
+}
+
+}  // namespace p261
+}  // namespace bn254

@@ -4,12 +4,36 @@
 #include "pairing.cuh"
 namespace keaki_internal {
 using namespace bn254;
+// One launch of k_pairing per chunk of at most PAIR_CHUNK items: the final exponentiation keeps FE_NSLOTS Fq12 values per item in HBM
+// (3.75 KB per item; 2^17 items = 480 MB, grow-only in the context).
+constexpr size_t PAIR_CHUNK = (size_t)1 << 17;
+static keaki_status pairing_launch(keaki_hip_ctx* ctx, u32 mode, const void* d_g1, const void* d_g2, int g2_stride, const void* d_f_in, size_t n,
+                                   void* d_out, size_t out_item_bytes, const void* d_fixed_lines, uint32_t lines_stride, const char* what) {
+  if (n == 0) return KEAKI_OK;
+  const size_t ch = n < PAIR_CHUNK ? n : PAIR_CHUNK;
+  if (mode & PAIR_FINAL_EXP) ST_TRY(reserve(ctx, ctx->pair_ws, (size_t)FE_NSLOTS * 12 * sizeof(Fq) * ch));
+  for (size_t lo = 0; lo < n; lo += ch) {
+    const size_t m = n - lo < ch ? n - lo : ch;
+    PairArgs a;
+    a.ps = d_g1 ? (const G1Aff*)d_g1 + lo : nullptr;
+    a.qs = d_g2 ? (const G2Aff*)d_g2 + lo * (size_t)g2_stride : nullptr;
+    a.q_stride = g2_stride;
+    a.n = (u32)m;
+    a.fixed_lines = d_fixed_lines ? (const Line*)d_fixed_lines + lo * (size_t)lines_stride : nullptr;
+    a.lines_stride = lines_stride;
+    a.f_in = d_f_in ? (const Fq*)d_f_in + 12 * lo : nullptr;
+    a.ws = (Fq*)ctx->pair_ws.p;
+    a.ws_n = ch;
+    a.out = (char*)d_out + lo * out_item_bytes;
+    a.mode = mode;
+    hipLaunchKernelGGL(k_pairing, dim3(cdiv(2 * m, 64)), dim3(64), 0, ctx->stream, a);
+  }
+  return launch_check(ctx, what);
+}
 keaki_status pairing_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, int g2_stride, size_t n, void* d_gt, const void* d_fixed_lines,
                          uint32_t lines_stride) {
-  // two lanes per pairing
-  hipLaunchKernelGGL(k_pairing_batch, dim3(cdiv(2 * n, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_g1, (const G2Aff*)d_g2, g2_stride, (u32)n,
-                     (const Line*)d_fixed_lines, lines_stride, (u32*)d_gt);
-  return launch_check(ctx, "pairing_batch");
+  return pairing_launch(ctx, PAIR_MILLER | PAIR_FINAL_EXP | PAIR_OUT_BYTES, d_g1, d_g2, g2_stride, nullptr, n, d_gt, 384, d_fixed_lines, lines_stride,
+                        "pairing_batch");
 }
 uint32_t g2_prepared_lines() { return (uint32_t)MILLER_MAX_LINES * 2; }
 size_t g2_prepared_bytes() { return (size_t)MILLER_MAX_LINES * 2 * sizeof(Line); }
@@ -17,9 +41,14 @@ keaki_status g2_prepare_run(keaki_hip_ctx* ctx, const void* d_q, void* d_lines) 
   hipLaunchKernelGGL(k_g2_prepare, dim3(1), dim3(64), 0, ctx->stream, (const G2Aff*)d_q, (Line*)d_lines);
   return launch_check(ctx, "g2_prepare");
 }
+// test hook: the table in the 2^256 Montgomery form of the ABI (the kernels keep it in the 2^261 form)
+keaki_status lines_to256_run(keaki_hip_ctx* ctx, const void* d_lines261, void* d_lines256) {
+  const u32 count = (u32)(g2_prepared_bytes() / sizeof(Fq));
+  hipLaunchKernelGGL(k_lines_to256, dim3(cdiv(count, 64)), dim3(64), 0, ctx->stream, (const Fq*)d_lines261, (Fq*)d_lines256, count);
+  return launch_check(ctx, "lines_to256");
+}
 keaki_status pairing_raw_fixed_run(keaki_hip_ctx* ctx, const void* d_g1, size_t n, const void* d_lines, void* d_out) {
-  hipLaunchKernelGGL(k_pairing_raw_fixed, dim3(cdiv(2 * n, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_g1, (u32)n, (const Line*)d_lines, (Fq*)d_out);
-  return launch_check(ctx, "pairing_raw_fixed");
+  return pairing_launch(ctx, PAIR_MILLER | PAIR_FINAL_EXP | PAIR_OUT_RAW261, d_g1, nullptr, 0, nullptr, n, d_out, 12 * sizeof(Fq), d_lines, 0, "pairing_raw_fixed");
 }
 size_t gt_table_bytes(uint32_t wb) { GtShape g = gt_shape(wb); return (size_t)g.windows * g.entries * 12 * sizeof(Fq); }
 uint32_t gt_table_powers(uint32_t wb) { GtShape g = gt_shape(wb); return g.wb * g.windows; }
@@ -38,12 +67,10 @@ keaki_status gt_encap_exp_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t 
   return launch_check(ctx, "gt_encap_exp");
 }
 keaki_status miller_only_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, size_t n, void* d_out) {
-  hipLaunchKernelGGL(k_miller_only, dim3(cdiv(2 * n, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_g1, (const G2Aff*)d_g2, (u32)n, (Fq*)d_out);
-  return launch_check(ctx, "miller_only");
+  return pairing_launch(ctx, PAIR_MILLER | PAIR_OUT_RAW256, d_g1, d_g2, 1, nullptr, n, d_out, 12 * sizeof(Fq), nullptr, 0, "miller_only");
 }
 keaki_status final_exp_only_run(keaki_hip_ctx* ctx, const void* d_in, size_t n, void* d_gt) {
-  hipLaunchKernelGGL(k_final_exp_only, dim3(cdiv(2 * n, 64)), dim3(64), 0, ctx->stream, (const Fq*)d_in, (u32)n, (u32*)d_gt);
-  return launch_check(ctx, "final_exp_only");
+  return pairing_launch(ctx, PAIR_FINAL_EXP | PAIR_OUT_BYTES, nullptr, nullptr, 0, d_in, n, d_gt, 384, nullptr, 0, "final_exp_only");
 }
 keaki_status blake3_gt_run(keaki_hip_ctx* ctx, const void* d_gt, size_t n, void* d_key, size_t msg_len) {
   hipLaunchKernelGGL(k_blake3_gt_xof, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const u32*)d_gt, (u32)n, (unsigned char*)d_key, (u32)msg_len);

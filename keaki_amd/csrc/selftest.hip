@@ -69,36 +69,98 @@ __global__ void __launch_bounds__(256) k_selftest_field(u32 seed, u32 iters, uns
   if (bad) atomicAdd(mismatches, bad);
 }
 
-// lane-pair Fq2 primitives (pairing.cuh) against the single-lane Fq2 code
+// lane-pair primitives of the pairing tower (pair261.cuh: 2^261 form, multi-product streams) against the single-lane Fq2 code of
+// bn254_field.cuh (2^256 form): operands are converted on the way in (to261), results on the way out (to256)
+KDEV Fq2 ref_add3(const Fq2& a, const Fq2& b, const Fq2& c) { return a + b + c; }
+struct RefFq6 { Fq2 c0, c1, c2; };
+KDEV RefFq6 ref_fq6_mul(const RefFq6& a, const RefFq6& b) {
+  return {ref_add3(a.c0 * b.c0, fq2_mul_xi(a.c1 * b.c2), fq2_mul_xi(a.c2 * b.c1)), ref_add3(a.c0 * b.c1, a.c1 * b.c0, fq2_mul_xi(a.c2 * b.c2)),
+          ref_add3(a.c0 * b.c2, a.c1 * b.c1, a.c2 * b.c0)};
+}
+KDEV RefFq6 ref_fq6_add(const RefFq6& a, const RefFq6& b) { return {a.c0 + b.c0, a.c1 + b.c1, a.c2 + b.c2}; }
+KDEV RefFq6 ref_fq6_mul_v(const RefFq6& a) { return {fq2_mul_xi(a.c2), a.c0, a.c1}; }
 __global__ void __launch_bounds__(64) k_selftest_fq2d(u32 seed, u32 iters, unsigned long long* mismatches) {
+  using namespace p261;
   u32 pair = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;
   u32 s = (seed ^ (pair * 0x9E3779B9u)) | 1u;
   const u32 par = lane_odd();
   unsigned long long bad = 0;
+  auto comp = [&](const Fq2& x) { return par ? x.c1 : x.c0; };
+  auto ld = [&](const Fq2& x) { return Fq2d{to261(comp(x))}; };                       // this lane's component, 2^261 form
+  auto eq = [&](const Fq2d& got, const Fq2& exp) { return fq_eq(to256(got.v), comp(exp)); };
   for (u32 it = 0; it < iters; it++) {
-    Fq2 a = {pick(s, 0), pick(s, 0)}, b = {pick(s, 0), pick(s, 0)};   // identical in both lanes of the pair
-    if ((it & 7) == 3) a.c1 = fq_zero();
+    const u32 sh = mix(s);
+    Fq2 a = {pick(s, (sh & 7) < 6 ? (sh & 7) : 0), pick(s, ((sh >> 3) & 7) < 6 ? ((sh >> 3) & 7) : 0)}, b = {pick(s, 0), pick(s, ((sh >> 6) & 7) < 6 ? ((sh >> 6) & 7) : 0)};
+    if ((it & 7) == 3) a.c1 = fq_zero();                                               // identical in both lanes of the pair
     if ((it & 7) == 5) b.c0 = fq_zero();
     Fq k = pick(s, 0);
-    Fq2d ad = fq2d_load(&a), bd = fq2d_load(&b);
-    auto comp = [&](const Fq2& x) { return par ? x.c1 : x.c0; };
-    bad += !fq_eq((ad * bd).v, comp(a * b));
-    bad += !fq_eq(fq2_sqr(ad).v, comp(fq2_sqr(a)));
-    bad += !fq_eq(fq2_mul_xi(ad).v, comp(fq2_mul_xi(a)));
-    bad += !fq_eq(fq2_conj(ad).v, comp(fq2_conj(a)));
-    bad += !fq_eq(fq2_inv(ad).v, comp(fq2_inv(a)));
-    bad += !fq_eq(fq2_mul_fq(ad, k).v, comp(fq2_mul_fq(a, k)));
-    bad += !fq_eq((ad + bd).v, comp(a + b));
-    bad += !fq_eq((ad - bd).v, comp(a - b));
-    bad += !fq_eq(fq2_dbl(ad).v, comp(fq2_dbl(a)));
-    bad += !fq_eq((-ad).v, comp(-a));
-    bad += !fq_eq(fq2d_one().v, comp(fq2_one()));
-    {  // unary minus right after a subtraction of a product (the line_add shape)
-      Fq2d x = ad - bd * ad;
-      Fq2d n1 = -x, n2 = fq2d_zero() - x;
-      bad += !fq_eq(n1.v, n2.v);
-      Fq2 xs = a - b * a;
-      bad += !fq_eq(n1.v, comp(-xs));
+    Fq2d ad = ld(a), bd = ld(b);
+    bad += !fq_eq(to256(to261(k)), k);
+    bad += !eq(ad * bd, a * b);
+    bad += !eq(fq2_sqr(ad), bn254::fq2_sqr(a));
+    bad += !eq(fq2_mul_xi(ad), bn254::fq2_mul_xi(a));
+    bad += !eq(fq2_conj(ad), bn254::fq2_conj(a));
+    bad += !eq(fq2_inv(ad), bn254::fq2_inv(a));
+    bad += !eq(fq2_mul_fq(ad, to261(k)), bn254::fq2_mul_fq(a, k));
+    bad += !eq(ad + bd, a + b);
+    bad += !eq(ad - bd, a - b);
+    bad += !eq(fq2_dbl(ad), bn254::fq2_dbl(a));
+    bad += !eq(fq2_neg(ad), -a);
+    bad += !eq(fq2d_one(), fq2_one());
+    {  // canonical bytes of a 2^261 residue == from-Montgomery of the 2^256 residue
+      u32 w1[8], w2[8];
+      canon_words(w1, ad.v);
+      fp_from_mont<FqParams>(w2, comp(a));
+      for (int j = 0; j < 8; j++) bad += (w1[j] != w2[j]);
+    }
+    // the multi-product tower operations
+    Fq2 c = {pick(s, 0), pick(s, 0)}, d = {pick(s, 0), pick(s, 0)}, e = {pick(s, 0), pick(s, 0)}, f = {pick(s, 0), pick(s, 0)};
+    if ((it & 7) == 6) { c = a; d = a; }
+    const RefFq6 ra = {a, c, d}, rb = {b, e, f};
+    {
+      Fq6 xa = {ld(a), ld(c), ld(d)}, xb = {ld(b), ld(e), ld(f)}, xr;
+      fq6_mul(&xr, &xa, &xb);
+      const RefFq6 rr = ref_fq6_mul(ra, rb);
+      bad += !eq(xr.c0, rr.c0) + !eq(xr.c1, rr.c1) + !eq(xr.c2, rr.c2);
+      fq6_mul(&xa, &xa, &xa);                                                          // aliased: squares in place
+      const RefFq6 rs = ref_fq6_mul(ra, ra);
+      bad += !eq(xa.c0, rs.c0) + !eq(xa.c1, rs.c1) + !eq(xa.c2, rs.c2);
+    }
+    {  // Fq4 squaring (x + y s)^2, s^2 = xi
+      Fq2d t0, t1;
+      fq4_sqr(&t0, &t1, ad, bd);
+      bad += !eq(t0, bn254::fq2_sqr(a) + bn254::fq2_mul_xi(bn254::fq2_sqr(b))) + !eq(t1, bn254::fq2_dbl(a * b));
+    }
+    {  // sparse line product f * (l0 + (l1 + l2 v) w) with the line's coefficients as limbs (l0, l1 outputs of products by an Fq: < 2p)
+      Fq12 xf = {{ld(a), ld(c), ld(d)}, {ld(b), ld(e), ld(f)}};
+      Fq2 l0 = {pick(s, 0), pick(s, 0)}, l1 = {pick(s, 0), pick(s, 0)}, l2 = {pick(s, 0), pick(s, 2)};
+      const Fq py = pick(s, 0), px = pick(s, 2);
+      const U29 c0 = u29_mul(cut(ld(l0).v), cut(to261(py))), d0 = u29_mul(cut(ld(l1).v), cut(to261(px)));
+      fq12_mul_by_034_limbs(&xf, c0, d0, cut(ld(l2).v), true);
+      const Fq2 C0 = bn254::fq2_mul_fq(l0, py), D0 = bn254::fq2_mul_fq(l1, px);
+      const RefFq6 f0 = ra, f1 = rb, D = {D0, l2, fq2_zero()}, Cc = {C0, fq2_zero(), fq2_zero()};
+      const RefFq6 r0 = ref_fq6_add(ref_fq6_mul(f0, Cc), ref_fq6_mul_v(ref_fq6_mul(f1, D))), r1 = ref_fq6_add(ref_fq6_mul(f1, Cc), ref_fq6_mul(f0, D));
+      bad += !eq(xf.c0.c0, r0.c0) + !eq(xf.c0.c1, r0.c1) + !eq(xf.c0.c2, r0.c2) + !eq(xf.c1.c0, r1.c0) + !eq(xf.c1.c1, r1.c1) + !eq(xf.c1.c2, r1.c2);
+    }
+    {  // Fq12 product, squaring and inverse through the one-instance loops: (x y) == schoolbook over the reference Fq6; x * x^-1 == 1
+      Fq12 x = {{ld(a), ld(c), ld(d)}, {ld(b), ld(e), ld(f)}}, y = {{ld(e), ld(a), ld(f)}, {ld(d), ld(b), ld(c)}}, z, q;
+      const RefFq6 x0 = ra, x1 = rb, y0 = {e, a, f}, y1 = {d, b, c};
+      fq12_mul(&z, &x, &y);
+      const RefFq6 z0 = ref_fq6_add(ref_fq6_mul(x0, y0), ref_fq6_mul_v(ref_fq6_mul(x1, y1))), z1 = ref_fq6_add(ref_fq6_mul(x0, y1), ref_fq6_mul(x1, y0));
+      bad += !eq(z.c0.c0, z0.c0) + !eq(z.c0.c1, z0.c1) + !eq(z.c0.c2, z0.c2) + !eq(z.c1.c0, z1.c0) + !eq(z.c1.c1, z1.c1) + !eq(z.c1.c2, z1.c2);
+      fq12_sqr(&q, &x);
+      fq12_mul(&z, &x, &x);
+      const Fq2d* qa = reinterpret_cast<const Fq2d*>(&q);
+      const Fq2d* za = reinterpret_cast<const Fq2d*>(&z);
+      for (int j = 0; j < 6; j++) bad += !fq_eq(qa[j].v, za[j].v);
+      if ((it & 3) == 0) {
+        fq12_inv(&q, &x);
+        fq12_mul(&z, &q, &x);
+        Fq12 one;
+        fq12_set_one(&one);
+        const Fq2d* oa = reinterpret_cast<const Fq2d*>(&one);
+        for (int j = 0; j < 6; j++) bad += !fq_eq(za[j].v, oa[j].v);
+      }
     }
   }
   if (bad) atomicAdd(mismatches, bad);

@@ -1,0 +1,131 @@
+"""CPU checks of the pairing tower's round-2 restructuring against the big-int oracle (no GPU): the generated final-exponentiation
+PROGRAM (keaki_amd/csrc/pair261_constants.cuh: FE_PROG, an accumulator machine over slots) computes arkworks' final exponentiation;
+the Miller step list follows the NAF of 6z + 2; the written-out Fq6 / sparse-line / Fq4-squaring formulas of pair261.cuh (sums of
+up to three Fq2 products per output coefficient) equal the oracle's tower arithmetic; and the limb-level helpers (multiplication by
+9 + u on 29-bit limbs, column budgets of the six-product stream) hold their stated bounds."""
+import os
+import random
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _consts():
+    t = open(os.path.join(ROOT, "keaki_amd", "csrc", "pair261_constants.cuh")).read()
+    arr = lambda name: [int(x) for x in re.search(name + r"\[\d+\] = \{([^}]*)\}", t).group(1).split(",")]
+    return arr("MILLER_STEPS"), arr("FE_PROG"), int(re.search(r"FE_EASY_OPS = (\d+)", t).group(1))
+
+
+def test_generated_header_is_current():
+    import subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "keaki_amd", "csrc", "gen_constants.py"), "--pair261"], stdout=subprocess.PIPE, text=True, check=True).stdout
+    assert out == open(os.path.join(ROOT, "keaki_amd", "csrc", "pair261_constants.cuh")).read()
+
+
+def rand_f12(py, rng):
+    r2 = lambda: (rng.randrange(py.P), rng.randrange(py.P))
+    return ((r2(), r2(), r2()), (r2(), r2(), r2()))
+
+
+def test_final_exponentiation_program_equals_oracle(py):
+    _, prog, n_easy = _consts()
+    rng = random.Random(5)
+    for _ in range(2):
+        f = rand_f12(py, rng)
+        slots, acc = {}, f
+        for pc, b in enumerate(prog):
+            code, s = b & 15, b >> 4
+            if code == 0: acc = slots[s]
+            elif code == 1: slots[s] = acc
+            elif code == 2:
+                acc = py.f12_sqr(acc)                  # the cyclotomic squaring IS a squaring (valid after the easy part)
+                assert pc >= n_easy
+            elif code == 3: acc = py.f12_mul(acc, slots[s])
+            elif code == 4: acc = py.f12_mul(acc, py.f12_conj(slots[s]))
+            elif code == 5: acc = py.f12_conj(acc)
+            elif code == 6: acc = py.f12_frob(acc, s)
+            elif code == 7: acc = py.f12_inv(acc)
+            else: raise AssertionError(code)
+        assert acc == py.final_exponentiation(f)
+        assert max(slots) < 10
+
+
+def test_miller_steps_follow_the_naf(py):
+    steps, _, _ = _consts()
+    # replay the scalar: doublings and additions as the list says must end at 6z + 2
+    assert steps[0] == 0 and steps[-2:] == [4, 5]
+    acc = 1                                         # T = Q: the top digit of the NAF
+    for st in steps[:-2]:
+        if st in (0, 1): acc *= 2
+        elif st == 2: acc += 1
+        elif st == 3: acc -= 1
+        else: raise AssertionError(st)
+    assert acc == 6 * py.Z + 2
+    assert steps.count(0) == 1 and len(steps) <= 96
+
+
+def test_written_out_tower_formulas(py):
+    rng = random.Random(7)
+    r2 = lambda: (rng.randrange(py.P), rng.randrange(py.P))
+    xi = py.f2_mul_xi
+    m, add = py.f2_mul, py.f2_add
+    for _ in range(5):
+        a, b = (r2(), r2(), r2()), (r2(), r2(), r2())
+        c0 = add(add(m(a[0], b[0]), m(xi(a[1]), b[2])), m(xi(a[2]), b[1]))
+        c1 = add(add(m(a[0], b[1]), m(a[1], b[0])), m(xi(a[2]), b[2]))
+        c2 = add(add(m(a[0], b[2]), m(a[1], b[1])), m(a[2], b[0]))
+        assert (c0, c1, c2) == py.f6_mul(a, b)
+        # sparse line product f * (c0 + (d0 + d1 v) w)
+        f = rand_f12(py, rng)
+        lc0, d0, d1 = r2(), r2(), r2()
+        (a0, a1, a2), (e0, e1, e2) = f
+        s3 = lambda x, y, z: add(add(x, y), z)
+        r0 = (s3(m(a0, lc0), m(e1, xi(d1)), m(e2, xi(d0))), s3(m(a1, lc0), m(e0, d0), m(e2, xi(d1))), s3(m(a2, lc0), m(e0, d1), m(e1, d0)))
+        r1 = (s3(m(e0, lc0), m(a0, d0), m(a2, xi(d1))), s3(m(e1, lc0), m(a0, d1), m(a1, d0)), s3(m(e2, lc0), m(a1, d1), m(a2, d0)))
+        assert (r0, r1) == py.f12_mul_by_034(f, lc0, d0, d1)
+        # Fq4 squaring (x + y s)^2, s^2 = xi
+        x, y = r2(), r2()
+        t0 = add(m(x, x), m(xi(y), y)); t1 = py.f2_dbl(m(x, y))
+        assert t0 == add(py.f2_sqr(x), xi(py.f2_sqr(y))) and t1 == m(py.f2_dbl(x), y)
+
+
+def test_limb_helpers_and_column_budget(py):
+    """xi_limbs (pair261.cuh) on 29-bit limbs: value (9 a -/+ o + K p), every intermediate below 2^32, output limbs <= 2^29 + 8;
+    the six-product stream's column sums stay below 2^64 at the limb bound."""
+    P, MASK = py.P, (1 << 29) - 1
+    limbs = lambda v: [(v >> (29 * i)) & MASK for i in range(8)] + [v >> 232]
+    val = lambda l: sum(x << (29 * i) for i, x in enumerate(l))
+    def biased(c, bias_log=30):
+        k = limbs(c * P); b, cy = 1 << bias_log, (1 << bias_log) >> 29
+        return [k[0] + b] + [k[i] + b - cy for i in range(1, 8)] + [k[8] - cy]
+    def carry(x):
+        r = [x[0] & MASK] + [(x[i] & MASK) + (x[i - 1] >> 29) for i in range(1, 8)] + [x[8] + (x[7] >> 29)]
+        return r
+    def xi_limbs(a, o, K, odd):
+        t = []
+        for i in range(9):
+            addv = o[i] if odd else K[i] - o[i]
+            assert 0 <= addv < 1 << 32
+            lo8 = ((a[i] << 3) & MASK) if i < 8 else (a[i] << 3)
+            v = lo8 + a[i] + addv + ((a[i - 1] >> 26) if i else 0)
+            assert v < 1 << 32
+            t.append(v)
+        return carry(t)
+    rng = random.Random(11)
+    for bound, kmul in ((1, 2), (2, 4)):
+        K = biased(kmul)
+        for trial in range(300):
+            a = rng.randrange(bound * P) if trial else bound * P - 1
+            o = rng.randrange(bound * P) if trial > 1 else bound * P - 1
+            for odd in (False, True):
+                r = xi_limbs(limbs(a), limbs(o), K, odd)
+                assert all(x <= (1 << 29) + 8 for x in r[:8]) and r[8] < 1 << 29
+                exp = 9 * a + o if odd else 9 * a - o + kmul * P
+                assert val(r) == exp and val(r) < (9 * bound + kmul) * P
+    lim = (1 << 29) + 8
+    worst = 6 * 9 * lim * lim + 9 * MASK * MASK
+    assert worst + (worst >> 29) < 1 << 64
+    # dual stream with one side doubled (fq4_sqr: t1 = (2x) y): a, c < 2^30, b, d <= 2^29 + 8
+    assert 2 * 9 * (1 << 30) * lim + 9 * MASK * MASK < 1 << 64
