@@ -232,52 +232,38 @@ KDEV void fq12_set_one(Fq12* f) {
   f->c0.c0 = fq2d_one();
 }
 KDEV void fq12_conj(Fq12* r, const Fq12* a) { r->c0 = a->c0; r->c1 = fq6_neg(a->c1); }
-// Karatsuba over Fq6: three Fq6 products through ONE instance of fq6_mul (the loop counter is wave-uniform: the operand choice is
-// scalar control flow, not per-lane selects)
+// Karatsuba over Fq6: three Fq6 products. Straight-line on purpose: a loop over one instance of fq6_mul made hipcc pick the k-th operand
+// through a scratch array (48 stores + 48 loads per iteration: 40 K scratch instructions per pairing, profiles/r02_pairing_pmc_v1.csv).
 static KTOWER void fq12_mul(Fq12* r, const Fq12* a, const Fq12* b) {
   Fq6 t0, t1, m;
-#pragma unroll 1
-  for (int k = 0; k < 3; k++) {
-    Fq6 x, y, z;
-    if (k == 0) { x = a->c0; y = b->c0; }
-    else if (k == 1) { x = a->c1; y = b->c1; }
-    else { x = a->c0 + a->c1; y = b->c0 + b->c1; }
-    fq6_mul(&z, &x, &y);
-    if (k == 0) t0 = z; else if (k == 1) t1 = z; else m = z;
+  {
+    const Fq6 s0 = a->c0 + a->c1, s1 = b->c0 + b->c1;
+    fq6_mul(&m, &s0, &s1);
   }
+  fq6_mul(&t0, &a->c0, &b->c0);
+  fq6_mul(&t1, &a->c1, &b->c1);
   r->c1 = m - t0 - t1;
   r->c0 = t0 + fq6_mul_v(t1);
 }
 // complex squaring: a0 a1 and (a0 + a1)(a0 + v a1)
 static KTOWER void fq12_sqr(Fq12* r, const Fq12* a) {
   Fq6 ab, t;
-#pragma unroll 1
-  for (int k = 0; k < 2; k++) {
-    Fq6 x, y, z;
-    if (k == 0) { x = a->c0; y = a->c1; }
-    else { x = a->c0 + a->c1; y = a->c0 + fq6_mul_v(a->c1); }
-    fq6_mul(&z, &x, &y);
-    if (k == 0) ab = z; else t = z;
+  {
+    const Fq6 s0 = a->c0 + a->c1, s1 = a->c0 + fq6_mul_v(a->c1);
+    fq6_mul(&t, &s0, &s1);
   }
+  fq6_mul(&ab, &a->c0, &a->c1);
   r->c0 = t - ab - fq6_mul_v(ab);
   r->c1 = ab + ab;
 }
 static KTOWER void fq12_inv(Fq12* r, const Fq12* a) {
   Fq6 n0, n1, ni, r0, r1;
-#pragma unroll 1
-  for (int k = 0; k < 2; k++) {
-    Fq6 x = k ? a->c1 : a->c0, z;
-    fq6_mul(&z, &x, &x);
-    if (k == 0) n0 = z; else n1 = z;
-  }
+  fq6_mul(&n0, &a->c0, &a->c0);
+  fq6_mul(&n1, &a->c1, &a->c1);
   Fq6 n = n0 - fq6_mul_v(n1);
   fq6_inv(&ni, &n);
-#pragma unroll 1
-  for (int k = 0; k < 2; k++) {
-    Fq6 x = k ? a->c1 : a->c0, z;
-    fq6_mul(&z, &x, &ni);
-    if (k == 0) r0 = z; else r1 = z;
-  }
+  fq6_mul(&r0, &a->c0, &ni);
+  fq6_mul(&r1, &a->c1, &ni);
   r->c0 = r0;
   r->c1 = fq6_neg(r1);
 }
@@ -310,13 +296,9 @@ KDEV void fq4_sqr(Fq2d* t0, Fq2d* t1, const Fq2d& x, const Fq2d& y) {
 static KTOWER void fq12_cyc_sqr(Fq12* r, const Fq12* a) {
   const Fq2d r0 = a->c0.c0, r4 = a->c0.c1, r3 = a->c0.c2, r2 = a->c1.c0, r1 = a->c1.c1, r5 = a->c1.c2;
   Fq2d t0, t1, t2, t3, t4, t5;
-#pragma unroll 1
-  for (int k = 0; k < 3; k++) {
-    Fq2d x, y, u, w;
-    if (k == 0) { x = r0; y = r1; } else if (k == 1) { x = r2; y = r3; } else { x = r4; y = r5; }
-    fq4_sqr(&u, &w, x, y);
-    if (k == 0) { t0 = u; t1 = w; } else if (k == 1) { t2 = u; t3 = w; } else { t4 = u; t5 = w; }
-  }
+  fq4_sqr(&t0, &t1, r0, r1);
+  fq4_sqr(&t2, &t3, r2, r3);
+  fq4_sqr(&t4, &t5, r4, r5);
   Fq2d x5 = fq2_mul_xi(t5);
   r->c0.c0 = fq2_dbl(t0 - r0) + t0;
   r->c1.c1 = fq2_dbl(t1 + r1) + t1;
