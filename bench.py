@@ -81,17 +81,22 @@ G2_GEN = (1085704699902305713594457076223282948137075635957851808699051999328565
           4082367875863433681332203403145435568316851327593401208105741076214120093531)
 
 
-def issue_cycles_from_ubench():
-    """cycles per wave-instruction per SIMD of v_mad_u64_u32 at 4 waves/SIMD, from the committed micro-benchmark output"""
-    path = os.path.join(ROOT, "profiles", "r01_ubench_int_gfx950.txt")
+def stream_cycles_from_ubench(waves=3):
+    """SIMD-cycles of one 205-instruction product stream (u29_mul, 162 v_mad_u64_u32) and of one plain dependent 32-bit VALU instruction at the
+    bucket kernel's occupancy (3 waves per SIMD), from the committed micro-benchmark output (bench_tools/ubench_u29.hip)"""
+    path = os.path.join(ROOT, "profiles", "r01_ubench_u29_gfx950.txt")
+    mul = simple = None
     try:
         for line in open(path):
-            m = re.match(r"v_mad_u64_u32\s+waves/SIMD=4\s.*=>\s*([0-9.]+) cycles", line)
+            m = re.match(r"u29_mul \(205 instr\)\s+waves/SIMD=%d\s.*?([0-9.]+) SIMD-cycles" % waves, line)
             if m:
-                return float(m.group(1)), os.path.relpath(path, ROOT)
+                mul = float(m.group(1))
+            m = re.match(r"v_and_b32 dependent\s+waves/SIMD=%d\s.*?([0-9.]+) SIMD-cycles" % waves, line)
+            if m:
+                simple = float(m.group(1))
     except OSError:
         pass
-    return None, None
+    return mul, simple, os.path.relpath(path, ROOT)
 
 
 def stamped_profile(name, files):
@@ -422,15 +427,21 @@ def main():
     # ISA (bench_tools/count_isa.py -> profiles/r02_accumulate_isa.json), issue rate from the committed micro-benchmark
     alu = None
     isa, isa_why = stamped_profile("r02_accumulate_isa.json", MSM_KERNEL_SOURCES)
-    cyc, cyc_src = issue_cycles_from_ubench()
-    if isa is not None and cyc is not None:
-        ipa = float(isa["loop_instructions"])
-        modmul_peak = 1024 * 2.4e9 / cyc * 64 / ipa * 10.0
+    mul_cyc, simple_cyc, cyc_src = stream_cycles_from_ubench(3)
+    if isa is not None and mul_cyc is not None and simple_cyc is not None:
+        ipa, mads = float(isa["loop_instructions"]), float(isa["loop_v_mad_u64_u32"])
+        # model: every 162 multiply-adds are one product stream of 205 instructions at its measured rate, what is left of the loop body runs
+        # at the rate of a plain 32-bit VALU instruction
+        model_cycles = mads / 162.0 * mul_cyc + max(0.0, ipa - mads / 162.0 * 205.0) * simple_cyc
+        wave_adds_per_simd = n * windows / 64.0 / 1024.0
+        measured_cycles = avg_bucket_s * 2.4e9 / wave_adds_per_simd
         modmuls = 10.0 * n * windows / avg_bucket_s
-        alu = {"bound": "integer issue (v_mad_u64_u32)", "achieved": modmuls / 1e9, "peak": modmul_peak / 1e9, "unit": "G modmul/s",
-               "frac": modmuls / modmul_peak, "issues_per_mixed_add": ipa, "v_mad_u64_u32_per_mixed_add": isa.get("loop_v_mad_u64_u32"),
-               "cycles_per_issue": cyc, "sources": ["profiles/r02_accumulate_isa.json", cyc_src],
-               "note": "a schedule diagnostic (how close the kernel runs to the issue rate of ITS OWN instruction stream), not a claim that the stream is minimal"}
+        alu = {"bound": "integer issue (v_mad_u64_u32 streams)", "achieved": modmuls / 1e9, "peak": modmuls / 1e9 * measured_cycles / model_cycles, "unit": "G modmul/s",
+               "frac": model_cycles / measured_cycles, "simd_cycles_per_mixed_add_measured": measured_cycles, "simd_cycles_per_mixed_add_at_stream_rate": model_cycles,
+               "issues_per_mixed_add": ipa, "v_mad_u64_u32_per_mixed_add": mads, "product_stream_cycles": mul_cyc, "plain_valu_cycles": simple_cyc,
+               "sources": ["profiles/r02_accumulate_isa.json", cyc_src],
+               "note": "a schedule diagnostic (how close the kernel runs to the issue rate of ITS OWN instruction stream at 3 waves per SIMD and "
+                       "2.4 GHz), not a claim that the stream is minimal"}
     else:
         alu = {"note": isa_why or "no micro-benchmark file"}
     result = {

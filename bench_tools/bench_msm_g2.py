@@ -16,10 +16,14 @@ for log2n in [int(x) for x in sys.argv[1:]] or [16, 18]:
     pts = hip.g2_mul_batch(g2, random_fr_limbs(n, SEED + 1))
     sc = random_fr_limbs(n, SEED + 2)
     srs = hip.srs_g2_upload(pts)
-    hip.msm_g2(srs, sc)
-    t0 = time.perf_counter()
-    for _ in range(3):
+    for tables in (False, True):
+        if tables:
+            t0 = time.perf_counter(); nb = hip.srs_g2_precompute(srs); tb = time.perf_counter() - t0
         hip.msm_g2(srs, sc)
-    dt = (time.perf_counter() - t0) / 3
-    print("G2 MSM 2^%d: %.2f ms incl. %d MB scalar upload (%.2e scalar-mults/s)" % (log2n, dt * 1e3, n * 32 >> 20, n / dt), flush=True)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            hip.msm_g2(srs, sc)
+        dt = (time.perf_counter() - t0) / 3
+        print("G2 MSM 2^%d%s: %.2f ms incl. %d MB scalar upload (%.2e scalar-mults/s)%s" % (
+            log2n, " with window tables" if tables else "", dt * 1e3, n * 32 >> 20, n / dt, " [tables: %.0f MB built in %.2f s]" % (nb / 1e6, tb) if tables else ""), flush=True)
     srs.free()

@@ -89,6 +89,8 @@ keaki_status keaki_hip_srs_g1_precompute(keaki_hip_ctx* ctx, keaki_hip_srs_g1* s
 void keaki_hip_srs_g1_free(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs);
 keaki_status keaki_hip_srs_g2_upload(keaki_hip_ctx* ctx, const uint64_t* points_aff, size_t n, keaki_hip_srs_g2** out);
 keaki_status keaki_hip_srs_g2_wrap_dev(keaki_hip_ctx* ctx, const void* d_points_aff, size_t n, keaki_hip_srs_g2** out);
+/* window tables of a fixed G2 basis, as keaki_hip_srs_g1_precompute (W x n x 128 bytes): removes the per-window Horner doublings of a G2 MSM */
+keaki_status keaki_hip_srs_g2_precompute(keaki_hip_ctx* ctx, keaki_hip_srs_g2* srs, size_t* table_bytes_out);
 void keaki_hip_srs_g2_free(keaki_hip_ctx* ctx, keaki_hip_srs_g2* srs);
 
 /* ---- MSM: replaces <E::G1 as VariableBaseMSM>::msm_unchecked(&setup.g1_aff, p) (src/kzg.rs:98) -

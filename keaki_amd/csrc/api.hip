@@ -21,9 +21,35 @@ struct keaki_hip_srs_g2 {
   const void* d = nullptr;
   size_t n = 0;
   bool owned = false;
+  void* table = nullptr;          // window tables (keaki_hip_srs_g2_precompute), as for G1
+  size_t table_bytes = 0;
+  int c_table = 0;
 };
 
+#include <dlfcn.h>
 namespace {
+// roctx ranges around the kernel families (tracing), visible to `rocprofv3 --marker-trace`. The marker library is
+// looked up at run time so that the ABI has no link-time dependency on the profiler; without it the scopes are no-ops.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_LOCAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_LOCAL);
+    if (h) {
+      push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+      pop = (int (*)())dlsym(h, "roctxRangePop");
+      if (!push || !pop) push = nullptr;
+    }
+  }
+};
+const Roctx& roctx() { static Roctx r; return r; }
+struct RoctxScope {
+  bool on;
+  explicit RoctxScope(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+  ~RoctxScope() { if (on) roctx().pop(); }
+};
+#define TRACE_SCOPE(name) RoctxScope roctx_scope_(name)
 thread_local std::string g_create_error;
 constexpr size_t G1_AFF_BYTES = 64, G2_AFF_BYTES = 128;
 }  // namespace
@@ -204,6 +230,7 @@ void keaki_hip_srs_g1_free(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs) {
 }
 keaki_status keaki_hip_srs_g1_precompute(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, size_t* table_bytes_out) {
   CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.srs_precompute");
   if (!srs) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g1_precompute: srs is null");
   if (!srs->table && srs->n) {
     ST_TRY(msm_g1_precompute_run(ctx, srs->d, srs->n, &srs->c_table, &srs->table_bytes, &srs->table));
@@ -232,21 +259,33 @@ keaki_status keaki_hip_srs_g2_wrap_dev(keaki_hip_ctx* ctx, const void* d_points_
 }
 void keaki_hip_srs_g2_free(keaki_hip_ctx* ctx, keaki_hip_srs_g2* srs) {
   if (!srs) return;
-  if (srs->owned && srs->d) {
-    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
-    (void)hipFree((void*)srs->d);
-  }
+  if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+  if (srs->owned && srs->d) (void)hipFree((void*)srs->d);
+  if (srs->table) (void)hipFree(srs->table);
   delete srs;
+}
+keaki_status keaki_hip_srs_g2_precompute(keaki_hip_ctx* ctx, keaki_hip_srs_g2* srs, size_t* table_bytes_out) {
+  CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.srs_precompute");
+  if (!srs) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g2_precompute: srs is null");
+  if (!srs->table && srs->n) {
+    ST_TRY(msm_g2_precompute_run(ctx, srs->d, srs->n, &srs->c_table, &srs->table_bytes, &srs->table));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (table_bytes_out) *table_bytes_out = srs->table_bytes;
+  return KEAKI_OK;
 }
 
 // ---- MSM -----------------------------------------------------------------------------------------
 keaki_status keaki_hip_msm_g1_dev(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, const void* d_scalars, size_t n, void* d_out_jac) {
   CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.msm_g1");
   if (!srs) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm_g1: srs is null");
   return msm_g1_run(ctx, srs->d, srs->n, d_scalars, n, d_out_jac, srs->table, srs->c_table);
 }
 keaki_status keaki_hip_msm_g1(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, const uint64_t* scalars, size_t n, uint64_t* out_jac) {
   CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.msm_g1");
   if (!srs || !out_jac || (n && !scalars)) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm_g1: null pointer");
   if (n > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", n, srs->n);
   ST_TRY(upload(ctx, ctx->io_a, scalars, n * 32));
@@ -258,22 +297,25 @@ keaki_status keaki_hip_msm_g1(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, c
 }
 keaki_status keaki_hip_msm_g2_dev(keaki_hip_ctx* ctx, const keaki_hip_srs_g2* srs, const void* d_scalars, size_t n, void* d_out_jac) {
   CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.msm_g2");
   if (!srs) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm_g2: srs is null");
-  return msm_g2_run(ctx, srs->d, srs->n, d_scalars, n, d_out_jac);
+  return msm_g2_run(ctx, srs->d, srs->n, d_scalars, n, d_out_jac, srs->table, srs->c_table);
 }
 keaki_status keaki_hip_msm_g2(keaki_hip_ctx* ctx, const keaki_hip_srs_g2* srs, const uint64_t* scalars, size_t n, uint64_t* out_jac) {
   CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.msm_g2");
   if (!srs || !out_jac || (n && !scalars)) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm_g2: null pointer");
   if (n > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", n, srs->n);
   ST_TRY(upload(ctx, ctx->io_a, scalars, n * 32));
   ST_TRY(reserve(ctx, ctx->io_b, 192));
-  ST_TRY(msm_g2_run(ctx, srs->d, srs->n, ctx->io_a.p, n, ctx->io_b.p));
+  ST_TRY(msm_g2_run(ctx, srs->d, srs->n, ctx->io_a.p, n, ctx->io_b.p, srs->table, srs->c_table));
   ST_TRY(download(ctx, out_jac, ctx->io_b.p, 192));
   resolve_timing(ctx);
   return KEAKI_OK;
 }
 keaki_status keaki_hip_g1_sum_dev(keaki_hip_ctx* ctx, const void* d_points_jac, size_t k, void* d_out_jac) {
   CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.g1_sum");
   if (!d_out_jac || (k && !d_points_jac)) return fail(ctx, KEAKI_ERR_BAD_ARG, "g1_sum: null pointer");
   return g1_sum_run(ctx, d_points_jac, k, d_out_jac);
 }
@@ -290,6 +332,7 @@ keaki_status keaki_hip_g1_sum(keaki_hip_ctx* ctx, const uint64_t* points_jac, si
 keaki_status keaki_hip_g1_mul_batch_dev(keaki_hip_ctx* ctx, const void* d_points_aff, int32_t point_stride, const void* d_scalars, size_t n,
                                         void* d_out_aff) {
   CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.g1_mul_batch");
   if (n == 0) return KEAKI_OK;
   if (!d_points_aff || !d_scalars || !d_out_aff || (point_stride != 0 && point_stride != 1)) return fail(ctx, KEAKI_ERR_BAD_ARG, "g1_mul_batch: bad argument");
   return g1_mul_batch_run(ctx, d_points_aff, (int)point_stride, d_scalars, n, d_out_aff);
@@ -297,6 +340,7 @@ keaki_status keaki_hip_g1_mul_batch_dev(keaki_hip_ctx* ctx, const void* d_points
 keaki_status keaki_hip_g2_mul_batch_dev(keaki_hip_ctx* ctx, const void* d_points_aff, int32_t point_stride, const void* d_scalars, size_t n,
                                         void* d_out_aff) {
   CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.g2_mul_batch");
   if (n == 0) return KEAKI_OK;
   if (!d_points_aff || !d_scalars || !d_out_aff || (point_stride != 0 && point_stride != 1)) return fail(ctx, KEAKI_ERR_BAD_ARG, "g2_mul_batch: bad argument");
   return g2_mul_batch_run(ctx, d_points_aff, (int)point_stride, d_scalars, n, d_out_aff);
@@ -328,6 +372,7 @@ keaki_status keaki_hip_g2_mul_batch(keaki_hip_ctx* ctx, const uint64_t* points_a
 keaki_status keaki_hip_pairing_batch_dev(keaki_hip_ctx* ctx, const void* d_g1_aff, const void* d_g2_aff, int32_t g2_stride, size_t n,
                                          void* d_gt_out) {
   CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.pairing");
   if (n == 0) return KEAKI_OK;
   if (!d_g1_aff || !d_g2_aff || !d_gt_out || (g2_stride != 0 && g2_stride != 1)) return fail(ctx, KEAKI_ERR_BAD_ARG, "pairing_batch: bad argument");
   return pairing_run(ctx, d_g1_aff, d_g2_aff, (int)g2_stride, n, d_gt_out);
@@ -361,6 +406,7 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
                                        const void* d_values, const void* d_r, size_t n, void* d_ct_out_aff, void* d_gt_out, void* d_key_out,
                                        size_t msg_len) {
   CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.encap");
   if (n == 0) return KEAKI_OK;
   if (!d_com_aff || !d_tau_g2_aff || !d_points || !d_values || !d_r || !d_ct_out_aff || (!d_gt_out && !d_key_out) || msg_len > 65536)
     return fail(ctx, KEAKI_ERR_BAD_ARG, "encap_batch: bad argument");
@@ -510,6 +556,7 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
 keaki_status keaki_hip_decap_batch_dev(keaki_hip_ctx* ctx, const void* d_proofs_aff, const void* d_cts_aff, size_t n, void* d_gt_out,
                                        void* d_key_out, size_t msg_len) {
   CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.decap");
   if (n == 0) return KEAKI_OK;
   if (!d_proofs_aff || !d_cts_aff || (!d_gt_out && !d_key_out) || msg_len > 65536) return fail(ctx, KEAKI_ERR_BAD_ARG, "decap_batch: bad argument");
   void* gt = d_gt_out;
@@ -565,6 +612,7 @@ keaki_status keaki_hip_decap_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_af
 keaki_status keaki_hip_open_fk(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32_t log2d, const uint64_t* hat_a, const uint64_t* tw_2d,
                                const uint64_t* tw_2d_inv, const uint64_t* tw_d, uint64_t* proofs_out_aff) {
   CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.open_fk");
   if (!srs || !hat_a || !tw_2d || !tw_2d_inv || (!tw_d && log2d > 0) || !proofs_out_aff || log2d > 27) return fail(ctx, KEAKI_ERR_BAD_ARG, "open_fk: bad argument");
   const size_t d = (size_t)1 << log2d;
   if (d > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "open_fk: %zu coefficients but the SRS holds %zu points", d, srs->n);
@@ -592,6 +640,7 @@ keaki_status keaki_hip_open_fk(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32
 keaki_status keaki_hip_open_fk_poly(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32_t log2d, const uint64_t* coeffs, const uint64_t* omega_2d,
                                     const uint64_t* omega_2d_inv, const uint64_t* inv_2d, uint64_t* proofs_out_aff) {
   CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.open_fk");
   if (!srs || !coeffs || !omega_2d || !omega_2d_inv || !inv_2d || !proofs_out_aff || log2d > 27) return fail(ctx, KEAKI_ERR_BAD_ARG, "open_fk_poly: bad argument");
   const size_t d = (size_t)1 << log2d;
   if (d > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "open_fk: %zu coefficients but the SRS holds %zu points", d, srs->n);
@@ -616,6 +665,7 @@ keaki_status keaki_hip_srs_g1_precompute_fk(keaki_hip_ctx* ctx, keaki_hip_srs_g1
 // In-place scalar-field DFT of n = 2^log2n elements with the order-n root `omega`, then an optional scaling (the 1/n of an inverse transform).
 keaki_status keaki_hip_fr_fft(keaki_hip_ctx* ctx, uint64_t* data, uint32_t log2n, const uint64_t* omega, const uint64_t* scale_or_null) {
   CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.fr_fft");
   if (!data || !omega || log2n > 28) return fail(ctx, KEAKI_ERR_BAD_ARG, "fr_fft: bad argument");
   const size_t n = (size_t)1 << log2n;
   ST_TRY(reserve(ctx, ctx->io_d, n * 32 + (n / 2 + 1) * 32));
@@ -666,6 +716,7 @@ keaki_status keaki_hip_final_exp_batch(keaki_hip_ctx* ctx, const uint64_t* f_mon
 keaki_status keaki_hip_kzg_open(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, const uint64_t* coeffs, size_t n, const uint64_t* point,
                                 uint64_t* proof_out_jac, uint64_t* value_out) {
   CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.kzg_open");
   if (!srs || !point || !proof_out_jac || (n && !coeffs)) return fail(ctx, KEAKI_ERR_BAD_ARG, "kzg_open: null pointer");
   if (n && n - 1 > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", n - 1, srs->n);
   const size_t nq = n ? n - 1 : 0;
@@ -687,6 +738,7 @@ keaki_status keaki_hip_kzg_open(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs,
 keaki_status keaki_hip_kzg_verify(keaki_hip_ctx* ctx, const uint64_t* com_aff, const uint64_t* tau_g2_aff, const uint64_t* point,
                                   const uint64_t* value, const uint64_t* proof_aff, int32_t* ok_out) {
   CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.kzg_verify");
   if (!com_aff || !tau_g2_aff || !point || !value || !proof_aff || !ok_out) return fail(ctx, KEAKI_ERR_BAD_ARG, "kzg_verify: null pointer");
   // io block: [g2 128 | tau_g2 128 | com 64 | proof 64 | value 32 | point 32 | pairing inputs 128 | gt 768]
   constexpr size_t O_Q = 0, O_IN = 256, O_P = O_IN + 192, O_GT = O_P + 128, IO_BYTES = O_GT + 768;

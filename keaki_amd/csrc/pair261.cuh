@@ -104,7 +104,14 @@ static KNOINLINE Fq fq_inv261(const Fq a) {
 // ---- Fq2d: saturated front (same interface as round 1) ---------------------------------------------------------------------------
 KDEV Fq2d operator+(const Fq2d& a, const Fq2d& b) { return {a.v + b.v}; }
 KDEV Fq2d operator-(const Fq2d& a, const Fq2d& b) { return {a.v - b.v}; }
-KDEV Fq2d fq2_neg(const Fq2d& a) { return {fq_zero() - a.v}; }      // binary form on purpose: see DESIGN.md section 4.3 (the `-theta` note)
+// Negation. Round 1 saw a wrong value for the unary form (-theta, the fq_neg_asm stream) at ONE site of the fully inlined Miller loop and
+// switched to 0 - theta. Round 2 re-ran the experiment on the restructured kernel (build with -DKEAKI_NEG_UNARY: every fq2_neg becomes
+// the unary stream; bench_tools/dbg/neg_unary_experiment.sh): see DESIGN.md section 4.3 for the outcome. The binary form stays the default.
+#ifdef KEAKI_NEG_UNARY
+KDEV Fq2d fq2_neg(const Fq2d& a) { return {-a.v}; }
+#else
+KDEV Fq2d fq2_neg(const Fq2d& a) { return {fq_zero() - a.v}; }
+#endif
 KDEV Fq2d fq2_dbl(const Fq2d& a) { return {fq_dbl(a.v)}; }
 KDEV Fq2d fq2d_zero() { return {fq_zero()}; }
 KDEV Fq2d fq2d_one() { return {fq_select(lane_odd() != 0, fq_zero(), ONE)}; }

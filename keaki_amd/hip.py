@@ -17,7 +17,7 @@ _LIB = None
 EXPORTS = [
     "keaki_hip_ctx_create", "keaki_hip_ctx_destroy", "keaki_hip_last_error", "keaki_hip_synchronize", "keaki_hip_version",
     "keaki_hip_srs_g1_upload", "keaki_hip_srs_g1_wrap_dev", "keaki_hip_srs_g1_slice", "keaki_hip_srs_g1_len", "keaki_hip_srs_g1_precompute", "keaki_hip_srs_g1_free",
-    "keaki_hip_srs_g2_upload", "keaki_hip_srs_g2_wrap_dev", "keaki_hip_srs_g2_free",
+    "keaki_hip_srs_g2_upload", "keaki_hip_srs_g2_wrap_dev", "keaki_hip_srs_g2_precompute", "keaki_hip_srs_g2_free",
     "keaki_hip_msm_g1", "keaki_hip_msm_g1_dev", "keaki_hip_msm_g2", "keaki_hip_msm_g2_dev",
     "keaki_hip_g1_sum_dev", "keaki_hip_g1_sum",
     "keaki_hip_g1_mul_batch", "keaki_hip_g2_mul_batch", "keaki_hip_g1_mul_batch_dev", "keaki_hip_g2_mul_batch_dev",
@@ -67,6 +67,7 @@ def load_library():
             getattr(lib, f"keaki_hip_{g}_mul_batch").argtypes = [vp, vp, i32, vp, sz, vp]
             getattr(lib, f"keaki_hip_{g}_mul_batch_dev").argtypes = [vp, vp, i32, vp, sz, vp]
         lib.keaki_hip_srs_g1_precompute.argtypes = [vp, vp, C.POINTER(C.c_size_t)]
+        lib.keaki_hip_srs_g2_precompute.argtypes = [vp, vp, C.POINTER(C.c_size_t)]
         lib.keaki_hip_srs_g1_slice.argtypes = [vp, vp, sz, sz, C.POINTER(vp)]
         lib.keaki_hip_srs_g1_len.argtypes = [vp]
         lib.keaki_hip_srs_g1_len.restype = sz
@@ -202,6 +203,11 @@ class KeakiHip:
         """one-time window-table build for a fixed SRS; returns the table size in bytes"""
         nbytes = C.c_size_t(0)
         self._ck(self.lib.keaki_hip_srs_g1_precompute(self.ctx, srs.handle, C.byref(nbytes)))
+        return int(nbytes.value)
+
+    def srs_g2_precompute(self, srs: "SrsG2") -> int:
+        nbytes = C.c_size_t(0)
+        self._ck(self.lib.keaki_hip_srs_g2_precompute(self.ctx, srs.handle, C.byref(nbytes)))
         return int(nbytes.value)
 
     # ---- MSM

@@ -52,6 +52,7 @@ extern "C" {
     pub fn keaki_hip_srs_g1_free(ctx: *mut keaki_hip_ctx, srs: *mut keaki_hip_srs_g1);
     pub fn keaki_hip_srs_g2_upload(ctx: *mut keaki_hip_ctx, points_aff: *const u64, n: usize, out: *mut *mut keaki_hip_srs_g2) -> keaki_status;
     pub fn keaki_hip_srs_g2_wrap_dev(ctx: *mut keaki_hip_ctx, d_points_aff: *const c_void, n: usize, out: *mut *mut keaki_hip_srs_g2) -> keaki_status;
+    pub fn keaki_hip_srs_g2_precompute(ctx: *mut keaki_hip_ctx, srs: *mut keaki_hip_srs_g2, table_bytes_out: *mut usize) -> keaki_status;
     pub fn keaki_hip_srs_g2_free(ctx: *mut keaki_hip_ctx, srs: *mut keaki_hip_srs_g2);
 
     // ---- MSM (replaces msm_unchecked, src/kzg.rs:98)

@@ -106,17 +106,30 @@ def test_msm_too_large_is_an_error(oc, hip):
         srs.free()
 
 
-@pytest.mark.parametrize("n", [1, 33, 200])
+@pytest.mark.parametrize("n", [1, 33, 200, 1 << 12, 1 << 16])
 def test_msm_g2_vs_oracle(oc, hip, rand_fr, n):
     _, g2 = oc.generators()
-    pts = hip.g2_mul_batch(g2, mont(oc, rand_fr(n, 300 + n)))
-    sc = mont(oc, rand_fr(n, 400 + n))
+    if n <= 200:
+        pts = hip.g2_mul_batch(g2, mont(oc, rand_fr(n, 300 + n)))
+        sc = mont(oc, rand_fr(n, 400 + n))
+    else:
+        from bench import random_fr_limbs
+        pts = hip.g2_mul_batch(g2, random_fr_limbs(n, 300 + n))
+        sc = random_fr_limbs(n, 400 + n)
+        sc[5] = 0; pts[7] = 0                                  # a zero scalar, an identity point
     srs = hip.srs_g2_upload(pts)
     try:
         got = jac_to_aff(hip.msm_g2(srs, sc))
+        assert hip.srs_g2_precompute(srs) >= n * 128                 # window tables: shared buckets, no Horner doublings
+        got_t = jac_to_aff(hip.msm_g2(srs, sc))
+        got_short = jac_to_aff(hip.msm_g2(srs, sc[:max(1, n // 3)]))   # a shorter polynomial on the same tables (generic path)
     finally:
         srs.free()
-    assert np.array_equal(got, oc.msm_g2(pts, sc, threads=4))
+    import os
+    th = min(32, os.cpu_count() or 1)
+    exp = oc.msm_g2(pts, sc, threads=th)
+    assert np.array_equal(got, exp) and np.array_equal(got_t, exp)
+    assert np.array_equal(got_short, oc.msm_g2(pts[:max(1, n // 3)], sc[:max(1, n // 3)], threads=th))
 
 
 def test_g1_sum_of_partials(oc, hip, rand_fr):
