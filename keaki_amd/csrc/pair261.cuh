@@ -252,6 +252,30 @@ static KTOWER void fq12_mul(Fq12* r, const Fq12* a, const Fq12* b) {
   r->c1 = m - t0 - t1;
   r->c0 = t0 + fq6_mul_v(t1);
 }
+// The same with the second operand in MEMORY: `ld(h)` returns half h (c0 / c1) of b, this lane's components. b is read three times (both
+// halves for the Karatsuba sum, then one half per product) instead of being held in 48 registers next to the accumulator -- the difference
+// between spilling and not spilling in the kernels that multiply an accumulator by a table entry or a slot.
+template <class LoadHalf>
+static KTOWER void fq12_mul_ld(Fq12* r, const Fq12* a, LoadHalf ld) {
+  Fq6 t0, t1, m;
+  {
+    const Fq6 b0 = ld(0), b1 = ld(1);
+    const Fq6 s0 = a->c0 + a->c1, s1 = b0 + b1;
+    fq6_mul(&m, &s0, &s1);
+  }
+  asm volatile("" ::: "memory");          // the halves are loaded again, not kept
+  {
+    const Fq6 b0 = ld(0);
+    fq6_mul(&t0, &a->c0, &b0);
+  }
+  asm volatile("" ::: "memory");
+  {
+    const Fq6 b1 = ld(1);
+    fq6_mul(&t1, &a->c1, &b1);
+  }
+  r->c1 = m - t0 - t1;
+  r->c0 = t0 + fq6_mul_v(t1);
+}
 // complex squaring: a0 a1 and (a0 + a1)(a0 + v a1)
 static KTOWER void fq12_sqr(Fq12* r, const Fq12* a) {
   Fq6 ab, t;

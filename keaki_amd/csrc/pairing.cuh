@@ -141,10 +141,16 @@ static KTOWER void fe_run(Fq12* acc, Fq* __restrict__ ws, size_t ws_n, u32 item)
     } else if (code == 2) {
       fq12_cyc_sqr(acc, acc);
     } else if (code == 3 || code == 4) {
-      Fq12 e;
-      slot_load(&e, ws, ws_n, s, item);
-      if (code == 4) fq12_conj(&e, &e);
-      fq12_mul(acc, acc, &e);
+      const u32 par = lane_odd();
+      const bool cj = code == 4;                  // multiply by the conjugate: the second half negated
+      fq12_mul_ld(acc, acc, [&](int h) {
+        Fq6 x;
+        Fq2d* c = reinterpret_cast<Fq2d*>(&x);
+#pragma unroll
+        for (int k = 0; k < 3; k++) c[k].v = ws[(size_t)(s * 12 + 6 * h + 2 * k + par) * ws_n + item];
+        if (h == 1 && cj) x = fq6_neg(x);
+        return x;
+      });
     } else if (code == 5) {
       fq12_conj(acc, acc);
     } else if (code == 6) {
@@ -308,10 +314,21 @@ static KTOWER void gt_table_exp(Fq12* acc, const Fq* __restrict__ tab, GtShape g
     const bool neg = d > half;
     carry_d = neg ? 1u : 0u;
     if (neg) d = 2u * half - d;
-    Fq12 e;
-    if (d) { gt_load(&e, tab + ((size_t)j * g.entries + d) * 12); if (neg) fq12_conj(&e, &e); }
-    else fq12_set_one(&e);
-    fq12_mul(acc, acc, &e);
+    const Fq* src = tab + ((size_t)j * g.entries + d) * 12;
+    const u32 par = lane_odd();
+    fq12_mul_ld(acc, acc, [&](int h) {
+      Fq6 x;
+      Fq2d* c = reinterpret_cast<Fq2d*>(&x);
+      if (d) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) c[k].v = src[6 * h + 2 * k + par];
+        if (h == 1 && neg) x = fq6_neg(x);
+      } else {
+        x = fq6_zero();
+        if (h == 0) x.c0 = fq2d_one();
+      }
+      return x;
+    });
   }
 }
 // gt_out[i] = serialize(A^(r_i) * B^(-(r_i * beta_i)))   (tables of A and B). Two lanes per item.
