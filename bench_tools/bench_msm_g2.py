@@ -24,6 +24,16 @@ for log2n in [int(x) for x in sys.argv[1:]] or [16, 18]:
         for _ in range(3):
             hip.msm_g2(srs, sc)
         dt = (time.perf_counter() - t0) / 3
+        import torch
+        d_s = torch.from_numpy(sc.view(np.int64)).cuda(); d_o = torch.zeros(24, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        hip.msm_g2_dev(srs, d_s.data_ptr(), n, d_o.data_ptr()); hip.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            hip.msm_g2_dev(srs, d_s.data_ptr(), n, d_o.data_ptr())
+        hip.synchronize()
+        dd = (time.perf_counter() - t0) / 3
+        print("G2 MSM 2^%d%s, scalars resident: %.2f ms (%.2e scalar-mults/s)" % (log2n, " with window tables" if tables else "", dd * 1e3, n / dd), flush=True)
         print("G2 MSM 2^%d%s: %.2f ms incl. %d MB scalar upload (%.2e scalar-mults/s)%s" % (
             log2n, " with window tables" if tables else "", dt * 1e3, n * 32 >> 20, n / dt, " [tables: %.0f MB built in %.2f s]" % (nb / 1e6, tb) if tables else ""), flush=True)
     srs.free()

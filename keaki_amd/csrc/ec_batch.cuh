@@ -5,7 +5,9 @@
 // occur inside the loops of src/vec.rs:63-66.
 #pragma once
 #include "bn254_curve.cuh"
+#include <type_traits>
 #include "jac29.cuh"
+#include "xyzz29_g2.cuh"
 
 namespace bn254 {
 
@@ -176,6 +178,23 @@ KDEV Xyzz<F> fb_accumulate(Xyzz<F> acc, const Aff<F>* __restrict__ table, FbShap
   return acc;
 }
 
+// the same walk over the windows with the accumulator in the lazy limbs of xyzz29_g2.cuh (G2: the ciphertext side of `encapsulate`)
+KDEV void fb_accumulate_g2_u29(X29G2& acc, const Aff<Fq2>* __restrict__ table, FbShape g, u32* v) {
+  u32 carry = 0;
+  const u32 half = 1u << (g.wb - 1);
+#pragma unroll 1
+  for (u32 j = 0; j < g.windows; j++) {
+    u32 d = (v[0] & (2u * half - 1u)) + carry;
+#pragma unroll
+    for (int t = 0; t < 7; t++) v[t] = (v[t] >> g.wb) | (v[t + 1] << (32u - g.wb));
+    v[7] >>= g.wb;
+    const bool neg = d > half;
+    carry = neg ? 1u : 0u;
+    if (neg) d = 2u * half - d;
+    if (d) x29g2_add_mixed(acc, aff_cneg(table[(size_t)j * g.entries + d], neg));
+  }
+}
+
 // out[i] = r_i * BaseA + (-(r_i * x_i)) * BaseB   with tables for BaseA (C or [tau]_2) and BaseB (g1 or g2)
 template <class F, int OCC>
 __global__ void __launch_bounds__(64, OCC) k_encap_fixed(const Aff<F>* __restrict__ tab_a, FbShape ga, const Aff<F>* __restrict__ tab_b, FbShape gb,
@@ -187,10 +206,17 @@ __global__ void __launch_bounds__(64, OCC) k_encap_fixed(const Aff<F>* __restric
   u32 u[8], v[8];
   fp_from_mont<FrParams>(u, r);
   fp_from_mont<FrParams>(v, t);
-  Xyzz<F> acc = xyzz_inf<F>();
-  acc = fb_accumulate(acc, tab_a, ga, u);
-  acc = fb_accumulate(acc, tab_b, gb, v);
-  out[i] = xyzz_to_aff(acc);
+  if constexpr (std::is_same<F, Fq2>::value) {
+    X29G2 acc = x29g2_inf();
+    fb_accumulate_g2_u29(acc, tab_a, ga, u);
+    fb_accumulate_g2_u29(acc, tab_b, gb, v);
+    out[i] = xyzz_to_aff(x29g2_store(acc));
+  } else {
+    Xyzz<F> acc = xyzz_inf<F>();
+    acc = fb_accumulate(acc, tab_a, ga, u);
+    acc = fb_accumulate(acc, tab_b, gb, v);
+    out[i] = xyzz_to_aff(acc);
+  }
 }
 
 

@@ -20,6 +20,7 @@
 #include "fq29.cuh"
 #include "xyzz29.cuh"
 #include "jac29.cuh"
+#include "xyzz29_g2.cuh"
 
 namespace bn254 {
 
@@ -609,6 +610,25 @@ static __global__ void __launch_bounds__(256) k_msm_accumulate_g1_u29(const Aff<
     out.x = u29_to_fq(X1); out.y = u29_to_fq(Y1); out.zz = u29_to_fq(ZZ); out.zzz = u29_to_fq(ZZZ);
   }
   buckets[t] = out;
+}
+
+// G2 bucket accumulation in the lazy limbs (xyzz29_g2.cuh): same schedule, ~5,600 instead of ~9,000 instructions per mixed addition.
+// Buckets are written back saturated and canonical (the tail keeps the generic arithmetic).
+static __global__ void __launch_bounds__(256) k_msm_accumulate_g2_u29(const Aff<Fq2>* __restrict__ points, const u32* __restrict__ sorted,
+                                                                      const u32* __restrict__ offsets, const u32* __restrict__ counts,
+                                                                      const u32* __restrict__ perm, u32 nbuckets_total, Xyzz<Fq2>* __restrict__ buckets) {
+  u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane >= nbuckets_total) return;
+  u32 t = perm[lane];
+  u32 start = offsets[t], cnt = counts[t];
+  if (msm_bucket_is_heavy(cnt)) return;   // done by k_msm_heavy / k_msm_heavy_combine
+  X29G2 acc = x29g2_inf();
+  for (u32 k = 0; k < cnt; k++) {
+    u32 e = sorted[start + k];
+    Aff<Fq2> q = points[e & 0x7FFFFFFFu];
+    x29g2_add_mixed(acc, aff_cneg(q, (e >> 31) != 0));
+  }
+  buckets[t] = x29g2_store(acc);
 }
 
 // ---- K5: per-window weighted sum, chunked ----------------------------------------------------------

@@ -139,6 +139,13 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
       hipLaunchKernelGGL(k_msm_accumulate_g1_u29, dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
                          (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
   }
+  if constexpr (std::is_same<F, Fq2>::value) {
+    static const bool use_u29_g2 = !(getenv("KEAKI_ACC_U29_G2") && atoi(getenv("KEAKI_ACC_U29_G2")) == 0);   // A/B switch for profiling
+    u29 = use_u29_g2;
+    if (u29)
+      hipLaunchKernelGGL(k_msm_accumulate_g2_u29, dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
+                         (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
+  }
   if (!u29)
     hipLaunchKernelGGL((k_msm_accumulate<F>), dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
                        (const u32*)hist, (const u32*)perm, (u32)nb, buckets);

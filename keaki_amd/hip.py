@@ -224,6 +224,9 @@ class KeakiHip:
         self._ck(self.lib.keaki_hip_msm_g2(self.ctx, srs.handle, _ptr(sc), sc.shape[0], _ptr(out)))
         return out
 
+    def msm_g2_dev(self, srs: SrsG2, d_scalars: int, n: int, d_out: int):
+        self._ck(self.lib.keaki_hip_msm_g2_dev(self.ctx, srs.handle, C.c_void_p(d_scalars), n, C.c_void_p(d_out)))
+
     def g1_sum(self, points_jac) -> np.ndarray:
         p = _np(points_jac, 12); out = np.zeros(12, np.uint64)
         self._ck(self.lib.keaki_hip_g1_sum(self.ctx, _ptr(p), p.shape[0], _ptr(out)))

@@ -129,3 +129,13 @@ def test_limb_helpers_and_column_budget(py):
     assert worst + (worst >> 29) < 1 << 64
     # dual stream with one side doubled (fq4_sqr: t1 = (2x) y): a, c < 2^30, b, d <= 2^29 + 8
     assert 2 * 9 * (1 << 30) * lim + 9 * MASK * MASK < 1 << 64
+
+
+def test_g2_lazy_mixed_addition_model():
+    """keaki_amd/csrc/models/model_g2_add29.py: the G2 mixed addition of xyzz29_g2.cuh operation by operation on Python integers, with
+    assertions on every limb (no negative value, no overflow, stream budgets) and every stated bound, against plain Fq2 XYZZ arithmetic"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("model_g2_add29", os.path.join(ROOT, "keaki_amd", "csrc", "models", "model_g2_add29.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    maxima = m.run(trials=120, seed=3)
+    assert maxima["X3"] < 1.1 and maxima["Yacc"] < 1.5 and maxima["P"] < 5.3 and maxima["R"] < 7.3
