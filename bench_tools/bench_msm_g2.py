@@ -5,6 +5,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import random_fr_limbs, SEED
+import torch
+torch.cuda.init()      # before the library's context
 from keaki_amd.hip import KeakiHip
 hip = KeakiHip(0)
 P_MOD = 21888242871839275222246405745257275088696311157297823662689037894645226208583
@@ -24,7 +26,6 @@ for log2n in [int(x) for x in sys.argv[1:]] or [16, 18]:
         for _ in range(3):
             hip.msm_g2(srs, sc)
         dt = (time.perf_counter() - t0) / 3
-        import torch
         d_s = torch.from_numpy(sc.view(np.int64)).cuda(); d_o = torch.zeros(24, dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
         hip.msm_g2_dev(srs, d_s.data_ptr(), n, d_o.data_ptr()); hip.synchronize()

@@ -47,9 +47,9 @@ class Shard:
     def all_gather_rows(self, row):
         """row: 1-D torch int64 tensor (on the device for RCCL, anywhere for gloo) -> (world, len) tensor holding every rank's row,
         on the device `row` lives on. THE exchange step of the sharded MSM."""
-        import torch
         if self.world == 1:
             return row.reshape(1, -1)
+        import torch
         backend = self.dist.get_backend()
         if backend == "nccl":
             out = torch.empty((self.world, row.numel()), dtype=row.dtype, device=row.device)
@@ -62,9 +62,9 @@ class Shard:
 
     def all_gather_np(self, words: np.ndarray) -> np.ndarray:
         """host variant: u64[k] per rank -> (world, k)"""
-        import torch
         if self.world == 1:
             return words.reshape(1, -1).copy()
+        import torch
         t = torch.from_numpy(np.ascontiguousarray(words).view(np.int64))
         if self.dist.get_backend() == "nccl":
             t = t.cuda()
