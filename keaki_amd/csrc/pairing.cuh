@@ -55,9 +55,9 @@ static KTOWER void line_add(G2Hom* r, const Fq2d* qx, const Fq2d* qy, Line* l) {
   l->c0 = lam; l->c1 = fq2_neg(theta); l->c2 = M2(theta, *qx) - M2(lam, *qy);
 }
 // f *= l(P): the two products by P's coordinates leave the streams as limbs and go straight into the line product
-KDEV void ell(Fq12* f, const Line* l, const U29& px, const U29& py) {
+KDEV void ell(Fq12* f, const Line* l, const U29& px, const U29& py, uint4* park, int pidx) {
   const U29 c0 = u29_mul(cut(l->c0.v), py), d0 = u29_mul(cut(l->c1.v), px);
-  fq12_mul_by_034_limbs(f, c0, d0, cut(l->c2.v), true);
+  fq12_mul_by_034_limbs(f, c0, d0, cut(l->c2.v), true, park, pidx);
 }
 
 // Line table of a fixed Q (ark-ec's G2Prepared), per lane parity: lines[li * 2 + parity], li = index into MILLER_STEPS. 2^261 form.
@@ -65,31 +65,51 @@ constexpr int MILLER_MAX_LINES = 96;
 static_assert(MILLER_NSTEPS <= MILLER_MAX_LINES, "line table too small");
 
 // lines == nullptr: compute the lines on the fly from (qx, qy). P = (px, py) in the 2^261 form.
-static KTOWER void miller_loop(Fq12* f, const Fq& px, const Fq& py, const Fq2d* qx, const Fq2d* qy, const Line* __restrict__ lines) {
+// Register choreography through LDS (`park`, Fq indices): while f is squared and multiplied by the line, the running point T waits in
+// 0..2 and Q in 6..7, and the two big operations use 3..5 for their own temporaries; while the line function runs (a chain of CALLS of the Fq2
+// product, around each of which every live caller-saved register would be saved), f waits in 0..5 and T visits registers.
+static KTOWER void miller_loop(Fq12* f, const Fq& px, const Fq& py, const Fq2d* qx, const Fq2d* qy, const Line* __restrict__ lines, uint4* park) {
   const u32 par = lane_odd();
   fq12_set_one(f);
-  G2Hom r = {*qx, *qy, fq2d_one()};
+  if (!lines) {
+    park_fq(park, 0, qx->v); park_fq(park, 1, qy->v); park_fq(park, 2, fq2d_one().v);     // T = (Q.x, Q.y, 1)
+    park_fq(park, 6, qx->v); park_fq(park, 7, qy->v);
+  }
   const U29 pxl = cut(px), pyl = cut(py);
 #pragma unroll 1
   for (int li = 0; li < MILLER_NSTEPS; li++) {
     const int st = MILLER_STEPS[li];
-    if (st == 1) fq12_sqr(f, f);
+    if (st == 1) fq12_sqr(f, f, park, 3);
     Line l;
     if (lines) {
       l = lines[li * 2 + par];
-    } else if (st <= 1) {
-      line_double(&r, &l);
     } else {
-      // Q, -Q, pi(Q), -pi^2(Q)
-      Fq2d ax = *qx, ay = *qy;
-      if (st == 3) ay = fq2_neg(ay);
-      if (st >= 4) {
-        ax = M2(fq2_conj(ax), fq2d_load(&p261::TWIST_MUL_BY_Q_X)); ay = M2(fq2_conj(ay), fq2d_load(&p261::TWIST_MUL_BY_Q_Y));
-        if (st == 5) { ax = M2(fq2_conj(ax), fq2d_load(&p261::TWIST_MUL_BY_Q_X)); ay = fq2_neg(M2(fq2_conj(ay), fq2d_load(&p261::TWIST_MUL_BY_Q_Y))); }
+      G2Hom r = {{unpark_fq(park, 0)}, {unpark_fq(park, 1)}, {unpark_fq(park, 2)}};
+      {
+        const Fq2d* c = reinterpret_cast<const Fq2d*>(f);
+#pragma unroll
+        for (int k = 0; k < 6; k++) park_fq(park, k, c[k].v);                              // f out of the way of the calls
       }
-      line_add(&r, &ax, &ay, &l);
+      if (st <= 1) {
+        line_double(&r, &l);
+      } else {
+        // Q, -Q, pi(Q), -pi^2(Q)
+        Fq2d ax = {unpark_fq(park, 6)}, ay = {unpark_fq(park, 7)};
+        if (st == 3) ay = fq2_neg(ay);
+        if (st >= 4) {
+          ax = M2(fq2_conj(ax), fq2d_load(&p261::TWIST_MUL_BY_Q_X)); ay = M2(fq2_conj(ay), fq2d_load(&p261::TWIST_MUL_BY_Q_Y));
+          if (st == 5) { ax = M2(fq2_conj(ax), fq2d_load(&p261::TWIST_MUL_BY_Q_X)); ay = fq2_neg(M2(fq2_conj(ay), fq2d_load(&p261::TWIST_MUL_BY_Q_Y))); }
+        }
+        line_add(&r, &ax, &ay, &l);
+      }
+      {
+        Fq2d* c = reinterpret_cast<Fq2d*>(f);
+#pragma unroll
+        for (int k = 0; k < 6; k++) c[k].v = unpark_fq(park, k);
+      }
+      park_fq(park, 0, r.x.v); park_fq(park, 1, r.y.v); park_fq(park, 2, r.z.v);
     }
-    ell(f, &l, pxl, pyl);
+    ell(f, &l, pxl, pyl, park, 3);
   }
 }
 // the line sequence alone (k_g2_prepare)
@@ -130,7 +150,7 @@ KDEV void slot_store(Fq* __restrict__ ws, size_t ws_n, u32 slot, u32 i, const Fq
 }
 
 // the final exponentiation: FE_PROG on the accumulator `acc` (= the Miller loop's output on entry, the GT element on exit)
-static KTOWER void fe_run(Fq12* acc, Fq* __restrict__ ws, size_t ws_n, u32 item) {
+static KTOWER void fe_run(Fq12* acc, Fq* __restrict__ ws, size_t ws_n, u32 item, uint4* park) {
 #pragma unroll 1
   for (int pc = 0; pc < FE_NOPS; pc++) {
     const u32 op = FE_PROG[pc], code = op & 15u, s = op >> 4;
@@ -139,7 +159,7 @@ static KTOWER void fe_run(Fq12* acc, Fq* __restrict__ ws, size_t ws_n, u32 item)
     } else if (code == 1) {
       slot_store(ws, ws_n, s, item, acc);
     } else if (code == 2) {
-      fq12_cyc_sqr(acc, acc);
+      fq12_cyc_sqr(acc, acc, park);
     } else if (code == 3 || code == 4) {
       const u32 par = lane_odd();
       const bool cj = code == 4;                  // multiply by the conjugate: the second half negated
@@ -150,26 +170,29 @@ static KTOWER void fe_run(Fq12* acc, Fq* __restrict__ ws, size_t ws_n, u32 item)
         for (int k = 0; k < 3; k++) c[k].v = ws[(size_t)(s * 12 + 6 * h + 2 * k + par) * ws_n + item];
         if (h == 1 && cj) x = fq6_neg(x);
         return x;
-      });
+      }, park);
     } else if (code == 5) {
       fq12_conj(acc, acc);
     } else if (code == 6) {
-      fq12_frob(acc, acc, (int)s);
+      fq12_frob_parked(acc, acc, (int)s, park);
     } else {
-      fq12_inv(acc, acc);
+      fq12_inv(acc, acc, park);
     }
   }
 }
 
 // GT -> 384 canonical little-endian bytes in ark-serialize order (c0.c0.c0, c0.c0.c1, c0.c1.c0 ... c1.c2.c1):
 // Fq2 coefficient k of the element (k = 0..5 in memory order) fills the 32-byte slots 2k (even lane) and 2k+1 (odd lane).
-KDEV void gt_serialize(u32* out96, const Fq12* f) {
+// The loop runs over LDS (`park`, indices 0..5): a dynamic index into the REGISTER copy of f would force the whole element into scratch memory.
+KDEV void gt_serialize(u32* out96, const Fq12* f, uint4* park) {
   const Fq2d* c = reinterpret_cast<const Fq2d*>(f);
   const u32 par = lane_odd();
+#pragma unroll
+  for (int i = 0; i < 6; i++) park_fq(park, i, c[i].v);
 #pragma unroll 1
   for (int i = 0; i < 6; i++) {
     u32 w[8];
-    canon_words(w, c[i].v);
+    canon_words(w, unpark_fq(park, i));
 #pragma unroll
     for (int j = 0; j < 8; j++) out96[8 * (2 * i + par) + j] = w[j];
   }
@@ -203,6 +226,7 @@ static __global__ void __launch_bounds__(64, 2) k_pairing(PairArgs a) {
   const u32 item = t >> 1;
   const bool live = item < a.n;
   const u32 i = live ? item : (a.n - 1);
+  __shared__ uint4 park[PARK_CHUNKS * 64];
   Fq12 f;
   bool ident = false;
   if (a.mode & PAIR_MILLER) {
@@ -221,22 +245,29 @@ static __global__ void __launch_bounds__(64, 2) k_pairing(PairArgs a) {
     }
     ident = aff_is_inf(p) || qz != 0;
     // wave-uniform control flow: identity items run the same arithmetic (total on zeros) and discard it
-    miller_loop(&f, to261(p.x), to261(p.y), &qx, &qy, a.fixed_lines ? a.fixed_lines + (size_t)i * a.lines_stride : nullptr);
+    miller_loop(&f, to261(p.x), to261(p.y), &qx, &qy, a.fixed_lines ? a.fixed_lines + (size_t)i * a.lines_stride : nullptr, park);
   } else {
     Fq2d* c = reinterpret_cast<Fq2d*>(&f);
 #pragma unroll 1
-    for (int k = 0; k < 6; k++) c[k].v = to261(a.f_in[(size_t)12 * i + 2 * k + lane_odd()]);
+    for (int k = 0; k < 6; k++) park_fq(park, k, to261(a.f_in[(size_t)12 * i + 2 * k + lane_odd()]));
+#pragma unroll
+    for (int k = 0; k < 6; k++) c[k].v = unpark_fq(park, k);
   }
-  if (a.mode & PAIR_FINAL_EXP) fe_run(&f, a.ws, a.ws_n, i);
+  if (a.mode & PAIR_FINAL_EXP) fe_run(&f, a.ws, a.ws_n, i, park);
   if (ident) fq12_set_one(&f);
   if (!live) return;
   if (a.mode & PAIR_OUT_BYTES) {
-    gt_serialize((u32*)a.out + (size_t)96 * i, &f);
+    gt_serialize((u32*)a.out + (size_t)96 * i, &f, park);
   } else {
     const Fq2d* c = reinterpret_cast<const Fq2d*>(&f);
     Fq* o = (Fq*)a.out + (size_t)12 * i;
+#pragma unroll
+    for (int k = 0; k < 6; k++) park_fq(park, k, c[k].v);
 #pragma unroll 1
-    for (int k = 0; k < 6; k++) o[2 * k + lane_odd()] = (a.mode & PAIR_OUT_RAW256) ? to256(c[k].v) : c[k].v;
+    for (int k = 0; k < 6; k++) {
+      const Fq v = unpark_fq(park, k);
+      o[2 * k + lane_odd()] = (a.mode & PAIR_OUT_RAW256) ? to256(v) : v;
+    }
   }
 }
 // the line sequence of a fixed Q (2^256 form in); every lane pair of the single wave computes the same values, pair 0's layout is the table
@@ -302,7 +333,7 @@ static __global__ void __launch_bounds__(64, 2) k_gt_table_fill(Fq* __restrict__
 // acc *= base^k from the signed-window table of `base` (k canonical, consumed): digits in (-2^(wb-1), 2^(wb-1)], a digit above the half
 // becomes d - 2^wb with a carry (2^wb itself: digit 0, carry 1); a negative digit multiplies by the conjugate (unitary: inverse = conjugate).
 // A zero digit multiplies by one: the product is never skipped per lane (the lane pairs of a wave hold different digits).
-static KTOWER void gt_table_exp(Fq12* acc, const Fq* __restrict__ tab, GtShape g, u32* k) {
+static KTOWER void gt_table_exp(Fq12* acc, const Fq* __restrict__ tab, GtShape g, u32* k, uint4* park) {
   u32 carry_d = 0;
   const u32 half = 1u << (g.wb - 1);
 #pragma unroll 1
@@ -328,7 +359,7 @@ static KTOWER void gt_table_exp(Fq12* acc, const Fq* __restrict__ tab, GtShape g
         if (h == 0) x.c0 = fq2d_one();
       }
       return x;
-    });
+    }, park);
   }
 }
 // gt_out[i] = serialize(A^(r_i) * B^(-(r_i * beta_i)))   (tables of A and B). Two lanes per item.
@@ -343,11 +374,12 @@ static __global__ void __launch_bounds__(64, 2) k_gt_encap_exp(const Fq* __restr
   u32 u[8], v[8];
   fp_from_mont<FrParams>(u, r);
   fp_from_mont<FrParams>(v, m);
+  __shared__ uint4 park[PARK_CHUNKS * 64];
   Fq12 acc;
   fq12_set_one(&acc);
-  gt_table_exp(&acc, tab_a, ga, u);
-  gt_table_exp(&acc, tab_b, gb, v);
-  if (live) gt_serialize(gt_out + (size_t)96 * i, &acc);
+  gt_table_exp(&acc, tab_a, ga, u, park);
+  gt_table_exp(&acc, tab_b, gb, v, park);
+  if (live) gt_serialize(gt_out + (size_t)96 * i, &acc, park);
 }
 
 // ---- BLAKE3 XOF of a 384-byte GT encoding (single chunk, 6 blocks): replaces src/kem.rs:42-46,65-69 ----
