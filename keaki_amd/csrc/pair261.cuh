@@ -82,9 +82,9 @@ KDEV Fq fq_select(bool c, const Fq& a, const Fq& b) {  // c ? a : b
 // ---- LDS parking ----------------------------------------------------------------------------------------------------------------
 // Values that are not needed while a big tower operation runs wait in LDS instead of in registers the operation wants (the compiler
 // would spill them to scratch -- and saves every live caller-saved register around each call of an Fq2 product). One 16-byte chunk per
-// lane and index: chunk c of lane l at park[c * 64 + l] (conflict-free). 16 chunks per lane: 16 KB per 64-lane workgroup, 8 per CU.
+// lane and index: chunk c of lane l at park[c * 64 + l] (conflict-free). 18 chunks per lane: 18 KB per 64-lane workgroup, 8 per CU.
 // Fq index i = chunks 2i, 2i + 1. Map: 0..5 = an Fq12 (or T of the Miller loop in 0..2 and temporaries in 3..5), 6..7 = Q of the Miller loop.
-constexpr int PARK_CHUNKS = 16;
+constexpr int PARK_CHUNKS = 18;
 KDEV void park_fq(uint4* park, int idx, const Fq& v) {
   const uint4* w = reinterpret_cast<const uint4*>(v.l);
   park[(2 * idx) * 64 + threadIdx.x] = w[0];
@@ -277,7 +277,7 @@ static KTOWER void fq12_mul(Fq12* r, const Fq12* a, const Fq12* b) {
 KDEV void park_fq6(uint4* park, int idx, const Fq6& v) { park_fq(park, idx, v.c0.v); park_fq(park, idx + 1, v.c1.v); park_fq(park, idx + 2, v.c2.v); }
 KDEV Fq6 unpark_fq6(const uint4* park, int idx) { return {{unpark_fq(park, idx)}, {unpark_fq(park, idx + 1)}, {unpark_fq(park, idx + 2)}}; }
 // `park` (may be null: then everything stays in registers): six Fq of LDS per lane (indices 0..5) for the first two partial products
-template <class LoadHalf>
+template <bool PARK = false, class LoadHalf>
 static KTOWER void fq12_mul_ld(Fq12* r, const Fq12* a, LoadHalf ld, uint4* park = nullptr) {
   Fq6 t0, t1, m;
   {
@@ -285,52 +285,76 @@ static KTOWER void fq12_mul_ld(Fq12* r, const Fq12* a, LoadHalf ld, uint4* park 
     const Fq6 s0 = a->c0 + a->c1, s1 = b0 + b1;
     fq6_mul(&m, &s0, &s1);
   }
-  if (park) park_fq6(park, 0, m);
+  if constexpr (PARK) park_fq6(park, 0, m);
   asm volatile("" ::: "memory");          // the halves are loaded again, not kept
   {
     const Fq6 b0 = ld(0);
     fq6_mul(&t0, &a->c0, &b0);
   }
-  if (park) park_fq6(park, 3, t0);
+  if constexpr (PARK) park_fq6(park, 3, t0);
   asm volatile("" ::: "memory");
   {
     const Fq6 b1 = ld(1);
     fq6_mul(&t1, &a->c1, &b1);
   }
-  if (park) { m = unpark_fq6(park, 0); t0 = unpark_fq6(park, 3); }
+  if constexpr (PARK) { m = unpark_fq6(park, 0); t0 = unpark_fq6(park, 3); }
   r->c1 = m - t0 - t1;
   r->c0 = t0 + fq6_mul_v(t1);
 }
 // complex squaring: a0 a1 and (a0 + a1)(a0 + v a1)
+template <bool PARK = false>
 static KTOWER void fq12_sqr(Fq12* r, const Fq12* a, uint4* park = nullptr, int pidx = 0) {
   Fq6 ab, t;
   {
     const Fq6 s0 = a->c0 + a->c1, s1 = a->c0 + fq6_mul_v(a->c1);
     fq6_mul(&t, &s0, &s1);
   }
-  if (park) park_fq6(park, pidx, t);
+  if constexpr (PARK) park_fq6(park, pidx, t);
   fq6_mul(&ab, &a->c0, &a->c1);
-  if (park) t = unpark_fq6(park, pidx);
+  if constexpr (PARK) t = unpark_fq6(park, pidx);
   r->c0 = t - ab - fq6_mul_v(ab);
   r->c1 = ab + ab;
 }
+template <bool PARK = false>
 static KTOWER void fq12_inv(Fq12* r, const Fq12* a, uint4* park = nullptr) {
-  Fq6 n0, n1, ni, r0, r1;
-  fq6_mul(&n0, &a->c0, &a->c0);
-  fq6_mul(&n1, &a->c1, &a->c1);
-  Fq6 n = n0 - fq6_mul_v(n1);
-  Fq6 a0 = a->c0, a1 = a->c1;
-  if (park) { park_fq6(park, 0, a0); park_fq6(park, 3, a1); }        // the Fq6 inversion is a chain of function calls
-  fq6_inv(&ni, &n);
-  if (park) a0 = unpark_fq6(park, 0);
-  fq6_mul(&r0, &a0, &ni);
-  if (park) { park_fq6(park, 0, r0); a1 = unpark_fq6(park, 3); }
-  fq6_mul(&r1, &a1, &ni);
-  if (park) r0 = unpark_fq6(park, 0);
-  r->c0 = r0;
+  if constexpr (!PARK) {
+    Fq6 n0, n1, ni, r0, r1;
+    fq6_mul(&n0, &a->c0, &a->c0);
+    fq6_mul(&n1, &a->c1, &a->c1);
+    Fq6 n = n0 - fq6_mul_v(n1);
+    fq6_inv(&ni, &n);
+    fq6_mul(&r0, &a->c0, &ni);
+    fq6_mul(&r1, &a->c1, &ni);
+    r->c0 = r0;
+    r->c1 = fq6_neg(r1);
+  } else {
+  // with LDS: a waits in indices 0..5, its halves visit registers one at a time; n0 in 6..8
+#define PARK_FENCE() asm volatile("" ::: "memory")      /* keeps the scheduler from hoisting an LDS read (and with it a live range) over a big block */
+  park_fq6(park, 0, a->c0); park_fq6(park, 3, a->c1);
+  Fq6 n;
+  {
+    Fq6 n0, n1;
+    PARK_FENCE();
+    { const Fq6 a0 = unpark_fq6(park, 0); fq6_mul(&n0, &a0, &a0); }
+    park_fq6(park, 6, n0);
+    PARK_FENCE();
+    { const Fq6 a1 = unpark_fq6(park, 3); fq6_mul(&n1, &a1, &a1); }
+    PARK_FENCE();
+    n0 = unpark_fq6(park, 6);
+    n = n0 - fq6_mul_v(n1);
+  }
+  Fq6 ni, r0, r1;
+  fq6_inv(&ni, &n);                       // a chain of function calls
+  PARK_FENCE();
+  { const Fq6 a0 = unpark_fq6(park, 0); fq6_mul(&r0, &a0, &ni); }
+  park_fq6(park, 0, r0);
+  PARK_FENCE();
+  { const Fq6 a1 = unpark_fq6(park, 3); fq6_mul(&r1, &a1, &ni); }
+  PARK_FENCE();
+  r->c0 = unpark_fq6(park, 0);
   r->c1 = fq6_neg(r1);
+  }
 }
-// x -> x^(p^k), k = 1, 2, 3
 // the same with the element parked in LDS (indices 0..5) while the six Fq2 products (function calls) run: nothing big is alive across a call
 static KTOWER void fq12_frob_parked(Fq12* r, const Fq12* a, int k, uint4* park) {
   const Fq2d* c = reinterpret_cast<const Fq2d*>(a);          // memory order: c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2
@@ -373,16 +397,17 @@ KDEV void fq4_sqr(Fq2d* t0, Fq2d* t1, const Fq2d& x, const Fq2d& y) {
   t0->v = pack(dot2(xx, yx, xxy, yy));
   t1->v = pack(dot1(x2, yy));
 }
+template <bool PARK = false>
 static KTOWER void fq12_cyc_sqr(Fq12* r, const Fq12* a, uint4* park = nullptr) {
   Fq2d r0 = a->c0.c0, r4 = a->c0.c1, r3 = a->c0.c2, r2 = a->c1.c0, r1 = a->c1.c1, r5 = a->c1.c2;
   Fq2d t0, t1, t2, t3, t4, t5;
-  if (park) { park_fq(park, 0, r0.v); park_fq(park, 1, r1.v); park_fq(park, 2, r2.v); park_fq(park, 3, r3.v); }
+  if constexpr (PARK) { park_fq(park, 0, r0.v); park_fq(park, 1, r1.v); park_fq(park, 2, r2.v); park_fq(park, 3, r3.v); }
   fq4_sqr(&t4, &t5, r4, r5);
-  if (park) { park_fq(park, 4, r4.v); park_fq(park, 5, r5.v); r2.v = unpark_fq(park, 2); r3.v = unpark_fq(park, 3); }
+  if constexpr (PARK) { park_fq(park, 4, r4.v); park_fq(park, 5, r5.v); r2.v = unpark_fq(park, 2); r3.v = unpark_fq(park, 3); }
   fq4_sqr(&t2, &t3, r2, r3);
-  if (park) { r0.v = unpark_fq(park, 0); r1.v = unpark_fq(park, 1); }
+  if constexpr (PARK) { r0.v = unpark_fq(park, 0); r1.v = unpark_fq(park, 1); }
   fq4_sqr(&t0, &t1, r0, r1);
-  if (park) { r2.v = unpark_fq(park, 2); r3.v = unpark_fq(park, 3); r4.v = unpark_fq(park, 4); r5.v = unpark_fq(park, 5); }
+  if constexpr (PARK) { r2.v = unpark_fq(park, 2); r3.v = unpark_fq(park, 3); r4.v = unpark_fq(park, 4); r5.v = unpark_fq(park, 5); }
   Fq2d x5 = fq2_mul_xi(t5);
   r->c0.c0 = fq2_dbl(t0 - r0) + t0;
   r->c1.c1 = fq2_dbl(t1 + r1) + t1;
@@ -399,6 +424,7 @@ static KTOWER void fq12_cyc_sqr(Fq12* r, const Fq12* a, uint4* park = nullptr) {
 // six streams of six Fq products; the multiplications by xi sit on the line's side (two per line instead of one per product).
 // The line's coefficients arrive as LIMBS of this lane's component: c0, d0 exact and < 2p (outputs of the products by P's coordinates),
 // d1 exact and < p. Bounds: f's coefficients 1; terms c0: 2 + 2, d0: 2 + 2, d1: 1 + 2, xi d1 (< 11p, negated 16p): 27, xi d0 (< 22p, 32p): 54.
+template <bool PARK = false>
 static KTOWER void fq12_mul_by_034_limbs(Fq12* f, U29 c0, U29 d0, const U29& d1, bool fence_c0_d0, uint4* park = nullptr, int pidx = 0) {
   if (fence_c0_d0) { fence9(c0); fence9(d0); }
   const U29 c0o = quad<0xB1>(c0), d0o = quad<0xB1>(d0), d1o = quad<0xB1>(d1);
@@ -410,11 +436,11 @@ static KTOWER void fq12_mul_by_034_limbs(Fq12* f, U29 c0, U29 d0, const U29& d1,
   const Fq r00 = pack(dot3(a0, yc0, e1, yxd1, e2, yxd0));
   const Fq r01 = pack(dot3(a1, yc0, e0, yd0, e2, yxd1));
   const Fq r02 = pack(dot3(a2, yc0, e0, yd1, e1, yd0));
-  if (park) { park_fq(park, pidx, r00); park_fq(park, pidx + 1, r01); park_fq(park, pidx + 2, r02); }
+  if constexpr (PARK) { park_fq(park, pidx, r00); park_fq(park, pidx + 1, r01); park_fq(park, pidx + 2, r02); }
   const Fq r10 = pack(dot3(e0, yc0, a0, yd0, a2, yxd1));
   const Fq r11 = pack(dot3(e1, yc0, a0, yd1, a1, yd0));
   const Fq r12 = pack(dot3(e2, yc0, a1, yd1, a2, yd0));
-  if (park) { f->c0.c0.v = unpark_fq(park, pidx); f->c0.c1.v = unpark_fq(park, pidx + 1); f->c0.c2.v = unpark_fq(park, pidx + 2); }
+  if constexpr (PARK) { f->c0.c0.v = unpark_fq(park, pidx); f->c0.c1.v = unpark_fq(park, pidx + 1); f->c0.c2.v = unpark_fq(park, pidx + 2); }
   else { f->c0.c0.v = r00; f->c0.c1.v = r01; f->c0.c2.v = r02; }
   f->c1.c0.v = r10; f->c1.c1.v = r11; f->c1.c2.v = r12;
 }

@@ -57,29 +57,30 @@ static KTOWER void line_add(G2Hom* r, const Fq2d* qx, const Fq2d* qy, Line* l) {
 // f *= l(P): the two products by P's coordinates leave the streams as limbs and go straight into the line product
 KDEV void ell(Fq12* f, const Line* l, const U29& px, const U29& py, uint4* park, int pidx) {
   const U29 c0 = u29_mul(cut(l->c0.v), py), d0 = u29_mul(cut(l->c1.v), px);
-  fq12_mul_by_034_limbs(f, c0, d0, cut(l->c2.v), true, park, pidx);
+  fq12_mul_by_034_limbs<true>(f, c0, d0, cut(l->c2.v), true, park, pidx);
 }
 
 // Line table of a fixed Q (ark-ec's G2Prepared), per lane parity: lines[li * 2 + parity], li = index into MILLER_STEPS. 2^261 form.
 constexpr int MILLER_MAX_LINES = 96;
 static_assert(MILLER_NSTEPS <= MILLER_MAX_LINES, "line table too small");
 
-// lines == nullptr: compute the lines on the fly from (qx, qy). P = (px, py) in the 2^261 form.
+// lines == nullptr: compute the lines on the fly from Q (`qw`: its four coordinates in the 2^256 form, this lane's components at [par] and [2 + par]).
+// P = (px, py) in the 2^261 form.
 // Register choreography through LDS (`park`, Fq indices): while f is squared and multiplied by the line, the running point T waits in
-// 0..2 and Q in 6..7, and the two big operations use 3..5 for their own temporaries; while the line function runs (a chain of CALLS of the Fq2
-// product, around each of which every live caller-saved register would be saved), f waits in 0..5 and T visits registers.
-static KTOWER void miller_loop(Fq12* f, const Fq& px, const Fq& py, const Fq2d* qx, const Fq2d* qy, const Line* __restrict__ lines, uint4* park) {
+// 0..2 and P in 6..7, and the two big operations use 3..5 for their own temporaries; while the line function runs (a chain of CALLS of the Fq2
+// product, around each of which every live caller-saved register would be saved), f waits in 0..5 and T visits registers. Q is only
+// needed by the 24 addition steps: it is read again from global memory there (two conversions, 0.5 % of the loop).
+static KTOWER void miller_loop(Fq12* f, const Fq& px, const Fq& py, const Fq* __restrict__ qw, const Line* __restrict__ lines, uint4* park) {
   const u32 par = lane_odd();
   fq12_set_one(f);
   if (!lines) {
-    park_fq(park, 0, qx->v); park_fq(park, 1, qy->v); park_fq(park, 2, fq2d_one().v);     // T = (Q.x, Q.y, 1)
-    park_fq(park, 6, qx->v); park_fq(park, 7, qy->v);
+    park_fq(park, 0, to261(qw[par])); park_fq(park, 1, to261(qw[2 + par])); park_fq(park, 2, fq2d_one().v);     // T = (Q.x, Q.y, 1)
   }
-  const U29 pxl = cut(px), pyl = cut(py);
+  park_fq(park, 6, px); park_fq(park, 7, py);
 #pragma unroll 1
   for (int li = 0; li < MILLER_NSTEPS; li++) {
     const int st = MILLER_STEPS[li];
-    if (st == 1) fq12_sqr(f, f, park, 3);
+    if (st == 1) fq12_sqr<true>(f, f, park, 3);
     Line l;
     if (lines) {
       l = lines[li * 2 + par];
@@ -94,7 +95,7 @@ static KTOWER void miller_loop(Fq12* f, const Fq& px, const Fq& py, const Fq2d* 
         line_double(&r, &l);
       } else {
         // Q, -Q, pi(Q), -pi^2(Q)
-        Fq2d ax = {unpark_fq(park, 6)}, ay = {unpark_fq(park, 7)};
+        Fq2d ax = {to261(qw[par])}, ay = {to261(qw[2 + par])};
         if (st == 3) ay = fq2_neg(ay);
         if (st >= 4) {
           ax = M2(fq2_conj(ax), fq2d_load(&p261::TWIST_MUL_BY_Q_X)); ay = M2(fq2_conj(ay), fq2d_load(&p261::TWIST_MUL_BY_Q_Y));
@@ -109,7 +110,7 @@ static KTOWER void miller_loop(Fq12* f, const Fq& px, const Fq& py, const Fq2d* 
       }
       park_fq(park, 0, r.x.v); park_fq(park, 1, r.y.v); park_fq(park, 2, r.z.v);
     }
-    ell(f, &l, pxl, pyl, park, 3);
+    ell(f, &l, cut(unpark_fq(park, 6)), cut(unpark_fq(park, 7)), park, 3);
   }
 }
 // the line sequence alone (k_g2_prepare)
@@ -159,11 +160,11 @@ static KTOWER void fe_run(Fq12* acc, Fq* __restrict__ ws, size_t ws_n, u32 item,
     } else if (code == 1) {
       slot_store(ws, ws_n, s, item, acc);
     } else if (code == 2) {
-      fq12_cyc_sqr(acc, acc, park);
+      fq12_cyc_sqr<true>(acc, acc, park);
     } else if (code == 3 || code == 4) {
       const u32 par = lane_odd();
       const bool cj = code == 4;                  // multiply by the conjugate: the second half negated
-      fq12_mul_ld(acc, acc, [&](int h) {
+      fq12_mul_ld<true>(acc, acc, [&](int h) {
         Fq6 x;
         Fq2d* c = reinterpret_cast<Fq2d*>(&x);
 #pragma unroll
@@ -176,7 +177,7 @@ static KTOWER void fe_run(Fq12* acc, Fq* __restrict__ ws, size_t ws_n, u32 item,
     } else if (code == 6) {
       fq12_frob_parked(acc, acc, (int)s, park);
     } else {
-      fq12_inv(acc, acc, park);
+      fq12_inv<true>(acc, acc, park);
     }
   }
 }
@@ -231,21 +232,17 @@ static __global__ void __launch_bounds__(64, 2) k_pairing(PairArgs a) {
   bool ident = false;
   if (a.mode & PAIR_MILLER) {
     const G1Aff p = a.ps[i];
-    Fq2d qx = fq2d_zero(), qy = fq2d_zero();
+    const Fq* qw = nullptr;
     u32 qz = 0;
     if (!a.fixed_lines) {
-      const G2Aff* q = a.qs + (size_t)i * a.q_stride;
-      const Fq* qxw = reinterpret_cast<const Fq*>(&q->x);
-      const Fq* qyw = reinterpret_cast<const Fq*>(&q->y);
-      const Fq rx = qxw[lane_odd()], ry = qyw[lane_odd()];
+      qw = reinterpret_cast<const Fq*>(a.qs + (size_t)i * a.q_stride);          // (x.c0, x.c1, y.c0, y.c1)
       // identity in the second slot: all four components zero; both lanes of the pair must agree
-      qz = (fq_is_zero(rx) && fq_is_zero(ry)) ? 1u : 0u;
+      qz = (fq_is_zero(qw[lane_odd()]) && fq_is_zero(qw[2 + lane_odd()])) ? 1u : 0u;
       qz &= (u32)__builtin_amdgcn_update_dpp(0, (int)qz, 0xB1, 0xF, 0xF, true);
-      qx.v = to261(rx); qy.v = to261(ry);
     }
     ident = aff_is_inf(p) || qz != 0;
     // wave-uniform control flow: identity items run the same arithmetic (total on zeros) and discard it
-    miller_loop(&f, to261(p.x), to261(p.y), &qx, &qy, a.fixed_lines ? a.fixed_lines + (size_t)i * a.lines_stride : nullptr, park);
+    miller_loop(&f, to261(p.x), to261(p.y), qw, a.fixed_lines ? a.fixed_lines + (size_t)i * a.lines_stride : nullptr, park);
   } else {
     Fq2d* c = reinterpret_cast<Fq2d*>(&f);
 #pragma unroll 1
@@ -347,7 +344,7 @@ static KTOWER void gt_table_exp(Fq12* acc, const Fq* __restrict__ tab, GtShape g
     if (neg) d = 2u * half - d;
     const Fq* src = tab + ((size_t)j * g.entries + d) * 12;
     const u32 par = lane_odd();
-    fq12_mul_ld(acc, acc, [&](int h) {
+    fq12_mul_ld<true>(acc, acc, [&](int h) {
       Fq6 x;
       Fq2d* c = reinterpret_cast<Fq2d*>(&x);
       if (d) {
