@@ -3,6 +3,9 @@
 // the CPU here and there is no CPU fallback: without a gfx950 device every entry point fails.
 #include "internal.h"
 
+#include <algorithm>
+#include <utility>
+
 using namespace keaki_internal;
 
 struct keaki_hip_srs_g1 {
@@ -673,6 +676,90 @@ keaki_status keaki_hip_fr_fft(keaki_hip_ctx* ctx, uint64_t* data, uint32_t log2n
   HIP_TRY(ctx, hipMemcpyAsync(b, data, n * 32, hipMemcpyHostToDevice, ctx->stream));
   ST_TRY(fr_fft_run(ctx, b, log2n, omega, scale_or_null, b + n * 32));
   return download(ctx, data, b, n * 32);
+}
+
+// ---- FK23 sharded over `world` = 2^k ranks: one handle per rank, the caller runs the exchanges between the steps -----------------
+struct keaki_hip_fk_shard {
+  FkShard plan;
+  const keaki_hip_srs_g1* srs = nullptr;
+  uint32_t world = 0;
+};
+namespace {
+size_t fk_shard_buffer_bytes(const keaki_hip_fk_shard* fk) {
+  const size_t d = (size_t)1 << fk->plan.log2d;
+  return std::max(2 * d / fk->world * 96, d * 64);
+}
+void fk_shard_release(keaki_hip_fk_shard* fk) {
+  for (void** p : {&fk->plan.tw, &fk->plan.twi, &fk->plan.hat_a, &fk->plan.coeffs, &fk->plan.hat_s, &fk->plan.work})
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+}
+}  // namespace
+keaki_status keaki_hip_fk_shard_create(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, uint32_t log2d, uint32_t rank, uint32_t world,
+                                       const uint64_t* omega_2d, const uint64_t* omega_2d_inv, const uint64_t* inv_2d, keaki_hip_fk_shard** out) {
+  CTX_GUARD(ctx);
+  if (!srs || !omega_2d || !omega_2d_inv || !inv_2d || !out || log2d > 27) return fail(ctx, KEAKI_ERR_BAD_ARG, "fk_shard_create: bad argument");
+  *out = nullptr;
+  if (world < 2 || (world & (world - 1)) || rank >= world) return fail(ctx, KEAKI_ERR_BAD_ARG, "fk_shard_create: world = %u must be a power of two >= 2, rank %u below it", world, rank);
+  const size_t d = (size_t)1 << log2d;
+  if (d < (size_t)world * world)
+    return fail(ctx, KEAKI_ERR_BAD_ARG, "fk_shard_create: %zu openings are too few to shard over %u ranks (needs world^2); use keaki_hip_open_fk_poly", d, world);
+  if (d > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "open_fk: %zu coefficients but the SRS holds %zu points", d, srs->n);
+  auto* fk = new keaki_hip_fk_shard();
+  fk->srs = srs;
+  fk->world = world;
+  fk->plan.log2d = log2d;
+  fk->plan.rank = rank;
+  while ((1u << fk->plan.rho) < world) fk->plan.rho++;
+  memcpy(fk->plan.omega, omega_2d, 32); memcpy(fk->plan.omega_inv, omega_2d_inv, 32); memcpy(fk->plan.inv_2d, inv_2d, 32);
+  const size_t m = 2 * d / world;
+  keaki_status st = KEAKI_OK;
+  const std::pair<void**, size_t> want[] = {{&fk->plan.tw, d * 32}, {&fk->plan.twi, d * 32}, {&fk->plan.hat_a, 2 * d * 32}, {&fk->plan.coeffs, d * 32},
+                                            {&fk->plan.hat_s, m * 96}, {&fk->plan.work, m * 96}};
+  for (auto& w : want)
+    if (st == KEAKI_OK) st = dev_alloc(ctx, w.first, w.second);
+  if (st != KEAKI_OK) { fk_shard_release(fk); delete fk; return st; }
+  *out = fk;
+  return KEAKI_OK;
+}
+void keaki_hip_fk_shard_free(keaki_hip_ctx* ctx, keaki_hip_fk_shard* fk) {
+  if (!fk) return;
+  if (ctx) {
+    std::lock_guard<std::recursive_mutex> lock_(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    fk_shard_release(fk);
+  }
+  delete fk;
+}
+keaki_status keaki_hip_fk_shard_sizes(const keaki_hip_fk_shard* fk, size_t* out4) {
+  if (!fk || !out4) return KEAKI_ERR_BAD_ARG;
+  const size_t d = (size_t)1 << fk->plan.log2d, R = fk->world;
+  out4[0] = fk_shard_buffer_bytes(fk);
+  out4[1] = 2 * d / R / R * 96;      // all-to-all of the 2d-point transforms: bytes per peer
+  out4[2] = d / R / R * 96;          // all-to-all of the d-point transform
+  out4[3] = d / R * 64;              // all-gather of the affine proofs: bytes per rank
+  return KEAKI_OK;
+}
+keaki_status keaki_hip_fk_shard_setup(keaki_hip_ctx* ctx, keaki_hip_fk_shard* fk, int32_t step, void* d_send, void* d_recv) {
+  CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.fk_shard_setup");
+  if (!fk || step < 0 || step > 1 || (step == 0 && !d_send) || (step == 1 && !d_recv)) return fail(ctx, KEAKI_ERR_BAD_ARG, "fk_shard_setup: bad argument");
+  return fk_shard_setup_run(ctx, fk->plan, fk->srs->d, step, d_send, d_recv);
+}
+keaki_status keaki_hip_fk_shard_open(keaki_hip_ctx* ctx, keaki_hip_fk_shard* fk, int32_t step, const uint64_t* coeffs, void* d_send, void* d_recv,
+                                     uint64_t* proofs_out_aff) {
+  CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.fk_shard_open");
+  if (!fk || step < 0 || step > 3) return fail(ctx, KEAKI_ERR_BAD_ARG, "fk_shard_open: bad argument");
+  if (!fk->plan.hat_s_ready) return fail(ctx, KEAKI_ERR_BAD_ARG, "fk_shard_open: keaki_hip_fk_shard_setup steps 0 and 1 have not run");
+  const size_t d = (size_t)1 << fk->plan.log2d;
+  if ((step == 0 && (!coeffs || !d_send)) || (step == 1 && (!d_send || !d_recv)) || (step == 2 && (!d_send || !d_recv)) || (step == 3 && (!d_recv || !proofs_out_aff)))
+    return fail(ctx, KEAKI_ERR_BAD_ARG, "fk_shard_open: step %d is missing a buffer", step);
+  if (step == 0) HIP_TRY(ctx, hipMemcpyAsync(fk->plan.coeffs, coeffs, d * 32, hipMemcpyHostToDevice, ctx->stream));
+  if (step < 3) return fk_shard_open_run(ctx, fk->plan, step, d_send, d_recv, nullptr);
+  ST_TRY(reserve(ctx, ctx->io_d, d * 64));
+  ST_TRY(fk_shard_open_run(ctx, fk->plan, 3, nullptr, d_recv, ctx->io_d.p));
+  return download(ctx, proofs_out_aff, ctx->io_d.p, d * 64);
 }
 
 // ---- test hook: line table of a fixed Q (MILLER_MAX_LINES x 2 parities x 3 Fq, Montgomery)

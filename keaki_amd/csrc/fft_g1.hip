@@ -66,6 +66,70 @@ static __global__ void __launch_bounds__(64) k_g1_jac_to_aff(const G1Jac* __rest
   out[i] = jac_to_aff(a[i]);
 }
 
+// ---- FK23 sharded over R = 2^rho ranks (keaki_hip_fk_shard_*; index maps modelled in tests/fk_shard_model.py) ---------------------
+// A transform of N = R * M points never exists in one memory. Two layouts of the N positions over the ranks:
+//   cyclic: rank r holds position i = k R + r at local index k     (the HIGH log2 M bits of a position are local)
+//   block:  rank r holds position i = r M + k at local index k     (the LOW  log2 M bits are local)
+// A radix-2 stage of span `len` pairs positions that differ in bit log2(len) - 1, so spans 2R..N run on the cyclic layout, spans 2..M
+// on the block layout, and ONE all-to-all (the caller's: RCCL over xGMI) switches between them. Forward transforms run
+// decimation-in-frequency (natural order in, bit-reversed positions out: cyclic -> block), the inverse one decimation-in-time
+// (bit-reversed in, natural out: block -> cyclic), so no bit-reversal permutation -- which would be a second all-to-all -- is needed
+// anywhere but on the d affine proofs at the very end.
+// One stage over a LOCAL array of m points: local span 2 * half; the butterfly at local offset j takes the twiddle tw[(j A + B) stride]
+// ((A, B) = (R, rank) on the cyclic layout, (1, 0) on the block layout). Lane order as k_g1_fft_stage: a wave shares one twiddle
+// while the stage has at least 64 blocks.
+template <bool DIT>
+static __global__ void __launch_bounds__(64) k_g1_fft_stage_map(G1Jac* __restrict__ a, const Fr* __restrict__ tw, u32 m, u32 half, u32 A, u32 B, u32 stride) {
+  u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= m / 2) return;
+  const u32 nblocks = m / (2 * half);
+  u32 j, blk;
+  if (nblocks >= 64) { blk = b % nblocks; j = b / nblocks; }
+  else { j = b % half; blk = b / half; }
+  const u32 i0 = blk * 2 * half + j, i1 = i0 + half;
+  Fr w = tw[((size_t)j * A + B) * stride];
+  G1Jac u = a[i0], v = a[i1];
+  if (DIT) {
+    if (!fr_is_one(w)) v = jac_scalar_mul(v, w);
+    a[i0] = jac_add(u, v);
+    v.y = -v.y;
+    a[i1] = jac_add(u, v);
+  } else {
+    a[i0] = jac_add(u, v);
+    v.y = -v.y;
+    G1Jac t = jac_add(u, v);
+    if (!fr_is_one(w)) t = jac_scalar_mul(t, w);
+    a[i1] = t;
+  }
+}
+// reversed SRS padded with identities, the cyclic slice of rank r: out[k] = S[k R + r]
+static __global__ void __launch_bounds__(256) k_fk_load_cyclic(const G1Aff* __restrict__ srs, u32 d, u32 R, u32 r, u32 m, G1Jac* __restrict__ out) {
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m) return;
+  const u32 i = k * R + r;
+  out[k] = i < d ? jac_from_aff(srs[d - 1 - i]) : jac_inf<Fq>();
+}
+// out[c * rows + r] = in[r * cols + c]: the local half of a layout switch (the other half is the all-to-all)
+static __global__ void __launch_bounds__(256) k_jac_transpose(const G1Jac* __restrict__ in, u32 rows, u32 cols, G1Jac* __restrict__ out) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const u32 r = i / cols, c = i % cols;
+  out[(size_t)c * rows + r] = in[i];
+}
+// out[k] = hat_a[bitrev(base + k)] * hat_s[k]: hat_s is held at bit-reversed positions, hat_a in natural order
+static __global__ void __launch_bounds__(64) k_g1_mul_jac_brev(const G1Jac* __restrict__ in, const Fr* __restrict__ s, u32 log2n, u32 base, u32 m,
+                                                               G1Jac* __restrict__ out) {
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m) return;
+  out[k] = jac_scalar_mul(in[k], s[__brev(base + k) >> (32 - log2n)]);
+}
+// proofs[bitrev(q)] = gathered[q]
+static __global__ void __launch_bounds__(256) k_aff_unscramble(const G1Aff* __restrict__ in, u32 log2d, G1Aff* __restrict__ out) {
+  u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (1u << log2d)) return;
+  out[log2d ? (__brev(q) >> (32 - log2d)) : 0u] = in[q];
+}
+
 
 // ---- scalar-field (Fr) FFT on the device: row f-4 (the host-side ark-poly work of src/kzg.rs:182-185 and src/vec.rs:36-37) --------
 KDEV Fr fr_mul(const Fr& a, const Fr& b) { return fp_mul<FrParams>(a, b); }
@@ -243,6 +307,79 @@ keaki_status open_fk_poly_run(keaki_hip_ctx* ctx, const void* d_srs, void** hat_
     *hat_s_log2d = (int)log2d;
   }
   return open_fk_run(ctx, *hat_s_cache, log2d, hat_a, twi, twd, d_g_work, d_proofs_aff);
+}
+
+// ---- FK23 sharded (keaki_hip_fk_shard_*): the steps between the caller's exchanges ------------------------------------------------
+static void stage_map(keaki_hip_ctx* ctx, bool dit, G1Jac* a, const Fr* tw, u32 m, u32 half, u32 A, u32 B, u32 stride) {
+  if (dit) hipLaunchKernelGGL(k_g1_fft_stage_map<true>, dim3(cdiv(m / 2, 64)), dim3(64), 0, ctx->stream, a, tw, m, half, A, B, stride);
+  else hipLaunchKernelGGL(k_g1_fft_stage_map<false>, dim3(cdiv(m / 2, 64)), dim3(64), 0, ctx->stream, a, tw, m, half, A, B, stride);
+}
+static void fk_shard_tables(keaki_hip_ctx* ctx, FkShard& fk) {
+  if (fk.tables_ready) return;
+  const u32 d = 1u << fk.log2d;
+  Fr w, wi;
+  memcpy(&w, fk.omega, 32); memcpy(&wi, fk.omega_inv, 32);
+  hipLaunchKernelGGL(k_fr_powers, dim3(cdiv(d, 256)), dim3(256), 0, ctx->stream, w, d, (Fr*)fk.tw);
+  hipLaunchKernelGGL(k_fr_powers, dim3(cdiv(d, 256)), dim3(256), 0, ctx->stream, wi, d, (Fr*)fk.twi);
+  fk.tables_ready = true;
+}
+// hat_s of this rank. step 0: cyclic slice of the reversed SRS, spans N..2R -> d_send (chunk for rank q = [q M/R, (q+1) M/R));
+// step 1: d_recv (chunk from rank q at q M/R) -> block layout, spans R..2 -> fk.hat_s.
+keaki_status fk_shard_setup_run(keaki_hip_ctx* ctx, FkShard& fk, const void* d_srs, int step, void* d_send, void* d_recv) {
+  const u32 d = 1u << fk.log2d, N = 2 * d, R = 1u << fk.rho, M = N / R, r = fk.rank;
+  hipStream_t st = ctx->stream;
+  const Fr* tw = (const Fr*)fk.tw;
+  if (step == 0) {
+    fk_shard_tables(ctx, fk);
+    G1Jac* a = (G1Jac*)d_send;
+    hipLaunchKernelGGL(k_fk_load_cyclic, dim3(cdiv(M, 256)), dim3(256), 0, st, (const G1Aff*)d_srs, d, R, r, M, a);
+    for (u32 half = M / 2; half >= 1; half >>= 1) stage_map(ctx, false, a, tw, M, half, R, r, N / (2 * half * R));
+    return launch_check(ctx, "fk_shard_setup 0");
+  }
+  G1Jac* a = (G1Jac*)fk.hat_s;
+  hipLaunchKernelGGL(k_jac_transpose, dim3(cdiv(M, 256)), dim3(256), 0, st, (const G1Jac*)d_recv, R, M / R, a);
+  for (u32 half = R / 2; half >= 1; half >>= 1) stage_map(ctx, false, a, tw, M, half, 1, 0, N / (2 * half));
+  fk.hat_s_ready = true;
+  return launch_check(ctx, "fk_shard_setup 1");
+}
+// the openings. step 0: hat_a (replicated scalar-field work), hat_a * hat_s, inverse transform spans 2..M (block) -> d_send packed for the
+// switch to cyclic; step 1: d_recv = cyclic layout, spans 2M..N, h = first half, DFT_d spans d..2R -> d_send; step 2: d_recv -> block layout,
+// spans R..2, to affine -> d_send (d/R affine points: positions [rank d/R, ..) of the bit-reversed proof order);
+// step 3: d_recv = all d affine points in position order -> d_out_aff in natural order.
+keaki_status fk_shard_open_run(keaki_hip_ctx* ctx, FkShard& fk, int step, void* d_send, void* d_recv, void* d_out_aff) {
+  const u32 d = 1u << fk.log2d, N = 2 * d, R = 1u << fk.rho, M = N / R, Md = d / R, r = fk.rank;
+  hipStream_t st = ctx->stream;
+  const Fr *tw = (const Fr*)fk.tw, *twi = (const Fr*)fk.twi;
+  if (step == 0) {
+    Fr s;
+    memcpy(&s, fk.inv_2d, 32);
+    Fr* hat_a = (Fr*)fk.hat_a;
+    hipLaunchKernelGGL(k_fk_pad, dim3(cdiv(N, 256)), dim3(256), 0, st, (const Fr*)fk.coeffs, d, hat_a);
+    ST_TRY(fr_fft(ctx, hat_a, fk.log2d + 1, tw, 1));
+    hipLaunchKernelGGL(k_fr_scale, dim3(cdiv(N, 256)), dim3(256), 0, st, hat_a, s, N);
+    G1Jac* a = (G1Jac*)fk.work;
+    hipLaunchKernelGGL(k_g1_mul_jac_brev, dim3(cdiv(M, 64)), dim3(64), 0, st, (const G1Jac*)fk.hat_s, (const Fr*)hat_a, fk.log2d + 1, r * M, M, a);
+    for (u32 half = 1; 2 * half <= M; half <<= 1) stage_map(ctx, true, a, twi, M, half, 1, 0, N / (2 * half));
+    hipLaunchKernelGGL(k_jac_transpose, dim3(cdiv(M, 256)), dim3(256), 0, st, (const G1Jac*)a, M / R, R, (G1Jac*)d_send);
+    return launch_check(ctx, "fk_shard_open 0");
+  }
+  if (step == 1) {
+    G1Jac* a = (G1Jac*)d_recv;
+    for (u32 half = M / R; 2 * half <= M; half <<= 1) stage_map(ctx, true, a, twi, M, half, R, r, N / (2 * half * R));
+    G1Jac* h = (G1Jac*)d_send;
+    HIP_TRY(ctx, hipMemcpyAsync(h, a, (size_t)Md * sizeof(G1Jac), hipMemcpyDeviceToDevice, st));
+    for (u32 half = Md / 2; half >= 1; half >>= 1) stage_map(ctx, false, h, tw, Md, half, R, r, 2 * (d / (2 * half * R)));
+    return launch_check(ctx, "fk_shard_open 1");
+  }
+  if (step == 2) {
+    G1Jac* a = (G1Jac*)fk.work;
+    hipLaunchKernelGGL(k_jac_transpose, dim3(cdiv(Md, 256)), dim3(256), 0, st, (const G1Jac*)d_recv, R, Md / R, a);
+    for (u32 half = R / 2; half >= 1; half >>= 1) stage_map(ctx, false, a, tw, Md, half, 1, 0, 2 * (d / (2 * half)));
+    hipLaunchKernelGGL(k_g1_jac_to_aff, dim3(cdiv(Md, 64)), dim3(64), 0, st, (const G1Jac*)a, Md, (G1Aff*)d_send);
+    return launch_check(ctx, "fk_shard_open 2");
+  }
+  hipLaunchKernelGGL(k_aff_unscramble, dim3(cdiv(d, 256)), dim3(256), 0, st, (const G1Aff*)d_recv, fk.log2d, (G1Aff*)d_out_aff);
+  return launch_check(ctx, "fk_shard_open 3");
 }
 
 // hat_s = DFT_2d(reversed SRS) ahead of time (it depends on the SRS and d only): setup-time work like the MSM window tables

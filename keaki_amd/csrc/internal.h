@@ -128,6 +128,17 @@ keaki_status fk_precompute_run(keaki_hip_ctx* ctx, const void* d_srs, void** hat
 keaki_status fk_hat_s_run(keaki_hip_ctx* ctx, const void* d_srs, uint32_t log2d, const void* d_tw2d, void* d_hat_s);
 keaki_status open_fk_run(keaki_hip_ctx* ctx, const void* d_hat_s, uint32_t log2d, const void* d_hat_a, const void* d_tw2d_inv, const void* d_twd,
                          void* d_work, void* d_proofs_aff);
+// FK23 sharded over 2^rho ranks (fft_g1.hip): this rank's plan and device buffers (owned by the api layer)
+struct FkShard {
+  uint32_t log2d = 0, rho = 0, rank = 0;
+  uint64_t omega[4], omega_inv[4], inv_2d[4];
+  void *tw = nullptr, *twi = nullptr;     // omega_2d^k, omega_2d^-k, k < d
+  void *hat_a = nullptr, *coeffs = nullptr;   // 2d Fr, d Fr
+  void *hat_s = nullptr, *work = nullptr;     // 2d / R Jacobian points each
+  bool tables_ready = false, hat_s_ready = false;
+};
+keaki_status fk_shard_setup_run(keaki_hip_ctx* ctx, FkShard& fk, const void* d_srs, int step, void* d_send, void* d_recv);
+keaki_status fk_shard_open_run(keaki_hip_ctx* ctx, FkShard& fk, int step, void* d_send, void* d_recv, void* d_out_aff);
 keaki_status selftest_u29_run(keaki_hip_ctx* ctx, uint32_t blocks, uint32_t iters, uint32_t seed, void* d_mismatches);
 keaki_status selftest_field_run(keaki_hip_ctx* ctx, uint32_t blocks, uint32_t iters, uint32_t seed, void* d_mismatches);
 

@@ -10,8 +10,10 @@ What shards how:
   every rank (keaki_hip_g1_sum[_dev]). 96 bytes per rank: latency-bound, xGMI bandwidth is irrelevant.
 * vec_encrypt / vec_decrypt (src/vec.rs:63-66, :75-78) -- by item, no collective. Every rank draws the WHOLE stream of r values so that
   the ciphertexts equal the single-process ones.
-* kzg::open_fk (FK23, src/kzg.rs:157-203) inside vec_commit -- REPLICATED: every rank computes all proofs (its group FFTs would need
-  an all-to-all of 96-byte points; not built). Only the commit MSM of vec_commit is sharded.
+* kzg::open_fk (FK23, src/kzg.rs:157-203) inside vec_commit -- the three group FFTs and the 2d scalar-mults are split over the ranks
+  (ShardedFk below; keaki_hip_fk_shard_* in the C ABI): two all-to-alls of 96-byte points (2d / world^2 resp. d / world^2 points per
+  peer) and one all-gather of the d / world affine proofs per rank. The ONLY exchange of the path where xGMI bandwidth matters
+  (d = 2^21: 400 MB + 200 MB + 128 MB in total over all links). Needs a power-of-two world and d >= world^2; otherwise replicated.
 """
 from __future__ import annotations
 
@@ -128,10 +130,80 @@ def sharded_commit(K, setup, p, shard: Shard) -> np.ndarray:
     return K.commit_combine(setup, shard.all_gather_np(part))
 
 
-def sharded_vec_commit(K, rng, setup, v, shard: Shard):
-    """vec_commit (src/vec.rs:22-49): padding draw, iFFT and FK23 openings replicated on every rank (same rng seed -> same values),
-    the commit MSM sharded by point range, one all-gather. Returns (commitment, proofs) on every rank."""
-    part, proofs = K.vec_commit_partial(rng, setup, v, shard.rank, shard.world)
+class ShardedFk:
+    """kzg::open_fk of a setup sharded over the ranks: owns the two exchange buffers (torch tensors on the setup's GPU) and performs the
+    collectives keaki::dist::ShardedOpenFk asks for -- RCCL on the device buffers themselves, or through host memory for gloo.
+
+        fk = ShardedFk(K, setup, domain_size, shard); fk.prepare()       # setup time: this rank's part of hat_s (one all-to-all)
+        proofs = fk.open(coeffs)                                          # == K.open_fk(setup, coeffs, domain_size) on every rank
+    """
+
+    def __init__(self, K, setup, domain_size: int, shard: Shard, device: int = 0):
+        import torch
+        self.K, self.shard, self.torch = K, shard, torch
+        self.dev = torch.device("cuda", device)
+        self.inner = K.ShardedOpenFk(setup, domain_size, shard.rank, shard.world, self._all_to_all, self._all_gather)
+        nb = self.inner.buffer_bytes
+        self.send = torch.empty(nb, dtype=torch.uint8, device=self.dev)
+        self.recv = torch.empty(nb, dtype=torch.uint8, device=self.dev)
+        self.bytes_moved = 0
+
+    @staticmethod
+    def can_shard(K, setup, domain_size: int, shard: Shard) -> bool:
+        return shard.world > 1 and K.ShardedOpenFk.can_shard(setup, domain_size, shard.rank, shard.world)
+
+    # the library has synchronised its stream before it calls these; they return when d_recv is complete
+    def _all_to_all(self, d_send, d_recv, per_peer):
+        torch, dist, w = self.torch, self.shard.dist, self.shard.world
+        assert d_send == self.send.data_ptr() and d_recv == self.recv.data_ptr()
+        s, r = self.send[:w * per_peer], self.recv[:w * per_peer]
+        if dist.get_backend() == "nccl":
+            dist.all_to_all_single(r, s)
+            torch.cuda.current_stream(self.dev).synchronize()
+        else:
+            hs = s.cpu()
+            hr = torch.empty_like(hs)
+            dist.all_to_all_single(hr, hs)
+            r.copy_(hr)
+            torch.cuda.synchronize(self.dev)
+        self.bytes_moved += (w - 1) * per_peer
+
+    def _all_gather(self, d_send, d_recv, per_rank):
+        torch, dist, w = self.torch, self.shard.dist, self.shard.world
+        s, r = self.send[:per_rank], self.recv[:w * per_rank]
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(r, s)
+            torch.cuda.current_stream(self.dev).synchronize()
+        else:
+            hs = s.cpu()
+            hr = torch.empty(w * per_rank, dtype=torch.uint8)
+            dist.all_gather_into_tensor(hr, hs)
+            r.copy_(hr)
+            torch.cuda.synchronize(self.dev)
+        self.bytes_moved += (w - 1) * per_rank
+
+    def prepare(self):
+        self.inner.prepare(self.send.data_ptr(), self.recv.data_ptr())
+
+    def open(self, coeffs):
+        return self.inner.open(coeffs, self.send.data_ptr(), self.recv.data_ptr())
+
+    def vec_commit_partial(self, rng, v):
+        return self.inner.vec_commit_partial(rng, v, self.send.data_ptr(), self.recv.data_ptr())
+
+    def close(self):
+        self.inner.close()
+        self.send = self.recv = None
+
+
+def sharded_vec_commit(K, rng, setup, v, shard: Shard, fk: "ShardedFk | None" = None):
+    """vec_commit (src/vec.rs:22-49) on every rank: padding draw and iFFT replicated (same rng seed -> same values), the commit MSM sharded by
+    point range with one all-gather of the partials, and -- given a ShardedFk -- the FK23 openings sharded as well (without one they are
+    replicated). Returns (commitment, proofs) on every rank."""
+    if fk is not None:
+        part, proofs = fk.vec_commit_partial(rng, v)
+    else:
+        part, proofs = K.vec_commit_partial(rng, setup, v, shard.rank, shard.world)
     return K.commit_combine(setup, shard.all_gather_np(part)), proofs
 
 

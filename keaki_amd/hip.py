@@ -23,7 +23,7 @@ EXPORTS = [
     "keaki_hip_g1_mul_batch", "keaki_hip_g2_mul_batch", "keaki_hip_g1_mul_batch_dev", "keaki_hip_g2_mul_batch_dev",
     "keaki_hip_pairing_batch", "keaki_hip_pairing_batch_dev",
     "keaki_hip_encap_batch", "keaki_hip_encap_batch_dev", "keaki_hip_decap_batch", "keaki_hip_decap_batch_dev",
-    "keaki_hip_selftest_field", "keaki_hip_open_fk", "keaki_hip_open_fk_poly", "keaki_hip_srs_g1_precompute_fk", "keaki_hip_fr_fft", "keaki_hip_srs_g1_check", "keaki_hip_g2_check", "keaki_hip_kzg_open", "keaki_hip_kzg_verify", "keaki_hip_final_exp_batch", "keaki_hip_miller_loop_batch", "keaki_hip_g2_prepare", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
+    "keaki_hip_selftest_field", "keaki_hip_open_fk", "keaki_hip_open_fk_poly", "keaki_hip_srs_g1_precompute_fk", "keaki_hip_fk_shard_create", "keaki_hip_fk_shard_free", "keaki_hip_fk_shard_sizes", "keaki_hip_fk_shard_setup", "keaki_hip_fk_shard_open", "keaki_hip_fr_fft", "keaki_hip_srs_g1_check", "keaki_hip_g2_check", "keaki_hip_kzg_open", "keaki_hip_kzg_verify", "keaki_hip_final_exp_batch", "keaki_hip_miller_loop_batch", "keaki_hip_g2_prepare", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
 ]
 
 KEAKI_ERR_TOO_LARGE = -5
@@ -84,6 +84,12 @@ def load_library():
         lib.keaki_hip_open_fk_poly.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, vp, vp]
         lib.keaki_hip_fr_fft.argtypes = [vp, vp, C.c_uint32, vp, vp]
         lib.keaki_hip_srs_g1_precompute_fk.argtypes = [vp, vp, C.c_uint32, vp]
+        lib.keaki_hip_fk_shard_create.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, C.POINTER(vp)]
+        lib.keaki_hip_fk_shard_free.argtypes = [vp, vp]
+        lib.keaki_hip_fk_shard_free.restype = None
+        lib.keaki_hip_fk_shard_sizes.argtypes = [vp, C.POINTER(C.c_size_t)]
+        lib.keaki_hip_fk_shard_setup.argtypes = [vp, vp, C.c_int32, vp, vp]
+        lib.keaki_hip_fk_shard_open.argtypes = [vp, vp, C.c_int32, vp, vp, vp, vp]
         lib.keaki_hip_srs_g1_check.argtypes = [vp, vp, vp, vp]
         lib.keaki_hip_kzg_open.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp]
         lib.keaki_hip_g2_check.argtypes = [vp, vp, C.c_size_t, vp, vp]
@@ -125,6 +131,19 @@ class SrsG2(SrsG1):
     def free(self):
         if self.handle:
             self.owner.lib.keaki_hip_srs_g2_free(self.owner.ctx, self.handle)
+            self.handle = None
+
+
+class FkShardHandle:
+    """one rank's part of a sharded FK23 (keaki_hip_fk_shard). sizes = (buffer bytes, all-to-all bytes per peer of the 2d-point
+    transforms, of the d-point transform, all-gather bytes per rank)"""
+
+    def __init__(self, owner, handle, log2d, rank, world, sizes):
+        self.owner, self.handle, self.log2d, self.rank, self.world, self.sizes = owner, handle, log2d, rank, world, sizes
+
+    def free(self):
+        if self.handle:
+            self.owner.lib.keaki_hip_fk_shard_free(self.owner.ctx, self.handle)
             self.handle = None
 
 
@@ -334,6 +353,25 @@ class KeakiHip:
         return out
 
     # ---- KEM composites
+    # FK23 sharded over `world` ranks: the steps between the caller's exchanges (keaki_amd/dist.py::ShardedFk drives them)
+    def fk_shard_create(self, srs: "SrsG1", log2d: int, rank: int, world: int, omega_2d, omega_2d_inv, inv_2d) -> "FkShardHandle":
+        h = C.c_void_p()
+        self._ck(self.lib.keaki_hip_fk_shard_create(self.ctx, srs.handle, log2d, rank, world, _ptr(_np(omega_2d)), _ptr(_np(omega_2d_inv)),
+                                                    _ptr(_np(inv_2d)), C.byref(h)))
+        sizes = (C.c_size_t * 4)()
+        self._ck(self.lib.keaki_hip_fk_shard_sizes(h, sizes))
+        return FkShardHandle(self, h, log2d, rank, world, tuple(int(x) for x in sizes))
+
+    def fk_shard_setup(self, fk: "FkShardHandle", step: int, d_send: int, d_recv: int):
+        self._ck(self.lib.keaki_hip_fk_shard_setup(self.ctx, fk.handle, step, C.c_void_p(d_send), C.c_void_p(d_recv)))
+
+    def fk_shard_open(self, fk: "FkShardHandle", step: int, d_send: int, d_recv: int, coeffs=None):
+        """steps 0-2 return None; step 3 returns the d affine proofs (u64[d, 8]) in natural order"""
+        out = np.empty(((1 << fk.log2d), 8), dtype=np.uint64) if step == 3 else None
+        p = _np(coeffs, 4) if coeffs is not None else None
+        self._ck(self.lib.keaki_hip_fk_shard_open(self.ctx, fk.handle, step, _ptr(p), C.c_void_p(d_send), C.c_void_p(d_recv), _ptr(out)))
+        return out
+
     def encap_batch(self, com, tau_g2, points, values, rs, msg_len: int = 32):
         com = _np(com); tau = _np(tau_g2); pts = _np(points, 4); vals = _np(values, 4); rs = _np(rs, 4)
         n = pts.shape[0]

@@ -328,25 +328,27 @@ std::vector<Fr> Radix2Domain::ifft(std::vector<Fr> e) const {
 }
 
 // src/vec.rs:27-44: everything of vec_commit in front of the final commit -> (coefficients as a DensePolynomial, proofs)
-std::pair<DensePolynomial, std::vector<G1>> vec_commit_openings(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v) {
+std::vector<Fr> vec_commit_coeffs(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v) {
   size_t d = v.size() + PADDING_LEN;
   std::vector<Fr> padded(v);
   padded.push_back(fr_rand(rng));                    // src/vec.rs:31-33
   Radix2Domain domain = Radix2Domain::create(d);     // :36
-  std::vector<Fr> p_coeff;
-  if (d >= (size_t(1) << 12)) {                      // :37 on the device for large domains (keaki_hip_fr_fft), same values
-    p_coeff = std::move(padded);
-    p_coeff.resize(domain.size);
-    unsigned log_size = 0;
-    while ((size_t(1) << log_size) < domain.size) log_size++;
-    setup.device()->check(keaki_hip_fr_fft(setup.device()->ctx(), p_coeff[0].l, log_size, domain.group_gen_inv.l, domain.size_inv.l));
-  } else {
-    p_coeff = domain.ifft(padded);
-  }
-  std::vector<G1> proofs = kzg::open_fk(setup, p_coeff, domain.size).unwrap();  // :40
-  DensePolynomial dense = std::move(p_coeff);
-  while (!dense.empty() && dense.back().is_zero()) dense.pop_back();  // from_coefficients_vec trims
-  return {std::move(dense), std::move(proofs)};
+  if (d < (size_t(1) << 12)) return domain.ifft(padded);
+  // :37 on the device for large domains (keaki_hip_fr_fft), same values
+  padded.resize(domain.size);
+  unsigned log_size = 0;
+  while ((size_t(1) << log_size) < domain.size) log_size++;
+  setup.device()->check(keaki_hip_fr_fft(setup.device()->ctx(), padded[0].l, log_size, domain.group_gen_inv.l, domain.size_inv.l));
+  return padded;
+}
+static DensePolynomial trimmed(std::vector<Fr> c) {
+  while (!c.empty() && c.back().is_zero()) c.pop_back();  // from_coefficients_vec trims
+  return c;
+}
+std::pair<DensePolynomial, std::vector<G1>> vec_commit_openings(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v) {
+  std::vector<Fr> p_coeff = vec_commit_coeffs(rng, setup, v);
+  std::vector<G1> proofs = kzg::open_fk(setup, p_coeff, p_coeff.size()).unwrap();  // :40
+  return {trimmed(std::move(p_coeff)), std::move(proofs)};
 }
 std::pair<G1, std::vector<G1>> vec_commit(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v) {
   auto cp = vec_commit_openings(rng, setup, v);
@@ -442,6 +444,58 @@ kzg::Result<Partial> commit_partial(const kzg::KZGSetup& setup, const DensePolyn
 std::pair<Partial, std::vector<G1>> vec_commit_partial(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v, const Shard& sh) {
   auto cp = vec::vec_commit_openings(rng, setup, v);                 // replicated on every rank: same rng stream, same values
   return {commit_partial(setup, cp.first, sh).unwrap(), std::move(cp.second)};
+}
+
+static unsigned log2_of(size_t n) {
+  unsigned l = 0;
+  while ((size_t(1) << l) < n) l++;
+  return l;
+}
+bool ShardedOpenFk::can_shard(const kzg::KZGSetup& setup, size_t domain_size, const Shard& sh) {
+  const size_t w = sh.world;
+  return w >= 2 && (w & (w - 1)) == 0 && domain_size >= w * w && (domain_size & (domain_size - 1)) == 0 && domain_size <= setup.g1_pow().size();
+}
+ShardedOpenFk::ShardedOpenFk(const kzg::KZGSetup& setup, size_t domain_size, const Shard& sh) : setup_(setup), d_(domain_size) {
+  vec::Radix2Domain d2 = vec::Radix2Domain::create(2 * domain_size);
+  const Device& dev = *setup.device();
+  dev.check(keaki_hip_fk_shard_create(dev.ctx(), setup.srs(), log2_of(domain_size), (uint32_t)sh.rank, (uint32_t)sh.world, d2.group_gen.l,
+                                      d2.group_gen_inv.l, d2.size_inv.l, &fk_));
+  dev.check(keaki_hip_fk_shard_sizes(fk_, sizes_));
+}
+ShardedOpenFk::~ShardedOpenFk() { keaki_hip_fk_shard_free(setup_.device()->ctx(), fk_); }
+void ShardedOpenFk::prepare(void* d_send, void* d_recv, const FkExchange& ex) {
+  if (prepared_) return;
+  const Device& dev = *setup_.device();
+  dev.check(keaki_hip_fk_shard_setup(dev.ctx(), fk_, 0, d_send, nullptr));
+  dev.check(keaki_hip_synchronize(dev.ctx()));
+  ex.all_to_all(ex.user, d_send, d_recv, sizes_[1]);
+  dev.check(keaki_hip_fk_shard_setup(dev.ctx(), fk_, 1, nullptr, d_recv));
+  dev.check(keaki_hip_synchronize(dev.ctx()));
+  prepared_ = true;
+}
+std::vector<G1> ShardedOpenFk::open(const std::vector<Fr>& p, void* d_send, void* d_recv, const FkExchange& ex) {
+  if (p.size() != d_) throw std::runtime_error("ShardedOpenFk::open: the polynomial must have domain_size coefficients");
+  prepare(d_send, d_recv, ex);
+  const Device& dev = *setup_.device();
+  dev.check(keaki_hip_fk_shard_open(dev.ctx(), fk_, 0, p[0].l, d_send, nullptr, nullptr));
+  dev.check(keaki_hip_synchronize(dev.ctx()));
+  ex.all_to_all(ex.user, d_send, d_recv, sizes_[1]);
+  dev.check(keaki_hip_fk_shard_open(dev.ctx(), fk_, 1, nullptr, d_send, d_recv, nullptr));
+  dev.check(keaki_hip_synchronize(dev.ctx()));
+  ex.all_to_all(ex.user, d_send, d_recv, sizes_[2]);
+  dev.check(keaki_hip_fk_shard_open(dev.ctx(), fk_, 2, nullptr, d_send, d_recv, nullptr));
+  dev.check(keaki_hip_synchronize(dev.ctx()));
+  ex.all_gather(ex.user, d_send, d_recv, sizes_[3]);
+  std::vector<G1> out(d_);
+  dev.check(keaki_hip_fk_shard_open(dev.ctx(), fk_, 3, nullptr, nullptr, d_recv, out[0].w.data()));
+  return out;
+}
+std::pair<Partial, std::vector<G1>> vec_commit_partial_fk(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v, const Shard& sh,
+                                                          ShardedOpenFk& fk, void* d_send, void* d_recv, const FkExchange& ex) {
+  std::vector<Fr> coeffs = vec::vec_commit_coeffs(rng, setup, v);       // replicated: same rng stream, same values
+  std::vector<G1> proofs = fk.open(coeffs, d_send, d_recv, ex);
+  while (!coeffs.empty() && coeffs.back().is_zero()) coeffs.pop_back();
+  return {commit_partial(setup, coeffs, sh).unwrap(), std::move(proofs)};
 }
 
 G1 commit_combine(const kzg::KZGSetup& setup, const Partial* partials, size_t world) {

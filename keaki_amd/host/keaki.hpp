@@ -168,6 +168,8 @@ struct Radix2Domain {
 };
 // src/vec.rs:22-49
 std::pair<G1, std::vector<G1>> vec_commit(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v);
+// lines :27-37 of it (padding draw, iFFT): the coefficient vector over the whole domain, not trimmed
+std::vector<Fr> vec_commit_coeffs(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v);
 // lines :27-44 of it (padding draw, iFFT, open_fk): the dense coefficient vector and the proofs, without the final commit
 std::pair<DensePolynomial, std::vector<G1>> vec_commit_openings(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v);
 // src/vec.rs:52-69: one Fr::rand per item in index order, then ONE batched GPU call for all items
@@ -199,8 +201,42 @@ void prepare(const kzg::KZGSetup& setup, const Shard& sh);
 // this rank's share of kzg::commit: sum over i in bounds(setup.len) and i < p.size() of p[i] [tau^i]_1. Same error as commit.
 kzg::Result<Partial> commit_partial(const kzg::KZGSetup& setup, const DensePolynomial& p, const Shard& sh);
 // vec_commit with the final commit (src/vec.rs:46) left as this rank's partial. Padding draw, iFFT and the FK23 openings are REPLICATED:
-// every rank runs them with the same rng stream and gets the same proofs (the group FFTs of FK23 are not sharded).
+// every rank runs them with the same rng stream and gets the same proofs (vec_commit_partial_fk shards the openings too).
 std::pair<Partial, std::vector<G1>> vec_commit_partial(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v, const Shard& sh);
+// ---- kzg::open_fk (FK23, src/kzg.rs:157-203) sharded over the ranks: every rank does 1/world of the butterflies of the three group FFTs
+// and of the 2d scalar-mults (keaki_hip_fk_shard_*). Between the steps the ranks exchange 96-byte points: two all-to-alls of
+// (2d / world^2) resp. (d / world^2) points per peer and one all-gather of the d / world affine proofs per rank -- the one place of the
+// whole path where xGMI bandwidth matters. The exchanges are the CALLER's (RCCL in an application: the library never opens a connection):
+struct FkExchange {
+  // d_send: `world` chunks of bytes_per_peer, chunk q for rank q; d_recv: the chunks received, in rank order. Device memory.
+  // Must not return before d_recv is complete (the steps run on the Device's own stream).
+  void (*all_to_all)(void* user, void* d_send, void* d_recv, size_t bytes_per_peer);
+  // d_send: bytes_per_rank of this rank; d_recv: every rank's, in rank order
+  void (*all_gather)(void* user, void* d_send, void* d_recv, size_t bytes_per_rank);
+  void* user;
+};
+class ShardedOpenFk {
+ public:
+  // domain_size: a power of two >= world^2 and <= the SRS; world a power of two >= 2 (can_shard). The setup must outlive this object.
+  ShardedOpenFk(const kzg::KZGSetup& setup, size_t domain_size, const Shard& sh);
+  ~ShardedOpenFk();
+  ShardedOpenFk(const ShardedOpenFk&) = delete;
+  static bool can_shard(const kzg::KZGSetup& setup, size_t domain_size, const Shard& sh);
+  size_t buffer_bytes() const { return sizes_[0]; }       // of d_send and of d_recv (device memory, the caller's)
+  size_t domain_size() const { return d_; }
+  // setup time: this rank's part of hat_s = DFT_2d(reversed SRS); one all-to-all
+  void prepare(void* d_send, void* d_recv, const FkExchange& ex);
+  // == kzg::open_fk(setup, p, domain_size).unwrap() on every rank (p.size() == domain_size)
+  std::vector<G1> open(const std::vector<Fr>& p, void* d_send, void* d_recv, const FkExchange& ex);
+ private:
+  const kzg::KZGSetup& setup_;
+  keaki_hip_fk_shard* fk_ = nullptr;
+  size_t d_ = 0, sizes_[4] = {0, 0, 0, 0};
+  bool prepared_ = false;
+};
+// vec_commit_partial with the FK23 openings sharded as well: nothing but the padding draw and the scalar-field iFFT is replicated
+std::pair<Partial, std::vector<G1>> vec_commit_partial_fk(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v, const Shard& sh,
+                                                          ShardedOpenFk& fk, void* d_send, void* d_recv, const FkExchange& ex);
 // the sum of all ranks' partials (in any order)
 G1 commit_combine(const kzg::KZGSetup& setup, const Partial* partials, size_t world);
 // vec_encrypt_flat for the items in bounds(n) only: draws ALL n values of r in index order (so every rank's stream, and therefore every

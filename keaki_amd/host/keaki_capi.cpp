@@ -270,6 +270,37 @@ int keaki_host_vec_commit_partial(void* rng, void* s, const uint64_t* v, size_t 
     return 0;
   });
 }
+// ---- open_fk sharded (dist::ShardedOpenFk): the two callbacks are the caller's collectives over device memory
+typedef void (*keaki_host_a2a_fn)(void* user, void* d_send, void* d_recv, size_t bytes_per_peer);
+int keaki_host_fk_shard_can(void* s, size_t domain_size, size_t rank, size_t world) {
+  return dist::ShardedOpenFk::can_shard(((Setup*)s)->s, domain_size, dist::Shard{rank, world}) ? 1 : 0;
+}
+int keaki_host_fk_shard_new(void* s, size_t domain_size, size_t rank, size_t world, void** out) {
+  return guard([&] { *out = new dist::ShardedOpenFk(((Setup*)s)->s, domain_size, dist::Shard{rank, world}); return 0; });
+}
+void keaki_host_fk_shard_free(void* fk) { delete (dist::ShardedOpenFk*)fk; }
+size_t keaki_host_fk_shard_buffer_bytes(void* fk) { return ((dist::ShardedOpenFk*)fk)->buffer_bytes(); }
+int keaki_host_fk_shard_prepare(void* fk, void* d_send, void* d_recv, keaki_host_a2a_fn all_to_all, keaki_host_a2a_fn all_gather, void* user) {
+  return guard([&] { ((dist::ShardedOpenFk*)fk)->prepare(d_send, d_recv, dist::FkExchange{all_to_all, all_gather, user}); return 0; });
+}
+int keaki_host_fk_shard_open(void* fk, const uint64_t* coeffs, size_t n, void* d_send, void* d_recv, keaki_host_a2a_fn all_to_all,
+                             keaki_host_a2a_fn all_gather, void* user, uint64_t* out_g1s) {
+  return guard([&] {
+    auto r = ((dist::ShardedOpenFk*)fk)->open(frs_of(coeffs, n), d_send, d_recv, dist::FkExchange{all_to_all, all_gather, user});
+    for (size_t i = 0; i < r.size(); i++) memcpy(out_g1s + 8 * i, r[i].w.data(), 64);
+    return 0;
+  });
+}
+int keaki_host_vec_commit_partial_fk(void* rng, void* s, const uint64_t* v, size_t n, size_t rank, size_t world, void* fk, void* d_send, void* d_recv,
+                                     keaki_host_a2a_fn all_to_all, keaki_host_a2a_fn all_gather, void* user, uint64_t* out_jac12, uint64_t* proofs_out) {
+  return guard([&] {
+    auto r = dist::vec_commit_partial_fk(*(Rng*)rng, ((Setup*)s)->s, frs_of(v, n), dist::Shard{rank, world}, *(dist::ShardedOpenFk*)fk, d_send, d_recv,
+                                         dist::FkExchange{all_to_all, all_gather, user});
+    memcpy(out_jac12, r.first.data(), 96);
+    for (size_t i = 0; i < r.second.size(); i++) memcpy(proofs_out + 8 * i, r.second[i].w.data(), 64);
+    return 0;
+  });
+}
 int keaki_host_commit_combine(void* s, const uint64_t* partials_jac12, size_t world, uint64_t* out_g1) {
   return guard([&] {
     static_assert(sizeof(dist::Partial) == 96, "a partial is twelve u64 words");

@@ -358,6 +358,59 @@ def vec_commit_partial(rng: Rng, setup: KZGSetup, v, rank: int, world: int):
     return part, proofs
 
 
+EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)    # (user, d_send, d_recv, bytes per peer / per rank)
+
+
+class ShardedOpenFk:
+    """keaki::dist::ShardedOpenFk: kzg::open_fk with the group FFTs sharded over the ranks. `all_to_all(d_send, d_recv, bytes_per_peer)` and
+    `all_gather(d_send, d_recv, bytes_per_rank)` are the caller's collectives over device memory (they must have completed on return);
+    d_send / d_recv: device pointers to buffer_bytes each (keaki_amd/dist.py::ShardedFk provides all of this over torch.distributed)."""
+
+    def __init__(self, setup: KZGSetup, domain_size: int, rank: int, world: int, all_to_all, all_gather):
+        lib = _lib()
+        lib.keaki_host_fk_shard_buffer_bytes.restype = C.c_size_t
+        lib.keaki_host_fk_shard_buffer_bytes.argtypes = [C.c_void_p]
+        lib.keaki_host_fk_shard_free.argtypes = [C.c_void_p]
+        h = C.c_void_p()
+        _ck(lib.keaki_host_fk_shard_new(setup.h, C.c_size_t(domain_size), C.c_size_t(rank), C.c_size_t(world), C.byref(h)))
+        self.h, self.setup, self.domain_size, self.rank, self.world = h, setup, domain_size, rank, world
+        self.buffer_bytes = int(lib.keaki_host_fk_shard_buffer_bytes(h))
+        self._a2a = EXCHANGE_FN(lambda user, s, r, n: all_to_all(s, r, n))        # kept alive with the object
+        self._gather = EXCHANGE_FN(lambda user, s, r, n: all_gather(s, r, n))
+
+    @staticmethod
+    def can_shard(setup: KZGSetup, domain_size: int, rank: int, world: int) -> bool:
+        return bool(_lib().keaki_host_fk_shard_can(setup.h, C.c_size_t(domain_size), C.c_size_t(rank), C.c_size_t(world)))
+
+    def prepare(self, d_send: int, d_recv: int) -> None:
+        _ck(_lib().keaki_host_fk_shard_prepare(self.h, C.c_void_p(d_send), C.c_void_p(d_recv), self._a2a, self._gather, None))
+
+    def open(self, p, d_send: int, d_recv: int) -> np.ndarray:
+        c = _u64(p, 4); out = np.zeros((self.domain_size, 8), np.uint64)
+        _ck(_lib().keaki_host_fk_shard_open(self.h, _p(c), C.c_size_t(c.shape[0]), C.c_void_p(d_send), C.c_void_p(d_recv), self._a2a, self._gather,
+                                           None, _p(out)))
+        return out
+
+    def vec_commit_partial(self, rng: Rng, v, d_send: int, d_recv: int):
+        """keaki::dist::vec_commit_partial_fk -> (partial u64[12], proofs)"""
+        v = _u64(v, 4); n = v.shape[0]
+        part = np.zeros(12, np.uint64); proofs = np.zeros((self.domain_size, 8), np.uint64)
+        _ck(_lib().keaki_host_vec_commit_partial_fk(rng.h, self.setup.h, _p(v), C.c_size_t(n), C.c_size_t(self.rank), C.c_size_t(self.world), self.h,
+                                                   C.c_void_p(d_send), C.c_void_p(d_recv), self._a2a, self._gather, None, _p(part), _p(proofs)))
+        return part, proofs
+
+    def close(self):
+        if self.h:
+            _lib().keaki_host_fk_shard_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def commit_combine(setup: KZGSetup, partials) -> np.ndarray:
     pr = _u64(partials, 12); out = np.zeros(8, np.uint64)
     _ck(_lib().keaki_host_commit_combine(setup.h, _p(pr), C.c_size_t(pr.shape[0]), _p(out)))

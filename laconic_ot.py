@@ -11,8 +11,10 @@ Receiver::receive -> vec_decrypt : one batched GPU decapsulation (one pairing pe
 
 With N ranks (keaki_amd/dist.py; host side keaki::dist in keaki_amd/host/keaki.hpp):
   * every rank builds the same setup (same secret) and holds the whole SRS (2^21 points = 128 MiB);
-  * vec_commit: padding draw, iFFT and the FK23 openings are REPLICATED (every rank computes all proofs; the group FFTs are not
-    sharded), the commit MSM is sharded by point range: one all-gather of 96-byte partials + N - 1 EC additions;
+  * vec_commit: the padding draw and the scalar-field iFFT are replicated; the FK23 openings are SHARDED (every rank runs 1/N of the
+    butterflies of the three group FFTs and of the 2d scalar-mults; two all-to-alls of 96-byte points and one all-gather of the affine
+    proofs: keaki_amd/dist.py::ShardedFk; `--fk replicated` or a world that is not a power of two falls back to every rank computing all
+    proofs), the commit MSM is sharded by point range: one all-gather of 96-byte partials + N - 1 EC additions;
   * vec_encrypt / vec_decrypt: sharded by item, NO collective; every rank draws the whole stream of r so that the ciphertexts are the
     single-process ones. Rank q decrypts the items it encrypted, so nothing moves between ranks; the recovered messages are checked
     on the rank that holds them and the verdicts are combined at the end (one all-gather of a flag).
@@ -37,6 +39,7 @@ def main():
     ap.add_argument("--value-bytes", type=int, default=32)   # VALUE_BYTES (tests/laconic_ot.rs:124)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo lets several ranks share one GPU (1-GPU box)")
+    ap.add_argument("--fk", default="sharded", choices=["sharded", "replicated"], help="FK23 openings of Receiver::new on N > 1 ranks")
     ap.add_argument("--check-single", action="store_true",
                     help="rank 0 also runs the un-sharded calls with the same seeds and compares commitment and ciphertexts bit for bit")
     args = ap.parse_args()
@@ -46,7 +49,7 @@ def main():
     if world == 1 and args.gpus > 1:
         raise SystemExit("laconic_ot.py --gpus N with N > 1 must be launched through torch.distributed.run (one rank per GPU)")
     from keaki_amd import keaki as K
-    from keaki_amd.dist import Shard, sharded_vec_commit, sharded_vec_encrypt, sharded_vec_decrypt
+    from keaki_amd.dist import Shard, ShardedFk, sharded_vec_commit, sharded_vec_encrypt, sharded_vec_decrypt
     dist = None
     device = 0
     if world > 1:
@@ -59,8 +62,9 @@ def main():
             raise SystemExit("%d ranks but %d GPUs: RCCL needs one GPU per rank (use --backend gloo to share a GPU)" % (world, ndev))
         device = local_rank % ndev
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(device)
+        torch.cuda.init()                         # torch first, the library second (the exchange buffers of the sharded FK23 are torch tensors)
         if args.backend == "nccl":
-            torch.cuda.set_device(device)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -77,7 +81,12 @@ def main():
     while setup_degree < n + K.PADDING_LEN:
         setup_degree <<= 1
     s = K.KZGSetup.setup(rng.fr_rand(), setup_degree, device)      # SETUP_DEGREE: the domain of n+1 evaluations
-    K.precompute_open_fk(s, setup_degree)                  # SRS-only part of the FK23 openings, like the MSM window tables
+    fk = None
+    if args.fk == "sharded" and ShardedFk.can_shard(K, s, setup_degree, shard):
+        fk = ShardedFk(K, s, setup_degree, shard, device)
+        fk.prepare()                                       # this rank's part of the SRS-only transform (one all-to-all)
+    else:
+        K.precompute_open_fk(s, setup_degree)              # SRS-only part of the FK23 openings, like the MSM window tables
     K.prepare_shard(s, rank, world)                        # window tables of this rank's SRS chunk (N > 1)
     shard.barrier()
     t_setup = time.time() - t0
@@ -87,7 +96,7 @@ def main():
     choices = np.where(bits[:, None] == 0, zero[None, :], one[None, :]).astype(np.uint64)
 
     t0 = time.time()
-    commitment, proofs = sharded_vec_commit(K, rng, s, choices, shard)      # Receiver::new
+    commitment, proofs = sharded_vec_commit(K, rng, s, choices, shard, fk)  # Receiver::new
     t_receiver_new = phase_max(time.time() - t0)
 
     sets = [np_rng.integers(0, 256, size=(n, vb), dtype=np.uint8) for _ in range(2)]
@@ -126,8 +135,11 @@ def main():
                           "receiver_new_s": round(t_receiver_new, 3), "sender_send_s": round(t_sender_send, 3),
                           "receiver_receive_s": round(t_receive, 3), "all_messages_recovered": all_ok,
                           "sharded_equals_single_process": single,
-                          "sharding": None if world == 1 else "commit MSM by point range (1 all-gather of 96-B partials); FK23 openings replicated on "
-                                                              "every rank; encaps / decaps by item, no collective",
+                          "fk_sharded": fk is not None, "fk_exchange_bytes_sent_per_rank": fk.bytes_moved if fk is not None else 0,
+                          "sharding": None if world == 1 else "commit MSM by point range (1 all-gather of 96-B partials); FK23 openings %s; "
+                                                              "encaps / decaps by item, no collective"
+                                                              % ("sharded (2 all-to-alls of 96-B points + 1 all-gather of the proofs per call)"
+                                                                 if fk is not None else "replicated on every rank"),
                           "note": "wall-clock through the C++ host mirror (contiguous arrays in, arrays out), max over ranks per phase; "
                                   "GPU work: FK23 + MSM / 2n encaps / n decaps"}), flush=True)
     if world > 1:

@@ -34,6 +34,10 @@ pub struct keaki_hip_srs_g1 {
 pub struct keaki_hip_srs_g2 {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct keaki_hip_fk_shard {
+    _private: [u8; 0],
+}
 
 extern "C" {
     // ---- context
@@ -70,6 +74,14 @@ extern "C" {
                                   omega_2d_inv: *const u64, inv_2d: *const u64, proofs_out_aff: *mut u64) -> keaki_status;
     pub fn keaki_hip_srs_g1_precompute_fk(ctx: *mut keaki_hip_ctx, srs: *mut keaki_hip_srs_g1, log2d: u32, omega_2d: *const u64) -> keaki_status;
     pub fn keaki_hip_fr_fft(ctx: *mut keaki_hip_ctx, data: *mut u64, log2n: u32, omega: *const u64, scale_or_null: *const u64) -> keaki_status;
+    // FK23 sharded over the ranks of a multi-GPU job: the steps between the caller's RCCL exchanges (include/keaki_hip.h)
+    pub fn keaki_hip_fk_shard_create(ctx: *mut keaki_hip_ctx, srs: *const keaki_hip_srs_g1, log2d: u32, rank: u32, world: u32, omega_2d: *const u64,
+                                     omega_2d_inv: *const u64, inv_2d: *const u64, out: *mut *mut keaki_hip_fk_shard) -> keaki_status;
+    pub fn keaki_hip_fk_shard_free(ctx: *mut keaki_hip_ctx, fk: *mut keaki_hip_fk_shard);
+    pub fn keaki_hip_fk_shard_sizes(fk: *const keaki_hip_fk_shard, sizes4: *mut usize) -> keaki_status;
+    pub fn keaki_hip_fk_shard_setup(ctx: *mut keaki_hip_ctx, fk: *mut keaki_hip_fk_shard, step: i32, d_send: *mut c_void, d_recv: *mut c_void) -> keaki_status;
+    pub fn keaki_hip_fk_shard_open(ctx: *mut keaki_hip_ctx, fk: *mut keaki_hip_fk_shard, step: i32, coeffs: *const u64, d_send: *mut c_void,
+                                   d_recv: *mut c_void, proofs_out_aff: *mut u64) -> keaki_status;
 
     // ---- KZG open / verify in one call (src/kzg.rs:104-124, :127-151)
     pub fn keaki_hip_kzg_open(ctx: *mut keaki_hip_ctx, srs: *const keaki_hip_srs_g1, coeffs: *const u64, n: usize, point: *const u64,

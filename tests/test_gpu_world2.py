@@ -63,6 +63,20 @@ def test_world2_laconic_ot(multirank_runs):
     j = _json_line(run["log"])
     assert j["n_gpus"] == 2 and j["ranks_seen"] == 2
     assert j["all_messages_recovered"] is True and j["sharded_equals_single_process"] is True
+    # the FK23 openings were computed by the sharded pipeline (two all-to-alls + one all-gather per call, one all-to-all at setup)
+    d = 1024
+    assert j["fk_sharded"] is True and j["fk_exchange_bytes_sent_per_rank"] == (2 * d // 4 * 96) * 2 + d // 4 * 96 + d // 2 * 64
+
+
+def test_world4_and_world3_laconic_ot(multirank_runs):
+    """four ranks: two rank bits in every layout switch of the sharded FK23; three ranks: the openings fall back to the replicated path"""
+    for name, world, sharded in (("laconic4", 4, True), ("laconic3", 3, False)):
+        run = multirank_runs[name]
+        assert run["rc"] == 0, run["log"][-3000:]
+        j = _json_line(run["log"])
+        assert j["n_gpus"] == world and j["ranks_seen"] == world
+        assert j["all_messages_recovered"] is True and j["sharded_equals_single_process"] is True
+        assert j["fk_sharded"] is sharded
 
 
 def test_world1_under_torchrun(multirank_runs):

@@ -49,7 +49,7 @@ def c_class(t):
     stars = t.count("*")
     base = t.replace("*", "").strip()
     scalar = {"int32_t": "i32", "uint32_t": "u32", "size_t": "usize", "uint64_t": "u64", "uint8_t": "u8", "float": "f32", "void": "void", "char": "c_char",
-              "keaki_status": "i32", "keaki_hip_ctx": "ctx", "keaki_hip_srs_g1": "srs_g1", "keaki_hip_srs_g2": "srs_g2"}[base]
+              "keaki_status": "i32", "keaki_hip_ctx": "ctx", "keaki_hip_srs_g1": "srs_g1", "keaki_hip_srs_g2": "srs_g2", "keaki_hip_fk_shard": "fk_shard"}[base]
     return stars, scalar
 
 
@@ -58,7 +58,7 @@ def rust_class(t):
     stars = len(re.findall(r"\*(?:const|mut)", t))
     base = re.sub(r"\*(?:const|mut)\s*", "", t).strip()
     scalar = {"i32": "i32", "u32": "u32", "usize": "usize", "u64": "u64", "u8": "u8", "f32": "f32", "c_void": "void", "c_char": "c_char", "keaki_status": "i32",
-              "keaki_hip_ctx": "ctx", "keaki_hip_srs_g1": "srs_g1", "keaki_hip_srs_g2": "srs_g2", "()": "void"}[base]
+              "keaki_hip_ctx": "ctx", "keaki_hip_srs_g1": "srs_g1", "keaki_hip_srs_g2": "srs_g2", "keaki_hip_fk_shard": "fk_shard", "()": "void"}[base]
     return stars, scalar
 
 
