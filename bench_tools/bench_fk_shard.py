@@ -1,7 +1,7 @@
 """What ONE rank of an N-GPU job spends in the sharded FK23 openings (kzg::open_fk, reference src/kzg.rs:157-203; keaki_hip_fk_shard_*),
-measured on one GPU: rank 0's steps are run for world = 2, 4, 8 with the exchanges replaced by a device-to-device copy of the same
-number of bytes (the steps' run time does not depend on the values: the butterflies use fixed signed windows), next to the un-sharded
-call. The xGMI time of the real exchanges is NOT in these numbers; the bytes per rank are printed beside them.
+measured on one GPU: all ranks of world = 2, 4, 8 are played one after the other (every step of every rank timed on its own, the
+exchanges done as device-to-device copies outside the timed regions), the result is compared with the un-sharded call, and the slowest
+rank's sum of steps is reported. The xGMI time of the real exchanges is NOT in these numbers; the bytes per rank are printed beside them.
 
     python bench_tools/bench_fk_shard.py [log2d ...]          (default 16 20)
 """
@@ -47,31 +47,48 @@ def main():
         dom = (el[1], el[2 * d - 1], inv)
         row = {"log2d": log2d, "unsharded_s": round(t_plain, 4), "per_rank": {}}
         for world in (2, 4, 8):
-            fk = hip.fk_shard_create(srs, log2d, 0, world, *dom)
-            buf, a2a_big, a2a_small, gather = fk.sizes
-            send, recv = dmalloc(buf), dmalloc(buf)
+            fks = [hip.fk_shard_create(srs, log2d, r, world, *dom) for r in range(world)]
+            buf, a2a_big, a2a_small, gather = fks[0].sizes
+            send = [dmalloc(buf) for _ in range(world)]
+            recv = [dmalloc(buf) for _ in range(world)]
+            tt = np.zeros((world, 6))            # per rank: setup 0, setup 1, open 0, 1, 2, 3
 
-            def exch(nbytes):
-                hip.synchronize()
-                rt.hipMemcpy(recv, send, nbytes, 3)
+            def timed(r, col, fn):
+                hip.synchronize(); t0 = time.time(); out = fn(); hip.synchronize(); tt[r, col] = time.time() - t0
+                return out
 
-            t0 = time.time()
-            hip.fk_shard_setup(fk, 0, send.value, 0); exch(world * a2a_big)
-            hip.fk_shard_setup(fk, 1, 0, recv.value); hip.synchronize()
-            t_setup = time.time() - t0
-            best = None
-            for _ in range(2):
-                t0 = time.time()
-                hip.fk_shard_open(fk, 0, send.value, 0, coeffs=p); exch(world * a2a_big)
-                hip.fk_shard_open(fk, 1, send.value, recv.value); exch(world * a2a_small)
-                hip.fk_shard_open(fk, 2, send.value, recv.value); hip.synchronize()
-                rt.hipMemcpy(recv, send, gather, 3)
-                hip.fk_shard_open(fk, 3, 0, recv.value)
-                t = time.time() - t0
-                best = t if best is None else min(best, t)
-            row["per_rank"][str(world)] = {"hat_s_setup_s": round(t_setup, 4), "open_s": round(best, 4), "speedup_vs_unsharded": round(t_plain / best, 2),
-                                           "bytes_sent_per_rank": (world - 1) * (a2a_big + a2a_small + gather)}
-            fk.free(); rt.hipFree(send); rt.hipFree(recv)
+            def all_to_all(per_peer):            # the real data movement, on one GPU: chunk r of rank q's send -> chunk q of rank r's recv
+                for r in range(world):
+                    for q in range(world):
+                        rt.hipMemcpy(C.c_void_p(recv[r].value + q * per_peer), C.c_void_p(send[q].value + r * per_peer), per_peer, 3)
+
+            for r in range(world):
+                timed(r, 0, lambda: hip.fk_shard_setup(fks[r], 0, send[r].value, 0))
+            all_to_all(a2a_big)
+            for r in range(world):
+                timed(r, 1, lambda: hip.fk_shard_setup(fks[r], 1, 0, recv[r].value))
+            for r in range(world):
+                timed(r, 2, lambda: hip.fk_shard_open(fks[r], 0, send[r].value, 0, coeffs=p))
+            all_to_all(a2a_big)
+            for r in range(world):
+                timed(r, 3, lambda: hip.fk_shard_open(fks[r], 1, send[r].value, recv[r].value))
+            all_to_all(a2a_small)
+            for r in range(world):
+                timed(r, 4, lambda: hip.fk_shard_open(fks[r], 2, send[r].value, recv[r].value))
+            for r in range(world):
+                for q in range(world):
+                    rt.hipMemcpy(C.c_void_p(recv[r].value + q * gather), send[q], gather, 3)
+            outs = [timed(r, 5, lambda: hip.fk_shard_open(fks[r], 3, 0, recv[r].value)) for r in range(world)]
+            ok = all(np.array_equal(o, ref) for o in outs)
+            per_rank_open = tt[:, 2:].sum(axis=1)
+            row["per_rank"][str(world)] = {"hat_s_setup_s": round(float(tt[:, :2].sum(axis=1).max()), 4), "open_s": round(float(per_rank_open.max()), 4),
+                                           "open_steps_s": [round(float(x), 4) for x in tt[:, 2:].max(axis=0)],
+                                           "speedup_vs_unsharded": round(t_plain / float(per_rank_open.max()), 2),
+                                           "bytes_sent_per_rank": (world - 1) * (a2a_big + a2a_small + gather), "equals_unsharded": bool(ok)}
+            for fk in fks:
+                fk.free()
+            for m in send + recv:
+                rt.hipFree(m)
         srs.free(); s.close()
         print(json.dumps(row), flush=True)
 

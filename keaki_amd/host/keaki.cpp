@@ -468,7 +468,7 @@ void ShardedOpenFk::prepare(void* d_send, void* d_recv, const FkExchange& ex) {
   const Device& dev = *setup_.device();
   dev.check(keaki_hip_fk_shard_setup(dev.ctx(), fk_, 0, d_send, nullptr));
   dev.check(keaki_hip_synchronize(dev.ctx()));
-  ex.all_to_all(ex.user, d_send, d_recv, sizes_[1]);
+  if (ex.all_to_all(ex.user, d_send, d_recv, sizes_[1])) throw std::runtime_error("ShardedOpenFk: the caller's all-to-all failed");
   dev.check(keaki_hip_fk_shard_setup(dev.ctx(), fk_, 1, nullptr, d_recv));
   dev.check(keaki_hip_synchronize(dev.ctx()));
   prepared_ = true;
@@ -479,13 +479,13 @@ std::vector<G1> ShardedOpenFk::open(const std::vector<Fr>& p, void* d_send, void
   const Device& dev = *setup_.device();
   dev.check(keaki_hip_fk_shard_open(dev.ctx(), fk_, 0, p[0].l, d_send, nullptr, nullptr));
   dev.check(keaki_hip_synchronize(dev.ctx()));
-  ex.all_to_all(ex.user, d_send, d_recv, sizes_[1]);
+  if (ex.all_to_all(ex.user, d_send, d_recv, sizes_[1])) throw std::runtime_error("ShardedOpenFk: the caller's all-to-all failed");
   dev.check(keaki_hip_fk_shard_open(dev.ctx(), fk_, 1, nullptr, d_send, d_recv, nullptr));
   dev.check(keaki_hip_synchronize(dev.ctx()));
-  ex.all_to_all(ex.user, d_send, d_recv, sizes_[2]);
+  if (ex.all_to_all(ex.user, d_send, d_recv, sizes_[2])) throw std::runtime_error("ShardedOpenFk: the caller's all-to-all failed");
   dev.check(keaki_hip_fk_shard_open(dev.ctx(), fk_, 2, nullptr, d_send, d_recv, nullptr));
   dev.check(keaki_hip_synchronize(dev.ctx()));
-  ex.all_gather(ex.user, d_send, d_recv, sizes_[3]);
+  if (ex.all_gather(ex.user, d_send, d_recv, sizes_[3])) throw std::runtime_error("ShardedOpenFk: the caller's all-gather failed");
   std::vector<G1> out(d_);
   dev.check(keaki_hip_fk_shard_open(dev.ctx(), fk_, 3, nullptr, nullptr, d_recv, out[0].w.data()));
   return out;

@@ -209,10 +209,11 @@ std::pair<Partial, std::vector<G1>> vec_commit_partial(Rng& rng, const kzg::KZGS
 // whole path where xGMI bandwidth matters. The exchanges are the CALLER's (RCCL in an application: the library never opens a connection):
 struct FkExchange {
   // d_send: `world` chunks of bytes_per_peer, chunk q for rank q; d_recv: the chunks received, in rank order. Device memory.
-  // Must not return before d_recv is complete (the steps run on the Device's own stream).
-  void (*all_to_all)(void* user, void* d_send, void* d_recv, size_t bytes_per_peer);
+  // Must not return before d_recv is complete (the steps run on the Device's own stream). Returns 0, or non-zero to abort the call
+  // (the function then throws std::runtime_error).
+  int (*all_to_all)(void* user, void* d_send, void* d_recv, size_t bytes_per_peer);
   // d_send: bytes_per_rank of this rank; d_recv: every rank's, in rank order
-  void (*all_gather)(void* user, void* d_send, void* d_recv, size_t bytes_per_rank);
+  int (*all_gather)(void* user, void* d_send, void* d_recv, size_t bytes_per_rank);
   void* user;
 };
 class ShardedOpenFk {

@@ -271,7 +271,7 @@ int keaki_host_vec_commit_partial(void* rng, void* s, const uint64_t* v, size_t 
   });
 }
 // ---- open_fk sharded (dist::ShardedOpenFk): the two callbacks are the caller's collectives over device memory
-typedef void (*keaki_host_a2a_fn)(void* user, void* d_send, void* d_recv, size_t bytes_per_peer);
+typedef int (*keaki_host_a2a_fn)(void* user, void* d_send, void* d_recv, size_t bytes_per_peer);
 int keaki_host_fk_shard_can(void* s, size_t domain_size, size_t rank, size_t world) {
   return dist::ShardedOpenFk::can_shard(((Setup*)s)->s, domain_size, dist::Shard{rank, world}) ? 1 : 0;
 }

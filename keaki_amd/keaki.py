@@ -358,7 +358,7 @@ def vec_commit_partial(rng: Rng, setup: KZGSetup, v, rank: int, world: int):
     return part, proofs
 
 
-EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)    # (user, d_send, d_recv, bytes per peer / per rank)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)    # (user, d_send, d_recv, bytes per peer / per rank) -> 0 = ok
 
 
 class ShardedOpenFk:
@@ -375,19 +375,35 @@ class ShardedOpenFk:
         _ck(lib.keaki_host_fk_shard_new(setup.h, C.c_size_t(domain_size), C.c_size_t(rank), C.c_size_t(world), C.byref(h)))
         self.h, self.setup, self.domain_size, self.rank, self.world = h, setup, domain_size, rank, world
         self.buffer_bytes = int(lib.keaki_host_fk_shard_buffer_bytes(h))
-        self._a2a = EXCHANGE_FN(lambda user, s, r, n: all_to_all(s, r, n))        # kept alive with the object
-        self._gather = EXCHANGE_FN(lambda user, s, r, n: all_gather(s, r, n))
+        self.callback_error = None
+
+        def wrap(fn):
+            def cb(user, s, r, n):
+                try:                                   # an exception must not cross the C frames: report it as a status
+                    fn(s, r, n)
+                    return 0
+                except BaseException as e:             # noqa: BLE001
+                    self.callback_error = e
+                    return 1
+            return EXCHANGE_FN(cb)
+        self._a2a, self._gather = wrap(all_to_all), wrap(all_gather)          # kept alive with the object
 
     @staticmethod
     def can_shard(setup: KZGSetup, domain_size: int, rank: int, world: int) -> bool:
         return bool(_lib().keaki_host_fk_shard_can(setup.h, C.c_size_t(domain_size), C.c_size_t(rank), C.c_size_t(world)))
 
+    def _ck(self, st):
+        if st != 0 and self.callback_error is not None:
+            e, self.callback_error = self.callback_error, None
+            raise KeakiHostError("the exchange callback failed: %r" % (e,)) from e
+        _ck(st)
+
     def prepare(self, d_send: int, d_recv: int) -> None:
-        _ck(_lib().keaki_host_fk_shard_prepare(self.h, C.c_void_p(d_send), C.c_void_p(d_recv), self._a2a, self._gather, None))
+        self._ck(_lib().keaki_host_fk_shard_prepare(self.h, C.c_void_p(d_send), C.c_void_p(d_recv), self._a2a, self._gather, None))
 
     def open(self, p, d_send: int, d_recv: int) -> np.ndarray:
         c = _u64(p, 4); out = np.zeros((self.domain_size, 8), np.uint64)
-        _ck(_lib().keaki_host_fk_shard_open(self.h, _p(c), C.c_size_t(c.shape[0]), C.c_void_p(d_send), C.c_void_p(d_recv), self._a2a, self._gather,
+        self._ck(_lib().keaki_host_fk_shard_open(self.h, _p(c), C.c_size_t(c.shape[0]), C.c_void_p(d_send), C.c_void_p(d_recv), self._a2a, self._gather,
                                            None, _p(out)))
         return out
 
@@ -395,7 +411,7 @@ class ShardedOpenFk:
         """keaki::dist::vec_commit_partial_fk -> (partial u64[12], proofs)"""
         v = _u64(v, 4); n = v.shape[0]
         part = np.zeros(12, np.uint64); proofs = np.zeros((self.domain_size, 8), np.uint64)
-        _ck(_lib().keaki_host_vec_commit_partial_fk(rng.h, self.setup.h, _p(v), C.c_size_t(n), C.c_size_t(self.rank), C.c_size_t(self.world), self.h,
+        self._ck(_lib().keaki_host_vec_commit_partial_fk(rng.h, self.setup.h, _p(v), C.c_size_t(n), C.c_size_t(self.rank), C.c_size_t(self.world), self.h,
                                                    C.c_void_p(d_send), C.c_void_p(d_recv), self._a2a, self._gather, None, _p(part), _p(proofs)))
         return part, proofs
 
