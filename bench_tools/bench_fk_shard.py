@@ -61,6 +61,7 @@ def main():
                 for r in range(world):
                     for q in range(world):
                         rt.hipMemcpy(C.c_void_p(recv[r].value + q * per_peer), C.c_void_p(send[q].value + r * per_peer), per_peer, 3)
+                rt.hipDeviceSynchronize()        # device-to-device copies do not block the host, and the library's stream does not wait for them
 
             for r in range(world):
                 timed(r, 0, lambda: hip.fk_shard_setup(fks[r], 0, send[r].value, 0))
@@ -78,6 +79,7 @@ def main():
             for r in range(world):
                 for q in range(world):
                     rt.hipMemcpy(C.c_void_p(recv[r].value + q * gather), send[q], gather, 3)
+            rt.hipDeviceSynchronize()
             outs = [timed(r, 5, lambda: hip.fk_shard_open(fks[r], 3, 0, recv[r].value)) for r in range(world)]
             ok = all(np.array_equal(o, ref) for o in outs)
             per_rank_open = tt[:, 2:].sum(axis=1)

@@ -455,14 +455,14 @@ bool ShardedOpenFk::can_shard(const kzg::KZGSetup& setup, size_t domain_size, co
   const size_t w = sh.world;
   return w >= 2 && (w & (w - 1)) == 0 && domain_size >= w * w && (domain_size & (domain_size - 1)) == 0 && domain_size <= setup.g1_pow().size();
 }
-ShardedOpenFk::ShardedOpenFk(const kzg::KZGSetup& setup, size_t domain_size, const Shard& sh) : setup_(setup), d_(domain_size) {
+ShardedOpenFk::ShardedOpenFk(const kzg::KZGSetup& setup, size_t domain_size, const Shard& sh) : setup_(setup), dev_(setup.device()), d_(domain_size) {
   vec::Radix2Domain d2 = vec::Radix2Domain::create(2 * domain_size);
   const Device& dev = *setup.device();
   dev.check(keaki_hip_fk_shard_create(dev.ctx(), setup.srs(), log2_of(domain_size), (uint32_t)sh.rank, (uint32_t)sh.world, d2.group_gen.l,
                                       d2.group_gen_inv.l, d2.size_inv.l, &fk_));
   dev.check(keaki_hip_fk_shard_sizes(fk_, sizes_));
 }
-ShardedOpenFk::~ShardedOpenFk() { keaki_hip_fk_shard_free(setup_.device()->ctx(), fk_); }
+ShardedOpenFk::~ShardedOpenFk() { keaki_hip_fk_shard_free(dev_->ctx(), fk_); }
 void ShardedOpenFk::prepare(void* d_send, void* d_recv, const FkExchange& ex) {
   if (prepared_) return;
   const Device& dev = *setup_.device();

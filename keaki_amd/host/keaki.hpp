@@ -218,7 +218,7 @@ struct FkExchange {
 };
 class ShardedOpenFk {
  public:
-  // domain_size: a power of two >= world^2 and <= the SRS; world a power of two >= 2 (can_shard). The setup must outlive this object.
+  // domain_size: a power of two >= world^2 and <= the SRS; world a power of two >= 2 (can_shard). The setup must outlive every call of prepare / open.
   ShardedOpenFk(const kzg::KZGSetup& setup, size_t domain_size, const Shard& sh);
   ~ShardedOpenFk();
   ShardedOpenFk(const ShardedOpenFk&) = delete;
@@ -231,6 +231,7 @@ class ShardedOpenFk {
   std::vector<G1> open(const std::vector<Fr>& p, void* d_send, void* d_recv, const FkExchange& ex);
  private:
   const kzg::KZGSetup& setup_;
+  std::shared_ptr<Device> dev_;           // keeps the context alive for the destructor even if the setup goes first
   keaki_hip_fk_shard* fk_ = nullptr;
   size_t d_ = 0, sizes_[4] = {0, 0, 0, 0};
   bool prepared_ = false;

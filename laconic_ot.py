@@ -142,6 +142,8 @@ def main():
                                                                  if fk is not None else "replicated on every rank"),
                           "note": "wall-clock through the C++ host mirror (contiguous arrays in, arrays out), max over ranks per phase; "
                                   "GPU work: FK23 + MSM / 2n encaps / n decaps"}), flush=True)
+    if fk is not None:
+        fk.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
