@@ -365,9 +365,10 @@ class KeakiHip:
     def fk_shard_setup(self, fk: "FkShardHandle", step: int, d_send: int, d_recv: int):
         self._ck(self.lib.keaki_hip_fk_shard_setup(self.ctx, fk.handle, step, C.c_void_p(d_send), C.c_void_p(d_recv)))
 
-    def fk_shard_open(self, fk: "FkShardHandle", step: int, d_send: int, d_recv: int, coeffs=None):
-        """steps 0-2 return None; step 3 returns the d affine proofs (u64[d, 8]) in natural order"""
-        out = np.empty(((1 << fk.log2d), 8), dtype=np.uint64) if step == 3 else None
+    def fk_shard_open(self, fk: "FkShardHandle", step: int, d_send: int, d_recv: int, coeffs=None, out=None):
+        """steps 0-2 return None; step 3 returns the d affine proofs (u64[d, 8]) in natural order (written into `out` if given)"""
+        if step == 3 and out is None:
+            out = np.empty(((1 << fk.log2d), 8), dtype=np.uint64)
         p = _np(coeffs, 4) if coeffs is not None else None
         self._ck(self.lib.keaki_hip_fk_shard_open(self.ctx, fk.handle, step, _ptr(p), C.c_void_p(d_send), C.c_void_p(d_recv), _ptr(out)))
         return out
