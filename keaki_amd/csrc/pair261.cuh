@@ -135,7 +135,13 @@ KDEV Fq2d fq2_dbl(const Fq2d& a) { return {fq_dbl(a.v)}; }
 KDEV Fq2d fq2d_zero() { return {fq_zero()}; }
 KDEV Fq2d fq2d_one() { return {fq_select(lane_odd() != 0, fq_zero(), ONE)}; }
 KDEV Fq2d fq2_conj(const Fq2d& a) { return {fp_cneg<FqParams>(a.v, lane_odd() != 0)}; }
-KDEV Fq2d fq2d_load(const Fq2* a) { return {reinterpret_cast<const Fq*>(a)[lane_odd()]}; }    // this lane's component of a constant (c0, c1)
+// this lane's component of a constant (c0, c1). The lane's offset passes through an empty volatile statement so that the address is formed
+// HERE: hipcc otherwise forms base + lane offset for every constant at kernel entry and keeps (spills) the 64-bit addresses until the use.
+KDEV Fq2d fq2d_load(const Fq2* a) {
+  u32 odd = lane_odd();
+  asm volatile("" : "+v"(odd));
+  return {reinterpret_cast<const Fq*>(a)[odd]};
+}
 KDEV Fq2d fq2_mul_fq(const Fq2d& a, const Fq& k) { return {fq_mul261(a.v, k)}; }
 
 // ---- product operands in limb form ---------------------------------------------------------------------------------------------
@@ -343,13 +349,17 @@ static KTOWER void fq12_inv(Fq12* r, const Fq12* a, uint4* park = nullptr) {
     n0 = unpark_fq6(park, 6);
     n = n0 - fq6_mul_v(n1);
   }
-  Fq6 ni, r0, r1;
-  fq6_inv(&ni, &n);                       // a chain of function calls
+  Fq6 r0, r1;
+  {
+    Fq6 ni;
+    fq6_inv(&ni, &n);                     // a chain of function calls
+    park_fq6(park, 6, ni);                // read back per product: otherwise its operand forms (54 limbs + the xi forms) are shared by the
+  }                                       // two products and stay alive across the first one
   PARK_FENCE();
-  { const Fq6 a0 = unpark_fq6(park, 0); fq6_mul(&r0, &a0, &ni); }
+  { const Fq6 a0 = unpark_fq6(park, 0), nb = unpark_fq6(park, 6); fq6_mul(&r0, &a0, &nb); }
   park_fq6(park, 0, r0);
   PARK_FENCE();
-  { const Fq6 a1 = unpark_fq6(park, 3); fq6_mul(&r1, &a1, &ni); }
+  { const Fq6 a1 = unpark_fq6(park, 3), nb = unpark_fq6(park, 6); fq6_mul(&r1, &a1, &nb); }
   PARK_FENCE();
   r->c0 = unpark_fq6(park, 0);
   r->c1 = fq6_neg(r1);
@@ -384,17 +394,27 @@ static KTOWER void fq12_frob(Fq12* r, const Fq12* a, int k) {
 }
 
 // Granger-Scott squaring on the cyclotomic subgroup: three Fq4 squarings (x + y s)^2 = (x^2 + xi y^2) + 2 x y s, each as
-//   t0 = x x + (xi y) y   one stream of four Fq products      (bound 3 + 33)
-//   t1 = (2x) y           one dual stream                      (bound 2 + 4)
+//   t0 = x^2 + (xi y) y   one stream of THREE Fq products: x^2 costs a lane one product -- even lane (x0 + x1)(x0 - x1 + 2p), odd lane
+//                         x0 (2 x1) -- where the general Fq2 product costs it two      (bound 6 + 33)
+//   t1 = (2x) y           one dual stream                                              (bound 2 + 4)
 // then the linear recombination in the saturated words.
 KDEV void fq4_sqr(Fq2d* t0, Fq2d* t1, const Fq2d& x, const Fq2d& y) {
+  const bool odd = lane_odd() != 0;
   const XF xx = x_of(cut(x.v)), xy = x_of(cut(y.v));
   const XF xxy = x_of(xi_limbs(xy.s, xy.o, Q29::K2));
-  const YF yx = y_of(xx.s, Q29::K2), yy = y_of(xy.s, Q29::K2);
+  const YF yy = y_of(xy.s, Q29::K2);
+  U29 sx, sy;
   XF x2;
 #pragma unroll
-  for (int i = 0; i < 9; i++) { x2.s.l[i] = 2u * xx.s.l[i]; x2.o.l[i] = 2u * xx.o.l[i]; }      // limbs < 2^30: within the dual stream's budget
-  t0->v = pack(dot2(xx, yx, xxy, yy));
+  for (int i = 0; i < 9; i++) {
+    sx.l[i] = odd ? xx.o.l[i] : xx.s.l[i] + xx.o.l[i];                            // limbs < 2^30: one side of a product may be that wide
+    sy.l[i] = odd ? 2u * xx.s.l[i] : xx.s.l[i] - xx.o.l[i] + Q29::K2[i];
+    x2.s.l[i] = 2u * xx.s.l[i]; x2.o.l[i] = 2u * xx.o.l[i];                       // limbs < 2^30: within the dual stream's budget
+  }
+  sy = carry(sy);
+  U29 r;
+  u29_dot3_asm(r.l, sx.l, sy.l, xxy.s.l, yy.y0.l, xxy.o.l, yy.y1.l);
+  t0->v = pack(r);
   t1->v = pack(dot1(x2, yy));
 }
 template <bool PARK = false>

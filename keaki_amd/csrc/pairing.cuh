@@ -151,10 +151,18 @@ KDEV void slot_store(Fq* __restrict__ ws, size_t ws_n, u32 slot, u32 i, const Fq
 }
 
 // the final exponentiation: FE_PROG on the accumulator `acc` (= the Miller loop's output on entry, the GT element on exit)
-static KTOWER void fe_run(Fq12* acc, Fq* __restrict__ ws, size_t ws_n, u32 item, uint4* park) {
+// The lane's item index waits in LDS (chunk PARK_CHUNKS of `park`) and is read where it is needed: a register that lives from the kernel's
+// entry to its output is the one value hipcc spills to scratch memory.
+KDEV void item_park(uint4* park, u32 i) { reinterpret_cast<u32*>(park + PARK_CHUNKS * 64)[threadIdx.x] = i; }
+KDEV u32 item_unpark(const uint4* park) {
+  asm volatile("" ::: "memory");
+  return reinterpret_cast<const u32*>(park + PARK_CHUNKS * 64)[threadIdx.x];
+}
+static KTOWER void fe_run(Fq12* acc, Fq* __restrict__ ws, size_t ws_n, uint4* park) {
 #pragma unroll 1
   for (int pc = 0; pc < FE_NOPS; pc++) {
     const u32 op = FE_PROG[pc], code = op & 15u, s = op >> 4;
+    const u32 item = item_unpark(park);
     if (code == 0) {
       slot_load(acc, ws, ws_n, s, item);
     } else if (code == 1) {
@@ -227,7 +235,8 @@ static __global__ void __launch_bounds__(64, 2) k_pairing(PairArgs a) {
   const u32 item = t >> 1;
   const bool live = item < a.n;
   const u32 i = live ? item : (a.n - 1);
-  __shared__ uint4 park[PARK_CHUNKS * 64];
+  __shared__ uint4 park[PARK_CHUNKS * 64 + 16];     // + 64 words: the lanes' item indices
+  item_park(park, i);
   Fq12 f;
   bool ident = false;
   if (a.mode & PAIR_MILLER) {
@@ -246,18 +255,22 @@ static __global__ void __launch_bounds__(64, 2) k_pairing(PairArgs a) {
   } else {
     Fq2d* c = reinterpret_cast<Fq2d*>(&f);
 #pragma unroll 1
-    for (int k = 0; k < 6; k++) park_fq(park, k, to261(a.f_in[(size_t)12 * i + 2 * k + lane_odd()]));
+    for (int k = 0; k < 6; k++) park_fq(park, k, to261(a.f_in[(size_t)12 * item_unpark(park) + 2 * k + lane_odd()]));
 #pragma unroll
     for (int k = 0; k < 6; k++) c[k].v = unpark_fq(park, k);
   }
-  if (a.mode & PAIR_FINAL_EXP) fe_run(&f, a.ws, a.ws_n, i, park);
+  if (a.mode & PAIR_FINAL_EXP) fe_run(&f, a.ws, a.ws_n, park);
   if (ident) fq12_set_one(&f);
-  if (!live) return;
+  // the item index again, from a thread index the compiler cannot connect to the one of the kernel's entry (it would keep -- spill -- that one)
+  u32 tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const u32 item_out = (blockIdx.x * blockDim.x + tid) >> 1;
+  if (item_out >= a.n) return;
   if (a.mode & PAIR_OUT_BYTES) {
-    gt_serialize((u32*)a.out + (size_t)96 * i, &f, park);
+    gt_serialize((u32*)a.out + (size_t)96 * item_out, &f, park);
   } else {
     const Fq2d* c = reinterpret_cast<const Fq2d*>(&f);
-    Fq* o = (Fq*)a.out + (size_t)12 * i;
+    Fq* o = (Fq*)a.out + (size_t)12 * item_out;
 #pragma unroll
     for (int k = 0; k < 6; k++) park_fq(park, k, c[k].v);
 #pragma unroll 1
