@@ -7,8 +7,8 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MSM_KERNEL_SOURCES = ["msm.cuh", "msm_host.cuh", "msm_g1.hip", "fq29.cuh", "fq29_core.cuh", "fq29_asm.cuh", "xyzz29.cuh", "jac29.cuh",
                       "bn254_field.cuh", "bn254_field_asm.cuh", "bn254_curve.cuh"]
-PAIRING_KERNEL_SOURCES = ["pairing.cuh", "pairing.hip", "fq29.cuh", "fq29_core.cuh", "fq29_asm.cuh", "bn254_field.cuh", "bn254_field_asm.cuh",
-                          "bn254_curve.cuh"]
+PAIRING_KERNEL_SOURCES = ["pairing.cuh", "pairing.hip", "pair261.cuh", "pair261_constants.cuh", "fq29.cuh", "fq29_core.cuh", "fq29_asm.cuh",
+                          "fq29_dot_asm.cuh", "bn254_field.cuh", "bn254_field_asm.cuh", "bn254_curve.cuh"]
 
 
 def source_hash(files=MSM_KERNEL_SOURCES) -> str:
