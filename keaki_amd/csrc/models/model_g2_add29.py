@@ -147,6 +147,69 @@ def add_mixed(acc, q):
     return (X3, Y3, ZZ3, ZZZ3)
 
 
+def renorm(c):
+    return mul(c, ONE)
+
+
+def add_full(a, b):
+    """general XYZZ addition of two lazy accumulators (the MSM tail: k_msm_reduce and friends): every component below 4p, X below 2p."""
+    X1, Y1, ZZ1, ZZZ1 = a
+    X2, Y2, ZZ2, ZZZ2 = b
+    U1 = l2_mul(X1, ZZ2, K[2]); U2 = l2_mul(X2, ZZ1, K[2])
+    S1 = l2_mul(Y1, ZZZ2, K[4]); S2 = l2_mul(Y2, ZZZ1, K[4])
+    for n, v in (("fU", U1), ("fU", U2), ("fS", S1), ("fS", S2)):
+        note(n, v[0], 1.2); note(n, v[1], 1.2)
+    Pd = l2_sub(U2, U1, K[2]); Rd = l2_sub(S2, S1, K[2])
+    for c in Pd + Rd: note("fPR", c, 3.2)
+    PP = l2_sqr(Pd, K[4])
+    for c in PP: note("fPP", c, 1.3)
+    PPP = l2_mul(Pd, PP, K[4]); Q = l2_mul(U1, PP, K[2])
+    for c in PPP + Q: note("fPPPQ", c, 1.15)
+    RR = l2_sqr(Rd, K[4])
+    for c in RR: note("fRR", c, 1.3)
+    X3raw = tuple(carry([RR[j][i] - PPP[j][i] - 2 * Q[j][i] + K31[4][i] for i in range(9)]) for j in range(2))
+    for c in X3raw: note("fX3raw", c, 5.3)
+    X3 = tuple(renorm(c) for c in X3raw)
+    for c in X3: note("fX3", c, 1.1)
+    T = l2_sub(Q, X3, K[2])
+    for c in T: note("fT", c, 3.2)
+    nR1 = carry(neg_raw_any(Rd[1], K[4])); nS0 = carry(neg_raw_any(S1[0], K[2])); nS1 = carry(neg_raw_any(S1[1], K[2]))
+    Y3 = (dot4([(Rd[0], T[0]), (nR1, T[1]), (nS0, PPP[0]), (S1[1], PPP[1])]),
+          dot4([(Rd[0], T[1]), (Rd[1], T[0]), (nS0, PPP[1]), (nS1, PPP[0])]))
+    for c in Y3: note("fY3", c, 1.3)
+    ZZ3 = l2_mul(l2_mul(ZZ1, ZZ2, K[4]), PP, K[2]); ZZZ3 = l2_mul(l2_mul(ZZZ1, ZZZ2, K[4]), PPP, K[2])
+    for c in ZZ3 + ZZZ3: note("fZZ", c, 1.1)
+    return (X3, Y3, ZZ3, ZZZ3)
+
+
+def dbl_full(a):
+    """XYZZ doubling (a = 0) of a lazy accumulator: dbl-2008-s-1"""
+    X1, Y1, ZZ1, ZZZ1 = a
+    U = tuple(carry([2 * c[i] for i in range(9)]) for c in Y1)
+    for c in U: note("dU", c, 8)
+    V = l2_sqr(U, K[8])
+    for c in V: note("dV", c, 2.6)
+    Wd = l2_mul(U, V, K[8]); S = l2_mul(X1, V, K[2])
+    for c in Wd: note("dW", c, 1.3)
+    for c in S: note("dS", c, 1.1)
+    XX = l2_sqr(X1, K[2])
+    M = tuple(carry([3 * c[i] for i in range(9)]) for c in XX)
+    for c in M: note("dM", c, 3.4)
+    MM = l2_sqr(M, K[4])
+    for c in MM: note("dMM", c, 1.35)
+    X3raw = tuple(carry([MM[j][i] - 2 * S[j][i] + K31[4][i] for i in range(9)]) for j in range(2))
+    X3 = tuple(renorm(c) for c in X3raw)
+    for c in X3: note("dX3", c, 1.1)
+    T = l2_sub(S, X3, K[2])
+    nM1 = carry(neg_raw_any(M[1], K[4])); nW0 = carry(neg_raw_any(Wd[0], K[2])); nW1 = carry(neg_raw_any(Wd[1], K[2]))
+    Y3 = (dot4([(M[0], T[0]), (nM1, T[1]), (nW0, Y1[0]), (Wd[1], Y1[1])]),
+          dot4([(M[0], T[1]), (M[1], T[0]), (nW0, Y1[1]), (nW1, Y1[0])]))
+    for c in Y3: note("dY3", c, 1.3)
+    ZZ3 = l2_mul(V, ZZ1, K[4]); ZZZ3 = l2_mul(Wd, ZZZ1, K[2])
+    for c in ZZ3 + ZZZ3: note("dZZ", c, 1.2)
+    return (X3, Y3, ZZ3, ZZZ3)
+
+
 def neg_raw_any(b, k):
     x = [k[i] - b[i] for i in range(9)]
     assert all(0 <= v < 1 << 32 for v in x)
@@ -166,6 +229,27 @@ def ref_add(acc, q):
     X3 = f2s(f2s(f2m(Rd, Rd), PPP), ((2 * Q[0]) % P, (2 * Q[1]) % P))
     Y3 = f2s(f2m(Rd, f2s(Q, X3)), f2m(Y1, PPP))
     return (X3, Y3, f2m(ZZ, PP), f2m(ZZZ, PPP))
+
+
+def ref_add_full(a, b):
+    X1, Y1, ZZ1, ZZZ1 = a
+    X2, Y2, ZZ2, ZZZ2 = b
+    U1 = f2m(X1, ZZ2); U2 = f2m(X2, ZZ1); S1 = f2m(Y1, ZZZ2); S2 = f2m(Y2, ZZZ1)
+    Pd = f2s(U2, U1); Rd = f2s(S2, S1)
+    PP = f2m(Pd, Pd); PPP = f2m(Pd, PP); Q = f2m(U1, PP)
+    X3 = f2s(f2s(f2m(Rd, Rd), PPP), ((2 * Q[0]) % P, (2 * Q[1]) % P))
+    Y3 = f2s(f2m(Rd, f2s(Q, X3)), f2m(S1, PPP))
+    return (X3, Y3, f2m(f2m(ZZ1, ZZ2), PP), f2m(f2m(ZZZ1, ZZZ2), PPP))
+
+
+def ref_dbl(a):
+    X1, Y1, ZZ1, ZZZ1 = a
+    U = ((2 * Y1[0]) % P, (2 * Y1[1]) % P)
+    V = f2m(U, U); Wd = f2m(U, V); S = f2m(X1, V)
+    XX = f2m(X1, X1); M = ((3 * XX[0]) % P, (3 * XX[1]) % P)
+    X3 = f2s(f2m(M, M), ((2 * S[0]) % P, (2 * S[1]) % P))
+    Y3 = f2s(f2m(M, f2s(S, X3)), f2m(Wd, Y1))
+    return (X3, Y3, f2m(V, ZZ1), f2m(Wd, ZZZ1))
 
 
 def res(l):          # residue of a lazy 2^261-form value
@@ -193,7 +277,36 @@ def run(trials=400, seed=1):
             assert got == racc, (t, step)
             for n, c, b in (("X", acc[0], 2), ("Y", acc[1], 4), ("ZZ", acc[2], 4), ("ZZZ", acc[3], 4)):
                 note(n + "acc", c[0], b); note(n + "acc", c[1], b)
+    run_tail(trials // 2, seed + 1)
     return maxima
+
+
+def run_tail(trials, seed):
+    """the tail's working form: accumulators that are loads of reduced values (< 2p) or outputs of add_full / dbl_full, in any mix"""
+    rng = random.Random(seed)
+
+    def fresh(worst):
+        top = 12 * P // 10                                                  # l2_from_fq2 = (x << 5) * one / 2^261 < (32 / 169 + 1) p
+        v = lambda: (top - 1 if worst else rng.randrange(top))
+        return tuple((limbs(v()), limbs(v())) for _ in range(4))
+    for t in range(trials):
+        worst = t < 10
+        acc = fresh(worst)
+        racc = tuple((res(c[0]), res(c[1])) for c in acc)
+        for step in range(8):
+            kind = rng.randrange(3)
+            if kind == 0:
+                acc = dbl_full(acc); racc = ref_dbl(racc)
+            else:
+                other = fresh(worst) if kind == 1 else acc_prev if step else fresh(worst)
+                rother = tuple((res(c[0]), res(c[1])) for c in other)
+                acc_prev = acc
+                acc = add_full(acc, other); racc = ref_add_full(racc, rother)
+            if kind == 0:
+                acc_prev = acc
+            assert tuple((res(c[0]), res(c[1])) for c in acc) == racc, (t, step, kind)
+            for n, c, b in (("tX", acc[0], 2), ("tY", acc[1], 4), ("tZZ", acc[2], 4), ("tZZZ", acc[3], 4)):
+                note(n, c[0], b); note(n, c[1], b)
 
 
 if __name__ == "__main__":

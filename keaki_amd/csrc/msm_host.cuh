@@ -65,7 +65,8 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   if ((double)n * s.W >= 4294967295.0) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: n * windows overflows 32-bit positions");
   // reduce chunk length: the kernel is a serial chain of 2L additions (+ a scalar multiplication by the chunk index) per lane; measured:
   // 16 is best from 2^19 buckets on (2^20 .. 2^24 points), 8 below (2^18 points: 1.01 vs 1.09 ms)
-  u32 L = plan.max_b >= (1u << 19) ? 16 : (plan.max_b >= 64 ? 8 : plan.max_b);
+  // (G2, whose additions cost 2.3 x as much: 8 from 2^19 buckets on as well -- 5.10 vs 5.34 ms at 2^20 points)
+  u32 L = plan.max_b >= (1u << 19) ? (sizeof(F) > sizeof(Fq) ? 8 : 16) : (plan.max_b >= 64 ? 8 : plan.max_b);
   if (const char* e = getenv("KEAKI_REDUCE_L")) { int v = atoi(e); if (v >= 1 && v <= 4096 && (u32)v <= plan.max_b) L = (u32)v; }
   const u32 chunks = cdiv(plan.max_b, L);
   ST_TRY(reserve(ctx, ctx->wsums, (size_t)rs.W * sizeof(Xyzz<F>)));

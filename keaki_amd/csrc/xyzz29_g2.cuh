@@ -16,6 +16,7 @@
 #include "bn254_curve.cuh"
 #include "fq29.cuh"
 #include "fq29_dot_asm.cuh"
+#include "xyzz29.cuh"
 
 namespace bn254 {
 
@@ -105,5 +106,92 @@ KDEV void x29g2_add_mixed(X29G2& acc, const Aff<Fq2>& q) {
   acc.zzz = l2_mul(acc.zzz, PPP, Q29::K4);
   acc.x = X3; acc.y = Y3;
 }
+
+
+// ---- the MSM tail on G2 (k_msm_reduce, k_msm_partial_groups, k_msm_window_finish): general addition and doubling of two lazy accumulators.
+// Working form: every component a load of a reduced value (l2_from_fq2, < 1.2p) or an output of these functions (< 1.2p: X3 is brought back
+// by the product by `one` as in the mixed addition). models/model_g2_add29.py (add_full, dbl_full, run_tail) runs the same operations in
+// the same order with assertions on every limb and bound. Bounds: U, S < 1.1; P, R < 3.2; PP, RR < 1.3; T < 3.2; doubling: U = 2Y < 2.4,
+// V < 1.2, M = 3 X^2 < 3.4.
+KDEV L2 l2_renorm(const U29& ta, const U29& tb) {
+  const U29 one = u29_one();
+  return {u29_mul(u29_carry(ta), one), u29_mul(u29_carry(tb), one)};
+}
+KDEV X29G2 x29g2_dbl(const X29G2& a) {
+  if (a.empty) return a;
+  L2 U;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { U.a.l[i] = 2u * a.y.a.l[i]; U.b.l[i] = 2u * a.y.b.l[i]; }
+  U.a = u29_carry(U.a); U.b = u29_carry(U.b);
+  const L2 V = l2_sqr(U, Q29::K8), W = l2_mul(U, V, Q29::K8), S = l2_mul(a.x, V, Q29::K2), XX = l2_sqr(a.x, Q29::K2);
+  L2 M;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { M.a.l[i] = 3u * XX.a.l[i]; M.b.l[i] = 3u * XX.b.l[i]; }
+  M.a = u29_carry(M.a); M.b = u29_carry(M.b);
+  const L2 MM = l2_sqr(M, Q29::K4);
+  X29G2 r;
+  {
+    U29 ta, tb;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      ta.l[i] = MM.a.l[i] - 2u * S.a.l[i] + Q29::K4W[i];
+      tb.l[i] = MM.b.l[i] - 2u * S.b.l[i] + Q29::K4W[i];
+    }
+    r.x = l2_renorm(ta, tb);
+  }
+  const L2 T = l2_sub(S, r.x, Q29::K2);
+  const U29 nM1 = u29_neg_carried(M.b, Q29::K4), nW0 = u29_neg_carried(W.a, Q29::K2), nW1 = u29_neg_carried(W.b, Q29::K2);
+  u29_dot4_asm(r.y.a.l, M.a.l, T.a.l, nM1.l, T.b.l, nW0.l, a.y.a.l, W.b.l, a.y.b.l);        // M0 T0 - M1 T1 - W0 Y0 + W1 Y1
+  u29_dot4_asm(r.y.b.l, M.a.l, T.b.l, M.b.l, T.a.l, nW0.l, a.y.b.l, nW1.l, a.y.a.l);        // M0 T1 + M1 T0 - W0 Y1 - W1 Y0
+  r.zz = l2_mul(V, a.zz, Q29::K4);
+  r.zzz = l2_mul(W, a.zzz, Q29::K2);
+  r.empty = false;
+  return r;
+}
+KDEV X29G2 x29g2_add(const X29G2& a, const X29G2& b) {
+  if (a.empty) return b;
+  if (b.empty) return a;
+  const L2 U1 = l2_mul(a.x, b.zz, Q29::K2), U2 = l2_mul(b.x, a.zz, Q29::K2);
+  const L2 S1 = l2_mul(a.y, b.zzz, Q29::K4), S2 = l2_mul(b.y, a.zzz, Q29::K4);
+  const L2 P = l2_sub(U2, U1, Q29::K2), R = l2_sub(S2, S1, Q29::K2);
+  if (u29_maybe_zero(P.a) && u29_maybe_zero(P.b)) {
+    if (u29_is_zero(P.a) && u29_is_zero(P.b)) {
+      if (u29_is_zero(R.a) && u29_is_zero(R.b)) return x29g2_dbl(a);
+      return x29g2_inf();
+    }
+  }
+  const L2 PP = l2_sqr(P, Q29::K4);
+  const L2 PPP = l2_mul(P, PP, Q29::K4), Q = l2_mul(U1, PP, Q29::K2);
+  const L2 RR = l2_sqr(R, Q29::K4);
+  X29G2 r;
+  {
+    U29 ta, tb;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      ta.l[i] = RR.a.l[i] - PPP.a.l[i] - 2u * Q.a.l[i] + Q29::K4W[i];
+      tb.l[i] = RR.b.l[i] - PPP.b.l[i] - 2u * Q.b.l[i] + Q29::K4W[i];
+    }
+    r.x = l2_renorm(ta, tb);
+  }
+  const L2 T = l2_sub(Q, r.x, Q29::K2);
+  const U29 nR1 = u29_neg_carried(R.b, Q29::K4), nS0 = u29_neg_carried(S1.a, Q29::K2), nS1 = u29_neg_carried(S1.b, Q29::K2);
+  u29_dot4_asm(r.y.a.l, R.a.l, T.a.l, nR1.l, T.b.l, nS0.l, PPP.a.l, S1.b.l, PPP.b.l);       // R0 T0 - R1 T1 - S0 PPP0 + S1 PPP1
+  u29_dot4_asm(r.y.b.l, R.a.l, T.b.l, R.b.l, T.a.l, nS0.l, PPP.b.l, nS1.l, PPP.a.l);       // R0 T1 + R1 T0 - S0 PPP1 - S1 PPP0
+  r.zz = l2_mul(l2_mul(a.zz, b.zz, Q29::K4), PP, Q29::K2);
+  r.zzz = l2_mul(l2_mul(a.zzz, b.zzz, Q29::K4), PPP, Q29::K2);
+  r.empty = false;
+  return r;
+}
+
+// the working point of the MSM tail for G2 (see TailOps in xyzz29.cuh)
+template <>
+struct TailOps<Fq2> {
+  typedef X29G2 P;
+  static KDEV P inf() { return x29g2_inf(); }
+  static KDEV P load(const Xyzz<Fq2>& p) { return x29g2_load(p); }
+  static KDEV Xyzz<Fq2> store(const P& p) { return x29g2_store(p); }
+  static KDEV P add(const P& a, const P& b) { return x29g2_add(a, b); }
+  static KDEV P dbl(const P& a) { return x29g2_dbl(a); }
+};
 
 }  // namespace bn254
