@@ -70,7 +70,7 @@ def main():
                 timed(r, 1, lambda: hip.fk_shard_setup(fks[r], 1, 0, recv[r].value))
             for r in range(world):
                 timed(r, 2, lambda: hip.fk_shard_open(fks[r], 0, send[r].value, 0, coeffs=p))
-            all_to_all(a2a_big)
+            all_to_all(a2a_small)
             for r in range(world):
                 timed(r, 3, lambda: hip.fk_shard_open(fks[r], 1, send[r].value, recv[r].value))
             all_to_all(a2a_small)
@@ -89,7 +89,7 @@ def main():
             row["per_rank"][str(world)] = {"hat_s_setup_s": round(float(tt[:, :2].sum(axis=1).max()), 4), "open_s": round(float(per_rank_open.max()), 4),
                                            "open_steps_s": [round(float(x), 4) for x in tt[:, 2:].max(axis=0)],
                                            "speedup_vs_unsharded": round(t_plain / float(per_rank_open.max()), 2),
-                                           "bytes_sent_per_rank": (world - 1) * (a2a_big + a2a_small + gather), "equals_unsharded": bool(ok)}
+                                           "bytes_sent_per_rank": (world - 1) * (2 * a2a_small + gather), "equals_unsharded": bool(ok)}
             for fk in fks:
                 fk.free()
             for m in send + recv:

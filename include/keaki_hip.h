@@ -111,7 +111,7 @@ keaki_status keaki_hip_g1_sum(keaki_hip_ctx* ctx, const uint64_t* points_jac, si
  * All d = 2^log2d opening proofs of the polynomial p (d coefficients) at the d-th roots of unity, in O(d log d) group operations
  * (three G1 FFTs + 2d scalar-mults on the GPU). The scalar-field inputs are prepared by the caller (keaki's own host-side work):
  *   hat_a[2d]     = DFT_2d(0, ..., 0, p_0, ..., p_{d-1}) * (2d)^-1        (the 1/2d of the inverse transform folded in)
- *   tw_2d[d]      = omega_2d^k,  tw_2d_inv[d] = omega_2d^-k   (k < d),    tw_d[d/2] = omega_d^k   (k < d/2)
+ *   tw_2d[d]      = omega_2d^k,  tw_2d_inv[d] = omega_2d^-k   (k < d),    tw_d[d/2] = omega_d^k   (k < d/2; not read any more, may be NULL)
  * where omega_N is ark-poly's Radix2EvaluationDomain generator of order N. Uses srs[0..d). proofs_out_aff: d affine points.
  * The SRS-only transform hat_s = DFT_2d(reversed SRS) is computed on the first call for a given d and cached in the handle. */
 keaki_status keaki_hip_open_fk(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32_t log2d, const uint64_t* hat_a, const uint64_t* tw_2d,
@@ -125,22 +125,22 @@ keaki_status keaki_hip_open_fk_poly(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, u
  * first keaki_hip_open_fk[_poly] with this d does not pay for it (it depends on the SRS only; the calls cache it on first use anyway). */
 keaki_status keaki_hip_srs_g1_precompute_fk(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32_t log2d, const uint64_t* omega_2d);
 /* ---- FK23 sharded over `world` = 2^k ranks (one rank = one ctx = one GPU): kzg::open_fk (src/kzg.rs:157-203) of BASELINE config 5 on N GPUs.
- * The three group FFTs are split so that every rank does 1/world of the butterflies and of the 2d scalar-mults. The library runs NO
+ * The group transforms are split so that every rank does 1/world of the butterflies and of the 2d scalar-mults. The library runs NO
  * collective: a step leaves this rank's outgoing data in d_send, the CALLER exchanges (RCCL over xGMI: all-to-all with equal splits,
  * received chunks in rank order; one all-gather at the end) and hands d_recv to the next step. Steps are asynchronous on the ctx stream
  * like every *_dev entry: order the collective behind them (same stream, or keaki_hip_synchronize) and the next step behind it.
- * Needs d >= world^2 and the whole SRS (srs[0..d)) on every rank. d_send / d_recv: device buffers of sizes[0] bytes each.
- *   setup (once per handle; hat_s = DFT_2d of the reversed SRS, this rank's part):
- *     step 0 -> d_send | all-to-all, sizes[1] bytes per peer | step 1 <- d_recv
+ * Needs d >= world^2 and the whole SRS (srs[0..d)) on every rank. d_send / d_recv: device buffers of sizes4[0] bytes each.
+ *   setup (once per handle; the SRS-only transform, this rank's part):
+ *     step 0 -> d_send | all-to-all, sizes4[1] bytes per peer | step 1 <- d_recv
  *   open (per polynomial; coeffs: d Fr on the host, the same on every rank):
- *     step 0 (coeffs) -> d_send | all-to-all, sizes[1] per peer | step 1: d_recv -> d_send | all-to-all, sizes[2] per peer |
- *     step 2: d_recv -> d_send = d/world affine proofs | all-gather, sizes[3] per rank | step 3: d_recv -> proofs_out_aff (host, d affine
+ *     step 0 (coeffs) -> d_send | all-to-all, sizes4[2] per peer | step 1: d_recv -> d_send | all-to-all, sizes4[2] per peer |
+ *     step 2: d_recv -> d_send = d/world affine proofs | all-gather, sizes4[3] per rank | step 3: d_recv -> proofs_out_aff (host, d affine
  *     points in natural order, the bytes keaki_hip_open_fk_poly returns). */
 typedef struct keaki_hip_fk_shard keaki_hip_fk_shard;
 keaki_status keaki_hip_fk_shard_create(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, uint32_t log2d, uint32_t rank, uint32_t world,
                                        const uint64_t* omega_2d, const uint64_t* omega_2d_inv, const uint64_t* inv_2d, keaki_hip_fk_shard** out);
 void keaki_hip_fk_shard_free(keaki_hip_ctx* ctx, keaki_hip_fk_shard* fk);
-/* sizes4[0..4): [0] = bytes of d_send / d_recv; [1], [2] = bytes per peer of the two kinds of all-to-all; [3] = bytes per rank of the all-gather */
+/* sizes4[0..4): [0] = bytes of d_send / d_recv; [1] = bytes per peer of the setup's all-to-all, [2] of each of a call's two; [3] = bytes per rank of the all-gather */
 keaki_status keaki_hip_fk_shard_sizes(const keaki_hip_fk_shard* fk, size_t* sizes4);
 keaki_status keaki_hip_fk_shard_setup(keaki_hip_ctx* ctx, keaki_hip_fk_shard* fk, int32_t step, void* d_send, void* d_recv);
 keaki_status keaki_hip_fk_shard_open(keaki_hip_ctx* ctx, keaki_hip_fk_shard* fk, int32_t step, const uint64_t* coeffs, void* d_send, void* d_recv,

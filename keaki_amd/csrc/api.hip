@@ -616,7 +616,7 @@ keaki_status keaki_hip_open_fk(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32
                                const uint64_t* tw_2d_inv, const uint64_t* tw_d, uint64_t* proofs_out_aff) {
   CTX_GUARD(ctx);
   TRACE_SCOPE("keaki.open_fk");
-  if (!srs || !hat_a || !tw_2d || !tw_2d_inv || (!tw_d && log2d > 0) || !proofs_out_aff || log2d > 27) return fail(ctx, KEAKI_ERR_BAD_ARG, "open_fk: bad argument");
+  if (!srs || !hat_a || !tw_2d || !tw_2d_inv || !proofs_out_aff || log2d > 27) return fail(ctx, KEAKI_ERR_BAD_ARG, "open_fk: bad argument");
   const size_t d = (size_t)1 << log2d;
   if (d > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "open_fk: %zu coefficients but the SRS holds %zu points", d, srs->n);
   // one staging buffer: hat_a (2d Fr) | tw_2d (d) | tw_2d_inv (d) | tw_d (d/2) | work (2d Jacobian) | proofs (d affine)
@@ -628,14 +628,14 @@ keaki_status keaki_hip_open_fk(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32
   HIP_TRY(ctx, hipMemcpyAsync(b + o_ha, hat_a, 2 * d * 32, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(b + o_t1, tw_2d, d * 32, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(b + o_t2, tw_2d_inv, d * 32, hipMemcpyHostToDevice, st));
-  if (d >= 2) HIP_TRY(ctx, hipMemcpyAsync(b + o_t3, tw_d, (d / 2) * 32, hipMemcpyHostToDevice, st));
+  (void)tw_d;                       // the size-d transforms take every second entry of the 2d tables
   if (srs->fk_log2d != (int)log2d) {
     if (srs->fk_hat_s) { HIP_TRY(ctx, hipStreamSynchronize(st)); (void)hipFree(srs->fk_hat_s); srs->fk_hat_s = nullptr; srs->fk_log2d = -1; }
     HIP_TRY(ctx, hipMalloc(&srs->fk_hat_s, 2 * d * 96));
     ST_TRY(fk_hat_s_run(ctx, srs->d, log2d, b + o_t1, srs->fk_hat_s));
     srs->fk_log2d = (int)log2d;
   }
-  ST_TRY(open_fk_run(ctx, srs->fk_hat_s, log2d, b + o_ha, b + o_t2, b + o_t3, b + o_w, b + o_p));
+  ST_TRY(open_fk_run(ctx, srs->fk_hat_s, log2d, b + o_ha, b + o_t1, b + o_t2, b + o_w, b + o_p));
   return download(ctx, proofs_out_aff, b + o_p, d * 64);
 }
 
@@ -690,7 +690,7 @@ size_t fk_shard_buffer_bytes(const keaki_hip_fk_shard* fk) {
   return std::max(2 * d / fk->world * 96, d * 64);
 }
 void fk_shard_release(keaki_hip_fk_shard* fk) {
-  for (void** p : {&fk->plan.tw, &fk->plan.twi, &fk->plan.hat_a, &fk->plan.coeffs, &fk->plan.hat_s, &fk->plan.work})
+  for (void** p : {&fk->plan.tw, &fk->plan.twi, &fk->plan.hat_a, &fk->plan.coeffs, &fk->plan.hat_s, &fk->plan.work, &fk->plan.e})
     if (*p) { (void)hipFree(*p); *p = nullptr; }
 }
 }  // namespace
@@ -714,7 +714,7 @@ keaki_status keaki_hip_fk_shard_create(keaki_hip_ctx* ctx, const keaki_hip_srs_g
   const size_t m = 2 * d / world;
   keaki_status st = KEAKI_OK;
   const std::pair<void**, size_t> want[] = {{&fk->plan.tw, d * 32}, {&fk->plan.twi, d * 32}, {&fk->plan.hat_a, 2 * d * 32}, {&fk->plan.coeffs, d * 32},
-                                            {&fk->plan.hat_s, m * 96}, {&fk->plan.work, m * 96}};
+                                            {&fk->plan.hat_s, m * 96}, {&fk->plan.work, m * 96}, {&fk->plan.e, m / 2 * 96}};
   for (auto& w : want)
     if (st == KEAKI_OK) st = dev_alloc(ctx, w.first, w.second);
   if (st != KEAKI_OK) { fk_shard_release(fk); delete fk; return st; }
@@ -735,8 +735,8 @@ keaki_status keaki_hip_fk_shard_sizes(const keaki_hip_fk_shard* fk, size_t* out4
   if (!fk || !out4) return KEAKI_ERR_BAD_ARG;
   const size_t d = (size_t)1 << fk->plan.log2d, R = fk->world;
   out4[0] = fk_shard_buffer_bytes(fk);
-  out4[1] = 2 * d / R / R * 96;      // all-to-all of the 2d-point transforms: bytes per peer
-  out4[2] = d / R / R * 96;          // all-to-all of the d-point transform
+  out4[1] = 2 * d / R / R * 96;      // the setup's all-to-all (two d-point transforms in one exchange): bytes per peer
+  out4[2] = d / R / R * 96;          // the two all-to-alls of a call (one d-point transform each)
   out4[3] = d / R * 64;              // all-gather of the affine proofs: bytes per rank
   return KEAKI_OK;
 }

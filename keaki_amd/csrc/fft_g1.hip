@@ -2,14 +2,19 @@
 //
 // Replaces kzg::open_fk (reference src/kzg.rs:157-203; caller src/vec.rs:40), whose work is three ark-poly group FFTs
 // (`domain_2d.fft(&s)`, `domain_2d.ifft(&hat_h)`, `domain_d.fft(&h)`) and 2d scalar multiplications (`hat_s[i].mul(hat_a[i])`,
-// :189-191). Here:
-//   S[i] = [tau^(d-1-i)]_1 (i < d), identity (i >= d)            k_fk_load          (SRS reversed, src/kzg.rs:166-174)
-//   hat_s <- DFT_2d(S)                                           k_bitrev + k_g1_fft_stage x log2(2d); cached per (SRS, d)
-//   S[i] <- hat_a[i] * hat_s[i]                                  k_g1_mul_jac_oop   (hat_a = DFT_2d(0..0, p) / 2d, from the host)
-//   S <- DFT_2d^-1(S) (scaling folded into hat_a); h = S[0..d]   same kernels with inverse twiddles
-//   proofs <- DFT_d(h), normalised to affine                     k_g1_fft_stage x log2(d), k_g1_jac_to_aff
-// A butterfly is one scalar multiplication of a Jacobian point by a twiddle factor plus an add and a subtract; one lane
-// per butterfly, N/2 lanes per stage. Twiddle tables (omega^k, k < N/2) come from the host (scalar-field work stays there).
+// :189-191). The same proofs with a third less work: with V = hat_a o hat_s (the 2d products) and w = omega_2d,
+//   h_i = (1/2) (DFT_d^-1(V_even)_i + w^-i DFT_d^-1(V_odd)_i)  (i < d)   =>   proofs = DFT_d(h) = (1/2) V_even + (1/2) DFT_d(D o DFT_d^-1(V_odd))
+// (D_i = w^-i): the even half of the products IS half of the answer, only the odd half goes through one inverse and one forward transform of
+// size d with a twist between them -- d (log2 d + 3) scalar multiplications instead of the d (1.5 log2 d + 3) of the three transforms
+// (24 d instead of 34.5 d at d = 2^21). Forward transforms run decimation-in-frequency (natural order in, bit-reversed positions out), the
+// inverse one decimation-in-time (bit-reversed in, natural out), so the only permutation is the one on the d affine proofs at the end:
+//   hat_s <- DIF_2d(S), S[i] = [tau^(d-1-i)]_1 (i < d), identity (i >= d)     k_fk_load + stages; cached per (SRS, d). Position q < d holds
+//                                                                             hat_s[2 brev(q)], position d + q holds hat_s[2 brev(q) + 1]
+//   E[q] = (d a[2 brev(q)]) hat_s[q],  O[q] = a[2 brev(q) + 1] hat_s[d + q]   k_fk_pointwise   (a = DFT_2d(0..0, p) / 2d, natural order)
+//   O <- DIT_d (inverse twiddles), O[i] <- w^-i O[i], O <- DIF_d              k_g1_fft_stage_map, k_g1_mul_jac_strided
+//   proofs[brev(q)] = affine(E[q] + O[q])                                     k_fk_finish
+// A butterfly is one scalar multiplication of a Jacobian point by a twiddle factor plus an add and a subtract; one lane per butterfly.
+// tests/fk_shard_model.py::open_fk_split is this pipeline over Z_q, index for index.
 #include "ec_batch.cuh"
 #include "jac29.cuh"
 #include "internal.h"
@@ -30,36 +35,6 @@ static __global__ void __launch_bounds__(256) k_fk_load(const G1Aff* __restrict_
   if (i >= 2 * d) return;
   s[i] = i < d ? jac_from_aff(srs[d - 1 - i]) : jac_inf<Fq>();
 }
-static __global__ void __launch_bounds__(256) k_bitrev_jac(G1Jac* __restrict__ a, u32 log2n) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (1u << log2n)) return;
-  u32 r = __brev(i) >> (32 - log2n);
-  if (i < r) { G1Jac t = a[i]; a[i] = a[r]; a[r] = t; }
-}
-// stage with butterfly span `len`: for block blk and j < len/2: (u, v) = (a[i], w^j a[i + len/2]), w = omega^(n/len).
-// Lane order: while a stage still has at least 64 blocks, consecutive lanes take the SAME j in different blocks, so a wave shares one
-// twiddle and the ladder's digit branches are wave-uniform (with one twiddle per lane every iteration of every wave pays for both
-// additions: 258 instead of ~86 per scalar multiplication). The last six stages have fewer blocks than a wave has lanes.
-static __global__ void __launch_bounds__(64) k_g1_fft_stage(G1Jac* __restrict__ a, const Fr* __restrict__ tw, u32 n, u32 len) {
-  u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= n / 2) return;
-  const u32 half = len >> 1, nblocks = n / len;
-  u32 j, blk;
-  if (nblocks >= 64) { blk = b % nblocks; j = b / nblocks; }
-  else { j = b % half; blk = b / half; }
-  const u32 i0 = blk * len + j, i1 = i0 + half;
-  Fr w = tw[(size_t)j * nblocks];
-  G1Jac u = a[i0], v = a[i1];
-  if (!fr_is_one(w)) v = jac_scalar_mul(v, w);
-  a[i0] = jac_add(u, v);
-  v.y = -v.y;
-  a[i1] = jac_add(u, v);
-}
-static __global__ void __launch_bounds__(64) k_g1_mul_jac(G1Jac* __restrict__ a, const Fr* __restrict__ s, u32 n) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  a[i] = jac_scalar_mul(a[i], s[i]);
-}
 static __global__ void __launch_bounds__(64) k_g1_jac_to_aff(const G1Jac* __restrict__ a, u32 n, G1Aff* __restrict__ out) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -67,10 +42,10 @@ static __global__ void __launch_bounds__(64) k_g1_jac_to_aff(const G1Jac* __rest
 }
 
 // ---- FK23 sharded over R = 2^rho ranks (keaki_hip_fk_shard_*; index maps modelled in tests/fk_shard_model.py) ---------------------
-// A transform of N = R * M points never exists in one memory. Two layouts of the N positions over the ranks:
+// A transform of d = R * M points never exists in one memory. Two layouts of the d positions over the ranks:
 //   cyclic: rank r holds position i = k R + r at local index k     (the HIGH log2 M bits of a position are local)
 //   block:  rank r holds position i = r M + k at local index k     (the LOW  log2 M bits are local)
-// A radix-2 stage of span `len` pairs positions that differ in bit log2(len) - 1, so spans 2R..N run on the cyclic layout, spans 2..M
+// A radix-2 stage of span `len` pairs positions that differ in bit log2(len) - 1, so spans 2R..d run on the cyclic layout, spans 2..M
 // on the block layout, and ONE all-to-all (the caller's: RCCL over xGMI) switches between them. Forward transforms run
 // decimation-in-frequency (natural order in, bit-reversed positions out: cyclic -> block), the inverse one decimation-in-time
 // (bit-reversed in, natural out: block -> cyclic), so no bit-reversal permutation -- which would be a second all-to-all -- is needed
@@ -116,12 +91,59 @@ static __global__ void __launch_bounds__(256) k_jac_transpose(const G1Jac* __res
   const u32 r = i / cols, c = i % cols;
   out[(size_t)c * rows + r] = in[i];
 }
-// out[k] = hat_a[bitrev(base + k)] * hat_s[k]: hat_s is held at bit-reversed positions, hat_a in natural order
-static __global__ void __launch_bounds__(64) k_g1_mul_jac_brev(const G1Jac* __restrict__ in, const Fr* __restrict__ s, u32 log2n, u32 base, u32 m,
-                                                               G1Jac* __restrict__ out) {
+KDEV u32 brev_bits(u32 x, u32 bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
+// s * 2^k in the scalar field (k doublings: the factor d of the even half)
+KDEV Fr fr_shl(Fr s, u32 k) {
+  for (u32 i = 0; i < k; i++) s = fp_add<FrParams>(s, s);
+  return s;
+}
+// The 2m products of the positions [base, base + m) of the d: lane t < 2m, part = t / m, k = t % m, q = base + k:
+//   part 0: out_e[k] = (d a[2 brev(q)]) hs_even[k]        part 1: out_o[k] = a[2 brev(q) + 1] hs_odd[k]
+// (un-sharded: base = 0, m = d, hs_even = hat_s, hs_odd = hat_s + d, out_e = work, out_o = work + d)
+static __global__ void __launch_bounds__(64) k_fk_pointwise(const G1Jac* __restrict__ hs_even, const G1Jac* __restrict__ hs_odd, const Fr* __restrict__ a,
+                                                            u32 log2d, u32 base, u32 m, G1Jac* __restrict__ out_e, G1Jac* __restrict__ out_o) {
+  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * m) return;
+  const u32 part = t >= m ? 1u : 0u, k = part ? t - m : t;
+  Fr sc = a[2 * (size_t)brev_bits(base + k, log2d) + part];
+  if (!part) sc = fr_shl(sc, log2d);
+  const G1Jac r = jac_scalar_mul(part ? hs_odd[k] : hs_even[k], sc);
+  if (part) out_o[k] = r; else out_e[k] = r;
+}
+// a[k] <- s[k * stride + offset] * a[k]   (the twist by omega_2d^-i: un-sharded stride 1, offset 0; cyclic layout stride R, offset rank)
+static __global__ void __launch_bounds__(64) k_g1_mul_jac_strided(G1Jac* __restrict__ a, const Fr* __restrict__ s, u32 stride, u32 offset, u32 m) {
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= m) return;
-  out[k] = jac_scalar_mul(in[k], s[__brev(base + k) >> (32 - log2n)]);
+  a[k] = jac_scalar_mul(a[k], s[(size_t)k * stride + offset]);
+}
+static __global__ void __launch_bounds__(64) k_g1_mul_jac_strided_oop(const G1Jac* __restrict__ in, const Fr* __restrict__ s, u32 stride, u32 offset, u32 m,
+                                                                      G1Jac* __restrict__ out) {
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m) return;
+  out[k] = jac_scalar_mul(in[k], s[(size_t)k * stride + offset]);
+}
+// out[perm(k)] = affine(e[k] + o[k]); natural == true: perm = bit reversal over log2d bits of (base + k) (un-sharded), else perm = k (this
+// rank's d / R proofs in position order; the permutation happens after the all-gather)
+static __global__ void __launch_bounds__(64) k_fk_finish(const G1Jac* __restrict__ e, const G1Jac* __restrict__ o, u32 m, u32 log2d, bool natural,
+                                                         G1Aff* __restrict__ out) {
+  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m) return;
+  out[natural ? brev_bits(k, log2d) : k] = jac_to_aff(jac_add(e[k], o[k]));
+}
+// the layout switch of TWO arrays in one exchange: the chunk for / from rank q is [part 0 | part 1], c points each
+//   pack:   send[(q * 2 + part) * c + t] = arr[part * m + q * c + t]          (arr = [part 0 (m) | part 1 (m)], m = R c)
+//   unpack: arr[part * m + t * R + q] = recv[(q * 2 + part) * c + t]          (with the transpose to the block layout)
+static __global__ void __launch_bounds__(256) k_fk_pack2(const G1Jac* __restrict__ arr, u32 R, u32 c, G1Jac* __restrict__ send) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * R * c) return;
+  const u32 t = i % c, part = (i / c) & 1u, q = i / (2 * c);
+  send[i] = arr[(size_t)part * R * c + q * c + t];
+}
+static __global__ void __launch_bounds__(256) k_fk_unpack2(const G1Jac* __restrict__ recv, u32 R, u32 c, G1Jac* __restrict__ arr) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * R * c) return;
+  const u32 t = i % c, part = (i / c) & 1u, q = i / (2 * c);
+  arr[(size_t)part * R * c + (size_t)t * R + q] = recv[i];
 }
 // proofs[bitrev(q)] = gathered[q]
 static __global__ void __launch_bounds__(256) k_aff_unscramble(const G1Aff* __restrict__ in, u32 log2d, G1Aff* __restrict__ out) {
@@ -222,38 +244,34 @@ static __global__ void __launch_bounds__(64) k_fr_horner_down(const Fr* __restri
 namespace keaki_internal {
 using namespace bn254;
 
-static keaki_status g1_fft(keaki_hip_ctx* ctx, G1Jac* a, u32 log2n, const Fr* tw) {
-  const u32 n = 1u << log2n;
-  hipLaunchKernelGGL(k_bitrev_jac, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, a, log2n);
-  for (u32 len = 2; len <= n; len <<= 1)
-    hipLaunchKernelGGL(k_g1_fft_stage, dim3(cdiv(n / 2, 64)), dim3(64), 0, ctx->stream, a, tw, n, len);
-  return launch_check(ctx, "g1_fft");
+static void stage_map(keaki_hip_ctx* ctx, bool dit, G1Jac* a, const Fr* tw, u32 m, u32 half, u32 A, u32 B, u32 stride) {
+  if (dit) hipLaunchKernelGGL(k_g1_fft_stage_map<true>, dim3(cdiv(m / 2, 64)), dim3(64), 0, ctx->stream, a, tw, m, half, A, B, stride);
+  else hipLaunchKernelGGL(k_g1_fft_stage_map<false>, dim3(cdiv(m / 2, 64)), dim3(64), 0, ctx->stream, a, tw, m, half, A, B, stride);
 }
 
-// out[i] = s[i] * in[i] (out-of-place pointwise product; in = cached hat_s)
-static __global__ void __launch_bounds__(64) k_g1_mul_jac_oop(const G1Jac* __restrict__ in, const Fr* __restrict__ s, u32 n, G1Jac* __restrict__ out) {
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  out[i] = jac_scalar_mul(in[i], s[i]);
-}
-
-// hat_s = DFT_2d(reversed SRS padded with identities): depends on the SRS only, so it is computed once per (SRS, d) and cached.
+// hat_s = DIF_2d(reversed SRS padded with identities): depends on the SRS only, so it is computed once per (SRS, d) and cached.
+// d_tw2d: omega_2d^k, k < d.
 keaki_status fk_hat_s_run(keaki_hip_ctx* ctx, const void* d_srs, u32 log2d, const void* d_tw2d, void* d_hat_s) {
-  const u32 d = 1u << log2d;
+  const u32 d = 1u << log2d, N = 2 * d;
   G1Jac* s = (G1Jac*)d_hat_s;
-  hipLaunchKernelGGL(k_fk_load, dim3(cdiv(2 * d, 256)), dim3(256), 0, ctx->stream, (const G1Aff*)d_srs, d, s);
-  return g1_fft(ctx, s, log2d + 1, (const Fr*)d_tw2d);
+  hipLaunchKernelGGL(k_fk_load, dim3(cdiv(N, 256)), dim3(256), 0, ctx->stream, (const G1Aff*)d_srs, d, s);
+  for (u32 half = d; half >= 1; half >>= 1) stage_map(ctx, false, s, (const Fr*)d_tw2d, N, half, 1, 0, N / (2 * half));
+  return launch_check(ctx, "fk_hat_s");
 }
-// d = 2^log2d openings from the cached hat_s. d_work: 2d Jacobian points. d_hat_a: 2d Fr (already divided by 2d).
-// d_tw2d_inv: d Fr (omega_2d^-k); d_twd: d/2 Fr (omega_d^k). Output: d affine proofs.
-keaki_status open_fk_run(keaki_hip_ctx* ctx, const void* d_hat_s, u32 log2d, const void* d_hat_a, const void* d_tw2d_inv, const void* d_twd,
+// d = 2^log2d openings from the cached hat_s. d_work: 2d Jacobian points. d_hat_a: 2d Fr, natural order, already divided by 2d.
+// d_tw2d: omega_2d^k, d_tw2d_inv: omega_2d^-k (k < d). Output: d affine proofs, natural order.
+keaki_status open_fk_run(keaki_hip_ctx* ctx, const void* d_hat_s, u32 log2d, const void* d_hat_a, const void* d_tw2d, const void* d_tw2d_inv,
                          void* d_work, void* d_proofs_aff) {
   const u32 d = 1u << log2d;
-  G1Jac* s = (G1Jac*)d_work;
-  hipLaunchKernelGGL(k_g1_mul_jac_oop, dim3(cdiv(2 * d, 64)), dim3(64), 0, ctx->stream, (const G1Jac*)d_hat_s, (const Fr*)d_hat_a, 2 * d, s);
-  ST_TRY(g1_fft(ctx, s, log2d + 1, (const Fr*)d_tw2d_inv));
-  if (log2d > 0) ST_TRY(g1_fft(ctx, s, log2d, (const Fr*)d_twd));
-  hipLaunchKernelGGL(k_g1_jac_to_aff, dim3(cdiv(d, 64)), dim3(64), 0, ctx->stream, (const G1Jac*)s, d, (G1Aff*)d_proofs_aff);
+  hipStream_t st = ctx->stream;
+  const G1Jac* hs = (const G1Jac*)d_hat_s;
+  G1Jac *e = (G1Jac*)d_work, *o = e + d;
+  const Fr *tw = (const Fr*)d_tw2d, *twi = (const Fr*)d_tw2d_inv;
+  hipLaunchKernelGGL(k_fk_pointwise, dim3(cdiv(2 * d, 64)), dim3(64), 0, st, hs, hs + d, (const Fr*)d_hat_a, log2d, 0u, d, e, o);
+  for (u32 half = 1; 2 * half <= d; half <<= 1) stage_map(ctx, true, o, twi, d, half, 1, 0, 2 * (d / (2 * half)));
+  hipLaunchKernelGGL(k_g1_mul_jac_strided, dim3(cdiv(d, 64)), dim3(64), 0, st, o, twi, 1u, 0u, d);
+  for (u32 half = d / 2; half >= 1; half >>= 1) stage_map(ctx, false, o, tw, d, half, 1, 0, 2 * (d / (2 * half)));
+  hipLaunchKernelGGL(k_fk_finish, dim3(cdiv(d, 64)), dim3(64), 0, st, (const G1Jac*)e, (const G1Jac*)o, d, log2d, true, (G1Aff*)d_proofs_aff);
   return launch_check(ctx, "open_fk");
 }
 
@@ -282,7 +300,7 @@ keaki_status fr_fft_run(keaki_hip_ctx* ctx, void* d_data, u32 log2n, const uint6
   return launch_check(ctx, "fr_fft_run");
 }
 // FK23 from the polynomial itself: everything (twiddles, hat_a) is derived on the device from three scalars.
-// d_p: d Fr coefficients. d_fr_work: room for (2d + d + d + d/2 + 1) Fr. d_g_work: 2d Jacobian points. Output: d affine proofs.
+// d_p: d Fr coefficients. d_fr_work: room for (2d + d + d + 1) Fr. d_g_work: 2d Jacobian points. Output: d affine proofs.
 keaki_status open_fk_poly_run(keaki_hip_ctx* ctx, const void* d_srs, void** hat_s_cache, int* hat_s_log2d, u32 log2d, const void* d_p,
                               const uint64_t* omega_2d, const uint64_t* omega_2d_inv, const uint64_t* inv_2d, void* d_fr_work, void* d_g_work,
                               void* d_proofs_aff) {
@@ -292,11 +310,9 @@ keaki_status open_fk_poly_run(keaki_hip_ctx* ctx, const void* d_srs, void** hat_
   Fr* hat_a = (Fr*)d_fr_work;
   Fr* tw = hat_a + 2 * (size_t)d;       // omega_2d^k,  k < d
   Fr* twi = tw + d;                      // omega_2d^-k, k < d
-  Fr* twd = twi + d;                     // omega_d^k,   k < d/2
   hipStream_t st = ctx->stream;
   hipLaunchKernelGGL(k_fr_powers, dim3(cdiv(d, 256)), dim3(256), 0, st, w, d, tw);
   hipLaunchKernelGGL(k_fr_powers, dim3(cdiv(d, 256)), dim3(256), 0, st, wi, d, twi);
-  if (d >= 2) hipLaunchKernelGGL(k_fr_stride2, dim3(cdiv(d / 2, 256)), dim3(256), 0, st, (const Fr*)tw, d / 2, twd);
   hipLaunchKernelGGL(k_fk_pad, dim3(cdiv(2 * d, 256)), dim3(256), 0, st, (const Fr*)d_p, d, hat_a);
   ST_TRY(fr_fft(ctx, hat_a, log2d + 1, tw, 1));
   hipLaunchKernelGGL(k_fr_scale, dim3(cdiv(2 * d, 256)), dim3(256), 0, st, hat_a, s, 2 * d);
@@ -306,14 +322,10 @@ keaki_status open_fk_poly_run(keaki_hip_ctx* ctx, const void* d_srs, void** hat_
     ST_TRY(fk_hat_s_run(ctx, d_srs, log2d, tw, *hat_s_cache));
     *hat_s_log2d = (int)log2d;
   }
-  return open_fk_run(ctx, *hat_s_cache, log2d, hat_a, twi, twd, d_g_work, d_proofs_aff);
+  return open_fk_run(ctx, *hat_s_cache, log2d, hat_a, tw, twi, d_g_work, d_proofs_aff);
 }
 
-// ---- FK23 sharded (keaki_hip_fk_shard_*): the steps between the caller's exchanges ------------------------------------------------
-static void stage_map(keaki_hip_ctx* ctx, bool dit, G1Jac* a, const Fr* tw, u32 m, u32 half, u32 A, u32 B, u32 stride) {
-  if (dit) hipLaunchKernelGGL(k_g1_fft_stage_map<true>, dim3(cdiv(m / 2, 64)), dim3(64), 0, ctx->stream, a, tw, m, half, A, B, stride);
-  else hipLaunchKernelGGL(k_g1_fft_stage_map<false>, dim3(cdiv(m / 2, 64)), dim3(64), 0, ctx->stream, a, tw, m, half, A, B, stride);
-}
+// ---- FK23 sharded (keaki_hip_fk_shard_*): the steps between the caller's exchanges; tests/fk_shard_model.py::ShardModel step for step -----
 static void fk_shard_tables(keaki_hip_ctx* ctx, FkShard& fk) {
   if (fk.tables_ready) return;
   const u32 d = 1u << fk.log2d;
@@ -323,31 +335,42 @@ static void fk_shard_tables(keaki_hip_ctx* ctx, FkShard& fk) {
   hipLaunchKernelGGL(k_fr_powers, dim3(cdiv(d, 256)), dim3(256), 0, ctx->stream, wi, d, (Fr*)fk.twi);
   fk.tables_ready = true;
 }
-// hat_s of this rank. step 0: cyclic slice of the reversed SRS, spans N..2R -> d_send (chunk for rank q = [q M/R, (q+1) M/R));
-// step 1: d_recv (chunk from rank q at q M/R) -> block layout, spans R..2 -> fk.hat_s.
+// one size-d transform, forward (decimation in frequency), distributed: spans d..2R on the cyclic layout, spans R..2 on the block layout
+static void dif_cyclic(keaki_hip_ctx* ctx, G1Jac* a, const Fr* tw, u32 d, u32 R, u32 r) {
+  const u32 Md = d / R;
+  for (u32 half = Md / 2; half >= 1; half >>= 1) stage_map(ctx, false, a, tw, Md, half, R, r, 2 * (d / (2 * half * R)));
+}
+static void dif_block(keaki_hip_ctx* ctx, G1Jac* a, u32 m, const Fr* tw, u32 d, u32 R) {      // m: local points (a multiple of R)
+  for (u32 half = R / 2; half >= 1; half >>= 1) stage_map(ctx, false, a, tw, m, half, 1, 0, 2 * (d / (2 * half)));
+}
+// hat_s of this rank: even entries = DFT_d(S), odd entries = DFT_d(S_i omega_2d^i), both at bit-reversed positions, block layout.
+// step 0: the cyclic slices, spans d..2R, packed [even | odd] per peer -> d_send; step 1: d_recv -> block layout, spans R..2 -> fk.hat_s.
 keaki_status fk_shard_setup_run(keaki_hip_ctx* ctx, FkShard& fk, const void* d_srs, int step, void* d_send, void* d_recv) {
-  const u32 d = 1u << fk.log2d, N = 2 * d, R = 1u << fk.rho, M = N / R, r = fk.rank;
+  const u32 d = 1u << fk.log2d, R = 1u << fk.rho, Md = d / R, r = fk.rank;
   hipStream_t st = ctx->stream;
   const Fr* tw = (const Fr*)fk.tw;
   if (step == 0) {
     fk_shard_tables(ctx, fk);
-    G1Jac* a = (G1Jac*)d_send;
-    hipLaunchKernelGGL(k_fk_load_cyclic, dim3(cdiv(M, 256)), dim3(256), 0, st, (const G1Aff*)d_srs, d, R, r, M, a);
-    for (u32 half = M / 2; half >= 1; half >>= 1) stage_map(ctx, false, a, tw, M, half, R, r, N / (2 * half * R));
+    G1Jac *ev = (G1Jac*)fk.work, *od = ev + Md;
+    hipLaunchKernelGGL(k_fk_load_cyclic, dim3(cdiv(Md, 256)), dim3(256), 0, st, (const G1Aff*)d_srs, d, R, r, Md, ev);      // all of them below d
+    hipLaunchKernelGGL(k_g1_mul_jac_strided_oop, dim3(cdiv(Md, 64)), dim3(64), 0, st, (const G1Jac*)ev, tw, R, r, Md, od);
+    dif_cyclic(ctx, ev, tw, d, R, r);
+    dif_cyclic(ctx, od, tw, d, R, r);
+    hipLaunchKernelGGL(k_fk_pack2, dim3(cdiv(2 * Md, 256)), dim3(256), 0, st, (const G1Jac*)ev, R, Md / R, (G1Jac*)d_send);
     return launch_check(ctx, "fk_shard_setup 0");
   }
-  G1Jac* a = (G1Jac*)fk.hat_s;
-  hipLaunchKernelGGL(k_jac_transpose, dim3(cdiv(M, 256)), dim3(256), 0, st, (const G1Jac*)d_recv, R, M / R, a);
-  for (u32 half = R / 2; half >= 1; half >>= 1) stage_map(ctx, false, a, tw, M, half, 1, 0, N / (2 * half));
+  G1Jac* hs = (G1Jac*)fk.hat_s;                 // [even (Md) | odd (Md)]
+  hipLaunchKernelGGL(k_fk_unpack2, dim3(cdiv(2 * Md, 256)), dim3(256), 0, st, (const G1Jac*)d_recv, R, Md / R, hs);
+  dif_block(ctx, hs, 2 * Md, tw, d, R);
   fk.hat_s_ready = true;
   return launch_check(ctx, "fk_shard_setup 1");
 }
-// the openings. step 0: hat_a (replicated scalar-field work), hat_a * hat_s, inverse transform spans 2..M (block) -> d_send packed for the
-// switch to cyclic; step 1: d_recv = cyclic layout, spans 2M..N, h = first half, DFT_d spans d..2R -> d_send; step 2: d_recv -> block layout,
-// spans R..2, to affine -> d_send (d/R affine points: positions [rank d/R, ..) of the bit-reversed proof order);
-// step 3: d_recv = all d affine points in position order -> d_out_aff in natural order.
+// the openings. step 0: hat_a (replicated scalar-field work), the 2 d/R products of this rank's positions (E kept in fk.e), inverse
+// transform spans 2..d/R (block) -> d_send packed for the switch to cyclic; step 1: d_recv = cyclic layout, spans 2d/R..d, the twist,
+// forward transform spans d..2R -> d_send; step 2: d_recv -> block layout, spans R..2, + E, to affine -> d_send (d/R affine points:
+// positions [rank d/R, ..) of the bit-reversed proof order); step 3: d_recv = all d affine points in position order -> d_out_aff natural.
 keaki_status fk_shard_open_run(keaki_hip_ctx* ctx, FkShard& fk, int step, void* d_send, void* d_recv, void* d_out_aff) {
-  const u32 d = 1u << fk.log2d, N = 2 * d, R = 1u << fk.rho, M = N / R, Md = d / R, r = fk.rank;
+  const u32 d = 1u << fk.log2d, N = 2 * d, R = 1u << fk.rho, Md = d / R, r = fk.rank;
   hipStream_t st = ctx->stream;
   const Fr *tw = (const Fr*)fk.tw, *twi = (const Fr*)fk.twi;
   if (step == 0) {
@@ -357,25 +380,26 @@ keaki_status fk_shard_open_run(keaki_hip_ctx* ctx, FkShard& fk, int step, void* 
     hipLaunchKernelGGL(k_fk_pad, dim3(cdiv(N, 256)), dim3(256), 0, st, (const Fr*)fk.coeffs, d, hat_a);
     ST_TRY(fr_fft(ctx, hat_a, fk.log2d + 1, tw, 1));
     hipLaunchKernelGGL(k_fr_scale, dim3(cdiv(N, 256)), dim3(256), 0, st, hat_a, s, N);
-    G1Jac* a = (G1Jac*)fk.work;
-    hipLaunchKernelGGL(k_g1_mul_jac_brev, dim3(cdiv(M, 64)), dim3(64), 0, st, (const G1Jac*)fk.hat_s, (const Fr*)hat_a, fk.log2d + 1, r * M, M, a);
-    for (u32 half = 1; 2 * half <= M; half <<= 1) stage_map(ctx, true, a, twi, M, half, 1, 0, N / (2 * half));
-    hipLaunchKernelGGL(k_jac_transpose, dim3(cdiv(M, 256)), dim3(256), 0, st, (const G1Jac*)a, M / R, R, (G1Jac*)d_send);
+    const G1Jac* hs = (const G1Jac*)fk.hat_s;
+    G1Jac* o = (G1Jac*)fk.work;
+    hipLaunchKernelGGL(k_fk_pointwise, dim3(cdiv(2 * Md, 64)), dim3(64), 0, st, hs, hs + Md, (const Fr*)hat_a, fk.log2d, r * Md, Md, (G1Jac*)fk.e, o);
+    for (u32 half = 1; 2 * half <= Md; half <<= 1) stage_map(ctx, true, o, twi, Md, half, 1, 0, 2 * (d / (2 * half)));
+    hipLaunchKernelGGL(k_jac_transpose, dim3(cdiv(Md, 256)), dim3(256), 0, st, (const G1Jac*)o, Md / R, R, (G1Jac*)d_send);
     return launch_check(ctx, "fk_shard_open 0");
   }
   if (step == 1) {
     G1Jac* a = (G1Jac*)d_recv;
-    for (u32 half = M / R; 2 * half <= M; half <<= 1) stage_map(ctx, true, a, twi, M, half, R, r, N / (2 * half * R));
-    G1Jac* h = (G1Jac*)d_send;
-    HIP_TRY(ctx, hipMemcpyAsync(h, a, (size_t)Md * sizeof(G1Jac), hipMemcpyDeviceToDevice, st));
-    for (u32 half = Md / 2; half >= 1; half >>= 1) stage_map(ctx, false, h, tw, Md, half, R, r, 2 * (d / (2 * half * R)));
+    for (u32 half = Md / R; 2 * half <= Md; half <<= 1) stage_map(ctx, true, a, twi, Md, half, R, r, 2 * (d / (2 * half * R)));
+    hipLaunchKernelGGL(k_g1_mul_jac_strided, dim3(cdiv(Md, 64)), dim3(64), 0, st, a, twi, R, r, Md);
+    dif_cyclic(ctx, a, tw, d, R, r);
+    HIP_TRY(ctx, hipMemcpyAsync(d_send, a, (size_t)Md * sizeof(G1Jac), hipMemcpyDeviceToDevice, st));
     return launch_check(ctx, "fk_shard_open 1");
   }
   if (step == 2) {
     G1Jac* a = (G1Jac*)fk.work;
     hipLaunchKernelGGL(k_jac_transpose, dim3(cdiv(Md, 256)), dim3(256), 0, st, (const G1Jac*)d_recv, R, Md / R, a);
-    for (u32 half = R / 2; half >= 1; half >>= 1) stage_map(ctx, false, a, tw, Md, half, 1, 0, 2 * (d / (2 * half)));
-    hipLaunchKernelGGL(k_g1_jac_to_aff, dim3(cdiv(Md, 64)), dim3(64), 0, st, (const G1Jac*)a, Md, (G1Aff*)d_send);
+    dif_block(ctx, a, Md, tw, d, R);
+    hipLaunchKernelGGL(k_fk_finish, dim3(cdiv(Md, 64)), dim3(64), 0, st, (const G1Jac*)fk.e, (const G1Jac*)a, Md, fk.log2d, false, (G1Aff*)d_send);
     return launch_check(ctx, "fk_shard_open 2");
   }
   hipLaunchKernelGGL(k_aff_unscramble, dim3(cdiv(d, 256)), dim3(256), 0, st, (const G1Aff*)d_recv, fk.log2d, (G1Aff*)d_out_aff);

@@ -126,7 +126,7 @@ keaki_status open_fk_poly_run(keaki_hip_ctx* ctx, const void* d_srs, void** hat_
 keaki_status fk_precompute_run(keaki_hip_ctx* ctx, const void* d_srs, void** hat_s_cache, int* hat_s_log2d, uint32_t log2d, const uint64_t* omega_2d,
                                void* d_tw_work);
 keaki_status fk_hat_s_run(keaki_hip_ctx* ctx, const void* d_srs, uint32_t log2d, const void* d_tw2d, void* d_hat_s);
-keaki_status open_fk_run(keaki_hip_ctx* ctx, const void* d_hat_s, uint32_t log2d, const void* d_hat_a, const void* d_tw2d_inv, const void* d_twd,
+keaki_status open_fk_run(keaki_hip_ctx* ctx, const void* d_hat_s, uint32_t log2d, const void* d_hat_a, const void* d_tw2d, const void* d_tw2d_inv,
                          void* d_work, void* d_proofs_aff);
 // FK23 sharded over 2^rho ranks (fft_g1.hip): this rank's plan and device buffers (owned by the api layer)
 struct FkShard {
@@ -135,6 +135,7 @@ struct FkShard {
   void *tw = nullptr, *twi = nullptr;     // omega_2d^k, omega_2d^-k, k < d
   void *hat_a = nullptr, *coeffs = nullptr;   // 2d Fr, d Fr
   void *hat_s = nullptr, *work = nullptr;     // 2d / R Jacobian points each
+  void *e = nullptr;                          // d / R Jacobian points: the even half of the products, from step 0 to step 2
   bool tables_ready = false, hat_s_ready = false;
 };
 keaki_status fk_shard_setup_run(keaki_hip_ctx* ctx, FkShard& fk, const void* d_srs, int step, void* d_send, void* d_recv);

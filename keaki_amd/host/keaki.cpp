@@ -479,7 +479,7 @@ std::vector<G1> ShardedOpenFk::open(const std::vector<Fr>& p, void* d_send, void
   const Device& dev = *setup_.device();
   dev.check(keaki_hip_fk_shard_open(dev.ctx(), fk_, 0, p[0].l, d_send, nullptr, nullptr));
   dev.check(keaki_hip_synchronize(dev.ctx()));
-  if (ex.all_to_all(ex.user, d_send, d_recv, sizes_[1])) throw std::runtime_error("ShardedOpenFk: the caller's all-to-all failed");
+  if (ex.all_to_all(ex.user, d_send, d_recv, sizes_[2])) throw std::runtime_error("ShardedOpenFk: the caller's all-to-all failed");
   dev.check(keaki_hip_fk_shard_open(dev.ctx(), fk_, 1, nullptr, d_send, d_recv, nullptr));
   dev.check(keaki_hip_synchronize(dev.ctx()));
   if (ex.all_to_all(ex.user, d_send, d_recv, sizes_[2])) throw std::runtime_error("ShardedOpenFk: the caller's all-to-all failed");

@@ -68,7 +68,7 @@ def sharded_open_all_ranks(hip, mem, srs, log2d, R, p_mont, roots, n_polys=1):
         for p in p_mont[:n_polys]:
             for r in range(R):
                 hip.fk_shard_open(fks[r], 0, send[r], 0, coeffs=p)
-            all_to_all(hip, mem, send, recv, a2a_big)
+            all_to_all(hip, mem, send, recv, a2a_small)
             for r in range(R):
                 hip.fk_shard_open(fks[r], 1, send[r], recv[r])
             all_to_all(hip, mem, send, recv, a2a_small)

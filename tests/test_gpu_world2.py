@@ -63,9 +63,9 @@ def test_world2_laconic_ot(multirank_runs):
     j = _json_line(run["log"])
     assert j["n_gpus"] == 2 and j["ranks_seen"] == 2
     assert j["all_messages_recovered"] is True and j["sharded_equals_single_process"] is True
-    # the FK23 openings were computed by the sharded pipeline (two all-to-alls + one all-gather per call, one all-to-all at setup)
+    # the FK23 openings were computed by the sharded pipeline (one all-to-all at setup; two smaller ones + one all-gather per call)
     d = 1024
-    assert j["fk_sharded"] is True and j["fk_exchange_bytes_sent_per_rank"] == (2 * d // 4 * 96) * 2 + d // 4 * 96 + d // 2 * 64
+    assert j["fk_sharded"] is True and j["fk_exchange_bytes_sent_per_rank"] == 2 * d // 4 * 96 + 2 * (d // 4 * 96) + d // 2 * 64
 
 
 def test_world4_and_world3_laconic_ot(multirank_runs):
