@@ -135,7 +135,8 @@ keaki_status keaki_hip_srs_g1_precompute_fk(keaki_hip_ctx* ctx, keaki_hip_srs_g1
  *   open (per polynomial; coeffs: d Fr on the host, the same on every rank):
  *     step 0 (coeffs) -> d_send | all-to-all, sizes4[2] per peer | step 1: d_recv -> d_send | all-to-all, sizes4[2] per peer |
  *     step 2: d_recv -> d_send = d/world affine proofs | all-gather, sizes4[3] per rank | step 3: d_recv -> proofs_out_aff (host, d affine
- *     points in natural order, the bytes keaki_hip_open_fk_poly returns). */
+ *     points in natural order, the bytes keaki_hip_open_fk_poly returns).
+ * A step out of order is refused (KEAKI_ERR_BAD_ARG); open step 0 may always start over. `srs` must outlive the handle. */
 typedef struct keaki_hip_fk_shard keaki_hip_fk_shard;
 keaki_status keaki_hip_fk_shard_create(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, uint32_t log2d, uint32_t rank, uint32_t world,
                                        const uint64_t* omega_2d, const uint64_t* omega_2d_inv, const uint64_t* inv_2d, keaki_hip_fk_shard** out);

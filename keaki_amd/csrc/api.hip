@@ -681,8 +681,9 @@ keaki_status keaki_hip_fr_fft(keaki_hip_ctx* ctx, uint64_t* data, uint32_t log2n
 // ---- FK23 sharded over `world` = 2^k ranks: one handle per rank, the caller runs the exchanges between the steps -----------------
 struct keaki_hip_fk_shard {
   FkShard plan;
-  const keaki_hip_srs_g1* srs = nullptr;
+  const keaki_hip_srs_g1* srs = nullptr;      // must outlive the handle
   uint32_t world = 0;
+  int setup_next = 0, open_next = 0;          // the step each sequence expects next (a skipped exchange cannot be detected, a skipped step can)
 };
 namespace {
 size_t fk_shard_buffer_bytes(const keaki_hip_fk_shard* fk) {
@@ -744,7 +745,10 @@ keaki_status keaki_hip_fk_shard_setup(keaki_hip_ctx* ctx, keaki_hip_fk_shard* fk
   CTX_GUARD(ctx);
   TRACE_SCOPE("keaki.fk_shard_setup");
   if (!fk || step < 0 || step > 1 || (step == 0 && !d_send) || (step == 1 && !d_recv)) return fail(ctx, KEAKI_ERR_BAD_ARG, "fk_shard_setup: bad argument");
-  return fk_shard_setup_run(ctx, fk->plan, fk->srs->d, step, d_send, d_recv);
+  if (step != fk->setup_next) return fail(ctx, KEAKI_ERR_BAD_ARG, "fk_shard_setup: step %d out of order (step %d is next)", step, fk->setup_next);
+  ST_TRY(fk_shard_setup_run(ctx, fk->plan, fk->srs->d, step, d_send, d_recv));
+  fk->setup_next = step + 1;
+  return KEAKI_OK;
 }
 keaki_status keaki_hip_fk_shard_open(keaki_hip_ctx* ctx, keaki_hip_fk_shard* fk, int32_t step, const uint64_t* coeffs, void* d_send, void* d_recv,
                                      uint64_t* proofs_out_aff) {
@@ -755,10 +759,17 @@ keaki_status keaki_hip_fk_shard_open(keaki_hip_ctx* ctx, keaki_hip_fk_shard* fk,
   const size_t d = (size_t)1 << fk->plan.log2d;
   if ((step == 0 && (!coeffs || !d_send)) || (step == 1 && (!d_send || !d_recv)) || (step == 2 && (!d_send || !d_recv)) || (step == 3 && (!d_recv || !proofs_out_aff)))
     return fail(ctx, KEAKI_ERR_BAD_ARG, "fk_shard_open: step %d is missing a buffer", step);
+  if (step != fk->open_next && step != 0)      // step 0 may always start a new polynomial
+    return fail(ctx, KEAKI_ERR_BAD_ARG, "fk_shard_open: step %d out of order (step %d is next)", step, fk->open_next);
   if (step == 0) HIP_TRY(ctx, hipMemcpyAsync(fk->plan.coeffs, coeffs, d * 32, hipMemcpyHostToDevice, ctx->stream));
-  if (step < 3) return fk_shard_open_run(ctx, fk->plan, step, d_send, d_recv, nullptr);
+  if (step < 3) {
+    ST_TRY(fk_shard_open_run(ctx, fk->plan, step, d_send, d_recv, nullptr));
+    fk->open_next = step + 1;
+    return KEAKI_OK;
+  }
   ST_TRY(reserve(ctx, ctx->io_d, d * 64));
   ST_TRY(fk_shard_open_run(ctx, fk->plan, 3, nullptr, d_recv, ctx->io_d.p));
+  fk->open_next = 0;
   return download(ctx, proofs_out_aff, ctx->io_d.p, d * 64);
 }
 

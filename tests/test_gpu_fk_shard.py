@@ -126,6 +126,8 @@ def test_sharded_fk_argument_errors(oc, py, hip, rand_fr):
         try:
             with pytest.raises(KeakiHipError):                     # open before setup
                 hip.fk_shard_open(fk, 0, 1, 0, coeffs=mont(oc, rand_fr(d, 1901)))
+            with pytest.raises(KeakiHipError):                     # setup step 1 before step 0
+                hip.fk_shard_setup(fk, 1, 0, 1)
         finally:
             fk.free()
     finally:
