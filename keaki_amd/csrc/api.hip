@@ -173,8 +173,6 @@ void keaki_hip_ctx_destroy(keaki_hip_ctx* ctx) {
                     &ctx->fb_scalars, &ctx->fb_g1_gen, &ctx->fb_g2_gen, &ctx->fb_com, &ctx->fb_tau, &ctx->perm, &ctx->g2gen_lines, &ctx->gt_tab_a, &ctx->gt_tab_b, &ctx->gt_base, &ctx->heavy, &ctx->pair_ws, &ctx->verify_lines, &ctx->verify_io, &ctx->fbs_scalars, &ctx->fbs_g2_gen, &ctx->fbs_tau})
     if (b->p) (void)hipFree(b->p);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
-  for (auto& e : ctx->aux_ev) if (e) (void)hipEventDestroy(e);
-  if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -49,8 +49,6 @@ struct keaki_hip_ctx {
   keaki_internal::DevBuf fbs_scalars, fbs_g2_gen, fbs_tau;     // small (8-bit) tables of g2 and [tau]_2 for batches below 256 items
   bool fbs_ready = false, fbs_tau_valid = false;
   uint64_t fbs_tau_pt[16] = {};
-  hipStream_t aux_stream = nullptr;       // second stream of the MSM: partition of the next bucket range under the bucket kernel of this one
-  hipEvent_t aux_ev[9] = {};
   // instrumentation
   bool timing = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -256,12 +256,12 @@ static __global__ void k_part_total(const u32* __restrict__ counts, const u32* _
 template <u32 P2_CAP>
 static __global__ void __launch_bounds__(P2_THREADS) k_part_fine(const u64* __restrict__ entries, const u32* __restrict__ offsets, PartShape ps,
                                                                  const u32* __restrict__ total_ptr, u32 nbuckets_total, u32* __restrict__ bucket_offsets,
-                                                                 u32* __restrict__ bucket_counts, u32* __restrict__ sorted, u32 bin0) {
+                                                                 u32* __restrict__ bucket_counts, u32* __restrict__ sorted) {
   __shared__ u32 pay[P2_CAP];
   __shared__ u32 hist[PART_MAX_FINE];
   __shared__ u32 cursor[PART_MAX_FINE];
   __shared__ u32 wsum[P2_THREADS / 64];
-  const u32 bin = bin0 + blockIdx.x, nf = 1u << ps.shift, mask = nf - 1u, t = threadIdx.x;      // bin0: the launch covers the bins from there on
+  const u32 bin = blockIdx.x, nf = 1u << ps.shift, mask = nf - 1u, t = threadIdx.x;
   const u32 lo = offsets[(size_t)bin * ps.nwg];
   const u32 hi = (bin + 1 < ps.nbins) ? offsets[(size_t)(bin + 1) * ps.nwg] : *total_ptr;
   const u32 m = hi - lo;

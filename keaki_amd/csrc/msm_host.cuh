@@ -1,7 +1,6 @@
 // Host-side driver of the MSM pipeline (workspace sizing, window choice, kernel sequence), written
 // once and instantiated for G1 (msm_g1.hip) and G2 (msm_g2.hip).
 #pragma once
-#include <algorithm>
 #include <type_traits>
 #include "internal.h"
 #include "msm.cuh"
@@ -38,14 +37,6 @@ inline keaki_status device_scan(keaki_hip_ctx* ctx, const u32* in, u32 len, u32*
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, bs, nblocks, 0u);
   hipLaunchKernelGGL(k_scan_apply, dim3(nblocks), dim3(SCAN_THREADS), 0, ctx->stream, in, len, (const u32*)bs, out);
   return launch_check(ctx, "scan");
-}
-
-// the second stream of the MSM (and the events that order it against the caller's), created on first use
-inline keaki_status msm_aux_stream(keaki_hip_ctx* ctx) {
-  if (ctx->aux_stream) return KEAKI_OK;
-  HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-  for (auto& e : ctx->aux_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  return KEAKI_OK;
 }
 
 // d_table != nullptr: precomputed path (tables built by msm_build_tables with window target c_table for N = srs_len points)
@@ -114,108 +105,58 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   hipLaunchKernelGGL(k_part_scatter, dim3(ps.nwg), dim3(P1_THREADS), 0, st, (const Fr*)d_scalars, s, ps, (const u32*)poffsets, (const u32*)pcounts_t, entries);
   ST_TRY(launch_check(ctx, "part_scatter"));
   hipLaunchKernelGGL(k_part_total, dim3(1), dim3(64), 0, st, (const u32*)pcounts, (const u32*)poffsets, (u32)ncounts, poffsets + ncounts);
-  // From here on the buckets are handled in `parts` ranges of coarse bins: the fine partition and the size sort of range k + 1 run on a
-  // second stream while the bucket kernel of range k runs on the caller's (the partition is bound by LDS and HBM, the bucket kernel by the
-  // multiplier: they share the CUs without slowing each other; 2^24 points: the MSM goes from 17.8 to 16.9 ms). One range = the old flow.
-  const size_t total_pairs = n * (size_t)s.W;
-  u32 parts = 1;
-  {
-    static const int env_parts = getenv("KEAKI_MSM_PARTS") ? atoi(getenv("KEAKI_MSM_PARTS")) : 4;
-    if (env_parts > 1 && total_pairs >= ((size_t)1 << 24) && ps.nbins >= 64) parts = env_parts < 8 ? (u32)env_parts : 8u;
-  }
-  if (parts > 1) ST_TRY(msm_aux_stream(ctx));
   static const bool p2_small = getenv("KEAKI_P2_SMALL") && atoi(getenv("KEAKI_P2_SMALL")) != 0;
-  // per range: size-sort tables and the heavy-bucket list: [bucket[cap] | first[cap] | owner[slice_cap]] then the slice sums
-  const size_t cnt_bytes = ((2 * CNT_BINS * 4 + sizeof(HeavyList)) + 255) & ~(size_t)255;
-  ST_TRY(reserve(ctx, ctx->perm, nb * 4 + 256 + parts * cnt_bytes));
+  if (p2_small)
+    hipLaunchKernelGGL((k_part_fine<P2_CAP_SMALL>), dim3(ps.nbins), dim3(P2_THREADS), 0, st, (const u64*)entries, (const u32*)poffsets, ps,
+                       (const u32*)(poffsets + ncounts), (u32)nb, offsets, hist, sorted);
+  else
+    hipLaunchKernelGGL((k_part_fine<P2_CAP_BIG>), dim3(ps.nbins), dim3(P2_THREADS), 0, st, (const u64*)entries, (const u32*)poffsets, ps,
+                       (const u32*)(poffsets + ncounts), (u32)nb, offsets, hist, sorted);
+  ST_TRY(launch_check(ctx, "part_fine"));
+  // bucket schedule: descending size
+  ST_TRY(reserve(ctx, ctx->perm, nb * 4 + 2 * CNT_BINS * 4 + sizeof(HeavyList)));
   u32* perm = (u32*)ctx->perm.p;
-  char* cnt_base = (char*)ctx->perm.p + ((nb * 4 + 255) & ~(size_t)255);
+  u32 *gstart = perm + nb, *ghist = gstart + CNT_BINS;
+  HeavyList* hv = (HeavyList*)(ghist + CNT_BINS);                        // right behind the histogram: one memset clears both
+  HIP_TRY(ctx, hipMemsetAsync(ghist, 0, CNT_BINS * 4 + sizeof(HeavyList), st));
+  // heavy-bucket list: [bucket[cap] | first[cap] | owner[slice_cap]] then the slice sums
+  const size_t total_pairs = n * (size_t)s.W;
   const u32 hv_cap = (u32)(total_pairs / HEAVY_MIN + 1), hv_slice_cap = (u32)(hv_cap + total_pairs / HEAVY_SLICE + 1);
   const size_t hv_hdr = ((2 * (size_t)hv_cap + hv_slice_cap) * 4 + 255) & ~(size_t)255;
-  const size_t hv_bytes = (hv_hdr + (size_t)hv_slice_cap * sizeof(Xyzz<F>) + 255) & ~(size_t)255;
-  ST_TRY(reserve(ctx, ctx->heavy, parts * hv_bytes));
+  ST_TRY(reserve(ctx, ctx->heavy, hv_hdr + (size_t)hv_slice_cap * sizeof(Xyzz<F>)));
+  u32 *hv_bucket = (u32*)ctx->heavy.p, *hv_first = hv_bucket + hv_cap, *hv_owner = hv_first + hv_cap;
+  Xyzz<F>* hv_slices = (Xyzz<F>*)((char*)ctx->heavy.p + hv_hdr);
+  hipLaunchKernelGGL(k_cnt_hist, dim3(cdiv(nb, 1024)), dim3(256), 0, st, (const u32*)hist, (u32)nb, ghist, hv, hv_cap, hv_slice_cap, hv_bucket, hv_first,
+                     hv_owner);
+  hipLaunchKernelGGL(k_cnt_offsets, dim3(1), dim3(CNT_BINS), 0, st, (const u32*)ghist, gstart);
+  hipLaunchKernelGGL(k_cnt_scatter, dim3(cdiv(nb, 1024)), dim3(256), 0, st, (const u32*)hist, (u32)nb, gstart, perm);
+  ST_TRY(launch_check(ctx, "cnt_sort"));
+  if (ctx->timing) (void)hipEventRecord(ctx->ev[1], st);
   bool u29 = false;
   if constexpr (std::is_same<F, Fq>::value) {
     static const bool use_u29 = !(getenv("KEAKI_ACC_U29") && atoi(getenv("KEAKI_ACC_U29")) == 0);   // A/B switch for profiling
     u29 = use_u29;
+    if (u29)
+      hipLaunchKernelGGL(k_msm_accumulate_g1_u29, dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
+                         (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
   }
   if constexpr (std::is_same<F, Fq2>::value) {
     static const bool use_u29_g2 = !(getenv("KEAKI_ACC_U29_G2") && atoi(getenv("KEAKI_ACC_U29_G2")) == 0);   // A/B switch for profiling
     u29 = use_u29_g2;
+    if (u29)
+      hipLaunchKernelGGL(k_msm_accumulate_g2_u29, dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
+                         (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
   }
-  hipStream_t prep = parts > 1 ? ctx->aux_stream : st;
-  if (parts > 1) {
-    HIP_TRY(ctx, hipEventRecord(ctx->aux_ev[0], st));
-    HIP_TRY(ctx, hipStreamWaitEvent(prep, ctx->aux_ev[0], 0));
-  }
-  struct Range { u32 bin_lo, bin_hi, b_lo, b_n; };
-  Range rg[8];
-  for (u32 k = 0; k < parts; k++) {
-    rg[k].bin_lo = (u32)((size_t)ps.nbins * k / parts);
-    rg[k].bin_hi = (u32)((size_t)ps.nbins * (k + 1) / parts);
-    const size_t lo = (size_t)rg[k].bin_lo << ps.shift, hi = std::min((size_t)nb, (size_t)rg[k].bin_hi << ps.shift);
-    rg[k].b_lo = (u32)std::min(lo, (size_t)nb);
-    rg[k].b_n = hi > lo ? (u32)(hi - lo) : 0u;
-  }
-  // the preparation of every range, in order, on `prep`
-  for (u32 k = 0; k < parts; k++) {
-    const Range& r = rg[k];
-    u32 *gstart = (u32*)(cnt_base + k * cnt_bytes), *ghist = gstart + CNT_BINS;
-    HeavyList* hv = (HeavyList*)(ghist + CNT_BINS);                        // right behind the histogram: one memset clears both
-    u32 *hv_bucket = (u32*)((char*)ctx->heavy.p + k * hv_bytes), *hv_first = hv_bucket + hv_cap, *hv_owner = hv_first + hv_cap;
-    if (r.bin_hi > r.bin_lo) {
-      if (p2_small)
-        hipLaunchKernelGGL((k_part_fine<P2_CAP_SMALL>), dim3(r.bin_hi - r.bin_lo), dim3(P2_THREADS), 0, prep, (const u64*)entries, (const u32*)poffsets, ps,
-                           (const u32*)(poffsets + ncounts), (u32)nb, offsets, hist, sorted, r.bin_lo);
-      else
-        hipLaunchKernelGGL((k_part_fine<P2_CAP_BIG>), dim3(r.bin_hi - r.bin_lo), dim3(P2_THREADS), 0, prep, (const u64*)entries, (const u32*)poffsets, ps,
-                           (const u32*)(poffsets + ncounts), (u32)nb, offsets, hist, sorted, r.bin_lo);
-    }
-    // bucket schedule of the range: descending size (local bucket ids: the kernels below get the range's base pointers)
-    HIP_TRY(ctx, hipMemsetAsync(ghist, 0, CNT_BINS * 4 + sizeof(HeavyList), prep));
-    if (r.b_n) {
-      hipLaunchKernelGGL(k_cnt_hist, dim3(cdiv(r.b_n, 1024)), dim3(256), 0, prep, (const u32*)(hist + r.b_lo), r.b_n, ghist, hv, hv_cap, hv_slice_cap,
-                         hv_bucket, hv_first, hv_owner);
-      hipLaunchKernelGGL(k_cnt_offsets, dim3(1), dim3(CNT_BINS), 0, prep, (const u32*)ghist, gstart);
-      hipLaunchKernelGGL(k_cnt_scatter, dim3(cdiv(r.b_n, 1024)), dim3(256), 0, prep, (const u32*)(hist + r.b_lo), r.b_n, gstart, perm + r.b_lo);
-    }
-    if (parts > 1) HIP_TRY(ctx, hipEventRecord(ctx->aux_ev[1 + k], prep));
-  }
-  ST_TRY(launch_check(ctx, "part_fine / cnt_sort"));
-  // the bucket kernels of every range, in order, on the caller's stream
-  for (u32 k = 0; k < parts; k++) {
-    const Range& r = rg[k];
-    if (parts > 1) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->aux_ev[1 + k], 0));
-    if (k == 0 && ctx->timing) (void)hipEventRecord(ctx->ev[1], st);
-    if (!r.b_n) continue;
-    u32 *gstart = (u32*)(cnt_base + k * cnt_bytes), *ghist = gstart + CNT_BINS;
-    const HeavyList* hv = (const HeavyList*)(ghist + CNT_BINS);
-    const u32 *hv_bucket = (const u32*)((char*)ctx->heavy.p + k * hv_bytes), *hv_first = hv_bucket + hv_cap, *hv_owner = hv_first + hv_cap;
-    Xyzz<F>* hv_slices = (Xyzz<F>*)((char*)ctx->heavy.p + k * hv_bytes + hv_hdr);
-    const u32 *r_off = offsets + r.b_lo, *r_cnt = hist + r.b_lo, *r_perm = perm + r.b_lo;
-    Xyzz<F>* r_buckets = buckets + r.b_lo;
-    bool done = false;
-    if constexpr (std::is_same<F, Fq>::value) {
-      if (u29) {
-        hipLaunchKernelGGL(k_msm_accumulate_g1_u29, dim3(cdiv(r.b_n, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, r_off, r_cnt, r_perm, r.b_n, r_buckets);
-        done = true;
-      }
-    }
-    if constexpr (std::is_same<F, Fq2>::value) {
-      if (u29) {
-        hipLaunchKernelGGL(k_msm_accumulate_g2_u29, dim3(cdiv(r.b_n, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, r_off, r_cnt, r_perm, r.b_n, r_buckets);
-        done = true;
-      }
-    }
-    if (!done)
-      hipLaunchKernelGGL((k_msm_accumulate<F>), dim3(cdiv(r.b_n, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, r_off, r_cnt, r_perm, r.b_n, r_buckets);
-    // heavy buckets (structured scalars only; the grids exit after one load otherwise)
-    hipLaunchKernelGGL((k_msm_heavy<F>), dim3(HEAVY_GRID), dim3(256), 0, st, d_points, (const u32*)sorted, r_off, r_cnt, hv, hv_slice_cap, hv_bucket, hv_first,
-                       hv_owner, hv_slices);
-    hipLaunchKernelGGL((k_msm_heavy_combine<F>), dim3(HEAVY_COMBINE_GRID), dim3(64), 0, st, r_cnt, hv, hv_cap, hv_slice_cap, hv_bucket, hv_first,
-                       (const Xyzz<F>*)hv_slices, r_buckets);
-  }
-  ST_TRY(launch_check(ctx, "msm_accumulate / msm_heavy"));
+  if (!u29)
+    hipLaunchKernelGGL((k_msm_accumulate<F>), dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
+                       (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
+  ST_TRY(launch_check(ctx, "msm_accumulate"));
+  // heavy buckets (structured scalars only; the grids exit after one load otherwise)
+  hipLaunchKernelGGL((k_msm_heavy<F>), dim3(HEAVY_GRID), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets, (const u32*)hist,
+                     (const HeavyList*)hv, hv_slice_cap, (const u32*)hv_bucket, (const u32*)hv_first, (const u32*)hv_owner, hv_slices);
+  hipLaunchKernelGGL((k_msm_heavy_combine<F>), dim3(HEAVY_COMBINE_GRID), dim3(64), 0, st, (const u32*)hist, (const HeavyList*)hv, hv_cap, hv_slice_cap,
+                     (const u32*)hv_bucket, (const u32*)hv_first, (const Xyzz<F>*)hv_slices, buckets);
+  ST_TRY(launch_check(ctx, "msm_heavy"));
   if (ctx->timing) (void)hipEventRecord(ctx->ev[2], st);
   hipLaunchKernelGGL((k_msm_reduce<F>), dim3(cdiv((size_t)rs.W * chunks, 64)), dim3(64), 0, st, (const Xyzz<F>*)buckets, rs, L, chunks, partials);
   // chunk partials -> (at most 128 per window) -> window sums
