@@ -93,7 +93,6 @@ keaki_status reserve(keaki_hip_ctx* ctx, DevBuf& b, size_t bytes) {
   size_t want = bytes + bytes / 8 + 256;
   ST_TRY(dev_alloc(ctx, &b.p, want));
   b.cap = want;
-  ctx->ws_gen++;                       // captured graphs hold the old pointers
   return KEAKI_OK;
 }
 
@@ -174,7 +173,6 @@ void keaki_hip_ctx_destroy(keaki_hip_ctx* ctx) {
                     &ctx->fb_scalars, &ctx->fb_g1_gen, &ctx->fb_g2_gen, &ctx->fb_com, &ctx->fb_tau, &ctx->perm, &ctx->g2gen_lines, &ctx->gt_tab_a, &ctx->gt_tab_b, &ctx->gt_base, &ctx->heavy, &ctx->pair_ws, &ctx->verify_lines, &ctx->verify_io, &ctx->fbs_scalars, &ctx->fbs_g2_gen, &ctx->fbs_tau})
     if (b->p) (void)hipFree(b->p);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
-  for (auto& g : ctx->msm_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -288,55 +286,6 @@ keaki_status keaki_hip_msm_g1_dev(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* sr
   if (!srs) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm_g1: srs is null");
   return msm_g1_run(ctx, srs->d, srs->n, d_scalars, n, d_out_jac, srs->table, srs->c_table);
 }
-namespace {
-// Small MSMs through a hipGraph (see keaki_hip_ctx::MsmGraph). Returns true when the kernel sequence has been enqueued by a graph launch;
-// false: the caller enqueues it the ordinary way (first sighting of a shape, capture not possible, graphs switched off).
-constexpr size_t MSM_GRAPH_MAX_N = 65536;
-bool msm_g1_graph_launch(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, size_t n) {
-  static const bool enabled = !(getenv("KEAKI_MSM_GRAPH") && atoi(getenv("KEAKI_MSM_GRAPH")) == 0);
-  if (!enabled || n == 0 || n > MSM_GRAPH_MAX_N || ctx->timing || !ctx->own_stream) return false;   // capture needs a stream of our own
-  auto same = [&](const keaki_hip_ctx::MsmGraph& g) {
-    return g.srs_d == srs->d && g.srs_n == srs->n && g.n == n && g.table == srs->table && g.c == srs->c_table && g.in == ctx->io_a.p &&
-           g.out == ctx->io_b.p && g.gen == ctx->ws_gen;
-  };
-  ctx->msm_graph_clock++;
-  for (auto& g : ctx->msm_graphs)
-    if (g.exec && same(g)) {
-      g.last_use = ctx->msm_graph_clock;
-      return hipGraphLaunch(g.exec, ctx->stream) == hipSuccess;
-    }
-  if (!same(ctx->msm_seen)) {           // first sighting: run it the ordinary way (it also sizes every workspace), remember the shape
-    ctx->msm_seen.srs_d = srs->d; ctx->msm_seen.srs_n = srs->n; ctx->msm_seen.n = n; ctx->msm_seen.table = srs->table; ctx->msm_seen.c = srs->c_table;
-    ctx->msm_seen.in = ctx->io_a.p; ctx->msm_seen.out = ctx->io_b.p; ctx->msm_seen.gen = ctx->ws_gen;
-    return false;
-  }
-  // second sighting: capture
-  hipGraph_t graph = nullptr;
-  if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return false; }
-  const keaki_status st = msm_g1_run(ctx, srs->d, srs->n, ctx->io_a.p, n, ctx->io_b.p, srs->table, srs->c_table);
-  const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
-  if (st != KEAKI_OK || e != hipSuccess || !graph || !same(ctx->msm_seen)) {      // e.g. a workspace grew after all: nothing was enqueued
-    (void)hipGetLastError();
-    if (graph) (void)hipGraphDestroy(graph);
-    ctx->msm_seen = keaki_hip_ctx::MsmGraph();
-    return false;
-  }
-  hipGraphExec_t exec = nullptr;
-  const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(graph);
-  if (ei != hipSuccess || !exec) { (void)hipGetLastError(); return false; }
-  keaki_hip_ctx::MsmGraph* slot = &ctx->msm_graphs[0];
-  for (auto& g : ctx->msm_graphs) {
-    if (!g.exec) { slot = &g; break; }
-    if (g.last_use < slot->last_use) slot = &g;
-  }
-  if (slot->exec) (void)hipGraphExecDestroy(slot->exec);
-  *slot = ctx->msm_seen;
-  slot->exec = exec;
-  slot->last_use = ctx->msm_graph_clock;
-  return hipGraphLaunch(exec, ctx->stream) == hipSuccess;
-}
-}  // namespace
 keaki_status keaki_hip_msm_g1(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, const uint64_t* scalars, size_t n, uint64_t* out_jac) {
   CTX_GUARD(ctx);
   TRACE_SCOPE("keaki.msm_g1");
@@ -344,8 +293,7 @@ keaki_status keaki_hip_msm_g1(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, c
   if (n > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", n, srs->n);
   ST_TRY(upload(ctx, ctx->io_a, scalars, n * 32));
   ST_TRY(reserve(ctx, ctx->io_b, 96));
-  if (!msm_g1_graph_launch(ctx, srs, n))
-    ST_TRY(msm_g1_run(ctx, srs->d, srs->n, ctx->io_a.p, n, ctx->io_b.p, srs->table, srs->c_table));
+  ST_TRY(msm_g1_run(ctx, srs->d, srs->n, ctx->io_a.p, n, ctx->io_b.p, srs->table, srs->c_table));
   ST_TRY(download(ctx, out_jac, ctx->io_b.p, 96));
   resolve_timing(ctx);
   return KEAKI_OK;

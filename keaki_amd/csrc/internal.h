@@ -49,16 +49,6 @@ struct keaki_hip_ctx {
   keaki_internal::DevBuf fbs_scalars, fbs_g2_gen, fbs_tau;     // small (8-bit) tables of g2 and [tau]_2 for batches below 256 items
   bool fbs_ready = false, fbs_tau_valid = false;
   uint64_t fbs_tau_pt[16] = {};
-  // hipGraph cache of small MSMs (keaki_hip_msm_g1 with host scalars): the ~20 launches of a 10^2..10^4-point MSM are launch-bound, so
-  // the second call with the same shape captures the sequence and later calls replay it. `ws_gen` counts workspace reallocations: a
-  // graph holds raw pointers and dies with them.
-  struct MsmGraph {
-    const void* srs_d = nullptr; const void* table = nullptr; const void* in = nullptr; const void* out = nullptr;
-    size_t srs_n = 0, n = 0; int c = 0; uint64_t gen = 0; hipGraphExec_t exec = nullptr; uint64_t last_use = 0;
-  };
-  MsmGraph msm_graphs[8];
-  MsmGraph msm_seen;                      // the shape of the previous small call (capture happens on its repetition)
-  uint64_t ws_gen = 0, msm_graph_clock = 0;
   // instrumentation
   bool timing = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};

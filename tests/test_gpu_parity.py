@@ -62,33 +62,6 @@ def test_msm_g1_vs_oracle(oc, hip, rand_fr, n):
     assert np.array_equal(got, oc.msm_g1(pts, sc, threads=4))
 
 
-def test_msm_g1_repeated_small_calls_replay_a_graph(oc, hip, rand_fr):
-    """Small MSMs with host scalars are launch-bound: the second call of a shape captures the kernel sequence into a hipGraph, later calls
-    replay it (api.hip::msm_g1_graph_launch). Every call must still be the MSM of ITS scalars; a call of another shape, a larger call that
-    reallocates the workspaces (which kills the captured graphs) and window tables appearing on the handle must all be survived."""
-    n_a, n_b, n_big = 129, 1000, 40000
-    _, pts = make_points_g1(oc, hip, n_big, 4100)
-    srs = hip.srs_g1_upload(pts)
-    try:
-        def check(n, seed):
-            sc = mont(oc, rand_fr(n, seed))
-            assert np.array_equal(jac_to_aff(hip.msm_g1(srs, sc)), oc.msm_g1(pts[:n], sc, threads=4)), (n, seed)
-        for rep in range(4):                      # a: ordinary, capture, replay, replay -- interleaved with b
-            check(n_a, 4200 + rep)
-            check(n_a, 4300 + rep)
-            check(n_b, 4400 + rep)
-        check(n_big, 4500)                        # grows the workspaces: the graphs of a and b are stale now
-        for rep in range(3):
-            check(n_a, 4600 + rep)
-            check(n_b, 4700 + rep)
-        hip.srs_g1_precompute(srs)                # another code path behind the same handle
-        for rep in range(3):
-            check(n_b, 4800 + rep)
-            check(n_a, 4900 + rep)
-    finally:
-        srs.free()
-
-
 def test_msm_g1_edge_cases(oc, py, hip, rand_fr):
     n = 300
     _, pts = make_points_g1(oc, hip, n, 7)
