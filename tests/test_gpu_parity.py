@@ -62,6 +62,33 @@ def test_msm_g1_vs_oracle(oc, hip, rand_fr, n):
     assert np.array_equal(got, oc.msm_g1(pts, sc, threads=4))
 
 
+def test_msm_g1_repeated_calls_of_changing_shape(oc, hip, rand_fr):
+    """Back-to-back MSMs on one handle: repeated shapes with different scalars, a shape change in between, a larger call that reallocates
+    the grow-only workspaces, window tables appearing on the handle -- every call must be the MSM of ITS scalars (nothing cached from the
+    previous call of the same shape may leak: counts, offsets, heavy-bucket lists, bucket contents)."""
+    n_a, n_b, n_big = 129, 1000, 40000
+    _, pts = make_points_g1(oc, hip, n_big, 4100)
+    srs = hip.srs_g1_upload(pts)
+    try:
+        def check(n, seed):
+            sc = mont(oc, rand_fr(n, seed))
+            assert np.array_equal(jac_to_aff(hip.msm_g1(srs, sc)), oc.msm_g1(pts[:n], sc, threads=4)), (n, seed)
+        for rep in range(3):
+            check(n_a, 4200 + rep)
+            check(n_a, 4300 + rep)
+            check(n_b, 4400 + rep)
+        check(n_big, 4500)
+        for rep in range(2):
+            check(n_a, 4600 + rep)
+            check(n_b, 4700 + rep)
+        hip.srs_g1_precompute(srs)
+        for rep in range(2):
+            check(n_b, 4800 + rep)
+            check(n_a, 4900 + rep)
+    finally:
+        srs.free()
+
+
 def test_msm_g1_edge_cases(oc, py, hip, rand_fr):
     n = 300
     _, pts = make_points_g1(oc, hip, n, 7)
