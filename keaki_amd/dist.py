@@ -10,10 +10,11 @@ What shards how:
   every rank (keaki_hip_g1_sum[_dev]). 96 bytes per rank: latency-bound, xGMI bandwidth is irrelevant.
 * vec_encrypt / vec_decrypt (src/vec.rs:63-66, :75-78) -- by item, no collective. Every rank draws the WHOLE stream of r values so that
   the ciphertexts equal the single-process ones.
-* kzg::open_fk (FK23, src/kzg.rs:157-203) inside vec_commit -- the three group FFTs and the 2d scalar-mults are split over the ranks
-  (ShardedFk below; keaki_hip_fk_shard_* in the C ABI): two all-to-alls of 96-byte points (2d / world^2 resp. d / world^2 points per
-  peer) and one all-gather of the d / world affine proofs per rank. The ONLY exchange of the path where xGMI bandwidth matters
-  (d = 2^21: 400 MB + 200 MB + 128 MB in total over all links). Needs a power-of-two world and d >= world^2; otherwise replicated.
+* kzg::open_fk (FK23, src/kzg.rs:157-203) inside vec_commit -- its group transforms (one inverse and one forward FFT of size d on the odd
+  half of the 2d products; the even half needs none: fft_g1.hip) and the 2d scalar-mults are split over the ranks (ShardedFk below;
+  keaki_hip_fk_shard_* in the C ABI): two all-to-alls of 96-byte points (d / world^2 points per peer each) and one all-gather of the
+  d / world affine proofs per rank and call, one all-to-all (2d / world^2 per peer) at setup. The ONLY exchange of the path where xGMI
+  bandwidth matters (d = 2^21, 8 ranks: 161 MB sent per rank and call). Needs a power-of-two world and d >= world^2; otherwise replicated.
 """
 from __future__ import annotations
 

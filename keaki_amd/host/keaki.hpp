@@ -203,10 +203,11 @@ kzg::Result<Partial> commit_partial(const kzg::KZGSetup& setup, const DensePolyn
 // vec_commit with the final commit (src/vec.rs:46) left as this rank's partial. Padding draw, iFFT and the FK23 openings are REPLICATED:
 // every rank runs them with the same rng stream and gets the same proofs (vec_commit_partial_fk shards the openings too).
 std::pair<Partial, std::vector<G1>> vec_commit_partial(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v, const Shard& sh);
-// ---- kzg::open_fk (FK23, src/kzg.rs:157-203) sharded over the ranks: every rank does 1/world of the butterflies of the three group FFTs
-// and of the 2d scalar-mults (keaki_hip_fk_shard_*). Between the steps the ranks exchange 96-byte points: two all-to-alls of
-// (2d / world^2) resp. (d / world^2) points per peer and one all-gather of the d / world affine proofs per rank -- the one place of the
-// whole path where xGMI bandwidth matters. The exchanges are the CALLER's (RCCL in an application: the library never opens a connection):
+// ---- kzg::open_fk (FK23, src/kzg.rs:157-203) sharded over the ranks: every rank does 1/world of the butterflies of the group FFTs (one
+// inverse and one forward transform of size d: csrc/fft_g1.hip) and of the 2d scalar-mults (keaki_hip_fk_shard_*). Between the steps the
+// ranks exchange 96-byte points: two all-to-alls of d / world^2 points per peer and one all-gather of the d / world affine proofs per
+// rank and call, one all-to-all of 2d / world^2 points per peer at setup -- the one place of the whole path where xGMI bandwidth matters.
+// The exchanges are the CALLER's (RCCL in an application: the library never opens a connection):
 struct FkExchange {
   // d_send: `world` chunks of bytes_per_peer, chunk q for rank q; d_recv: the chunks received, in rank order. Device memory.
   // Must not return before d_recv is complete (the steps run on the Device's own stream). Returns 0, or non-zero to abort the call

@@ -12,7 +12,7 @@ Receiver::receive -> vec_decrypt : one batched GPU decapsulation (one pairing pe
 With N ranks (keaki_amd/dist.py; host side keaki::dist in keaki_amd/host/keaki.hpp):
   * every rank builds the same setup (same secret) and holds the whole SRS (2^21 points = 128 MiB);
   * vec_commit: the padding draw and the scalar-field iFFT are replicated; the FK23 openings are SHARDED (every rank runs 1/N of the
-    butterflies of the three group FFTs and of the 2d scalar-mults; two all-to-alls of 96-byte points and one all-gather of the affine
+    butterflies of the two size-d group FFTs and of the 2d scalar-mults; two all-to-alls of 96-byte points and one all-gather of the affine
     proofs: keaki_amd/dist.py::ShardedFk; `--fk replicated` or a world that is not a power of two falls back to every rank computing all
     proofs), the commit MSM is sharded by point range: one all-gather of 96-byte partials + N - 1 EC additions;
   * vec_encrypt / vec_decrypt: sharded by item, NO collective; every rank draws the whole stream of r so that the ciphertexts are the
