@@ -131,6 +131,31 @@ def sharded_commit(K, setup, p, shard: Shard) -> np.ndarray:
     return K.commit_combine(setup, shard.all_gather_np(part))
 
 
+def exchange_all_to_all(dist, send, recv):
+    """`send`: world equal chunks laid end to end, chunk q for rank q; `recv`: the chunks received, in rank order. RCCL works on the device
+    tensors themselves (ordered on torch's current stream); gloo goes through host memory when the tensors live on a GPU."""
+    import torch
+    if dist.get_backend() == "nccl" or not send.is_cuda:
+        dist.all_to_all_single(recv, send)
+    else:
+        hs = send.cpu()
+        hr = torch.empty_like(hs)
+        dist.all_to_all_single(hr, hs)
+        recv.copy_(hr)
+
+
+def exchange_all_gather(dist, send, recv):
+    """`recv` = every rank's `send`, in rank order"""
+    import torch
+    if dist.get_backend() == "nccl" or not send.is_cuda:
+        dist.all_gather_into_tensor(recv, send)
+    else:
+        hs = send.cpu()
+        hr = torch.empty(recv.numel(), dtype=recv.dtype)
+        dist.all_gather_into_tensor(hr, hs)
+        recv.copy_(hr)
+
+
 class ShardedFk:
     """kzg::open_fk of a setup sharded over the ranks: owns the two exchange buffers (torch tensors on the setup's GPU) and performs the
     collectives keaki::dist::ShardedOpenFk asks for -- RCCL on the device buffers themselves, or through host memory for gloo.
@@ -155,32 +180,16 @@ class ShardedFk:
 
     # the library has synchronised its stream before it calls these; they return when d_recv is complete
     def _all_to_all(self, d_send, d_recv, per_peer):
-        torch, dist, w = self.torch, self.shard.dist, self.shard.world
+        w = self.shard.world
         assert d_send == self.send.data_ptr() and d_recv == self.recv.data_ptr()
-        s, r = self.send[:w * per_peer], self.recv[:w * per_peer]
-        if dist.get_backend() == "nccl":
-            dist.all_to_all_single(r, s)
-            torch.cuda.current_stream(self.dev).synchronize()
-        else:
-            hs = s.cpu()
-            hr = torch.empty_like(hs)
-            dist.all_to_all_single(hr, hs)
-            r.copy_(hr)
-            torch.cuda.synchronize(self.dev)
+        exchange_all_to_all(self.shard.dist, self.send[:w * per_peer], self.recv[:w * per_peer])
+        self.torch.cuda.synchronize(self.dev)
         self.bytes_moved += (w - 1) * per_peer
 
     def _all_gather(self, d_send, d_recv, per_rank):
-        torch, dist, w = self.torch, self.shard.dist, self.shard.world
-        s, r = self.send[:per_rank], self.recv[:w * per_rank]
-        if dist.get_backend() == "nccl":
-            dist.all_gather_into_tensor(r, s)
-            torch.cuda.current_stream(self.dev).synchronize()
-        else:
-            hs = s.cpu()
-            hr = torch.empty(w * per_rank, dtype=torch.uint8)
-            dist.all_gather_into_tensor(hr, hs)
-            r.copy_(hr)
-            torch.cuda.synchronize(self.dev)
+        w = self.shard.world
+        exchange_all_gather(self.shard.dist, self.send[:per_rank], self.recv[:w * per_rank])
+        self.torch.cuda.synchronize(self.dev)
         self.bytes_moved += (w - 1) * per_rank
 
     def prepare(self):

@@ -154,3 +154,50 @@ def test_chunk_bounds_cover_everything():
         Shard(0, 2, None)
     one = Shard()
     assert one.bounds(10) == (0, 10) and one.all_gather_np(np.arange(3, dtype=np.uint64)).shape == (1, 3)
+
+
+# ---- the sharded FK23 pipeline across real processes: the exchange helpers of keaki_amd/dist.py (all_to_all_single / all_gather_into_tensor
+# with equal splits) must move the chunks exactly as tests/fk_shard_model.py::all_to_all says; every process plays one rank of the model
+def _fk_worker(rank, world, port, log2d, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import random
+    from fk_shard_model import Q, ShardModel, open_fk_plain
+    from keaki_amd.dist import exchange_all_to_all, exchange_all_gather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rnd = random.Random(4242 + log2d)                       # the same inputs on every rank
+        d = 1 << log2d
+        srs = [rnd.randrange(Q) for _ in range(d)]
+        p = [rnd.randrange(Q) for _ in range(d)]
+        m = ShardModel(srs, log2d, world)
+
+        def a2a(values):
+            send = torch.tensor(values, dtype=torch.int64)
+            recv = torch.empty_like(send)
+            exchange_all_to_all(dist, send, recv)
+            return recv.tolist()
+        m.hs_even, m.hs_odd = [None] * world, [None] * world
+        m.hs_even[rank], m.hs_odd[rank] = m.setup_step1(rank, a2a(m.setup_step0(rank)))
+        part = m.open_step2(rank, a2a(m.open_step1(rank, a2a(m.open_step0(rank, p)))))
+        send = torch.tensor(part, dtype=torch.int64)
+        recv = torch.empty(d, dtype=torch.int64)
+        exchange_all_gather(dist, send, recv)
+        got = m.open_step3(recv.tolist())
+        q.put((rank, got == open_fk_plain(srs, p, log2d)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,log2d", [(2, 4), (4, 5)])
+def test_sharded_fk_exchanges_across_processes(world, log2d):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 200 + world
+    procs = [ctx.Process(target=_fk_worker, args=(r, world, port, log2d, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for pr in procs:
+        pr.join(60)
+    assert sorted(res) == [(r, True) for r in range(world)]
