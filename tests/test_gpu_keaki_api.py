@@ -237,7 +237,8 @@ def test_vec_encrypt_matches_serial_reference_loop(K, oc, py):
 
 
 def test_open_fk_gpu_vs_oracle_and_per_point_open(K, oc, py):
-    """FK23 on the GPU (three G1 FFTs + 2d scalar-mults): against the oracle's literal restatement at d = 8 and against per-point
+    """FK23 on the GPU (fft_g1.hip: the even half of the 2d products + one inverse and one forward G1 FFT of size d on the odd half):
+    against the oracle's literal restatement of the reference's three transforms at d = 8 and against per-point
     `open` + `verify` at d = 64 (the relation the reference asserts in src/kzg.rs:470-505)."""
     rng = K.Rng(21)
     secret = rng.fr_rand()
@@ -339,3 +340,22 @@ def test_new_from_file_ptau_fixture(K, oc, py, tmp_path):
     with pytest.raises(K.SetupFileError) as e:
         K.KZGSetup.new_from_file(str(tmp_path / "nope.ptau"))
     assert e.value.kind == "FileError"
+
+
+@pytest.mark.parametrize("log2d", [9, 12, 15])
+def test_open_fk_large_domains_vs_per_point_open(K, log2d):
+    """FK23 at sizes where every branch of the stage kernels is taken (stages with at least 64 blocks share one twiddle per wave, the last
+    six do not; trivial twiddles skip the ladder): proofs at the corners and at 20 random positions equal `open` at that root of unity,
+    and one of them verifies (src/kzg.rs:470-505 at scale)."""
+    d = 1 << log2d
+    rng = K.Rng(3300 + log2d)
+    s = K.KZGSetup.setup(rng.fr_rand(), d)
+    p = np.stack([rng.fr_rand() for _ in range(d)])
+    p[d // 3] = 0
+    proofs = K.open_fk(s, p, d)
+    el = K.domain_elements(d)
+    pick = np.random.default_rng(log2d).integers(0, d, 20).tolist() + [0, 1, d // 2 - 1, d // 2, d - 2, d - 1]
+    for i in pick:
+        assert np.array_equal(proofs[i], K.open(s, p, el[i])), i
+    i = pick[0]
+    assert K.verify(s, K.commit(s, p), el[i], K.poly_evaluate(p, el[i]), proofs[i])
