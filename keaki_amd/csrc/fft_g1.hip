@@ -53,7 +53,8 @@ static __global__ void __launch_bounds__(64) k_g1_jac_to_aff(const G1Jac* __rest
 // One stage over a LOCAL array of m points: local span 2 * half; the butterfly at local offset j takes the twiddle tw[(j A + B) stride]
 // ((A, B) = (R, rank) on the cyclic layout, (1, 0) on the block layout). Lane order as k_g1_fft_stage: a wave shares one twiddle
 // while the stage has at least 64 blocks.
-template <bool DIT>
+// UNIFORM (chosen by the host: at least 64 blocks and at least one full wave): every wave has ONE twiddle and takes the sliding-window ladder.
+template <bool DIT, bool UNIFORM>
 static __global__ void __launch_bounds__(64) k_g1_fft_stage_map(G1Jac* __restrict__ a, const Fr* __restrict__ tw, u32 m, u32 half, u32 A, u32 B, u32 stride) {
   u32 b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= m / 2) return;
@@ -64,8 +65,13 @@ static __global__ void __launch_bounds__(64) k_g1_fft_stage_map(G1Jac* __restric
   const u32 i0 = blk * 2 * half + j, i1 = i0 + half;
   Fr w = tw[((size_t)j * A + B) * stride];
   G1Jac u = a[i0], v = a[i1];
+  __shared__ unsigned char dig[UNIFORM ? 2 * UNIFORM_DIG_STRIDE : 4];
+  auto mul = [&](const G1Jac& pt) {
+    if constexpr (UNIFORM) return jac_scalar_mul_uniform_u29(pt, w, dig);
+    else return jac_scalar_mul(pt, w);
+  };
   if (DIT) {
-    if (!fr_is_one(w)) v = jac_scalar_mul(v, w);
+    if (!fr_is_one(w)) v = mul(v);
     a[i0] = jac_add(u, v);
     v.y = -v.y;
     a[i1] = jac_add(u, v);
@@ -73,7 +79,7 @@ static __global__ void __launch_bounds__(64) k_g1_fft_stage_map(G1Jac* __restric
     a[i0] = jac_add(u, v);
     v.y = -v.y;
     G1Jac t = jac_add(u, v);
-    if (!fr_is_one(w)) t = jac_scalar_mul(t, w);
+    if (!fr_is_one(w)) t = mul(t);
     a[i1] = t;
   }
 }
@@ -245,8 +251,13 @@ namespace keaki_internal {
 using namespace bn254;
 
 static void stage_map(keaki_hip_ctx* ctx, bool dit, G1Jac* a, const Fr* tw, u32 m, u32 half, u32 A, u32 B, u32 stride) {
-  if (dit) hipLaunchKernelGGL(k_g1_fft_stage_map<true>, dim3(cdiv(m / 2, 64)), dim3(64), 0, ctx->stream, a, tw, m, half, A, B, stride);
-  else hipLaunchKernelGGL(k_g1_fft_stage_map<false>, dim3(cdiv(m / 2, 64)), dim3(64), 0, ctx->stream, a, tw, m, half, A, B, stride);
+  static const bool sliding = !(getenv("KEAKI_FK_UNIFORM") && atoi(getenv("KEAKI_FK_UNIFORM")) == 0);      // A/B switch
+  const bool uniform = sliding && m / (2 * half) >= 64;        // blocks: a power of two, so every 64-lane workgroup then shares one twiddle
+  const dim3 grid(cdiv(m / 2, 64)), block(64);
+  if (dit && uniform) hipLaunchKernelGGL((k_g1_fft_stage_map<true, true>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride);
+  else if (dit) hipLaunchKernelGGL((k_g1_fft_stage_map<true, false>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride);
+  else if (uniform) hipLaunchKernelGGL((k_g1_fft_stage_map<false, true>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride);
+  else hipLaunchKernelGGL((k_g1_fft_stage_map<false, false>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride);
 }
 
 // hat_s = DIF_2d(reversed SRS padded with identities): depends on the SRS only, so it is computed once per (SRS, d) and cached.

@@ -232,4 +232,101 @@ KDEV Jac<Fq> jac_scalar_mul_u29(const Jac<Fq>& p, const Fr& k_mont) {
   return {u29_to_fq(acc.x), u29_to_fq(acc.y), u29_to_fq(acc.z)};
 }
 
+
+// ---- the same product when EVERY lane of the wave multiplies ITS point by the SAME k (the FK23 stages with at least 64 blocks: one
+// twiddle per wave). A uniform scalar costs no divergence whatever its digits are, so the windows may slide: width-5 NAF of both GLV
+// halves -- odd digits in [-15, 15], on average one non-zero digit in six positions -- over ONE table of the odd multiples 1, 3 .. 15
+// (phi of an entry is the entry with beta X): 129 doublings + ~43 additions + 9 table operations instead of 129 + 66 + 11. The digits are
+// computed once per wave from the scalar's first-lane copy (scalar unit) and wait in LDS (`dig`: 2 x 132 bytes of this wave), one byte per
+// position: (|d| + 1) / 2 in the low bits, the sign in bit 7. Bounds: j29_dbl and j29_add map the running point's bound set into itself
+// (header of this file), so the order of the operations does not matter.
+constexpr int UNIFORM_DIG_STRIDE = 132;
+KDEV Jac<Fq> jac_scalar_mul_uniform_u29(const Jac<Fq>& p, const Fr& k_mont, unsigned char* dig) {
+  u32 k[8], k1[5], k2[5];
+  bool neg1, neg2;
+  fp_from_mont<FrParams>(k, k_mont);
+#pragma unroll
+  for (int i = 0; i < 8; i++) k[i] = (u32)__builtin_amdgcn_readfirstlane((int)k[i]);
+  glv_decompose(k, k1, neg1, k2, neg2);
+  // width-5 NAF, least significant digit first
+#pragma unroll 1
+  for (int h = 0; h < 2; h++) {
+    u32 a0 = h ? k2[0] : k1[0], a1 = h ? k2[1] : k1[1], a2 = h ? k2[2] : k1[2], a3 = h ? k2[3] : k1[3];      // < 2^127
+#pragma unroll 1
+    for (int pos = 0; pos < 129; pos++) {
+      u32 byte = 0;
+      if (a0 & 1u) {
+        const u32 m = a0 & 31u;
+        if (m < 16u) {                      // digit +m
+          a0 -= m;
+          byte = (m + 1u) >> 1;
+        } else {                            // digit -(32 - m): the value goes UP to the next multiple of 32
+          const u32 add = 32u - m;
+          u64 c = (u64)a0 + add; a0 = (u32)c; c >>= 32;
+          c += a1; a1 = (u32)c; c >>= 32;
+          c += a2; a2 = (u32)c; c >>= 32;
+          a3 += (u32)c;
+          byte = ((add + 1u) >> 1) | 0x80u;
+        }
+      }
+      dig[h * UNIFORM_DIG_STRIDE + pos] = (unsigned char)byte;
+      a0 = (a0 >> 1) | (a1 << 31); a1 = (a1 >> 1) | (a2 << 31); a2 = (a2 >> 1) | (a3 << 31); a3 >>= 1;
+    }
+  }
+  // table T[i] = (2 i + 1) P
+  J29T T[8];
+  const U29 beta = u29_const(GlvParams::BETA29);
+  {
+    J29 m1;
+    m1.x = u29_from_fq(p.x); m1.y = u29_from_fq(p.y); m1.z = u29_from_fq(p.z);
+    auto put = [&](int idx, const J29& q) {
+      T[idx].x = q.x; T[idx].y = q.y; T[idx].z = q.z;
+      T[idx].xb = u29_mul(q.x, beta);
+      T[idx].zz = u29_sqr(q.z);
+      T[idx].zcu = u29_mul(q.z, T[idx].zz);
+    };
+    put(0, m1);
+    const J29 d2 = j29_dbl(m1);
+    const U29 d2zz = u29_sqr(d2.z), d2zcu = u29_mul(d2.z, d2zz);
+    J29 run = m1;
+#pragma unroll 1
+    for (int i = 1; i < 8; i++) {
+      int special;
+      run = j29_add(run, d2.x, d2.y, d2.z, d2zz, d2zcu, special);
+      put(i, run);
+    }
+  }
+  U29 zero;
+#pragma unroll
+  for (int i = 0; i < 9; i++) zero.l[i] = 0;
+  J29 acc;
+  acc.x = zero; acc.y = zero; acc.z = zero;
+  bool empty = true;
+#pragma unroll 1
+  for (int pos = 128; pos >= 0; pos--) {
+    if (!empty) acc = j29_dbl(acc);
+#pragma unroll 1
+    for (int which = 0; which < 2; which++) {
+      const u32 byte = (u32)__builtin_amdgcn_readfirstlane((int)dig[which * UNIFORM_DIG_STRIDE + pos]);
+      if (byte) {
+        const bool neg = ((byte >> 7) != 0) != (which ? neg2 : neg1);
+        const J29T& e = T[(byte & 0x7Fu) - 1u];
+        const U29 ex = which ? e.xb : e.x;
+        const U29 ey = neg ? u29_sub(zero, e.y, Q29::K32) : e.y;
+        if (empty) {
+          acc.x = ex; acc.y = ey; acc.z = e.z;
+          empty = false;
+        } else {
+          int special;
+          acc = j29_add(acc, ex, ey, e.z, e.zz, e.zcu, special);
+          if (special == 1) acc = j29_dbl(acc);
+          if (special == 2) empty = true;
+        }
+      }
+    }
+  }
+  if (empty || jac_is_inf(p)) return jac_inf<Fq>();
+  return {u29_to_fq(acc.x), u29_to_fq(acc.y), u29_to_fq(acc.z)};
+}
+
 }  // namespace bn254
