@@ -55,7 +55,7 @@ static __global__ void __launch_bounds__(64) k_g1_jac_to_aff(const G1Jac* __rest
 // while the stage has at least 64 blocks.
 // UNIFORM (chosen by the host: at least 64 blocks and at least one full wave): every wave has ONE twiddle and takes the sliding-window ladder.
 template <bool DIT, bool UNIFORM>
-static __global__ void __launch_bounds__(64) k_g1_fft_stage_map(G1Jac* __restrict__ a, const Fr* __restrict__ tw, u32 m, u32 half, u32 A, u32 B, u32 stride) {
+static __global__ void __launch_bounds__(64, 3) k_g1_fft_stage_map(G1Jac* __restrict__ a, const Fr* __restrict__ tw, u32 m, u32 half, u32 A, u32 B, u32 stride) {
   u32 b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= m / 2) return;
   const u32 nblocks = m / (2 * half);
