@@ -359,3 +359,22 @@ def test_open_fk_large_domains_vs_per_point_open(K, log2d):
         assert np.array_equal(proofs[i], K.open(s, p, el[i])), i
     i = pick[0]
     assert K.verify(s, K.commit(s, p), el[i], K.poly_evaluate(p, el[i]), proofs[i])
+
+
+def test_open_fk_zero_and_sparse_polynomials(K):
+    """FK23 with scalars that vanish: the zero polynomial (every product of the pipeline is the identity: every proof is the identity),
+    a constant (the quotient is zero: identity proofs again) and single monomials (most of hat_a's inputs are zero) -- the ladders'
+    empty-accumulator paths, at a size where the wave-uniform ladder runs."""
+    d = 512
+    rng = K.Rng(3500)
+    s = K.KZGSetup.setup(rng.fr_rand(), d)
+    el = K.domain_elements(d)
+    zero = np.zeros((d, 4), np.uint64)
+    assert not np.any(K.open_fk(s, zero, d))
+    const = zero.copy(); const[0] = rng.fr_rand()
+    assert not np.any(K.open_fk(s, const, d))
+    for k in (1, 2, d // 2, d - 1):
+        p = zero.copy(); p[k] = K.fr(1) if k != 2 else rng.fr_rand()
+        proofs = K.open_fk(s, p, d)
+        for i in (0, 1, 7, d // 2, d - 1):
+            assert np.array_equal(proofs[i], K.open(s, p, el[i])), (k, i)
