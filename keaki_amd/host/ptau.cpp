@@ -133,6 +133,7 @@ FileResult<PowersOfTau> get_powers_from_file(const std::string& path) {
 
 }  // namespace ptau
 
+#ifndef KEAKI_PTAU_PARSE_ONLY          /* the sanitizer harness (ptau_fuzz_main.cpp) builds the parser alone: no GPU library behind it */
 namespace kzg {
 FileSetup new_from_file(std::shared_ptr<Device> dev, const std::string& path) {
   auto fail = [](ptau::SetupFileError e) { return FileSetup{false, nullptr, std::move(e)}; };
@@ -149,4 +150,5 @@ FileSetup new_from_file(std::shared_ptr<Device> dev, const std::string& path) {
   return FileSetup{true, std::move(s), ptau::SetupFileError{ptau::SetupFileError::FileError, 0, 0, ""}};
 }
 }  // namespace kzg
+#endif
 }  // namespace keaki
