@@ -66,3 +66,18 @@ def test_truncated_and_corrupted_files_never_read_out_of_bounds(harness, tmp_pat
     assert all(l.startswith("ok ") or l.startswith("err ") for l in out)
     n_err = sum(l.startswith("err ") for l in out)
     assert n_err >= 200 and n_err < len(out)       # every truncation and most header corruptions are errors; flips inside unused payload still parse
+
+
+def test_host_mirror_cpu_arithmetic_under_the_sanitizers():
+    """keaki_amd/host/host_cpu_asan_main.cpp: the mirror's scalar field and radix-2 domain (what keaki takes from ark-ff / ark-poly on the
+    host) -- algebraic identities and fft / ifft round trips for sizes 1 .. 4096, with AddressSanitizer and UBSan watching the limb
+    arithmetic. Links libkeaki_hip.so but calls nothing in it."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    if not os.path.exists(os.path.join(ROOT, "keaki_amd", "libkeaki_hip.so")):
+        pytest.skip("libkeaki_hip.so not built")
+    r = subprocess.run(["make", "-C", HOST, "host_cpu_asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    env = dict(os.environ, ASAN_OPTIONS="exitcode=99:detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1:exitcode=98")
+    r = subprocess.run([os.path.join(HOST, "host_cpu_asan")], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
