@@ -129,6 +129,12 @@ def test_limb_helpers_and_column_budget(py):
     assert worst + (worst >> 29) < 1 << 64
     # dual stream with one side doubled (fq4_sqr: t1 = (2x) y): a, c < 2^30, b, d <= 2^29 + 8
     assert 2 * 9 * (1 << 30) * lim + 9 * MASK * MASK < 1 << 64
+    # three-product stream with ONE wide operand (fq4_sqr: t0 = sx sy + (xi y) y, sx = x0 + x1 with limbs below 2^30): 9 wide products,
+    # 18 ordinary ones, 9 reduction products and the carry of the column below
+    worst3 = 9 * (1 << 30) * lim + 18 * lim * lim + 9 * MASK * MASK
+    assert worst3 + (worst3 >> 29) < 1 << 64
+    # its value: even lane (x0 + x1)(x0 - x1 + 2p) < 2p * 3p, the xi products 11p * p + 11p * 2p: (6 + 33) p^2 / 2^261 + p < 2p
+    assert (6 + 33) * P * P // (1 << 261) + P < 2 * P
 
 
 def test_g2_lazy_mixed_addition_model():
