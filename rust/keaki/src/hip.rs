@@ -246,6 +246,87 @@ pub fn open_fk(srs: &HipSrs, coeffs: &[Fr], omega_2d: &Fr, omega_2d_inv: &Fr, in
     out.chunks_exact(8).map(|w| g1_from_words(w).into()).collect()
 }
 
+/// The collectives a sharded `open_fk` owes between its steps: implemented by the application over its communication library (RCCL:
+/// `ncclAllToAll`-style exchange with equal splits, `ncclAllGather`) on DEVICE buffers; both must have completed when they return.
+pub trait FkExchange {
+    /// `send`: `world` chunks of `bytes_per_peer`, chunk q for rank q; `recv`: the chunks received, in rank order
+    fn all_to_all(&mut self, send: *mut core::ffi::c_void, recv: *mut core::ffi::c_void, bytes_per_peer: usize);
+    /// `send`: `bytes_per_rank` of this rank; `recv`: every rank's, in rank order
+    fn all_gather(&mut self, send: *mut core::ffi::c_void, recv: *mut core::ffi::c_void, bytes_per_rank: usize);
+}
+
+/// `open_fk` with its group FFTs sharded over the `world` ranks (= GPUs) of a job: every rank calls this with the same coefficients and
+/// gets all `d` proofs; it runs 1/world of the butterflies and scalar-mults (`keaki_hip_fk_shard_*`, include/keaki_hip.h). `send` / `recv`:
+/// device buffers of `buffer_bytes()` each, owned by the caller (they are what the collectives move).
+pub struct ShardedOpenFk {
+    fk: *mut sys::keaki_hip_fk_shard,
+    sizes: [usize; 4],
+    d: usize,
+    prepared: bool,
+}
+unsafe impl Send for ShardedOpenFk {}
+
+impl ShardedOpenFk {
+    /// `d`: a power of two with `world^2 <= d <= srs.len()`; `world` a power of two >= 2; roots as for `open_fk`
+    pub fn new(srs: &HipSrs, d: usize, rank: u32, world: u32, omega_2d: &Fr, omega_2d_inv: &Fr, inv_2d: &Fr) -> Self {
+        let dev = Device::global();
+        assert!(d.is_power_of_two() && d <= srs.len());
+        let mut fk = core::ptr::null_mut();
+        dev.check(
+            unsafe {
+                sys::keaki_hip_fk_shard_create(
+                    dev.ctx, srs.srs, d.trailing_zeros(), rank, world, fr_ptr(core::slice::from_ref(omega_2d)),
+                    fr_ptr(core::slice::from_ref(omega_2d_inv)), fr_ptr(core::slice::from_ref(inv_2d)), &mut fk,
+                )
+            },
+            "fk_shard_create",
+        );
+        let mut sizes = [0usize; 4];
+        dev.check(unsafe { sys::keaki_hip_fk_shard_sizes(fk, sizes.as_mut_ptr()) }, "fk_shard_sizes");
+        ShardedOpenFk { fk, sizes, d, prepared: false }
+    }
+    pub fn buffer_bytes(&self) -> usize {
+        self.sizes[0]
+    }
+    /// setup time: this rank's part of the SRS-only transform (one all-to-all)
+    pub fn prepare(&mut self, send: *mut core::ffi::c_void, recv: *mut core::ffi::c_void, ex: &mut dyn FkExchange) {
+        if self.prepared {
+            return;
+        }
+        let dev = Device::global();
+        dev.check(unsafe { sys::keaki_hip_fk_shard_setup(dev.ctx, self.fk, 0, send, core::ptr::null_mut()) }, "fk_shard_setup 0");
+        dev.check(unsafe { sys::keaki_hip_synchronize(dev.ctx) }, "synchronize");
+        ex.all_to_all(send, recv, self.sizes[1]);
+        dev.check(unsafe { sys::keaki_hip_fk_shard_setup(dev.ctx, self.fk, 1, core::ptr::null_mut(), recv) }, "fk_shard_setup 1");
+        dev.check(unsafe { sys::keaki_hip_synchronize(dev.ctx) }, "synchronize");
+        self.prepared = true;
+    }
+    pub fn open(&mut self, coeffs: &[Fr], send: *mut core::ffi::c_void, recv: *mut core::ffi::c_void, ex: &mut dyn FkExchange) -> Vec<G1Projective> {
+        assert!(coeffs.len() == self.d);
+        self.prepare(send, recv, ex);
+        let dev = Device::global();
+        let null = core::ptr::null_mut::<core::ffi::c_void>();
+        let step = |i: i32, c: *const u64, s, r, out: *mut u64| {
+            dev.check(unsafe { sys::keaki_hip_fk_shard_open(dev.ctx, self.fk, i, c, s, r, out) }, "fk_shard_open");
+            dev.check(unsafe { sys::keaki_hip_synchronize(dev.ctx) }, "synchronize");
+        };
+        step(0, fr_ptr(coeffs), send, null, core::ptr::null_mut());
+        ex.all_to_all(send, recv, self.sizes[2]);
+        step(1, core::ptr::null(), send, recv, core::ptr::null_mut());
+        ex.all_to_all(send, recv, self.sizes[2]);
+        step(2, core::ptr::null(), send, recv, core::ptr::null_mut());
+        ex.all_gather(send, recv, self.sizes[3]);
+        let mut out = vec![0u64; 8 * self.d];
+        step(3, core::ptr::null(), null, recv, out.as_mut_ptr());
+        out.chunks_exact(8).map(|w| g1_from_words(w).into()).collect()
+    }
+}
+impl Drop for ShardedOpenFk {
+    fn drop(&mut self) {
+        unsafe { sys::keaki_hip_fk_shard_free(Device::global().ctx, self.fk) }
+    }
+}
+
 /// The loop body of `vec_encrypt` (src/vec.rs:63-66 -> src/enc.rs:19-40 -> src/kem.rs:13-50) for all items at once: the SAME commitment
 /// and setup for every item, `rs[i]` drawn by the caller in index order. Returns the ciphertext points and `n * msg_len` key bytes.
 pub fn encap_batch(commitment: &G1Projective, tau_g2: &G2Projective, points: &[Fr], values: &[Fr], rs: &[Fr], msg_len: usize) -> (Vec<G2Projective>, Vec<u8>) {

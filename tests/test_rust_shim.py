@@ -88,11 +88,12 @@ def test_glue_calls_only_declared_symbols():
     declared = set(rust_functions())
     for rel in ("keaki/src/hip.rs", "keaki/tests/hip_parity.rs", "keaki/keaki-hip.patch"):
         text = open(os.path.join(RUST, rel)).read()
-        used = set(re.findall(r"\b(keaki_hip_\w+)\b", text)) - {"keaki_hip_sys", "keaki_hip_ctx", "keaki_hip_srs_g1", "keaki_hip_srs_g2"}
+        used = set(re.findall(r"\b(keaki_hip_\w+)\b", text)) - {"keaki_hip_sys", "keaki_hip_ctx", "keaki_hip_srs_g1", "keaki_hip_srs_g2", "keaki_hip_fk_shard"}
         assert used <= declared, (rel, sorted(used - declared))
     glue = open(os.path.join(RUST, "keaki", "src", "hip.rs")).read()
     for sym in ("keaki_hip_msm_g1", "keaki_hip_kzg_open", "keaki_hip_kzg_verify", "keaki_hip_open_fk_poly", "keaki_hip_encap_batch", "keaki_hip_decap_batch",
-                "keaki_hip_pairing_batch", "keaki_hip_srs_g1_upload", "keaki_hip_srs_g1_precompute"):
+                "keaki_hip_pairing_batch", "keaki_hip_srs_g1_upload", "keaki_hip_srs_g1_precompute", "keaki_hip_fk_shard_create", "keaki_hip_fk_shard_setup",
+                "keaki_hip_fk_shard_open", "keaki_hip_fk_shard_free"):
         assert sym in glue
     # the precompute call passes three arguments (the declaration VERDICT r01 found wrong had two)
     assert re.search(r"keaki_hip_srs_g1_precompute\(\s*dev\.ctx,\s*srs,\s*core::ptr::null_mut\(\)\s*\)", glue)
