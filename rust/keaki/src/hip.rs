@@ -256,7 +256,7 @@ pub trait FkExchange {
 }
 
 /// `open_fk` with its group FFTs sharded over the `world` ranks (= GPUs) of a job: every rank calls this with the same coefficients and
-/// gets all `d` proofs; it runs 1/world of the butterflies and scalar-mults (`keaki_hip_fk_shard_*`, include/keaki_hip.h). `send` / `recv`:
+/// gets all `d` proofs; it runs 1/world of the butterflies and scalar-mults (the `fk_shard` entry points of include/keaki_hip.h). `send` / `recv`:
 /// device buffers of `buffer_bytes()` each, owned by the caller (they are what the collectives move).
 pub struct ShardedOpenFk {
     fk: *mut sys::keaki_hip_fk_shard,
