@@ -414,7 +414,7 @@ def main():
     # HBM traffic of the dominant kernel from PMC counters (separate rocprofv3 --pmc passes, committed under profiles/, stamped with
     # the kernel sources they were measured on)
     traffic, traffic_note = None, None
-    tj, why = stamped_profile("r02_msm_2p24_hbm_traffic_pmc.json", MSM_KERNEL_SOURCES)
+    tj, why = stamped_profile("r03_msm_2p24_hbm_traffic_pmc.json", MSM_KERNEL_SOURCES)
     if tj is None:
         traffic_note = why
     elif tj.get("log2n") != args.log2n or bool(tj.get("precompute", True)) != (not args.no_precompute):
@@ -424,9 +424,9 @@ def main():
             if "k_msm_accumulate" in kname:
                 traffic = kv["fetch_bytes"] + kv["write_bytes"]
     # integer roofline: one XYZZ mixed add = 8M + 2S = 10 Montgomery products; instruction count of the loop body from the shipped
-    # ISA (bench_tools/count_isa.py -> profiles/r02_accumulate_isa.json), issue rate from the committed micro-benchmark
+    # ISA (bench_tools/count_isa.py -> profiles/r03_accumulate_isa.json), issue rate from the committed micro-benchmark
     alu = None
-    isa, isa_why = stamped_profile("r02_accumulate_isa.json", MSM_KERNEL_SOURCES)
+    isa, isa_why = stamped_profile("r03_accumulate_isa.json", MSM_KERNEL_SOURCES)
     mul_cyc, simple_cyc, cyc_src = stream_cycles_from_ubench(3)
     if isa is not None and mul_cyc is not None and simple_cyc is not None:
         ipa, mads = float(isa["loop_instructions"]), float(isa["loop_v_mad_u64_u32"])
@@ -439,7 +439,7 @@ def main():
         alu = {"bound": "integer issue (v_mad_u64_u32 streams)", "achieved": modmuls / 1e9, "peak": modmuls / 1e9 * measured_cycles / model_cycles, "unit": "G modmul/s",
                "frac": model_cycles / measured_cycles, "simd_cycles_per_mixed_add_measured": measured_cycles, "simd_cycles_per_mixed_add_at_stream_rate": model_cycles,
                "issues_per_mixed_add": ipa, "v_mad_u64_u32_per_mixed_add": mads, "product_stream_cycles": mul_cyc, "plain_valu_cycles": simple_cyc,
-               "sources": ["profiles/r02_accumulate_isa.json", cyc_src],
+               "sources": ["profiles/r03_accumulate_isa.json", cyc_src],
                "note": "a schedule diagnostic (how close the kernel runs to the issue rate of ITS OWN instruction stream at 3 waves per SIMD and "
                        "2.4 GHz), not a claim that the stream is minimal"}
     else:

@@ -5,7 +5,7 @@
 FETCH_SIZE for the bucket kernel: MI355X_MICROARCH.md calibrates that factor only for 16-B-per-lane coalesced streams and
 says other shapes are uncalibrated; the kernel gathers 64-B rows at per-lane addresses.
 
-    python bench_tools/collect_pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w profiles/r02_msm_2p24_hbm_traffic_pmc.json
+    python bench_tools/collect_pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w profiles/r03_msm_2p24_hbm_traffic_pmc.json
 
 The output is stamped with the SHA-256 of the kernel sources (bench_tools/srchash.py): bench.py refuses it when the tree differs.
 """
@@ -16,7 +16,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench_tools.srchash import source_hash, MSM_KERNEL_SOURCES  # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+from bench_tools.srchash import built_hash  # noqa: E402
 
 
 def last_per_kernel(d, counter):
@@ -32,13 +33,19 @@ def last_per_kernel(d, counter):
     return {k: v[1] for k, v in out.items()}
 
 
+def _stamp():
+    """hash embedded in the libkeaki_hip.so that was measured (raises if that build and the tree disagree)"""
+    import ctypes
+    return built_hash(ctypes.CDLL(os.path.join(ROOT, "keaki_amd", "libkeaki_hip.so")), "msm")
+
+
 def main():
     fdir, wdir, dst = sys.argv[1:4]
     f, w = last_per_kernel(fdir, "FETCH_SIZE"), last_per_kernel(wdir, "WRITE_SIZE")
     kernels = {k: {"fetch_bytes": f.get(k), "write_bytes": w.get(k)} for k in sorted(set(f) | set(w))}
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes; counters in KB x 1024), python3 bench.py --log2n 24 "
                          "--steps 1 --warmup 0 --no-cpu-baseline --no-extras --kem-log2n 0, MI355X; last launch of each kernel",
-               "unit": "bytes per launch", "log2n": 24, "precompute": True, "kernel_source_sha256": source_hash(MSM_KERNEL_SOURCES),
+               "unit": "bytes per launch", "log2n": 24, "precompute": True, "kernel_source_sha256": _stamp(),
                "note": "FETCH_SIZE as measured (no x2: the gfx950 correction is calibrated for 16-B-per-lane coalesced streams only; "
                        "k_msm_accumulate_g1_u29 gathers 64-B table rows at per-lane addresses). Expected reads of that kernel: 12 windows "
                        "x 2^24 x 64 B = 12.9 GB of table rows + 0.8 GB of sorted indices; writes = 2^21 buckets x 128 B.",

@@ -1,7 +1,7 @@
 // Debug harness (not part of the library): per-check mismatch counters of the lane-pair tower primitives.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I keaki_amd/csrc bench_tools/dbg/dbg_pair.hip -o /tmp/dbg_pair && /tmp/dbg_pair
 #include <cstdio>
-#include "pairing.cuh"
+#include "pairing.hip.h"
 using namespace bn254;
 using namespace bn254::p261;
 KDEV u32 mix(u32& s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }

@@ -13,8 +13,8 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -o w -
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/pmc -o p -- python3 $R/bench_tools/profile_pairing_split.py > $O/pmc.log 2>&1; echo "pmc_pair rc=$?" >> $O/rc.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/split -o s -- python3 $R/bench_tools/profile_pairing_split.py > $O/split.log 2>&1; echo "split rc=$?" >> $O/rc.txt
 cd $R
-python3 bench_tools/collect_pmc_traffic.py $O/pmc_f $O/pmc_w $O/r02_msm_2p24_hbm_traffic_pmc.json > $O/collect.log 2>&1
-cp $O/r02_msm_2p24_hbm_traffic_pmc.json profiles/ 2>/dev/null
+python3 bench_tools/collect_pmc_traffic.py $O/pmc_f $O/pmc_w $O/r03_msm_2p24_hbm_traffic_pmc.json > $O/collect.log 2>&1
+cp $O/r03_msm_2p24_hbm_traffic_pmc.json profiles/ 2>/dev/null
 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_after_restamp.json 2>> $O/bench.err
 python3 bench_kem.py > $O/kem16.json 2>&1
 python3 bench_kem.py --log2n 20 > $O/kem20.json 2>&1

@@ -1,7 +1,7 @@
 // Micro-benchmark of the fq29 streams on gfx950: cycles per Montgomery product / square at 1..4 waves per SIMD, against
 // a dependent v_mad_u64_u32 chain, v_lshrrev_b64 and the saturated fq_mul_asm. Prices the "issue ceiling" of DESIGN.md.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I keaki_amd/csrc -o bench_tools/ubench_u29 bench_tools/ubench_u29.hip
-#include "fq29.cuh"
+#include "fq29.hip.h"
 #include <stdio.h>
 using namespace bn254;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)

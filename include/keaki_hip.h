@@ -24,14 +24,24 @@
  *                      c0.c0.c0, c0.c0.c1, c0.c1.c0, ..., c1.c2.c1, each canonical 32-byte LE.
  *    (arkworks' in-memory `Affine { x, y, infinity: bool }` is repr(Rust); the shim must write x,y
  *    explicitly and map `infinity` to the all-zero encoding.)
- *  - A ctx is bound to one GPU. Multi-GPU = one ctx (one process) per GPU: each rank runs
- *    msm on its contiguous chunk of (scalar, point) pairs, the 96-byte partial sums are exchanged
- *    with RCCL all-gather by the caller, and keaki_hip_g1_sum_dev adds them.
+ *  - A ctx is bound to one GPU. Multi-GPU, two ways: (a) in one process, keaki_hip_group_* below (one ctx and
+ *    one host thread per GPU inside the library, partial sums through host memory); (b) one process per GPU:
+ *    each rank runs msm on its contiguous chunk of (scalar, point) pairs, the 96-byte partial sums are
+ *    exchanged with RCCL all-gather by the caller, and keaki_hip_g1_sum_dev adds them.
  *  - Thread-safety: a ctx serialises calls internally (one recursive mutex, held from the first staging
  *    copy of a host-pointer call to its last download, so the shared staging buffers belong to one
  *    call at a time); calls from several host threads on one ctx are safe and run one after another.
- *    Use one ctx per host thread for concurrency. Handles (keaki_hip_srs_*) must not be freed while
- *    another thread still uses them.
+ *    Use one ctx per host thread for concurrency. An SRS handle (keaki_hip_srs_*) is device memory, not
+ *    context state: every ctx on the same device may pass it to msm / kzg_open / open_fk, so N threads with a
+ *    ctx each share ONE copy of the points, the window tables and the FK23 transform (the handle locks its
+ *    lazily built members; a handle from another device is refused with KEAKI_ERR_BAD_ARG). Handles must not
+ *    be freed while another thread still uses them.
+ *  - Memory: keaki_hip_ctx_memory reports what a ctx holds. Per ctx: MSM workspaces (2.4 GB at 2^24 points),
+ *    pairing slots (0.48 GB), the GT tables of encapsulate (2.6 GB + 0.2 GB once a batch >= 2^16 ran). Per SRS
+ *    handle (shared by every ctx of the device): points (64 B each) + window tables (W x 64 B each: 12.9 GB at
+ *    2^24) + the FK23 transform (192 B per opening). All optional tables fall back when they do not fit.
+ *  - The library reads the environment only inside keaki_hip_ctx_create (initial values of the tuning switches
+ *    of keaki_hip_ctx_set_option); nothing on a call path calls getenv.
  */
 #ifndef KEAKI_HIP_H
 #define KEAKI_HIP_H
@@ -70,7 +80,21 @@ keaki_status keaki_hip_ctx_create(int32_t device, void* stream, keaki_hip_ctx** 
 void keaki_hip_ctx_destroy(keaki_hip_ctx* ctx);
 const char* keaki_hip_last_error(const keaki_hip_ctx* ctx); /* ctx may be NULL: last create error */
 keaki_status keaki_hip_synchronize(keaki_hip_ctx* ctx);
+/* "keaki-hip <ver> (gfx950) src=msm:<hash>,pairing:<hash>": the hashes of the kernel sources the binary was built from */
 const char* keaki_hip_version(void);
+/* keaki_hip_last_error: the returned string is a copy private to the calling thread (valid until its next call of this function). */
+/* Tuning / A-B switches of a context (profiling and tests; defaults are what ships). Initial values come from the environment variable
+ * KEAKI_<NAME> at keaki_hip_ctx_create; afterwards only this call changes them. Names: "msm_c", "msm_c_shared" (window bits, 0 = automatic),
+ * "reduce_l", "part_shift", "p1_sub", "p2_small", "acc_u29", "acc_u29_g2", "fk_uniform", "fb_occ1", "gt_wb_b" (window bits of the table of
+ * e(g1, g2), 0 = automatic; a change rebuilds the table on the next use), "encap_gt" (batch size from which encap_batch takes the GT
+ * fixed-base path and below which it never does; -1 = the automatic policy). Unknown name -> KEAKI_ERR_BAD_ARG. */
+keaki_status keaki_hip_ctx_set_option(keaki_hip_ctx* ctx, const char* name, int64_t value);
+/* Test hook: every single device allocation of this ctx above `bytes` fails with KEAKI_ERR_OOM (0 = no limit). This is how the tests
+ * exercise the optional-memory fallbacks (SRS window tables, the wide GT table); nothing in the library sets it. */
+keaki_status keaki_hip_debug_set_alloc_limit(keaki_hip_ctx* ctx, size_t bytes);
+/* Device memory this ctx holds right now, bytes: out4[0] = window tables + FK23 transforms of SRS handles built through this ctx (the
+ * points themselves belong to the caller's upload), [1] = grow-only workspaces, [2] = fixed-base / GT tables of encapsulate, [3] = total. */
+keaki_status keaki_hip_ctx_memory(keaki_hip_ctx* ctx, size_t* out4);
 
 /* ---- SRS: replaces KZGSetup::g1_aff (src/kzg.rs:22-29, built at :63) -------------------------- */
 keaki_status keaki_hip_srs_g1_upload(keaki_hip_ctx* ctx, const uint64_t* points_aff, size_t n, keaki_hip_srs_g1** out);
@@ -160,6 +184,11 @@ keaki_status keaki_hip_fr_fft(keaki_hip_ctx* ctx, uint64_t* data, uint32_t log2n
 keaki_status keaki_hip_kzg_open(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, const uint64_t* coeffs, size_t n, const uint64_t* point,
                                 uint64_t* proof_out_jac, uint64_t* value_out);
 
+/* The quotient alone, for callers that run the MSM elsewhere (keaki_hip_group_kzg_open does): quotient_out = n - 1 Fr (may be NULL when
+ * n <= 1), value_out = p(point) (u64[4] or NULL). Same recurrence as keaki_hip_kzg_open, host pointers in and out. */
+keaki_status keaki_hip_kzg_quotient(keaki_hip_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t* point, uint64_t* quotient_out,
+                                    uint64_t* value_out);
+
 /* ---- KZG `verify` in one call -------------------------------------------------------------------------------------
  * Replaces the body of `verify` (reference src/kzg.rs:127-146): e(com - value g1, g2) == e(proof, [tau]_2 - point g2).
  * Evaluated as e(com - value g1 + point proof, g2) == e(proof, [tau]_2): the same predicate by bilinearity, with both second
@@ -208,6 +237,38 @@ keaki_status keaki_hip_decap_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_af
                                    uint8_t* gt_out, uint8_t* key_out, size_t msg_len);
 keaki_status keaki_hip_decap_batch_dev(keaki_hip_ctx* ctx, const void* d_proofs_aff, const void* d_cts_aff, size_t n,
                                        void* d_gt_out, void* d_key_out, size_t msg_len);
+
+/* ---- device group: in-process multi-GPU (SURVEY 8b `_create(n_devices)`, 8e "single process, one host thread per GPU") -----------------
+ * What a Rust caller of keaki gets with more than one GPU and no PyTorch / RCCL: the library keeps one ctx and one host worker thread per
+ * entry of `devices` (an ordinal may repeat: several contexts on one GPU, which is how the single-GPU test box exercises it), the SRS is
+ * split into contiguous chunks, chunk i resident on devices[i] with ITS window tables (built in parallel at upload), and
+ *   keaki_hip_group_msm_g1      = commit's MSM (src/kzg.rs:98): every member runs a complete Pippenger on its (scalar, point) range, the
+ *                                 N partial sums (96 B each) come back through host memory -- no collective in-process -- and member 0
+ *                                 adds them (keaki_hip_g1_sum). EC addition is exact: the affine result equals the one-GPU result.
+ *   keaki_hip_group_kzg_open    = `open` (src/kzg.rs:104-124): quotient on member 0, then the group MSM.
+ *   keaki_hip_group_encap_batch / _decap_batch = the loops of vec_encrypt / vec_decrypt (src/vec.rs:63-66, :75-78) split by item range,
+ *                                 every member writing straight into its slice of the caller's output arrays.
+ * Ranges follow the SRS (member i owns points [i*len/N ...)), not the polynomial, so the tables serve every polynomial.
+ * Errors: the first failing member's status; keaki_hip_group_last_error names the member. Calls on one group are serialised. */
+typedef struct keaki_hip_group keaki_hip_group;
+typedef struct keaki_hip_group_srs_g1 keaki_hip_group_srs_g1;
+keaki_status keaki_hip_group_create(const int32_t* devices, size_t n_devices, keaki_hip_group** out);
+void keaki_hip_group_destroy(keaki_hip_group* g);
+size_t keaki_hip_group_size(const keaki_hip_group* g);
+keaki_hip_ctx* keaki_hip_group_ctx(const keaki_hip_group* g, size_t member);   /* member's ctx, e.g. for verify / open_fk on member 0 */
+const char* keaki_hip_group_last_error(const keaki_hip_group* g);               /* g may be NULL: last create error */
+/* precompute != 0: also build every chunk's window tables (KEAKI_ERR_OOM of a table is tolerated: that member runs the generic MSM) */
+keaki_status keaki_hip_group_srs_g1_upload(keaki_hip_group* g, const uint64_t* points_aff, size_t n, int32_t precompute, keaki_hip_group_srs_g1** out);
+size_t keaki_hip_group_srs_g1_len(const keaki_hip_group_srs_g1* srs);
+void keaki_hip_group_srs_g1_free(keaki_hip_group* g, keaki_hip_group_srs_g1* srs);
+keaki_status keaki_hip_group_msm_g1(keaki_hip_group* g, const keaki_hip_group_srs_g1* srs, const uint64_t* scalars, size_t n, uint64_t* out_jac);
+keaki_status keaki_hip_group_kzg_open(keaki_hip_group* g, const keaki_hip_group_srs_g1* srs, const uint64_t* coeffs, size_t n, const uint64_t* point,
+                                      uint64_t* proof_out_jac, uint64_t* value_out);
+keaki_status keaki_hip_group_encap_batch(keaki_hip_group* g, const uint64_t* com_aff, const uint64_t* tau_g2_aff, const uint64_t* points,
+                                         const uint64_t* values, const uint64_t* r, size_t n, uint64_t* ct_out_aff, uint8_t* gt_out,
+                                         uint8_t* key_out, size_t msg_len);
+keaki_status keaki_hip_group_decap_batch(keaki_hip_group* g, const uint64_t* proofs_aff, const uint64_t* cts_aff, size_t n, uint8_t* gt_out,
+                                         uint8_t* key_out, size_t msg_len);
 
 /* ---- instrumentation (bench.py reads these; not part of the reference surface) ---------------- */
 /* device time in milliseconds of the dominant kernel (bucket accumulation) of the last msm_*_dev

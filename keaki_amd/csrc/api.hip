@@ -5,13 +5,21 @@
 
 #include <algorithm>
 #include <utility>
+#include <vector>
 
 using namespace keaki_internal;
 
+// An SRS handle is device memory, not context state: every context ON THE SAME DEVICE may pass it to msm / open / open_fk (read-only use
+// of the points, the window tables and the cached FK23 transform), so N host threads with a context each share ONE set of tables.
+// `mu` guards the lazily built members (table, fk_hat_s); `acct` is the context whose keaki_hip_ctx_memory counts them.
 struct keaki_hip_srs_g1 {
   const void* d = nullptr;
   size_t n = 0;
   bool owned = false;
+  int device = -1;
+  std::recursive_mutex mu;
+  keaki_hip_ctx* acct = nullptr;
+  size_t fk_bytes = 0;
   // precomputed window tables (keaki_hip_srs_g1_precompute): table[w * n + i] = 2^(offset_w) * P_i
   void* table = nullptr;
   size_t table_bytes = 0;
@@ -24,6 +32,9 @@ struct keaki_hip_srs_g2 {
   const void* d = nullptr;
   size_t n = 0;
   bool owned = false;
+  int device = -1;
+  std::recursive_mutex mu;
+  keaki_hip_ctx* acct = nullptr;
   void* table = nullptr;          // window tables (keaki_hip_srs_g2_precompute), as for G1
   size_t table_bytes = 0;
   int c_table = 0;
@@ -70,10 +81,8 @@ keaki_status fail(keaki_hip_ctx* ctx, keaki_status code, const char* fmt, ...) {
 }
 
 keaki_status dev_alloc(keaki_hip_ctx* ctx, void** p, size_t bytes) {
-  if (const char* lim = getenv("KEAKI_TEST_ALLOC_LIMIT")) {
-    if (bytes > (size_t)strtoull(lim, nullptr, 10))
-      return fail(ctx, KEAKI_ERR_OOM, "allocation of %zu bytes refused by KEAKI_TEST_ALLOC_LIMIT=%s", bytes, lim);
-  }
+  if (ctx && ctx->tune.alloc_limit && bytes > ctx->tune.alloc_limit)
+    return fail(ctx, KEAKI_ERR_OOM, "allocation of %zu bytes refused by keaki_hip_debug_set_alloc_limit(%zu)", bytes, ctx->tune.alloc_limit);
   hipError_t e = hipMalloc(p, bytes);
   if (e != hipSuccess) {
     (void)hipGetLastError();
@@ -126,6 +135,30 @@ keaki_status download(keaki_hip_ctx* ctx, void* host, const void* dev, size_t by
   return KEAKI_OK;
 }
 
+// (table, window target) of a handle, read under its lock: another context may be building the tables right now
+template <class H>
+std::pair<const void*, int> srs_tables(const H* srs) {
+  std::lock_guard<std::recursive_mutex> hl(const_cast<H*>(srs)->mu);
+  return {srs->table, srs->c_table};
+}
+// bookkeeping after a call that may have (re)built the cached FK23 transform of a handle (2d Jacobian points)
+void fk_account(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs) {
+  const size_t now = srs->fk_hat_s && srs->fk_log2d >= 0 ? ((size_t)2 << srs->fk_log2d) * 96 : 0;
+  if (now == srs->fk_bytes) return;
+  if (srs->acct == ctx || !srs->acct) { srs->acct = ctx; ctx->mem_tables -= std::min(ctx->mem_tables, srs->fk_bytes); ctx->mem_tables += now; }
+  srs->fk_bytes = now;
+}
+template <class H>
+H* new_srs(keaki_hip_ctx* ctx, const void* d, size_t n, bool owned) {
+  H* h = new H();
+  h->d = d; h->n = n; h->owned = owned; h->device = ctx->device; h->acct = ctx;
+  return h;
+}
+// a handle may be used by any context of the device it lives on
+#define SRS_CHECK(ctx, srs, what)                                                                                                     \
+  if ((srs)->device != (ctx)->device)                                                                                                 \
+    return fail(ctx, KEAKI_ERR_BAD_ARG, what ": the SRS handle lives on device %d, this context on device %d", (srs)->device, (ctx)->device)
+
 #define CTX_GUARD(ctx)                                \
   if (!(ctx)) return KEAKI_ERR_BAD_ARG;               \
   std::lock_guard<std::recursive_mutex> lock_((ctx)->mu);       \
@@ -135,7 +168,46 @@ keaki_status download(keaki_hip_ctx* ctx, void* host, const void* dev, size_t by
 
 extern "C" {
 
-const char* keaki_hip_version(void) { return "keaki-hip 0.1 (gfx950)"; }
+#ifndef KEAKI_SRC_HASH
+#define KEAKI_SRC_HASH "unknown"
+#endif
+// "... src=<hash>": the hash of the kernel sources this binary was built from (csrc/Makefile, bench_tools/srchash.py); the profile
+// collectors stamp their output with it and bench.py refuses figures measured on another build.
+const char* keaki_hip_version(void) { return "keaki-hip 0.3 (gfx950) src=" KEAKI_SRC_HASH; }
+
+extern "C++" {
+namespace {
+// The ONE place the library reads the environment: initial values of a context's tuning switches.
+void tune_from_env(Tuning& t) {
+  auto geti = [](const char* name, long long& out) { const char* e = getenv(name); if (!e || !*e) return false; out = atoll(e); return true; };
+  long long v;
+  if (geti("KEAKI_MSM_C", v)) t.msm_c = (int)v;
+  if (geti("KEAKI_MSM_C_SHARED", v)) t.msm_c_shared = (int)v;
+  if (geti("KEAKI_REDUCE_L", v)) t.reduce_l = (int)v;
+  if (geti("KEAKI_PART_SHIFT", v)) t.part_shift = (int)v;
+  if (geti("KEAKI_P1_SUB", v)) t.p1_sub = v > 0 ? (uint32_t)v : 1u;
+  if (geti("KEAKI_P2_SMALL", v)) t.p2_small = v != 0;
+  if (geti("KEAKI_ACC_U29", v)) t.acc_u29 = v != 0;
+  if (geti("KEAKI_ACC_U29_G2", v)) t.acc_u29_g2 = v != 0;
+  if (geti("KEAKI_FK_UNIFORM", v)) t.fk_uniform = v != 0;
+  if (geti("KEAKI_FB_OCC1", v)) t.fb_occ1 = v != 0;
+  if (geti("KEAKI_GT_WB_B", v)) t.gt_wb_b = (int)v;
+  if (geti("KEAKI_ENCAP_GT", v)) t.encap_gt = v;
+}
+struct BufClass { DevBuf* b; int cls; };   // cls: 1 = workspace, 2 = GT / fixed-base tables of encapsulate
+std::vector<BufClass> all_bufs(keaki_hip_ctx* ctx) {
+  std::vector<BufClass> v;
+  for (DevBuf* b : {&ctx->digits, &ctx->hist, &ctx->offsets, &ctx->cursor, &ctx->sorted, &ctx->buckets, &ctx->partials, &ctx->wsums, &ctx->bsums,
+                    &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->io_a, &ctx->io_b, &ctx->io_c, &ctx->io_d, &ctx->io_e, &ctx->perm, &ctx->heavy,
+                    &ctx->pair_ws, &ctx->verify_lines, &ctx->verify_io, &ctx->g2gen_lines})
+    v.push_back({b, 1});
+  for (DevBuf* b : {&ctx->fb_scalars, &ctx->fb_g1_gen, &ctx->fb_g2_gen, &ctx->fb_com, &ctx->fb_tau, &ctx->gt_tab_a, &ctx->gt_tab_b, &ctx->gt_base,
+                    &ctx->fbs_scalars, &ctx->fbs_g2_gen, &ctx->fbs_tau})
+    v.push_back({b, 2});
+  return v;
+}
+}  // namespace
+}  // extern "C++"
 
 keaki_status keaki_hip_ctx_create(int32_t device, void* stream, keaki_hip_ctx** out) {
   if (!out) return fail(nullptr, KEAKI_ERR_BAD_ARG, "ctx_create: out is null");
@@ -150,6 +222,7 @@ keaki_status keaki_hip_ctx_create(int32_t device, void* stream, keaki_hip_ctx** 
     return fail(nullptr, KEAKI_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
   keaki_hip_ctx* ctx = new keaki_hip_ctx();
   ctx->device = device;
+  tune_from_env(ctx->tune);
   if (stream) {
     ctx->stream = (hipStream_t)stream;
   } else {
@@ -168,16 +241,63 @@ void keaki_hip_ctx_destroy(keaki_hip_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  for (DevBuf* b : {&ctx->digits, &ctx->hist, &ctx->offsets, &ctx->cursor, &ctx->sorted, &ctx->buckets, &ctx->partials, &ctx->wsums,
-                    &ctx->bsums, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->io_a, &ctx->io_b, &ctx->io_c, &ctx->io_d, &ctx->io_e,
-                    &ctx->fb_scalars, &ctx->fb_g1_gen, &ctx->fb_g2_gen, &ctx->fb_com, &ctx->fb_tau, &ctx->perm, &ctx->g2gen_lines, &ctx->gt_tab_a, &ctx->gt_tab_b, &ctx->gt_base, &ctx->heavy, &ctx->pair_ws, &ctx->verify_lines, &ctx->verify_io, &ctx->fbs_scalars, &ctx->fbs_g2_gen, &ctx->fbs_tau})
-    if (b->p) (void)hipFree(b->p);
+  for (const BufClass& bc : all_bufs(ctx))
+    if (bc.b->p) (void)hipFree(bc.b->p);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 
-const char* keaki_hip_last_error(const keaki_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+// The message is copied under the context lock into a buffer of the CALLING thread (valid until that thread's next call of this
+// function), so a concurrent failing call on another thread cannot reallocate the string under the reader.
+const char* keaki_hip_last_error(const keaki_hip_ctx* ctx) {
+  if (!ctx) return g_create_error.c_str();
+  thread_local std::string copy;
+  keaki_hip_ctx* c = const_cast<keaki_hip_ctx*>(ctx);
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
+  copy = c->err;
+  return copy.c_str();
+}
+
+keaki_status keaki_hip_ctx_set_option(keaki_hip_ctx* ctx, const char* name, int64_t value) {
+  if (!ctx) return KEAKI_ERR_BAD_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(ctx->mu);
+  if (!name) return fail(ctx, KEAKI_ERR_BAD_ARG, "ctx_set_option: name is null");
+  Tuning& t = ctx->tune;
+  const std::string k(name);
+  if (k == "msm_c") t.msm_c = (int)value;
+  else if (k == "msm_c_shared") t.msm_c_shared = (int)value;
+  else if (k == "reduce_l") t.reduce_l = (int)value;
+  else if (k == "part_shift") t.part_shift = (int)value;
+  else if (k == "p1_sub") t.p1_sub = value > 0 ? (uint32_t)value : 1u;
+  else if (k == "p2_small") t.p2_small = value != 0;
+  else if (k == "acc_u29") t.acc_u29 = value != 0;
+  else if (k == "acc_u29_g2") t.acc_u29_g2 = value != 0;
+  else if (k == "fk_uniform") t.fk_uniform = value != 0;
+  else if (k == "fb_occ1") t.fb_occ1 = value != 0;
+  else if (k == "gt_wb_b") {
+    if (value != 0 && (value < 8 || value > 22 || gt_table_powers((uint32_t)value) > 320)) return fail(ctx, KEAKI_ERR_BAD_ARG, "ctx_set_option: gt_wb_b = %lld out of range", (long long)value);
+    if ((int)value != t.gt_wb_b) { ctx->gt_b_ready = false; ctx->gt_b_fallback = false; }      // the table of B is rebuilt at the new width on the next use
+    t.gt_wb_b = (int)value;
+  } else if (k == "encap_gt") t.encap_gt = value;
+  else return fail(ctx, KEAKI_ERR_BAD_ARG, "ctx_set_option: unknown option '%s'", name);
+  return KEAKI_OK;
+}
+keaki_status keaki_hip_debug_set_alloc_limit(keaki_hip_ctx* ctx, size_t bytes) {
+  if (!ctx) return KEAKI_ERR_BAD_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(ctx->mu);
+  ctx->tune.alloc_limit = bytes;
+  return KEAKI_OK;
+}
+keaki_status keaki_hip_ctx_memory(keaki_hip_ctx* ctx, size_t* out4) {
+  if (!ctx) return KEAKI_ERR_BAD_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(ctx->mu);
+  if (!out4) return fail(ctx, KEAKI_ERR_BAD_ARG, "ctx_memory: out4 is null");
+  size_t ws = 0, gt = 0;
+  for (const BufClass& bc : all_bufs(ctx)) (bc.cls == 1 ? ws : gt) += bc.b->cap;
+  out4[0] = ctx->mem_tables; out4[1] = ws; out4[2] = gt; out4[3] = ctx->mem_tables + ws + gt;
+  return KEAKI_OK;
+}
 
 keaki_status keaki_hip_synchronize(keaki_hip_ctx* ctx) {
   CTX_GUARD(ctx);
@@ -205,13 +325,13 @@ keaki_status keaki_hip_srs_g1_upload(keaki_hip_ctx* ctx, const uint64_t* points_
     hipError_t e = hipMemcpy(d, points_aff, n * G1_AFF_BYTES, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(d); return fail(ctx, KEAKI_ERR_HIP, "srs upload copy failed: %s", hipGetErrorString(e)); }
   }
-  *out = new keaki_hip_srs_g1{d, n, true};
+  *out = new_srs<keaki_hip_srs_g1>(ctx, d, n, true);
   return KEAKI_OK;
 }
 keaki_status keaki_hip_srs_g1_wrap_dev(keaki_hip_ctx* ctx, const void* d_points_aff, size_t n, keaki_hip_srs_g1** out) {
   CTX_GUARD(ctx);
   if (!out || (n && !d_points_aff)) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g1_wrap_dev: null pointer");
-  *out = new keaki_hip_srs_g1{d_points_aff, n, false};
+  *out = new_srs<keaki_hip_srs_g1>(ctx, d_points_aff, n, false);
   return KEAKI_OK;
 }
 // non-owning view of points [offset, offset + n) of an uploaded SRS: the chunk a rank owns when an MSM is sharded by point range
@@ -219,25 +339,38 @@ keaki_status keaki_hip_srs_g1_slice(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* 
   CTX_GUARD(ctx);
   if (!srs || !out) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g1_slice: null pointer");
   if (offset > srs->n || n > srs->n - offset) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g1_slice: [%zu, %zu) is outside the %zu points of the SRS", offset, offset + n, srs->n);
-  *out = new keaki_hip_srs_g1{(const char*)srs->d + offset * G1_AFF_BYTES, n, false};
+  if (srs->device != ctx->device) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g1_slice: the SRS lives on device %d, this context on device %d", srs->device, ctx->device);
+  *out = new_srs<keaki_hip_srs_g1>(ctx, (const char*)srs->d + offset * G1_AFF_BYTES, n, false);
   return KEAKI_OK;
 }
 size_t keaki_hip_srs_g1_len(const keaki_hip_srs_g1* srs) { return srs ? srs->n : 0; }
 void keaki_hip_srs_g1_free(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs) {
   if (!srs) return;
   if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+  if (srs->device >= 0) (void)hipSetDevice(srs->device);
   if (srs->owned && srs->d) (void)hipFree((void*)srs->d);
   if (srs->table) (void)hipFree(srs->table);
   if (srs->fk_hat_s) (void)hipFree(srs->fk_hat_s);
+  if (ctx && ctx == srs->acct) {
+    std::lock_guard<std::recursive_mutex> lock_(ctx->mu);
+    const size_t held = srs->table_bytes + srs->fk_bytes;
+    ctx->mem_tables -= std::min(ctx->mem_tables, held);
+  }
   delete srs;
 }
 keaki_status keaki_hip_srs_g1_precompute(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, size_t* table_bytes_out) {
   CTX_GUARD(ctx);
   TRACE_SCOPE("keaki.srs_precompute");
   if (!srs) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g1_precompute: srs is null");
+  SRS_CHECK(ctx, srs, "srs_g1_precompute");
+  std::lock_guard<std::recursive_mutex> hl(srs->mu);       // contexts sharing the handle: the first one builds, the others find the tables
   if (!srs->table && srs->n) {
-    ST_TRY(msm_g1_precompute_run(ctx, srs->d, srs->n, &srs->c_table, &srs->table_bytes, &srs->table));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int c = 0; size_t bytes = 0; void* t = nullptr;
+    ST_TRY(msm_g1_precompute_run(ctx, srs->d, srs->n, &c, &bytes, &t));
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(t); return fail(ctx, KEAKI_ERR_HIP, "srs_g1_precompute: %s", hipGetErrorString(e)); }
+    srs->c_table = c; srs->table_bytes = bytes; srs->table = t;       // published only when complete
+    srs->acct = ctx; ctx->mem_tables += bytes;
   }
   if (table_bytes_out) *table_bytes_out = srs->table_bytes;
   return KEAKI_OK;
@@ -251,29 +384,40 @@ keaki_status keaki_hip_srs_g2_upload(keaki_hip_ctx* ctx, const uint64_t* points_
     hipError_t e = hipMemcpy(d, points_aff, n * G2_AFF_BYTES, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(d); return fail(ctx, KEAKI_ERR_HIP, "srs upload copy failed: %s", hipGetErrorString(e)); }
   }
-  *out = new keaki_hip_srs_g2{d, n, true};
+  *out = new_srs<keaki_hip_srs_g2>(ctx, d, n, true);
   return KEAKI_OK;
 }
 keaki_status keaki_hip_srs_g2_wrap_dev(keaki_hip_ctx* ctx, const void* d_points_aff, size_t n, keaki_hip_srs_g2** out) {
   CTX_GUARD(ctx);
   if (!out || (n && !d_points_aff)) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g2_wrap_dev: null pointer");
-  *out = new keaki_hip_srs_g2{d_points_aff, n, false};
+  *out = new_srs<keaki_hip_srs_g2>(ctx, d_points_aff, n, false);
   return KEAKI_OK;
 }
 void keaki_hip_srs_g2_free(keaki_hip_ctx* ctx, keaki_hip_srs_g2* srs) {
   if (!srs) return;
   if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+  if (srs->device >= 0) (void)hipSetDevice(srs->device);
   if (srs->owned && srs->d) (void)hipFree((void*)srs->d);
   if (srs->table) (void)hipFree(srs->table);
+  if (ctx && ctx == srs->acct) {
+    std::lock_guard<std::recursive_mutex> lock_(ctx->mu);
+    ctx->mem_tables -= std::min(ctx->mem_tables, srs->table_bytes);
+  }
   delete srs;
 }
 keaki_status keaki_hip_srs_g2_precompute(keaki_hip_ctx* ctx, keaki_hip_srs_g2* srs, size_t* table_bytes_out) {
   CTX_GUARD(ctx);
   TRACE_SCOPE("keaki.srs_precompute");
   if (!srs) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g2_precompute: srs is null");
+  SRS_CHECK(ctx, srs, "srs_g2_precompute");
+  std::lock_guard<std::recursive_mutex> hl(srs->mu);
   if (!srs->table && srs->n) {
-    ST_TRY(msm_g2_precompute_run(ctx, srs->d, srs->n, &srs->c_table, &srs->table_bytes, &srs->table));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int c = 0; size_t bytes = 0; void* t = nullptr;
+    ST_TRY(msm_g2_precompute_run(ctx, srs->d, srs->n, &c, &bytes, &t));
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(t); return fail(ctx, KEAKI_ERR_HIP, "srs_g2_precompute: %s", hipGetErrorString(e)); }
+    srs->c_table = c; srs->table_bytes = bytes; srs->table = t;
+    srs->acct = ctx; ctx->mem_tables += bytes;
   }
   if (table_bytes_out) *table_bytes_out = srs->table_bytes;
   return KEAKI_OK;
@@ -284,16 +428,20 @@ keaki_status keaki_hip_msm_g1_dev(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* sr
   CTX_GUARD(ctx);
   TRACE_SCOPE("keaki.msm_g1");
   if (!srs) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm_g1: srs is null");
-  return msm_g1_run(ctx, srs->d, srs->n, d_scalars, n, d_out_jac, srs->table, srs->c_table);
+  SRS_CHECK(ctx, srs, "msm_g1");
+  const auto tb = srs_tables(srs);
+  return msm_g1_run(ctx, srs->d, srs->n, d_scalars, n, d_out_jac, tb.first, tb.second);
 }
 keaki_status keaki_hip_msm_g1(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, const uint64_t* scalars, size_t n, uint64_t* out_jac) {
   CTX_GUARD(ctx);
   TRACE_SCOPE("keaki.msm_g1");
   if (!srs || !out_jac || (n && !scalars)) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm_g1: null pointer");
+  SRS_CHECK(ctx, srs, "msm_g1");
   if (n > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", n, srs->n);
   ST_TRY(upload(ctx, ctx->io_a, scalars, n * 32));
   ST_TRY(reserve(ctx, ctx->io_b, 96));
-  ST_TRY(msm_g1_run(ctx, srs->d, srs->n, ctx->io_a.p, n, ctx->io_b.p, srs->table, srs->c_table));
+  const auto tb = srs_tables(srs);
+  ST_TRY(msm_g1_run(ctx, srs->d, srs->n, ctx->io_a.p, n, ctx->io_b.p, tb.first, tb.second));
   ST_TRY(download(ctx, out_jac, ctx->io_b.p, 96));
   resolve_timing(ctx);
   return KEAKI_OK;
@@ -302,16 +450,20 @@ keaki_status keaki_hip_msm_g2_dev(keaki_hip_ctx* ctx, const keaki_hip_srs_g2* sr
   CTX_GUARD(ctx);
   TRACE_SCOPE("keaki.msm_g2");
   if (!srs) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm_g2: srs is null");
-  return msm_g2_run(ctx, srs->d, srs->n, d_scalars, n, d_out_jac, srs->table, srs->c_table);
+  SRS_CHECK(ctx, srs, "msm_g2");
+  const auto tb = srs_tables(srs);
+  return msm_g2_run(ctx, srs->d, srs->n, d_scalars, n, d_out_jac, tb.first, tb.second);
 }
 keaki_status keaki_hip_msm_g2(keaki_hip_ctx* ctx, const keaki_hip_srs_g2* srs, const uint64_t* scalars, size_t n, uint64_t* out_jac) {
   CTX_GUARD(ctx);
   TRACE_SCOPE("keaki.msm_g2");
   if (!srs || !out_jac || (n && !scalars)) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm_g2: null pointer");
+  SRS_CHECK(ctx, srs, "msm_g2");
   if (n > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", n, srs->n);
   ST_TRY(upload(ctx, ctx->io_a, scalars, n * 32));
   ST_TRY(reserve(ctx, ctx->io_b, 192));
-  ST_TRY(msm_g2_run(ctx, srs->d, srs->n, ctx->io_a.p, n, ctx->io_b.p, srs->table, srs->c_table));
+  const auto tb = srs_tables(srs);
+  ST_TRY(msm_g2_run(ctx, srs->d, srs->n, ctx->io_a.p, n, ctx->io_b.p, tb.first, tb.second));
   ST_TRY(download(ctx, out_jac, ctx->io_b.p, 192));
   resolve_timing(ctx);
   return KEAKI_OK;
@@ -393,7 +545,7 @@ keaki_status keaki_hip_pairing_batch(keaki_hip_ctx* ctx, const uint64_t* g1_aff,
 }
 
 // signed-window table of e(P, g2) for a G1 point P in device memory: the powers of two e(P, g2)^(2^s) = e(2^s P, g2) come from one
-// pairing launch over the doubling chain of P (latency of one pairing), the rest of every window by products (pairing.cuh)
+// pairing launch over the doubling chain of P (latency of one pairing), the rest of every window by products (pairing.hip.h)
 static keaki_status gt_table_of(keaki_hip_ctx* ctx, const void* d_p_aff, void* d_table, uint32_t wb) {
   char* gb = (char*)ctx->gt_base.p;
   const uint32_t cnt = gt_table_powers(wb);
@@ -491,9 +643,9 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
   // already there: keaki's own loops (src/vec.rs:63-66) and a caller of the single `encapsulate` do exactly that, and an item then costs
   // ~30 Fq12 products instead of two G1 ladders and a pairing (single call: 9.2 -> 2.6 ms).
   constexpr uint32_t GT_WB_A_FIRST = 13, GT_WB_A_REPEAT = 16;
-  const char* wbb_env = getenv("KEAKI_GT_WB_B");
-  const char* gt_env = getenv("KEAKI_ENCAP_GT");
-  const size_t gt_threshold = gt_env ? (size_t)atoll(gt_env) : (size_t)65536;
+  const bool wbb_env = ctx->tune.gt_wb_b != 0;          // Tuning::gt_wb_b / encap_gt (the environment is read in keaki_hip_ctx_create only)
+  const bool gt_env = ctx->tune.encap_gt >= 0;
+  const size_t gt_threshold = gt_env ? (size_t)ctx->tune.encap_gt : (size_t)65536;
   uint64_t com_host[8];
   HIP_TRY(ctx, hipMemcpyAsync(com_host, d_com_aff, 64, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -506,13 +658,13 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
   const bool a_cached = ctx->gt_b_ready && ctx->gt_a_valid && memcmp(com_host, ctx->gt_a_com, 64) == 0;
   const bool use_gt = n >= gt_threshold || (!gt_env && (a_cached || ctx->seen_com_runs >= 3));
   if (use_gt) {
-    // GT_i = A^(r_i) B^(-beta_i r_i) with A = e(C, g2), B = e(g1, g2) (see pairing.cuh): no pairing per item
+    // GT_i = A^(r_i) B^(-beta_i r_i) with A = e(C, g2), B = e(g1, g2) (see pairing.hip.h): no pairing per item
     ST_TRY(reserve(ctx, ctx->gt_base, G1_AFF_BYTES + 320 * (G1_AFF_BYTES + 384)));   // a point | 2^s multiples | their pairings
     char* gb = (char*)ctx->gt_base.p;
     // B: 20-bit windows for a context that runs large batches, 16-bit (201 MB) for one that only ever made small calls; widened once when a large batch comes
-    const uint32_t wb_b_req = wbb_env ? (uint32_t)atoi(wbb_env) : (n >= 65536 ? 20u : 16u);
+    const uint32_t wb_b_req = wbb_env ? (uint32_t)ctx->tune.gt_wb_b : (n >= 65536 ? 20u : 16u);
     if (!ctx->gt_b_ready || (!wbb_env && wb_b_req > ctx->gt_b_wb && !ctx->gt_b_fallback)) {
-      if (wb_b_req < 8 || wb_b_req > 22 || gt_table_powers(wb_b_req) > 320) return fail(ctx, KEAKI_ERR_BAD_ARG, "KEAKI_GT_WB_B=%u out of range", wb_b_req);
+      if (wb_b_req < 8 || wb_b_req > 22 || gt_table_powers(wb_b_req) > 320) return fail(ctx, KEAKI_ERR_BAD_ARG, "gt_wb_b = %u out of range", wb_b_req);
       ctx->gt_b_ready = false;
       ctx->gt_b_wb = wb_b_req;
       keaki_status st_b = reserve(ctx, ctx->gt_tab_b, gt_table_bytes(ctx->gt_b_wb));
@@ -617,6 +769,8 @@ keaki_status keaki_hip_open_fk(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32
   CTX_GUARD(ctx);
   TRACE_SCOPE("keaki.open_fk");
   if (!srs || !hat_a || !tw_2d || !tw_2d_inv || !proofs_out_aff || log2d > 27) return fail(ctx, KEAKI_ERR_BAD_ARG, "open_fk: bad argument");
+  SRS_CHECK(ctx, srs, "open_fk");
+  std::lock_guard<std::recursive_mutex> hl(srs->mu);        // the cached transform hat_s belongs to the handle: one FK23 call per handle at a time
   const size_t d = (size_t)1 << log2d;
   if (d > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "open_fk: %zu coefficients but the SRS holds %zu points", d, srs->n);
   // one staging buffer: hat_a (2d Fr) | tw_2d (d) | tw_2d_inv (d) | tw_d (d/2) | work (2d Jacobian) | proofs (d affine)
@@ -634,6 +788,7 @@ keaki_status keaki_hip_open_fk(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32
     HIP_TRY(ctx, hipMalloc(&srs->fk_hat_s, 2 * d * 96));
     ST_TRY(fk_hat_s_run(ctx, srs->d, log2d, b + o_t1, srs->fk_hat_s));
     srs->fk_log2d = (int)log2d;
+    fk_account(ctx, srs);
   }
   ST_TRY(open_fk_run(ctx, srs->fk_hat_s, log2d, b + o_ha, b + o_t1, b + o_t2, b + o_w, b + o_p));
   return download(ctx, proofs_out_aff, b + o_p, d * 64);
@@ -645,23 +800,31 @@ keaki_status keaki_hip_open_fk_poly(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, u
   CTX_GUARD(ctx);
   TRACE_SCOPE("keaki.open_fk");
   if (!srs || !coeffs || !omega_2d || !omega_2d_inv || !inv_2d || !proofs_out_aff || log2d > 27) return fail(ctx, KEAKI_ERR_BAD_ARG, "open_fk_poly: bad argument");
+  SRS_CHECK(ctx, srs, "open_fk_poly");
+  std::lock_guard<std::recursive_mutex> hl(srs->mu);
   const size_t d = (size_t)1 << log2d;
   if (d > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "open_fk: %zu coefficients but the SRS holds %zu points", d, srs->n);
   const size_t o_p = 0, o_fr = o_p + d * 32, o_g = o_fr + (4 * d + d / 2 + 2) * 32, o_out = o_g + 2 * d * 96, total = o_out + d * 64;
   ST_TRY(reserve(ctx, ctx->io_d, total));
   char* b = (char*)ctx->io_d.p;
   HIP_TRY(ctx, hipMemcpyAsync(b + o_p, coeffs, d * 32, hipMemcpyHostToDevice, ctx->stream));
-  ST_TRY(open_fk_poly_run(ctx, srs->d, &srs->fk_hat_s, &srs->fk_log2d, log2d, b + o_p, omega_2d, omega_2d_inv, inv_2d, b + o_fr, b + o_g, b + o_out));
+  const keaki_status st_fk = open_fk_poly_run(ctx, srs->d, &srs->fk_hat_s, &srs->fk_log2d, log2d, b + o_p, omega_2d, omega_2d_inv, inv_2d, b + o_fr, b + o_g, b + o_out);
+  fk_account(ctx, srs);
+  ST_TRY(st_fk);
   return download(ctx, proofs_out_aff, b + o_out, d * 64);
 }
 // hat_s = DFT_2d(reversed SRS) for later open_fk calls with this d: setup-time work (the FK23 analogue of keaki_hip_srs_g1_precompute)
 keaki_status keaki_hip_srs_g1_precompute_fk(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32_t log2d, const uint64_t* omega_2d) {
   CTX_GUARD(ctx);
   if (!srs || !omega_2d || log2d > 27) return fail(ctx, KEAKI_ERR_BAD_ARG, "srs_g1_precompute_fk: bad argument");
+  SRS_CHECK(ctx, srs, "srs_g1_precompute_fk");
+  std::lock_guard<std::recursive_mutex> hl(srs->mu);
   const size_t d = (size_t)1 << log2d;
   if (d > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "open_fk: %zu coefficients but the SRS holds %zu points", d, srs->n);
   ST_TRY(reserve(ctx, ctx->io_d, d * 32));
-  ST_TRY(fk_precompute_run(ctx, srs->d, &srs->fk_hat_s, &srs->fk_log2d, log2d, omega_2d, ctx->io_d.p));
+  const keaki_status st_fk = fk_precompute_run(ctx, srs->d, &srs->fk_hat_s, &srs->fk_log2d, log2d, omega_2d, ctx->io_d.p);
+  fk_account(ctx, srs);
+  ST_TRY(st_fk);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // setup-time call: return when the table exists
   return KEAKI_OK;
 }
@@ -705,6 +868,7 @@ keaki_status keaki_hip_fk_shard_create(keaki_hip_ctx* ctx, const keaki_hip_srs_g
   if (d < (size_t)world * world)
     return fail(ctx, KEAKI_ERR_BAD_ARG, "fk_shard_create: %zu openings are too few to shard over %u ranks (needs world^2); use keaki_hip_open_fk_poly", d, world);
   if (d > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "open_fk: %zu coefficients but the SRS holds %zu points", d, srs->n);
+  SRS_CHECK(ctx, srs, "fk_shard_create");
   auto* fk = new keaki_hip_fk_shard();
   fk->srs = srs;
   fk->world = world;
@@ -728,8 +892,11 @@ void keaki_hip_fk_shard_free(keaki_hip_ctx* ctx, keaki_hip_fk_shard* fk) {
     std::lock_guard<std::recursive_mutex> lock_(ctx->mu);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    fk_shard_release(fk);
+  } else if (fk->srs && fk->srs->device >= 0) {
+    (void)hipSetDevice(fk->srs->device);
+    (void)hipDeviceSynchronize();
   }
+  fk_shard_release(fk);             // hipFree needs no context: the device buffers go even when the caller's ctx is already gone
   delete fk;
 }
 keaki_status keaki_hip_fk_shard_sizes(const keaki_hip_fk_shard* fk, size_t* out4) {
@@ -745,7 +912,9 @@ keaki_status keaki_hip_fk_shard_setup(keaki_hip_ctx* ctx, keaki_hip_fk_shard* fk
   CTX_GUARD(ctx);
   TRACE_SCOPE("keaki.fk_shard_setup");
   if (!fk || step < 0 || step > 1 || (step == 0 && !d_send) || (step == 1 && !d_recv)) return fail(ctx, KEAKI_ERR_BAD_ARG, "fk_shard_setup: bad argument");
-  if (step != fk->setup_next) return fail(ctx, KEAKI_ERR_BAD_ARG, "fk_shard_setup: step %d out of order (step %d is next)", step, fk->setup_next);
+  // step 0 may always start over (the caller's exchange failed after it, say): it recomputes this rank's outgoing points from the SRS
+  if (step != fk->setup_next && step != 0) return fail(ctx, KEAKI_ERR_BAD_ARG, "fk_shard_setup: step %d out of order (step %d is next)", step, fk->setup_next);
+  if (step == 0) { fk->plan.hat_s_ready = false; fk->setup_next = 0; }
   ST_TRY(fk_shard_setup_run(ctx, fk->plan, fk->srs->d, step, d_send, d_recv));
   fk->setup_next = step + 1;
   return KEAKI_OK;
@@ -816,6 +985,7 @@ keaki_status keaki_hip_kzg_open(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs,
   CTX_GUARD(ctx);
   TRACE_SCOPE("keaki.kzg_open");
   if (!srs || !point || !proof_out_jac || (n && !coeffs)) return fail(ctx, KEAKI_ERR_BAD_ARG, "kzg_open: null pointer");
+  SRS_CHECK(ctx, srs, "kzg_open");
   if (n && n - 1 > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", n - 1, srs->n);
   const size_t nq = n ? n - 1 : 0;
   const size_t o_q = 0, o_v = o_q + (nq + 1) * 32, o_w = o_v + 32, total = o_w + (2 * (n / 255 + 8) + 8) * 32;
@@ -825,10 +995,30 @@ keaki_status keaki_hip_kzg_open(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs,
   char* b = (char*)ctx->io_c.p;
   HIP_TRY(ctx, hipMemsetAsync(b + o_v, 0, 32, ctx->stream));                     // the zero polynomial evaluates to 0
   if (n) ST_TRY(open_quotient_run(ctx, ctx->io_a.p, n, point, b + o_q, b + o_v, b + o_w));
-  ST_TRY(msm_g1_run(ctx, srs->d, srs->n, b + o_q, nq, ctx->io_b.p, srs->table, srs->c_table));
+  const auto tb = srs_tables(srs);
+  ST_TRY(msm_g1_run(ctx, srs->d, srs->n, b + o_q, nq, ctx->io_b.p, tb.first, tb.second));
   ST_TRY(download(ctx, proof_out_jac, ctx->io_b.p, 96));
   if (value_out) ST_TRY(download(ctx, value_out, b + o_v, 32));
   resolve_timing(ctx);
+  return KEAKI_OK;
+}
+
+// the quotient alone (host in / out): what keaki_hip_group_kzg_open feeds to the MSM of all members
+keaki_status keaki_hip_kzg_quotient(keaki_hip_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t* point, uint64_t* quotient_out,
+                                    uint64_t* value_out) {
+  CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.kzg_quotient");
+  if (!point || (n && !coeffs) || (n > 1 && !quotient_out)) return fail(ctx, KEAKI_ERR_BAD_ARG, "kzg_quotient: null pointer");
+  const size_t nq = n ? n - 1 : 0;
+  const size_t o_q = 0, o_v = o_q + (nq + 1) * 32, o_w = o_v + 32, total = o_w + (2 * (n / 255 + 8) + 8) * 32;
+  ST_TRY(upload(ctx, ctx->io_a, coeffs, n * 32));
+  ST_TRY(reserve(ctx, ctx->io_c, total));
+  char* b = (char*)ctx->io_c.p;
+  HIP_TRY(ctx, hipMemsetAsync(b + o_v, 0, 32, ctx->stream));
+  if (n) ST_TRY(open_quotient_run(ctx, ctx->io_a.p, n, point, b + o_q, b + o_v, b + o_w));
+  if (nq) HIP_TRY(ctx, hipMemcpyAsync(quotient_out, b + o_q, nq * 32, hipMemcpyDeviceToHost, ctx->stream));
+  if (value_out) HIP_TRY(ctx, hipMemcpyAsync(value_out, b + o_v, 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return KEAKI_OK;
 }
 

@@ -7,7 +7,7 @@
 // scalar-mult ladders use Jacobian (2M+5S doubling). All results are compared at the affine level,
 // where they are representation-independent.
 #pragma once
-#include "bn254_field.cuh"
+#include "bn254_field.hip.h"
 
 namespace bn254 {
 

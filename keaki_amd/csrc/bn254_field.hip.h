@@ -33,8 +33,8 @@ struct alignas(16) Fq2 {
 
 }  // namespace bn254
 
-#include "bn254_constants.cuh"
-#include "fq29_core.cuh"
+#include "bn254_constants.hip.h"
+#include "fq29_core.hip.h"
 
 namespace bn254 {
 
@@ -221,7 +221,7 @@ KDEV Fp<P> fp_to_mont(const u32* canon) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fq: hand-scheduled gfx950 streams (bn254_field_asm.cuh) replace the portable templates above.
+// Fq: hand-scheduled gfx950 streams (bn254_field_asm.hip.h) replace the portable templates above.
 // The portable code stays the implementation for Fr and the reference the on-device self-test
 // (k_selftest_field) compares the streams with, through FqParamsRef.
 // ---------------------------------------------------------------------------------------------
@@ -229,7 +229,7 @@ struct FqParamsRef : FqParams {};   // same constants, but takes the portable te
 struct FrParamsRef : FrParams {};
 }  // namespace bn254
 #ifndef KEAKI_PORTABLE_FIELD
-#include "bn254_field_asm.cuh"
+#include "bn254_field_asm.hip.h"
 namespace bn254 {
 template <> KDEV Fq fp_mul<FqParams>(const Fq& a, const Fq& b) { Fq r; fq_mul_asm(r.l, a.l, b.l); return r; }
 template <> KDEV Fq fp_add<FqParams>(const Fq& a, const Fq& b) { Fq r; fq_add_asm(r.l, a.l, b.l); return r; }
@@ -240,7 +240,7 @@ template <> KDEV void fp_from_mont<FrParams>(u32* out, const Fr& a) { fr_from_mo
 #endif
 namespace bn254 {
 
-// a^(p-2). Not inlined: 254 squarings + ~127 products, in the 29-bit lazy limbs of fq29_core.cuh (813 / 933 SIMD-cycles each against
+// a^(p-2). Not inlined: 254 squarings + ~127 products, in the 29-bit lazy limbs of fq29_core.hip.h (813 / 933 SIMD-cycles each against
 // 1,198 for the saturated stream; every intermediate stays below 2p); called once per affine conversion / per pairing.
 static __device__ __noinline__ Fq fq_inv(const Fq& a) {
   const U29 one = u29_const(Fq29Params::ONE);
@@ -330,7 +330,7 @@ KDEV Fq2 fq2_zero() { return {fq_zero(), fq_zero()}; }
 KDEV Fq2 fq2_one() { return {fq_one(), fq_zero()}; }
 KDEV bool fq2_is_zero(const Fq2& a) { return fq_is_zero(a.c0) && fq_is_zero(a.c1); }
 KDEV bool fq2_eq(const Fq2& a, const Fq2& b) { return fq_eq(a.c0, b.c0) && fq_eq(a.c1, b.c1); }
-// Each component is ONE dual product in the 9 x 29-bit limbs of fq29_core.cuh -- two products sharing a single Montgomery
+// Each component is ONE dual product in the 9 x 29-bit limbs of fq29_core.hip.h -- two products sharing a single Montgomery
 // reduction, no carry instructions: c0 = a0 b0 + (64p - 32 a1) b1, c1 = a0 b1 + a1 b0. The left factors enter shifted by 5 bits
 // (2^256 -> 2^261 Montgomery form), results come back as canonical saturated residues. ~770 instructions against ~1020 for the
 // Karatsuba form on the saturated streams (3 products + 5 modular additions).

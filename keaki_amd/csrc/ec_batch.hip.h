@@ -4,10 +4,10 @@
 // Replaces `.mul(scalar)` at reference src/kem.rs:22,30,36,37 and src/kzg.rs:57,60,135,144 as they
 // occur inside the loops of src/vec.rs:63-66.
 #pragma once
-#include "bn254_curve.cuh"
+#include "bn254_curve.hip.h"
 #include <type_traits>
-#include "jac29.cuh"
-#include "xyzz29_g2.cuh"
+#include "jac29.hip.h"
+#include "xyzz29_g2.hip.h"
 
 namespace bn254 {
 
@@ -37,7 +37,7 @@ KDEV Jac<F> scalar_mul_sat(const Aff<F>& p, const Fr& k_mont) {
   return acc;
 }
 
-// G2 (and the reference ladder of the self-test): the saturated double-and-add above. G1: the NAF ladder in 29-bit limbs (jac29.cuh).
+// G2 (and the reference ladder of the self-test): the saturated double-and-add above. G1: the NAF ladder in 29-bit limbs (jac29.hip.h).
 template <class F> KDEV Jac<F> scalar_mul(const Aff<F>& p, const Fr& k_mont) { return scalar_mul_sat(p, k_mont); }
 KDEV Jac<Fq> scalar_mul(const Aff<Fq>& p, const Fr& k_mont) { return jac_scalar_mul_u29(jac_from_aff(p), k_mont); }
 
@@ -178,7 +178,7 @@ KDEV Xyzz<F> fb_accumulate(Xyzz<F> acc, const Aff<F>* __restrict__ table, FbShap
   return acc;
 }
 
-// the same walk over the windows with the accumulator in the lazy limbs of xyzz29_g2.cuh (G2: the ciphertext side of `encapsulate`)
+// the same walk over the windows with the accumulator in the lazy limbs of xyzz29_g2.hip.h (G2: the ciphertext side of `encapsulate`)
 KDEV void fb_accumulate_g2_u29(X29G2& acc, const Aff<Fq2>* __restrict__ table, FbShape g, u32* v) {
   u32 carry = 0;
   const u32 half = 1u << (g.wb - 1);

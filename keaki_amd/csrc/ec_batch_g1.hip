@@ -1,5 +1,5 @@
 // G1 batched scalar multiplication and the G1 half of encapsulate (reference src/kem.rs:22,30).
-#include "ec_batch.cuh"
+#include "ec_batch.hip.h"
 #include "internal.h"
 namespace keaki_internal {
 using namespace bn254;

@@ -1,7 +1,7 @@
 #include <cstdlib>
 // G2 batched scalar multiplication and the G2 half of encapsulate (reference src/kem.rs:36-37).
 #define KEAKI_FQ2_OUTLINE 1
-#include "ec_batch.cuh"
+#include "ec_batch.hip.h"
 #include "internal.h"
 namespace keaki_internal {
 using namespace bn254;
@@ -26,7 +26,7 @@ keaki_status encap_g2_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_
                                 const void* d_rs, size_t n, void* d_out) {
   // 285 registers per lane: one wave per SIMD. Batches that fill every SIMD more than once do better with two waves and 29 spilled
   // registers (2^20 items: 32.2 -> 29.1 ms per encap batch); up to one wave per SIMD (2^16 items) the unspilled kernel wins by 3 %.
-  if (n <= 65536 || getenv("KEAKI_FB_OCC1")) {
+  if (n <= 65536 || ctx->tune.fb_occ1) {
     hipLaunchKernelGGL((k_encap_fixed<Fq2, 1>), dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, (const G2Aff*)d_tab_a, fb_shape(wb_a), (const G2Aff*)d_tab_b,
                      fb_shape(wb_b), (const Fr*)d_xs, (const Fr*)d_rs, (u32)n, (G2Aff*)d_out);
   } else {

@@ -15,13 +15,13 @@
 //   proofs[brev(q)] = affine(E[q] + O[q])                                     k_fk_finish
 // A butterfly is one scalar multiplication of a Jacobian point by a twiddle factor plus an add and a subtract; one lane per butterfly.
 // tests/fk_shard_model.py::open_fk_split is this pipeline over Z_q, index for index.
-#include "ec_batch.cuh"
-#include "jac29.cuh"
+#include "ec_batch.hip.h"
+#include "jac29.hip.h"
 #include "internal.h"
 
 namespace bn254 {
 
-// k * P for a Jacobian P: NAF ladder in the 29-bit lazy arithmetic (jac29.cuh). k: Montgomery Fr.
+// k * P for a Jacobian P: NAF ladder in the 29-bit lazy arithmetic (jac29.hip.h). k: Montgomery Fr.
 KDEV G1Jac jac_scalar_mul(const G1Jac& p, const Fr& k_mont) { return jac_scalar_mul_u29(p, k_mont); }
 KDEV bool fr_is_one(const Fr& a) {
   u32 o = 0;
@@ -251,8 +251,7 @@ namespace keaki_internal {
 using namespace bn254;
 
 static void stage_map(keaki_hip_ctx* ctx, bool dit, G1Jac* a, const Fr* tw, u32 m, u32 half, u32 A, u32 B, u32 stride) {
-  static const bool sliding = !(getenv("KEAKI_FK_UNIFORM") && atoi(getenv("KEAKI_FK_UNIFORM")) == 0);      // A/B switch
-  const bool uniform = sliding && m / (2 * half) >= 64;        // blocks: a power of two, so every 64-lane workgroup then shares one twiddle
+  const bool uniform = ctx->tune.fk_uniform && m / (2 * half) >= 64;        // blocks: a power of two, so every 64-lane workgroup then shares one twiddle
   const dim3 grid(cdiv(m / 2, 64)), block(64);
   if (dit && uniform) hipLaunchKernelGGL((k_g1_fft_stage_map<true, true>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride);
   else if (dit) hipLaunchKernelGGL((k_g1_fft_stage_map<true, false>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride);

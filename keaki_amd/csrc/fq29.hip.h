@@ -1,6 +1,6 @@
-// Fq-typed entry points of the 9 x 29-bit lazy arithmetic; the arithmetic itself is in fq29_core.cuh (see its header).
+// Fq-typed entry points of the 9 x 29-bit lazy arithmetic; the arithmetic itself is in fq29_core.hip.h (see its header).
 #pragma once
-#include "bn254_field.cuh"
+#include "bn254_field.hip.h"
 
 namespace bn254 {
 

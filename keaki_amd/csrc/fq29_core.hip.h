@@ -1,6 +1,6 @@
-// (core part: no dependency on the Fq type, so that bn254_field.cuh itself can use it for the Fq2 product)
+// (core part: no dependency on the Fq type, so that bn254_field.hip.h itself can use it for the Fq2 product)
 // BN254 base field in 9 x 29-bit limbs, Montgomery radix 2^261, lazily reduced -- the arithmetic of the bucket-accumulation
-// kernel (k_msm_accumulate_g1_u29 in msm.cuh; replaces the inner loop of ark-ec's VariableBaseMSM::msm_bigint_wnaf bucket
+// kernel (k_msm_accumulate_g1_u29 in msm.hip.h; replaces the inner loop of ark-ec's VariableBaseMSM::msm_bigint_wnaf bucket
 // phase behind src/kzg.rs:98).
 //
 // Why a second representation: on gfx950 v_mad_u64_u32 issues at the rate of a 32-bit add (profiles/r01_ubench_int_gfx950.txt),
@@ -20,7 +20,7 @@
 // tests: keaki_hip_selftest_field runs k_selftest_u29 (products, squares, differences, zero filter, round trips against the
 // saturated asm field) and the MSM parity tests cover the kernel.
 #pragma once
-// included from bn254_field.cuh after the basic types and bn254_constants.cuh
+// included from bn254_field.hip.h after the basic types and bn254_constants.hip.h
 
 namespace bn254 {
 
@@ -71,7 +71,7 @@ KDEV void u29_slide(u32& lo, u32& hi) {
   hi >>= 29;
 }
 
-// Portable statements of the product and the square (the shipped ones are the asm streams of fq29_asm.cuh; the self-test
+// Portable statements of the product and the square (the shipped ones are the asm streams of fq29_asm.hip.h; the self-test
 // compares the two). Montgomery product, radix 2^261. Limbs of a, b at most 2^30 + 16 on one side and 2^29 + 8 on the other (columns stay < 2^64).
 KDEV U29 u29_mul_ref(const U29& a, const U29& b) {
   u64 acc = 0;
@@ -140,7 +140,7 @@ KDEV U29 u29_sqr_ref(const U29& a) {
 }
 
 }  // namespace bn254
-#include "fq29_asm.cuh"
+#include "fq29_asm.hip.h"
 namespace bn254 {
 KDEV U29 u29_mul(const U29& a, const U29& b) {
   U29 r;
@@ -152,7 +152,7 @@ KDEV U29 u29_sqr(const U29& a) {
   u29_sqr_asm(r.l, a.l);
   return r;
 }
-// (a b + c d) / 2^261 with one reduction (limb bounds: see fq29_asm.cuh)
+// (a b + c d) / 2^261 with one reduction (limb bounds: see fq29_asm.hip.h)
 KDEV U29 u29_mul2(const U29& a, const U29& b, const U29& c, const U29& d) {
   U29 r;
   u29_mul2_asm(r.l, a.l, b.l, c.l, d.l);
@@ -194,7 +194,7 @@ KDEV U29 u29_sub3(const U29& a, const U29& b, const U29& c) {
 KDEV bool u29_maybe_zero(const U29& x) { return ((x.l[0] * Q29::PINV) & Q29::MASK) <= 17u; }
 
 // t < 2p with exact limbs (a product's output) -> the canonical integer below p, packed into 8 x 32 bits
-KDEV void fq_cond_sub_p_asm(u32* __restrict__ r, const u32* __restrict__ t);   // bn254_field_asm.cuh (included after this file)
+KDEV void fq_cond_sub_p_asm(u32* __restrict__ r, const u32* __restrict__ t);   // bn254_field_asm.hip.h (included after this file)
 KDEV void u29_pack_canonical(u32* out, const U29& t) {
   // pack the (exact) limbs into 8 x 32 bits first -- 2p < 2^255 fits -- then ONE conditional subtraction on the hardware borrow chain
   // (16 instructions); a signed ripple over nine 29-bit limbs costs 45

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Emits keaki_amd/csrc/bn254_field_asm.cuh: hand-scheduled gfx950 instruction streams for the BN254
+"""Emits keaki_amd/csrc/bn254_field_asm.hip.h: hand-scheduled gfx950 instruction streams for the BN254
 base-field (Fq) Montgomery product, addition, subtraction and negation on 8 x 32-bit limbs.
 
 Why hand-written: on gfx950 v_mad_u64_u32 issues at the same rate as a 32-bit add (measured:
@@ -21,7 +21,7 @@ by VOP2 (_e32) forms, whose VCC read is implicit (it still occupies the single c
 modulus limbs of the carry chains are VGPR operands); gfx940+ needs two wait states between a VALU SGPR
 write and an EXPLICIT SGPR operand read, which these streams never do. VGPR RAW is interlocked.
 
-    python keaki_amd/csrc/gen_field_asm.py > keaki_amd/csrc/bn254_field_asm.cuh
+    python keaki_amd/csrc/gen_field_asm.py > keaki_amd/csrc/bn254_field_asm.hip.h
 """
 
 SEP = "\\n\\t"

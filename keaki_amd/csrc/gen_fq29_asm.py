@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Emits keaki_amd/csrc/fq29_asm.cuh: gfx950 instruction streams for the 9 x 29-bit lazy Montgomery product and square
-(radix 2^261) of fq29.cuh.
+"""Emits keaki_amd/csrc/fq29_asm.hip.h: gfx950 instruction streams for the 9 x 29-bit lazy Montgomery product and square
+(radix 2^261) of fq29.hip.h.
 
 ONE asm statement per product: 162 (square: 126) v_mad_u64_u32 in column order into a single 64-bit accumulator, per column
 one v_lshrrev_b64 (slide), for the low nine columns v_mul_lo_u32 + v_and (m_k), for the high eight one v_and (result limb):
-205 (square: 177) instructions. Columns never overflow 64 bits (fq29.cuh), so the carry-out that v_mad_u64_u32 must name
+205 (square: 177) instructions. Columns never overflow 64 bits (fq29.hip.h), so the carry-out that v_mad_u64_u32 must name
 (VCC) is dead.
 
 Why one statement: hipcc's own schedule of the portable loops splits every column into two chains joined by 64-bit adds (289
@@ -12,12 +12,12 @@ instructions); and with one statement per column it puts a wait state behind eve
 an asm block ends in a partial-register write, the "dst_sel forwarding" hazard) -- 24 dead issue slots per product. The halves
 of a 64-bit asm operand cannot be named inside the string, so the accumulator is a fixed VGPR pair declared as clobbered
 (v[54:55]: inside the allocation of every kernel that uses these streams, so it costs no occupancy, and in a
-caller-saved block of the AMDGPU calling convention, so a non-inlined function that contains a stream -- fq2d_mul in pairing.cuh --
+caller-saved block of the AMDGPU calling convention, so a non-inlined function that contains a stream -- fq2d_mul in pairing.hip.h --
 need not save and restore it; v[126:127] cost two AGPR spill slots there and with them the second wave per SIMD).
 m_k lives in the register of result limb k (m_k is last read in column k + 8, limb k is produced in column k + 9).
 Hazards: every VGPR dependency in the block is interlocked by the hardware; VCC is written and never read.
 
-    python keaki_amd/csrc/gen_fq29_asm.py > keaki_amd/csrc/fq29_asm.cuh
+    python keaki_amd/csrc/gen_fq29_asm.py > keaki_amd/csrc/fq29_asm.hip.h
 """
 ACC = "v[54:55]"
 ACC_LO, ACC_HI = "v54", "v55"
@@ -133,7 +133,7 @@ def main():
     print("#pragma once")
     print("namespace bn254 {")
     if dots:
-        # the multi-product streams of the pairing tower (pair261.cuh): python gen_fq29_asm.py --dots > fq29_dot_asm.cuh
+        # the multi-product streams of the pairing tower (pair261.hip.h): python gen_fq29_asm.py --dots > fq29_dot_asm.hip.h
         for nprod in (3, 4, 6):
             emit_dot(nprod)
     else:

@@ -20,8 +20,32 @@ struct DevBuf {
 
 }  // namespace keaki_internal
 
+namespace keaki_internal {
+// Tuning / diagnostic switches of a context. The environment is read ONCE, in keaki_hip_ctx_create (tune_from_env); afterwards only
+// keaki_hip_ctx_set_option changes them (under the context lock). No other code in the library calls getenv.
+struct Tuning {
+  int msm_c = 0;                 // KEAKI_MSM_C / "msm_c": window bits of the generic MSM, 0 = choose_window
+  int msm_c_shared = 0;          // KEAKI_MSM_C_SHARED / "msm_c_shared": window target of the SRS window tables, 0 = choose_window_shared
+  int reduce_l = 0;              // KEAKI_REDUCE_L / "reduce_l": chunk length of the bucket reduction, 0 = automatic
+  int part_shift = -1;           // KEAKI_PART_SHIFT / "part_shift": fine bits of the two-pass partition, -1 = automatic
+  uint32_t p1_sub = 8;           // KEAKI_P1_SUB / "p1_sub": tiles one scatter workgroup walks
+  bool p2_small = false;         // KEAKI_P2_SMALL / "p2_small"
+  bool acc_u29 = true;           // KEAKI_ACC_U29 / "acc_u29": G1 bucket kernel in the 29-bit lazy limbs (A/B switch for profiling)
+  bool acc_u29_g2 = true;        // KEAKI_ACC_U29_G2 / "acc_u29_g2"
+  bool fk_uniform = true;        // KEAKI_FK_UNIFORM / "fk_uniform": sliding-window ladder in the wave-uniform FK23 stages
+  bool fb_occ1 = false;          // KEAKI_FB_OCC1 / "fb_occ1": one wave per SIMD for the G2 fixed-base kernel at any batch size
+  int gt_wb_b = 0;               // KEAKI_GT_WB_B / "gt_wb_b": window bits of the table of e(g1, g2), 0 = automatic (20 / 16)
+  long long encap_gt = -1;       // KEAKI_ENCAP_GT / "encap_gt": batch size from which encap takes the GT fixed-base path; -1 = automatic policy
+  size_t alloc_limit = 0;        // keaki_hip_debug_set_alloc_limit: single allocations above it fail with KEAKI_ERR_OOM; 0 = none
+};
+}  // namespace keaki_internal
+
 struct keaki_hip_ctx {
   int device = 0;
+  keaki_internal::Tuning tune;
+  // bytes this context allocated and still holds, by class (keaki_hip_ctx_memory): SRS window tables + FK23 transforms of handles built
+  // through it | grow-only workspaces | GT / fixed-base tables of encapsulate
+  size_t mem_tables = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::recursive_mutex mu;   // recursive: host-pointer entry points hold it across stage -> *_dev -> download
@@ -36,7 +60,7 @@ struct keaki_hip_ctx {
   uint64_t seen_com[8] = {};              // commitment of the last encap call and how many consecutive calls carried it
   uint32_t seen_com_runs = 0;
   uint32_t gt_a_wb = 0, gt_b_wb = 0;      // window widths of the GT tables in gt_tab_a / gt_tab_b
-  keaki_internal::DevBuf pair_ws;                   // per-item slots of the final exponentiation (pairing.cuh)
+  keaki_internal::DevBuf pair_ws;                   // per-item slots of the final exponentiation (pairing.hip.h)
   keaki_internal::DevBuf verify_lines, verify_io;   // kzg verify: [lines of g2 | lines of [tau]_2], small in/out block
   bool verify_ready = false;              // set only after every init step of kzg verify succeeded
   bool verify_tau_valid = false;
@@ -61,8 +85,9 @@ namespace keaki_internal {
 
 keaki_status fail(keaki_hip_ctx* ctx, keaki_status code, const char* fmt, ...);
 keaki_status reserve(keaki_hip_ctx* ctx, DevBuf& b, size_t bytes);
-// hipMalloc behind the library's one allocation gate. KEAKI_TEST_ALLOC_LIMIT=<bytes> (tests only) makes every single allocation above
-// that size fail with KEAKI_ERR_OOM, which is how the optional-memory fallbacks (SRS window tables, the wide GT table) are exercised.
+// hipMalloc behind the library's one allocation gate. keaki_hip_debug_set_alloc_limit(ctx, bytes) makes every single allocation of this
+// context above that size fail with KEAKI_ERR_OOM, which is how the tests exercise the optional-memory fallbacks (SRS window tables,
+// the wide GT table).
 keaki_status dev_alloc(keaki_hip_ctx* ctx, void** p, size_t bytes);
 keaki_status launch_check(keaki_hip_ctx* ctx, const char* what);
 inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }

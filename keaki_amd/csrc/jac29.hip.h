@@ -1,4 +1,4 @@
-// Jacobian scalar multiplication of BN254 G1 points in the 9 x 29-bit lazy representation (fq29.cuh): the inner loop of the FK23
+// Jacobian scalar multiplication of BN254 G1 points in the 9 x 29-bit lazy representation (fq29.hip.h): the inner loop of the FK23
 // butterflies (fft_g1.hip; reference src/kzg.rs:182-200 = ark-poly group FFTs, every butterfly one `Group * ScalarField`).
 // GLV split k = k1 + k2 lambda (128-bit halves, phi(P) = (beta X, Y, Z)), fixed signed 4-bit windows over one table of 8 multiples, doubling dbl-2009-l with
 // D = 4 X Y^2 taken as a product (keeps every value small), addition add-2007-bl with the addend's Z^2, Z^3 precomputed.
@@ -6,8 +6,8 @@
 // model with 64-bit overflow assertions ran full 254-bit multiplications before this was written; test: k_selftest_j29 and the
 // FK23 parity tests.
 #pragma once
-#include "bn254_curve.cuh"
-#include "fq29.cuh"
+#include "bn254_curve.hip.h"
+#include "fq29.hip.h"
 
 namespace bn254 {
 
@@ -40,7 +40,7 @@ KDEV J29 j29_dbl(const J29& p) {
 }
 // a + (X2, Y2, Z2) with Z2Z2 = Z2^2, Z2cu = Z2^3. special: 0 = ordinary sum (returned), 1 = the two points are equal (the caller doubles),
 // 2 = they are opposite (the sum is the identity). In a ladder k P with k < r that only happens for k = r - 2 (running multiple -P,
-// last digit -1), but it costs three instructions to notice (zero filter of fq29_core.cuh).
+// last digit -1), but it costs three instructions to notice (zero filter of fq29_core.hip.h).
 KDEV J29 j29_add(const J29& a, const U29& X2, const U29& Y2, const U29& Z2, const U29& Z2Z2, const U29& Z2cu, int& special) {
   const U29 Z1Z1 = u29_sqr(a.z), U1 = u29_mul(a.x, Z2Z2), U2 = u29_mul(X2, Z1Z1), S1 = u29_mul(a.y, Z2cu);
   const U29 S2 = u29_mul(Y2, u29_mul(a.z, Z1Z1));

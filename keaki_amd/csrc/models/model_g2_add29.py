@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Limb-exact model of the G2 mixed addition in the 9 x 29-bit lazy arithmetic (xyzz29_g2.cuh): same operations in the same order on Python
+"""Limb-exact model of the G2 mixed addition in the 9 x 29-bit lazy arithmetic (xyzz29_g2.hip.h): same operations in the same order on Python
 integers, with assertions on every limb (no negative value, no 32-bit overflow, stream operands within their budgets) and on every value
 bound; checked against plain Fq2 XYZZ arithmetic. Run before the kernel was written; tests/test_pair261_model.py runs it in the CPU suite.
 
-Streams (fq29_asm.cuh / fq29_dot_asm.cuh): limbs exact on output, value < (sum of products)/2^261 + p.
+Streams (fq29_asm.hip.h / fq29_dot_asm.hip.h): limbs exact on output, value < (sum of products)/2^261 + p.
   mul(a, b):       a <= 2^30 + 16, b <= 2^29 + 8
   mul2(a,b,c,d):   a, b, d <= 2^29 + 8, c <= 1.5 * 2^30
   dot4:            every limb <= 2^29 + 8

@@ -16,11 +16,11 @@
 // Order of additions inside a bucket depends on LDS-atomic arrival order; EC addition is exact and
 // commutative, so the affine result is bit-identical run to run.
 #pragma once
-#include "bn254_curve.cuh"
-#include "fq29.cuh"
-#include "xyzz29.cuh"
-#include "jac29.cuh"
-#include "xyzz29_g2.cuh"
+#include "bn254_curve.hip.h"
+#include "fq29.hip.h"
+#include "xyzz29.hip.h"
+#include "jac29.hip.h"
+#include "xyzz29_g2.hip.h"
 
 namespace bn254 {
 
@@ -403,7 +403,7 @@ struct HeavyList {
   u32 n;            // heavy buckets found
   u32 nslices;      // slice ids handed out
 };
-// capacities (host side, msm_host.cuh): cap = pairs / HEAVY_MIN + 1 >= the number of buckets that can hold HEAVY_MIN pairs, and
+// capacities (host side, msm_host.hip.h): cap = pairs / HEAVY_MIN + 1 >= the number of buckets that can hold HEAVY_MIN pairs, and
 // slice_cap = cap + pairs / HEAVY_SLICE + 1 >= sum of ceil(count / HEAVY_SLICE) over them: neither can overflow; the bounds checks
 // in the kernels are belt and braces.
 static __global__ void __launch_bounds__(256) k_cnt_hist(const u32* __restrict__ counts, u32 nb, u32* __restrict__ ghist, HeavyList* __restrict__ hv,
@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const Aff<F>* __restrict
   buckets[t] = acc;
 }
 
-// G1 bucket accumulation in the 9 x 29-bit lazy representation (fq29.cuh): same schedule and memory traffic as the generic
+// G1 bucket accumulation in the 9 x 29-bit lazy representation (fq29.hip.h): same schedule and memory traffic as the generic
 // kernel above, ~2450 instead of ~3200 issues per mixed addition. Table / SRS rows stay in the saturated 2^256 form (the
 // 2^261 form is the same integer shifted by 5 bits); buckets are written back saturated and canonical.
 // Value bounds (multiples of p; measured maxima in brackets): X < 9.4 [8.7], Y < 1.6 [1.4], ZZ, ZZZ < 1.4; P = U2 - X + 16p < 17.4;
@@ -612,7 +612,7 @@ static __global__ void __launch_bounds__(256) k_msm_accumulate_g1_u29(const Aff<
   buckets[t] = out;
 }
 
-// G2 bucket accumulation in the lazy limbs (xyzz29_g2.cuh): same schedule, ~5,600 instead of ~9,000 instructions per mixed addition.
+// G2 bucket accumulation in the lazy limbs (xyzz29_g2.hip.h): same schedule, ~5,600 instead of ~9,000 instructions per mixed addition.
 // Buckets are written back saturated and canonical (the tail keeps the generic arithmetic).
 static __global__ void __launch_bounds__(256) k_msm_accumulate_g2_u29(const Aff<Fq2>* __restrict__ points, const u32* __restrict__ sorted,
                                                                       const u32* __restrict__ offsets, const u32* __restrict__ counts,

@@ -3,18 +3,15 @@
 #pragma once
 #include <type_traits>
 #include "internal.h"
-#include "msm.cuh"
+#include "msm.hip.h"
 
 namespace keaki_internal {
 using namespace bn254;
 
 // GPU window choice: minimise (n * W mixed adds) + (2 * W * B full adds, ~1.4x a mixed add each)
 // while keeping enough buckets (= lanes of the accumulate kernel) to fill 256 CUs.
-inline int choose_window(size_t n) {
-  if (const char* e = getenv("KEAKI_MSM_C")) {
-    int c = atoi(e);
-    if (c >= 3 && c <= 24) return c;
-  }
+inline int choose_window(size_t n, int forced = 0) {
+  if (forced >= 3 && forced <= 24) return forced;         // Tuning::msm_c
   if (n < 32) return 3;
   double best = 1e300;
   int bc = 3;
@@ -47,7 +44,7 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   if (n > srs_len) return fail(ctx, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", n, srs_len);
   if (n >= (1ull << 31)) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: n must be < 2^31 per device");
   const bool shared = d_table != nullptr && n * 2 > srs_len;   // short polynomials: the generic path with its own window size is faster
-  const MsmPlan plan = shared ? msm_make_plan(n, c_table) : msm_make_plan(n, choose_window(n));
+  const MsmPlan plan = shared ? msm_make_plan(n, c_table) : msm_make_plan(n, choose_window(n, ctx->tune.msm_c));
   MsmShape s = plan.s;
   // reduction shape: generic = the plan itself; shared = ONE window holding max_b = 2^cr buckets (top-window rule: 2^width buckets)
   MsmShape rs = s;
@@ -67,7 +64,7 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   // 16 is best from 2^19 buckets on (2^20 .. 2^24 points), 8 below (2^18 points: 1.01 vs 1.09 ms)
   // (G2, whose additions cost 2.3 x as much: 8 from 2^19 buckets on as well -- 5.10 vs 5.34 ms at 2^20 points)
   u32 L = plan.max_b >= (1u << 19) ? (sizeof(F) > sizeof(Fq) ? 8 : 16) : (plan.max_b >= 64 ? 8 : plan.max_b);
-  if (const char* e = getenv("KEAKI_REDUCE_L")) { int v = atoi(e); if (v >= 1 && v <= 4096 && (u32)v <= plan.max_b) L = (u32)v; }
+  if (ctx->tune.reduce_l >= 1 && ctx->tune.reduce_l <= 4096 && (u32)ctx->tune.reduce_l <= plan.max_b) L = (u32)ctx->tune.reduce_l;
   const u32 chunks = cdiv(plan.max_b, L);
   ST_TRY(reserve(ctx, ctx->wsums, (size_t)rs.W * sizeof(Xyzz<F>)));
   Xyzz<F>* wsums = (Xyzz<F>*)ctx->wsums.p;
@@ -79,9 +76,8 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
     return launch_check(ctx, "msm_final");
   }
   PartShape ps;
-  int shift_override = -1;
-  if (const char* e = getenv("KEAKI_PART_SHIFT")) shift_override = atoi(e);
-  static const u32 sub_max = getenv("KEAKI_P1_SUB") ? (u32)atoi(getenv("KEAKI_P1_SUB")) : 8u;
+  const int shift_override = ctx->tune.part_shift;
+  const u32 sub_max = ctx->tune.p1_sub;
   if (!part_make_shape(n, s.W, nb, &ps, shift_override, sub_max ? sub_max : 1u))
     return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: %zu buckets / %u windows exceed the partition's LDS budget (window too large)", nb, s.W);
   const size_t ncounts = (size_t)ps.nbins * ps.nwg;
@@ -105,8 +101,7 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   hipLaunchKernelGGL(k_part_scatter, dim3(ps.nwg), dim3(P1_THREADS), 0, st, (const Fr*)d_scalars, s, ps, (const u32*)poffsets, (const u32*)pcounts_t, entries);
   ST_TRY(launch_check(ctx, "part_scatter"));
   hipLaunchKernelGGL(k_part_total, dim3(1), dim3(64), 0, st, (const u32*)pcounts, (const u32*)poffsets, (u32)ncounts, poffsets + ncounts);
-  static const bool p2_small = getenv("KEAKI_P2_SMALL") && atoi(getenv("KEAKI_P2_SMALL")) != 0;
-  if (p2_small)
+  if (ctx->tune.p2_small)
     hipLaunchKernelGGL((k_part_fine<P2_CAP_SMALL>), dim3(ps.nbins), dim3(P2_THREADS), 0, st, (const u64*)entries, (const u32*)poffsets, ps,
                        (const u32*)(poffsets + ncounts), (u32)nb, offsets, hist, sorted);
   else
@@ -134,15 +129,13 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   if (ctx->timing) (void)hipEventRecord(ctx->ev[1], st);
   bool u29 = false;
   if constexpr (std::is_same<F, Fq>::value) {
-    static const bool use_u29 = !(getenv("KEAKI_ACC_U29") && atoi(getenv("KEAKI_ACC_U29")) == 0);   // A/B switch for profiling
-    u29 = use_u29;
+    u29 = ctx->tune.acc_u29;                                 // A/B switch for profiling
     if (u29)
       hipLaunchKernelGGL(k_msm_accumulate_g1_u29, dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
                          (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
   }
   if constexpr (std::is_same<F, Fq2>::value) {
-    static const bool use_u29_g2 = !(getenv("KEAKI_ACC_U29_G2") && atoi(getenv("KEAKI_ACC_U29_G2")) == 0);   // A/B switch for profiling
-    u29 = use_u29_g2;
+    u29 = ctx->tune.acc_u29_g2;                              // A/B switch for profiling
     if (u29)
       hipLaunchKernelGGL(k_msm_accumulate_g2_u29, dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
                          (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
@@ -195,11 +188,8 @@ keaki_status msm_build_tables(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t
   return launch_check(ctx, "msm_build_tables");
 }
 // window target for the shared-bucket (precomputed) path: adds = n * W(c); bucket reduction ~ 2.8 * max_b once
-inline int choose_window_shared(size_t n) {
-  if (const char* e = getenv("KEAKI_MSM_C_SHARED")) {
-    int c = atoi(e);
-    if (c >= 3 && c <= 24) return c;
-  }
+inline int choose_window_shared(size_t n, int forced = 0) {
+  if (forced >= 3 && forced <= 24) return forced;         // Tuning::msm_c_shared
   double best = 1e300;
   int bc = 8;
   for (int c = 8; c <= 23; c++) {

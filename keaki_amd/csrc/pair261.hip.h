@@ -9,7 +9,7 @@
 // by DPP quad_perm (register to register); both lanes run the same instruction stream.
 //
 // What is new in round 2 -- where the instructions went, and how they were removed:
-//   * Radix. Everything in this file is a residue x 2^261 mod p, the radix the 9 x 29-bit product streams of fq29_asm.cuh reduce
+//   * Radix. Everything in this file is a residue x 2^261 mod p, the radix the 9 x 29-bit product streams of fq29_asm.hip.h reduce
 //     by, so no operand needs the 5-bit shift that bridged from the 2^256 form (and multiplied its bound by 32). Inputs are
 //     converted once at kernel entry (to261), GT leaves through the same from-Montgomery product it always needed.
 //   * Lazy reduction ACROSS products (Aranha et al., "Faster explicit formulas for computing pairings over ordinary curves",
@@ -24,10 +24,10 @@
 //     -a1 b1 term is carried by the y operand (2p - y1), prepared once per operand.
 // Value bounds (multiples of p) and limb classes are stated at every helper; the streams' budget is: every limb <= 2^29 + 8.
 #pragma once
-#include "bn254_curve.cuh"
-#include "fq29.cuh"
-#include "fq29_dot_asm.cuh"
-#include "pair261_constants.cuh"
+#include "bn254_curve.hip.h"
+#include "fq29.hip.h"
+#include "fq29_dot_asm.hip.h"
+#include "pair261_constants.hip.h"
 
 namespace bn254 {
 namespace p261 {

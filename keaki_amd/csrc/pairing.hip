@@ -1,7 +1,7 @@
 // Batched pairing + GT serialisation + BLAKE3 KDF kernels (reference src/kem.rs:30-46,58-69).
 #define KEAKI_FQ2_OUTLINE 1
 #include "internal.h"
-#include "pairing.cuh"
+#include "pairing.hip.h"
 namespace keaki_internal {
 using namespace bn254;
 // One launch of k_pairing per chunk of at most PAIR_CHUNK items: the final exponentiation keeps FE_NSLOTS Fq12 values per item in HBM

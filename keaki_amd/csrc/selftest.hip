@@ -1,6 +1,6 @@
 // On-device self-test of the hand-scheduled Fq streams against the portable template code.
-#include "pairing.cuh"
-#include "fq29.cuh"
+#include "pairing.hip.h"
+#include "fq29.hip.h"
 #include "internal.h"
 namespace bn254 {
 using FqRef = Fp<FqParamsRef>;
@@ -69,8 +69,8 @@ __global__ void __launch_bounds__(256) k_selftest_field(u32 seed, u32 iters, uns
   if (bad) atomicAdd(mismatches, bad);
 }
 
-// lane-pair primitives of the pairing tower (pair261.cuh: 2^261 form, multi-product streams) against the single-lane Fq2 code of
-// bn254_field.cuh (2^256 form): operands are converted on the way in (to261), results on the way out (to256)
+// lane-pair primitives of the pairing tower (pair261.hip.h: 2^261 form, multi-product streams) against the single-lane Fq2 code of
+// bn254_field.hip.h (2^256 form): operands are converted on the way in (to261), results on the way out (to256)
 KDEV Fq2 ref_add3(const Fq2& a, const Fq2& b, const Fq2& c) { return a + b + c; }
 struct RefFq6 { Fq2 c0, c1, c2; };
 KDEV RefFq6 ref_fq6_mul(const RefFq6& a, const RefFq6& b) {

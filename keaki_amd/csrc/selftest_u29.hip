@@ -1,10 +1,10 @@
 // On-device self-tests of the 29-bit lazy arithmetic (fq29 / xyzz29 / jac29) against the saturated streams. Split from selftest.hip
 // so that the two translation units compile in parallel.
-#include "bn254_curve.cuh"
-#include "fq29.cuh"
-#include "xyzz29.cuh"
-#include "jac29.cuh"
-#include "ec_batch.cuh"
+#include "bn254_curve.hip.h"
+#include "fq29.hip.h"
+#include "xyzz29.hip.h"
+#include "jac29.hip.h"
+#include "ec_batch.hip.h"
 #include "internal.h"
 namespace bn254 {
 using FqRef = Fp<FqParamsRef>;
@@ -29,7 +29,7 @@ KDEV Fq pick(u32& s, u32 shape) {
   return x;
 }
 
-// 9 x 29-bit lazy arithmetic (fq29.cuh) against the saturated streams: every result is brought back with u29_to_fq
+// 9 x 29-bit lazy arithmetic (fq29.hip.h) against the saturated streams: every result is brought back with u29_to_fq
 __global__ void __launch_bounds__(256) k_selftest_u29(u32 seed, u32 iters, unsigned long long* mismatches) {
   u32 s = (seed ^ (blockIdx.x * 0x9E3779B9u) ^ (threadIdx.x * 0xC2B2AE35u)) | 1u;
   unsigned long long bad = 0;
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256) k_selftest_u29(u32 seed, u32 iters, unsig
   if (bad) atomicAdd(mismatches, bad);
 }
 
-// XYZZ addition / doubling in the 29-bit representation (xyzz29.cuh) against the saturated formulas, projectively compared
+// XYZZ addition / doubling in the 29-bit representation (xyzz29.hip.h) against the saturated formulas, projectively compared
 KDEV bool xyzz_same(const Xyzz<Fq>& a, const Xyzz<Fq>& b) {
   if (xyzz_is_inf(a) || xyzz_is_inf(b)) return xyzz_is_inf(a) && xyzz_is_inf(b);
   return fq_eq(a.x * b.zz, b.x * a.zz) && fq_eq(a.y * b.zzz, b.y * a.zzz);
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(64) k_selftest_x29(u32 seed, u32 iters, unsign
   if (bad) atomicAdd(mismatches, bad);
 }
 
-// NAF ladder in the 29-bit Jacobian arithmetic (jac29.cuh) against the saturated double-and-add of ec_batch.cuh
+// NAF ladder in the 29-bit Jacobian arithmetic (jac29.hip.h) against the saturated double-and-add of ec_batch.hip.h
 __global__ void __launch_bounds__(64) k_selftest_j29(u32 seed, u32 iters, unsigned long long* mismatches) {
   u32 s = (seed ^ ((blockIdx.x * 64 + threadIdx.x) * 0x9E3779B9u)) | 1u;
   unsigned long long bad = 0;

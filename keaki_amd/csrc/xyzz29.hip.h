@@ -1,14 +1,14 @@
-// XYZZ points of BN254 G1 in the 9 x 29-bit lazy representation of fq29.cuh: the working form of the MSM tail (k_msm_reduce,
+// XYZZ points of BN254 G1 in the 9 x 29-bit lazy representation of fq29.hip.h: the working form of the MSM tail (k_msm_reduce,
 // k_msm_partial_groups, k_msm_window_finish) for G1. Every coordinate is carried (limbs 0..7 below 2^29 + 8) and below 32 p, so a
 // saturated coordinate enters by u29_from_sat_shift5 alone; formulas are EFD add-2008-s and dbl-2008-s-1 (a = 0), the same ones
-// bn254_curve.cuh uses in the saturated arithmetic. Bounds (multiples of p), inputs < 32:
+// bn254_curve.hip.h uses in the saturated arithmetic. Bounds (multiples of p), inputs < 32:
 //   add: U1, U2, S1, S2 < 7.1; P, R = difference + 8p < 15.1; PP < 2.4; PPP, Q < 1.3; X3 < 10.4; T < 17.1 (uncarried, only multiplied by
 //        the carried R); Y3 < 4.6; ZZ3, ZZZ3 < 1.1
 //   dbl: U = 2Y < 64; V < 25.2; W < 10.5; S < 5.8; M = 3X^2 < 21.2; X3 < 19.7; T < 37.8 (uncarried); Y3 < 9.7; ZZ3 < 5.8; ZZZ3 < 3
 // (a limb-exact model with 64-bit overflow assertions ran these chains before the kernels were written).
 #pragma once
-#include "bn254_curve.cuh"
-#include "fq29.cuh"
+#include "bn254_curve.hip.h"
+#include "fq29.hip.h"
 
 namespace bn254 {
 

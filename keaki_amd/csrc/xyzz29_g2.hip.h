@@ -1,6 +1,6 @@
-// XYZZ accumulation on BN254's G2 (coordinates in Fq2) in the 9 x 29-bit lazy limbs of fq29.cuh, one lane per point: the mixed addition
-// of the G2 bucket kernel (k_msm_accumulate_g2_u29, msm.cuh) and of the fixed-base sums of `encapsulate` (k_encap_fixed<Fq2>,
-// ec_batch.cuh: ct = r [tau]_2 - (r alpha) g2, reference src/kem.rs:36-37).
+// XYZZ accumulation on BN254's G2 (coordinates in Fq2) in the 9 x 29-bit lazy limbs of fq29.hip.h, one lane per point: the mixed addition
+// of the G2 bucket kernel (k_msm_accumulate_g2_u29, msm.hip.h) and of the fixed-base sums of `encapsulate` (k_encap_fixed<Fq2>,
+// ec_batch.hip.h: ct = r [tau]_2 - (r alpha) g2, reference src/kem.rs:36-37).
 //
 // An Fq2 value is two limb vectors (re, im), Montgomery radix 2^261, lazily reduced. A product component is ONE dual stream
 //   re = a0 b0 + (K p - a1) b1        im = a0 b1 + a1 b0          (u29_mul2: one reduction for two products)
@@ -13,10 +13,10 @@
 // X3 before the reduction < 6.4, after < 1.1; T < 3.1; Y3 < 1.5; ZZ3, ZZZ3 < 1.1.
 // ~5,600 instructions per addition (4,700 v_mad_u64_u32) against ~9,000 for the generic saturated formulas over the Fq2 product.
 #pragma once
-#include "bn254_curve.cuh"
-#include "fq29.cuh"
-#include "fq29_dot_asm.cuh"
-#include "xyzz29.cuh"
+#include "bn254_curve.hip.h"
+#include "fq29.hip.h"
+#include "fq29_dot_asm.hip.h"
+#include "xyzz29.hip.h"
 
 namespace bn254 {
 
@@ -183,7 +183,7 @@ KDEV X29G2 x29g2_add(const X29G2& a, const X29G2& b) {
   return r;
 }
 
-// the working point of the MSM tail for G2 (see TailOps in xyzz29.cuh)
+// the working point of the MSM tail for G2 (see TailOps in xyzz29.hip.h)
 template <>
 struct TailOps<Fq2> {
   typedef X29G2 P;

@@ -24,6 +24,10 @@ EXPORTS = [
     "keaki_hip_pairing_batch", "keaki_hip_pairing_batch_dev",
     "keaki_hip_encap_batch", "keaki_hip_encap_batch_dev", "keaki_hip_decap_batch", "keaki_hip_decap_batch_dev",
     "keaki_hip_selftest_field", "keaki_hip_open_fk", "keaki_hip_open_fk_poly", "keaki_hip_srs_g1_precompute_fk", "keaki_hip_fk_shard_create", "keaki_hip_fk_shard_free", "keaki_hip_fk_shard_sizes", "keaki_hip_fk_shard_setup", "keaki_hip_fk_shard_open", "keaki_hip_fr_fft", "keaki_hip_srs_g1_check", "keaki_hip_g2_check", "keaki_hip_kzg_open", "keaki_hip_kzg_verify", "keaki_hip_final_exp_batch", "keaki_hip_miller_loop_batch", "keaki_hip_g2_prepare", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
+    "keaki_hip_ctx_set_option", "keaki_hip_debug_set_alloc_limit", "keaki_hip_ctx_memory", "keaki_hip_kzg_quotient",
+    "keaki_hip_group_create", "keaki_hip_group_destroy", "keaki_hip_group_size", "keaki_hip_group_ctx", "keaki_hip_group_last_error",
+    "keaki_hip_group_srs_g1_upload", "keaki_hip_group_srs_g1_len", "keaki_hip_group_srs_g1_free", "keaki_hip_group_msm_g1",
+    "keaki_hip_group_kzg_open", "keaki_hip_group_encap_batch", "keaki_hip_group_decap_batch",
 ]
 
 KEAKI_ERR_TOO_LARGE = -5
@@ -102,6 +106,28 @@ def load_library():
         lib.keaki_hip_last_msm_total_ms.argtypes = [vp]
         lib.keaki_hip_last_msm_total_ms.restype = C.c_float
         lib.keaki_hip_last_msm_window_bits.argtypes = [vp]
+        lib.keaki_hip_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+        lib.keaki_hip_debug_set_alloc_limit.argtypes = [vp, sz]
+        lib.keaki_hip_ctx_memory.argtypes = [vp, C.POINTER(C.c_size_t)]
+        lib.keaki_hip_kzg_quotient.argtypes = [vp, vp, sz, vp, vp, vp]
+        lib.keaki_hip_group_create.argtypes = [C.POINTER(i32), sz, C.POINTER(vp)]
+        lib.keaki_hip_group_destroy.argtypes = [vp]
+        lib.keaki_hip_group_destroy.restype = None
+        lib.keaki_hip_group_size.argtypes = [vp]
+        lib.keaki_hip_group_size.restype = sz
+        lib.keaki_hip_group_ctx.argtypes = [vp, sz]
+        lib.keaki_hip_group_ctx.restype = vp
+        lib.keaki_hip_group_last_error.argtypes = [vp]
+        lib.keaki_hip_group_last_error.restype = C.c_char_p
+        lib.keaki_hip_group_srs_g1_upload.argtypes = [vp, vp, sz, i32, C.POINTER(vp)]
+        lib.keaki_hip_group_srs_g1_len.argtypes = [vp]
+        lib.keaki_hip_group_srs_g1_len.restype = sz
+        lib.keaki_hip_group_srs_g1_free.argtypes = [vp, vp]
+        lib.keaki_hip_group_srs_g1_free.restype = None
+        lib.keaki_hip_group_msm_g1.argtypes = [vp, vp, vp, sz, vp]
+        lib.keaki_hip_group_kzg_open.argtypes = [vp, vp, vp, sz, vp, vp, vp]
+        lib.keaki_hip_group_encap_batch.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, sz]
+        lib.keaki_hip_group_decap_batch.argtypes = [vp, vp, vp, sz, vp, vp, sz]
         _LIB = lib
     return _LIB
 
@@ -181,6 +207,29 @@ class KeakiHip:
 
     def synchronize(self):
         self._ck(self.lib.keaki_hip_synchronize(self.ctx))
+
+    def set_option(self, name: str, value: int):
+        """tuning / A-B switch of this context (keaki_hip_ctx_set_option); the environment is only read when a context is created"""
+        self._ck(self.lib.keaki_hip_ctx_set_option(self.ctx, name.encode(), int(value)))
+
+    def debug_set_alloc_limit(self, nbytes: int):
+        """test hook: single allocations of this context above nbytes fail with KEAKI_ERR_OOM (0 = no limit)"""
+        self._ck(self.lib.keaki_hip_debug_set_alloc_limit(self.ctx, int(nbytes)))
+
+    def memory(self) -> dict:
+        out = (C.c_size_t * 4)()
+        self._ck(self.lib.keaki_hip_ctx_memory(self.ctx, out))
+        return {"tables": int(out[0]), "workspaces": int(out[1]), "gt_tables": int(out[2]), "total": int(out[3])}
+
+    def version(self) -> str:
+        return self.lib.keaki_hip_version().decode()
+
+    def kzg_quotient(self, coeffs, point):
+        """-> ((n - 1) x u64[4] quotient coefficients, p(point) u64[4])"""
+        c = _np(coeffs, 4); n = c.shape[0]
+        q = np.zeros((max(n - 1, 0), 4), np.uint64); val = np.zeros(4, np.uint64)
+        self._ck(self.lib.keaki_hip_kzg_quotient(self.ctx, _ptr(c) if n else None, n, _ptr(_np(point)), _ptr(q) if n > 1 else None, _ptr(val)))
+        return q, val
 
     def set_timing(self, on: bool):
         self._ck(self.lib.keaki_hip_set_timing(self.ctx, 1 if on else 0))
@@ -394,6 +443,83 @@ class KeakiHip:
     def decap_batch_dev(self, d_proofs, d_cts, n, d_gt, d_key, msg_len):
         v = lambda x: C.c_void_p(x) if x else None
         self._ck(self.lib.keaki_hip_decap_batch_dev(self.ctx, v(d_proofs), v(d_cts), n, v(d_gt), v(d_key), msg_len))
+
+
+class GroupSrsG1:
+    def __init__(self, owner, handle, n):
+        self.owner, self.handle, self.n = owner, handle, n
+
+    def free(self):
+        if self.handle:
+            self.owner.lib.keaki_hip_group_srs_g1_free(self.owner.g, self.handle)
+            self.handle = None
+
+
+class KeakiHipGroup:
+    """keaki_hip_group_*: one context + one host thread per entry of `devices` inside the library (in-process multi-GPU; an ordinal may
+    repeat). The SRS is split into contiguous chunks, one per member, each with its own window tables."""
+
+    def __init__(self, devices):
+        self.lib = load_library()
+        devs = (C.c_int32 * len(devices))(*devices)
+        g = C.c_void_p()
+        st = self.lib.keaki_hip_group_create(devs, len(devices), C.byref(g))
+        if st != 0:
+            raise KeakiHipError(st, self.lib.keaki_hip_group_last_error(None).decode())
+        self.g = g
+        self.size = len(devices)
+
+    def close(self):
+        if getattr(self, "g", None):
+            self.lib.keaki_hip_group_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, st):
+        if st != 0:
+            raise KeakiHipError(st, self.lib.keaki_hip_group_last_error(self.g).decode())
+
+    def member_memory(self, i: int) -> dict:
+        out = (C.c_size_t * 4)()
+        st = self.lib.keaki_hip_ctx_memory(self.lib.keaki_hip_group_ctx(self.g, i), out)
+        if st != 0:
+            raise KeakiHipError(st, "ctx_memory")
+        return {"tables": int(out[0]), "workspaces": int(out[1]), "gt_tables": int(out[2]), "total": int(out[3])}
+
+    def srs_g1_upload(self, points, precompute: bool = True) -> GroupSrsG1:
+        pts = _np(points, 8); h = C.c_void_p()
+        self._ck(self.lib.keaki_hip_group_srs_g1_upload(self.g, _ptr(pts), pts.shape[0], 1 if precompute else 0, C.byref(h)))
+        return GroupSrsG1(self, h, pts.shape[0])
+
+    def msm_g1(self, srs: GroupSrsG1, scalars) -> np.ndarray:
+        sc = _np(scalars, 4); out = np.zeros(12, np.uint64)
+        self._ck(self.lib.keaki_hip_group_msm_g1(self.g, srs.handle, _ptr(sc) if sc.shape[0] else None, sc.shape[0], _ptr(out)))
+        return out
+
+    def kzg_open(self, srs: GroupSrsG1, coeffs, point):
+        c = _np(coeffs, 4)
+        out = np.zeros(12, np.uint64); val = np.zeros(4, np.uint64)
+        self._ck(self.lib.keaki_hip_group_kzg_open(self.g, srs.handle, _ptr(c) if c.shape[0] else None, c.shape[0], _ptr(_np(point)), _ptr(out), _ptr(val)))
+        return out, val
+
+    def encap_batch(self, com, tau_g2, points, values, rs, msg_len: int = 32):
+        com = _np(com); tau = _np(tau_g2); pts = _np(points, 4); vals = _np(values, 4); rs = _np(rs, 4)
+        n = pts.shape[0]
+        ct = np.zeros((n, 16), np.uint64); gt = np.zeros((n, 384), np.uint8); key = np.zeros((n, max(msg_len, 1)), np.uint8)
+        self._ck(self.lib.keaki_hip_group_encap_batch(self.g, _ptr(com), _ptr(tau), _ptr(pts), _ptr(vals), _ptr(rs), n,
+                                                      _ptr(ct), _ptr(gt), _ptr(key) if msg_len else None, msg_len))
+        return ct, gt, key[:, :msg_len]
+
+    def decap_batch(self, proofs, cts, msg_len: int = 32):
+        p = _np(proofs, 8); c = _np(cts, 16); n = p.shape[0]
+        gt = np.zeros((n, 384), np.uint8); key = np.zeros((n, max(msg_len, 1)), np.uint8)
+        self._ck(self.lib.keaki_hip_group_decap_batch(self.g, _ptr(p), _ptr(c), n, _ptr(gt), _ptr(key) if msg_len else None, msg_len))
+        return gt, key[:, :msg_len]
 
 
 def jac_to_affine_words(jac) -> np.ndarray:

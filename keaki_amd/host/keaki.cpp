@@ -84,9 +84,22 @@ Device::Device(int ordinal) {
   int st = keaki_hip_ctx_create(ordinal, nullptr, &ctx_);
   if (st != KEAKI_OK) throw HipError(st, keaki_hip_last_error(nullptr));
 }
-Device::~Device() { keaki_hip_ctx_destroy(ctx_); }
+Device::Device(const std::vector<int>& ordinals) {
+  std::vector<int32_t> d(ordinals.begin(), ordinals.end());
+  int st = keaki_hip_group_create(d.data(), d.size(), &group_);
+  if (st != KEAKI_OK) throw HipError(st, keaki_hip_group_last_error(nullptr));
+  ctx_ = keaki_hip_group_ctx(group_, 0);       // owned by the group
+}
+Device::~Device() {
+  if (group_) keaki_hip_group_destroy(group_);
+  else keaki_hip_ctx_destroy(ctx_);
+}
+size_t Device::members() const { return group_ ? keaki_hip_group_size(group_) : 1; }
 void Device::check(int status) const {
   if (status != KEAKI_OK) throw HipError(status, keaki_hip_last_error(ctx_));
+}
+void Device::check_group(int status) const {
+  if (status != KEAKI_OK) throw HipError(status, keaki_hip_group_last_error(group_));
 }
 
 namespace {
@@ -123,11 +136,16 @@ std::string KZGError::to_string() const {
 KZGSetup::~KZGSetup() {
   if (chunk_ && dev_) keaki_hip_srs_g1_free(dev_->ctx(), chunk_);
   if (srs_ && dev_) keaki_hip_srs_g1_free(dev_->ctx(), srs_);
+  if (gsrs_ && dev_) keaki_hip_group_srs_g1_free(dev_->group(), gsrs_);
 }
 KZGSetup::KZGSetup(KZGSetup&& o) noexcept
-    : dev_(std::move(o.dev_)), g1_aff_(std::move(o.g1_aff_)), tau_g2_(o.tau_g2_), srs_(o.srs_), tables_(o.tables_), chunk_(o.chunk_),
+    : dev_(std::move(o.dev_)), g1_aff_(std::move(o.g1_aff_)), tau_g2_(o.tau_g2_), srs_(o.srs_), gsrs_(o.gsrs_), tables_(o.tables_), chunk_(o.chunk_),
       chunk_lo_(o.chunk_lo_), chunk_hi_(o.chunk_hi_) {
-  o.srs_ = nullptr; o.chunk_ = nullptr;
+  o.srs_ = nullptr; o.chunk_ = nullptr; o.gsrs_ = nullptr;
+}
+keaki_hip_srs_g1* KZGSetup::srs() const {
+  if (!srs_) dev_->check(keaki_hip_srs_g1_upload(dev_->ctx(), g1_aff_.empty() ? nullptr : g1_aff_[0].w.data(), g1_aff_.size(), &srs_));
+  return srs_;
 }
 
 // window tables are an optimisation: when they do not fit (KEAKI_ERR_OOM) the handle keeps working through the generic path
@@ -139,10 +157,10 @@ static bool try_precompute(const Device& dev, keaki_hip_srs_g1* srs) {
 }
 
 keaki_hip_srs_g1* KZGSetup::chunk_srs(size_t lo, size_t hi) const {
-  if (lo == 0 && hi == g1_aff_.size()) return srs_;            // one rank: the chunk is the SRS, its tables are there already
+  if (lo == 0 && hi == g1_aff_.size()) return srs();            // one rank: the chunk is the SRS, its tables are there already
   if (chunk_ && chunk_lo_ == lo && chunk_hi_ == hi) return chunk_;
   if (chunk_) { keaki_hip_srs_g1_free(dev_->ctx(), chunk_); chunk_ = nullptr; }
-  dev_->check(keaki_hip_srs_g1_slice(dev_->ctx(), srs_, lo, hi - lo, &chunk_));
+  dev_->check(keaki_hip_srs_g1_slice(dev_->ctx(), srs(), lo, hi - lo, &chunk_));
   chunk_lo_ = lo; chunk_hi_ = hi;
   if (tables_ && hi > lo) (void)try_precompute(*dev_, chunk_);
   return chunk_;
@@ -153,6 +171,12 @@ KZGSetup KZGSetup::from_powers(std::shared_ptr<Device> dev, std::vector<G1> g1_a
   s.dev_ = std::move(dev);
   s.g1_aff_ = std::move(g1_aff);
   s.tau_g2_ = tau_g2;
+  if (s.dev_->group()) {
+    // several GPUs in this process: chunk i of the SRS and its window tables live on member i from now on (src/kzg.rs:98 reads them)
+    s.dev_->check_group(keaki_hip_group_srs_g1_upload(s.dev_->group(), s.g1_aff_.empty() ? nullptr : s.g1_aff_[0].w.data(), s.g1_aff_.size(), 1, &s.gsrs_));
+    s.tables_ = true;
+    return s;
+  }
   s.dev_->check(keaki_hip_srs_g1_upload(s.dev_->ctx(), s.g1_aff_.empty() ? nullptr : s.g1_aff_[0].w.data(), s.g1_aff_.size(), &s.srs_));
   // The SRS never changes after setup: tabulate [2^(window offset)] tau^i G1 once so that every later commit/open runs the
   // shared-bucket MSM (W x the SRS in HBM). It pays at every size: a 1000-coefficient commit takes 0.64 ms with tables, 1.98 ms
@@ -180,7 +204,10 @@ Result<G1> commit(const KZGSetup& setup, const DensePolynomial& p) {
   if (p.size() > setup.g1_pow().size())
     return Result<G1>::Err(KZGError{KZGError::PolynomialTooLarge, p.size(), setup.g1_pow().size()});
   uint64_t jac[12];
-  setup.device()->check(keaki_hip_msm_g1(setup.device()->ctx(), setup.srs(), p.empty() ? nullptr : p[0].l, p.size(), jac));
+  if (setup.group_srs())
+    setup.device()->check_group(keaki_hip_group_msm_g1(setup.device()->group(), setup.group_srs(), p.empty() ? nullptr : p[0].l, p.size(), jac));
+  else
+    setup.device()->check(keaki_hip_msm_g1(setup.device()->ctx(), setup.srs(), p.empty() ? nullptr : p[0].l, p.size(), jac));
   return Result<G1>::Ok(jac_to_g1(jac));
 }
 
@@ -196,7 +223,10 @@ Result<G1> open(const KZGSetup& setup, const DensePolynomial& p_in, const Fr& po
   if (qlen > setup.g1_pow().size())                       // the commit inside open fails with the QUOTIENT's length (src/kzg.rs:123,91-96)
     return Result<G1>::Err(KZGError{KZGError::PolynomialTooLarge, qlen, setup.g1_pow().size()});
   uint64_t jac[12];
-  setup.device()->check(keaki_hip_kzg_open(setup.device()->ctx(), setup.srs(), p.empty() ? nullptr : p[0].l, p.size(), point.l, jac, nullptr));
+  if (setup.group_srs())
+    setup.device()->check_group(keaki_hip_group_kzg_open(setup.device()->group(), setup.group_srs(), p.empty() ? nullptr : p[0].l, p.size(), point.l, jac, nullptr));
+  else
+    setup.device()->check(keaki_hip_kzg_open(setup.device()->ctx(), setup.srs(), p.empty() ? nullptr : p[0].l, p.size(), point.l, jac, nullptr));
   return Result<G1>::Ok(jac_to_g1(jac));
 }
 
@@ -281,6 +311,24 @@ std::vector<uint8_t> decrypt(const kzg::KZGSetup& setup, const G1& proof, const 
 
 // ------------------------------------------------------------------------------------------------ vec
 namespace vec {
+namespace {
+// the loop bodies of src/vec.rs:63-66 / :75-78 as one batched call: over all members of a group device for large batches
+void encap_many(const kzg::KZGSetup& setup, const G1& com, const uint64_t* points, const uint64_t* values, const uint64_t* rs, size_t n,
+                uint64_t* ct, uint8_t* key, size_t msg_len) {
+  const Device& dev = *setup.device();
+  if (dev.group() && n >= GROUP_MIN_ITEMS)
+    dev.check_group(keaki_hip_group_encap_batch(dev.group(), com.w.data(), setup.tau_g2().w.data(), points, values, rs, n, ct, nullptr, key, msg_len));
+  else
+    dev.check(keaki_hip_encap_batch(dev.ctx(), com.w.data(), setup.tau_g2().w.data(), points, values, rs, n, ct, nullptr, key, msg_len));
+}
+void decap_many(const kzg::KZGSetup& setup, const uint64_t* proofs, const uint64_t* cts, size_t n, uint8_t* key, size_t msg_len) {
+  const Device& dev = *setup.device();
+  if (dev.group() && n >= GROUP_MIN_ITEMS)
+    dev.check_group(keaki_hip_group_decap_batch(dev.group(), proofs, cts, n, nullptr, key, msg_len));   // keys only: no 384 B/item GT download
+  else
+    dev.check(keaki_hip_decap_batch(dev.ctx(), proofs, cts, n, nullptr, key, msg_len));
+}
+}  // namespace
 
 Radix2Domain Radix2Domain::create(size_t min_size) {
   size_t size = 1; unsigned log = 0;
@@ -368,8 +416,7 @@ std::vector<enc::Ciphertext> vec_encrypt(Rng& rng, const kzg::KZGSetup& setup, c
   for (auto& m : messages) max_len = std::max(max_len, m.size());
   std::vector<uint64_t> ct(16 * n);
   std::vector<uint8_t> key(n * std::max<size_t>(max_len, 1));
-  setup.device()->check(keaki_hip_encap_batch(setup.device()->ctx(), com.w.data(), setup.tau_g2().w.data(), points[0].l, values[0].l, rs[0].l, n,
-                                              ct.data(), nullptr, key.data(), max_len));
+  encap_many(setup, com, points[0].l, values[0].l, rs[0].l, n, ct.data(), key.data(), max_len);
   for (size_t i = 0; i < n; i++) {
     memcpy(out[i].first.w.data(), &ct[16 * i], 128);
     out[i].second.resize(messages[i].size());
@@ -386,14 +433,17 @@ void vec_encrypt_flat(Rng& rng, const kzg::KZGSetup& setup, const G1& com, const
   if (!n) return;
   std::vector<Fr> rs(n);
   for (size_t i = 0; i < n; i++) rs[i] = fr_rand(rng);        // one r per item, in index order (src/vec.rs:63-66 -> src/kem.rs:26)
-  setup.device()->check(keaki_hip_encap_batch(setup.device()->ctx(), com.w.data(), setup.tau_g2().w.data(), points[0].l, values[0].l, rs[0].l, n,
-                                              ct_g2_out, nullptr, msg_len ? ct_msg_out : nullptr, msg_len));
+  std::vector<uint8_t> gt_unused;
+  if (!msg_len) gt_unused.resize(n * 384);       // the ABI wants at least one of gt / key
+  if (msg_len) encap_many(setup, com, points[0].l, values[0].l, rs[0].l, n, ct_g2_out, ct_msg_out, msg_len);
+  else setup.device()->check(keaki_hip_encap_batch(setup.device()->ctx(), com.w.data(), setup.tau_g2().w.data(), points[0].l, values[0].l, rs[0].l, n,
+                                                   ct_g2_out, gt_unused.data(), nullptr, 0));
   for (size_t i = 0; i < n * msg_len; i++) ct_msg_out[i] ^= msgs[i];                                          // src/enc.rs:32-36
 }
 void vec_decrypt_flat(const kzg::KZGSetup& setup, const uint64_t* proofs, const uint64_t* ct_g2, const uint8_t* ct_msgs, size_t n, size_t msg_len,
                       uint8_t* msgs_out) {
   if (!n || !msg_len) return;
-  setup.device()->check(keaki_hip_decap_batch(setup.device()->ctx(), proofs, ct_g2, n, nullptr, msgs_out, msg_len));
+  decap_many(setup, proofs, ct_g2, n, msgs_out, msg_len);
   for (size_t i = 0; i < n * msg_len; i++) msgs_out[i] ^= ct_msgs[i];                                         // src/enc.rs:48-52
 }
 std::vector<std::vector<uint8_t>> vec_decrypt(const kzg::KZGSetup& setup, const std::vector<G1>& proofs,
@@ -406,7 +456,7 @@ std::vector<std::vector<uint8_t>> vec_decrypt(const kzg::KZGSetup& setup, const 
   std::vector<uint64_t> pr(8 * n), ct(16 * n);
   for (size_t i = 0; i < n; i++) { memcpy(&pr[8 * i], proofs[i].w.data(), 64); memcpy(&ct[16 * i], cts[i]->first.w.data(), 128); }
   std::vector<uint8_t> key(n * std::max<size_t>(max_len, 1));
-  setup.device()->check(keaki_hip_decap_batch(setup.device()->ctx(), pr.data(), ct.data(), n, nullptr, key.data(), max_len));   // keys only: no 384 B/item GT download
+  decap_many(setup, pr.data(), ct.data(), n, key.data(), max_len);
   for (size_t i = 0; i < n; i++) {
     out[i].resize(cts[i]->second.size());
     for (size_t j = 0; j < out[i].size(); j++) out[i][j] = key[i * max_len + j] ^ cts[i]->second[j];

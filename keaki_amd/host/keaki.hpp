@@ -68,17 +68,28 @@ struct HipError : std::runtime_error {
   HipError(int s, const std::string& m) : std::runtime_error(m), status(s) {}
 };
 
-// One GPU context shared by the setup objects created from it.
+// One GPU context shared by the setup objects created from it -- or, built from a LIST of ordinals, several GPUs of this process behind
+// one object (keaki_hip_group_*: one context and one host thread per entry inside the library; an ordinal may repeat). With a group,
+// kzg::commit / open spread the MSM over all members by SRS range (each member keeps its chunk of the SRS and that chunk's window
+// tables from setup on; the 96-byte partial sums come back through host memory) and the loops of vec_encrypt / vec_decrypt are
+// split by item range. Everything else (verify, single encapsulate / decapsulate, open_fk) runs on member 0, whose context ctx() returns.
 class Device {
  public:
   explicit Device(int ordinal = 0);
+  explicit Device(const std::vector<int>& ordinals);
   ~Device();
   Device(const Device&) = delete;
   keaki_hip_ctx* ctx() const { return ctx_; }
-  void check(int status) const;  // throws HipError
+  keaki_hip_group* group() const { return group_; }   // null for a single-GPU device
+  size_t members() const;
+  void check(int status) const;        // throws HipError
+  void check_group(int status) const;  // the same for keaki_hip_group_* calls
  private:
   keaki_hip_ctx* ctx_ = nullptr;
+  keaki_hip_group* group_ = nullptr;
 };
+// batches below this many items stay on member 0 of a group (a launch per member costs more than it saves)
+constexpr size_t GROUP_MIN_ITEMS = 1024;
 
 using DensePolynomial = std::vector<Fr>;  // coefficients, low degree first (ark-poly DensePolynomial::coeffs)
 
@@ -116,7 +127,10 @@ class KZGSetup {
   const std::vector<G1>& g1_aff() const { return g1_aff_; }
   const G2& tau_g2() const { return tau_g2_; }
   const std::shared_ptr<Device>& device() const { return dev_; }
-  keaki_hip_srs_g1* srs() const { return srs_; }
+  // device-resident copy of the whole SRS on (member 0 of) the device. With a group it is uploaded on first use: commit / open never
+  // need it (they read the per-member chunks), open_fk and the keaki::dist calls do.
+  keaki_hip_srs_g1* srs() const;
+  keaki_hip_group_srs_g1* group_srs() const { return gsrs_; }
   // false when the optional window tables of the SRS did not fit in HBM: commit / open then run the generic per-window MSM (same results)
   bool has_window_tables() const { return tables_; }
   // this rank's chunk [lo, hi) of the SRS as a handle of its own, with its own window tables (built on first use; see keaki::dist)
@@ -126,7 +140,8 @@ class KZGSetup {
   std::shared_ptr<Device> dev_;
   std::vector<G1> g1_aff_;
   G2 tau_g2_;
-  keaki_hip_srs_g1* srs_ = nullptr;  // device-resident copy of g1_aff, uploaded once
+  mutable keaki_hip_srs_g1* srs_ = nullptr;  // device-resident copy of g1_aff, uploaded once
+  keaki_hip_group_srs_g1* gsrs_ = nullptr;   // group devices: one chunk (+ its window tables) per member
   bool tables_ = false;
   mutable keaki_hip_srs_g1* chunk_ = nullptr;
   mutable size_t chunk_lo_ = 0, chunk_hi_ = 0;

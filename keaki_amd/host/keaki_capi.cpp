@@ -78,6 +78,39 @@ void keaki_host_fft(const uint64_t* coeffs, size_t n, size_t domain_min, uint64_
   for (size_t i = 0; i < c.size(); i++) memcpy(out + 4 * i, c[i].l, 32);
 }
 
+// ---- Device objects: one GPU, or a list of ordinals = several GPUs of this process behind one object (keaki::Device) ---------------
+// A handle is a std::shared_ptr<Device>*: setups created on it keep the device alive after the handle is freed.
+int keaki_host_device_new(const int* ordinals, size_t n, void** out) {
+  return guard([&] {
+    if (n == 1) *out = new std::shared_ptr<Device>(std::make_shared<Device>(ordinals[0]));
+    else *out = new std::shared_ptr<Device>(std::make_shared<Device>(std::vector<int>(ordinals, ordinals + n)));
+    return 0;
+  });
+}
+void keaki_host_device_free(void* dev) { delete (std::shared_ptr<Device>*)dev; }
+size_t keaki_host_device_members(void* dev) { return (*(std::shared_ptr<Device>*)dev)->members(); }
+// the keaki_hip_ctx of a member (member 0 for a single-GPU device): for the debug / option / memory calls of the C ABI
+void* keaki_host_device_ctx(void* dev, size_t member) {
+  auto& d = *(std::shared_ptr<Device>*)dev;
+  return d->group() ? (void*)keaki_hip_group_ctx(d->group(), member) : (member == 0 ? (void*)d->ctx() : nullptr);
+}
+int keaki_host_setup_on(void* dev, const uint64_t* secret, size_t max_d, void** out) {
+  return guard([&] {
+    auto d = *(std::shared_ptr<Device>*)dev;
+    *out = new Setup{d, kzg::KZGSetup::setup(d, fr_of(secret), max_d)};
+    return 0;
+  });
+}
+int keaki_host_setup_from_powers_on(void* dev, const uint64_t* g1_aff, size_t n, const uint64_t* tau_g2, void** out) {
+  return guard([&] {
+    auto d = *(std::shared_ptr<Device>*)dev;
+    std::vector<G1> pts(n);
+    for (size_t i = 0; i < n; i++) pts[i] = g1_of(g1_aff + 8 * i);
+    *out = new Setup{d, kzg::KZGSetup::from_powers(d, std::move(pts), g2_of(tau_g2))};
+    return 0;
+  });
+}
+
 // KZGSetup::setup(secret, max_d)
 int keaki_host_setup(int device, const uint64_t* secret, size_t max_d, void** out) {
   return guard([&] {

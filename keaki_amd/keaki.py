@@ -177,20 +177,85 @@ def ptau_section_index(section_id: int) -> int:
     return _lib().keaki_host_ptau_section_index(C.c_uint8(section_id))
 
 
+class _CtxView:
+    """a keaki_hip_ctx owned by someone else (a keaki::Device), with the option / debug / memory calls of the C ABI"""
+
+    def __init__(self, ctx):
+        from . import hip as H
+        self.lib, self.ctx, self._H = H.load_library(), ctx, H
+
+    def _ck(self, st):
+        if st != 0:
+            raise self._H.KeakiHipError(st, self.lib.keaki_hip_last_error(self.ctx).decode())
+
+    def set_option(self, name: str, value: int):
+        self._ck(self.lib.keaki_hip_ctx_set_option(self.ctx, name.encode(), int(value)))
+
+    def debug_set_alloc_limit(self, nbytes: int):
+        self._ck(self.lib.keaki_hip_debug_set_alloc_limit(self.ctx, int(nbytes)))
+
+    def memory(self) -> dict:
+        out = (C.c_size_t * 4)()
+        self._ck(self.lib.keaki_hip_ctx_memory(self.ctx, out))
+        return {"tables": int(out[0]), "workspaces": int(out[1]), "gt_tables": int(out[2]), "total": int(out[3])}
+
+
+class Device:
+    """keaki::Device: one GPU context shared by the setups created on it -- or, from a LIST of ordinals, several GPUs of this process
+    behind one object (one context + one host thread per entry inside libkeaki_hip.so; an ordinal may repeat): commit / open then
+    spread the MSM over the members by SRS range, vec_encrypt / vec_decrypt split their items."""
+
+    def __init__(self, ordinals=0):
+        lib = _lib()
+        lib.keaki_host_device_ctx.restype = C.c_void_p
+        lib.keaki_host_device_ctx.argtypes = [C.c_void_p, C.c_size_t]
+        lib.keaki_host_device_members.restype = C.c_size_t
+        lib.keaki_host_device_members.argtypes = [C.c_void_p]
+        lib.keaki_host_device_free.argtypes = [C.c_void_p]
+        ords = [int(ordinals)] if isinstance(ordinals, (int, np.integer)) else [int(o) for o in ordinals]
+        arr = (C.c_int * len(ords))(*ords)
+        h = C.c_void_p()
+        _ck(lib.keaki_host_device_new(arr, C.c_size_t(len(ords)), C.byref(h)))
+        self.h = h
+        self.members = int(lib.keaki_host_device_members(h))
+
+    def hip(self, member: int = 0):
+        """the member's context as a non-owning view with set_option / debug_set_alloc_limit / memory (keaki_amd.hip.KeakiHip's methods)"""
+        return _CtxView(C.c_void_p(_lib().keaki_host_device_ctx(self.h, member)))
+
+    def close(self):
+        if self.h:
+            _lib().keaki_host_device_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class KZGSetup:
     def __init__(self, handle):
         self.h = handle
 
     @staticmethod
-    def setup(secret, max_d: int, device: int = 0) -> "KZGSetup":
+    def setup(secret, max_d: int, device=0) -> "KZGSetup":
+        """device: a GPU ordinal (a context of its own is created) or a Device (shared context, or a group of GPUs)"""
         h = C.c_void_p()
-        _ck(_lib().keaki_host_setup(device, _p(_u64(secret)), C.c_size_t(max_d), C.byref(h)))
+        if isinstance(device, Device):
+            _ck(_lib().keaki_host_setup_on(device.h, _p(_u64(secret)), C.c_size_t(max_d), C.byref(h)))
+        else:
+            _ck(_lib().keaki_host_setup(device, _p(_u64(secret)), C.c_size_t(max_d), C.byref(h)))
         return KZGSetup(h)
 
     @staticmethod
-    def from_powers(g1_aff, tau_g2, device: int = 0) -> "KZGSetup":
+    def from_powers(g1_aff, tau_g2, device=0) -> "KZGSetup":
         pts = _u64(g1_aff, 8); h = C.c_void_p()
-        _ck(_lib().keaki_host_setup_from_powers(device, _p(pts), C.c_size_t(pts.shape[0]), _p(_u64(tau_g2)), C.byref(h)))
+        if isinstance(device, Device):
+            _ck(_lib().keaki_host_setup_from_powers_on(device.h, _p(pts), C.c_size_t(pts.shape[0]), _p(_u64(tau_g2)), C.byref(h)))
+        else:
+            _ck(_lib().keaki_host_setup_from_powers(device, _p(pts), C.c_size_t(pts.shape[0]), _p(_u64(tau_g2)), C.byref(h)))
         return KZGSetup(h)
 
     @staticmethod

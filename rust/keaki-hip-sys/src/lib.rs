@@ -38,6 +38,15 @@ pub struct keaki_hip_srs_g2 {
 pub struct keaki_hip_fk_shard {
     _private: [u8; 0],
 }
+/// in-process multi-GPU: one context and one host thread per member inside the library
+#[repr(C)]
+pub struct keaki_hip_group {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct keaki_hip_group_srs_g1 {
+    _private: [u8; 0],
+}
 
 extern "C" {
     // ---- context
@@ -46,6 +55,9 @@ extern "C" {
     pub fn keaki_hip_last_error(ctx: *const keaki_hip_ctx) -> *const c_char;
     pub fn keaki_hip_synchronize(ctx: *mut keaki_hip_ctx) -> keaki_status;
     pub fn keaki_hip_version() -> *const c_char;
+    pub fn keaki_hip_ctx_set_option(ctx: *mut keaki_hip_ctx, name: *const c_char, value: i64) -> keaki_status;
+    pub fn keaki_hip_debug_set_alloc_limit(ctx: *mut keaki_hip_ctx, bytes: usize) -> keaki_status;
+    pub fn keaki_hip_ctx_memory(ctx: *mut keaki_hip_ctx, out4: *mut usize) -> keaki_status;
 
     // ---- SRS (replaces KZGSetup::g1_aff, src/kzg.rs:22-29)
     pub fn keaki_hip_srs_g1_upload(ctx: *mut keaki_hip_ctx, points_aff: *const u64, n: usize, out: *mut *mut keaki_hip_srs_g1) -> keaki_status;
@@ -86,6 +98,8 @@ extern "C" {
     // ---- KZG open / verify in one call (src/kzg.rs:104-124, :127-151)
     pub fn keaki_hip_kzg_open(ctx: *mut keaki_hip_ctx, srs: *const keaki_hip_srs_g1, coeffs: *const u64, n: usize, point: *const u64,
                               proof_out_jac: *mut u64, value_out: *mut u64) -> keaki_status;
+    pub fn keaki_hip_kzg_quotient(ctx: *mut keaki_hip_ctx, coeffs: *const u64, n: usize, point: *const u64, quotient_out: *mut u64,
+                                  value_out: *mut u64) -> keaki_status;
     pub fn keaki_hip_kzg_verify(ctx: *mut keaki_hip_ctx, com_aff: *const u64, tau_g2_aff: *const u64, point: *const u64, value: *const u64,
                                 proof_aff: *const u64, ok_out: *mut i32) -> keaki_status;
 
@@ -113,6 +127,24 @@ extern "C" {
                                  msg_len: usize) -> keaki_status;
     pub fn keaki_hip_decap_batch_dev(ctx: *mut keaki_hip_ctx, d_proofs_aff: *const c_void, d_cts_aff: *const c_void, n: usize, d_gt_out: *mut c_void,
                                      d_key_out: *mut c_void, msg_len: usize) -> keaki_status;
+
+    // ---- device group: several GPUs of ONE process (one context + one host thread per member inside the library)
+    pub fn keaki_hip_group_create(devices: *const i32, n_devices: usize, out: *mut *mut keaki_hip_group) -> keaki_status;
+    pub fn keaki_hip_group_destroy(g: *mut keaki_hip_group);
+    pub fn keaki_hip_group_size(g: *const keaki_hip_group) -> usize;
+    pub fn keaki_hip_group_ctx(g: *const keaki_hip_group, member: usize) -> *mut keaki_hip_ctx;
+    pub fn keaki_hip_group_last_error(g: *const keaki_hip_group) -> *const c_char;
+    pub fn keaki_hip_group_srs_g1_upload(g: *mut keaki_hip_group, points_aff: *const u64, n: usize, precompute: i32,
+                                         out: *mut *mut keaki_hip_group_srs_g1) -> keaki_status;
+    pub fn keaki_hip_group_srs_g1_len(srs: *const keaki_hip_group_srs_g1) -> usize;
+    pub fn keaki_hip_group_srs_g1_free(g: *mut keaki_hip_group, srs: *mut keaki_hip_group_srs_g1);
+    pub fn keaki_hip_group_msm_g1(g: *mut keaki_hip_group, srs: *const keaki_hip_group_srs_g1, scalars: *const u64, n: usize, out_jac: *mut u64) -> keaki_status;
+    pub fn keaki_hip_group_kzg_open(g: *mut keaki_hip_group, srs: *const keaki_hip_group_srs_g1, coeffs: *const u64, n: usize, point: *const u64,
+                                    proof_out_jac: *mut u64, value_out: *mut u64) -> keaki_status;
+    pub fn keaki_hip_group_encap_batch(g: *mut keaki_hip_group, com_aff: *const u64, tau_g2_aff: *const u64, points: *const u64, values: *const u64,
+                                       r: *const u64, n: usize, ct_out_aff: *mut u64, gt_out: *mut u8, key_out: *mut u8, msg_len: usize) -> keaki_status;
+    pub fn keaki_hip_group_decap_batch(g: *mut keaki_hip_group, proofs_aff: *const u64, cts_aff: *const u64, n: usize, gt_out: *mut u8, key_out: *mut u8,
+                                       msg_len: usize) -> keaki_status;
 
     // ---- instrumentation
     pub fn keaki_hip_set_timing(ctx: *mut keaki_hip_ctx, enabled: i32) -> keaki_status;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised cross-check of encap_batch / decap_batch against the CPU oracle over batch sizes that hit every path (ladder < 256 <= fixed-base
-tables; per-item pairing vs the GT fixed-base path, forced with KEAKI_ENCAP_GT).  python tests/fuzz/fuzz_kem.py [rounds [seed]]"""
+tables; per-item pairing vs the GT fixed-base path, forced with the context option encap_gt).  python tests/fuzz/fuzz_kem.py [rounds [seed]]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +17,7 @@ rng = np.random.default_rng(seed)
 S0 = 0 if seed == 7 else seed * 100003
 bad = 0
 for it in range(rounds):
-    os.environ["KEAKI_ENCAP_GT"] = "64" if it % 2 else "1000000000"
+    hip.set_option("encap_gt", 64 if it % 2 else 1000000000)
     n = int(rng.integers(1, 700)) if it % 4 else [1, 255, 256, 257][(it // 4) % 4]
     tau, c0 = rand_fr_ints(2, S0 + 100 + it)
     com = hip.g1_mul_batch(g1, mont([c0]))[0]; tau_g2 = hip.g2_mul_batch(g2, mont([tau]))[0]

@@ -57,10 +57,8 @@ for it in range(rounds):
         desc = "n=%d" % n
     elif op in ("encap", "decap"):
         mode = rng.random()
-        if mode < 0.3:
-            os.environ.pop("KEAKI_ENCAP_GT", None)          # the library's own policy (GT path once a commitment repeats)
-        else:
-            os.environ["KEAKI_ENCAP_GT"] = "64" if mode < 0.7 else "1000000000"
+        gt_opt = -1 if mode < 0.3 else (64 if mode < 0.7 else 1000000000)      # -1: the library's own policy (GT path once a commitment repeats)
+        hip.set_option("encap_gt", gt_opt)
         n = int([1, 63, 100, 300, 700][int(rng.integers(0, 5))])
         com = coms[int(rng.integers(0, 3))]
         A, V, Rr = (mont(rand_fr_ints(n, S0 + 2000 + 3 * it + k)) for k in range(3))
@@ -73,7 +71,7 @@ for it in range(rounds):
             dgt, dkey = hip.decap_batch(proofs, ct, ml)
             egt2, ekey2 = oc.decap_batch(proofs, ect, ml, threads=8)
             ok = ok and np.array_equal(dgt, egt2) and np.array_equal(dkey, ekey2)
-        desc = "n=%d gt=%s" % (n, os.environ.get("KEAKI_ENCAP_GT", "auto"))
+        desc = "n=%d gt=%s" % (n, "auto" if gt_opt < 0 else gt_opt)
     elif op in ("open", "verify"):
         n = int(rng.integers(1, 400))
         c = rand_fr_ints(n, S0 + 4000 + it)

@@ -366,10 +366,11 @@ def test_miller_and_final_exp_stages(oc, hip, rand_fr):
         assert canon == exp[i].tobytes()
 
 
-def test_encap_gt_fixed_base_path_vs_oracle(oc, py, hip, rand_fr, monkeypatch):
+def test_encap_gt_fixed_base_path_vs_oracle(oc, py, hip, rand_fr, request):
     """Large batches compute GT_i = A^(r_i) * B^(-beta_i r_i) with A = e(C, g2), B = e(g1, g2) (fixed-base GT tables) instead of
     one pairing per item. Forced here with a low threshold; the bytes must equal the oracle's serial e(r(C - beta g1), g2)."""
-    monkeypatch.setenv("KEAKI_ENCAP_GT", "64")
+    hip.set_option("encap_gt", 64)
+    request.addfinalizer(lambda: hip.set_option("encap_gt", -1))      # the shared context goes back to the automatic policy
     g1, g2 = oc.generators()
     n = 300
     tau, c0, c1 = rand_fr(3, 81)
@@ -397,20 +398,20 @@ def test_encap_gt_fixed_base_path_vs_oracle(oc, py, hip, rand_fr, monkeypatch):
     ect, egt, _ = oc.encap_batch(z, tau_g2, A[:128], V[:128], Rr[:128], 32, threads=8)
     assert np.array_equal(ct, ect) and np.array_equal(gt, egt)
     # and the per-item pairing path agrees with it
-    monkeypatch.setenv("KEAKI_ENCAP_GT", "1000000000")
+    hip.set_option("encap_gt", 1000000000)
     com = hip.g1_mul_batch(g1, mont(oc, [c0]))[0]
     ct2, gt2, _ = hip.encap_batch(com, tau_g2, A, V, Rr, 32)
-    monkeypatch.setenv("KEAKI_ENCAP_GT", "64")
+    hip.set_option("encap_gt", 64)
     ct3, gt3, _ = hip.encap_batch(com, tau_g2, A, V, Rr, 32)
     assert np.array_equal(gt2, gt3) and np.array_equal(ct2, ct3)
 
 
 def test_encap_small_calls_switch_to_gt_path_when_commitment_repeats(oc, py, rand_fr, monkeypatch):
-    """Without KEAKI_ENCAP_GT the third consecutive call with one commitment (any batch size) builds the tables of A = e(C, g2) and B and
+    """Under the automatic policy (option encap_gt = -1) the third consecutive call with one commitment (any batch size) builds the tables of A = e(C, g2) and B and
     takes the GT fixed-base path; later calls reuse them, a different commitment goes back to the per-item path. Own context (the policy is
     per context); every call against the oracle."""
     from keaki_amd.hip import KeakiHip
-    monkeypatch.delenv("KEAKI_ENCAP_GT", raising=False)
+    monkeypatch.delenv("KEAKI_ENCAP_GT", raising=False)      # the environment only matters while a context is created
     monkeypatch.delenv("KEAKI_GT_WB_B", raising=False)
     h = KeakiHip(0)
     try:
@@ -445,9 +446,10 @@ def test_encap_gt_path_other_window_widths(oc, py, rand_fr, monkeypatch, wb):
     """The constant-base GT table at another window width (16 bits is what a context falls back to when the 2.6 GB 20-bit table does not
     fit; 11 leaves a 1-bit top window): own context, since the table is built once per context."""
     from keaki_amd.hip import KeakiHip
-    monkeypatch.setenv("KEAKI_ENCAP_GT", "64")
-    monkeypatch.setenv("KEAKI_GT_WB_B", str(wb))
+    monkeypatch.setenv("KEAKI_ENCAP_GT", "64")                 # read once, by keaki_hip_ctx_create: the initial value of option encap_gt
     h = KeakiHip(0)
+    monkeypatch.setenv("KEAKI_ENCAP_GT", "1000000000")         # changing the environment afterwards must not matter
+    h.set_option("gt_wb_b", wb)
     try:
         g1, g2 = oc.generators()
         n = 96
@@ -774,8 +776,8 @@ def test_one_context_four_threads_different_sizes(oc, rand_fr):
 
 
 def test_optional_memory_is_optional(oc, py, rand_fr, monkeypatch):
-    """VERDICT r01 'next' item 8: when the SRS window tables do not fit (KEAKI_TEST_ALLOC_LIMIT makes every allocation above the limit
-    fail with KEAKI_ERR_OOM) the ABI reports OOM and the handle keeps working through the generic path; KZGSetup survives and says so;
+    """VERDICT r01 'next' item 8: when the SRS window tables do not fit (keaki_hip_debug_set_alloc_limit makes every allocation of the
+    context above the limit fail with KEAKI_ERR_OOM) the ABI reports OOM and the handle keeps working through the generic path; KZGSetup survives and says so;
     the wide GT table of B falls back to the 16-bit one (201 MB) and encapsulation stays bit-exact."""
     from keaki_amd.hip import KeakiHip, KeakiHipError
     from keaki_amd import keaki as K
@@ -788,19 +790,20 @@ def test_optional_memory_is_optional(oc, py, rand_fr, monkeypatch):
         exp = oc.msm_g1(pts, sc, threads=8)
         srs = h.srs_g1_upload(pts)
         h.msm_g1(srs, sc)                                               # workspaces exist before the limit is set
-        monkeypatch.setenv("KEAKI_TEST_ALLOC_LIMIT", str(1 << 20))     # the table of 5000 points is ~4 MB
+        h.debug_set_alloc_limit(1 << 20)                                # the table of 5000 points is ~4 MB
         with pytest.raises(KeakiHipError) as e:
             h.srs_g1_precompute(srs)
-        assert e.value.status == -3
+        assert e.value.status == -3 and "keaki_hip_debug_set_alloc_limit" in e.value.message
         assert np.array_equal(jac_to_aff(h.msm_g1(srs, sc)), exp)
-        monkeypatch.delenv("KEAKI_TEST_ALLOC_LIMIT")
+        h.debug_set_alloc_limit(0)
         assert h.srs_g1_precompute(srs) > 0
         assert np.array_equal(jac_to_aff(h.msm_g1(srs, sc)), exp)
         srs.free()
         # the host mirror: setup survives the failed table build
-        monkeypatch.setenv("KEAKI_TEST_ALLOC_LIMIT", str(1 << 20))
-        s = K.KZGSetup.from_powers(pts, h.g2_mul_batch(g2, mont(oc, [5]))[0])
-        monkeypatch.delenv("KEAKI_TEST_ALLOC_LIMIT")
+        dev = K.Device(0)
+        dev.hip().debug_set_alloc_limit(1 << 20)
+        s = K.KZGSetup.from_powers(pts, h.g2_mul_batch(g2, mont(oc, [5]))[0], device=dev)
+        dev.hip().debug_set_alloc_limit(0)
         assert s.has_window_tables() is False
         assert np.array_equal(K.commit(s, sc), exp)
         s.close()
@@ -821,9 +824,9 @@ def test_optional_memory_is_optional(oc, py, rand_fr, monkeypatch):
             a[:, 3] &= np.uint64((1 << 60) - 1)
             return a
         A, V, Rr = limbs(m), limbs(m), limbs(m)
-        monkeypatch.setenv("KEAKI_TEST_ALLOC_LIMIT", str(1 << 30))
+        h.debug_set_alloc_limit(1 << 30)
         ct, gt, key = h.encap_batch(com, tau_g2, A, V, Rr, 32)
-        monkeypatch.delenv("KEAKI_TEST_ALLOC_LIMIT")
+        h.debug_set_alloc_limit(0)
         idx = np.array([0, 1, 2, m - 1, 12345])
         ect, egt, ekey = oc.encap_batch(com, tau_g2, A[idx], V[idx], Rr[idx], 32, threads=8)
         assert np.array_equal(ct[idx], ect) and np.array_equal(gt[idx], egt) and np.array_equal(key[idx], ekey)

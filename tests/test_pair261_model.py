@@ -1,6 +1,6 @@
 """CPU checks of the pairing tower's round-2 restructuring against the big-int oracle (no GPU): the generated final-exponentiation
-PROGRAM (keaki_amd/csrc/pair261_constants.cuh: FE_PROG, an accumulator machine over slots) computes arkworks' final exponentiation;
-the Miller step list follows the NAF of 6z + 2; the written-out Fq6 / sparse-line / Fq4-squaring formulas of pair261.cuh (sums of
+PROGRAM (keaki_amd/csrc/pair261_constants.hip.h: FE_PROG, an accumulator machine over slots) computes arkworks' final exponentiation;
+the Miller step list follows the NAF of 6z + 2; the written-out Fq6 / sparse-line / Fq4-squaring formulas of pair261.hip.h (sums of
 up to three Fq2 products per output coefficient) equal the oracle's tower arithmetic; and the limb-level helpers (multiplication by
 9 + u on 29-bit limbs, column budgets of the six-product stream) hold their stated bounds."""
 import os
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _consts():
-    t = open(os.path.join(ROOT, "keaki_amd", "csrc", "pair261_constants.cuh")).read()
+    t = open(os.path.join(ROOT, "keaki_amd", "csrc", "pair261_constants.hip.h")).read()
     arr = lambda name: [int(x) for x in re.search(name + r"\[\d+\] = \{([^}]*)\}", t).group(1).split(",")]
     return arr("MILLER_STEPS"), arr("FE_PROG"), int(re.search(r"FE_EASY_OPS = (\d+)", t).group(1))
 
@@ -21,7 +21,7 @@ def _consts():
 def test_generated_header_is_current():
     import subprocess, sys
     out = subprocess.run([sys.executable, os.path.join(ROOT, "keaki_amd", "csrc", "gen_constants.py"), "--pair261"], stdout=subprocess.PIPE, text=True, check=True).stdout
-    assert out == open(os.path.join(ROOT, "keaki_amd", "csrc", "pair261_constants.cuh")).read()
+    assert out == open(os.path.join(ROOT, "keaki_amd", "csrc", "pair261_constants.hip.h")).read()
 
 
 def rand_f12(py, rng):
@@ -92,7 +92,7 @@ def test_written_out_tower_formulas(py):
 
 
 def test_limb_helpers_and_column_budget(py):
-    """xi_limbs (pair261.cuh) on 29-bit limbs: value (9 a -/+ o + K p), every intermediate below 2^32, output limbs <= 2^29 + 8;
+    """xi_limbs (pair261.hip.h) on 29-bit limbs: value (9 a -/+ o + K p), every intermediate below 2^32, output limbs <= 2^29 + 8;
     the six-product stream's column sums stay below 2^64 at the limb bound."""
     P, MASK = py.P, (1 << 29) - 1
     limbs = lambda v: [(v >> (29 * i)) & MASK for i in range(8)] + [v >> 232]
@@ -138,7 +138,7 @@ def test_limb_helpers_and_column_budget(py):
 
 
 def test_g2_lazy_mixed_addition_model():
-    """keaki_amd/csrc/models/model_g2_add29.py: the G2 mixed addition of xyzz29_g2.cuh operation by operation on Python integers, with
+    """keaki_amd/csrc/models/model_g2_add29.py: the G2 mixed addition of xyzz29_g2.hip.h operation by operation on Python integers, with
     assertions on every limb (no negative value, no overflow, stream budgets) and every stated bound, against plain Fq2 XYZZ arithmetic"""
     import importlib.util
     spec = importlib.util.spec_from_file_location("model_g2_add29", os.path.join(ROOT, "keaki_amd", "csrc", "models", "model_g2_add29.py"))

@@ -49,7 +49,7 @@ def c_class(t):
     stars = t.count("*")
     base = t.replace("*", "").strip()
     scalar = {"int32_t": "i32", "uint32_t": "u32", "size_t": "usize", "uint64_t": "u64", "uint8_t": "u8", "float": "f32", "void": "void", "char": "c_char",
-              "keaki_status": "i32", "keaki_hip_ctx": "ctx", "keaki_hip_srs_g1": "srs_g1", "keaki_hip_srs_g2": "srs_g2", "keaki_hip_fk_shard": "fk_shard"}[base]
+              "keaki_status": "i32", "keaki_hip_ctx": "ctx", "keaki_hip_srs_g1": "srs_g1", "keaki_hip_srs_g2": "srs_g2", "keaki_hip_fk_shard": "fk_shard", "int64_t": "i64", "keaki_hip_group": "group", "keaki_hip_group_srs_g1": "group_srs_g1"}[base]
     return stars, scalar
 
 
@@ -58,7 +58,8 @@ def rust_class(t):
     stars = len(re.findall(r"\*(?:const|mut)", t))
     base = re.sub(r"\*(?:const|mut)\s*", "", t).strip()
     scalar = {"i32": "i32", "u32": "u32", "usize": "usize", "u64": "u64", "u8": "u8", "f32": "f32", "c_void": "void", "c_char": "c_char", "keaki_status": "i32",
-              "keaki_hip_ctx": "ctx", "keaki_hip_srs_g1": "srs_g1", "keaki_hip_srs_g2": "srs_g2", "keaki_hip_fk_shard": "fk_shard", "()": "void"}[base]
+              "keaki_hip_ctx": "ctx", "keaki_hip_srs_g1": "srs_g1", "keaki_hip_srs_g2": "srs_g2", "keaki_hip_fk_shard": "fk_shard", "()": "void", "i64": "i64",
+              "keaki_hip_group": "group", "keaki_hip_group_srs_g1": "group_srs_g1"}[base]
     return stars, scalar
 
 
@@ -88,7 +89,7 @@ def test_glue_calls_only_declared_symbols():
     declared = set(rust_functions())
     for rel in ("keaki/src/hip.rs", "keaki/tests/hip_parity.rs", "keaki/keaki-hip.patch"):
         text = open(os.path.join(RUST, rel)).read()
-        used = set(re.findall(r"\b(keaki_hip_\w+)\b", text)) - {"keaki_hip_sys", "keaki_hip_ctx", "keaki_hip_srs_g1", "keaki_hip_srs_g2", "keaki_hip_fk_shard"}
+        used = set(re.findall(r"\b(keaki_hip_\w+)\b", text)) - {"keaki_hip_sys", "keaki_hip_ctx", "keaki_hip_srs_g1", "keaki_hip_srs_g2", "keaki_hip_fk_shard", "keaki_hip_group", "keaki_hip_group_srs_g1"}
         assert used <= declared, (rel, sorted(used - declared))
     glue = open(os.path.join(RUST, "keaki", "src", "hip.rs")).read()
     for sym in ("keaki_hip_msm_g1", "keaki_hip_kzg_open", "keaki_hip_kzg_verify", "keaki_hip_open_fk_poly", "keaki_hip_encap_batch", "keaki_hip_decap_batch",

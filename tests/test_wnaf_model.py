@@ -1,4 +1,4 @@
-"""The width-5 NAF recoding of keaki_amd/csrc/jac29.cuh::jac_scalar_mul_uniform_u29 (the sliding-window ladder of the wave-uniform FK23
+"""The width-5 NAF recoding of keaki_amd/csrc/jac29.hip.h::jac_scalar_mul_uniform_u29 (the sliding-window ladder of the wave-uniform FK23
 stages), restated word for word on Python integers with the device's 32-bit word arithmetic: the digits must represent the value, be odd
 and below 16 in magnitude, never sit closer than five positions, and fit the 129 positions the device reserves -- for random 127-bit
 magnitudes and for the corners (0, 1, 2^127 - 1, runs of ones that carry to the top). CPU only."""
