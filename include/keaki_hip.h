@@ -276,6 +276,9 @@ keaki_status keaki_hip_group_decap_batch(keaki_hip_group* g, const uint64_t* pro
 keaki_status keaki_hip_set_timing(keaki_hip_ctx* ctx, int32_t enabled);
 float keaki_hip_last_msm_bucket_ms(const keaki_hip_ctx* ctx);
 float keaki_hip_last_msm_total_ms(const keaki_hip_ctx* ctx);
+/* device time (ms) of the last keaki_hip_open_fk[_poly] call made while timing was enabled: out3 = [the 2d pointwise scalar-mults, the butterfly
+ * stages of the two size-d group transforms (the dominant kernel k_g1_fft_stage_map), the whole device pipeline]; < 0 when there was none */
+keaki_status keaki_hip_last_fk_ms(keaki_hip_ctx* ctx, float* out3);
 /* window size (bits) the last MSM used */
 int32_t keaki_hip_last_msm_window_bits(const keaki_hip_ctx* ctx);
 

@@ -123,6 +123,15 @@ void resolve_timing(keaki_hip_ctx* ctx) {
   }
   ctx->timing_pending = false;
 }
+void resolve_fk_timing(keaki_hip_ctx* ctx) {
+  if (!ctx->fk_timing_pending) return;
+  if (hipEventSynchronize(ctx->fk_ev[3]) == hipSuccess) {
+    (void)hipEventElapsedTime(&ctx->last_fk_ms[0], ctx->fk_ev[0], ctx->fk_ev[1]);
+    (void)hipEventElapsedTime(&ctx->last_fk_ms[1], ctx->fk_ev[1], ctx->fk_ev[2]);
+    (void)hipEventElapsedTime(&ctx->last_fk_ms[2], ctx->fk_ev[0], ctx->fk_ev[3]);
+  }
+  ctx->fk_timing_pending = false;
+}
 
 keaki_status upload(keaki_hip_ctx* ctx, DevBuf& b, const void* host, size_t bytes) {
   ST_TRY(reserve(ctx, b, bytes ? bytes : 16));
@@ -244,6 +253,7 @@ void keaki_hip_ctx_destroy(keaki_hip_ctx* ctx) {
   for (const BufClass& bc : all_bufs(ctx))
     if (bc.b->p) (void)hipFree(bc.b->p);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ctx->fk_ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -309,6 +319,17 @@ keaki_status keaki_hip_synchronize(keaki_hip_ctx* ctx) {
 keaki_status keaki_hip_set_timing(keaki_hip_ctx* ctx, int32_t enabled) {
   CTX_GUARD(ctx);
   ctx->timing = enabled != 0;
+  if (ctx->timing && !ctx->fk_ev[0])
+    for (auto& e : ctx->fk_ev) (void)hipEventCreate(&e);
+  return KEAKI_OK;
+}
+// device time of the last FK23 call (keaki_hip_open_fk[_poly]) with timing enabled, milliseconds: out3 = [the 2d pointwise scalar-mults,
+// the butterfly stages of the two size-d transforms (k_g1_fft_stage_map + the twist), the whole device pipeline]; < 0 if none
+keaki_status keaki_hip_last_fk_ms(keaki_hip_ctx* ctx, float* out3) {
+  CTX_GUARD(ctx);
+  if (!out3) return fail(ctx, KEAKI_ERR_BAD_ARG, "last_fk_ms: out3 is null");
+  resolve_fk_timing(ctx);
+  for (int i = 0; i < 3; i++) out3[i] = ctx->last_fk_ms[i];
   return KEAKI_OK;
 }
 float keaki_hip_last_msm_bucket_ms(const keaki_hip_ctx* ctx) { return ctx ? ctx->last_bucket_ms : -1.f; }

@@ -277,11 +277,16 @@ keaki_status open_fk_run(keaki_hip_ctx* ctx, const void* d_hat_s, u32 log2d, con
   const G1Jac* hs = (const G1Jac*)d_hat_s;
   G1Jac *e = (G1Jac*)d_work, *o = e + d;
   const Fr *tw = (const Fr*)d_tw2d, *twi = (const Fr*)d_tw2d_inv;
+  const bool timed = ctx->timing && ctx->fk_ev[0];
+  if (timed) (void)hipEventRecord(ctx->fk_ev[0], st);
   hipLaunchKernelGGL(k_fk_pointwise, dim3(cdiv(2 * d, 64)), dim3(64), 0, st, hs, hs + d, (const Fr*)d_hat_a, log2d, 0u, d, e, o);
+  if (timed) (void)hipEventRecord(ctx->fk_ev[1], st);
   for (u32 half = 1; 2 * half <= d; half <<= 1) stage_map(ctx, true, o, twi, d, half, 1, 0, 2 * (d / (2 * half)));
   hipLaunchKernelGGL(k_g1_mul_jac_strided, dim3(cdiv(d, 64)), dim3(64), 0, st, o, twi, 1u, 0u, d);
   for (u32 half = d / 2; half >= 1; half >>= 1) stage_map(ctx, false, o, tw, d, half, 1, 0, 2 * (d / (2 * half)));
+  if (timed) (void)hipEventRecord(ctx->fk_ev[2], st);
   hipLaunchKernelGGL(k_fk_finish, dim3(cdiv(d, 64)), dim3(64), 0, st, (const G1Jac*)e, (const G1Jac*)o, d, log2d, true, (G1Aff*)d_proofs_aff);
+  if (timed) { (void)hipEventRecord(ctx->fk_ev[3], st); ctx->fk_timing_pending = true; }
   return launch_check(ctx, "open_fk");
 }
 

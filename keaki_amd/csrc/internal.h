@@ -79,6 +79,10 @@ struct keaki_hip_ctx {
   float last_bucket_ms = -1.f, last_total_ms = -1.f;
   int last_c = 0;
   bool timing_pending = false;
+  // FK23 openings: [start | after the 2d pointwise products | after the two size-d group transforms | after the affine conversion]
+  hipEvent_t fk_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool fk_timing_pending = false;
+  float last_fk_ms[3] = {-1.f, -1.f, -1.f};      // pointwise products, butterfly stages (k_g1_fft_stage_map), whole device pipeline
 };
 
 namespace keaki_internal {

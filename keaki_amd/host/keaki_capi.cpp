@@ -50,6 +50,8 @@ void* keaki_host_rng_splitmix(uint64_t seed) { return new SplitMix64Rng(seed); }
 void* keaki_host_rng_callback(uint64_t (*fn)(void*), void* user) { auto* r = new CallbackRng(); r->fn = fn; r->user = user; return r; }
 void keaki_host_rng_free(void* rng) { delete (Rng*)rng; }
 void keaki_host_fr_rand(void* rng, uint64_t* out) { Fr r = fr_rand(*(Rng*)rng); memcpy(out, r.l, 32); }
+// n consecutive draws (what a loop of `Fr::rand(rng)` consumes), for harnesses that replay the stream of vec_encrypt
+void keaki_host_fr_rand_many(void* rng, size_t n, uint64_t* out) { for (size_t i = 0; i < n; i++) { Fr r = fr_rand(*(Rng*)rng); memcpy(out + 4 * i, r.l, 32); } }
 
 // Fr helpers for the harness (Fr::from(i64), arithmetic, polynomial evaluation)
 void keaki_host_fr_from_i64(int64_t v, uint64_t* out) { Fr r = Fr::from_i64(v); memcpy(out, r.l, 32); }
@@ -189,6 +191,10 @@ int keaki_host_setup_from_file(int device, const char* path, void** out, uint64_
 void keaki_host_setup_free(void* s) { delete (Setup*)s; }
 size_t keaki_host_setup_len(void* s) { return ((Setup*)s)->s.g1_pow().size(); }
 void keaki_host_setup_g1_pow(void* s, size_t i, uint64_t* out) { memcpy(out, ((Setup*)s)->s.g1_pow()[i].w.data(), 64); }
+void keaki_host_setup_g1_all(void* s, uint64_t* out) {   // all of g1_pow at once: len x 8 words
+  const auto& v = ((Setup*)s)->s.g1_pow();
+  for (size_t i = 0; i < v.size(); i++) memcpy(out + 8 * i, v[i].w.data(), 64);
+}
 void keaki_host_setup_tau_g2(void* s, uint64_t* out) { memcpy(out, ((Setup*)s)->s.tau_g2().w.data(), 128); }
 
 int keaki_host_commit(void* s, const uint64_t* coeffs, size_t n, uint64_t* out_g1, uint64_t* err_out) {

@@ -95,6 +95,12 @@ class Rng:
         _lib().keaki_host_fr_rand(self.h, _p(out))
         return out
 
+    def fr_rand_many(self, n: int) -> np.ndarray:
+        """n consecutive Fr::rand draws, (n, 4)"""
+        out = np.zeros((n, 4), np.uint64)
+        _lib().keaki_host_fr_rand_many(self.h, C.c_size_t(n), _p(out))
+        return out
+
     def __del__(self):
         try:
             _lib().keaki_host_rng_free(self.h)
@@ -268,8 +274,7 @@ class KZGSetup:
     def g1_pow(self) -> np.ndarray:
         n = _lib().keaki_host_setup_len(self.h)
         out = np.zeros((n, 8), np.uint64)
-        for i in range(n):
-            _lib().keaki_host_setup_g1_pow(self.h, C.c_size_t(i), _p(out[i]))
+        _lib().keaki_host_setup_g1_all(self.h, _p(out))
         return out
 
     g1_aff = g1_pow

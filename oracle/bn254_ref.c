@@ -636,3 +636,47 @@ void ref_fr_dot(const u64 *a, const u64 *b, size_t n, u64 *out) {
     for (size_t i = 0; i < n; i++) { u64 t[4]; fr_mul(t, a + 4 * i, b + 4 * i); mod_add(acc, acc, t, FR_MOD); }
     memcpy(out, acc, 32);
 }
+
+/* ------------------------------------------------------------------ scalar-field polynomial helpers (checkers of vec_commit / open / open_fk)
+ * ark-poly 0.4.2 (Cargo.lock of the reference; not vendored) Radix2EvaluationDomain::fft / ifft as keaki calls them at src/vec.rs:36-37
+ * and src/kzg.rs:182-200: out[j] = sum_i in[i] omega^(i j) over the size-n domain (n = 2^log2n, omega = its group_gen); ifft = the same
+ * with omega^-1, then times n^-1. In place; data and omega are Montgomery limbs. Plain radix-2 decimation in time. */
+void ref_fr_fft(u64 *data, int log2n, const u64 *omega) {
+    size_t n = (size_t)1 << log2n;
+    for (size_t i = 1, j = 0; i < n; i++) {                 /* bit reversal */
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { u64 t[4]; memcpy(t, data + 4 * i, 32); memcpy(data + 4 * i, data + 4 * j, 32); memcpy(data + 4 * j, t, 32); }
+    }
+    u64 one_m[4], one_c[4] = {1, 0, 0, 0};
+    fr_to_mont(one_m, one_c);
+    for (size_t len = 2; len <= n; len <<= 1) {
+        u64 w[4]; memcpy(w, omega, 32);
+        for (size_t k = len; k < n; k <<= 1) fr_mul(w, w, w);      /* omega^(n/len) */
+        for (size_t i = 0; i < n; i += len) {
+            u64 x[4]; memcpy(x, one_m, 32);
+            for (size_t j = 0; j < len / 2; j++) {
+                u64 *a = data + 4 * (i + j), *b = data + 4 * (i + j + len / 2), v[4], u[4];
+                memcpy(u, a, 32);
+                fr_mul(v, b, x);
+                mod_add(a, u, v, FR_MOD);
+                mod_sub(b, u, v, FR_MOD);
+                fr_mul(x, x, w);
+            }
+        }
+    }
+}
+void ref_fr_scale(u64 *data, size_t n, const u64 *k) { for (size_t i = 0; i < n; i++) fr_mul(data + 4 * i, data + 4 * i, k); }
+/* `open` of the reference, src/kzg.rs:109-120: value = p(point), quotient = (p(x) - value) / (x - point) by synthetic division
+ * (what DensePolynomial::div computes for a monic linear divisor). coeffs: n Fr low degree first; q_out: n - 1 Fr; all Montgomery. */
+void ref_fr_quotient(const u64 *coeffs, size_t n, const u64 *point, u64 *q_out, u64 *value_out) {
+    u64 carry[4] = {0, 0, 0, 0};
+    for (size_t k = n; k-- > 0;) {
+        u64 t[4];
+        fr_mul(t, carry, point);
+        mod_add(carry, t, coeffs + 4 * k, FR_MOD);
+        if (k >= 1) memcpy(q_out + 4 * (k - 1), carry, 32);
+    }
+    if (value_out) memcpy(value_out, carry, 32);
+}

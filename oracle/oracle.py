@@ -206,3 +206,22 @@ def make_digits(scalar_canonical_int: int, w: int) -> list:
     s = ints_to_limbs([scalar_canonical_int]); nd = (254 + w - 1) // w
     d = np.zeros(nd, np.int32)
     lib().ref_make_digits(_p(s), C.c_int(w), _p(d)); return d.tolist()
+
+
+def fr_fft(data, omega, scale=None) -> np.ndarray:
+    """ark-poly Radix2EvaluationDomain::fft over the domain generated by `omega` (pass omega^-1 and scale = n^-1 for ifft); Montgomery"""
+    a = _u64(data).reshape(-1, 4).copy(); n = a.shape[0]
+    log2n = n.bit_length() - 1
+    assert n == 1 << log2n
+    lib().ref_fr_fft(_p(a), C.c_int(log2n), _p(_u64(omega)))
+    if scale is not None:
+        lib().ref_fr_scale(_p(a), C.c_size_t(n), _p(_u64(scale)))
+    return a
+
+
+def fr_quotient(coeffs, point):
+    """src/kzg.rs:109-120 -> (quotient (n-1, 4), p(point) (4,)); Montgomery"""
+    c = _u64(coeffs).reshape(-1, 4); n = c.shape[0]
+    q = np.zeros((max(n - 1, 0), 4), np.uint64); v = np.zeros(4, np.uint64)
+    lib().ref_fr_quotient(_p(c), C.c_size_t(n), _p(_u64(point)), _p(q), _p(v))
+    return q, v

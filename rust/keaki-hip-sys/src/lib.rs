@@ -151,6 +151,7 @@ extern "C" {
     pub fn keaki_hip_last_msm_bucket_ms(ctx: *const keaki_hip_ctx) -> f32;
     pub fn keaki_hip_last_msm_total_ms(ctx: *const keaki_hip_ctx) -> f32;
     pub fn keaki_hip_last_msm_window_bits(ctx: *const keaki_hip_ctx) -> i32;
+    pub fn keaki_hip_last_fk_ms(ctx: *mut keaki_hip_ctx, out3: *mut f32) -> keaki_status;
 
     // ---- test hooks
     pub fn keaki_hip_g2_prepare(ctx: *mut keaki_hip_ctx, g2_aff: *const u64, lines_out: *mut u64, lines_out_bytes: usize) -> keaki_status;

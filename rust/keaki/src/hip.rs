@@ -28,10 +28,27 @@ const _: () = assert!(core::mem::size_of::<Fq>() == 32);
 pub const GT_BYTES: usize = 384;
 
 // ------------------------------------------------------------------------------------------------ device
-/// One GPU context for the process (`KEAKI_HIP_DEVICE` picks the ordinal, default 0). The C ABI serialises calls on a context
-/// internally, so sharing it between threads is sound.
+/// The GPU side of the process. One context (`KEAKI_HIP_DEVICE` picks the ordinal, default 0) -- or, with `KEAKI_HIP_DEVICES` set to a
+/// count (`4` = ordinals 0..3) or a list (`0,1,2,3`; an ordinal may repeat), a *device group*: `libkeaki_hip.so` then keeps one
+/// context and one host thread per entry, `commit` / `open` spread the MSM over the members by SRS range (every member holds its chunk
+/// of the SRS and that chunk's window tables; the 96-byte partial sums come back through host memory, no collective, no RCCL) and
+/// `encap_batch` / `decap_batch` split their items. `ctx` is member 0's context in that case (verify, open_fk, single calls).
+/// The C ABI serialises calls on a context / group internally, so sharing this between threads is sound.
 pub struct Device {
     ctx: *mut sys::keaki_hip_ctx,
+    group: *mut sys::keaki_hip_group,
+}
+
+/// batches below this many items stay on member 0 of a group
+const GROUP_MIN_ITEMS: usize = 1024;
+
+fn parse_devices(v: &str) -> Vec<i32> {
+    let v = v.trim();
+    if v.contains(',') {
+        v.split(',').filter_map(|t| t.trim().parse().ok()).collect()
+    } else {
+        (0..v.parse::<i32>().unwrap_or(1).max(1)).collect()
+    }
 }
 unsafe impl Send for Device {}
 unsafe impl Sync for Device {}
@@ -40,6 +57,20 @@ impl Device {
     pub fn global() -> &'static Device {
         static DEV: OnceLock<Device> = OnceLock::new();
         DEV.get_or_init(|| {
+            if let Ok(list) = std::env::var("KEAKI_HIP_DEVICES") {
+                let ordinals = parse_devices(&list);
+                if ordinals.len() > 1 {
+                    let mut group = core::ptr::null_mut();
+                    let st = unsafe { sys::keaki_hip_group_create(ordinals.as_ptr(), ordinals.len(), &mut group) };
+                    if st != sys::KEAKI_OK {
+                        let msg = unsafe { CStr::from_ptr(sys::keaki_hip_group_last_error(core::ptr::null())) }.to_string_lossy().into_owned();
+                        panic!("keaki `hip` feature: cannot create a device group on {ordinals:?}: {msg} (status {st})");
+                    }
+                    let dev = Device { ctx: unsafe { sys::keaki_hip_group_ctx(group, 0) }, group };
+                    dev.self_check();
+                    return dev;
+                }
+            }
             let ordinal = std::env::var("KEAKI_HIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0i32);
             let mut ctx = core::ptr::null_mut();
             let st = unsafe { sys::keaki_hip_ctx_create(ordinal, sys::KEAKI_HIP_STREAM_PRIVATE, &mut ctx) };
@@ -48,10 +79,22 @@ impl Device {
                 let msg = unsafe { CStr::from_ptr(sys::keaki_hip_last_error(core::ptr::null())) }.to_string_lossy().into_owned();
                 panic!("keaki `hip` feature: cannot create a context on device {ordinal}: {msg} (status {st})");
             }
-            let dev = Device { ctx };
+            let dev = Device { ctx, group: core::ptr::null_mut() };
             dev.self_check();
             dev
         })
+    }
+
+    /// number of GPUs (contexts) behind this device
+    pub fn members(&self) -> usize {
+        if self.group.is_null() { 1 } else { unsafe { sys::keaki_hip_group_size(self.group) } }
+    }
+
+    fn check_group(&self, st: sys::keaki_status, what: &str) {
+        if st != sys::KEAKI_OK {
+            let msg = unsafe { CStr::from_ptr(sys::keaki_hip_group_last_error(self.group)) }.to_string_lossy().into_owned();
+            panic!("libkeaki_hip: {what} failed with status {st}: {msg}");
+        }
     }
 
     fn check(&self, st: sys::keaki_status, what: &str) {
@@ -75,7 +118,11 @@ impl Device {
 
 impl Drop for Device {
     fn drop(&mut self) {
-        unsafe { sys::keaki_hip_ctx_destroy(self.ctx) }
+        if self.group.is_null() {
+            unsafe { sys::keaki_hip_ctx_destroy(self.ctx) }
+        } else {
+            unsafe { sys::keaki_hip_group_destroy(self.group) } // owns the members' contexts
+        }
     }
 }
 
@@ -132,26 +179,83 @@ fn g1_from_jac(w: &[u64; 12]) -> G1Projective {
 }
 
 // ------------------------------------------------------------------------------------------------ the SRS on the device
-/// `KZGSetup::g1_aff` resident in HBM (uploaded once, with the window tables of the fixed bases).
+/// `KZGSetup::g1_aff` resident in HBM (uploaded once, with the window tables of the fixed bases). On a device group: one chunk of the
+/// SRS (and its tables) per member for `commit` / `open` (`gsrs`), plus -- only once `open_fk` asks for it -- the whole SRS on member 0.
 pub struct HipSrs {
-    srs: *mut sys::keaki_hip_srs_g1,
+    whole: OnceLock<WholeSrs>,
+    gsrs: *mut sys::keaki_hip_group_srs_g1,
+    words: Vec<u64>, // kept only on a group (the lazy whole-SRS upload needs them); empty otherwise
     len: usize,
 }
+struct WholeSrs(*mut sys::keaki_hip_srs_g1);
+unsafe impl Send for WholeSrs {}
+unsafe impl Sync for WholeSrs {}
 unsafe impl Send for HipSrs {}
 unsafe impl Sync for HipSrs {}
+
+/// `ShardedCommit`: what `commit` / `open` run on when the process has a device group -- the in-process multi-GPU form of
+/// `msm_unchecked(&setup.g1_aff, p)` (src/kzg.rs:98). Exposed so that an application can also hold one explicitly.
+pub struct ShardedCommit<'a> {
+    srs: &'a HipSrs,
+}
+impl<'a> ShardedCommit<'a> {
+    /// `None` on a single-GPU device
+    pub fn new(srs: &'a HipSrs) -> Option<Self> {
+        if srs.gsrs.is_null() { None } else { Some(ShardedCommit { srs }) }
+    }
+    pub fn members(&self) -> usize {
+        Device::global().members()
+    }
+    /// Σ coeffs[i]·[τ^i]₁ over all members; bit-identical (affine) to the single-GPU result
+    pub fn commit(&self, coeffs: &[Fr]) -> G1Projective {
+        let dev = Device::global();
+        let mut out = [0u64; 12];
+        dev.check_group(unsafe { sys::keaki_hip_group_msm_g1(dev.group, self.srs.gsrs, fr_ptr(coeffs), coeffs.len(), out.as_mut_ptr()) }, "group_msm_g1");
+        g1_from_jac(&out)
+    }
+    /// quotient on member 0, MSM on all members
+    pub fn open(&self, coeffs: &[Fr], point: &Fr) -> G1Projective {
+        let dev = Device::global();
+        let mut out = [0u64; 12];
+        dev.check_group(
+            unsafe {
+                sys::keaki_hip_group_kzg_open(dev.group, self.srs.gsrs, fr_ptr(coeffs), coeffs.len(), fr_ptr(core::slice::from_ref(point)), out.as_mut_ptr(), core::ptr::null_mut())
+            },
+            "group_kzg_open",
+        );
+        g1_from_jac(&out)
+    }
+}
 
 impl HipSrs {
     pub fn upload(g1_aff: &[G1Affine]) -> Self {
         let dev = Device::global();
         let words: Vec<u64> = g1_aff.iter().flat_map(|p| g1_words(p)).collect();
-        let mut srs = core::ptr::null_mut();
-        dev.check(unsafe { sys::keaki_hip_srs_g1_upload(dev.ctx, words.as_ptr(), g1_aff.len(), &mut srs) }, "srs_g1_upload");
-        // optional memory: without room for the tables the handle keeps working through the generic MSM path
-        let st = unsafe { sys::keaki_hip_srs_g1_precompute(dev.ctx, srs, core::ptr::null_mut()) };
-        if st != sys::KEAKI_ERR_OOM {
-            dev.check(st, "srs_g1_precompute");
+        if !dev.group.is_null() {
+            let mut gsrs = core::ptr::null_mut();
+            dev.check_group(unsafe { sys::keaki_hip_group_srs_g1_upload(dev.group, words.as_ptr(), g1_aff.len(), 1, &mut gsrs) }, "group_srs_g1_upload");
+            return HipSrs { whole: OnceLock::new(), gsrs, words, len: g1_aff.len() };
         }
-        HipSrs { srs, len: g1_aff.len() }
+        let whole = OnceLock::new();
+        let _ = whole.set(WholeSrs(Self::upload_whole(&words, g1_aff.len(), true)));
+        HipSrs { whole, gsrs: core::ptr::null_mut(), words: Vec::new(), len: g1_aff.len() }
+    }
+    fn upload_whole(words: &[u64], n: usize, tables: bool) -> *mut sys::keaki_hip_srs_g1 {
+        let dev = Device::global();
+        let mut srs = core::ptr::null_mut();
+        dev.check(unsafe { sys::keaki_hip_srs_g1_upload(dev.ctx, words.as_ptr(), n, &mut srs) }, "srs_g1_upload");
+        if tables {
+            // optional memory: without room for the tables the handle keeps working through the generic MSM path
+            let st = unsafe { sys::keaki_hip_srs_g1_precompute(dev.ctx, srs, core::ptr::null_mut()) };
+            if st != sys::KEAKI_ERR_OOM {
+                dev.check(st, "srs_g1_precompute");
+            }
+        }
+        srs
+    }
+    /// the whole SRS on (member 0 of) the device: what `open_fk` reads. On a group it is uploaded on first use, without window tables.
+    fn srs(&self) -> *mut sys::keaki_hip_srs_g1 {
+        self.whole.get_or_init(|| WholeSrs(Self::upload_whole(&self.words, self.len, false))).0
     }
     pub fn len(&self) -> usize {
         self.len
@@ -162,7 +266,13 @@ impl HipSrs {
 }
 impl Drop for HipSrs {
     fn drop(&mut self) {
-        unsafe { sys::keaki_hip_srs_g1_free(Device::global().ctx, self.srs) }
+        let dev = Device::global();
+        if let Some(w) = self.whole.get() {
+            unsafe { sys::keaki_hip_srs_g1_free(dev.ctx, w.0) }
+        }
+        if !self.gsrs.is_null() {
+            unsafe { sys::keaki_hip_group_srs_g1_free(dev.group, self.gsrs) }
+        }
     }
 }
 
@@ -197,18 +307,24 @@ impl Eq for SetupCache {}
 
 // ------------------------------------------------------------------------------------------------ BN254 entry points
 pub fn commit(srs: &HipSrs, coeffs: &[Fr]) -> G1Projective {
+    if let Some(sharded) = ShardedCommit::new(srs) {
+        return sharded.commit(coeffs); // KEAKI_HIP_DEVICES > 1: every GPU of the process works on its range of the SRS
+    }
     let dev = Device::global();
     let mut out = [0u64; 12];
-    dev.check(unsafe { sys::keaki_hip_msm_g1(dev.ctx, srs.srs, fr_ptr(coeffs), coeffs.len(), out.as_mut_ptr()) }, "msm_g1");
+    dev.check(unsafe { sys::keaki_hip_msm_g1(dev.ctx, srs.srs(), fr_ptr(coeffs), coeffs.len(), out.as_mut_ptr()) }, "msm_g1");
     g1_from_jac(&out)
 }
 
 /// `open`: quotient and its commitment in one device call. `coeffs` = the polynomial with trailing zeros trimmed (DensePolynomial).
 pub fn open(srs: &HipSrs, coeffs: &[Fr], point: &Fr) -> G1Projective {
+    if let Some(sharded) = ShardedCommit::new(srs) {
+        return sharded.open(coeffs, point);
+    }
     let dev = Device::global();
     let mut out = [0u64; 12];
     dev.check(
-        unsafe { sys::keaki_hip_kzg_open(dev.ctx, srs.srs, fr_ptr(coeffs), coeffs.len(), fr_ptr(core::slice::from_ref(point)), out.as_mut_ptr(), core::ptr::null_mut()) },
+        unsafe { sys::keaki_hip_kzg_open(dev.ctx, srs.srs(), fr_ptr(coeffs), coeffs.len(), fr_ptr(core::slice::from_ref(point)), out.as_mut_ptr(), core::ptr::null_mut()) },
         "kzg_open",
     );
     g1_from_jac(&out)
@@ -237,7 +353,7 @@ pub fn open_fk(srs: &HipSrs, coeffs: &[Fr], omega_2d: &Fr, omega_2d_inv: &Fr, in
     dev.check(
         unsafe {
             sys::keaki_hip_open_fk_poly(
-                dev.ctx, srs.srs, d.trailing_zeros(), fr_ptr(coeffs), fr_ptr(core::slice::from_ref(omega_2d)),
+                dev.ctx, srs.srs(), d.trailing_zeros(), fr_ptr(coeffs), fr_ptr(core::slice::from_ref(omega_2d)),
                 fr_ptr(core::slice::from_ref(omega_2d_inv)), fr_ptr(core::slice::from_ref(inv_2d)), out.as_mut_ptr(),
             )
         },
@@ -260,6 +376,7 @@ pub trait FkExchange {
 /// device buffers of `buffer_bytes()` each, owned by the caller (they are what the collectives move).
 pub struct ShardedOpenFk {
     fk: *mut sys::keaki_hip_fk_shard,
+    _srs: Arc<HipSrs>, // the C handle keeps a raw pointer to the SRS and reads it lazily (setup step 0 runs inside the first open)
     sizes: [usize; 4],
     d: usize,
     prepared: bool,
@@ -268,14 +385,14 @@ unsafe impl Send for ShardedOpenFk {}
 
 impl ShardedOpenFk {
     /// `d`: a power of two with `world^2 <= d <= srs.len()`; `world` a power of two >= 2; roots as for `open_fk`
-    pub fn new(srs: &HipSrs, d: usize, rank: u32, world: u32, omega_2d: &Fr, omega_2d_inv: &Fr, inv_2d: &Fr) -> Self {
+    pub fn new(srs: &Arc<HipSrs>, d: usize, rank: u32, world: u32, omega_2d: &Fr, omega_2d_inv: &Fr, inv_2d: &Fr) -> Self {
         let dev = Device::global();
         assert!(d.is_power_of_two() && d <= srs.len());
         let mut fk = core::ptr::null_mut();
         dev.check(
             unsafe {
                 sys::keaki_hip_fk_shard_create(
-                    dev.ctx, srs.srs, d.trailing_zeros(), rank, world, fr_ptr(core::slice::from_ref(omega_2d)),
+                    dev.ctx, srs.srs(), d.trailing_zeros(), rank, world, fr_ptr(core::slice::from_ref(omega_2d)),
                     fr_ptr(core::slice::from_ref(omega_2d_inv)), fr_ptr(core::slice::from_ref(inv_2d)), &mut fk,
                 )
             },
@@ -283,7 +400,7 @@ impl ShardedOpenFk {
         );
         let mut sizes = [0usize; 4];
         dev.check(unsafe { sys::keaki_hip_fk_shard_sizes(fk, sizes.as_mut_ptr()) }, "fk_shard_sizes");
-        ShardedOpenFk { fk, sizes, d, prepared: false }
+        ShardedOpenFk { fk, _srs: srs.clone(), sizes, d, prepared: false }
     }
     pub fn buffer_bytes(&self) -> usize {
         self.sizes[0]
@@ -337,17 +454,20 @@ pub fn encap_batch(commitment: &G1Projective, tau_g2: &G2Projective, points: &[F
     let mut ct = vec![0u64; 16 * n];
     let mut gt = vec![0u8; if msg_len == 0 { GT_BYTES * n } else { 0 }];
     let mut key = vec![0u8; n * msg_len];
-    dev.check(
-        unsafe {
-            sys::keaki_hip_encap_batch(
-                dev.ctx, c.as_ptr(), t.as_ptr(), fr_ptr(points), fr_ptr(values), fr_ptr(rs), n, ct.as_mut_ptr(),
-                if msg_len == 0 { gt.as_mut_ptr() } else { core::ptr::null_mut() },
-                if msg_len == 0 { core::ptr::null_mut() } else { key.as_mut_ptr() },
-                msg_len,
-            )
-        },
-        "encap_batch",
-    );
+    let gt_ptr = if msg_len == 0 { gt.as_mut_ptr() } else { core::ptr::null_mut() };
+    let key_ptr = if msg_len == 0 { core::ptr::null_mut() } else { key.as_mut_ptr() };
+    if !dev.group.is_null() && n >= GROUP_MIN_ITEMS {
+        // the items of src/vec.rs:63-66 split by range over the GPUs of the process; every member writes its slice of ct / key in place
+        dev.check_group(
+            unsafe { sys::keaki_hip_group_encap_batch(dev.group, c.as_ptr(), t.as_ptr(), fr_ptr(points), fr_ptr(values), fr_ptr(rs), n, ct.as_mut_ptr(), gt_ptr, key_ptr, msg_len) },
+            "group_encap_batch",
+        );
+    } else {
+        dev.check(
+            unsafe { sys::keaki_hip_encap_batch(dev.ctx, c.as_ptr(), t.as_ptr(), fr_ptr(points), fr_ptr(values), fr_ptr(rs), n, ct.as_mut_ptr(), gt_ptr, key_ptr, msg_len) },
+            "encap_batch",
+        );
+    }
     (ct.chunks_exact(16).map(|w| g2_from_words(w).into()).collect(), key)
 }
 
@@ -361,10 +481,17 @@ pub fn decap_batch(proofs: &[G1Projective], cts: &[G2Projective], msg_len: usize
     let p: Vec<u64> = G1Projective::normalize_batch(&proofs[..n]).iter().flat_map(|a| g1_words(a)).collect();
     let q: Vec<u64> = G2Projective::normalize_batch(cts).iter().flat_map(|a| g2_words(a)).collect();
     let mut key = vec![0u8; n * msg_len];
-    dev.check(
-        unsafe { sys::keaki_hip_decap_batch(dev.ctx, p.as_ptr(), q.as_ptr(), n, core::ptr::null_mut(), key.as_mut_ptr(), msg_len) },
-        "decap_batch",
-    );
+    if !dev.group.is_null() && n >= GROUP_MIN_ITEMS {
+        dev.check_group(
+            unsafe { sys::keaki_hip_group_decap_batch(dev.group, p.as_ptr(), q.as_ptr(), n, core::ptr::null_mut(), key.as_mut_ptr(), msg_len) },
+            "group_decap_batch",
+        );
+    } else {
+        dev.check(
+            unsafe { sys::keaki_hip_decap_batch(dev.ctx, p.as_ptr(), q.as_ptr(), n, core::ptr::null_mut(), key.as_mut_ptr(), msg_len) },
+            "decap_batch",
+        );
+    }
     key
 }
 
@@ -419,7 +546,8 @@ pub fn same_vec<A: 'static, B: 'static>(v: Vec<A>) -> Vec<B> {
     unsafe { Vec::from_raw_parts(v.as_mut_ptr() as *mut B, v.len(), v.capacity()) }
 }
 
-/// The device copy of a setup's SRS (uploaded on first use).
-pub fn srs_of<'a, E: Pairing>(cache: &'a SetupCache, g1_aff: &[E::G1Affine]) -> &'a HipSrs {
+/// The device copy of a setup's SRS (uploaded on first use). An `Arc`: `ShardedOpenFk::new` keeps a clone, because the C handle behind it
+/// reads the SRS lazily.
+pub fn srs_of<'a, E: Pairing>(cache: &'a SetupCache, g1_aff: &[E::G1Affine]) -> &'a Arc<HipSrs> {
     cache.get(same_slice::<E::G1Affine, G1Affine>(g1_aff))
 }

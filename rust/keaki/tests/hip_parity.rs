@@ -148,6 +148,34 @@ fn msm_commit_open_verify_match_arkworks() {
     }
 }
 
+/// In-process multi-GPU (`KEAKI_HIP_DEVICES=4`, or `0,0,0` to put three contexts on one GPU): `commit` / `open` are then the sharded
+/// MSM of `hip::ShardedCommit` -- every member sums its range of the SRS, the partials are added -- and must still equal arkworks.
+/// Run the whole file once more with the variable set: every test above then goes through the device group as well.
+#[test]
+fn sharded_commit_over_a_device_group_matches_arkworks() {
+    let rng = &mut test_rng();
+    let n = 1usize << 12;
+    let setup = KZGSetup::<Bn254>::setup(Fr::rand(rng), n);
+    let srs = hip::HipSrs::upload(setup.g1_aff());
+    let Some(sharded) = hip::ShardedCommit::new(&srs) else {
+        eprintln!("single-GPU device (KEAKI_HIP_DEVICES unset): sharded commit not exercised");
+        return;
+    };
+    assert!(sharded.members() > 1);
+    for &len in &[0usize, 1, 5, n / 3, n - 1, n] {
+        // shorter than the SRS: members whose range lies beyond the polynomial contribute the identity
+        let coeffs: Vec<Fr> = (0..len).map(|_| Fr::rand(rng)).collect();
+        let cpu = <G1Projective as VariableBaseMSM>::msm_unchecked(&setup.g1_aff()[..len], &coeffs);
+        assert_eq!(sharded.commit(&coeffs).into_affine(), cpu.into_affine(), "sharded commit len={len}");
+    }
+    let p = DensePolynomial::from_coefficients_vec((0..n).map(|_| Fr::rand(rng)).collect());
+    let z = Fr::rand(rng);
+    std::env::set_var("KEAKI_HIP", "off");
+    let proof_cpu = open(&setup, &p, &z).unwrap();
+    std::env::remove_var("KEAKI_HIP");
+    assert_eq!(sharded.open(&p.coeffs, &z).into_affine(), proof_cpu.into_affine(), "sharded open");
+}
+
 #[test]
 fn kem_vector_of_the_oracle_arkworks_and_gpu() {
     let tau = fr(KEM_TAU);

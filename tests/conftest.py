@@ -55,11 +55,11 @@ def multirank_runs(request, tmp_path_factory):
                              "--kem-log2n", "10", "--steps", "3", "--warmup", "1", "--cpu-log2n", "14", "--strong-log2n", "19"], 1500)
     out["bench"] = {"rc": rc, "log": log}
     # (3) laconic_ot.py at world 2
-    rc, log = _run(launch + ["--nproc-per-node", "2", "--master-port", str(port + 2), "laconic_ot.py", "--gpus", "2", "--backend", "gloo", "--log2n", "9",
+    rc, log = _run(launch + ["--nproc-per-node", "2", "--master-port", str(port + 2), "laconic_ot.py", "--gpus", "2", "--backend", "gloo", "--log2n", "15",
                              "--check-single"], 1500)
     out["laconic"] = {"rc": rc, "log": log}
     # (3b) four ranks (two rank bits in the sharded FK23), and three (not a power of two: the openings fall back to replicated)
-    rc, log = _run(launch + ["--nproc-per-node", "4", "--master-port", str(port + 5), "laconic_ot.py", "--gpus", "4", "--backend", "gloo", "--log2n", "9",
+    rc, log = _run(launch + ["--nproc-per-node", "4", "--master-port", str(port + 5), "laconic_ot.py", "--gpus", "4", "--backend", "gloo", "--log2n", "15",
                              "--check-single"], 1500)
     out["laconic4"] = {"rc": rc, "log": log}
     rc, log = _run(launch + ["--nproc-per-node", "3", "--master-port", str(port + 6), "laconic_ot.py", "--gpus", "3", "--backend", "gloo", "--log2n", "8",

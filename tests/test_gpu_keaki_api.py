@@ -342,23 +342,7 @@ def test_new_from_file_ptau_fixture(K, oc, py, tmp_path):
     assert e.value.kind == "FileError"
 
 
-@pytest.mark.parametrize("log2d", [9, 12, 15])
-def test_open_fk_large_domains_vs_per_point_open(K, log2d):
-    """FK23 at sizes where every branch of the stage kernels is taken (stages with at least 64 blocks share one twiddle per wave, the last
-    six do not; trivial twiddles skip the ladder): proofs at the corners and at 20 random positions equal `open` at that root of unity,
-    and one of them verifies (src/kzg.rs:470-505 at scale)."""
-    d = 1 << log2d
-    rng = K.Rng(3300 + log2d)
-    s = K.KZGSetup.setup(rng.fr_rand(), d)
-    p = np.stack([rng.fr_rand() for _ in range(d)])
-    p[d // 3] = 0
-    proofs = K.open_fk(s, p, d)
-    el = K.domain_elements(d)
-    pick = np.random.default_rng(log2d).integers(0, d, 20).tolist() + [0, 1, d // 2 - 1, d // 2, d - 2, d - 1]
-    for i in pick:
-        assert np.array_equal(proofs[i], K.open(s, p, el[i])), i
-    i = pick[0]
-    assert K.verify(s, K.commit(s, p), el[i], K.poly_evaluate(p, el[i]), proofs[i])
+# FK23 at d = 2^9 .. 2^18 against the ORACLE's per-point opening: tests/test_gpu_config5.py::test_open_fk_large_domains_vs_oracle
 
 
 def test_open_fk_zero_and_sparse_polynomials(K):

@@ -64,7 +64,8 @@ def test_world2_laconic_ot(multirank_runs):
     assert j["n_gpus"] == 2 and j["ranks_seen"] == 2
     assert j["all_messages_recovered"] is True and j["sharded_equals_single_process"] is True
     # the FK23 openings were computed by the sharded pipeline (one all-to-all at setup; two smaller ones + one all-gather per call)
-    d = 1024
+    assert j["n_choices"] == 1 << 15                     # 2^15 receiver bits => domain d = 2^16: 2^14 points per rank and layout
+    d = 1 << 16
     assert j["fk_sharded"] is True and j["fk_exchange_bytes_sent_per_rank"] == 2 * d // 4 * 96 + 2 * (d // 4 * 96) + d // 2 * 64
 
 
@@ -77,6 +78,7 @@ def test_world4_and_world3_laconic_ot(multirank_runs):
         assert j["n_gpus"] == world and j["ranks_seen"] == world
         assert j["all_messages_recovered"] is True and j["sharded_equals_single_process"] is True
         assert j["fk_sharded"] is sharded
+        assert j["n_choices"] == (1 << 15 if world == 4 else 1 << 8)
 
 
 def test_world1_under_torchrun(multirank_runs):

@@ -234,3 +234,36 @@ def test_kzg_open_fk_restatement(py):
     assert fk == [py.kzg_open(g1p, p, z) for z in pts]
     com = py.kzg_commit(g1p, p)
     assert py.kzg_verify(tau_g2, com, pts[1], py.poly_eval(p, pts[1]), fk[1])
+
+
+def test_oracle_fr_fft_and_quotient_vs_bigint(oc, py):
+    """The scalar-field helpers the full-size GPU tests lean on (oracle.fr_fft = ark-poly's domain.fft / ifft as keaki calls it at
+    src/vec.rs:36-37; oracle.fr_quotient = the division inside `open`, src/kzg.rs:109-120) against the big-int oracle: naive DFT,
+    round trip, Horner evaluation, q (x - z) + v == p; and FK23's own statement (src/kzg.rs:157-203, restated in bn254_py.kzg_open_fk)
+    equals per-point openings built from fr_quotient."""
+    R = py.R
+    m = lambda xs: oc.fr_to_mont(oc.ints_to_limbs(xs))
+    ints = lambda a: oc.limbs_to_ints(oc.fr_from_mont(a))
+    for n in (1, 2, 8, 64):
+        w = py.fr_root_of_unity(n)
+        vals = [(i * i * 7919 + 3) % R for i in range(n)]
+        out = ints(oc.fr_fft(m(vals), m([w])[0]))
+        assert out == [sum(vals[i] * pow(w, i * j, R) for i in range(n)) % R for j in range(n)]
+        back = ints(oc.fr_fft(m(out), m([pow(w, -1, R)])[0], m([pow(n, -1, R)])[0]))
+        assert back == vals
+    coeffs = [(i * 31337 + 5) % R for i in range(33)]
+    for z in (0, 1, 123456789, R - 1):
+        q, v = oc.fr_quotient(m(coeffs), m([z])[0])
+        assert ints(v)[0] == py.poly_eval(coeffs, z)
+        assert ints(q) == py.poly_quotient(coeffs, z)
+    q, v = oc.fr_quotient(m([5]), m([9])[0])
+    assert q.shape == (0, 4) and ints(v) == [5]
+    # FK23 (literal restatement of the reference) == openings from fr_quotient + the oracle's MSM, d = 8
+    g1p, _ = py.kzg_setup(777, 8)
+    p = [3, 1, 4, 1, 5, 9, 2, 6]
+    fk = py.kzg_open_fk(g1p, p)
+    srs = oc.g1_from_ints(g1p)
+    w = py.fr_root_of_unity(8)
+    for i in range(8):
+        q, _ = oc.fr_quotient(m(p), m([pow(w, i, R)])[0])
+        assert oc.g1_to_ints(oc.msm_g1(srs[:7], q)[None, :])[0] == fk[i]

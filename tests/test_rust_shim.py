@@ -127,4 +127,19 @@ def test_parity_constants_are_the_golden_vectors():
     assert join("GT_OF_GENERATORS_HEX") == g["pairing"][0]["gt_hex"] and g["pairing"][0]["a"] == "1" and g["pairing"][0]["b"] == "1"
     assert join("KEM_GT_HEX") == g["kem"]["gt_hex"]
     assert g["kem"]["key_hex"] in t and g["kem"]["r"] in t and g["kem"]["tau"] in t
+    # every constant of the file comes from the golden vectors, not only the two byte strings
+    const = lambda name: re.search(r"const %s: &str = \"(\d+)\";" % name, t).group(1)
+    assert const("KEM_TAU") == g["kem"]["tau"] and const("KEM_R") == g["kem"]["r"]
+    assert const("KEM_POINT") == g["kem"]["point"] and const("KEM_VALUE") == g["kem"]["value"]
+    com = re.search(r'KEM_COM: \[&str; 2\] = \["(\d+)", "(\d+)"\]', t).groups()
+    assert list(com) == [str(v) for v in g["kem"]["commitment"]]
+    assert re.search(r'KEM_KEY_HEX: &str = "%s"' % g["kem"]["key_hex"], t)
+    # the device group is exercised by the parity file and reachable from the glue
+    assert "sharded_commit_over_a_device_group_matches_arkworks" in t and "hip::ShardedCommit::new" in t
+    glue = open(os.path.join(RUST, "keaki", "src", "hip.rs")).read()
+    for sym in ("keaki_hip_group_create", "keaki_hip_group_srs_g1_upload", "keaki_hip_group_msm_g1", "keaki_hip_group_kzg_open",
+                "keaki_hip_group_encap_batch", "keaki_hip_group_decap_batch", "keaki_hip_group_destroy", "KEAKI_HIP_DEVICES"):
+        assert sym in glue, sym
+    # the sharded FK handle keeps the SRS alive
+    assert re.search(r"_srs: Arc<HipSrs>", glue) and "srs: &Arc<HipSrs>" in glue
     assert "e109983de6d3ff0d8d4e1236dd4d91d2a313d7e7a22e3a15062b6759ad70331c" == g["pairing"][0]["gt_sha256"]
