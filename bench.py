@@ -440,8 +440,9 @@ def main():
                            "achieved": fk_algo / (stages_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fk_algo / (stages_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "note": "integer-issue bound like every kernel of the path: d log2 d butterfly scalar-mults of ~129 doublings + 43..66 additions each"},
               "alu": {"scalar_mults_per_s_in_stages": d * lg / (stages_ms * 1e-3), "simd_cycles_per_butterfly": stages_ms * 1e-3 * 2.4e9 / (d * lg / 64.0 / 1024.0),
-                      "note": "SIMD cycles one wave spends per butterfly (scalar-mult + add + sub) at 2.4 GHz, 1024 SIMDs: compare 129 x 6.6 K (doubling) + 43 x 13 K "
-                              "(addition) / 64 lanes per wave = the ladder at the product stream's issue rate (DESIGN 4.2b)"}}
+                      "note": "SIMD cycles one wave (64 butterflies) spends per butterfly stage step = scalar-mult + add + sub, at 2.4 GHz on 1024 SIMDs. The ladder at the "
+                              "product stream's issue rate: 129 doublings x 6.6 K + 43 (wave-uniform sliding window) .. 66 (fixed windows) additions x 13 K = "
+                              "1.41 .. 1.71 M cycles (DESIGN 4.2b)"}}
         fk_check = (fsrs, coeffs, proofs, om)
     # ---- Laconic OT, one GPU: the three phases the reference's test prints (tests/laconic_ot.rs:143-188) at 2^--laconic-log2n bits --------
     laconic = None
