@@ -198,6 +198,7 @@ void tune_from_env(Tuning& t) {
   if (geti("KEAKI_P2_SMALL", v)) t.p2_small = v != 0;
   if (geti("KEAKI_ACC_U29", v)) t.acc_u29 = v != 0;
   if (geti("KEAKI_ACC_U29_G2", v)) t.acc_u29_g2 = v != 0;
+  if (geti("KEAKI_ACC_NT", v)) t.acc_nt = v != 0;
   if (geti("KEAKI_FK_UNIFORM", v)) t.fk_uniform = v != 0;
   if (geti("KEAKI_FB_OCC1", v)) t.fb_occ1 = v != 0;
   if (geti("KEAKI_GT_WB_B", v)) t.gt_wb_b = (int)v;
@@ -283,6 +284,7 @@ keaki_status keaki_hip_ctx_set_option(keaki_hip_ctx* ctx, const char* name, int6
   else if (k == "p2_small") t.p2_small = value != 0;
   else if (k == "acc_u29") t.acc_u29 = value != 0;
   else if (k == "acc_u29_g2") t.acc_u29_g2 = value != 0;
+  else if (k == "acc_nt") t.acc_nt = value != 0;
   else if (k == "fk_uniform") t.fk_uniform = value != 0;
   else if (k == "fb_occ1") t.fb_occ1 = value != 0;
   else if (k == "gt_wb_b") {

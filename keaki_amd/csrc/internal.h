@@ -32,6 +32,7 @@ struct Tuning {
   bool p2_small = false;         // KEAKI_P2_SMALL / "p2_small"
   bool acc_u29 = true;           // KEAKI_ACC_U29 / "acc_u29": G1 bucket kernel in the 29-bit lazy limbs (A/B switch for profiling)
   bool acc_u29_g2 = true;        // KEAKI_ACC_U29_G2 / "acc_u29_g2"
+  bool acc_nt = false;           // KEAKI_ACC_NT / "acc_nt": non-temporal loads of the table rows in the G1 bucket kernel
   bool fk_uniform = true;        // KEAKI_FK_UNIFORM / "fk_uniform": sliding-window ladder in the wave-uniform FK23 stages
   bool fb_occ1 = false;          // KEAKI_FB_OCC1 / "fb_occ1": one wave per SIMD for the G2 fixed-base kernel at any batch size
   int gt_wb_b = 0;               // KEAKI_GT_WB_B / "gt_wb_b": window bits of the table of e(g1, g2), 0 = automatic (20 / 16)

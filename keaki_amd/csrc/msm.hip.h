@@ -556,6 +556,25 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const Aff<F>* __restrict
 // 2^261 form is the same integer shifted by 5 bits); buckets are written back saturated and canonical.
 // Value bounds (multiples of p; measured maxima in brackets): X < 9.4 [8.7], Y < 1.6 [1.4], ZZ, ZZZ < 1.4; P = U2 - X + 16p < 17.4;
 // R = S2 - Y + 4p < 5.3 [4.9]; every product of those stays < 3p.
+// One 64-byte table row. A plain load makes the vector L1 fill the whole 128-byte line the row sits in: two 64-byte requests to L2 per
+// row, the second one for a neighbour row nobody wants (profiles/r03_msm_2p24_l2_counters.json: 404.9 M L1->L2 read requests for 201.3 M
+// rows, 1.48 fabric requests per row). NT = 1: non-temporal loads (the rows are used exactly once).
+typedef u32 v4u_t __attribute__((ext_vector_type(4)));
+template <int NT>
+KDEV Aff<Fq> msm_load_row(const Aff<Fq>* __restrict__ p) {
+  if constexpr (NT == 0) {
+    return *p;
+  } else {
+    const v4u_t* s = reinterpret_cast<const v4u_t*>(p);
+    const v4u_t w0 = __builtin_nontemporal_load(s), w1 = __builtin_nontemporal_load(s + 1), w2 = __builtin_nontemporal_load(s + 2),
+                w3 = __builtin_nontemporal_load(s + 3);
+    Aff<Fq> q;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { q.x.l[i] = w0[i]; q.x.l[4 + i] = w1[i]; q.y.l[i] = w2[i]; q.y.l[4 + i] = w3[i]; }
+    return q;
+  }
+}
+template <int NT>
 static __global__ void __launch_bounds__(256) k_msm_accumulate_g1_u29(const Aff<Fq>* __restrict__ points, const u32* __restrict__ sorted,
                                                                       const u32* __restrict__ offsets, const u32* __restrict__ counts,
                                                                       const u32* __restrict__ perm, u32 nbuckets_total, Xyzz<Fq>* __restrict__ buckets) {
@@ -568,7 +587,7 @@ static __global__ void __launch_bounds__(256) k_msm_accumulate_g1_u29(const Aff<
   bool empty = true;
   for (u32 k = 0; k < cnt; k++) {
     u32 e = sorted[start + k];
-    Aff<Fq> q = points[e & 0x7FFFFFFFu];
+    Aff<Fq> q = msm_load_row<NT>(points + (e & 0x7FFFFFFFu));
     if (aff_is_inf(q)) continue;
     q.y = f_cneg(q.y, (e >> 31) != 0);
     const U29 X2 = u29_from_sat_shift5(q.x.l), Y2 = u29_from_sat_shift5(q.y.l);

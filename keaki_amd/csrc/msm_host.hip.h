@@ -130,8 +130,11 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   bool u29 = false;
   if constexpr (std::is_same<F, Fq>::value) {
     u29 = ctx->tune.acc_u29;                                 // A/B switch for profiling
-    if (u29)
-      hipLaunchKernelGGL(k_msm_accumulate_g1_u29, dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
+    if (u29 && ctx->tune.acc_nt)
+      hipLaunchKernelGGL(k_msm_accumulate_g1_u29<1>, dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
+                         (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
+    else if (u29)
+      hipLaunchKernelGGL(k_msm_accumulate_g1_u29<0>, dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
                          (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
   }
   if constexpr (std::is_same<F, Fq2>::value) {
