@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--cpu-log2n", type=int, default=20, help="log2 of the CPU-baseline sample size")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (one rank per GPU). gloo: several ranks may share one GPU (how the world-2 path is exercised on a 1-GPU box)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="initialise the process group and run every exchange through it even with ONE rank: executes the RCCL path "
+                         "(init, all-gather on the kernels' stream, barrier) on a single-GPU box")
     ap.add_argument("--strong", action="store_true", help="also run BASELINE config 4 (2^--strong-log2n points in TOTAL, split over the ranks) at N = 1")
     ap.add_argument("--strong-log2n", type=int, default=26)
     ap.add_argument("--no-extras", action="store_true", help="skip value_no_tables / value_incl_scalar_h2d / strong / fk / laconic")
@@ -154,13 +157,15 @@ def main():
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    use_dist = world > 1 or args.force_collectives
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-    shard = Shard(rank, world, dist if world > 1 else None)
+    shard = Shard(rank, world, dist if use_dist else None, force_collectives=args.force_collectives)
 
     # ONE stream for torch, RCCL and keaki: a real (non-default) stream, made current for the whole run
     stream = torch.cuda.Stream(dev)
@@ -169,12 +174,12 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
     def max_over_ranks(x):
-        if world == 1:
+        if not use_dist:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -224,7 +229,7 @@ def main():
 
         def last_result_affine(self):
             torch.cuda.synchronize(dev)
-            out = self.sm.out if world > 1 else self.sm.part
+            out = self.sm.out if use_dist else self.sm.part
             return jac_to_affine_words(out.cpu().numpy().view(np.uint64))
 
         def check_last(self, oc):
@@ -301,7 +306,7 @@ def main():
 
     # ---- BASELINE config 4: 2^26 points in TOTAL, split over the ranks (strong scaling) ----------------------------------------------
     strong = None
-    if (world > 1 or args.strong) and not args.no_extras:
+    if (use_dist or args.strong) and not args.no_extras:
         per = (1 << args.strong_log2n) // world
         lg = per.bit_length() - 1
         if (1 << lg) == per:
@@ -326,7 +331,7 @@ def main():
 
     # time of the exchange step alone (all-gather of the partials + EC adds), N > 1
     exchange_ms = None
-    if world > 1:
+    if use_dist:
         inst.sm.combine()
         sync_all()
         t0 = time.perf_counter()
@@ -553,7 +558,7 @@ def main():
         "config": {"workload": "2^%d-point BN254 G1 Pippenger MSM per GPU, SRS + scalars resident in HBM%s" % (
             args.log2n, "" if world == 1 else "; %d chunks, %s all-gather of 96-B partial sums + %d EC adds" % (world, "RCCL" if args.backend == "nccl" else "gloo", world - 1)),
             "points_per_gpu": n, "window_bits": stats["window_bits"], "windows": windows, "setup_s": round(inst.setup_s, 2),
-            "srs_window_tables_bytes": inst.table_bytes, "ranks_seen": shard.world, "backend": args.backend if world > 1 else None,
+            "srs_window_tables_bytes": inst.table_bytes, "ranks_seen": shard.world, "backend": args.backend if use_dist else None,
             "exchange_ms": exchange_ms},
         "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate_g1_u29", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
@@ -634,7 +639,7 @@ def main():
         result["value"] = None                         # a number whose result is wrong is not a measurement
         result["failed_checks"] = failed
     print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if failed:

@@ -343,15 +343,19 @@ static __global__ void __launch_bounds__(64, 2) k_gt_table_fill(Fq* __restrict__
 // acc *= base^k from the signed-window table of `base` (k canonical, consumed): digits in (-2^(wb-1), 2^(wb-1)], a digit above the half
 // becomes d - 2^wb with a carry (2^wb itself: digit 0, carry 1); a negative digit multiplies by the conjugate (unitary: inverse = conjugate).
 // A zero digit multiplies by one: the product is never skipped per lane (the lane pairs of a wave hold different digits).
-static KTOWER void gt_table_exp(Fq12* acc, const Fq* __restrict__ tab, GtShape g, u32* k, uint4* park) {
+// The exponent waits in LDS (chunks 12, 13 of the parking area: the Fq12 product uses 0..11) and a window's bits are read from there:
+// eight registers fewer across the product than a shift register of the exponent words (the last spills of k_gt_encap_exp).
+static KTOWER void gt_table_exp(Fq12* acc, const Fq* __restrict__ tab, GtShape g, const u32 (&k)[8], uint4* park) {
+  park[12 * 64 + threadIdx.x] = make_uint4(k[0], k[1], k[2], k[3]);
+  park[13 * 64 + threadIdx.x] = make_uint4(k[4], k[5], k[6], k[7]);
+  const u32* kw = reinterpret_cast<const u32*>(park);
+  auto word = [&](u32 w) -> u32 { return w < 8u ? kw[((12u + (w >> 2)) * 64u + threadIdx.x) * 4u + (w & 3u)] : 0u; };
   u32 carry_d = 0;
   const u32 half = 1u << (g.wb - 1);
 #pragma unroll 1
   for (u32 j = 0; j < g.windows; j++) {
-    u32 d = (k[0] & (2u * half - 1u)) + carry_d;
-#pragma unroll
-    for (int w = 0; w < 7; w++) k[w] = (k[w] >> g.wb) | (k[w + 1] << (32u - g.wb));
-    k[7] >>= g.wb;
+    const u32 off = j * g.wb, w = off >> 5, sh = off & 31u;
+    u32 d = (__builtin_amdgcn_alignbit(word(w + 1), word(w), sh) & (2u * half - 1u)) + carry_d;
     const bool neg = d > half;
     carry_d = neg ? 1u : 0u;
     if (neg) d = 2u * half - d;
@@ -379,16 +383,20 @@ static __global__ void __launch_bounds__(64, 2) k_gt_encap_exp(const Fq* __restr
   const u32 item = t >> 1;
   const bool live = item < n;
   const u32 i = live ? item : (n - 1);
-  Fr r = rs[i];
-  Fr m = fp_neg<FrParams>(fp_mul<FrParams>(r, betas[i]));
-  u32 u[8], v[8];
-  fp_from_mont<FrParams>(u, r);
-  fp_from_mont<FrParams>(v, m);
   __shared__ uint4 park[PARK_CHUNKS * 64];
   Fq12 acc;
   fq12_set_one(&acc);
-  gt_table_exp(&acc, tab_a, ga, u, park);
-  gt_table_exp(&acc, tab_b, gb, v, park);
+  {
+    u32 u[8];
+    fp_from_mont<FrParams>(u, rs[i]);
+    gt_table_exp(&acc, tab_a, ga, u, park);
+  }
+  asm volatile("" ::: "memory");          // the second exponent is formed here, not carried across the first exponentiation
+  {
+    u32 v[8];
+    fp_from_mont<FrParams>(v, fp_neg<FrParams>(fp_mul<FrParams>(rs[i], betas[i])));
+    gt_table_exp(&acc, tab_b, gb, v, park);
+  }
   if (live) gt_serialize(gt_out + (size_t)96 * i, &acc, park);
 }
 

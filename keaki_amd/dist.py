@@ -29,12 +29,15 @@ def chunk_bounds(n_total: int, world: int, rank: int):
 
 
 class Shard:
-    """This process's place in the job. world == 1 needs no process group at all."""
+    """This process's place in the job. world == 1 needs no process group at all -- unless `force_collectives` is set: then every
+    exchange goes through torch.distributed even with one rank (how the RCCL path -- init, all-gather on the stream the kernels run on,
+    barrier -- is executed on a box with a single GPU: bench.py --force-collectives)."""
 
-    def __init__(self, rank: int = 0, world: int = 1, dist_module=None):
+    def __init__(self, rank: int = 0, world: int = 1, dist_module=None, force_collectives: bool = False):
         self.rank, self.world, self.dist = rank, world, dist_module
-        if world > 1 and dist_module is None:
+        if (world > 1 or force_collectives) and dist_module is None:
             raise ValueError("world > 1 needs the initialised torch.distributed module")
+        self.collective = world > 1 or force_collectives
 
     @classmethod
     def from_env(cls):
@@ -50,7 +53,7 @@ class Shard:
     def all_gather_rows(self, row):
         """row: 1-D torch int64 tensor (on the device for RCCL, anywhere for gloo) -> (world, len) tensor holding every rank's row,
         on the device `row` lives on. THE exchange step of the sharded MSM."""
-        if self.world == 1:
+        if not self.collective:
             return row.reshape(1, -1)
         import torch
         backend = self.dist.get_backend()
@@ -65,7 +68,7 @@ class Shard:
 
     def all_gather_np(self, words: np.ndarray) -> np.ndarray:
         """host variant: u64[k] per rank -> (world, k)"""
-        if self.world == 1:
+        if not self.collective:
             return words.reshape(1, -1).copy()
         import torch
         t = torch.from_numpy(np.ascontiguousarray(words).view(np.int64))
@@ -74,7 +77,7 @@ class Shard:
         return self.all_gather_rows(t).cpu().numpy().view(np.uint64)
 
     def barrier(self):
-        if self.world > 1:
+        if self.collective:
             self.dist.barrier()
 
 
@@ -108,7 +111,7 @@ class ShardedMsm:
 
     def combine(self):
         """all-gather the partials, add them: afterwards self.out holds the whole MSM on every rank"""
-        if self.shard.world == 1:
+        if not self.shard.collective:
             return self.part
         self._all = self.shard.all_gather_rows(self.part)
         self.hip.g1_sum_dev(self._all.data_ptr(), self.shard.world, self.out.data_ptr())

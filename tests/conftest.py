@@ -71,6 +71,19 @@ def multirank_runs(request, tmp_path_factory):
     out["bench1"] = {"rc": rc, "log": log}
     rc, log = _run(launch + ["--nproc-per-node", "1", "--master-port", str(port + 4), "laconic_ot.py", "--gpus", "1", "--log2n", "9"], 1500)
     out["laconic1"] = {"rc": rc, "log": log}
+    # (5) RCCL itself, with the one rank a one-GPU box allows: the calls of the N > 1 path (init "nccl", all-gather / all-to-all on device
+    # buffers on the kernels' stream, barrier) and bench.py's whole distributed branch through --force-collectives
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port + 7), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        p = subprocess.run([py_exe, os.path.join(ROOT, "tests", "multirank", "rccl_world1.py")], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=900, text=True)
+        out["rccl1"] = {"rc": p.returncode, "log": p.stdout}
+    except subprocess.TimeoutExpired as e:
+        out["rccl1"] = {"rc": -9, "log": "TIMEOUT\n%s" % (e.stdout or "")}
+    rc, log = _run(launch + ["--nproc-per-node", "1", "--master-port", str(port + 8), "bench.py", "--gpus", "1", "--force-collectives", "--backend", "nccl",
+                             "--log2n", "18", "--kem-log2n", "10", "--steps", "3", "--warmup", "1", "--cpu-log2n", "14", "--strong-log2n", "18",
+                             "--fk-log2d", "0", "--laconic-log2n", "0"], 1500)
+    out["bench_rccl1"] = {"rc": rc, "log": log}
     yield out
 
 

@@ -90,3 +90,21 @@ def test_world1_under_torchrun(multirank_runs):
         assert j["n_gpus"] == 1
     assert _json_line(multirank_runs["bench1"]["log"])["checks"]["full_size_check"] is True
     assert _json_line(multirank_runs["laconic1"]["log"])["all_messages_recovered"] is True
+
+
+def test_rccl_executes_on_hardware_with_one_rank(multirank_runs):
+    """RCCL (torch.distributed backend "nccl") had never run under this code: the box has one GPU and RCCL wants one GPU per rank. With
+    ONE rank it does run: process-group init, the all-gather of the MSM partials on the stream the kernels are enqueued on followed by
+    the EC sum (checked against the oracle), the all-to-all / all-gather of the FK23 exchange buffers, barrier, teardown; and bench.py's
+    whole distributed branch (--force-collectives) through the driver's launch line."""
+    run = multirank_runs["rccl1"]
+    assert run["rc"] == 0, run["log"][-3000:]
+    j = _json_line(run["log"])
+    assert j["backend"] == "nccl" and j["world"] == 1
+    assert j["msm_allgather_sum_ok"] and j["used_collective_output"] and j["all_to_all_ok"] and j["all_gather_ok"] and j["all_gather_np_ok"]
+    run = multirank_runs["bench_rccl1"]
+    assert run["rc"] == 0, run["log"][-3000:]
+    j = _json_line(run["log"])
+    assert j["n_gpus"] == 1 and j["config"]["backend"] == "nccl" and j["config"]["exchange_ms"] is not None and j["config"]["exchange_ms"] > 0
+    assert j["checks"]["full_size_check"] is True and j["checks"]["sample_bit_exact"] is True
+    assert j["strong"]["full_size_check"] is True and j["strong"]["ranks_seen"] == 1
