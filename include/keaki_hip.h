@@ -95,6 +95,9 @@ keaki_status keaki_hip_debug_set_alloc_limit(keaki_hip_ctx* ctx, size_t bytes);
 /* Device memory this ctx holds right now, bytes: out4[0] = window tables + FK23 transforms of SRS handles built through this ctx (the
  * points themselves belong to the caller's upload), [1] = grow-only workspaces, [2] = fixed-base / GT tables of encapsulate, [3] = total. */
 keaki_status keaki_hip_ctx_memory(keaki_hip_ctx* ctx, size_t* out4);
+/* Gives back every workspace and every fixed-base / GT table of the context (out4[1] and out4[2] drop to 0): for a long-lived process after
+ * an unusually large call. Everything is rebuilt on demand; results never change. SRS handles (and their tables) are the caller's. */
+keaki_status keaki_hip_ctx_trim(keaki_hip_ctx* ctx);
 
 /* ---- SRS: replaces KZGSetup::g1_aff (src/kzg.rs:22-29, built at :63) -------------------------- */
 keaki_status keaki_hip_srs_g1_upload(keaki_hip_ctx* ctx, const uint64_t* points_aff, size_t n, keaki_hip_srs_g1** out);
@@ -269,6 +272,17 @@ keaki_status keaki_hip_group_encap_batch(keaki_hip_group* g, const uint64_t* com
                                          uint8_t* key_out, size_t msg_len);
 keaki_status keaki_hip_group_decap_batch(keaki_hip_group* g, const uint64_t* proofs_aff, const uint64_t* cts_aff, size_t n, uint8_t* gt_out,
                                          uint8_t* key_out, size_t msg_len);
+
+/* kzg::open_fk (src/kzg.rs:157-203) over the members of a group: the sharded FK23 pipeline (keaki_hip_fk_shard_*, member i = rank i) with the
+ * exchanges done inside the library -- device-to-device copies between the members' buffers (hipMemcpyPeer), no collective, no RCCL. The
+ * handle keeps srs[0..d) on every member (points_aff: the first d = 2^log2d points of the SRS) and every member's part of the SRS-only
+ * transform. Needs a power-of-two group and d >= N^2; any other shape runs un-sharded on member 0. omega_2d, omega_2d_inv, inv_2d as for
+ * keaki_hip_open_fk_poly. _open: coeffs = d Fr on the host, proofs_out_aff = d affine points, the bytes keaki_hip_open_fk_poly returns. */
+typedef struct keaki_hip_group_fk keaki_hip_group_fk;
+keaki_status keaki_hip_group_fk_create(keaki_hip_group* g, const uint64_t* points_aff, uint32_t log2d, const uint64_t* omega_2d,
+                                       const uint64_t* omega_2d_inv, const uint64_t* inv_2d, keaki_hip_group_fk** out);
+keaki_status keaki_hip_group_fk_open(keaki_hip_group* g, keaki_hip_group_fk* fk, const uint64_t* coeffs, uint64_t* proofs_out_aff);
+void keaki_hip_group_fk_free(keaki_hip_group* g, keaki_hip_group_fk* fk);
 
 /* ---- instrumentation (bench.py reads these; not part of the reference surface) ---------------- */
 /* device time in milliseconds of the dominant kernel (bucket accumulation) of the last msm_*_dev

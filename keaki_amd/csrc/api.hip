@@ -301,6 +301,20 @@ keaki_status keaki_hip_debug_set_alloc_limit(keaki_hip_ctx* ctx, size_t bytes) {
   ctx->tune.alloc_limit = bytes;
   return KEAKI_OK;
 }
+// Releases every grow-only workspace and encapsulate table of the context (they come back on the next call that needs them; a table's
+// rebuild costs what the first call cost). SRS handles are not touched.
+keaki_status keaki_hip_ctx_trim(keaki_hip_ctx* ctx) {
+  CTX_GUARD(ctx);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (const BufClass& bc : all_bufs(ctx))
+    if (bc.b->p) { (void)hipFree(bc.b->p); bc.b->p = nullptr; bc.b->cap = 0; }
+  ctx->gt_b_ready = ctx->gt_a_valid = ctx->gt_b_fallback = false;
+  ctx->seen_com_runs = 0;
+  ctx->verify_ready = ctx->verify_tau_valid = false;
+  ctx->fb_tau_valid = ctx->g2gen_lines_ready = ctx->fb_ready = false;
+  ctx->fbs_ready = ctx->fbs_tau_valid = false;
+  return KEAKI_OK;
+}
 keaki_status keaki_hip_ctx_memory(keaki_hip_ctx* ctx, size_t* out4) {
   if (!ctx) return KEAKI_ERR_BAD_ARG;
   std::lock_guard<std::recursive_mutex> lock_(ctx->mu);

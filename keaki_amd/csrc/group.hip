@@ -241,4 +241,128 @@ keaki_status keaki_hip_group_decap_batch(keaki_hip_group* g, const uint64_t* pro
   });
 }
 
+// ---- FK23 (kzg::open_fk, src/kzg.rs:157-203) over the members of a group -------------------------------------------------------------------
+// The sharded pipeline of keaki_hip_fk_shard_* (member i = rank i: 1/N of the butterflies of both size-d transforms and of the 2d scalar-mults)
+// with the exchanges done HERE, in-process: an all-to-all is N^2 device-to-device copies between the members' buffers (hipMemcpyPeer; plain
+// device copies when two members share a GPU), the final all-gather lands in member 0's buffer only, which writes the d proofs to the host.
+// Needs N a power of two and d >= N^2; any other shape runs un-sharded on member 0.
+}  // extern "C"
+
+struct keaki_hip_group_fk {
+  uint32_t log2d = 0;
+  bool sharded = false;
+  std::vector<keaki_hip_srs_g1*> srs;       // srs[0..d) on every member (sharded) or on member 0 only
+  std::vector<keaki_hip_fk_shard*> fk;
+  std::vector<void*> send, recv;            // sizes[0] bytes each, on the member's device
+  size_t sizes[4] = {0, 0, 0, 0};
+  uint64_t om[4], omi[4], inv2d[4];
+};
+
+namespace {
+keaki_status copy_between(keaki_hip_group* g, size_t dst_m, void* dst, size_t src_m, const void* src, size_t bytes) {
+  const int dd = g->ctx[dst_m]->device, sd = g->ctx[src_m]->device;
+  hipError_t e;
+  if (dd == sd) { (void)hipSetDevice(dd); e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice); }
+  else e = hipMemcpyPeer(dst, dd, src, sd, bytes);
+  if (e != hipSuccess) return gfail(g, KEAKI_ERR_HIP, "group_fk: copy member %zu -> member %zu failed: %s", src_m, dst_m, hipGetErrorString(e));
+  return KEAKI_OK;
+}
+// chunk j of member i's send buffer -> chunk i of member j's receive buffer (every member has finished its step: run_all waited and synchronised)
+keaki_status all_to_all(keaki_hip_group* g, keaki_hip_group_fk* f, size_t per_peer) {
+  const size_t N = g->ctx.size();
+  for (size_t i = 0; i < N; i++)
+    for (size_t j = 0; j < N; j++)
+      ST_TRY(copy_between(g, j, (char*)f->recv[j] + i * per_peer, i, (const char*)f->send[i] + j * per_peer, per_peer));
+  return KEAKI_OK;
+}
+void group_fk_release(keaki_hip_group* g, keaki_hip_group_fk* f) {
+  for (size_t i = 0; i < f->fk.size(); i++) keaki_hip_fk_shard_free(g && i < g->ctx.size() ? g->ctx[i] : nullptr, f->fk[i]);
+  for (size_t i = 0; i < f->srs.size(); i++) keaki_hip_srs_g1_free(g && i < g->ctx.size() ? g->ctx[i] : nullptr, f->srs[i]);
+  for (size_t i = 0; i < f->send.size(); i++) {
+    if (g && i < g->ctx.size()) (void)hipSetDevice(g->ctx[i]->device);
+    if (f->send[i]) (void)hipFree(f->send[i]);
+    if (f->recv[i]) (void)hipFree(f->recv[i]);
+  }
+  delete f;
+}
+// a step on every member, each followed by a synchronisation of the member's stream (the copies that follow read the buffers)
+keaki_status step_all(keaki_hip_group* g, const char* what, const std::function<keaki_status(size_t)>& fn) {
+  return run_all(g, what, [&](size_t i) -> keaki_status {
+    const keaki_status st = fn(i);
+    return st != KEAKI_OK ? st : keaki_hip_synchronize(g->ctx[i]);
+  });
+}
+}  // namespace
+
+extern "C" {
+
+keaki_status keaki_hip_group_fk_create(keaki_hip_group* g, const uint64_t* points_aff, uint32_t log2d, const uint64_t* omega_2d, const uint64_t* omega_2d_inv,
+                                       const uint64_t* inv_2d, keaki_hip_group_fk** out) {
+  if (!g) return KEAKI_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (!points_aff || !omega_2d || !omega_2d_inv || !inv_2d || !out || log2d > 27) return gfail(g, KEAKI_ERR_BAD_ARG, "group_fk_create: bad argument");
+  *out = nullptr;
+  const size_t N = g->ctx.size(), d = (size_t)1 << log2d;
+  auto* f = new keaki_hip_group_fk();
+  f->log2d = log2d;
+  memcpy(f->om, omega_2d, 32); memcpy(f->omi, omega_2d_inv, 32); memcpy(f->inv2d, inv_2d, 32);
+  f->sharded = N >= 2 && (N & (N - 1)) == 0 && d >= N * N;
+  keaki_status st;
+  if (!f->sharded) {
+    f->srs.assign(1, nullptr);
+    st = keaki_hip_srs_g1_upload(g->ctx[0], points_aff, d, &f->srs[0]);
+    if (st == KEAKI_OK) st = keaki_hip_srs_g1_precompute_fk(g->ctx[0], f->srs[0], log2d, omega_2d);
+    if (st != KEAKI_OK) { gfail(g, st, "group_fk_create: member 0: %s", keaki_hip_last_error(g->ctx[0])); group_fk_release(g, f); return st; }
+    *out = f;
+    return KEAKI_OK;
+  }
+  f->srs.assign(N, nullptr); f->fk.assign(N, nullptr); f->send.assign(N, nullptr); f->recv.assign(N, nullptr);
+  st = run_all(g, "group_fk_create", [&](size_t i) -> keaki_status {
+    ST_TRY(keaki_hip_srs_g1_upload(g->ctx[i], points_aff, d, &f->srs[i]));
+    ST_TRY(keaki_hip_fk_shard_create(g->ctx[i], f->srs[i], log2d, (uint32_t)i, (uint32_t)N, omega_2d, omega_2d_inv, inv_2d, &f->fk[i]));
+    size_t sz[4];
+    ST_TRY(keaki_hip_fk_shard_sizes(f->fk[i], sz));
+    if (i == 0) memcpy(f->sizes, sz, sizeof sz);
+    (void)hipSetDevice(g->ctx[i]->device);
+    ST_TRY(keaki_internal::dev_alloc(g->ctx[i], &f->send[i], sz[0]));
+    return keaki_internal::dev_alloc(g->ctx[i], &f->recv[i], sz[0]);
+  });
+  // the SRS-only transform: every member's part, one all-to-all
+  if (st == KEAKI_OK) st = step_all(g, "group_fk_create (setup 0)", [&](size_t i) { return keaki_hip_fk_shard_setup(g->ctx[i], f->fk[i], 0, f->send[i], nullptr); });
+  if (st == KEAKI_OK) st = all_to_all(g, f, f->sizes[1]);
+  if (st == KEAKI_OK) st = step_all(g, "group_fk_create (setup 1)", [&](size_t i) { return keaki_hip_fk_shard_setup(g->ctx[i], f->fk[i], 1, nullptr, f->recv[i]); });
+  if (st != KEAKI_OK) { group_fk_release(g, f); return st; }
+  *out = f;
+  return KEAKI_OK;
+}
+
+void keaki_hip_group_fk_free(keaki_hip_group* g, keaki_hip_group_fk* fk) {
+  if (!fk) return;
+  if (g) { std::lock_guard<std::mutex> lk(g->mu); group_fk_release(g, fk); }
+  else group_fk_release(nullptr, fk);
+}
+
+keaki_status keaki_hip_group_fk_open(keaki_hip_group* g, keaki_hip_group_fk* f, const uint64_t* coeffs, uint64_t* proofs_out_aff) {
+  if (!g) return KEAKI_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (!f || !coeffs || !proofs_out_aff) return gfail(g, KEAKI_ERR_BAD_ARG, "group_fk_open: null pointer");
+  if (!f->sharded) {
+    const keaki_status st = keaki_hip_open_fk_poly(g->ctx[0], f->srs[0], f->log2d, coeffs, f->om, f->omi, f->inv2d, proofs_out_aff);
+    if (st != KEAKI_OK) return gfail(g, st, "group_fk_open: member 0: %s", keaki_hip_last_error(g->ctx[0]));
+    return KEAKI_OK;
+  }
+  const size_t N = g->ctx.size();
+  if (f->fk.size() != N) return gfail(g, KEAKI_ERR_BAD_ARG, "group_fk_open: the handle belongs to a group of another size");
+  ST_TRY(step_all(g, "group_fk_open (step 0)", [&](size_t i) { return keaki_hip_fk_shard_open(g->ctx[i], f->fk[i], 0, coeffs, f->send[i], nullptr, nullptr); }));
+  ST_TRY(all_to_all(g, f, f->sizes[2]));
+  ST_TRY(step_all(g, "group_fk_open (step 1)", [&](size_t i) { return keaki_hip_fk_shard_open(g->ctx[i], f->fk[i], 1, nullptr, f->send[i], f->recv[i], nullptr); }));
+  ST_TRY(all_to_all(g, f, f->sizes[2]));
+  ST_TRY(step_all(g, "group_fk_open (step 2)", [&](size_t i) { return keaki_hip_fk_shard_open(g->ctx[i], f->fk[i], 2, nullptr, f->send[i], f->recv[i], nullptr); }));
+  // the all-gather of the d / N affine proofs of every member, into member 0 only (it alone writes the host output)
+  for (size_t i = 0; i < N; i++) ST_TRY(copy_between(g, 0, (char*)f->recv[0] + i * f->sizes[3], i, f->send[i], f->sizes[3]));
+  const keaki_status st = keaki_hip_fk_shard_open(g->ctx[0], f->fk[0], 3, nullptr, nullptr, f->recv[0], proofs_out_aff);
+  if (st != KEAKI_OK) return gfail(g, st, "group_fk_open (step 3): member 0: %s", keaki_hip_last_error(g->ctx[0]));
+  return KEAKI_OK;
+}
+
 }  // extern "C"

@@ -24,10 +24,11 @@ EXPORTS = [
     "keaki_hip_pairing_batch", "keaki_hip_pairing_batch_dev",
     "keaki_hip_encap_batch", "keaki_hip_encap_batch_dev", "keaki_hip_decap_batch", "keaki_hip_decap_batch_dev",
     "keaki_hip_selftest_field", "keaki_hip_open_fk", "keaki_hip_open_fk_poly", "keaki_hip_srs_g1_precompute_fk", "keaki_hip_fk_shard_create", "keaki_hip_fk_shard_free", "keaki_hip_fk_shard_sizes", "keaki_hip_fk_shard_setup", "keaki_hip_fk_shard_open", "keaki_hip_fr_fft", "keaki_hip_srs_g1_check", "keaki_hip_g2_check", "keaki_hip_kzg_open", "keaki_hip_kzg_verify", "keaki_hip_final_exp_batch", "keaki_hip_miller_loop_batch", "keaki_hip_g2_prepare", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
-    "keaki_hip_last_fk_ms", "keaki_hip_ctx_set_option", "keaki_hip_debug_set_alloc_limit", "keaki_hip_ctx_memory", "keaki_hip_kzg_quotient",
+    "keaki_hip_last_fk_ms", "keaki_hip_ctx_set_option", "keaki_hip_debug_set_alloc_limit", "keaki_hip_ctx_memory", "keaki_hip_ctx_trim", "keaki_hip_kzg_quotient",
     "keaki_hip_group_create", "keaki_hip_group_destroy", "keaki_hip_group_size", "keaki_hip_group_ctx", "keaki_hip_group_last_error",
     "keaki_hip_group_srs_g1_upload", "keaki_hip_group_srs_g1_len", "keaki_hip_group_srs_g1_free", "keaki_hip_group_msm_g1",
     "keaki_hip_group_kzg_open", "keaki_hip_group_encap_batch", "keaki_hip_group_decap_batch",
+    "keaki_hip_group_fk_create", "keaki_hip_group_fk_open", "keaki_hip_group_fk_free",
 ]
 
 KEAKI_ERR_TOO_LARGE = -5
@@ -110,6 +111,7 @@ def load_library():
         lib.keaki_hip_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
         lib.keaki_hip_debug_set_alloc_limit.argtypes = [vp, sz]
         lib.keaki_hip_ctx_memory.argtypes = [vp, C.POINTER(C.c_size_t)]
+        lib.keaki_hip_ctx_trim.argtypes = [vp]
         lib.keaki_hip_kzg_quotient.argtypes = [vp, vp, sz, vp, vp, vp]
         lib.keaki_hip_group_create.argtypes = [C.POINTER(i32), sz, C.POINTER(vp)]
         lib.keaki_hip_group_destroy.argtypes = [vp]
@@ -129,6 +131,10 @@ def load_library():
         lib.keaki_hip_group_kzg_open.argtypes = [vp, vp, vp, sz, vp, vp, vp]
         lib.keaki_hip_group_encap_batch.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, sz]
         lib.keaki_hip_group_decap_batch.argtypes = [vp, vp, vp, sz, vp, vp, sz]
+        lib.keaki_hip_group_fk_create.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, C.POINTER(vp)]
+        lib.keaki_hip_group_fk_open.argtypes = [vp, vp, vp, vp]
+        lib.keaki_hip_group_fk_free.argtypes = [vp, vp]
+        lib.keaki_hip_group_fk_free.restype = None
         _LIB = lib
     return _LIB
 
@@ -221,6 +227,10 @@ class KeakiHip:
         out = (C.c_size_t * 4)()
         self._ck(self.lib.keaki_hip_ctx_memory(self.ctx, out))
         return {"tables": int(out[0]), "workspaces": int(out[1]), "gt_tables": int(out[2]), "total": int(out[3])}
+
+    def trim(self):
+        """release every workspace / encapsulate table of the context (rebuilt on demand)"""
+        self._ck(self.lib.keaki_hip_ctx_trim(self.ctx))
 
     def version(self) -> str:
         return self.lib.keaki_hip_version().decode()
@@ -512,6 +522,24 @@ class KeakiHipGroup:
         out = np.zeros(12, np.uint64); val = np.zeros(4, np.uint64)
         self._ck(self.lib.keaki_hip_group_kzg_open(self.g, srs.handle, _ptr(c) if c.shape[0] else None, c.shape[0], _ptr(_np(point)), _ptr(out), _ptr(val)))
         return out, val
+
+    def fk_create(self, points, log2d: int, omega_2d, omega_2d_inv, inv_2d):
+        """FK23 over the members (keaki_hip_group_fk_*): handle for domain size 2^log2d over the first 2^log2d points"""
+        pts = _np(points, 8)
+        assert pts.shape[0] >= 1 << log2d
+        h = C.c_void_p()
+        self._ck(self.lib.keaki_hip_group_fk_create(self.g, _ptr(pts), log2d, _ptr(_np(omega_2d)), _ptr(_np(omega_2d_inv)), _ptr(_np(inv_2d)), C.byref(h)))
+        return h
+
+    def fk_open(self, fk, log2d: int, coeffs) -> np.ndarray:
+        p = _np(coeffs, 4)
+        assert p.shape[0] == 1 << log2d
+        out = np.zeros((1 << log2d, 8), np.uint64)
+        self._ck(self.lib.keaki_hip_group_fk_open(self.g, fk, _ptr(p), _ptr(out)))
+        return out
+
+    def fk_free(self, fk):
+        self.lib.keaki_hip_group_fk_free(self.g, fk)
 
     def encap_batch(self, com, tau_g2, points, values, rs, msg_len: int = 32):
         com = _np(com); tau = _np(tau_g2); pts = _np(points, 4); vals = _np(values, 4); rs = _np(rs, 4)

@@ -137,11 +137,20 @@ KZGSetup::~KZGSetup() {
   if (chunk_ && dev_) keaki_hip_srs_g1_free(dev_->ctx(), chunk_);
   if (srs_ && dev_) keaki_hip_srs_g1_free(dev_->ctx(), srs_);
   if (gsrs_ && dev_) keaki_hip_group_srs_g1_free(dev_->group(), gsrs_);
+  if (gfk_ && dev_) keaki_hip_group_fk_free(dev_->group(), gfk_);
 }
 KZGSetup::KZGSetup(KZGSetup&& o) noexcept
-    : dev_(std::move(o.dev_)), g1_aff_(std::move(o.g1_aff_)), tau_g2_(o.tau_g2_), srs_(o.srs_), gsrs_(o.gsrs_), tables_(o.tables_), chunk_(o.chunk_),
-      chunk_lo_(o.chunk_lo_), chunk_hi_(o.chunk_hi_) {
-  o.srs_ = nullptr; o.chunk_ = nullptr; o.gsrs_ = nullptr;
+    : dev_(std::move(o.dev_)), g1_aff_(std::move(o.g1_aff_)), tau_g2_(o.tau_g2_), srs_(o.srs_), gsrs_(o.gsrs_), gfk_(o.gfk_), gfk_log2d_(o.gfk_log2d_),
+      tables_(o.tables_), chunk_(o.chunk_), chunk_lo_(o.chunk_lo_), chunk_hi_(o.chunk_hi_) {
+  o.srs_ = nullptr; o.chunk_ = nullptr; o.gsrs_ = nullptr; o.gfk_ = nullptr;
+}
+keaki_hip_group_fk* KZGSetup::group_fk(unsigned log2d) const {
+  if (gfk_ && gfk_log2d_ == log2d) return gfk_;
+  if (gfk_) { keaki_hip_group_fk_free(dev_->group(), gfk_); gfk_ = nullptr; }
+  vec::Radix2Domain d2 = vec::Radix2Domain::create((size_t)2 << log2d);
+  dev_->check_group(keaki_hip_group_fk_create(dev_->group(), g1_aff_[0].w.data(), log2d, d2.group_gen.l, d2.group_gen_inv.l, d2.size_inv.l, &gfk_));
+  gfk_log2d_ = log2d;
+  return gfk_;
 }
 keaki_hip_srs_g1* KZGSetup::srs() const {
   if (!srs_) dev_->check(keaki_hip_srs_g1_upload(dev_->ctx(), g1_aff_.empty() ? nullptr : g1_aff_[0].w.data(), g1_aff_.size(), &srs_));
@@ -242,6 +251,7 @@ void precompute_open_fk(const KZGSetup& setup, size_t d) {
   if (d < 1 || (d & (d - 1)) != 0 || d > setup.g1_pow().size()) return;   // open_fk falls back to per-point openings for such shapes
   unsigned log2d = 0;
   while ((size_t(1) << log2d) < d) log2d++;
+  if (setup.device()->group()) { (void)setup.group_fk(log2d); return; }      // every member's part of the SRS-only transform
   vec::Radix2Domain d2 = vec::Radix2Domain::create(2 * d);
   setup.device()->check(keaki_hip_srs_g1_precompute_fk(setup.device()->ctx(), setup.srs(), log2d, d2.group_gen.l));
 }
@@ -257,7 +267,10 @@ Result<std::vector<G1>> open_fk(const KZGSetup& setup, const std::vector<Fr>& p,
     vec::Radix2Domain d2 = vec::Radix2Domain::create(2 * d);
     std::vector<G1> out(d);
     const Device& dev = *setup.device();
-    dev.check(keaki_hip_open_fk_poly(dev.ctx(), setup.srs(), log2d, p[0].l, d2.group_gen.l, d2.group_gen_inv.l, d2.size_inv.l, out[0].w.data()));
+    if (dev.group())       // the group FFTs and the 2d scalar-mults split over the members, exchanges inside the library
+      dev.check_group(keaki_hip_group_fk_open(dev.group(), setup.group_fk(log2d), p[0].l, out[0].w.data()));
+    else
+      dev.check(keaki_hip_open_fk_poly(dev.ctx(), setup.srs(), log2d, p[0].l, d2.group_gen.l, d2.group_gen_inv.l, d2.size_inv.l, out[0].w.data()));
     return Result<std::vector<G1>>::Ok(std::move(out));
   }
   // shapes FK23 does not cover (the reference would panic on them): one opening per root of unity

@@ -131,6 +131,9 @@ class KZGSetup {
   // need it (they read the per-member chunks), open_fk and the keaki::dist calls do.
   keaki_hip_srs_g1* srs() const;
   keaki_hip_group_srs_g1* group_srs() const { return gsrs_; }
+  // group devices: the FK23 handle of domain size d = 2^log2d (every member's copy of srs[0..d) and its part of the SRS-only transform),
+  // built on first use and kept until another size is asked for
+  keaki_hip_group_fk* group_fk(unsigned log2d) const;
   // false when the optional window tables of the SRS did not fit in HBM: commit / open then run the generic per-window MSM (same results)
   bool has_window_tables() const { return tables_; }
   // this rank's chunk [lo, hi) of the SRS as a handle of its own, with its own window tables (built on first use; see keaki::dist)
@@ -142,6 +145,8 @@ class KZGSetup {
   G2 tau_g2_;
   mutable keaki_hip_srs_g1* srs_ = nullptr;  // device-resident copy of g1_aff, uploaded once
   keaki_hip_group_srs_g1* gsrs_ = nullptr;   // group devices: one chunk (+ its window tables) per member
+  mutable keaki_hip_group_fk* gfk_ = nullptr;
+  mutable unsigned gfk_log2d_ = 0;
   bool tables_ = false;
   mutable keaki_hip_srs_g1* chunk_ = nullptr;
   mutable size_t chunk_lo_ = 0, chunk_hi_ = 0;

@@ -47,6 +47,10 @@ pub struct keaki_hip_group {
 pub struct keaki_hip_group_srs_g1 {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct keaki_hip_group_fk {
+    _private: [u8; 0],
+}
 
 extern "C" {
     // ---- context
@@ -58,6 +62,7 @@ extern "C" {
     pub fn keaki_hip_ctx_set_option(ctx: *mut keaki_hip_ctx, name: *const c_char, value: i64) -> keaki_status;
     pub fn keaki_hip_debug_set_alloc_limit(ctx: *mut keaki_hip_ctx, bytes: usize) -> keaki_status;
     pub fn keaki_hip_ctx_memory(ctx: *mut keaki_hip_ctx, out4: *mut usize) -> keaki_status;
+    pub fn keaki_hip_ctx_trim(ctx: *mut keaki_hip_ctx) -> keaki_status;
 
     // ---- SRS (replaces KZGSetup::g1_aff, src/kzg.rs:22-29)
     pub fn keaki_hip_srs_g1_upload(ctx: *mut keaki_hip_ctx, points_aff: *const u64, n: usize, out: *mut *mut keaki_hip_srs_g1) -> keaki_status;
@@ -145,6 +150,11 @@ extern "C" {
                                        r: *const u64, n: usize, ct_out_aff: *mut u64, gt_out: *mut u8, key_out: *mut u8, msg_len: usize) -> keaki_status;
     pub fn keaki_hip_group_decap_batch(g: *mut keaki_hip_group, proofs_aff: *const u64, cts_aff: *const u64, n: usize, gt_out: *mut u8, key_out: *mut u8,
                                        msg_len: usize) -> keaki_status;
+
+    pub fn keaki_hip_group_fk_create(g: *mut keaki_hip_group, points_aff: *const u64, log2d: u32, omega_2d: *const u64, omega_2d_inv: *const u64,
+                                     inv_2d: *const u64, out: *mut *mut keaki_hip_group_fk) -> keaki_status;
+    pub fn keaki_hip_group_fk_open(g: *mut keaki_hip_group, fk: *mut keaki_hip_group_fk, coeffs: *const u64, proofs_out_aff: *mut u64) -> keaki_status;
+    pub fn keaki_hip_group_fk_free(g: *mut keaki_hip_group, fk: *mut keaki_hip_group_fk);
 
     // ---- instrumentation
     pub fn keaki_hip_set_timing(ctx: *mut keaki_hip_ctx, enabled: i32) -> keaki_status;

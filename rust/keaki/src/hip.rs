@@ -184,12 +184,15 @@ fn g1_from_jac(w: &[u64; 12]) -> G1Projective {
 pub struct HipSrs {
     whole: OnceLock<WholeSrs>,
     gsrs: *mut sys::keaki_hip_group_srs_g1,
+    gfk: std::sync::Mutex<Option<(u32, GroupFk)>>, // group devices: the FK23 handle of the last domain size asked for
     words: Vec<u64>, // kept only on a group (the lazy whole-SRS upload needs them); empty otherwise
     len: usize,
 }
 struct WholeSrs(*mut sys::keaki_hip_srs_g1);
 unsafe impl Send for WholeSrs {}
 unsafe impl Sync for WholeSrs {}
+struct GroupFk(*mut sys::keaki_hip_group_fk);
+unsafe impl Send for GroupFk {}
 unsafe impl Send for HipSrs {}
 unsafe impl Sync for HipSrs {}
 
@@ -234,11 +237,11 @@ impl HipSrs {
         if !dev.group.is_null() {
             let mut gsrs = core::ptr::null_mut();
             dev.check_group(unsafe { sys::keaki_hip_group_srs_g1_upload(dev.group, words.as_ptr(), g1_aff.len(), 1, &mut gsrs) }, "group_srs_g1_upload");
-            return HipSrs { whole: OnceLock::new(), gsrs, words, len: g1_aff.len() };
+            return HipSrs { whole: OnceLock::new(), gsrs, gfk: std::sync::Mutex::new(None), words, len: g1_aff.len() };
         }
         let whole = OnceLock::new();
         let _ = whole.set(WholeSrs(Self::upload_whole(&words, g1_aff.len(), true)));
-        HipSrs { whole, gsrs: core::ptr::null_mut(), words: Vec::new(), len: g1_aff.len() }
+        HipSrs { whole, gsrs: core::ptr::null_mut(), gfk: std::sync::Mutex::new(None), words: Vec::new(), len: g1_aff.len() }
     }
     fn upload_whole(words: &[u64], n: usize, tables: bool) -> *mut sys::keaki_hip_srs_g1 {
         let dev = Device::global();
@@ -272,6 +275,9 @@ impl Drop for HipSrs {
         }
         if !self.gsrs.is_null() {
             unsafe { sys::keaki_hip_group_srs_g1_free(dev.group, self.gsrs) }
+        }
+        if let Some((_, fk)) = self.gfk.lock().unwrap().take() {
+            unsafe { sys::keaki_hip_group_fk_free(dev.group, fk.0) }
         }
     }
 }
@@ -350,6 +356,31 @@ pub fn open_fk(srs: &HipSrs, coeffs: &[Fr], omega_2d: &Fr, omega_2d_inv: &Fr, in
     let d = coeffs.len();
     assert!(d.is_power_of_two() && d <= srs.len());
     let mut out = vec![0u64; 8 * d];
+    if !dev.group.is_null() {
+        // several GPUs in this process: the sharded FK23 pipeline with the exchanges inside the library (the group_fk entry points); the handle
+        // (every member's copy of srs[0..d) and its part of the SRS-only transform) is kept for the next call with the same d
+        let log2d = d.trailing_zeros();
+        let mut slot = srs.gfk.lock().unwrap();
+        if slot.as_ref().map(|(l, _)| *l) != Some(log2d) {
+            if let Some((_, old)) = slot.take() {
+                unsafe { sys::keaki_hip_group_fk_free(dev.group, old.0) }
+            }
+            let mut fk = core::ptr::null_mut();
+            dev.check_group(
+                unsafe {
+                    sys::keaki_hip_group_fk_create(
+                        dev.group, srs.words.as_ptr(), log2d, fr_ptr(core::slice::from_ref(omega_2d)), fr_ptr(core::slice::from_ref(omega_2d_inv)),
+                        fr_ptr(core::slice::from_ref(inv_2d)), &mut fk,
+                    )
+                },
+                "group_fk_create",
+            );
+            *slot = Some((log2d, GroupFk(fk)));
+        }
+        let fk = slot.as_ref().unwrap().1 .0;
+        dev.check_group(unsafe { sys::keaki_hip_group_fk_open(dev.group, fk, fr_ptr(coeffs), out.as_mut_ptr()) }, "group_fk_open");
+        return out.chunks_exact(8).map(|w| g1_from_words(w).into()).collect();
+    }
     dev.check(
         unsafe {
             sys::keaki_hip_open_fk_poly(

@@ -113,6 +113,71 @@ def test_group_encap_decap_split_by_item(oc, hip, rand_fr):
     assert np.array_equal(dgt1[idx], egt2) and np.array_equal(dkey1[idx], ekey2)
 
 
+@pytest.mark.parametrize("members,log2d", [(2, 12), (4, 12), (4, 16), (3, 10), (2, 1)])
+def test_group_open_fk_equals_single_context_and_oracle(oc, py, hip, members, log2d):
+    """kzg::open_fk (src/kzg.rs:157-203) over the members of a group: the sharded FK23 pipeline with the exchanges done inside the library
+    (device-to-device copies between the members' buffers). Power-of-two groups shard (two rank bits at four members), three members and
+    d < N^2 fall back to member 0: always the bytes of keaki_hip_open_fk_poly on one context, and the oracle's per-point openings."""
+    from keaki_amd.hip import KeakiHipGroup
+    from bench import random_fr_limbs
+    d = 1 << log2d
+    g1, _ = oc.generators()
+    tau = 0x1234567890ABCDEF1234567 % oc.R_MOD
+    pw, acc = [], 1
+    for _ in range(d):
+        pw.append(acc); acc = acc * tau % oc.R_MOD
+    srs_pts = hip.g1_mul_batch(g1, mont(oc, pw))
+    w2 = py.fr_root_of_unity(2 * d)
+    om, omi, inv = mont(oc, [w2])[0], mont(oc, [pow(w2, -1, py.R)])[0], mont(oc, [pow(2 * d, -1, py.R)])[0]
+    p = random_fr_limbs(d, 8800 + log2d)
+    srs1 = hip.srs_g1_upload(srs_pts)
+    single = hip.open_fk_poly(srs1, log2d, p, om, omi, inv)
+    srs1.free()
+    g = KeakiHipGroup([0] * members)
+    try:
+        fk = g.fk_create(srs_pts, log2d, om, omi, inv)
+        for rep in range(2):                                   # the handle is reused: second polynomial, same SRS transform
+            q = p if rep == 0 else random_fr_limbs(d, 8900 + log2d)
+            got = g.fk_open(fk, log2d, q)
+            if rep == 0:
+                assert np.array_equal(got, single)
+            w = pow(w2, 2, py.R)
+            for i in sorted({0, 1, d // 2, d - 1}):
+                qq, _ = oc.fr_quotient(q, mont(oc, [pow(w, i, py.R)])[0])
+                assert np.array_equal(got[i], oc.msm_g1(srs_pts[:d - 1], qq, threads=NCPU)), (rep, i)
+        g.fk_free(fk)
+    finally:
+        g.close()
+
+
+def test_ctx_trim_releases_and_rebuilds(oc, rand_fr):
+    from keaki_amd.hip import KeakiHip
+    h = KeakiHip(0)
+    try:
+        g1, g2 = oc.generators()
+        n = 300
+        pts = h.g1_mul_batch(g1, mont(oc, rand_fr(n, 31)))
+        sc = mont(oc, rand_fr(n, 32))
+        srs = h.srs_g1_upload(pts)
+        h.srs_g1_precompute(srs)
+        r1 = h.msm_g1(srs, sc)
+        tau_g2 = h.g2_mul_batch(g2, mont(oc, [77]))[0]
+        A, V, Rr = (mont(oc, rand_fr(n, 33 + k)) for k in range(3))
+        e1 = h.encap_batch(pts[0], tau_g2, A, V, Rr, 32)
+        m = h.memory()
+        assert m["workspaces"] > 0 and m["gt_tables"] > 0 and m["tables"] > 0
+        h.trim()
+        m2 = h.memory()
+        assert m2["workspaces"] == 0 and m2["gt_tables"] == 0 and m2["tables"] == m["tables"]      # the SRS tables are the caller's
+        assert np.array_equal(h.msm_g1(srs, sc), r1)
+        e2 = h.encap_batch(pts[0], tau_g2, A, V, Rr, 32)
+        assert all(np.array_equal(a, b) for a, b in zip(e1, e2))
+        assert h.kzg_verify(pts[0], tau_g2, A[0], A[1], pts[1]) in (True, False)
+        srs.free()
+    finally:
+        h.close()
+
+
 def test_group_errors(oc):
     from keaki_amd.hip import KeakiHipGroup, KeakiHipError
     with pytest.raises(KeakiHipError) as e:
@@ -165,9 +230,16 @@ def test_host_mirror_on_a_device_group(oc, py):
         bits = np.random.default_rng(5).integers(0, 2, m)
         choices = np.where(bits[:, None] == 0, K.fr(0)[None, :], K.fr(1)[None, :]).astype(np.uint64)
         ra, rb = K.Rng(17), K.Rng(17)
-        com3, proofs3 = K.vec_commit(ra, s3, choices)
+        com3, proofs3 = K.vec_commit(ra, s3, choices)          # three members: FK23 un-sharded on member 0 (not a power of two)
         com1, proofs1 = K.vec_commit(rb, s1, choices)
         assert np.array_equal(com3, com1) and np.array_equal(proofs3, proofs1)
+        # a power-of-two group shards the openings as well (keaki_hip_group_fk_*): same proofs
+        dev4 = K.Device([0, 0, 0, 0])
+        s4 = K.KZGSetup.setup(secret, n, device=dev4)
+        K.precompute_open_fk(s4, m + 1)
+        com4, proofs4 = K.vec_commit(K.Rng(17), s4, choices)
+        assert np.array_equal(com4, com1) and np.array_equal(proofs4, proofs1)
+        s4.close(); dev4.close()
         el = K.domain_elements(m + 1)
         msgs = np.random.default_rng(6).integers(0, 256, size=(m, 32), dtype=np.uint8)
         vals = np.repeat(K.fr(1)[None, :], m, 0)

@@ -49,7 +49,7 @@ def c_class(t):
     stars = t.count("*")
     base = t.replace("*", "").strip()
     scalar = {"int32_t": "i32", "uint32_t": "u32", "size_t": "usize", "uint64_t": "u64", "uint8_t": "u8", "float": "f32", "void": "void", "char": "c_char",
-              "keaki_status": "i32", "keaki_hip_ctx": "ctx", "keaki_hip_srs_g1": "srs_g1", "keaki_hip_srs_g2": "srs_g2", "keaki_hip_fk_shard": "fk_shard", "int64_t": "i64", "keaki_hip_group": "group", "keaki_hip_group_srs_g1": "group_srs_g1"}[base]
+              "keaki_status": "i32", "keaki_hip_ctx": "ctx", "keaki_hip_srs_g1": "srs_g1", "keaki_hip_srs_g2": "srs_g2", "keaki_hip_fk_shard": "fk_shard", "int64_t": "i64", "keaki_hip_group": "group", "keaki_hip_group_srs_g1": "group_srs_g1", "keaki_hip_group_fk": "group_fk"}[base]
     return stars, scalar
 
 
@@ -59,7 +59,7 @@ def rust_class(t):
     base = re.sub(r"\*(?:const|mut)\s*", "", t).strip()
     scalar = {"i32": "i32", "u32": "u32", "usize": "usize", "u64": "u64", "u8": "u8", "f32": "f32", "c_void": "void", "c_char": "c_char", "keaki_status": "i32",
               "keaki_hip_ctx": "ctx", "keaki_hip_srs_g1": "srs_g1", "keaki_hip_srs_g2": "srs_g2", "keaki_hip_fk_shard": "fk_shard", "()": "void", "i64": "i64",
-              "keaki_hip_group": "group", "keaki_hip_group_srs_g1": "group_srs_g1"}[base]
+              "keaki_hip_group": "group", "keaki_hip_group_srs_g1": "group_srs_g1", "keaki_hip_group_fk": "group_fk"}[base]
     return stars, scalar
 
 
@@ -89,7 +89,7 @@ def test_glue_calls_only_declared_symbols():
     declared = set(rust_functions())
     for rel in ("keaki/src/hip.rs", "keaki/tests/hip_parity.rs", "keaki/keaki-hip.patch"):
         text = open(os.path.join(RUST, rel)).read()
-        used = set(re.findall(r"\b(keaki_hip_\w+)\b", text)) - {"keaki_hip_sys", "keaki_hip_ctx", "keaki_hip_srs_g1", "keaki_hip_srs_g2", "keaki_hip_fk_shard", "keaki_hip_group", "keaki_hip_group_srs_g1"}
+        used = set(re.findall(r"\b(keaki_hip_\w+)\b", text)) - {"keaki_hip_sys", "keaki_hip_ctx", "keaki_hip_srs_g1", "keaki_hip_srs_g2", "keaki_hip_fk_shard", "keaki_hip_group", "keaki_hip_group_srs_g1", "keaki_hip_group_fk"}
         assert used <= declared, (rel, sorted(used - declared))
     glue = open(os.path.join(RUST, "keaki", "src", "hip.rs")).read()
     for sym in ("keaki_hip_msm_g1", "keaki_hip_kzg_open", "keaki_hip_kzg_verify", "keaki_hip_open_fk_poly", "keaki_hip_encap_batch", "keaki_hip_decap_batch",
@@ -138,7 +138,8 @@ def test_parity_constants_are_the_golden_vectors():
     assert "sharded_commit_over_a_device_group_matches_arkworks" in t and "hip::ShardedCommit::new" in t
     glue = open(os.path.join(RUST, "keaki", "src", "hip.rs")).read()
     for sym in ("keaki_hip_group_create", "keaki_hip_group_srs_g1_upload", "keaki_hip_group_msm_g1", "keaki_hip_group_kzg_open",
-                "keaki_hip_group_encap_batch", "keaki_hip_group_decap_batch", "keaki_hip_group_destroy", "KEAKI_HIP_DEVICES"):
+                "keaki_hip_group_encap_batch", "keaki_hip_group_decap_batch", "keaki_hip_group_destroy", "keaki_hip_group_fk_create", "keaki_hip_group_fk_open",
+                "keaki_hip_group_fk_free", "KEAKI_HIP_DEVICES"):
         assert sym in glue, sym
     # the sharded FK handle keeps the SRS alive
     assert re.search(r"_srs: Arc<HipSrs>", glue) and "srs: &Arc<HipSrs>" in glue
