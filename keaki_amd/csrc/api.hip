@@ -325,6 +325,8 @@ keaki_status keaki_hip_ctx_memory(keaki_hip_ctx* ctx, size_t* out4) {
   return KEAKI_OK;
 }
 
+void* keaki_hip_ctx_stream(const keaki_hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
 keaki_status keaki_hip_synchronize(keaki_hip_ctx* ctx) {
   CTX_GUARD(ctx);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -1,0 +1,121 @@
+// libkeaki_hip_rccl.so (include/keaki_hip_rccl.h): the three collectives of the one-process-per-GPU form over RCCL, on the context's stream.
+// Host code only. Links librccl; libkeaki_hip.so does not.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "../../include/keaki_hip_rccl.h"
+
+struct keaki_hip_rccl {
+  keaki_hip_ctx* ctx = nullptr;
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  void* gathered = nullptr;      // world x 96 bytes: the partials of the sharded MSM
+  void* partial = nullptr;       // 96 bytes
+  std::mutex mu;
+  std::string err;
+};
+
+namespace {
+thread_local std::string g_create_error;
+keaki_status rfail(keaki_hip_rccl* rc, keaki_status code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (rc) rc->err = buf; else g_create_error = buf;
+  return code;
+}
+#define NCCL_TRY(rc, call)                                                                                        \
+  do {                                                                                                            \
+    ncclResult_t r_ = (call);                                                                                     \
+    if (r_ != ncclSuccess) return rfail(rc, KEAKI_ERR_RCCL, "%s failed: %s", #call, ncclGetErrorString(r_));       \
+  } while (0)
+}  // namespace
+
+extern "C" {
+
+keaki_status keaki_hip_rccl_unique_id(uint8_t out128[128]) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  if (!out128) return rfail(nullptr, KEAKI_ERR_BAD_ARG, "rccl_unique_id: null pointer");
+  ncclUniqueId id;
+  NCCL_TRY(nullptr, ncclGetUniqueId(&id));
+  memcpy(out128, &id, 128);
+  return KEAKI_OK;
+}
+
+keaki_status keaki_hip_rccl_create(keaki_hip_ctx* ctx, const uint8_t id128[128], int32_t rank, int32_t world, keaki_hip_rccl** out) {
+  if (!ctx || !id128 || !out || world < 1 || rank < 0 || rank >= world) return rfail(nullptr, KEAKI_ERR_BAD_ARG, "rccl_create: bad argument");
+  *out = nullptr;
+  // the communicator must be created with the context's device current: a context-bound call of the main library sets it
+  keaki_status st = keaki_hip_synchronize(ctx);
+  if (st != KEAKI_OK) return rfail(nullptr, st, "rccl_create: %s", keaki_hip_last_error(ctx));
+  auto* rc = new keaki_hip_rccl();
+  rc->ctx = ctx; rc->rank = rank; rc->world = world;
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  ncclResult_t r = ncclCommInitRank(&rc->comm, world, id, rank);
+  if (r != ncclSuccess) { rfail(nullptr, KEAKI_ERR_RCCL, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, ncclGetErrorString(r)); delete rc; return KEAKI_ERR_RCCL; }
+  if (hipMalloc(&rc->gathered, (size_t)world * 96) != hipSuccess || hipMalloc(&rc->partial, 96) != hipSuccess) {
+    rfail(nullptr, KEAKI_ERR_OOM, "rccl_create: hipMalloc failed");
+    keaki_hip_rccl_destroy(rc);
+    return KEAKI_ERR_OOM;
+  }
+  *out = rc;
+  return KEAKI_OK;
+}
+
+void keaki_hip_rccl_destroy(keaki_hip_rccl* rc) {
+  if (!rc) return;
+  if (rc->ctx) (void)keaki_hip_synchronize(rc->ctx);
+  if (rc->comm) (void)ncclCommDestroy(rc->comm);
+  if (rc->gathered) (void)hipFree(rc->gathered);
+  if (rc->partial) (void)hipFree(rc->partial);
+  delete rc;
+}
+
+const char* keaki_hip_rccl_last_error(const keaki_hip_rccl* rc) {
+  if (!rc) return g_create_error.c_str();
+  thread_local std::string copy;
+  auto* r = const_cast<keaki_hip_rccl*>(rc);
+  std::lock_guard<std::mutex> lk(r->mu);
+  copy = r->err;
+  return copy.c_str();
+}
+
+keaki_status keaki_hip_rccl_all_gather(keaki_hip_rccl* rc, const void* d_send, void* d_recv, size_t bytes_per_rank) {
+  if (!rc) return KEAKI_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(rc->mu);
+  if (!d_send || !d_recv) return rfail(rc, KEAKI_ERR_BAD_ARG, "rccl_all_gather: null pointer");
+  NCCL_TRY(rc, ncclAllGather(d_send, d_recv, bytes_per_rank, ncclUint8, rc->comm, (hipStream_t)keaki_hip_ctx_stream(rc->ctx)));
+  return KEAKI_OK;
+}
+
+keaki_status keaki_hip_rccl_all_to_all(keaki_hip_rccl* rc, const void* d_send, void* d_recv, size_t bytes_per_peer) {
+  if (!rc) return KEAKI_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(rc->mu);
+  if (!d_send || !d_recv) return rfail(rc, KEAKI_ERR_BAD_ARG, "rccl_all_to_all: null pointer");
+  NCCL_TRY(rc, ncclAllToAll(d_send, d_recv, bytes_per_peer, ncclUint8, rc->comm, (hipStream_t)keaki_hip_ctx_stream(rc->ctx)));
+  return KEAKI_OK;
+}
+
+keaki_status keaki_hip_rccl_msm_g1(keaki_hip_rccl* rc, const keaki_hip_srs_g1* srs_chunk, const void* d_scalars, size_t n, void* d_out_jac) {
+  if (!rc) return KEAKI_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(rc->mu);
+  if (!srs_chunk || !d_out_jac) return rfail(rc, KEAKI_ERR_BAD_ARG, "rccl_msm_g1: null pointer");
+  keaki_status st = keaki_hip_msm_g1_dev(rc->ctx, srs_chunk, d_scalars, n, rc->partial);
+  if (st != KEAKI_OK) return rfail(rc, st, "rccl_msm_g1: %s", keaki_hip_last_error(rc->ctx));
+  // EC addition is not an RCCL reduction operator: all-gather the 96-byte partials, add them on every rank
+  NCCL_TRY(rc, ncclAllGather(rc->partial, rc->gathered, 96, ncclUint8, rc->comm, (hipStream_t)keaki_hip_ctx_stream(rc->ctx)));
+  st = keaki_hip_g1_sum_dev(rc->ctx, rc->gathered, (size_t)rc->world, d_out_jac);
+  if (st != KEAKI_OK) return rfail(rc, st, "rccl_msm_g1: %s", keaki_hip_last_error(rc->ctx));
+  return KEAKI_OK;
+}
+
+}  // extern "C"

@@ -6,5 +6,8 @@ fn main() {
         .expect("set KEAKI_HIP_LIB_DIR to the directory that contains libkeaki_hip.so");
     println!("cargo:rustc-link-search=native={dir}");
     println!("cargo:rustc-link-lib=dylib=keaki_hip");
+    if std::env::var("CARGO_FEATURE_RCCL").is_ok() {
+        println!("cargo:rustc-link-lib=dylib=keaki_hip_rccl"); // the optional RCCL collectives (include/keaki_hip_rccl.h)
+    }
     println!("cargo:rustc-link-arg=-Wl,-rpath,{dir}");
 }

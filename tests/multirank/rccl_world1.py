@@ -58,6 +58,23 @@ def main():
     torch.cuda.synchronize(dev)
     out["all_gather_ok"] = bool(torch.equal(send[:64 * 512], recv[:64 * 512]))
     out["all_gather_np_ok"] = bool(np.array_equal(shard.all_gather_np(np.arange(12, dtype=np.uint64)), np.arange(12, dtype=np.uint64)[None, :]))
+    # the torch-free companion library (include/keaki_hip_rccl.h): its own communicator on the same stream, world 1
+    from keaki_amd import rccl as R
+    rc = R.KeakiRccl(hip, R.unique_id(), 0, 1)
+    d_out2 = torch.zeros(12, dtype=torch.int64, device=dev)
+    for _ in range(2):
+        rc.msm_g1(sm.srs, d_s.data_ptr(), n, d_out2.data_ptr())
+    hip.synchronize()
+    out["shim_msm_ok"] = bool(np.array_equal(jac_to_affine_words(d_out2.cpu().numpy().view(np.uint64)), exp))
+    recv.zero_()
+    rc.all_to_all(send.data_ptr(), recv.data_ptr(), send.numel())
+    hip.synchronize()
+    out["shim_all_to_all_ok"] = bool(torch.equal(send, recv))
+    recv.zero_()
+    rc.all_gather(send.data_ptr(), recv.data_ptr(), 4096)
+    hip.synchronize()
+    out["shim_all_gather_ok"] = bool(torch.equal(send[:4096], recv[:4096]))
+    rc.close()
     shard.barrier()
     sm.close()
     hip.close()

@@ -28,6 +28,25 @@ def test_header_symbols_are_exported_and_bound():
     assert b"gfx950" in lib.keaki_hip_version()
 
 
+def test_rccl_companion_library_exports_its_header():
+    """include/keaki_hip_rccl.h (the optional RCCL collectives of the one-process-per-GPU form) against libkeaki_hip_rccl.so, its ctypes
+    binding and its Rust declarations; the MAIN library must not depend on RCCL."""
+    import subprocess
+    from keaki_amd import rccl
+    lib = rccl.load_rccl_library()
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "keaki_hip_rccl.h")).read(), flags=re.S)
+    syms = sorted(set(re.findall(r"\b(keaki_hip_rccl_[a-z0-9_]+)\s*\(", hdr)))
+    assert syms == sorted(rccl.EXPORTS) and len(syms) == 7
+    for s in syms:
+        assert hasattr(lib, s), s
+    rs = open(os.path.join(ROOT, "rust", "keaki-hip-sys", "src", "rccl.rs")).read()
+    assert sorted(set(re.findall(r"pub fn (keaki_hip_rccl_\w+)", rs))) == syms
+    needed = subprocess.run(["readelf", "-d", os.path.join(ROOT, "keaki_amd", "libkeaki_hip.so")], stdout=subprocess.PIPE, text=True).stdout
+    assert "librccl" not in needed, "libkeaki_hip.so must not link RCCL"
+    needed = subprocess.run(["readelf", "-d", os.path.join(ROOT, "keaki_amd", "libkeaki_hip_rccl.so")], stdout=subprocess.PIPE, text=True).stdout
+    assert "librccl" in needed and "libkeaki_hip.so" in needed
+
+
 def test_library_carries_gfx950_code_only():
     path = os.path.join(ROOT, "keaki_amd", "libkeaki_hip.so")
     blob = open(path, "rb").read()

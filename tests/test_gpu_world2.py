@@ -102,6 +102,8 @@ def test_rccl_executes_on_hardware_with_one_rank(multirank_runs):
     j = _json_line(run["log"])
     assert j["backend"] == "nccl" and j["world"] == 1
     assert j["msm_allgather_sum_ok"] and j["used_collective_output"] and j["all_to_all_ok"] and j["all_gather_ok"] and j["all_gather_np_ok"]
+    # libkeaki_hip_rccl.so (no PyTorch in the exchange): MSM + ncclAllGather + EC sum on the context's stream, all-to-all, all-gather
+    assert j["shim_msm_ok"] and j["shim_all_to_all_ok"] and j["shim_all_gather_ok"]
     run = multirank_runs["bench_rccl1"]
     assert run["rc"] == 0, run["log"][-3000:]
     j = _json_line(run["log"])
