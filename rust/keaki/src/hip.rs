@@ -556,6 +556,16 @@ pub fn active<E: Pairing>() -> bool {
     TypeId::of::<E>() == TypeId::of::<Bn254>() && std::env::var("KEAKI_HIP").map(|v| v != "off").unwrap_or(true)
 }
 
+/// Pairing work of fewer than `KEAKI_HIP_MIN_BATCH` items (default 8) stays on arkworks: ONE pairing on the GPU is bound by the instruction
+/// count of one lane pair (5.2 ms for a decapsulation, 5.3 ms for `verify`'s two pairings; profiles/r02_small_calls.txt) where a CPU core
+/// needs about a millisecond each -- the GPU wins from a handful of items on and by four orders of magnitude at 2^16. Used by the
+/// single-item `encapsulate` / `decapsulate` (1 item), `verify` (2 pairings) and the `vec_*` loops (their length). `KEAKI_HIP_MIN_BATCH=0`
+/// sends everything to the GPU (the parity test does that). MSM-shaped calls (`commit`, `open`, `open_fk`) always go to the GPU.
+pub fn active_batch<E: Pairing>(items: usize) -> bool {
+    let min = std::env::var("KEAKI_HIP_MIN_BATCH").ok().and_then(|v| v.parse::<usize>().ok()).unwrap_or(8);
+    active::<E>() && items >= min
+}
+
 /// Reinterpret `&A` as `&B` when they are the same type. The callers have established `E == Bn254`, which makes `E::G1` and
 /// `G1Projective` (etc.) one type; TypeId re-checks it, so a wrong call panics instead of transmuting.
 pub fn same<A: 'static, B: 'static>(a: &A) -> &B {

@@ -51,6 +51,11 @@ const KEM_GT_HEX: &str = concat!(
 );
 const KEM_KEY_HEX: &str = "e7f29112b1833c5614ca4457b23f10fce69eabfb19695af33781b81007d8c244";
 
+/// single-item calls and short vectors stay on arkworks by default (`hip::active_batch`): the parity tests want them on the GPU
+fn gpu_for_small_batches() {
+    std::env::set_var("KEAKI_HIP_MIN_BATCH", "0");
+}
+
 fn fr(s: &str) -> Fr {
     Fr::from_le_bytes_mod_order(&num_le(s))
 }
@@ -128,6 +133,7 @@ fn pairing_batch_matches_arkworks_on_random_points() {
 
 #[test]
 fn msm_commit_open_verify_match_arkworks() {
+    gpu_for_small_batches();
     let rng = &mut test_rng();
     for &n in &[1usize, 2, 33, 129, 1 << 12] {
         let setup = KZGSetup::<Bn254>::setup(Fr::rand(rng), n);
@@ -178,6 +184,7 @@ fn sharded_commit_over_a_device_group_matches_arkworks() {
 
 #[test]
 fn kem_vector_of_the_oracle_arkworks_and_gpu() {
+    gpu_for_small_batches();
     let tau = fr(KEM_TAU);
     let setup = KZGSetup::<Bn254>::setup(tau, 8);
     let com: G1Projective = G1Affine::new(fq(KEM_COM[0]), fq(KEM_COM[1])).into();
@@ -197,6 +204,7 @@ fn kem_vector_of_the_oracle_arkworks_and_gpu() {
 
 #[test]
 fn vec_flow_matches_serial_arkworks_loop() {
+    gpu_for_small_batches();
     // Laconic-OT shaped: vec_commit, vec_encrypt to "value i == b", vec_decrypt; GPU path and arkworks path from the same rng seed
     let n = 15usize; // domain 16
     let run = |hip_on: bool| {
