@@ -180,6 +180,16 @@ keaki_status keaki_hip_fk_shard_open(keaki_hip_ctx* ctx, keaki_hip_fk_shard* fk,
  * (pass omega^-1 and n^-1 for the inverse transform). */
 keaki_status keaki_hip_fr_fft(keaki_hip_ctx* ctx, uint64_t* data, uint32_t log2n, const uint64_t* omega, const uint64_t* scale_or_null);
 
+/* ---- vec_commit in one call: the body of vec::vec_commit (reference src/vec.rs:36-46) behind its padding draw -----------------------------
+ * values: n Fr (the vector), pad: the one random scalar the caller drew (src/vec.rs:31-33; NULL: none), together the first n + 1 evaluations
+ * over the domain of size d = 2^log2d (the rest are zero, as ark-poly's ifft pads). On the device, without the coefficients ever returning to
+ * the host: domain.ifft (omega_d_inv = the domain's group_gen_inv, inv_d = its size_inv), the FK23 openings (omega_2d ... as for
+ * keaki_hip_open_fk_poly) and the commitment (MSM over all d coefficients: trailing zeros, which DensePolynomial trims, contribute nothing).
+ * com_out_jac: u64[12] normalised Jacobian; proofs_out_aff: d affine points. Needs d <= len(srs). */
+keaki_status keaki_hip_vec_commit(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, const uint64_t* values, size_t n, const uint64_t* pad, uint32_t log2d,
+                                  const uint64_t* omega_d_inv, const uint64_t* inv_d, const uint64_t* omega_2d, const uint64_t* omega_2d_inv,
+                                  const uint64_t* inv_2d, uint64_t* com_out_jac, uint64_t* proofs_out_aff);
+
 /* ---- KZG `open` in one call (scope row f-4) -------------------------------------------------------------------------
  * Replaces the body of `open` (reference src/kzg.rs:104-124): value = p(point) and proof = commit(q), q = (p - p(point)) / (x - point),
  * with the synthetic division done on the device (blockwise Horner recurrence) right in front of the MSM, so the n - 1 quotient

@@ -880,6 +880,40 @@ keaki_status keaki_hip_fr_fft(keaki_hip_ctx* ctx, uint64_t* data, uint32_t log2n
   return download(ctx, data, b, n * 32);
 }
 
+// ---- vec_commit in one call (src/vec.rs:22-49 behind the padding draw): iFFT -> FK23 openings -> commit, coefficients never leave the device ----
+keaki_status keaki_hip_vec_commit(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, const uint64_t* values, size_t n, const uint64_t* pad, uint32_t log2d,
+                                  const uint64_t* omega_d_inv, const uint64_t* inv_d, const uint64_t* omega_2d, const uint64_t* omega_2d_inv,
+                                  const uint64_t* inv_2d, uint64_t* com_out_jac, uint64_t* proofs_out_aff) {
+  CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.vec_commit");
+  if (!srs || (n && !values) || !omega_d_inv || !inv_d || !omega_2d || !omega_2d_inv || !inv_2d || !com_out_jac || !proofs_out_aff || log2d > 27)
+    return fail(ctx, KEAKI_ERR_BAD_ARG, "vec_commit: bad argument");
+  SRS_CHECK(ctx, srs, "vec_commit");
+  const size_t d = (size_t)1 << log2d, m = n + (pad ? 1 : 0);
+  if (m > d) return fail(ctx, KEAKI_ERR_BAD_ARG, "vec_commit: %zu evaluations do not fit the domain of %zu", m, d);
+  if (d > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "open_fk: %zu coefficients but the SRS holds %zu points", d, srs->n);
+  std::lock_guard<std::recursive_mutex> hl(srs->mu);
+  // one staging block: coefficients (d Fr) | twiddles of the iFFT (d/2 + 1) | FK23 scalar work | FK23 point work (2d Jacobian) | proofs (d affine) | commitment
+  const size_t o_c = 0, o_tw = o_c + d * 32, o_fr = o_tw + (d / 2 + 1) * 32, o_g = o_fr + (4 * d + d / 2 + 2) * 32, o_out = o_g + 2 * d * 96,
+               o_com = o_out + d * 64, total = o_com + 96;
+  ST_TRY(reserve(ctx, ctx->io_d, total));
+  char* b = (char*)ctx->io_d.p;
+  hipStream_t st = ctx->stream;
+  if (m < d) HIP_TRY(ctx, hipMemsetAsync(b + o_c + m * 32, 0, (d - m) * 32, st));          // evaluations beyond the padded vector are zero (ark-poly's ifft resizes)
+  if (n) HIP_TRY(ctx, hipMemcpyAsync(b + o_c, values, n * 32, hipMemcpyHostToDevice, st));
+  if (pad) HIP_TRY(ctx, hipMemcpyAsync(b + o_c + n * 32, pad, 32, hipMemcpyHostToDevice, st));
+  ST_TRY(fr_fft_run(ctx, b + o_c, log2d, omega_d_inv, inv_d, b + o_tw));                  // domain.ifft (src/vec.rs:37)
+  const keaki_status st_fk = open_fk_poly_run(ctx, srs->d, &srs->fk_hat_s, &srs->fk_log2d, log2d, b + o_c, omega_2d, omega_2d_inv, inv_2d, b + o_fr, b + o_g, b + o_out);   // :40
+  fk_account(ctx, srs);
+  ST_TRY(st_fk);
+  const auto tb = srs_tables(srs);
+  ST_TRY(msm_g1_run(ctx, srs->d, srs->n, b + o_c, d, b + o_com, tb.first, tb.second));     // :46 (trailing zero coefficients contribute nothing)
+  HIP_TRY(ctx, hipMemcpyAsync(com_out_jac, b + o_com, 96, hipMemcpyDeviceToHost, st));
+  ST_TRY(download(ctx, proofs_out_aff, b + o_out, d * 64));
+  resolve_timing(ctx);
+  return KEAKI_OK;
+}
+
 // ---- FK23 sharded over `world` = 2^k ranks: one handle per rank, the caller runs the exchanges between the steps -----------------
 struct keaki_hip_fk_shard {
   FkShard plan;

@@ -24,7 +24,7 @@ EXPORTS = [
     "keaki_hip_pairing_batch", "keaki_hip_pairing_batch_dev",
     "keaki_hip_encap_batch", "keaki_hip_encap_batch_dev", "keaki_hip_decap_batch", "keaki_hip_decap_batch_dev",
     "keaki_hip_selftest_field", "keaki_hip_open_fk", "keaki_hip_open_fk_poly", "keaki_hip_srs_g1_precompute_fk", "keaki_hip_fk_shard_create", "keaki_hip_fk_shard_free", "keaki_hip_fk_shard_sizes", "keaki_hip_fk_shard_setup", "keaki_hip_fk_shard_open", "keaki_hip_fr_fft", "keaki_hip_srs_g1_check", "keaki_hip_g2_check", "keaki_hip_kzg_open", "keaki_hip_kzg_verify", "keaki_hip_final_exp_batch", "keaki_hip_miller_loop_batch", "keaki_hip_g2_prepare", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
-    "keaki_hip_last_fk_ms", "keaki_hip_ctx_stream", "keaki_hip_ctx_set_option", "keaki_hip_debug_set_alloc_limit", "keaki_hip_ctx_memory", "keaki_hip_ctx_trim", "keaki_hip_kzg_quotient",
+    "keaki_hip_last_fk_ms", "keaki_hip_ctx_stream", "keaki_hip_ctx_set_option", "keaki_hip_debug_set_alloc_limit", "keaki_hip_ctx_memory", "keaki_hip_ctx_trim", "keaki_hip_kzg_quotient", "keaki_hip_vec_commit",
     "keaki_hip_group_create", "keaki_hip_group_destroy", "keaki_hip_group_size", "keaki_hip_group_ctx", "keaki_hip_group_last_error",
     "keaki_hip_group_srs_g1_upload", "keaki_hip_group_srs_g1_len", "keaki_hip_group_srs_g1_free", "keaki_hip_group_msm_g1",
     "keaki_hip_group_kzg_open", "keaki_hip_group_encap_batch", "keaki_hip_group_decap_batch",
@@ -115,6 +115,7 @@ def load_library():
         lib.keaki_hip_ctx_stream.argtypes = [vp]
         lib.keaki_hip_ctx_stream.restype = vp
         lib.keaki_hip_kzg_quotient.argtypes = [vp, vp, sz, vp, vp, vp]
+        lib.keaki_hip_vec_commit.argtypes = [vp, vp, vp, sz, vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp]
         lib.keaki_hip_group_create.argtypes = [C.POINTER(i32), sz, C.POINTER(vp)]
         lib.keaki_hip_group_destroy.argtypes = [vp]
         lib.keaki_hip_group_destroy.restype = None
@@ -243,6 +244,15 @@ class KeakiHip:
         q = np.zeros((max(n - 1, 0), 4), np.uint64); val = np.zeros(4, np.uint64)
         self._ck(self.lib.keaki_hip_kzg_quotient(self.ctx, _ptr(c) if n else None, n, _ptr(_np(point)), _ptr(q) if n > 1 else None, _ptr(val)))
         return q, val
+
+    def vec_commit(self, srs: "SrsG1", values, pad, log2d: int, omega_d_inv, inv_d, omega_2d, omega_2d_inv, inv_2d):
+        """the body of vec::vec_commit behind the padding draw -> (commitment as normalised Jacobian u64[12], d affine proofs)"""
+        v = _np(values, 4); d = 1 << log2d
+        com = np.zeros(12, np.uint64); proofs = np.zeros((d, 8), np.uint64)
+        self._ck(self.lib.keaki_hip_vec_commit(self.ctx, srs.handle, _ptr(v) if v.shape[0] else None, v.shape[0], _ptr(_np(pad)) if pad is not None else None, log2d,
+                                               _ptr(_np(omega_d_inv)), _ptr(_np(inv_d)), _ptr(_np(omega_2d)), _ptr(_np(omega_2d_inv)), _ptr(_np(inv_2d)),
+                                               _ptr(com), _ptr(proofs)))
+        return com, proofs
 
     def set_timing(self, on: bool):
         self._ck(self.lib.keaki_hip_set_timing(self.ctx, 1 if on else 0))

@@ -411,10 +411,29 @@ std::pair<DensePolynomial, std::vector<G1>> vec_commit_openings(Rng& rng, const 
   std::vector<G1> proofs = kzg::open_fk(setup, p_coeff, p_coeff.size()).unwrap();  // :40
   return {trimmed(std::move(p_coeff)), std::move(proofs)};
 }
+G1 vec_commit_flat(Rng& rng, const kzg::KZGSetup& setup, const Fr* v, size_t n, uint64_t* proofs_out) {
+  const size_t d = n + PADDING_LEN;
+  Radix2Domain domain = Radix2Domain::create(d);     // src/vec.rs:36
+  const Device& dev = *setup.device();
+  if (!dev.group() && domain.size >= (size_t(1) << 12) && domain.size <= setup.g1_pow().size()) {
+    const Fr pad = fr_rand(rng);                     // :31-33, the only draw
+    unsigned log_size = 0;
+    while ((size_t(1) << log_size) < domain.size) log_size++;
+    Radix2Domain d2 = Radix2Domain::create(2 * domain.size);
+    uint64_t jac[12];
+    dev.check(keaki_hip_vec_commit(dev.ctx(), setup.srs(), n ? v[0].l : nullptr, n, pad.l, log_size, domain.group_gen_inv.l, domain.size_inv.l,
+                                   d2.group_gen.l, d2.group_gen_inv.l, d2.size_inv.l, jac, proofs_out));
+    return jac_to_g1(jac);
+  }
+  auto cp = vec_commit_openings(rng, setup, std::vector<Fr>(v, v + n));
+  for (size_t i = 0; i < cp.second.size(); i++) memcpy(proofs_out + 8 * i, cp.second[i].w.data(), 64);
+  return kzg::commit(setup, cp.first).unwrap();      // :46
+}
 std::pair<G1, std::vector<G1>> vec_commit(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v) {
-  auto cp = vec_commit_openings(rng, setup, v);
-  G1 com = kzg::commit(setup, cp.first).unwrap();    // :46
-  return {com, std::move(cp.second)};
+  static_assert(sizeof(G1) == 64, "a G1 is eight u64 words");
+  std::vector<G1> proofs(Radix2Domain::create(v.size() + PADDING_LEN).size);
+  G1 com = vec_commit_flat(rng, setup, v.data(), v.size(), proofs.empty() ? nullptr : proofs[0].w.data());
+  return {com, std::move(proofs)};
 }
 
 std::vector<enc::Ciphertext> vec_encrypt(Rng& rng, const kzg::KZGSetup& setup, const G1& com, const std::vector<Fr>& points,

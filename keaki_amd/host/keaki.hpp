@@ -188,6 +188,10 @@ struct Radix2Domain {
 };
 // src/vec.rs:22-49
 std::pair<G1, std::vector<G1>> vec_commit(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v);
+// the same on contiguous buffers: proofs_out = domain_size affine points (8 words each). For domains of >= 2^12 evaluations on a single-GPU
+// device everything behind the padding draw is ONE device call (keaki_hip_vec_commit: iFFT, FK23 openings, commit; the coefficients never
+// return to the host); smaller domains and group devices take the steps one by one. Same values either way.
+G1 vec_commit_flat(Rng& rng, const kzg::KZGSetup& setup, const Fr* v, size_t n, uint64_t* proofs_out);
 // lines :27-37 of it (padding draw, iFFT): the coefficient vector over the whole domain, not trimmed
 std::vector<Fr> vec_commit_coeffs(Rng& rng, const kzg::KZGSetup& setup, const std::vector<Fr>& v);
 // lines :27-44 of it (padding draw, iFFT, open_fk): the dense coefficient vector and the proofs, without the final commit

@@ -264,9 +264,9 @@ int keaki_host_decrypt(void* s, const uint64_t* proof, const uint64_t* ct_g2, co
 // vec_commit: v has n scalars; outputs commitment and `domain_size` proofs (caller sizes proofs_out with keaki_host_domain(n+1))
 int keaki_host_vec_commit(void* rng, void* s, const uint64_t* v, size_t n, uint64_t* com_out, uint64_t* proofs_out) {
   return guard([&] {
-    auto r = vec::vec_commit(*(Rng*)rng, ((Setup*)s)->s, frs_of(v, n));
-    memcpy(com_out, r.first.w.data(), 64);
-    for (size_t i = 0; i < r.second.size(); i++) memcpy(proofs_out + 8 * i, r.second[i].w.data(), 64);
+    static_assert(sizeof(Fr) == 32, "Fr is four u64 limbs");
+    G1 com = vec::vec_commit_flat(*(Rng*)rng, ((Setup*)s)->s, reinterpret_cast<const Fr*>(v), n, proofs_out);      // straight into the caller's array
+    memcpy(com_out, com.w.data(), 64);
     return 0;
   });
 }

@@ -104,6 +104,11 @@ extern "C" {
     pub fn keaki_hip_fk_shard_open(ctx: *mut keaki_hip_ctx, fk: *mut keaki_hip_fk_shard, step: i32, coeffs: *const u64, d_send: *mut c_void,
                                    d_recv: *mut c_void, proofs_out_aff: *mut u64) -> keaki_status;
 
+    // vec_commit's body in one call (src/vec.rs:36-46): iFFT, FK23 openings, commit, coefficients stay on the device
+    pub fn keaki_hip_vec_commit(ctx: *mut keaki_hip_ctx, srs: *mut keaki_hip_srs_g1, values: *const u64, n: usize, pad: *const u64, log2d: u32,
+                                omega_d_inv: *const u64, inv_d: *const u64, omega_2d: *const u64, omega_2d_inv: *const u64, inv_2d: *const u64,
+                                com_out_jac: *mut u64, proofs_out_aff: *mut u64) -> keaki_status;
+
     // ---- KZG open / verify in one call (src/kzg.rs:104-124, :127-151)
     pub fn keaki_hip_kzg_open(ctx: *mut keaki_hip_ctx, srs: *const keaki_hip_srs_g1, coeffs: *const u64, n: usize, point: *const u64,
                               proof_out_jac: *mut u64, value_out: *mut u64) -> keaki_status;

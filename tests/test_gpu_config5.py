@@ -141,3 +141,38 @@ def test_laconic_ot_2p20_bits_vs_oracle(K, oc, py):
         assert not (other == unchosen).all(axis=1).any()
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("log2d,n,with_pad", [(12, 4095, True), (12, 3000, True), (13, 8192, False), (4, 7, True)])
+def test_vec_commit_one_call_vs_oracle(oc, py, hip, log2d, n, with_pad):
+    """keaki_hip_vec_commit = the body of vec::vec_commit (src/vec.rs:36-46) in one device call (iFFT -> FK23 openings -> commit, the coefficients
+    never return to the host): commitment and sampled proofs against the oracle's own iFFT, quotient and MSM; evaluations beyond the padded
+    vector are zero (ark-poly's ifft pads), a vector that fills the domain has no pad."""
+    from bench import random_fr_limbs
+    from keaki_amd.hip import jac_to_affine_words
+    d = 1 << log2d
+    g1, _ = oc.generators()
+    tau = 987654321987654321 % oc.R_MOD
+    pw, acc = [], 1
+    for _ in range(d):
+        pw.append(acc); acc = acc * tau % oc.R_MOD
+    srs_pts = hip.g1_mul_batch(g1, mont(oc, pw))
+    srs = hip.srs_g1_upload(srs_pts)
+    hip.srs_g1_precompute(srs)
+    try:
+        v = random_fr_limbs(n, 7700 + n)
+        pad = random_fr_limbs(1, 7800 + n)[0] if with_pad else None
+        wd, w2 = py.fr_root_of_unity(d), py.fr_root_of_unity(2 * d)
+        m1 = lambda x: mont(oc, [x])[0]
+        com, proofs = hip.vec_commit(srs, v, pad, log2d, m1(pow(wd, -1, py.R)), m1(pow(d, -1, py.R)), m1(w2), m1(pow(w2, -1, py.R)), m1(pow(2 * d, -1, py.R)))
+        evals = np.zeros((d, 4), np.uint64)
+        evals[:n] = v
+        if with_pad:
+            evals[n] = pad
+        coeffs = oc.fr_fft(evals, m1(pow(wd, -1, py.R)), m1(pow(d, -1, py.R)))
+        assert np.array_equal(jac_to_affine_words(com), oc.msm_g1(srs_pts, coeffs, threads=NCPU))
+        for i in sorted({0, 1, n - 1, min(n, d - 1), d - 1}):
+            exp, val = oracle_opening(oc, srs_pts, coeffs, m1(pow(wd, i, py.R)))
+            assert np.array_equal(val, evals[i]) and np.array_equal(proofs[i], exp), i
+    finally:
+        srs.free()
