@@ -393,6 +393,35 @@ pub fn open_fk(srs: &HipSrs, coeffs: &[Fr], omega_2d: &Fr, omega_2d_inv: &Fr, in
     out.chunks_exact(8).map(|w| g1_from_words(w).into()).collect()
 }
 
+/// Whether `vec_commit` takes the one-call device path: a domain of at least 2^12 evaluations that the SRS covers, on a single-GPU device
+/// (a device group runs the steps one by one: its FK23 openings and its commit are sharded over the members).
+pub fn fused_vec_commit(domain_size: usize, srs_len: usize) -> bool {
+    Device::global().group.is_null() && domain_size >= (1 << 12) && domain_size <= srs_len
+}
+
+/// The body of `vec_commit` (src/vec.rs:36-46) behind its padding draw, in ONE device call: `padded` = the vector and the padding scalar,
+/// `size` = the domain size (`Radix2EvaluationDomain::new(padded.len())`'s). Returns the commitment and the `size` proofs.
+pub fn vec_commit(srs: &HipSrs, padded: &[Fr], size: usize) -> (G1Projective, Vec<G1Projective>) {
+    use ark_poly::{EvaluationDomain, Radix2EvaluationDomain};
+    let dev = Device::global();
+    assert!(size.is_power_of_two() && padded.len() <= size && size <= srs.len());
+    let dom = Radix2EvaluationDomain::<Fr>::new(size).unwrap();
+    let dom2 = Radix2EvaluationDomain::<Fr>::new(2 * size).unwrap();
+    let one = |x: &Fr| fr_ptr(core::slice::from_ref(x));
+    let mut com = [0u64; 12];
+    let mut out = vec![0u64; 8 * size];
+    dev.check(
+        unsafe {
+            sys::keaki_hip_vec_commit(
+                dev.ctx, srs.srs(), fr_ptr(padded), padded.len(), core::ptr::null(), size.trailing_zeros(), one(&dom.group_gen_inv), one(&dom.size_inv),
+                one(&dom2.group_gen), one(&dom2.group_gen_inv), one(&dom2.size_inv), com.as_mut_ptr(), out.as_mut_ptr(),
+            )
+        },
+        "vec_commit",
+    );
+    (g1_from_jac(&com), out.chunks_exact(8).map(|w| g1_from_words(w).into()).collect())
+}
+
 /// The collectives a sharded `open_fk` owes between its steps: implemented by the application over its communication library (RCCL:
 /// `ncclAllToAll`-style exchange with equal splits, `ncclAllGather`) on DEVICE buffers; both must have completed when they return.
 pub trait FkExchange {

@@ -105,6 +105,7 @@ def test_patch_touches_the_cited_call_sites_and_applies():
     for f in ("Cargo.toml", "src/lib.rs", "src/kzg.rs", "src/kem.rs", "src/vec.rs"):
         assert "+++ b/%s" % f in patch
     for needle in ("crate::hip::commit", "crate::hip::open(", "crate::hip::verify", "crate::hip::open_fk", "crate::hip::encap_batch", "crate::hip::decap_batch",
+                   "crate::hip::vec_commit", "crate::hip::fused_vec_commit", "crate::hip::active_batch::<E>(",
                    'hip = ["dep:keaki-hip-sys"'):
         assert needle in patch, needle
     ref = "/root/reference"
