@@ -458,6 +458,7 @@ def main():
         t0 = time.perf_counter()
         ls = K.KZGSetup.setup(lrng.fr_rand(), 2 * ln, dev_index)
         K.precompute_open_fk(ls, 2 * ln)
+        K.kem_prepare(ls, ln)                              # the tables of encapsulation that depend on the setup only (generators, [tau]_2, e(g1, g2))
         l_setup = time.perf_counter() - t0
         np_rng = np.random.default_rng(7)
         bits = np_rng.integers(0, 2, ln)

@@ -247,6 +247,10 @@ keaki_status keaki_hip_encap_batch(keaki_hip_ctx* ctx, const uint64_t* com_aff, 
 keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff, const void* d_tau_g2_aff,
                                        const void* d_points, const void* d_values, const void* d_r, size_t n,
                                        void* d_ct_out_aff, void* d_gt_out, void* d_key_out, size_t msg_len);
+/* Setup-time (optional): everything of encap_batch that depends on the SETUP only -- the fixed-base window tables of g1, g2 and [tau]_2, the
+ * line sequence of g2 and, for batch_hint >= 65,536, the GT table of e(g1, g2) -- built now instead of inside the first large encap_batch of
+ * the context (~60 ms). The KEM analogue of keaki_hip_srs_g1_precompute; results never depend on it. */
+keaki_status keaki_hip_encap_prepare(keaki_hip_ctx* ctx, const uint64_t* tau_g2_aff, size_t batch_hint);
 /* decap_batch (src/kem.rs:55-72): gt[i] = serialize(e(proofs[i], cts[i])), key[i] = BLAKE3-XOF(gt[i]) */
 keaki_status keaki_hip_decap_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_aff, const uint64_t* cts_aff, size_t n,
                                    uint8_t* gt_out, uint8_t* key_out, size_t msg_len);

@@ -596,18 +596,15 @@ static keaki_status gt_table_of(keaki_hip_ctx* ctx, const void* d_p_aff, void* d
 }
 
 // ---- KEM composites ------------------------------------------------------------------------------------------
-keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff, const void* d_tau_g2_aff, const void* d_points,
-                                       const void* d_values, const void* d_r, size_t n, void* d_ct_out_aff, void* d_gt_out, void* d_key_out,
-                                       size_t msg_len) {
-  CTX_GUARD(ctx);
-  TRACE_SCOPE("keaki.encap");
-  if (n == 0) return KEAKI_OK;
-  if (!d_com_aff || !d_tau_g2_aff || !d_points || !d_values || !d_r || !d_ct_out_aff || (!d_gt_out && !d_key_out) || msg_len > 65536)
-    return fail(ctx, KEAKI_ERR_BAD_ARG, "encap_batch: bad argument");
-  ST_TRY(reserve(ctx, ctx->tmp_a, n * G1_AFF_BYTES));
+// `prep`: build what depends on the SETUP only (generator tables, the line sequence of g2, the table of [tau]_2, the GT table of e(g1, g2)) for
+// batches of n items, and stop: keaki_hip_encap_prepare. Nothing per item, nothing per commitment.
+static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_aff, const void* d_tau_g2_aff, const void* d_points,
+                               const void* d_values, const void* d_r, size_t n, void* d_ct_out_aff, void* d_gt_out, void* d_key_out,
+                               size_t msg_len) {
+  if (!prep) ST_TRY(reserve(ctx, ctx->tmp_a, n * G1_AFF_BYTES));
   ST_TRY(reserve(ctx, ctx->tmp_c, G2_AFF_BYTES));
   void* gt = d_gt_out;
-  if (!gt) { ST_TRY(reserve(ctx, ctx->tmp_b, n * 384)); gt = ctx->tmp_b.p; }
+  if (!gt && !prep) { ST_TRY(reserve(ctx, ctx->tmp_b, n * 384)); gt = ctx->tmp_b.p; }
   // generator g2 in device memory for the pairing's second slot (src/kem.rs:30 pairs with E::G2Affine::generator())
   ST_TRY(g2_generator_to(ctx, ctx->tmp_c.p));
   // window widths of the fixed-base tables: 16 bits for bases that outlive a batch (generators: per context, [tau]_2: per setup),
@@ -651,7 +648,7 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
         memcpy(ctx->fb_tau_pt, tau_host, 128);
         ctx->fb_tau_valid = true;
       }
-      ST_TRY(encap_g2_fixed_run(ctx, ctx->fb_tau.p, FB_WB_LONG, ctx->fb_g2_gen.p, FB_WB_LONG, d_points, d_r, n, d_ct_out_aff));
+      if (!prep) ST_TRY(encap_g2_fixed_run(ctx, ctx->fb_tau.p, FB_WB_LONG, ctx->fb_g2_gen.p, FB_WB_LONG, d_points, d_r, n, d_ct_out_aff));
     } else {
       constexpr uint32_t FB_WB_SMALL = 8;
       const size_t FBX = fb_table_entries(FB_WB_SMALL);
@@ -670,7 +667,7 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
         memcpy(ctx->fbs_tau_pt, tau_host, 128);
         ctx->fbs_tau_valid = true;
       }
-      ST_TRY(encap_g2_fixed_run(ctx, ctx->fbs_tau.p, FB_WB_SMALL, ctx->fbs_g2_gen.p, FB_WB_SMALL, d_points, d_r, n, d_ct_out_aff));
+      if (!prep) ST_TRY(encap_g2_fixed_run(ctx, ctx->fbs_tau.p, FB_WB_SMALL, ctx->fbs_g2_gen.p, FB_WB_SMALL, d_points, d_r, n, d_ct_out_aff));
     }
   }
   // window widths of the GT tables. The constant B = e(g1, g2) is tabulated once per context: 20-bit windows (13 products per item, 2.6 GB;
@@ -685,17 +682,20 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
   const bool wbb_env = ctx->tune.gt_wb_b != 0;          // Tuning::gt_wb_b / encap_gt (the environment is read in keaki_hip_ctx_create only)
   const bool gt_env = ctx->tune.encap_gt >= 0;
   const size_t gt_threshold = gt_env ? (size_t)ctx->tune.encap_gt : (size_t)65536;
-  uint64_t com_host[8];
-  HIP_TRY(ctx, hipMemcpyAsync(com_host, d_com_aff, 64, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->seen_com_runs && memcmp(com_host, ctx->seen_com, 64) == 0) {
-    if (ctx->seen_com_runs < 1000000) ctx->seen_com_runs++;
-  } else {
-    memcpy(ctx->seen_com, com_host, 64);
-    ctx->seen_com_runs = 1;
+  uint64_t com_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool a_cached = false;
+  if (!prep) {
+    HIP_TRY(ctx, hipMemcpyAsync(com_host, d_com_aff, 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->seen_com_runs && memcmp(com_host, ctx->seen_com, 64) == 0) {
+      if (ctx->seen_com_runs < 1000000) ctx->seen_com_runs++;
+    } else {
+      memcpy(ctx->seen_com, com_host, 64);
+      ctx->seen_com_runs = 1;
+    }
+    a_cached = ctx->gt_b_ready && ctx->gt_a_valid && memcmp(com_host, ctx->gt_a_com, 64) == 0;
   }
-  const bool a_cached = ctx->gt_b_ready && ctx->gt_a_valid && memcmp(com_host, ctx->gt_a_com, 64) == 0;
-  const bool use_gt = n >= gt_threshold || (!gt_env && (a_cached || ctx->seen_com_runs >= 3));
+  const bool use_gt = n >= gt_threshold || (!prep && !gt_env && (a_cached || ctx->seen_com_runs >= 3));
   if (use_gt) {
     // GT_i = A^(r_i) B^(-beta_i r_i) with A = e(C, g2), B = e(g1, g2) (see pairing.hip.h): no pairing per item
     ST_TRY(reserve(ctx, ctx->gt_base, G1_AFF_BYTES + 320 * (G1_AFF_BYTES + 384)));   // a point | 2^s multiples | their pairings
@@ -719,6 +719,7 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
       ctx->gt_b_ready = true;
       ctx->gt_a_valid = false;                    // gt_base now holds B's powers
     }
+    if (prep) return KEAKI_OK;
     // A depends on the commitment only: reuse the table while the caller keeps encrypting to the same commitment
     if (!ctx->gt_a_valid || memcmp(com_host, ctx->gt_a_com, 64) != 0) {
       ctx->gt_a_valid = false;
@@ -735,6 +736,7 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
     }
     ST_TRY(gt_encap_exp_run(ctx, ctx->gt_tab_a.p, ctx->gt_a_wb, ctx->gt_tab_b.p, ctx->gt_b_wb, d_values, d_r, n, gt));
   } else {
+    if (prep) return KEAKI_OK;
     // per-item pairing e(r_i (C - beta_i g1), g2) with the tabulated lines of g2
     if (use_tables) {
       ST_TRY(g1_fb_table_run(ctx, d_com_aff, (char*)ctx->fb_scalars.p + FBL * 32, ctx->fb_com.p, FB_WB_BATCH));
@@ -745,6 +747,30 @@ keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff
     ST_TRY(pairing_run(ctx, ctx->tmp_a.p, ctx->tmp_c.p, 0, n, gt, ctx->g2gen_lines.p));
   }
   if (d_key_out && msg_len) ST_TRY(blake3_gt_run(ctx, gt, n, d_key_out, msg_len));
+  return KEAKI_OK;
+}
+keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff, const void* d_tau_g2_aff, const void* d_points,
+                                       const void* d_values, const void* d_r, size_t n, void* d_ct_out_aff, void* d_gt_out, void* d_key_out,
+                                       size_t msg_len) {
+  CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.encap");
+  if (n == 0) return KEAKI_OK;
+  if (!d_com_aff || !d_tau_g2_aff || !d_points || !d_values || !d_r || !d_ct_out_aff || (!d_gt_out && !d_key_out) || msg_len > 65536)
+    return fail(ctx, KEAKI_ERR_BAD_ARG, "encap_batch: bad argument");
+  return encap_impl(ctx, false, d_com_aff, d_tau_g2_aff, d_points, d_values, d_r, n, d_ct_out_aff, d_gt_out, d_key_out, msg_len);
+}
+// Setup-time: everything of encap_batch that depends on the setup only, for batches of `batch_hint` items (the KEM analogue of
+// keaki_hip_srs_g1_precompute): fixed-base window tables of g1, g2 and [tau]_2, the line sequence of g2, and -- for hints >= 65,536 (or the
+// threshold of option "encap_gt") -- the GT table of e(g1, g2) (2.6 GB; the 16-bit one when that does not fit). ~60 ms that the first
+// large encap_batch of a context would otherwise pay. Results never depend on it.
+keaki_status keaki_hip_encap_prepare(keaki_hip_ctx* ctx, const uint64_t* tau_g2_aff, size_t batch_hint) {
+  CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.encap_prepare");
+  if (!tau_g2_aff) return fail(ctx, KEAKI_ERR_BAD_ARG, "encap_prepare: null pointer");
+  if (batch_hint == 0) return KEAKI_OK;
+  ST_TRY(upload(ctx, ctx->io_e, tau_g2_aff, 128));
+  ST_TRY(encap_impl(ctx, true, nullptr, ctx->io_e.p, nullptr, nullptr, nullptr, batch_hint, nullptr, nullptr, nullptr, 0));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return KEAKI_OK;
 }
 keaki_status keaki_hip_decap_batch_dev(keaki_hip_ctx* ctx, const void* d_proofs_aff, const void* d_cts_aff, size_t n, void* d_gt_out,

@@ -306,6 +306,19 @@ std::vector<uint8_t> decapsulate(const kzg::KZGSetup& setup, const G1& proof, co
   return key;
 }
 
+void prepare(const kzg::KZGSetup& setup, size_t batch_hint) {
+  const Device& dev = *setup.device();
+  if (dev.group() && batch_hint >= GROUP_MIN_ITEMS) {
+    const size_t N = dev.members(), share = (batch_hint + N - 1) / N;
+    for (size_t i = 0; i < N; i++) {
+      keaki_hip_ctx* c = keaki_hip_group_ctx(dev.group(), i);
+      const int st = keaki_hip_encap_prepare(c, setup.tau_g2().w.data(), share);
+      if (st != KEAKI_OK) throw HipError(st, keaki_hip_last_error(c));
+    }
+    return;
+  }
+  dev.check(keaki_hip_encap_prepare(dev.ctx(), setup.tau_g2().w.data(), batch_hint));
+}
 }  // namespace kem
 
 namespace enc {

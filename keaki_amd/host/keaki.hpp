@@ -168,6 +168,9 @@ namespace kem {
 std::pair<G2, std::vector<uint8_t>> encapsulate(Rng& rng, const kzg::KZGSetup& setup, const G1& commitment, const Fr& point,
                                                 const Fr& value, size_t msg_len);
 std::vector<uint8_t> decapsulate(const kzg::KZGSetup& setup, const G1& proof, const G2& ciphertext, size_t msg_len);
+// setup-time (optional): the tables of encapsulation that depend on the setup only (generators, [tau]_2, e(g1, g2)), for batches of
+// `batch_hint` items per call -- on every member of a group device for its share. Like the SRS window tables: results never depend on it.
+void prepare(const kzg::KZGSetup& setup, size_t batch_hint);
 }  // namespace kem
 
 namespace enc {

@@ -237,6 +237,9 @@ int keaki_host_encapsulate(void* rng, void* s, const uint64_t* com, const uint64
     return 0;
   });
 }
+int keaki_host_kem_prepare(void* s, size_t batch_hint) {
+  return guard([&] { kem::prepare(((Setup*)s)->s, batch_hint); return 0; });
+}
 int keaki_host_decapsulate(void* s, const uint64_t* proof, const uint64_t* ct, size_t msg_len, uint8_t* key_out) {
   return guard([&] {
     auto k = kem::decapsulate(((Setup*)s)->s, g1_of(proof), g2_of(ct), msg_len);

@@ -337,6 +337,11 @@ def encapsulate(rng: Rng, setup: KZGSetup, commitment, point, value, msg_len: in
     return ct, key[:msg_len].tobytes()
 
 
+def kem_prepare(setup: KZGSetup, batch_hint: int) -> None:
+    """setup-time: the tables of encapsulation that depend on the setup only, for batches of `batch_hint` items (keaki::kem::prepare)"""
+    _ck(_lib().keaki_host_kem_prepare(setup.h, C.c_size_t(batch_hint)))
+
+
 def decapsulate(setup: KZGSetup, proof, ciphertext, msg_len: int) -> bytes:
     key = np.zeros(max(msg_len, 1), np.uint8)
     _ck(_lib().keaki_host_decapsulate(setup.h, _p(_u64(proof)), _p(_u64(ciphertext)), C.c_size_t(msg_len), _p(key)))

@@ -88,6 +88,7 @@ def main():
     else:
         K.precompute_open_fk(s, setup_degree)              # SRS-only part of the FK23 openings, like the MSM window tables
     K.prepare_shard(s, rank, world)                        # window tables of this rank's SRS chunk (N > 1)
+    K.kem_prepare(s, (n + world - 1) // world)             # the tables of encapsulation that depend on the setup only, for this rank's share
     shard.barrier()
     t_setup = time.time() - t0
     np_rng = np.random.default_rng(7)

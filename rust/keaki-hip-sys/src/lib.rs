@@ -137,6 +137,7 @@ extern "C" {
     pub fn keaki_hip_encap_batch_dev(ctx: *mut keaki_hip_ctx, d_com_aff: *const c_void, d_tau_g2_aff: *const c_void, d_points: *const c_void,
                                      d_values: *const c_void, d_r: *const c_void, n: usize, d_ct_out_aff: *mut c_void, d_gt_out: *mut c_void,
                                      d_key_out: *mut c_void, msg_len: usize) -> keaki_status;
+    pub fn keaki_hip_encap_prepare(ctx: *mut keaki_hip_ctx, tau_g2_aff: *const u64, batch_hint: usize) -> keaki_status;
     pub fn keaki_hip_decap_batch(ctx: *mut keaki_hip_ctx, proofs_aff: *const u64, cts_aff: *const u64, n: usize, gt_out: *mut u8, key_out: *mut u8,
                                  msg_len: usize) -> keaki_status;
     pub fn keaki_hip_decap_batch_dev(ctx: *mut keaki_hip_ctx, d_proofs_aff: *const c_void, d_cts_aff: *const c_void, n: usize, d_gt_out: *mut c_void,

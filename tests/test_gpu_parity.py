@@ -406,6 +406,36 @@ def test_encap_gt_fixed_base_path_vs_oracle(oc, py, hip, rand_fr, request):
     assert np.array_equal(gt2, gt3) and np.array_equal(ct2, ct3)
 
 
+def test_encap_prepare_changes_nothing_but_the_first_call(oc, rand_fr):
+    """keaki_hip_encap_prepare builds the setup-only tables ahead of time: a prepared context and a fresh one give the same bytes (per-item
+    pairing path at 300 items, GT fixed-base path at 2^16), the prepared one holds its tables before the first batch, and a second [tau]_2
+    replaces the first one's table."""
+    from keaki_amd.hip import KeakiHip
+    a, b = KeakiHip(0), KeakiHip(0)
+    try:
+        g1, g2 = oc.generators()
+        tau_g2 = a.g2_mul_batch(g2, mont(oc, [4242]))[0]
+        tau2 = a.g2_mul_batch(g2, mont(oc, [4243]))[0]
+        com = a.g1_mul_batch(g1, mont(oc, [77]))[0]
+        a.encap_prepare(tau2, 1 << 16)
+        a.encap_prepare(tau_g2, 1 << 16)                 # the setup's [tau]_2 changes: its table is rebuilt
+        assert a.memory()["gt_tables"] > (1 << 30) and b.memory()["gt_tables"] == 0
+        n = 300
+        A, V, Rr = (mont(oc, rand_fr(n, 9900 + k)) for k in range(3))
+        ra, rb = a.encap_batch(com, tau_g2, A, V, Rr, 32), b.encap_batch(com, tau_g2, A, V, Rr, 32)
+        assert all(np.array_equal(x, y) for x, y in zip(ra, rb))
+        e = oc.encap_batch(com, tau_g2, A, V, Rr, 32, threads=8)
+        assert all(np.array_equal(x, y) for x, y in zip(ra, e))
+        m = 1 << 16
+        idx = np.random.default_rng(3).integers(0, n, m)
+        ra, rb = a.encap_batch(com, tau_g2, A[idx], V[idx], Rr[idx], 32), b.encap_batch(com, tau_g2, A[idx], V[idx], Rr[idx], 32)
+        assert all(np.array_equal(x, y) for x, y in zip(ra, rb))
+        assert np.array_equal(ra[0][:64], e[0][idx[:64]]) and np.array_equal(ra[2][:64], e[2][idx[:64]])
+        a.encap_prepare(tau_g2, 0)                       # a hint of zero items is a no-op
+    finally:
+        a.close(); b.close()
+
+
 def test_encap_small_calls_switch_to_gt_path_when_commitment_repeats(oc, py, rand_fr, monkeypatch):
     """Under the automatic policy (option encap_gt = -1) the third consecutive call with one commitment (any batch size) builds the tables of A = e(C, g2) and B and
     takes the GT fixed-base path; later calls reuse them, a different commitment goes back to the per-item path. Own context (the policy is
