@@ -84,6 +84,17 @@ def multirank_runs(request, tmp_path_factory):
                              "--log2n", "18", "--kem-log2n", "10", "--steps", "3", "--warmup", "1", "--cpu-log2n", "14", "--strong-log2n", "18",
                              "--fk-log2d", "0", "--laconic-log2n", "0"], 1500)
     out["bench_rccl1"] = {"rc": rc, "log": log}
+    # (6) EIGHT ranks on the one GPU (gloo): the driver's 8-GPU launch lines with everything but the transport real --
+    # BASELINE config 4 at its size (bench.py's strong block: 2^26 points in total = 2^23 per rank, each rank with the window tables of its
+    # chunk) and BASELINE config 5 at its size (laconic_ot.py: 2^20 receiver bits, FK23 openings sharded 8 ways at d = 2^21, the commit MSM
+    # by point range, 2^21 encapsulations and 2^20 decapsulations by item range; rank 0 re-runs the un-sharded calls and compares bytes)
+    rc, log = _run(launch + ["--nproc-per-node", "8", "--master-port", str(port + 9), "bench.py", "--gpus", "8", "--backend", "gloo", "--log2n", "20",
+                             "--kem-log2n", "10", "--steps", "2", "--warmup", "1", "--cpu-log2n", "14", "--strong-log2n", "26",
+                             "--fk-log2d", "0", "--laconic-log2n", "0"], 1500)
+    out["bench8"] = {"rc": rc, "log": log}
+    rc, log = _run(launch + ["--nproc-per-node", "8", "--master-port", str(port + 10), "laconic_ot.py", "--gpus", "8", "--backend", "gloo", "--log2n", "20",
+                             "--check-single"], 1500)
+    out["laconic8"] = {"rc": rc, "log": log}
     yield out
 
 

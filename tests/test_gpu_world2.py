@@ -110,3 +110,28 @@ def test_rccl_executes_on_hardware_with_one_rank(multirank_runs):
     assert j["n_gpus"] == 1 and j["config"]["backend"] == "nccl" and j["config"]["exchange_ms"] is not None and j["config"]["exchange_ms"] > 0
     assert j["checks"]["full_size_check"] is True and j["checks"]["sample_bit_exact"] is True
     assert j["strong"]["full_size_check"] is True and j["strong"]["ranks_seen"] == 1
+
+
+def test_eight_ranks_config4_and_config5_at_full_size(multirank_runs):
+    """BASELINE configs 4 and 5 at their stated sizes through the driver's 8-rank launch lines, all eight ranks on the one GPU of the box
+    (gloo instead of RCCL: the transport is the only thing that differs from an 8-GPU node).
+      config 4: 2^26-point G1 MSM, 2^23 points per rank with the window tables of the chunk, all-gather of eight 96-byte partials + EC sum,
+                checked at full size by the O(n) identity over all ranks (every rank contributes its sum of s_i k_i);
+      config 5: Laconic OT at 2^20 receiver bits: FK23 openings sharded 8 ways at d = 2^21 (three rank bits in every layout switch), commit
+                by point range, 2^21 encapsulations / 2^20 decapsulations by item range; rank 0 re-runs the un-sharded calls with the same
+                seeds and compares commitment, all 2^21 proofs and its ciphertexts byte for byte (those un-sharded calls are what
+                tests/test_gpu_config5.py checks against the oracle)."""
+    run = multirank_runs["bench8"]
+    assert run["rc"] == 0, run["log"][-3000:]
+    j = _json_line(run["log"])
+    assert j["n_gpus"] == 8 and j["config"]["ranks_seen"] == 8 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["checks"]["full_size_check"] is True and j["checks"]["sample_bit_exact"] is True
+    st = j["strong"]
+    assert st["total_points"] == 1 << 26 and st["points_per_gpu"] == 1 << 23 and st["ranks_seen"] == 8 and st["full_size_check"] is True
+    run = multirank_runs["laconic8"]
+    assert run["rc"] == 0, run["log"][-3000:]
+    j = _json_line(run["log"])
+    assert j["n_gpus"] == 8 and j["ranks_seen"] == 8 and j["n_choices"] == 1 << 20
+    assert j["all_messages_recovered"] is True and j["sharded_equals_single_process"] is True and j["fk_sharded"] is True
+    d = 1 << 21
+    assert j["fk_exchange_bytes_sent_per_rank"] == 7 * (2 * (d // 64 * 96) + d // 8 * 64) + 7 * (2 * d // 64 * 96)
