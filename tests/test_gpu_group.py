@@ -334,3 +334,71 @@ def test_options_are_per_context_and_unknown_names_are_refused(oc, hip):
         assert "src=msm:" in h.version() and "pairing:" in h.version()
     finally:
         h.close()
+
+
+def test_group_of_eight_config4_2p26_points(oc):
+    """BASELINE config 4 at its size through the in-process path a Rust caller gets (KEAKI_HIP_DEVICES=8): 2^26 points in total, eight members
+    with 2^23 points and the chunk's window tables each (eight contexts on the one GPU of the box), partial sums through host memory, one
+    EC sum. Checked at full size by the O(n) identity MSM(s, k_i G) = (sum s_i k_i) G; the chunk sizes and tables are the 8-GPU ones."""
+    from keaki_amd.hip import KeakiHip, KeakiHipGroup
+    from bench import random_fr_limbs, SEED
+    n = 1 << 26
+    g1, _ = oc.generators()
+    h = KeakiHip(0)
+    k = random_fr_limbs(n, SEED + 26)
+    pts = h.g1_mul_batch(g1, k)                           # 4 GiB of valid points, generated on the device
+    h.close()
+    s = random_fr_limbs(n, SEED + 27)
+    g = KeakiHipGroup([0] * 8)
+    try:
+        srs = g.srs_g1_upload(pts, precompute=True)
+        mem = [g.member_memory(i) for i in range(8)]
+        assert all(m["tables"] >= 5 * (1 << 30) for m in mem), mem      # W x 2^23 x 64 B per member: the 6 GiB of the 8-GPU configuration
+        got = g.msm_g1(srs, s)
+        exp = oc.g1_mul_batch(g1, oc.fr_dot(s, k)[None, :])[0]
+        assert np.array_equal(jac_to_aff(got), exp)
+        # a second polynomial, shorter than the SRS: the last members' ranges are empty or cut
+        m = (5 << 23) + 12345
+        exp = oc.g1_mul_batch(g1, oc.fr_dot(s[:m], k[:m])[None, :])[0]
+        assert np.array_equal(jac_to_aff(g.msm_g1(srs, s[:m])), exp)
+        srs.free()
+    finally:
+        g.close()
+
+
+def test_group_of_eight_config5_2p20_bits(oc):
+    """BASELINE config 5 at its size on a device group of eight (the in-process form): vec_commit with the FK23 openings sharded 8 ways inside
+    the library (d = 2^21) and the commit MSM by SRS range, 2 x vec_encrypt and vec_decrypt split by item range -- commitment, all 2^21
+    proofs, all ciphertexts and all recovered messages byte-equal to the single-context mirror with the same seeds (whose values
+    tests/test_gpu_config5.py checks against the oracle)."""
+    from keaki_amd import keaki as K
+    n = 1 << 20
+    d = 2 * n
+    secret = K.Rng(2024).fr_rand()
+    bits = np.random.default_rng(7).integers(0, 2, n)
+    zero, one = K.fr(0), K.fr(1)
+    choices = np.where(bits[:, None] == 0, zero[None, :], one[None, :]).astype(np.uint64)
+    msgs = np.random.default_rng(8).integers(0, 256, size=(n, 32), dtype=np.uint8)
+    elements = K.domain_elements(n + K.PADDING_LEN)
+    ones = np.repeat(one[None, :], n, 0)
+    res = []
+    for dev in (None, K.Device([0] * 8)):
+        s = K.KZGSetup.setup(secret, d) if dev is None else K.KZGSetup.setup(secret, d, device=dev)
+        try:
+            rng = K.Rng(99)
+            K.precompute_open_fk(s, d)
+            K.kem_prepare(s, n)
+            com, proofs = K.vec_commit(rng, s, choices)
+            g2, body = K.vec_encrypt_arrays(rng, s, com, elements, ones, msgs)
+            out = K.vec_decrypt_arrays(s, proofs[:n], g2, body)
+            res.append((com, proofs, g2, body, out))
+        finally:
+            s.close()
+            if dev is not None:
+                dev.close()
+    a, b = res
+    assert np.array_equal(a[0], b[0]), "commitment"
+    assert np.array_equal(a[1], b[1]), "FK23 proofs"
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]), "ciphertexts"
+    assert np.array_equal(a[4], b[4])
+    assert np.array_equal(b[4][bits == 1], msgs[bits == 1]) and not np.array_equal(b[4][bits == 0], msgs[bits == 0])
