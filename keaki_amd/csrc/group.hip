@@ -267,13 +267,23 @@ keaki_status copy_between(keaki_hip_group* g, size_t dst_m, void* dst, size_t sr
   if (e != hipSuccess) return gfail(g, KEAKI_ERR_HIP, "group_fk: copy member %zu -> member %zu failed: %s", src_m, dst_m, hipGetErrorString(e));
   return KEAKI_OK;
 }
+// A device-to-device hipMemcpy may return before the copy has run (it is ordered on the null stream only), and the members' streams are
+// non-blocking, i.e. NOT ordered behind the null stream: wait for every member's device before the next step reads the buffers.
+keaki_status copies_done(keaki_hip_group* g) {
+  for (size_t i = 0; i < g->ctx.size(); i++) {
+    (void)hipSetDevice(g->ctx[i]->device);
+    const hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return gfail(g, KEAKI_ERR_HIP, "group_fk: hipDeviceSynchronize on member %zu failed: %s", i, hipGetErrorString(e));
+  }
+  return KEAKI_OK;
+}
 // chunk j of member i's send buffer -> chunk i of member j's receive buffer (every member has finished its step: run_all waited and synchronised)
 keaki_status all_to_all(keaki_hip_group* g, keaki_hip_group_fk* f, size_t per_peer) {
   const size_t N = g->ctx.size();
   for (size_t i = 0; i < N; i++)
     for (size_t j = 0; j < N; j++)
       ST_TRY(copy_between(g, j, (char*)f->recv[j] + i * per_peer, i, (const char*)f->send[i] + j * per_peer, per_peer));
-  return KEAKI_OK;
+  return copies_done(g);
 }
 void group_fk_release(keaki_hip_group* g, keaki_hip_group_fk* f) {
   for (size_t i = 0; i < f->fk.size(); i++) keaki_hip_fk_shard_free(g && i < g->ctx.size() ? g->ctx[i] : nullptr, f->fk[i]);
@@ -360,6 +370,7 @@ keaki_status keaki_hip_group_fk_open(keaki_hip_group* g, keaki_hip_group_fk* f, 
   ST_TRY(step_all(g, "group_fk_open (step 2)", [&](size_t i) { return keaki_hip_fk_shard_open(g->ctx[i], f->fk[i], 2, nullptr, f->send[i], f->recv[i], nullptr); }));
   // the all-gather of the d / N affine proofs of every member, into member 0 only (it alone writes the host output)
   for (size_t i = 0; i < N; i++) ST_TRY(copy_between(g, 0, (char*)f->recv[0] + i * f->sizes[3], i, f->send[i], f->sizes[3]));
+  ST_TRY(copies_done(g));
   const keaki_status st = keaki_hip_fk_shard_open(g->ctx[0], f->fk[0], 3, nullptr, nullptr, f->recv[0], proofs_out_aff);
   if (st != KEAKI_OK) return gfail(g, st, "group_fk_open (step 3): member 0: %s", keaki_hip_last_error(g->ctx[0]));
   return KEAKI_OK;
