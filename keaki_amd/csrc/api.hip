@@ -361,7 +361,9 @@ keaki_status keaki_hip_srs_g1_upload(keaki_hip_ctx* ctx, const uint64_t* points_
   void* d = nullptr;
   HIP_TRY(ctx, hipMalloc(&d, n ? n * G1_AFF_BYTES : 16));
   if (n) {
-    hipError_t e = hipMemcpy(d, points_aff, n * G1_AFF_BYTES, hipMemcpyHostToDevice);
+    // on the context's stream (non-blocking: not ordered behind the null stream a plain hipMemcpy uses), complete before the call returns
+    hipError_t e = hipMemcpyAsync(d, points_aff, n * G1_AFF_BYTES, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { (void)hipFree(d); return fail(ctx, KEAKI_ERR_HIP, "srs upload copy failed: %s", hipGetErrorString(e)); }
   }
   *out = new_srs<keaki_hip_srs_g1>(ctx, d, n, true);
@@ -420,7 +422,8 @@ keaki_status keaki_hip_srs_g2_upload(keaki_hip_ctx* ctx, const uint64_t* points_
   void* d = nullptr;
   HIP_TRY(ctx, hipMalloc(&d, n ? n * G2_AFF_BYTES : 16));
   if (n) {
-    hipError_t e = hipMemcpy(d, points_aff, n * G2_AFF_BYTES, hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpyAsync(d, points_aff, n * G2_AFF_BYTES, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { (void)hipFree(d); return fail(ctx, KEAKI_ERR_HIP, "srs upload copy failed: %s", hipGetErrorString(e)); }
   }
   *out = new_srs<keaki_hip_srs_g2>(ctx, d, n, true);
