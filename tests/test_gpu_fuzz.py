@@ -41,6 +41,6 @@ def test_fuzz_mixed_call_sequences(seed):
     _run("fuzz_mixed.py", 40, seed)
 
 
-@pytest.mark.parametrize("seed,members", [(1, 4), (2, 3)])
+@pytest.mark.parametrize("seed,members", [(1, 4), (2, 3), (3, 8)])
 def test_fuzz_device_group_call_sequences(seed, members):
     _run("fuzz_group.py", 30, seed, members)
