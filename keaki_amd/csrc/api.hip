@@ -211,6 +211,7 @@ void tune_from_env(Tuning& t) {
   if (geti("KEAKI_ACC_U29_G2", v)) t.acc_u29_g2 = v != 0;
   if (geti("KEAKI_ACC_NT", v)) t.acc_nt = v != 0;
   if (geti("KEAKI_FK_UNIFORM", v)) t.fk_uniform = v != 0;
+  if (geti("KEAKI_FK_GTAB", v)) t.fk_gtab = v != 0;
   if (geti("KEAKI_FB_OCC1", v)) t.fb_occ1 = v != 0;
   if (geti("KEAKI_GT_WB_B", v)) t.gt_wb_b = (int)v;
   if (geti("KEAKI_ENCAP_GT", v)) t.encap_gt = v;
@@ -220,7 +221,7 @@ std::vector<BufClass> all_bufs(keaki_hip_ctx* ctx) {
   std::vector<BufClass> v;
   for (DevBuf* b : {&ctx->digits, &ctx->hist, &ctx->offsets, &ctx->cursor, &ctx->sorted, &ctx->buckets, &ctx->partials, &ctx->wsums, &ctx->bsums,
                     &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->io_a, &ctx->io_b, &ctx->io_c, &ctx->io_d, &ctx->io_e, &ctx->perm, &ctx->heavy,
-                    &ctx->pair_ws, &ctx->verify_lines, &ctx->verify_io, &ctx->g2gen_lines})
+                    &ctx->pair_ws, &ctx->verify_lines, &ctx->verify_io, &ctx->g2gen_lines, &ctx->fk_tab})
     v.push_back({b, 1});
   for (DevBuf* b : {&ctx->fb_scalars, &ctx->fb_g1_gen, &ctx->fb_g2_gen, &ctx->fb_com, &ctx->fb_tau, &ctx->gt_tab_a, &ctx->gt_tab_b, &ctx->gt_base,
                     &ctx->fbs_scalars, &ctx->fbs_g2_gen, &ctx->fbs_tau})
@@ -297,6 +298,7 @@ keaki_status keaki_hip_ctx_set_option(keaki_hip_ctx* ctx, const char* name, int6
   else if (k == "acc_u29_g2") t.acc_u29_g2 = value != 0;
   else if (k == "acc_nt") t.acc_nt = value != 0;
   else if (k == "fk_uniform") t.fk_uniform = value != 0;
+  else if (k == "fk_gtab") t.fk_gtab = value != 0;
   else if (k == "fb_occ1") t.fb_occ1 = value != 0;
   else if (k == "gt_wb_b") {
     if (value != 0 && (value < 8 || value > 22 || gt_table_powers((uint32_t)value) > 320)) return fail(ctx, KEAKI_ERR_BAD_ARG, "ctx_set_option: gt_wb_b = %lld out of range", (long long)value);

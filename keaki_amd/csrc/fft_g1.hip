@@ -22,7 +22,16 @@
 namespace bn254 {
 
 // k * P for a Jacobian P: NAF ladder in the 29-bit lazy arithmetic (jac29.hip.h). k: Montgomery Fr.
-KDEV G1Jac jac_scalar_mul(const G1Jac& p, const Fr& k_mont) { return jac_scalar_mul_u29(p, k_mont); }
+// tab_lane: this lane's slot of the window-table workspace (null: the table lives in private memory)
+// GT: the kernel was launched with a table workspace (one instantiation per form: a kernel that carries both ladders needs 190 registers)
+template <bool GT>
+KDEV G1Jac jac_scalar_mul_t(const G1Jac& p, const Fr& k_mont, uint4* tab_lane) {
+  if constexpr (GT) return jac_scalar_mul_gtab_u29(p, k_mont, tab_lane);
+  else return jac_scalar_mul_u29(p, k_mont);
+}
+// A launch of a per-lane-scalar ladder kernel covers the lanes [first, first + gridDim.x * 64) of the whole job; with a table workspace the
+// host launches at most FK_TAB_LANES lanes at a time and lane b uses slot b - first.
+KDEV uint4* ladder_slot(uint4* tab, u32 b, u32 first) { return tab ? tab + (size_t)(b - first) * GTAB_UINT4_PER_LANE : nullptr; }
 KDEV bool fr_is_one(const Fr& a) {
   u32 o = 0;
 #pragma unroll
@@ -54,9 +63,10 @@ static __global__ void __launch_bounds__(64) k_g1_jac_to_aff(const G1Jac* __rest
 // ((A, B) = (R, rank) on the cyclic layout, (1, 0) on the block layout). Lane order as k_g1_fft_stage: a wave shares one twiddle
 // while the stage has at least 64 blocks.
 // UNIFORM (chosen by the host: at least 64 blocks and at least one full wave): every wave has ONE twiddle and takes the sliding-window ladder.
-template <bool DIT, bool UNIFORM>
-static __global__ void __launch_bounds__(64, 3) k_g1_fft_stage_map(G1Jac* __restrict__ a, const Fr* __restrict__ tw, u32 m, u32 half, u32 A, u32 B, u32 stride) {
-  u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+template <bool DIT, bool UNIFORM, bool GT>
+static __global__ void __launch_bounds__(64, 3) k_g1_fft_stage_map(G1Jac* __restrict__ a, const Fr* __restrict__ tw, u32 m, u32 half, u32 A, u32 B, u32 stride,
+                                                                   uint4* __restrict__ tab, u32 first) {
+  u32 b = first + blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= m / 2) return;
   const u32 nblocks = m / (2 * half);
   u32 j, blk;
@@ -64,18 +74,21 @@ static __global__ void __launch_bounds__(64, 3) k_g1_fft_stage_map(G1Jac* __rest
   else { j = b % half; blk = b / half; }
   const u32 i0 = blk * 2 * half + j, i1 = i0 + half;
   Fr w = tw[((size_t)j * A + B) * stride];
-  G1Jac u = a[i0], v = a[i1];
   __shared__ unsigned char dig[UNIFORM ? 2 * UNIFORM_DIG_STRIDE : 4];
   auto mul = [&](const G1Jac& pt) {
     if constexpr (UNIFORM) return jac_scalar_mul_uniform_u29(pt, w, dig);
-    else return jac_scalar_mul(pt, w);
+    else return jac_scalar_mul_t<GT>(pt, w, ladder_slot(tab, b, first));
   };
   if (DIT) {
+    G1Jac v = a[i1];
     if (!fr_is_one(w)) v = mul(v);
+    const G1Jac u = a[i0];                 // read after the ladder: 24 registers less across it
     a[i0] = jac_add(u, v);
     v.y = -v.y;
     a[i1] = jac_add(u, v);
   } else {
+    const G1Jac u = a[i0];
+    G1Jac v = a[i1];
     a[i0] = jac_add(u, v);
     v.y = -v.y;
     G1Jac t = jac_add(u, v);
@@ -106,27 +119,32 @@ KDEV Fr fr_shl(Fr s, u32 k) {
 // The 2m products of the positions [base, base + m) of the d: lane t < 2m, part = t / m, k = t % m, q = base + k:
 //   part 0: out_e[k] = (d a[2 brev(q)]) hs_even[k]        part 1: out_o[k] = a[2 brev(q) + 1] hs_odd[k]
 // (un-sharded: base = 0, m = d, hs_even = hat_s, hs_odd = hat_s + d, out_e = work, out_o = work + d)
+template <bool GT>
 static __global__ void __launch_bounds__(64) k_fk_pointwise(const G1Jac* __restrict__ hs_even, const G1Jac* __restrict__ hs_odd, const Fr* __restrict__ a,
-                                                            u32 log2d, u32 base, u32 m, G1Jac* __restrict__ out_e, G1Jac* __restrict__ out_o) {
-  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+                                                            u32 log2d, u32 base, u32 m, G1Jac* __restrict__ out_e, G1Jac* __restrict__ out_o,
+                                                            uint4* __restrict__ tab, u32 first) {
+  u32 t = first + blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 2 * m) return;
   const u32 part = t >= m ? 1u : 0u, k = part ? t - m : t;
   Fr sc = a[2 * (size_t)brev_bits(base + k, log2d) + part];
   if (!part) sc = fr_shl(sc, log2d);
-  const G1Jac r = jac_scalar_mul(part ? hs_odd[k] : hs_even[k], sc);
+  const G1Jac r = jac_scalar_mul_t<GT>(part ? hs_odd[k] : hs_even[k], sc, ladder_slot(tab, t, first));
   if (part) out_o[k] = r; else out_e[k] = r;
 }
 // a[k] <- s[k * stride + offset] * a[k]   (the twist by omega_2d^-i: un-sharded stride 1, offset 0; cyclic layout stride R, offset rank)
-static __global__ void __launch_bounds__(64) k_g1_mul_jac_strided(G1Jac* __restrict__ a, const Fr* __restrict__ s, u32 stride, u32 offset, u32 m) {
-  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+template <bool GT>
+static __global__ void __launch_bounds__(64) k_g1_mul_jac_strided(G1Jac* __restrict__ a, const Fr* __restrict__ s, u32 stride, u32 offset, u32 m,
+                                                                  uint4* __restrict__ tab, u32 first) {
+  u32 k = first + blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= m) return;
-  a[k] = jac_scalar_mul(a[k], s[(size_t)k * stride + offset]);
+  a[k] = jac_scalar_mul_t<GT>(a[k], s[(size_t)k * stride + offset], ladder_slot(tab, k, first));
 }
+template <bool GT>
 static __global__ void __launch_bounds__(64) k_g1_mul_jac_strided_oop(const G1Jac* __restrict__ in, const Fr* __restrict__ s, u32 stride, u32 offset, u32 m,
-                                                                      G1Jac* __restrict__ out) {
-  u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+                                                                      G1Jac* __restrict__ out, uint4* __restrict__ tab, u32 first) {
+  u32 k = first + blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= m) return;
-  out[k] = jac_scalar_mul(in[k], s[(size_t)k * stride + offset]);
+  out[k] = jac_scalar_mul_t<GT>(in[k], s[(size_t)k * stride + offset], ladder_slot(tab, k, first));
 }
 // out[perm(k)] = affine(e[k] + o[k]); natural == true: perm = bit reversal over log2d bits of (base + k) (un-sharded), else perm = k (this
 // rank's d / R proofs in position order; the permutation happens after the all-gather)
@@ -250,13 +268,58 @@ static __global__ void __launch_bounds__(64) k_fr_horner_down(const Fr* __restri
 namespace keaki_internal {
 using namespace bn254;
 
+// ---- launching the kernels whose lanes run the per-lane-scalar ladder --------------------------------------------------------------------
+// Their window tables live in a workspace of the context, one 2 KB slot per lane of a launch (jac29.hip.h: jac_scalar_mul_gtab_u29): at most
+// FK_TAB_LANES lanes per launch, i.e. 2 GB. When the workspace cannot be had (or option fk_gtab = 0) the kernels keep the table in private
+// memory, one launch for all lanes.
+constexpr u32 FK_TAB_LANES = 1u << 20;
+static uint4* fk_table(keaki_hip_ctx* ctx, u32 lanes) {
+  if (!ctx->tune.fk_gtab || lanes == 0) return nullptr;
+  const size_t want = (size_t)std::min(lanes, FK_TAB_LANES) * GTAB_UINT4_PER_LANE * sizeof(uint4);
+  if (reserve(ctx, ctx->fk_tab, want) != KEAKI_OK) { (void)hipGetLastError(); return nullptr; }       // optional memory
+  return (uint4*)ctx->fk_tab.p;
+}
+// launch(tab, first, lanes_in_this_launch) for every piece of `total` lanes
+template <class L>
+static void ladder_launches(keaki_hip_ctx* ctx, u32 total, L launch) {
+  uint4* tab = fk_table(ctx, total);
+  if (!tab) { launch((uint4*)nullptr, 0u, total); return; }
+  for (u32 first = 0; first < total; first += FK_TAB_LANES) launch(tab, first, std::min(FK_TAB_LANES, total - first));
+}
 static void stage_map(keaki_hip_ctx* ctx, bool dit, G1Jac* a, const Fr* tw, u32 m, u32 half, u32 A, u32 B, u32 stride) {
   const bool uniform = ctx->tune.fk_uniform && m / (2 * half) >= 64;        // blocks: a power of two, so every 64-lane workgroup then shares one twiddle
-  const dim3 grid(cdiv(m / 2, 64)), block(64);
-  if (dit && uniform) hipLaunchKernelGGL((k_g1_fft_stage_map<true, true>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride);
-  else if (dit) hipLaunchKernelGGL((k_g1_fft_stage_map<true, false>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride);
-  else if (uniform) hipLaunchKernelGGL((k_g1_fft_stage_map<false, true>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride);
-  else hipLaunchKernelGGL((k_g1_fft_stage_map<false, false>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride);
+  const dim3 block(64);
+  if (uniform) {
+    const dim3 grid(cdiv(m / 2, 64));
+    if (dit) hipLaunchKernelGGL((k_g1_fft_stage_map<true, true, false>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride, (uint4*)nullptr, 0u);
+    else hipLaunchKernelGGL((k_g1_fft_stage_map<false, true, false>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride, (uint4*)nullptr, 0u);
+    return;
+  }
+  ladder_launches(ctx, m / 2, [&](uint4* tab, u32 first, u32 cnt) {
+    const dim3 grid(cdiv(cnt, 64));
+    if (dit && tab) hipLaunchKernelGGL((k_g1_fft_stage_map<true, false, true>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride, tab, first);
+    else if (dit) hipLaunchKernelGGL((k_g1_fft_stage_map<true, false, false>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride, tab, first);
+    else if (tab) hipLaunchKernelGGL((k_g1_fft_stage_map<false, false, true>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride, tab, first);
+    else hipLaunchKernelGGL((k_g1_fft_stage_map<false, false, false>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride, tab, first);
+  });
+}
+static void launch_pointwise(keaki_hip_ctx* ctx, const G1Jac* hs_even, const G1Jac* hs_odd, const Fr* a, u32 log2d, u32 base, u32 m, G1Jac* out_e, G1Jac* out_o) {
+  ladder_launches(ctx, 2 * m, [&](uint4* tab, u32 first, u32 cnt) {
+    if (tab) hipLaunchKernelGGL(k_fk_pointwise<true>, dim3(cdiv(cnt, 64)), dim3(64), 0, ctx->stream, hs_even, hs_odd, a, log2d, base, m, out_e, out_o, tab, first);
+    else hipLaunchKernelGGL(k_fk_pointwise<false>, dim3(cdiv(cnt, 64)), dim3(64), 0, ctx->stream, hs_even, hs_odd, a, log2d, base, m, out_e, out_o, tab, first);
+  });
+}
+static void launch_mul_strided(keaki_hip_ctx* ctx, G1Jac* a, const Fr* s, u32 stride, u32 offset, u32 m) {
+  ladder_launches(ctx, m, [&](uint4* tab, u32 first, u32 cnt) {
+    if (tab) hipLaunchKernelGGL(k_g1_mul_jac_strided<true>, dim3(cdiv(cnt, 64)), dim3(64), 0, ctx->stream, a, s, stride, offset, m, tab, first);
+    else hipLaunchKernelGGL(k_g1_mul_jac_strided<false>, dim3(cdiv(cnt, 64)), dim3(64), 0, ctx->stream, a, s, stride, offset, m, tab, first);
+  });
+}
+static void launch_mul_strided_oop(keaki_hip_ctx* ctx, const G1Jac* in, const Fr* s, u32 stride, u32 offset, u32 m, G1Jac* out) {
+  ladder_launches(ctx, m, [&](uint4* tab, u32 first, u32 cnt) {
+    if (tab) hipLaunchKernelGGL(k_g1_mul_jac_strided_oop<true>, dim3(cdiv(cnt, 64)), dim3(64), 0, ctx->stream, in, s, stride, offset, m, out, tab, first);
+    else hipLaunchKernelGGL(k_g1_mul_jac_strided_oop<false>, dim3(cdiv(cnt, 64)), dim3(64), 0, ctx->stream, in, s, stride, offset, m, out, tab, first);
+  });
 }
 
 // hat_s = DIF_2d(reversed SRS padded with identities): depends on the SRS only, so it is computed once per (SRS, d) and cached.
@@ -279,10 +342,10 @@ keaki_status open_fk_run(keaki_hip_ctx* ctx, const void* d_hat_s, u32 log2d, con
   const Fr *tw = (const Fr*)d_tw2d, *twi = (const Fr*)d_tw2d_inv;
   const bool timed = ctx->timing && ctx->fk_ev[0];
   if (timed) (void)hipEventRecord(ctx->fk_ev[0], st);
-  hipLaunchKernelGGL(k_fk_pointwise, dim3(cdiv(2 * d, 64)), dim3(64), 0, st, hs, hs + d, (const Fr*)d_hat_a, log2d, 0u, d, e, o);
+  launch_pointwise(ctx, hs, hs + d, (const Fr*)d_hat_a, log2d, 0u, d, e, o);
   if (timed) (void)hipEventRecord(ctx->fk_ev[1], st);
   for (u32 half = 1; 2 * half <= d; half <<= 1) stage_map(ctx, true, o, twi, d, half, 1, 0, 2 * (d / (2 * half)));
-  hipLaunchKernelGGL(k_g1_mul_jac_strided, dim3(cdiv(d, 64)), dim3(64), 0, st, o, twi, 1u, 0u, d);
+  launch_mul_strided(ctx, o, twi, 1u, 0u, d);
   for (u32 half = d / 2; half >= 1; half >>= 1) stage_map(ctx, false, o, tw, d, half, 1, 0, 2 * (d / (2 * half)));
   if (timed) (void)hipEventRecord(ctx->fk_ev[2], st);
   hipLaunchKernelGGL(k_fk_finish, dim3(cdiv(d, 64)), dim3(64), 0, st, (const G1Jac*)e, (const G1Jac*)o, d, log2d, true, (G1Aff*)d_proofs_aff);
@@ -368,7 +431,7 @@ keaki_status fk_shard_setup_run(keaki_hip_ctx* ctx, FkShard& fk, const void* d_s
     fk_shard_tables(ctx, fk);
     G1Jac *ev = (G1Jac*)fk.work, *od = ev + Md;
     hipLaunchKernelGGL(k_fk_load_cyclic, dim3(cdiv(Md, 256)), dim3(256), 0, st, (const G1Aff*)d_srs, d, R, r, Md, ev);      // all of them below d
-    hipLaunchKernelGGL(k_g1_mul_jac_strided_oop, dim3(cdiv(Md, 64)), dim3(64), 0, st, (const G1Jac*)ev, tw, R, r, Md, od);
+    launch_mul_strided_oop(ctx, (const G1Jac*)ev, tw, R, r, Md, od);
     dif_cyclic(ctx, ev, tw, d, R, r);
     dif_cyclic(ctx, od, tw, d, R, r);
     hipLaunchKernelGGL(k_fk_pack2, dim3(cdiv(2 * Md, 256)), dim3(256), 0, st, (const G1Jac*)ev, R, Md / R, (G1Jac*)d_send);
@@ -397,7 +460,7 @@ keaki_status fk_shard_open_run(keaki_hip_ctx* ctx, FkShard& fk, int step, void* 
     hipLaunchKernelGGL(k_fr_scale, dim3(cdiv(N, 256)), dim3(256), 0, st, hat_a, s, N);
     const G1Jac* hs = (const G1Jac*)fk.hat_s;
     G1Jac* o = (G1Jac*)fk.work;
-    hipLaunchKernelGGL(k_fk_pointwise, dim3(cdiv(2 * Md, 64)), dim3(64), 0, st, hs, hs + Md, (const Fr*)hat_a, fk.log2d, r * Md, Md, (G1Jac*)fk.e, o);
+    launch_pointwise(ctx, hs, hs + Md, (const Fr*)hat_a, fk.log2d, r * Md, Md, (G1Jac*)fk.e, o);
     for (u32 half = 1; 2 * half <= Md; half <<= 1) stage_map(ctx, true, o, twi, Md, half, 1, 0, 2 * (d / (2 * half)));
     hipLaunchKernelGGL(k_jac_transpose, dim3(cdiv(Md, 256)), dim3(256), 0, st, (const G1Jac*)o, Md / R, R, (G1Jac*)d_send);
     return launch_check(ctx, "fk_shard_open 0");
@@ -405,7 +468,7 @@ keaki_status fk_shard_open_run(keaki_hip_ctx* ctx, FkShard& fk, int step, void* 
   if (step == 1) {
     G1Jac* a = (G1Jac*)d_recv;
     for (u32 half = Md / R; 2 * half <= Md; half <<= 1) stage_map(ctx, true, a, twi, Md, half, R, r, 2 * (d / (2 * half * R)));
-    hipLaunchKernelGGL(k_g1_mul_jac_strided, dim3(cdiv(Md, 64)), dim3(64), 0, st, a, twi, R, r, Md);
+    launch_mul_strided(ctx, a, twi, R, r, Md);
     dif_cyclic(ctx, a, tw, d, R, r);
     HIP_TRY(ctx, hipMemcpyAsync(d_send, a, (size_t)Md * sizeof(G1Jac), hipMemcpyDeviceToDevice, st));
     return launch_check(ctx, "fk_shard_open 1");

@@ -34,6 +34,7 @@ struct Tuning {
   bool acc_u29_g2 = true;        // KEAKI_ACC_U29_G2 / "acc_u29_g2"
   bool acc_nt = false;           // KEAKI_ACC_NT / "acc_nt": non-temporal loads of the table rows in the G1 bucket kernel
   bool fk_uniform = true;        // KEAKI_FK_UNIFORM / "fk_uniform": sliding-window ladder in the wave-uniform FK23 stages
+  bool fk_gtab = true;           // KEAKI_FK_GTAB / "fk_gtab": window tables of the per-lane-scalar ladders in a lane-contiguous workspace (0: private memory)
   bool fb_occ1 = false;          // KEAKI_FB_OCC1 / "fb_occ1": one wave per SIMD for the G2 fixed-base kernel at any batch size
   int gt_wb_b = 0;               // KEAKI_GT_WB_B / "gt_wb_b": window bits of the table of e(g1, g2), 0 = automatic (20 / 16)
   long long encap_gt = -1;       // KEAKI_ENCAP_GT / "encap_gt": batch size from which encap takes the GT fixed-base path; -1 = automatic policy
@@ -62,6 +63,7 @@ struct keaki_hip_ctx {
   uint32_t seen_com_runs = 0;
   uint32_t gt_a_wb = 0, gt_b_wb = 0;      // window widths of the GT tables in gt_tab_a / gt_tab_b
   keaki_internal::DevBuf pair_ws;                   // per-item slots of the final exponentiation (pairing.hip.h)
+  keaki_internal::DevBuf fk_tab;                    // window tables of the per-lane-scalar ladders of FK23: 2 KB per lane of a launch, at most 2 GB (fft_g1.hip)
   keaki_internal::DevBuf verify_lines, verify_io;   // kzg verify: [lines of g2 | lines of [tau]_2], small in/out block
   bool verify_ready = false;              // set only after every init step of kzg verify succeeded
   bool verify_tau_valid = false;

@@ -66,6 +66,50 @@ KDEV J29 j29_add(const J29& a, const U29& X2, const U29& Y2, const U29& Z2, cons
   return r;
 }
 
+// j29_add with the addend in MEMORY (a window-table entry of jac_scalar_mul_gtab_u29: words [0..8] y, [9..17] z, [18..26] z^2, [27..35] z^3,
+// [36..44] x, [48..56] beta x): every field is loaded where the formula first needs it, so that at most one of them is alive beside the
+// running point (loading all five up front costs 55 registers: the kernels then drop to two waves per SIMD or spill).
+KDEV U29 ld9(const u32* __restrict__ p) {
+  U29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = p[i];
+  return r;
+}
+KDEV J29 j29_add_mem(const J29& a, const u32* __restrict__ e, bool phi, bool neg, int& special) {
+  const U29 Z1Z1 = u29_sqr(a.z);
+  const U29 U1 = u29_mul(a.x, ld9(e + 18));
+  const U29 U2 = u29_mul(ld9(e + (phi ? 48 : 36)), Z1Z1);
+  const U29 S1 = u29_mul(a.y, ld9(e + 27));
+  U29 Y2 = ld9(e);
+  if (neg) {
+    U29 zero;
+#pragma unroll
+    for (int i = 0; i < 9; i++) zero.l[i] = 0;
+    Y2 = u29_sub(zero, Y2, Q29::K32);
+  }
+  const U29 S2 = u29_mul(Y2, u29_mul(a.z, Z1Z1));
+  const U29 H = u29_sub(U2, U1, Q29::K2);
+  special = 0;
+  if (u29_maybe_zero(H)) {
+    if (u29_is_zero(H)) {
+      special = u29_is_zero(u29_sub(S2, S1, Q29::K2)) ? 1 : 2;
+      return a;
+    }
+  }
+  const U29 I = u29_scale(u29_sqr(H), 4), J = u29_mul(H, I);
+  U29 t;
+#pragma unroll
+  for (int i = 0; i < 9; i++) t.l[i] = 2u * (S2.l[i] - S1.l[i] + Q29::K2[i]);
+  const U29 rr = u29_carry(t);
+  const U29 V = u29_mul(U1, I);
+  J29 r;
+  r.x = u29_sub3(u29_sqr(rr), J, V);
+  const U29 T = u29_sub_raw(V, r.x, Q29::K16);
+  r.y = u29_sub2x(u29_mul(rr, T), u29_mul(S1, J), Q29::K4W);
+  r.z = u29_scale(u29_mul(u29_mul(a.z, ld9(e + 9)), H), 2);
+  return r;
+}
+
 // ---- GLV: k = k1 + k2 lambda (mod r), |k1|, |k2| < 2^127, phi(x, y) = (beta x, y) = lambda (x, y) ------------------------------
 // Babai rounding on the short basis (a1, b1), (a2, b2): c_i = (k g_i) >> 256, k1 = k - c1 a1 - c2 a2, k2 = -c1 b1 - c2 b2, all computed
 // modulo 2^160 (the results fit 128 signed bits). out: magnitudes (5 words, top word 0) and signs.
@@ -222,6 +266,128 @@ KDEV Jac<Fq> jac_scalar_mul_u29(const Jac<Fq>& p, const Fr& k_mont) {
         } else {
           int special;
           acc = j29_add(acc, ex, ey, e.z, e.zz, e.zcu, special);
+          if (special == 1) acc = j29_dbl(acc);
+          if (special == 2) empty = true;
+        }
+      }
+    }
+  }
+  if (empty) return jac_inf<Fq>();
+  return {u29_to_fq(acc.x), u29_to_fq(acc.y), u29_to_fq(acc.z)};
+}
+
+
+// ---- the same ladder with the window table in GLOBAL memory, one contiguous slot per lane (round 3) --------------------------------------
+// With a scalar per lane every lane indexes its table differently. In private (scratch) memory the hardware interleaves the lanes dword by
+// dword, so the 45 dwords of "entry e of lane l" lie in 45 different 256-byte rows, and a wave whose lanes ask for up to 8 different entries
+// touches up to 8 x 45 rows per addition: 48 - 64 GB of fabric traffic per butterfly stage of 2^20 lanes (profiles/
+// r03_fk_pairing_hbm_traffic_pmc.json), and the same ladder runs 19 % slower than with one scalar per wave (16.5 vs 13.9 ms per 2^20
+// scalar-mults, bench_tools/ab_ladder_table_traffic.py). Here lane l owns 8 x 256 contiguous bytes of a workspace: an entry is two cache
+// lines whatever the other lanes read. Entry layout in 16-byte units: [0..8] y z zz zcu (36 words), [9..11] x (+ 3 pad), [12..14] beta x
+// (+ 3 pad), [15] unused. `tab`: this lane's 128 x 16 bytes.
+constexpr u32 GTAB_UINT4_PER_LANE = 128;
+KDEV void gtab_store9(uint4* dst, const U29& a) {
+  dst[0] = make_uint4(a.l[0], a.l[1], a.l[2], a.l[3]);
+  dst[1] = make_uint4(a.l[4], a.l[5], a.l[6], a.l[7]);
+  dst[2] = make_uint4(a.l[8], 0u, 0u, 0u);
+}
+KDEV U29 gtab_load9(const uint4* src) {
+  const uint4 a = src[0], b = src[1], c = src[2];
+  U29 r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w; r.l[8] = c.x;
+  return r;
+}
+KDEV void st9(u32* __restrict__ p, const U29& a) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) p[i] = a.l[i];
+}
+KDEV void gtab_put(uint4* e4, const J29& q, const U29& beta, U29* zz_out, U29* zcu_out) {
+  u32* e = reinterpret_cast<u32*>(e4);
+  st9(e + 36, q.x); st9(e, q.y); st9(e + 9, q.z);
+  st9(e + 48, u29_mul(q.x, beta));
+  const U29 zz = u29_sqr(q.z);
+  st9(e + 18, zz);
+  const U29 zcu = u29_mul(q.z, zz);
+  st9(e + 27, zcu);
+  if (zz_out) { *zz_out = zz; *zcu_out = zcu; }
+}
+KDEV Jac<Fq> jac_scalar_mul_gtab_u29(const Jac<Fq>& p, const Fr& k_mont, uint4* __restrict__ tab) {
+  if (jac_is_inf(p)) return jac_inf<Fq>();
+  u32 k[8], k1[5], k2[5];
+  bool neg1, neg2;
+  fp_from_mont<FrParams>(k, k_mont);
+  glv_decompose(k, k1, neg1, k2, neg2);
+  const U29 beta = u29_const(GlvParams::BETA29);
+  {
+    // table entry m - 1 = m P, m = 1..8 (the same chain as jac_scalar_mul_u29); P and its Z^2, Z^3 stay in registers while it is built
+    J29 m1;
+    m1.x = u29_from_fq(p.x); m1.y = u29_from_fq(p.y); m1.z = u29_from_fq(p.z);
+    U29 zz1, zcu1;
+    gtab_put(tab, m1, beta, &zz1, &zcu1);
+    // every multiple goes to the table as soon as it exists and is read back (x, y, z) when a later one needs it: only P itself stays in
+    // registers across the build (the fences keep the compiler from forwarding the stored values, i.e. from keeping them alive)
+    auto back = [&](int idx) {
+      asm volatile("" ::: "memory");
+      const u32* e = reinterpret_cast<const u32*>(tab + idx * 16);
+      J29 q;
+      q.x = ld9(e + 36); q.y = ld9(e); q.z = ld9(e + 9);
+      return q;
+    };
+    int special;
+    { const J29 m2 = j29_dbl(m1);                                                   gtab_put(tab + 16, m2, beta, nullptr, nullptr); }
+    { const J29 m3 = j29_add(back(1), m1.x, m1.y, m1.z, zz1, zcu1, special);         gtab_put(tab + 32, m3, beta, nullptr, nullptr); }
+    { const J29 m4 = j29_dbl(back(1));                                               gtab_put(tab + 48, m4, beta, nullptr, nullptr); }
+    { const J29 m5 = j29_add(back(3), m1.x, m1.y, m1.z, zz1, zcu1, special);         gtab_put(tab + 64, m5, beta, nullptr, nullptr); }
+    { const J29 m6 = j29_dbl(back(2));                                               gtab_put(tab + 80, m6, beta, nullptr, nullptr); }
+    { const J29 m7 = j29_add(back(5), m1.x, m1.y, m1.z, zz1, zcu1, special);         gtab_put(tab + 96, m7, beta, nullptr, nullptr); }
+    { const J29 m8 = j29_dbl(back(3));                                               gtab_put(tab + 112, m8, beta, nullptr, nullptr); }
+    asm volatile("" ::: "memory");
+  }
+  U29 zero;
+#pragma unroll
+  for (int i = 0; i < 9; i++) zero.l[i] = 0;
+  u32 dig1[5], dig2[5], car = 0;
+  u32 sg1[2] = {0, 0}, sg2[2] = {0, 0};
+#pragma unroll
+  for (int w = 0; w < 5; w++) { dig1[w] = 0; dig2[w] = 0; }
+#pragma unroll 1
+  for (int j = 0; j < 33; j++) {
+    u32 d = ((j < 32) ? ((k1[j >> 3] >> ((j & 7) * 4)) & 15u) : 0u) + car;
+    car = d > 8u ? 1u : 0u;
+    const u32 mag = car ? 16u - d : d;
+    dig1[j >> 3] |= mag << ((j & 7) * 4);
+    sg1[j >> 5] |= car << (j & 31);
+  }
+  car = 0;
+#pragma unroll 1
+  for (int j = 0; j < 33; j++) {
+    u32 d = ((j < 32) ? ((k2[j >> 3] >> ((j & 7) * 4)) & 15u) : 0u) + car;
+    car = d > 8u ? 1u : 0u;
+    const u32 mag = car ? 16u - d : d;
+    dig2[j >> 3] |= mag << ((j & 7) * 4);
+    sg2[j >> 5] |= car << (j & 31);
+  }
+  J29 acc;
+  acc.x = zero; acc.y = zero; acc.z = zero;
+  bool empty = true;
+#pragma unroll 1
+  for (int j = 32; j >= 0; j--) {
+    if (!empty) { acc = j29_dbl(acc); acc = j29_dbl(acc); acc = j29_dbl(acc); acc = j29_dbl(acc); }
+#pragma unroll 1
+    for (int which = 0; which < 2; which++) {
+      const u32 mag = ((which ? dig2[j >> 3] : dig1[j >> 3]) >> ((j & 7) * 4)) & 15u;
+      if (mag) {
+        const bool neg = (((which ? sg2[j >> 5] : sg1[j >> 5]) >> (j & 31)) & 1u) != (which ? neg2 : neg1);
+        const u32* e32 = reinterpret_cast<const u32*>(tab + (mag - 1u) * 16u);
+        if (empty) {
+          acc.x = ld9(e32 + (which ? 48 : 36));
+          const U29 y = ld9(e32);
+          acc.y = neg ? u29_sub(zero, y, Q29::K32) : y;
+          acc.z = ld9(e32 + 9);
+          empty = false;
+        } else {
+          int special;
+          acc = j29_add_mem(acc, e32, which != 0, neg, special);
           if (special == 1) acc = j29_dbl(acc);
           if (special == 2) empty = true;
         }
