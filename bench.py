@@ -448,6 +448,23 @@ def main():
                       "note": "SIMD cycles one wave (64 butterflies) spends per butterfly stage step = scalar-mult + add + sub, at 2.4 GHz on 1024 SIMDs. The ladder at the "
                               "product stream's issue rate: 129 doublings x 6.6 K + 43 (wave-uniform sliding window) .. 66 (fixed windows) additions x 13 K = "
                               "1.41 .. 1.71 M cycles (DESIGN 4.2b)"}}
+        # fabric traffic of one call from the committed counter passes (bench_tools/collect_pmc_fk_pairing.sh), when they were made on this build
+        fk_traffic, fk_traffic_note = None, None
+        try:
+            from bench_tools.srchash import library_hashes
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r03_fk_pairing_hbm_traffic_pmc.json")))
+            hip.lib.keaki_hip_version.restype = C.c_char_p
+            if pj.get("hashes", {}).get("fk") != library_hashes(hip.lib.keaki_hip_version().decode()).get("fk"):
+                fk_traffic_note = "profiles/r03_fk_pairing_hbm_traffic_pmc.json was measured on other FK23 kernel sources: refused"
+            elif pj.get("fk_one_call", {}).get("log2d") != lg:
+                fk_traffic_note = "committed PMC figure is for another domain size"
+            else:
+                fk_traffic = pj["fk_one_call"]["fetch_bytes"] + pj["fk_one_call"]["write_bytes"]
+        except (OSError, ValueError, KeyError) as e:
+            fk_traffic_note = "no committed PMC figure (%s)" % type(e).__name__
+        fk["roofline"]["traffic"] = fk_traffic
+        fk["roofline"]["traffic_note"] = fk_traffic_note or ("FETCH_SIZE + WRITE_SIZE of ONE call, all FK23 kernels: the per-lane window tables of the ladders (2 KB written, "
+                                                             "43..66 x 256 B read per scalar-mult) and the 96-byte points, not the algorithmic 96 B per opening")
         fk_check = (fsrs, coeffs, proofs, om)
     # ---- Laconic OT, one GPU: the three phases the reference's test prints (tests/laconic_ot.rs:143-188) at 2^--laconic-log2n bits --------
     laconic = None

@@ -5,7 +5,8 @@ export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/$1; mkdir -p $O
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/fk_$c -o p -- python3 $R/bench_tools/bench_fk.py 21 > $O/fk_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/fk_$c -o p -- python3 $R/bench_tools/fk_calls.py 21 2 > $O/fk_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/fk1_$c -o p -- python3 $R/bench_tools/fk_calls.py 21 1 > $O/fk1_$c.log 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pair_$c -o p -- python3 $R/bench_tools/profile_pairing_split.py > $O/pair_$c.log 2>&1
 done
 cd $R
@@ -24,7 +25,7 @@ def per_kernel(d, counter):
                 out.setdefault(k, []).append(float(r["Counter_Value"]) * 1024.0)
     return out
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; KB x 1024; no gfx950 x2 correction: scattered 96-B / 64-B accesses, uncalibrated) of bench_tools/bench_fk.py 21 "
-                 "(setup + two calls) and bench_tools/profile_pairing_split.py (2^14 pairings, three launches per kernel); MI355X",
+                 "-> bench_tools/fk_calls.py 21 2 (setup + two calls; `fk_one_call` = that run minus a run with one call) and bench_tools/profile_pairing_split.py (2^14 pairings, three launches per kernel); MI355X",
        "library": lib.keaki_hip_version().decode(), "hashes": library_hashes(lib.keaki_hip_version().decode()), "fk_d": 1 << 21, "pairings": 1 << 14, "kernels": {}}
 for tag in ("fk", "pair"):
     f, w = per_kernel(tag + "_FETCH_SIZE", "FETCH_SIZE"), per_kernel(tag + "_WRITE_SIZE", "WRITE_SIZE")
@@ -32,6 +33,11 @@ for tag in ("fk", "pair"):
         if any(x in k for x in ("stage_map", "pointwise", "mul_jac", "fk_finish", "k_pairing", "k_miller", "k_final")):
             res["kernels"][k] = {"launches": len(f.get(k, [])), "fetch_bytes_total": sum(f.get(k, [])), "write_bytes_total": sum(w.get(k, [])),
                                  "fetch_bytes_per_launch": sum(f.get(k, [])) / max(1, len(f.get(k, []))), "write_bytes_per_launch": sum(w.get(k, [])) / max(1, len(w.get(k, [])))}
+# one call = (setup + 2 calls) - (setup + 1 call), summed over the FK23 kernels
+def total(tag, counter):
+    return sum(sum(v) for k, v in per_kernel(tag + "_" + counter, counter).items() if any(x in k for x in ("stage_map", "pointwise", "mul_jac", "fk_finish", "k_fr_", "k_fk_")))
+res["fk_one_call"] = {"fetch_bytes": total("fk", "FETCH_SIZE") - total("fk1", "FETCH_SIZE"), "write_bytes": total("fk", "WRITE_SIZE") - total("fk1", "WRITE_SIZE"), "log2d": 21}
+print("one call of open_fk at d = 2^21: fetch %.1f GB, write %.1f GB" % (res["fk_one_call"]["fetch_bytes"] / 1e9, res["fk_one_call"]["write_bytes"] / 1e9))
 json.dump(res, open(O + "/r03_fk_pairing_hbm_traffic_pmc.json", "w"), indent=1)
 for k, v in res["kernels"].items():
     print("%-50s launches %3d  fetch %.3f GB  write %.3f GB (totals)" % (k, v["launches"], v["fetch_bytes_total"] / 1e9, v["write_bytes_total"] / 1e9))

@@ -7,6 +7,7 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MSM_KERNEL_SOURCES = ["msm.hip.h", "msm_host.hip.h", "msm_g1.hip", "fq29.hip.h", "fq29_core.hip.h", "fq29_asm.hip.h", "xyzz29.hip.h", "jac29.hip.h",
                       "bn254_field.hip.h", "bn254_field_asm.hip.h", "bn254_curve.hip.h"]
+FK_KERNEL_SOURCES = ["fft_g1.hip", "jac29.hip.h", "fq29.hip.h", "fq29_core.hip.h", "fq29_asm.hip.h", "bn254_field.hip.h", "bn254_field_asm.hip.h", "bn254_curve.hip.h"]
 PAIRING_KERNEL_SOURCES = ["pairing.hip.h", "pairing.hip", "pair261.hip.h", "pair261_constants.hip.h", "fq29.hip.h", "fq29_core.hip.h", "fq29_asm.hip.h",
                           "fq29_dot_asm.hip.h", "bn254_field.hip.h", "bn254_field_asm.hip.h", "bn254_curve.hip.h"]
 
@@ -25,7 +26,7 @@ def source_hash(files=MSM_KERNEL_SOURCES) -> str:
 
 def define_string() -> str:
     """What csrc/Makefile embeds in keaki_hip_version(): 'msm:<hash>,pairing:<hash>'."""
-    return "msm:%s,pairing:%s" % (source_hash(MSM_KERNEL_SOURCES), source_hash(PAIRING_KERNEL_SOURCES))
+    return "msm:%s,pairing:%s,fk:%s" % (source_hash(MSM_KERNEL_SOURCES), source_hash(PAIRING_KERNEL_SOURCES), source_hash(FK_KERNEL_SOURCES))
 
 
 def library_hashes(version: str) -> dict:
@@ -45,7 +46,7 @@ def built_hash(hip_lib, which="msm") -> str:
     import ctypes
     hip_lib.keaki_hip_version.restype = ctypes.c_char_p
     got = library_hashes(hip_lib.keaki_hip_version().decode()).get(which)
-    want = source_hash(MSM_KERNEL_SOURCES if which == "msm" else PAIRING_KERNEL_SOURCES)
+    want = source_hash({"msm": MSM_KERNEL_SOURCES, "pairing": PAIRING_KERNEL_SOURCES, "fk": FK_KERNEL_SOURCES}[which])
     if got != want:
         raise RuntimeError("libkeaki_hip.so was built from other %s kernel sources (%s) than this tree holds (%s): rebuild" % (which, got, want))
     return got
@@ -58,3 +59,4 @@ if __name__ == "__main__":
     else:
         print("msm", source_hash(MSM_KERNEL_SOURCES))
         print("pairing", source_hash(PAIRING_KERNEL_SOURCES))
+        print("fk", source_hash(FK_KERNEL_SOURCES))
