@@ -445,9 +445,10 @@ def main():
                            "achieved": fk_algo / (stages_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fk_algo / (stages_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "note": "integer-issue bound like every kernel of the path: d log2 d butterfly scalar-mults of ~129 doublings + 43..66 additions each"},
               "alu": {"scalar_mults_per_s_in_stages": d * lg / (stages_ms * 1e-3), "simd_cycles_per_butterfly": stages_ms * 1e-3 * 2.4e9 / (d * lg / 64.0 / 1024.0),
-                      "note": "SIMD cycles one wave (64 butterflies) spends per butterfly stage step = scalar-mult + add + sub, at 2.4 GHz on 1024 SIMDs. The ladder at the "
-                              "product stream's issue rate: 129 doublings x 6.6 K + 43 (wave-uniform sliding window) .. 66 (fixed windows) additions x 13 K = "
-                              "1.41 .. 1.71 M cycles (DESIGN 4.2b)"}}
+                      "note": "SIMD cycles one wave (64 butterflies) spends per butterfly stage step = scalar-mult + add + sub, at 2.4 GHz on 1024 SIMDs. Counted "
+                              "(SQ_INSTS_VALU, profiles/r03_pairing_pmc_sq_insts.csv): 300 K VALU instructions per wave-butterfly in the stages with one twiddle per wave "
+                              "(129 doublings + 43 additions), 425 K in the six with a twiddle per lane (66 additions) = 1.37 / 1.93 M cycles at the product stream's "
+                              "issue rate, 1.53 M over the 21 stages of a transform at d = 2^21 (DESIGN 4.2b, 7.3)"}}
         # fabric traffic of one call from the committed counter passes (bench_tools/collect_pmc_fk_pairing.sh), when they were made on this build
         fk_traffic, fk_traffic_note = None, None
         try:

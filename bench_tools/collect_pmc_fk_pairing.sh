@@ -1,5 +1,6 @@
 #!/bin/bash
-# Fabric traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the FK23 stage kernels at d = 2^21 and of the pairing kernel at 2^14 pairings.
+# Fabric traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the FK23 stage kernels at d = 2^21 and of the pairing kernel at 2^14 pairings,
+# and the SQ instruction counters of the FK23 kernels (per wave).
 # Usage (repo root): bench_tools/collect_pmc_fk_pairing.sh <tag>   ->  gpurun_out/<tag>/r03_fk_pairing_hbm_traffic_pmc.json
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/$1; mkdir -p $O
@@ -9,6 +10,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/fk1_$c -o p -- python3 $R/bench_tools/fk_calls.py 21 1 > $O/fk1_$c.log 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pair_$c -o p -- python3 $R/bench_tools/profile_pairing_split.py > $O/pair_$c.log 2>&1
 done
+rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/fk_SQ -o p -- python3 $R/bench_tools/fk_calls.py 21 1 > $O/fk_SQ.log 2>&1
 cd $R
 python3 - $O <<'PY'
 import csv, glob, json, os, sys, ctypes
@@ -33,6 +35,17 @@ for tag in ("fk", "pair"):
         if any(x in k for x in ("stage_map", "pointwise", "mul_jac", "fk_finish", "k_pairing", "k_miller", "k_final")):
             res["kernels"][k] = {"launches": len(f.get(k, [])), "fetch_bytes_total": sum(f.get(k, [])), "write_bytes_total": sum(w.get(k, [])),
                                  "fetch_bytes_per_launch": sum(f.get(k, [])) / max(1, len(f.get(k, []))), "write_bytes_per_launch": sum(w.get(k, [])) / max(1, len(w.get(k, [])))}
+# instruction counters of the FK23 kernels, per wave (sums over all launches / SQ_WAVES)
+sq = {}
+for path in glob.glob("%s/fk_SQ/**/*counter_collection.csv" % O, recursive=True):
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0][-48:]
+        if any(x in k for x in ("stage_map", "pointwise", "mul_jac")):
+            sq.setdefault(k, {}).setdefault(r["Counter_Name"], 0.0)
+            sq[k][r["Counter_Name"]] += float(r["Counter_Value"])
+res["fk_instructions_per_wave"] = {k: {c.lower()[3:]: v[c] / v["SQ_WAVES"] for c in v if c != "SQ_WAVES"} for k, v in sq.items() if v.get("SQ_WAVES")}
+for k, v in res["fk_instructions_per_wave"].items():
+    print("%-50s per wave: %s" % (k, {c: int(x) for c, x in v.items()}))
 # one call = (setup + 2 calls) - (setup + 1 call), summed over the FK23 kernels
 def total(tag, counter):
     return sum(sum(v) for k, v in per_kernel(tag + "_" + counter, counter).items() if any(x in k for x in ("stage_map", "pointwise", "mul_jac", "fk_finish", "k_fr_", "k_fk_")))
