@@ -40,6 +40,9 @@
  *    pairing slots (0.48 GB), the GT tables of encapsulate (2.6 GB + 0.2 GB once a batch >= 2^16 ran). Per SRS
  *    handle (shared by every ctx of the device): points (64 B each) + window tables (W x 64 B each: 12.9 GB at
  *    2^24) + the FK23 transform (192 B per opening). All optional tables fall back when they do not fit.
+ *  - Current device: every call makes its ctx's GPU the calling thread's current HIP device for the duration of the
+ *    call and puts the caller's own choice back before it returns; the library never calls hipDeviceReset and
+ *    creates only non-blocking streams, so it can share a thread and a GPU with PyTorch or another HIP library.
  *  - The library reads the environment only inside keaki_hip_ctx_create (initial values of the tuning switches
  *    of keaki_hip_ctx_set_option); nothing on a call path calls getenv.
  */

@@ -182,7 +182,8 @@ void prefault_out(void* p, size_t bytes) {
 #define CTX_GUARD(ctx)                                \
   if (!(ctx)) return KEAKI_ERR_BAD_ARG;               \
   std::lock_guard<std::recursive_mutex> lock_((ctx)->mu);       \
-  if (hipSetDevice((ctx)->device) != hipSuccess) return fail(ctx, KEAKI_ERR_HIP, "hipSetDevice(%d) failed", (ctx)->device)
+  keaki_internal::DeviceScope dev_((ctx)->device);              \
+  if (!dev_.ok) return fail(ctx, KEAKI_ERR_HIP, "hipSetDevice(%d) failed", (ctx)->device)
 
 }  // namespace
 
@@ -237,7 +238,8 @@ keaki_status keaki_hip_ctx_create(int32_t device, void* stream, keaki_hip_ctx** 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, KEAKI_ERR_NO_DEVICE, "no HIP device visible");
   if (device < 0 || device >= ndev) return fail(nullptr, KEAKI_ERR_BAD_ARG, "device %d out of range (%d visible)", device, ndev);
-  HIP_TRY(nullptr, hipSetDevice(device));
+  keaki_internal::DeviceScope dev_(device);
+  if (!dev_.ok) return fail(nullptr, KEAKI_ERR_HIP, "hipSetDevice(%d) failed", device);
   hipDeviceProp_t prop;
   HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -261,13 +263,15 @@ keaki_status keaki_hip_ctx_create(int32_t device, void* stream, keaki_hip_ctx** 
 
 void keaki_hip_ctx_destroy(keaki_hip_ctx* ctx) {
   if (!ctx) return;
-  (void)hipSetDevice(ctx->device);
+  {
+  keaki_internal::DeviceScope dev_(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (const BufClass& bc : all_bufs(ctx))
     if (bc.b->p) (void)hipFree(bc.b->p);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : ctx->fk_ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  }
   delete ctx;
 }
 
@@ -400,8 +404,8 @@ keaki_status keaki_hip_srs_g1_slice(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* 
 size_t keaki_hip_srs_g1_len(const keaki_hip_srs_g1* srs) { return srs ? srs->n : 0; }
 void keaki_hip_srs_g1_free(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs) {
   if (!srs) return;
-  if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
-  if (srs->device >= 0) (void)hipSetDevice(srs->device);
+  if (ctx) { keaki_internal::DeviceScope dc_(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+  keaki_internal::DeviceScope dev_(srs->device);
   if (srs->owned && srs->d) (void)hipFree((void*)srs->d);
   if (srs->table) (void)hipFree(srs->table);
   if (srs->fk_hat_s) (void)hipFree(srs->fk_hat_s);
@@ -450,8 +454,8 @@ keaki_status keaki_hip_srs_g2_wrap_dev(keaki_hip_ctx* ctx, const void* d_points_
 }
 void keaki_hip_srs_g2_free(keaki_hip_ctx* ctx, keaki_hip_srs_g2* srs) {
   if (!srs) return;
-  if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
-  if (srs->device >= 0) (void)hipSetDevice(srs->device);
+  if (ctx) { keaki_internal::DeviceScope dc_(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+  keaki_internal::DeviceScope dev_(srs->device);
   if (srs->owned && srs->d) (void)hipFree((void*)srs->d);
   if (srs->table) (void)hipFree(srs->table);
   if (ctx && ctx == srs->acct) {
@@ -1011,12 +1015,11 @@ keaki_status keaki_hip_fk_shard_create(keaki_hip_ctx* ctx, const keaki_hip_srs_g
 }
 void keaki_hip_fk_shard_free(keaki_hip_ctx* ctx, keaki_hip_fk_shard* fk) {
   if (!fk) return;
+  keaki_internal::DeviceScope dev_(ctx ? ctx->device : fk->srs ? fk->srs->device : -1);
   if (ctx) {
     std::lock_guard<std::recursive_mutex> lock_(ctx->mu);
-    (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
   } else if (fk->srs && fk->srs->device >= 0) {
-    (void)hipSetDevice(fk->srs->device);
     (void)hipDeviceSynchronize();
   }
   fk_shard_release(fk);             // hipFree needs no context: the device buffers go even when the caller's ctx is already gone

@@ -262,7 +262,7 @@ namespace {
 keaki_status copy_between(keaki_hip_group* g, size_t dst_m, void* dst, size_t src_m, const void* src, size_t bytes) {
   const int dd = g->ctx[dst_m]->device, sd = g->ctx[src_m]->device;
   hipError_t e;
-  if (dd == sd) { (void)hipSetDevice(dd); e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice); }
+  if (dd == sd) { keaki_internal::DeviceScope dev_(dd); e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice); }
   else e = hipMemcpyPeer(dst, dd, src, sd, bytes);
   if (e != hipSuccess) return gfail(g, KEAKI_ERR_HIP, "group_fk: copy member %zu -> member %zu failed: %s", src_m, dst_m, hipGetErrorString(e));
   return KEAKI_OK;
@@ -271,7 +271,7 @@ keaki_status copy_between(keaki_hip_group* g, size_t dst_m, void* dst, size_t sr
 // non-blocking, i.e. NOT ordered behind the null stream: wait for every member's device before the next step reads the buffers.
 keaki_status copies_done(keaki_hip_group* g) {
   for (size_t i = 0; i < g->ctx.size(); i++) {
-    (void)hipSetDevice(g->ctx[i]->device);
+    keaki_internal::DeviceScope dev_(g->ctx[i]->device);
     const hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return gfail(g, KEAKI_ERR_HIP, "group_fk: hipDeviceSynchronize on member %zu failed: %s", i, hipGetErrorString(e));
   }
@@ -289,7 +289,7 @@ void group_fk_release(keaki_hip_group* g, keaki_hip_group_fk* f) {
   for (size_t i = 0; i < f->fk.size(); i++) keaki_hip_fk_shard_free(g && i < g->ctx.size() ? g->ctx[i] : nullptr, f->fk[i]);
   for (size_t i = 0; i < f->srs.size(); i++) keaki_hip_srs_g1_free(g && i < g->ctx.size() ? g->ctx[i] : nullptr, f->srs[i]);
   for (size_t i = 0; i < f->send.size(); i++) {
-    if (g && i < g->ctx.size()) (void)hipSetDevice(g->ctx[i]->device);
+    keaki_internal::DeviceScope dev_(g && i < g->ctx.size() ? g->ctx[i]->device : -1);
     if (f->send[i]) (void)hipFree(f->send[i]);
     if (f->recv[i]) (void)hipFree(f->recv[i]);
   }

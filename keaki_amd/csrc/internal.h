@@ -90,6 +90,25 @@ struct keaki_hip_ctx {
 
 namespace keaki_internal {
 
+// Makes `device` the calling thread's current HIP device for the scope and puts the caller's own choice back on exit: a host application
+// (PyTorch, another HIP library) that shares the thread never sees its current device change behind its back.
+struct DeviceScope {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceScope(int device) {
+    if (device < 0) return;
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == device) return;
+    ok = hipSetDevice(device) == hipSuccess;
+    if (ok) prev = cur;
+  }
+  ~DeviceScope() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 keaki_status fail(keaki_hip_ctx* ctx, keaki_status code, const char* fmt, ...);
 keaki_status reserve(keaki_hip_ctx* ctx, DevBuf& b, size_t bytes);
 // hipMalloc behind the library's one allocation gate. keaki_hip_debug_set_alloc_limit(ctx, bytes) makes every single allocation of this

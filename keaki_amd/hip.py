@@ -451,13 +451,15 @@ class KeakiHip:
         self._ck(self.lib.keaki_hip_fk_shard_open(self.ctx, fk.handle, step, _ptr(p), C.c_void_p(d_send), C.c_void_p(d_recv), _ptr(out)))
         return out
 
-    def encap_batch(self, com, tau_g2, points, values, rs, msg_len: int = 32):
+    def encap_batch(self, com, tau_g2, points, values, rs, msg_len: int = 32, want_gt: bool = True):
+        """-> (ct, gt, key), or (ct, key) with want_gt=False (the GT bytes stay on the device: only the keys come back)"""
         com = _np(com); tau = _np(tau_g2); pts = _np(points, 4); vals = _np(values, 4); rs = _np(rs, 4)
         n = pts.shape[0]
-        ct = np.zeros((n, 16), np.uint64); gt = np.zeros((n, 384), np.uint8); key = np.zeros((n, max(msg_len, 1)), np.uint8)
+        ct = np.zeros((n, 16), np.uint64); key = np.zeros((n, max(msg_len, 1)), np.uint8)
+        gt = np.zeros((n, 384), np.uint8) if want_gt else None
         self._ck(self.lib.keaki_hip_encap_batch(self.ctx, _ptr(com), _ptr(tau), _ptr(pts), _ptr(vals), _ptr(rs), n,
-                                                _ptr(ct), _ptr(gt), _ptr(key) if msg_len else None, msg_len))
-        return ct, gt, key[:, :msg_len]
+                                                _ptr(ct), _ptr(gt) if want_gt else None, _ptr(key) if msg_len else None, msg_len))
+        return (ct, gt, key[:, :msg_len]) if want_gt else (ct, key[:, :msg_len])
 
     def encap_prepare(self, tau_g2, batch_hint: int):
         """setup-time: the tables of encap_batch that depend on the setup only (keaki_hip_encap_prepare)"""

@@ -436,6 +436,26 @@ def test_encap_prepare_changes_nothing_but_the_first_call(oc, rand_fr):
         a.close(); b.close()
 
 
+def test_encap_keys_only(oc, rand_fr):
+    """encap_batch with gt_out = NULL (what vec_encrypt asks for: ciphertext points and keys, the 384 GT bytes per item stay on the device):
+    same points and keys as with the GT output, and as the oracle's."""
+    from keaki_amd.hip import KeakiHip
+    a = KeakiHip(0)
+    try:
+        g1, g2 = oc.generators()
+        tau_g2 = a.g2_mul_batch(g2, mont(oc, [91]))[0]
+        com = a.g1_mul_batch(g1, mont(oc, [92]))[0]
+        n = 700
+        A, V, Rr = (mont(oc, rand_fr(n, 9950 + k)) for k in range(3))
+        e = oc.encap_batch(com, tau_g2, A, V, Rr, 40, threads=8)
+        ct, key = a.encap_batch(com, tau_g2, A, V, Rr, 40, want_gt=False)
+        assert np.array_equal(ct, e[0]) and np.array_equal(key, e[2])
+        full = a.encap_batch(com, tau_g2, A, V, Rr, 40)
+        assert all(np.array_equal(x, y) for x, y in zip(full, e))
+    finally:
+        a.close()
+
+
 def test_encap_small_calls_switch_to_gt_path_when_commitment_repeats(oc, py, rand_fr, monkeypatch):
     """Under the automatic policy (option encap_gt = -1) the third consecutive call with one commitment (any batch size) builds the tables of A = e(C, g2) and B and
     takes the GT fixed-base path; later calls reuse them, a different commitment goes back to the per-item path. Own context (the policy is
