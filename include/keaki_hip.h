@@ -85,6 +85,8 @@ const char* keaki_hip_last_error(const keaki_hip_ctx* ctx); /* ctx may be NULL: 
 keaki_status keaki_hip_synchronize(keaki_hip_ctx* ctx);
 /* the hipStream_t every call of this ctx enqueues on (for callers that order their own work -- RCCL collectives, copies -- with it) */
 void* keaki_hip_ctx_stream(const keaki_hip_ctx* ctx);
+/* the HIP device ordinal the ctx is bound to (-1 for NULL): for companions that make their own HIP / RCCL calls beside it (keaki_hip_rccl.h) */
+int32_t keaki_hip_ctx_device(const keaki_hip_ctx* ctx);
 /* "keaki-hip <ver> (gfx950) src=msm:<hash>,pairing:<hash>,fk:<hash>": the hashes of the kernel sources the binary was built from */
 const char* keaki_hip_version(void);
 /* keaki_hip_last_error: the returned string is a copy private to the calling thread (valid until its next call of this function). */

@@ -343,6 +343,7 @@ keaki_status keaki_hip_ctx_memory(keaki_hip_ctx* ctx, size_t* out4) {
 }
 
 void* keaki_hip_ctx_stream(const keaki_hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+int32_t keaki_hip_ctx_device(const keaki_hip_ctx* ctx) { return ctx ? ctx->device : -1; }
 
 keaki_status keaki_hip_synchronize(keaki_hip_ctx* ctx) {
   CTX_GUARD(ctx);

@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <condition_variable>
 #include <functional>
+#include <memory>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -28,7 +30,8 @@ struct Worker {
       std::function<keaki_status()> j = std::move(job);
       has_job = false;
       lk.unlock();
-      keaki_status r = j();
+      keaki_status r;
+      try { r = j(); } catch (...) { r = KEAKI_ERR_OOM; }       // std::bad_alloc of a host vector: no exception leaves the thread
       lk.lock();
       result = r;
       done = true;
@@ -112,7 +115,8 @@ keaki_status keaki_hip_group_create(const int32_t* devices, size_t n_devices, ke
   }
   for (size_t i = 0; i < n_devices; i++) {
     Worker* w = new Worker();
-    w->th = std::thread([w] { w->loop(); });
+    const int device = g->ctx[i]->device;
+    w->th = std::thread([w, device] { (void)hipSetDevice(device); w->loop(); });     // the member's GPU is its thread's current device throughout
     g->workers.push_back(w);
   }
   *out = g;
@@ -201,10 +205,11 @@ keaki_status keaki_hip_group_kzg_open(keaki_hip_group* g, const keaki_hip_group_
   if (!srs || !point || !proof_out_jac || (n && !coeffs)) return gfail(g, KEAKI_ERR_BAD_ARG, "group_kzg_open: null pointer");
   const size_t nq = n ? n - 1 : 0;
   if (nq > srs->n) return gfail(g, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", nq, srs->n);
-  std::vector<uint64_t> q(4 * std::max<size_t>(nq, 1));
-  const keaki_status st = keaki_hip_kzg_quotient(g->ctx[0], coeffs, n, point, q.data(), value_out);
+  std::unique_ptr<uint64_t[]> q(new (std::nothrow) uint64_t[4 * std::max<size_t>(nq, 1)]);      // 32 bytes per coefficient: 0.5 GB at 2^24
+  if (!q) return gfail(g, KEAKI_ERR_OOM, "group_kzg_open: no host memory for the %zu coefficients of the quotient", nq);
+  const keaki_status st = keaki_hip_kzg_quotient(g->ctx[0], coeffs, n, point, q.get(), value_out);
   if (st != KEAKI_OK) return gfail(g, st, "group_kzg_open: quotient: %s", keaki_hip_last_error(g->ctx[0]));
-  return group_msm_locked(g, srs, q.data(), nq, proof_out_jac);
+  return group_msm_locked(g, srs, q.get(), nq, proof_out_jac);
 }
 
 keaki_status keaki_hip_group_encap_batch(keaki_hip_group* g, const uint64_t* com_aff, const uint64_t* tau_g2_aff, const uint64_t* points,

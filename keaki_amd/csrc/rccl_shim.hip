@@ -23,6 +23,22 @@ struct keaki_hip_rccl {
 
 namespace {
 thread_local std::string g_create_error;
+// the context's GPU as the calling thread's current device for the scope (RCCL binds a communicator and its launches to the current device);
+// the caller's own choice comes back on exit, as in the main library
+struct DeviceScope {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceScope(const keaki_hip_ctx* ctx) {
+    const int device = keaki_hip_ctx_device(ctx);
+    int cur = -1;
+    if (device < 0 || (hipGetDevice(&cur) == hipSuccess && cur == device)) return;
+    ok = hipSetDevice(device) == hipSuccess;
+    if (ok) prev = cur;
+  }
+  ~DeviceScope() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
 keaki_status rfail(keaki_hip_rccl* rc, keaki_status code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -53,7 +69,8 @@ keaki_status keaki_hip_rccl_unique_id(uint8_t out128[128]) {
 keaki_status keaki_hip_rccl_create(keaki_hip_ctx* ctx, const uint8_t id128[128], int32_t rank, int32_t world, keaki_hip_rccl** out) {
   if (!ctx || !id128 || !out || world < 1 || rank < 0 || rank >= world) return rfail(nullptr, KEAKI_ERR_BAD_ARG, "rccl_create: bad argument");
   *out = nullptr;
-  // the communicator must be created with the context's device current: a context-bound call of the main library sets it
+  DeviceScope dev_(ctx);           // the communicator and the two buffers below belong to the context's GPU
+  if (!dev_.ok) return rfail(nullptr, KEAKI_ERR_HIP, "rccl_create: hipSetDevice(%d) failed", (int)keaki_hip_ctx_device(ctx));
   keaki_status st = keaki_hip_synchronize(ctx);
   if (st != KEAKI_OK) return rfail(nullptr, st, "rccl_create: %s", keaki_hip_last_error(ctx));
   auto* rc = new keaki_hip_rccl();
@@ -73,6 +90,7 @@ keaki_status keaki_hip_rccl_create(keaki_hip_ctx* ctx, const uint8_t id128[128],
 
 void keaki_hip_rccl_destroy(keaki_hip_rccl* rc) {
   if (!rc) return;
+  DeviceScope dev_(rc->ctx);
   if (rc->ctx) (void)keaki_hip_synchronize(rc->ctx);
   if (rc->comm) (void)ncclCommDestroy(rc->comm);
   if (rc->gathered) (void)hipFree(rc->gathered);
@@ -93,6 +111,7 @@ keaki_status keaki_hip_rccl_all_gather(keaki_hip_rccl* rc, const void* d_send, v
   if (!rc) return KEAKI_ERR_BAD_ARG;
   std::lock_guard<std::mutex> lk(rc->mu);
   if (!d_send || !d_recv) return rfail(rc, KEAKI_ERR_BAD_ARG, "rccl_all_gather: null pointer");
+  DeviceScope dev_(rc->ctx);
   NCCL_TRY(rc, ncclAllGather(d_send, d_recv, bytes_per_rank, ncclUint8, rc->comm, (hipStream_t)keaki_hip_ctx_stream(rc->ctx)));
   return KEAKI_OK;
 }
@@ -101,6 +120,7 @@ keaki_status keaki_hip_rccl_all_to_all(keaki_hip_rccl* rc, const void* d_send, v
   if (!rc) return KEAKI_ERR_BAD_ARG;
   std::lock_guard<std::mutex> lk(rc->mu);
   if (!d_send || !d_recv) return rfail(rc, KEAKI_ERR_BAD_ARG, "rccl_all_to_all: null pointer");
+  DeviceScope dev_(rc->ctx);
   NCCL_TRY(rc, ncclAllToAll(d_send, d_recv, bytes_per_peer, ncclUint8, rc->comm, (hipStream_t)keaki_hip_ctx_stream(rc->ctx)));
   return KEAKI_OK;
 }
@@ -109,6 +129,7 @@ keaki_status keaki_hip_rccl_msm_g1(keaki_hip_rccl* rc, const keaki_hip_srs_g1* s
   if (!rc) return KEAKI_ERR_BAD_ARG;
   std::lock_guard<std::mutex> lk(rc->mu);
   if (!srs_chunk || !d_out_jac) return rfail(rc, KEAKI_ERR_BAD_ARG, "rccl_msm_g1: null pointer");
+  DeviceScope dev_(rc->ctx);
   keaki_status st = keaki_hip_msm_g1_dev(rc->ctx, srs_chunk, d_scalars, n, rc->partial);
   if (st != KEAKI_OK) return rfail(rc, st, "rccl_msm_g1: %s", keaki_hip_last_error(rc->ctx));
   // EC addition is not an RCCL reduction operator: all-gather the 96-byte partials, add them on every rank

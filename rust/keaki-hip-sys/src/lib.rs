@@ -62,6 +62,7 @@ extern "C" {
     pub fn keaki_hip_last_error(ctx: *const keaki_hip_ctx) -> *const c_char;
     pub fn keaki_hip_synchronize(ctx: *mut keaki_hip_ctx) -> keaki_status;
     pub fn keaki_hip_ctx_stream(ctx: *const keaki_hip_ctx) -> *mut c_void;
+    pub fn keaki_hip_ctx_device(ctx: *const keaki_hip_ctx) -> i32;
     pub fn keaki_hip_version() -> *const c_char;
     pub fn keaki_hip_ctx_set_option(ctx: *mut keaki_hip_ctx, name: *const c_char, value: i64) -> keaki_status;
     pub fn keaki_hip_debug_set_alloc_limit(ctx: *mut keaki_hip_ctx, bytes: usize) -> keaki_status;
