@@ -1,10 +1,11 @@
 // Jacobian scalar multiplication of BN254 G1 points in the 9 x 29-bit lazy representation (fq29.hip.h): the inner loop of the FK23
 // butterflies (fft_g1.hip; reference src/kzg.rs:182-200 = ark-poly group FFTs, every butterfly one `Group * ScalarField`).
 // GLV split k = k1 + k2 lambda (128-bit halves, phi(P) = (beta X, Y, Z)), fixed signed 4-bit windows over one table of 8 multiples, doubling dbl-2009-l with
-// D = 4 X Y^2 taken as a product (keeps every value small), addition add-2007-bl with the addend's Z^2, Z^3 precomputed.
-// Value bounds (multiples of p) on the running point: X < 17.6, Y < 19.3, Z < 3.4; the addend is below 1.2 (u29_from_fq). A limb-exact
-// model with 64-bit overflow assertions ran full 254-bit multiplications before this was written; test: k_selftest_j29 and the
-// FK23 parity tests.
+// D = 4 X Y^2 taken as a product (keeps every value small), addition add-1998-cmo-2 (no factors of two) with the addend's Z^2, Z^3 precomputed; the Y
+// coordinate of both formulas is one dual stream (two products, one reduction).
+// Value bounds (multiples of p) on the running point: X < 17.6, Y < 3.8 (a dual stream's output), Z < 2.1; the addend is below 1.2
+// (u29_from_fq). A limb-exact model with 64-bit overflow assertions (models/model_jac29.py, run by the CPU suite) executes whole ladders
+// with these formulas; tests: k_selftest_j29 and the FK23 parity tests.
 #pragma once
 #include "bn254_curve.hip.h"
 #include "fq29.hip.h"
@@ -29,13 +30,25 @@ KDEV U29 u29_sub2x(const U29& a, const U29& b, const u32 (&K)[9]) {
   return u29_carry(t);
 }
 KDEV J29 j29_dbl(const J29& p) {
-  const U29 A = u29_sqr(p.x), B = u29_sqr(p.y), C = u29_sqr(B), S = u29_mul(p.x, B);
-  const U29 D = u29_scale(S, 4), E = u29_scale(A, 3);
+  // dbl-2009-l with D = 4 X Y^2 as a product. No scaling passes: the factors of two ride on raw doubled limbs (a stream's wide operand).
+  const U29 A = u29_sqr(p.x), B = u29_sqr(p.y);
+  U29 b2, y2, n4, t;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { b2.l[i] = 2u * B.l[i]; y2.l[i] = 2u * p.y.l[i]; n4.l[i] = Q29::K16W[i] - 4u * B.l[i]; }
+  const U29 S2 = u29_mul(b2, p.x);                       // 2 X B = D / 2 (p.x carried)
+  const U29 E = u29_scale(A, 3);
+  const U29 EE = u29_sqr(E);
   J29 r;
-  r.x = u29_sub2x(u29_sqr(E), D, Q29::K16W);
-  const U29 T = u29_sub_raw(D, r.x, Q29::K32);
-  r.y = u29_sub2x(u29_mul(E, T), u29_scale(C, 4), Q29::K16W);
-  r.z = u29_scale(u29_mul(p.y, p.z), 2);
+#pragma unroll
+  for (int i = 0; i < 9; i++) t.l[i] = EE.l[i] - 4u * S2.l[i] + Q29::K16W[i];                 // E^2 - 2D + 16p
+  r.x = u29_carry(t);
+#pragma unroll
+  for (int i = 0; i < 9; i++) t.l[i] = 2u * S2.l[i] - r.x.l[i] + Q29::K32[i];                 // D - X3 + 32p
+  const U29 T = u29_carry(t);
+  // Y3 = E T - 8 B^2 as ONE dual stream (two products, one reduction): E T + (2B)(16p - 4B). 2B stays raw (limbs < 2^30: the wide operand),
+  // 16p - 4B is carried. The square C = B^2 and the product E T are no separate streams any more (models/model_jac29.py).
+  r.y = u29_mul2(E, T, b2, u29_carry(n4));
+  r.z = u29_mul(y2, p.z);                                // (2Y) Z
   return r;
 }
 // a + (X2, Y2, Z2) with Z2Z2 = Z2^2, Z2cu = Z2^3. special: 0 = ordinary sum (returned), 1 = the two points are equal (the caller doubles),
@@ -52,17 +65,19 @@ KDEV J29 j29_add(const J29& a, const U29& X2, const U29& Y2, const U29& Z2, cons
       return a;
     }
   }
-  const U29 I = u29_scale(u29_sqr(H), 4), J = u29_mul(H, I);
-  U29 t;
-#pragma unroll
-  for (int i = 0; i < 9; i++) t.l[i] = 2u * (S2.l[i] - S1.l[i] + Q29::K2[i]);
-  const U29 rr = u29_carry(t);
-  const U29 V = u29_mul(U1, I);
+  const U29 HH = u29_sqr(H), HHH = u29_mul(H, HH);
+  const U29 rr = u29_sub(S2, S1, Q29::K2);
+  const U29 V = u29_mul(U1, HH);
   J29 r;
-  r.x = u29_sub3(u29_sqr(rr), J, V);
-  const U29 T = u29_sub_raw(V, r.x, Q29::K16);
-  r.y = u29_sub2x(u29_mul(rr, T), u29_mul(S1, J), Q29::K4W);
-  r.z = u29_scale(u29_mul(u29_mul(a.z, Z2), H), 2);
+  r.x = u29_sub3(u29_sqr(rr), HHH, V);
+  const U29 T = u29_sub(V, r.x, Q29::K16);
+  // Y3 = r T - S1 H^3 as ONE dual stream: r T + (2p - S1) H^3, the second factor raw (S1 is a stream output below 1.1 p with exact limbs: 2p - S1
+  // stays positive in every limb and below 1.5 * 2^30)
+  U29 ns;
+#pragma unroll
+  for (int i = 0; i < 9; i++) ns.l[i] = Q29::K2[i] - S1.l[i];
+  r.y = u29_mul2(rr, T, ns, HHH);
+  r.z = u29_mul(u29_mul(a.z, Z2), H);
   return r;
 }
 
@@ -85,7 +100,7 @@ KDEV J29 j29_add_mem(const J29& a, const u32* __restrict__ e, bool phi, bool neg
     U29 zero;
 #pragma unroll
     for (int i = 0; i < 9; i++) zero.l[i] = 0;
-    Y2 = u29_sub(zero, Y2, Q29::K32);
+    Y2 = u29_sub(zero, Y2, Q29::K4);          // table y < 3.8 p (a dual stream's output or the input point)
   }
   const U29 S2 = u29_mul(Y2, u29_mul(a.z, Z1Z1));
   const U29 H = u29_sub(U2, U1, Q29::K2);
@@ -96,17 +111,19 @@ KDEV J29 j29_add_mem(const J29& a, const u32* __restrict__ e, bool phi, bool neg
       return a;
     }
   }
-  const U29 I = u29_scale(u29_sqr(H), 4), J = u29_mul(H, I);
-  U29 t;
-#pragma unroll
-  for (int i = 0; i < 9; i++) t.l[i] = 2u * (S2.l[i] - S1.l[i] + Q29::K2[i]);
-  const U29 rr = u29_carry(t);
-  const U29 V = u29_mul(U1, I);
+  const U29 HH = u29_sqr(H), HHH = u29_mul(H, HH);
+  const U29 rr = u29_sub(S2, S1, Q29::K2);
+  const U29 V = u29_mul(U1, HH);
   J29 r;
-  r.x = u29_sub3(u29_sqr(rr), J, V);
-  const U29 T = u29_sub_raw(V, r.x, Q29::K16);
-  r.y = u29_sub2x(u29_mul(rr, T), u29_mul(S1, J), Q29::K4W);
-  r.z = u29_scale(u29_mul(u29_mul(a.z, ld9(e + 9)), H), 2);
+  r.x = u29_sub3(u29_sqr(rr), HHH, V);
+  const U29 T = u29_sub(V, r.x, Q29::K16);
+  // Y3 = r T - S1 H^3 as ONE dual stream: r T + (2p - S1) H^3, the second factor raw (S1 is a stream output below 1.1 p with exact limbs: 2p - S1
+  // stays positive in every limb and below 1.5 * 2^30)
+  U29 ns;
+#pragma unroll
+  for (int i = 0; i < 9; i++) ns.l[i] = Q29::K2[i] - S1.l[i];
+  r.y = u29_mul2(rr, T, ns, HHH);
+  r.z = u29_mul(u29_mul(a.z, ld9(e + 9)), H);
   return r;
 }
 
@@ -259,7 +276,7 @@ KDEV Jac<Fq> jac_scalar_mul_u29(const Jac<Fq>& p, const Fr& k_mont) {
         const bool neg = (((which ? sg2[j >> 5] : sg1[j >> 5]) >> (j & 31)) & 1u) != (which ? neg2 : neg1);
         const J29T& e = T[mag - 1];
         const U29 ex = which ? e.xb : e.x;
-        const U29 ey = neg ? u29_sub(zero, e.y, Q29::K32) : e.y;
+        const U29 ey = neg ? u29_sub(zero, e.y, Q29::K4) : e.y;      // table y < 3.8 p; the negation may become the running point's y: j29_dbl wants it < 19 p
         if (empty) {
           acc.x = ex; acc.y = ey; acc.z = e.z;
           empty = false;
@@ -382,7 +399,7 @@ KDEV Jac<Fq> jac_scalar_mul_gtab_u29(const Jac<Fq>& p, const Fr& k_mont, uint4* 
         if (empty) {
           acc.x = ld9(e32 + (which ? 48 : 36));
           const U29 y = ld9(e32);
-          acc.y = neg ? u29_sub(zero, y, Q29::K32) : y;
+          acc.y = neg ? u29_sub(zero, y, Q29::K4) : y;
           acc.z = ld9(e32 + 9);
           empty = false;
         } else {
@@ -478,7 +495,7 @@ KDEV Jac<Fq> jac_scalar_mul_uniform_u29(const Jac<Fq>& p, const Fr& k_mont, unsi
         const bool neg = ((byte >> 7) != 0) != (which ? neg2 : neg1);
         const J29T& e = T[(byte & 0x7Fu) - 1u];
         const U29 ex = which ? e.xb : e.x;
-        const U29 ey = neg ? u29_sub(zero, e.y, Q29::K32) : e.y;
+        const U29 ey = neg ? u29_sub(zero, e.y, Q29::K4) : e.y;      // table y < 3.8 p; the negation may become the running point's y: j29_dbl wants it < 19 p
         if (empty) {
           acc.x = ex; acc.y = ey; acc.z = e.z;
           empty = false;

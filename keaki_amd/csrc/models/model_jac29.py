@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Limb-exact model of the Jacobian doubling and addition of jac29.hip.h (the ladders of the FK23 butterflies) in the 9 x 29-bit lazy
+arithmetic: the same operations in the same order on Python integers, with assertions on every limb (no negative value, no 32-bit overflow,
+stream operands within their budgets) and on every value bound, checked against plain affine arithmetic. Round 3's form: Y3 of the doubling
+(E T - 8 B^2) and of the addition (r T - 2 S1 J) are ONE dual stream each (u29_mul2: two products, one reduction) -- the square C = B^2
+and one product disappear as separate streams. tests/test_pair261_model.py runs this in the CPU suite.
+
+Streams (fq29_asm.hip.h): limbs exact on output, value < (sum of products) / 2^261 + p.
+  mul(a, b):      a <= 2^30 + 16, b <= 2^29 + 8          sqr(a): a <= 2^29 + 8
+  mul2(a,b,c,d):  a, b, d <= 2^29 + 8, c <= 1.5 * 2^30
+"""
+import random
+
+P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+MASK = (1 << 29) - 1
+R_ORDER = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+R261 = 1 << 261
+C = (1 << 29) + 8
+W = (1 << 30) + 16
+W15 = 3 << 29
+
+
+def limbs(v):
+    return [(v >> (29 * i)) & MASK for i in range(8)] + [v >> 232]
+
+
+def val(l):
+    return sum(x << (29 * i) for i, x in enumerate(l))
+
+
+def biased(c, bias_log=30):
+    k = limbs(c * P)
+    b, cy = 1 << bias_log, (1 << bias_log) >> 29
+    out = [k[0] + b] + [k[i] + b - cy for i in range(1, 8)] + [k[8] - cy]
+    assert val(out) == c * P and all(0 <= x < 1 << 32 for x in out)
+    return out
+
+
+K2, K4, K16, K32 = (biased(c) for c in (2, 4, 16, 32))
+K8W, K16W = biased(8, 31), biased(16, 31)
+maxima = {}
+
+
+def note(name, l, bound):
+    v = val(l)
+    assert v < bound * P, (name, v / P, bound)
+    maxima[name] = max(maxima.get(name, 0.0), v / P)
+    return l
+
+
+def chk(l, lim, what):
+    assert all(0 <= x <= lim for x in l[:8]) and 0 <= l[8] < 1 << 32, (what, [hex(x) for x in l])
+
+
+def u32s(l, what):
+    assert all(0 <= x < 1 << 32 for x in l), (what, l)
+    return l
+
+
+def carry(x):
+    u32s(x, "carry.in")
+    r = [x[0] & MASK] + [(x[i] & MASK) + (x[i - 1] >> 29) for i in range(1, 8)] + [x[8] + (x[7] >> 29)]
+    assert r[8] < 1 << 32 and val(r) == val(x)
+    return r
+
+
+def redc(t):
+    m = (t * ((-pow(P, -1, R261)) % R261)) % R261
+    r = (t + m * P) >> 261
+    assert r < t // R261 + P + 1
+    return limbs(r)
+
+
+def mul(a, b):
+    chk(a, W, "mul.a"); chk(b, C, "mul.b")
+    return redc(val(a) * val(b))
+
+
+def sqr(a):
+    chk(a, C, "sqr.a")
+    return redc(val(a) ** 2)
+
+
+def mul2(a, b, c, d):
+    chk(a, C, "mul2.a"); chk(b, C, "mul2.b"); chk(c, W15, "mul2.c"); chk(d, C, "mul2.d")
+    return redc(val(a) * val(b) + val(c) * val(d))
+
+
+def scale(a, k):
+    return carry(u32s([k * x for x in a], "scale"))
+
+
+def sub(a, b, K):
+    return carry(u32s([x - y + k for x, y, k in zip(a, b, K)], "sub"))
+
+
+def sub2x(a, b, K):
+    return carry(u32s([x - 2 * y + k for x, y, k in zip(a, b, K)], "sub2x"))
+
+
+def sub3(a, b, c):
+    return carry(u32s([x - y - 2 * z + k for x, y, z, k in zip(a, b, c, K8W)], "sub3"))
+
+
+# ---- the two formulas, as jac29.hip.h writes them ------------------------------------------------------------------------------
+def j29_dbl(p):
+    """dbl-2009-l with D = 4 X Y^2 as a product: A = X^2, B = Y^2, S2 = X (2B) = D / 2, E = 3A, X3 = E^2 - 2D, Y3 = E (D - X3) - 8 B^2, Z3 = (2Y) Z"""
+    x, y, z = p
+    A, B = sqr(x), sqr(y)
+    B2 = u32s([2 * b for b in B], "dbl.2B")                                  # raw: limbs < 2^30, a wide operand
+    S2 = mul(B2, x)                                                          # 2 X B; x carried
+    E = scale(A, 3)
+    x3 = note("dbl.x", carry(u32s([e - 4 * s + k for e, s, k in zip(sqr(E), S2, K16W)], "dbl.x3")), 19)      # E^2 - 8 X B + 16p
+    T = note("dbl.T", carry(u32s([2 * s - v + k for s, v, k in zip(S2, x3, K32)], "dbl.T")), 41)            # 4 X B - X3 + 32p
+    N4 = note("dbl.N4", carry(u32s([k - 4 * b for k, b in zip(K16W, B)], "dbl.N4")), 16.01)                   # 16p - 4B == -4B
+    y3 = note("dbl.y", mul2(E, T, B2, N4), 3.8)                              # E T - 8 B^2
+    Y2 = u32s([2 * v for v in y], "dbl.2y")
+    z3 = note("dbl.z", mul(Y2, z), 2.01)
+    return (x3, y3, z3)
+
+
+def j29_add(a, X2, Y2, Z2, Z2Z2, Z2cu):
+    """add-1998-cmo-2 (no factors of two anywhere): H = U2 - U1, r = S2 - S1, X3 = r^2 - H^3 - 2 U1 H^2, Y3 = r (U1 H^2 - X3) - S1 H^3, Z3 = Z1 Z2 H"""
+    x, y, z = a
+    Z1Z1 = sqr(z)
+    U1, U2, S1 = mul(x, Z2Z2), mul(X2, Z1Z1), mul(y, Z2cu)
+    S2 = mul(Y2, mul(z, Z1Z1))
+    H = sub(U2, U1, K2)
+    if val(H) % P == 0:
+        return None
+    HH = sqr(H)
+    HHH = mul(H, HH)
+    V = mul(U1, HH)
+    rr = sub(S2, S1, K2)
+    x3 = note("add.x", sub3(sqr(rr), HHH, V), 12)
+    T = note("add.T", sub(V, x3, K16), 19)
+    N = u32s([k - s1 for k, s1 in zip(K2, S1)], "add.N")                     # raw 2p - S1: limbs below 1.5 * 2^30, S1 < 1.1 p
+    note("add.S1", S1, 1.2)
+    y3 = note("add.y", mul2(rr, T, N, HHH), 3)                               # r T - S1 H^3
+    z3 = note("add.z", mul(mul(z, Z2), H), 2.01)
+    return (x3, y3, z3)
+
+
+# ---- plain arithmetic to compare with -------------------------------------------------------------------------------------------
+def aff_add(p, q):
+    if p is None: return q
+    if q is None: return p
+    (x1, y1), (x2, y2) = p, q
+    if x1 == x2:
+        if (y1 + y2) % P == 0: return None
+        lam = 3 * x1 * x1 * pow(2 * y1, -1, P) % P
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, -1, P) % P
+    x3 = (lam * lam - x1 - x2) % P
+    return (x3, (lam * (x1 - x3) - y1) % P)
+
+
+def aff_mul(k, p):
+    r = None
+    while k:
+        if k & 1: r = aff_add(r, p)
+        p = aff_add(p, p); k >>= 1
+    return r
+
+
+def to_aff(j):
+    X, Y, Z = (val(c) * pow(R261, -1, P) % P for c in j)
+    if Z == 0: return None
+    zi = pow(Z, -1, P)
+    return (X * zi * zi % P, Y * zi * zi * zi % P)
+
+
+def mont(v):
+    return limbs(v * R261 % P)
+
+
+def run(seed=1, ladders=6, bits=127):
+    rnd = random.Random(seed)
+    for it in range(ladders):
+        # a point in the bounds the ladders start from (u29_from_fq: < 1.2 p after the conversion product; here canonical)
+        while True:
+            x = rnd.randrange(P); y2 = (x * x * x + 3) % P
+            y = pow(y2, (P + 1) // 4, P)
+            if y * y % P == y2: break
+        base = (x, y)
+        P1 = (mont(x), mont(y), mont(1))
+        # window table 1..8 as the kernels build it: 2P by doubling, then +P each
+        tab = [P1, j29_dbl(P1)]
+        for m in range(3, 9):
+            q = tab[0]
+            tab.append(j29_add(tab[-1], q[0], q[1], q[2], sqr(q[2]), mul(q[2], sqr(q[2]))))
+        for m, t in enumerate(tab, 1):
+            assert to_aff(t) == aff_mul(m, base), m
+        k = rnd.getrandbits(bits) | (1 << (bits - 1))
+        digs = []
+        kk = k
+        while kk:
+            digs.append(kk & 15); kk >>= 4
+        acc, accv = None, 0
+        zero = [0] * 9
+        for d in reversed(digs):
+            if acc is not None:
+                for _ in range(4):
+                    acc = j29_dbl(acc)
+                accv *= 16
+            if d:
+                m = (d - 1) % 8 + 1                       # every table entry meets every kind of running point
+                neg = rnd.random() < 0.5                  # signed digits / negative half-scalars: the entry's y negated with 4p
+                e = tab[m - 1]
+                note("table.y", e[1], 3.8)
+                ey = sub(zero, e[1], K4) if neg else e[1]
+                sm = -m if neg else m
+                if acc is None:
+                    acc, accv = (e[0], ey, e[2]), sm
+                else:
+                    r = j29_add(acc, e[0], ey, e[2], sqr(e[2]), mul(e[2], sqr(e[2])))
+                    if r is None:
+                        if (accv - sm) % R_ORDER == 0:
+                            acc = j29_dbl(acc); accv *= 2
+                        else:
+                            acc, accv = None, 0
+                    else:
+                        acc, accv = r, accv + sm
+        if acc is None:
+            continue
+        accv %= R_ORDER
+        assert to_aff(acc) == aff_mul(accv, base)
+    return dict(maxima)
+
+
+if __name__ == "__main__":
+    m = run(1, 12)
+    for k in sorted(m):
+        print("%-8s max %.3f p" % (k, m[k]))

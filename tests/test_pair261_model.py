@@ -145,3 +145,19 @@ def test_g2_lazy_mixed_addition_model():
     m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
     maxima = m.run(trials=120, seed=3)
     assert maxima["X3"] < 1.1 and maxima["Yacc"] < 1.5 and maxima["P"] < 5.3 and maxima["R"] < 7.3
+
+
+def test_jacobian_ladder_formulas_model():
+    """keaki_amd/csrc/models/model_jac29.py: the Jacobian doubling and addition of jac29.hip.h (FK23 ladders) operation by operation on Python
+    integers -- Y3 of both formulas as ONE dual stream -- with assertions on every limb and every value bound; whole 127-bit window ladders
+    (table of eight multiples, four doublings and an addition per window) against plain affine arithmetic."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("model_jac29", os.path.join(ROOT, "keaki_amd", "csrc", "models", "model_jac29.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    maxima = m.run(seed=5, ladders=4)
+    assert maxima["dbl.x"] < 17.6 and maxima["dbl.y"] < 3.8 and maxima["add.y"] < 3.0 and maxima["dbl.z"] < 2.1 and maxima["add.z"] < 2.1
+    # worst cases by the stream rule value < (sum of products) / 2^261 + p, 2^261 / p > 169:
+    #   dbl: A < 19^2/169 + 1 = 3.14, E = 3A < 9.5, S < 19 * 3.2/169 + 1 = 1.4, D < 5.5, T < D + 32 = 37.5, B < 3.2 (the old Y bound), 2B (16 - 4B) <= 6.4 * 16
+    assert (9.5 * 37.5 + 6.4 * 16) / 169 + 1 < 3.8
+    #   add: r < 2 (1.3 + 2) = 6.6, V < 1.3, T < 17.3, 4p - 2 S1 < 4, J < 1.3
+    assert (6.6 * 17.3 + 4 * 1.3) / 169 + 1 < 3.0
