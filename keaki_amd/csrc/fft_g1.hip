@@ -63,7 +63,8 @@ static __global__ void __launch_bounds__(64) k_g1_jac_to_aff(const G1Jac* __rest
 // ((A, B) = (R, rank) on the cyclic layout, (1, 0) on the block layout). Lane order as k_g1_fft_stage: a wave shares one twiddle
 // while the stage has at least 64 blocks.
 // UNIFORM (chosen by the host: at least 64 blocks and at least one full wave): every wave has ONE twiddle and takes the sliding-window ladder.
-template <bool DIT, bool UNIFORM, bool GT>
+// AS29: the butterfly's add and subtract in the lazy limbs with their shared products computed once (option fk_addsub29, default on)
+template <bool DIT, bool UNIFORM, bool GT, bool AS29>
 static __global__ void __launch_bounds__(64, 3) k_g1_fft_stage_map(G1Jac* __restrict__ a, const Fr* __restrict__ tw, u32 m, u32 half, u32 A, u32 B, u32 stride,
                                                                    uint4* __restrict__ tab, u32 first) {
   u32 b = first + blockIdx.x * blockDim.x + threadIdx.x;
@@ -75,24 +76,48 @@ static __global__ void __launch_bounds__(64, 3) k_g1_fft_stage_map(G1Jac* __rest
   const u32 i0 = blk * 2 * half + j, i1 = i0 + half;
   Fr w = tw[((size_t)j * A + B) * stride];
   __shared__ unsigned char dig[UNIFORM ? 2 * UNIFORM_DIG_STRIDE : 4];
-  auto mul = [&](const G1Jac& pt) {
-    if constexpr (UNIFORM) return jac_scalar_mul_uniform_u29(pt, w, dig);
-    else return jac_scalar_mul_t<GT>(pt, w, ladder_slot(tab, b, first));
+  // w * pt into the lazy limbs; false: the product is the identity
+  auto mul_j = [&](const G1Jac& pt, J29& out) -> bool {
+    if constexpr (UNIFORM) return jac_scalar_mul_uniform_u29_j(pt, w, dig, out);
+    else if constexpr (GT) return jac_scalar_mul_gtab_u29_j(pt, w, ladder_slot(tab, b, first), out);
+    else return jac_scalar_mul_u29_j(pt, w, out);
+  };
+  // (u + v, u - v): in the lazy limbs with the shared products computed once (jac29.hip.h: j29_addsub); an identity on either side or
+  // u = +-v takes the generic saturated additions
+  auto addsub = [&](const G1Jac& u, bool v_inf, const J29& vj, G1Jac& sum, G1Jac& diff) {
+    if constexpr (AS29) {
+      J29 sj, dj;
+      if (!v_inf && !jac_is_inf(u) && j29_addsub(j29_from_sat(u), vj, sj, dj)) {
+        sum = j29_to_sat(sj);
+        diff = j29_to_sat(dj);
+        return;
+      }
+    }
+    G1Jac v = v_inf ? jac_inf<Fq>() : j29_to_sat(vj);
+    sum = jac_add(u, v);
+    v.y = -v.y;
+    diff = jac_add(u, v);
   };
   if (DIT) {
-    G1Jac v = a[i1];
-    if (!fr_is_one(w)) v = mul(v);
+    const G1Jac v = a[i1];
+    J29 vj;
+    bool v_inf;
+    if (fr_is_one(w)) { v_inf = jac_is_inf(v); vj = j29_from_sat(v); }
+    else v_inf = !mul_j(v, vj);
     const G1Jac u = a[i0];                 // read after the ladder: 24 registers less across it
-    a[i0] = jac_add(u, v);
-    v.y = -v.y;
-    a[i1] = jac_add(u, v);
+    G1Jac s_, d_;
+    addsub(u, v_inf, vj, s_, d_);
+    a[i0] = s_;
+    a[i1] = d_;
   } else {
-    const G1Jac u = a[i0];
-    G1Jac v = a[i1];
-    a[i0] = jac_add(u, v);
-    v.y = -v.y;
-    G1Jac t = jac_add(u, v);
-    if (!fr_is_one(w)) t = mul(t);
+    const G1Jac u = a[i0], v = a[i1];
+    G1Jac s_, t;
+    addsub(u, jac_is_inf(v), j29_from_sat(v), s_, t);
+    a[i0] = s_;
+    if (!fr_is_one(w)) {
+      J29 tj;
+      t = mul_j(t, tj) ? j29_to_sat(tj) : jac_inf<Fq>();
+    }
     a[i1] = t;
   }
 }
@@ -286,21 +311,37 @@ static void ladder_launches(keaki_hip_ctx* ctx, u32 total, L launch) {
   if (!tab) { launch((uint4*)nullptr, 0u, total); return; }
   for (u32 first = 0; first < total; first += FK_TAB_LANES) launch(tab, first, std::min(FK_TAB_LANES, total - first));
 }
+// the instantiation for (dit, uniform, table workspace, lazy butterflies); uniform never has a table workspace
+template <bool DIT, bool UNI, bool GT>
+static void launch_stage3(bool as29, dim3 grid, dim3 block, hipStream_t st, G1Jac* a, const Fr* tw, u32 m, u32 half, u32 A, u32 B, u32 stride, uint4* tab, u32 first) {
+  if (as29) hipLaunchKernelGGL((k_g1_fft_stage_map<DIT, UNI, GT, true>), grid, block, 0, st, a, tw, m, half, A, B, stride, tab, first);
+  else hipLaunchKernelGGL((k_g1_fft_stage_map<DIT, UNI, GT, false>), grid, block, 0, st, a, tw, m, half, A, B, stride, tab, first);
+}
+static void launch_stage(bool dit, bool uni, bool gt, bool as29, dim3 grid, dim3 block, hipStream_t st, G1Jac* a, const Fr* tw, u32 m, u32 half, u32 A, u32 B,
+                         u32 stride, uint4* tab, u32 first) {
+  if (uni) {
+    if (dit) launch_stage3<true, true, false>(as29, grid, block, st, a, tw, m, half, A, B, stride, tab, first);
+    else launch_stage3<false, true, false>(as29, grid, block, st, a, tw, m, half, A, B, stride, tab, first);
+  } else if (gt) {
+    if (dit) launch_stage3<true, false, true>(as29, grid, block, st, a, tw, m, half, A, B, stride, tab, first);
+    else launch_stage3<false, false, true>(as29, grid, block, st, a, tw, m, half, A, B, stride, tab, first);
+  } else {
+    if (dit) launch_stage3<true, false, false>(as29, grid, block, st, a, tw, m, half, A, B, stride, tab, first);
+    else launch_stage3<false, false, false>(as29, grid, block, st, a, tw, m, half, A, B, stride, tab, first);
+  }
+}
 static void stage_map(keaki_hip_ctx* ctx, bool dit, G1Jac* a, const Fr* tw, u32 m, u32 half, u32 A, u32 B, u32 stride) {
+  const bool as29 = ctx->tune.fk_addsub29;
   const bool uniform = ctx->tune.fk_uniform && m / (2 * half) >= 64;        // blocks: a power of two, so every 64-lane workgroup then shares one twiddle
   const dim3 block(64);
   if (uniform) {
     const dim3 grid(cdiv(m / 2, 64));
-    if (dit) hipLaunchKernelGGL((k_g1_fft_stage_map<true, true, false>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride, (uint4*)nullptr, 0u);
-    else hipLaunchKernelGGL((k_g1_fft_stage_map<false, true, false>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride, (uint4*)nullptr, 0u);
+    launch_stage(dit, true, false, as29, grid, block, ctx->stream, a, tw, m, half, A, B, stride, (uint4*)nullptr, 0u);
     return;
   }
   ladder_launches(ctx, m / 2, [&](uint4* tab, u32 first, u32 cnt) {
     const dim3 grid(cdiv(cnt, 64));
-    if (dit && tab) hipLaunchKernelGGL((k_g1_fft_stage_map<true, false, true>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride, tab, first);
-    else if (dit) hipLaunchKernelGGL((k_g1_fft_stage_map<true, false, false>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride, tab, first);
-    else if (tab) hipLaunchKernelGGL((k_g1_fft_stage_map<false, false, true>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride, tab, first);
-    else hipLaunchKernelGGL((k_g1_fft_stage_map<false, false, false>), grid, block, 0, ctx->stream, a, tw, m, half, A, B, stride, tab, first);
+    launch_stage(dit, false, tab != nullptr, as29, grid, block, ctx->stream, a, tw, m, half, A, B, stride, tab, first);
   });
 }
 static void launch_pointwise(keaki_hip_ctx* ctx, const G1Jac* hs_even, const G1Jac* hs_odd, const Fr* a, u32 log2d, u32 base, u32 m, G1Jac* out_e, G1Jac* out_o) {

@@ -35,6 +35,7 @@ struct Tuning {
   bool acc_nt = false;           // KEAKI_ACC_NT / "acc_nt": non-temporal loads of the table rows in the G1 bucket kernel
   bool fk_uniform = true;        // KEAKI_FK_UNIFORM / "fk_uniform": sliding-window ladder in the wave-uniform FK23 stages
   bool fk_gtab = true;           // KEAKI_FK_GTAB / "fk_gtab": window tables of the per-lane-scalar ladders in a lane-contiguous workspace (0: private memory)
+  bool fk_addsub29 = true;      // KEAKI_FK_ADDSUB29 / "fk_addsub29": the butterflies' add + subtract in the lazy limbs, shared products once (A/B switch)
   bool fb_occ1 = false;          // KEAKI_FB_OCC1 / "fb_occ1": one wave per SIMD for the G2 fixed-base kernel at any batch size
   int gt_wb_b = 0;               // KEAKI_GT_WB_B / "gt_wb_b": window bits of the table of e(g1, g2), 0 = automatic (20 / 16)
   long long encap_gt = -1;       // KEAKI_ENCAP_GT / "encap_gt": batch size from which encap takes the GT fixed-base path; -1 = automatic policy

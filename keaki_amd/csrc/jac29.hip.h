@@ -127,6 +127,40 @@ KDEV J29 j29_add_mem(const J29& a, const u32* __restrict__ e, bool phi, bool neg
   return r;
 }
 
+// (u + v, u - v) of an FK23 butterfly in the lazy limbs. u, v: Jacobian, every coordinate below 32 p with carried limbs (a saturated residue
+// through u29_from_sat_shift5, or a ladder's running point), neither the identity. The products up to H = U2 - U1 and Z3 = Z1 Z2 H are shared
+// by the two results; r^2 and the dual stream of Y are per result (add-1998-cmo-2, r' = -S2 - S1 for the difference). Returns false when
+// u = +-v (H = 0): the caller takes the generic path. Bounds: models/model_jac29.py (j29_addsub). 15 streams + 2 x 2 instead of two saturated
+// additions of 16 products each and three conversions of the ladder's result.
+KDEV bool j29_addsub(const J29& u, const J29& v, J29& sum, J29& diff) {
+  const U29 Z1Z1 = u29_sqr(u.z), Z2Z2 = u29_sqr(v.z);
+  const U29 U1 = u29_mul(u.x, Z2Z2), U2 = u29_mul(v.x, Z1Z1);
+  const U29 S1 = u29_mul(u.y, u29_mul(v.z, Z2Z2)), S2 = u29_mul(v.y, u29_mul(u.z, Z1Z1));
+  const U29 H = u29_sub(U2, U1, Q29::K4);
+  if (u29_maybe_zero(H)) {
+    if (u29_is_zero(H)) return false;
+  }
+  sum.z = u29_mul(u29_mul(u.z, v.z), H);
+  diff.z = sum.z;
+  const U29 HH = u29_sqr(H), HHH = u29_mul(H, HH), V = u29_mul(U1, HH);
+  U29 ns, t;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { ns.l[i] = Q29::K2[i] - S1.l[i]; t.l[i] = Q29::K4[i] - S2.l[i] - S1.l[i]; }
+  {
+    const U29 rr = u29_sub(S2, S1, Q29::K2);
+    sum.x = u29_sub3(u29_sqr(rr), HHH, V);
+    sum.y = u29_mul2(rr, u29_sub(V, sum.x, Q29::K16), ns, HHH);
+  }
+  {
+    const U29 rr = u29_carry(t);
+    diff.x = u29_sub3(u29_sqr(rr), HHH, V);
+    diff.y = u29_mul2(rr, u29_sub(V, diff.x, Q29::K16), ns, HHH);
+  }
+  return true;
+}
+KDEV J29 j29_from_sat(const Jac<Fq>& p) { return {u29_from_sat_shift5(p.x.l), u29_from_sat_shift5(p.y.l), u29_from_sat_shift5(p.z.l)}; }
+KDEV Jac<Fq> j29_to_sat(const J29& a) { return {u29_to_fq(a.x), u29_to_fq(a.y), u29_to_fq(a.z)}; }
+
 // ---- GLV: k = k1 + k2 lambda (mod r), |k1|, |k2| < 2^127, phi(x, y) = (beta x, y) = lambda (x, y) ------------------------------
 // Babai rounding on the short basis (a1, b1), (a2, b2): c_i = (k g_i) >> 256, k1 = k - c1 a1 - c2 a2, k2 = -c1 b1 - c2 b2, all computed
 // modulo 2^160 (the results fit 128 signed bits). out: magnitudes (5 words, top word 0) and signs.
@@ -209,8 +243,10 @@ struct J29T {            // table entry: multiple m P with everything an additio
 // is the same entry with beta X): 33 windows x (4 doublings + 2 additions) = 129 doublings + 66 additions + 11 table operations. Every
 // lane of a wave does the same work whatever its scalar -- a NAF ladder with per-lane scalars executes its addition in nearly every
 // iteration (some lane always has a non-zero digit): 258 additions. The table lives in private memory (per-lane index).
-KDEV Jac<Fq> jac_scalar_mul_u29(const Jac<Fq>& p, const Fr& k_mont) {
-  if (jac_is_inf(p)) return jac_inf<Fq>();
+// The *_j forms return the running point in the lazy limbs (false: the product is the identity): the FK23 butterflies add and subtract it
+// without a detour through the saturated words.
+KDEV bool jac_scalar_mul_u29_j(const Jac<Fq>& p, const Fr& k_mont, J29& out) {
+  if (jac_is_inf(p)) return false;
   u32 k[8], k1[5], k2[5];
   bool neg1, neg2;
   fp_from_mont<FrParams>(k, k_mont);
@@ -289,8 +325,14 @@ KDEV Jac<Fq> jac_scalar_mul_u29(const Jac<Fq>& p, const Fr& k_mont) {
       }
     }
   }
-  if (empty) return jac_inf<Fq>();
-  return {u29_to_fq(acc.x), u29_to_fq(acc.y), u29_to_fq(acc.z)};
+  if (empty) return false;
+  out = acc;
+  return true;
+}
+KDEV Jac<Fq> jac_scalar_mul_u29(const Jac<Fq>& p, const Fr& k_mont) {
+  J29 a;
+  if (!jac_scalar_mul_u29_j(p, k_mont, a)) return jac_inf<Fq>();
+  return {u29_to_fq(a.x), u29_to_fq(a.y), u29_to_fq(a.z)};
 }
 
 
@@ -328,8 +370,8 @@ KDEV void gtab_put(uint4* e4, const J29& q, const U29& beta, U29* zz_out, U29* z
   st9(e + 27, zcu);
   if (zz_out) { *zz_out = zz; *zcu_out = zcu; }
 }
-KDEV Jac<Fq> jac_scalar_mul_gtab_u29(const Jac<Fq>& p, const Fr& k_mont, uint4* __restrict__ tab) {
-  if (jac_is_inf(p)) return jac_inf<Fq>();
+KDEV bool jac_scalar_mul_gtab_u29_j(const Jac<Fq>& p, const Fr& k_mont, uint4* __restrict__ tab, J29& out) {
+  if (jac_is_inf(p)) return false;
   u32 k[8], k1[5], k2[5];
   bool neg1, neg2;
   fp_from_mont<FrParams>(k, k_mont);
@@ -411,8 +453,14 @@ KDEV Jac<Fq> jac_scalar_mul_gtab_u29(const Jac<Fq>& p, const Fr& k_mont, uint4* 
       }
     }
   }
-  if (empty) return jac_inf<Fq>();
-  return {u29_to_fq(acc.x), u29_to_fq(acc.y), u29_to_fq(acc.z)};
+  if (empty) return false;
+  out = acc;
+  return true;
+}
+KDEV Jac<Fq> jac_scalar_mul_gtab_u29(const Jac<Fq>& p, const Fr& k_mont, uint4* __restrict__ tab) {
+  J29 a;
+  if (!jac_scalar_mul_gtab_u29_j(p, k_mont, tab, a)) return jac_inf<Fq>();
+  return {u29_to_fq(a.x), u29_to_fq(a.y), u29_to_fq(a.z)};
 }
 
 
@@ -424,7 +472,7 @@ KDEV Jac<Fq> jac_scalar_mul_gtab_u29(const Jac<Fq>& p, const Fr& k_mont, uint4* 
 // position: (|d| + 1) / 2 in the low bits, the sign in bit 7. Bounds: j29_dbl and j29_add map the running point's bound set into itself
 // (header of this file), so the order of the operations does not matter.
 constexpr int UNIFORM_DIG_STRIDE = 132;
-KDEV Jac<Fq> jac_scalar_mul_uniform_u29(const Jac<Fq>& p, const Fr& k_mont, unsigned char* dig) {
+KDEV bool jac_scalar_mul_uniform_u29_j(const Jac<Fq>& p, const Fr& k_mont, unsigned char* dig, J29& out) {
   u32 k[8], k1[5], k2[5];
   bool neg1, neg2;
   fp_from_mont<FrParams>(k, k_mont);
@@ -508,8 +556,14 @@ KDEV Jac<Fq> jac_scalar_mul_uniform_u29(const Jac<Fq>& p, const Fr& k_mont, unsi
       }
     }
   }
-  if (empty || jac_is_inf(p)) return jac_inf<Fq>();
-  return {u29_to_fq(acc.x), u29_to_fq(acc.y), u29_to_fq(acc.z)};
+  if (empty || jac_is_inf(p)) return false;
+  out = acc;
+  return true;
+}
+KDEV Jac<Fq> jac_scalar_mul_uniform_u29(const Jac<Fq>& p, const Fr& k_mont, unsigned char* dig) {
+  J29 a;
+  if (!jac_scalar_mul_uniform_u29_j(p, k_mont, dig, a)) return jac_inf<Fq>();
+  return {u29_to_fq(a.x), u29_to_fq(a.y), u29_to_fq(a.z)};
 }
 
 }  // namespace bn254

@@ -141,6 +141,36 @@ def j29_add(a, X2, Y2, Z2, Z2Z2, Z2cu):
     return (x3, y3, z3)
 
 
+def j29_addsub(u, v):
+    """(u + v, u - v) of the FK23 butterflies, both Jacobian with every coordinate below 32 p (a saturated residue shifted by 5 bits, or a ladder's
+    running point): the products up to H and Z3 are shared, r^2 and the dual stream of Y are per output. None when u = +-v."""
+    X1, Y1, Z1 = u
+    X2, Y2, Z2 = v
+    Z1Z1, Z2Z2 = sqr(Z1), sqr(Z2)
+    U1, U2 = note("as.U1", mul(X1, Z2Z2), 2.35), note("as.U2", mul(X2, Z1Z1), 2.35)
+    Z1cu, Z2cu = mul(Z1, Z1Z1), mul(Z2, Z2Z2)
+    S1, S2 = note("as.S1", mul(Y1, Z2cu), 1.45), note("as.S2", mul(Y2, Z1cu), 1.45)
+    ZZ = mul(Z1, Z2)
+    H = note("as.H", sub(U2, U1, K4), 6.35)
+    if val(H) % P == 0:
+        return None
+    z3 = note("as.z", mul(ZZ, H), 1.3)
+    HH = sqr(H)
+    HHH, V = mul(H, HH), mul(U1, HH)
+    N = u32s([k - s1 for k, s1 in zip(K2, S1)], "as.N")
+    out = []
+    for minus in (False, True):
+        if minus:
+            rr = note("as.r-", carry(u32s([k - a - b for k, a, b in zip(K4, S2, S1)], "as.r-")), 4.01)
+        else:
+            rr = note("as.r+", sub(S2, S1, K2), 3.45)
+        x3 = note("as.x", sub3(sqr(rr), HHH, V), 9.2)
+        T = note("as.T", sub(V, x3, K16), 17.1)
+        y3 = note("as.y", mul2(rr, T, N, HHH), 1.45)
+        out.append((x3, y3, z3))
+    return out
+
+
 # ---- plain arithmetic to compare with -------------------------------------------------------------------------------------------
 def aff_add(p, q):
     if p is None: return q
@@ -225,6 +255,28 @@ def run(seed=1, ladders=6, bits=127):
             continue
         accv %= R_ORDER
         assert to_aff(acc) == aff_mul(accv, base)
+    # the butterflies' (u + v, u - v): inputs are canonical residues in the 2^256 form shifted by 5 bits (values up to 32 p), or a ladder's output
+    for it in range(4 * ladders):
+        pts = []
+        for _ in range(2):
+            while True:
+                x = rnd.randrange(P); y2 = (x * x * x + 3) % P
+                y = pow(y2, (P + 1) // 4, P)
+                if y * y % P == y2: break
+            zz = rnd.randrange(1, P)
+            R256 = 1 << 256
+            jac = (x * zz * zz % P, y * zz * zz * zz % P, zz)
+            big = it % 2 == 0                              # worst case: residues close to p
+            coords = tuple(limbs((((P - 1 - rnd.randrange(1 << 20)) if big and k != 2 else (c * R256 % P)) << 5)) for k, c in enumerate(jac))
+            if big:
+                # keep it a curve point: only the bounds matter in this branch, compare nothing
+                pts.append((coords, None))
+            else:
+                pts.append((coords, (x, y)))
+        (u, ua), (v, va) = pts
+        res = j29_addsub(u, v)
+        if res is not None and ua is not None and va is not None:
+            assert to_aff(res[0]) == aff_add(ua, va) and to_aff(res[1]) == aff_add(ua, (va[0], (P - va[1]) % P))
     return dict(maxima)
 
 

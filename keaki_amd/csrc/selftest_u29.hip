@@ -136,6 +136,28 @@ __global__ void __launch_bounds__(64) k_selftest_j29(u32 seed, u32 iters, unsign
     Aff<Fq> got = jac_to_aff(a);
     bad += !(fq_eq(got.x, ref.x) && fq_eq(got.y, ref.y));
     bad += !jac_is_inf(jac_scalar_mul_u29(jac_inf<Fq>(), k));
+    // the butterflies' shared add / subtract: the ladder's running point against the base, against the saturated additions
+    J29 aj, sj, dj;
+    if (jac_scalar_mul_u29_j(p, k, aj)) {
+      const bool ok = j29_addsub(j29_from_sat(p), aj, sj, dj);
+      Jac<Fq> na = a;
+      na.y = -na.y;
+      const Jac<Fq> es = jac_add(p, a), ed = jac_add(p, na);
+      if (ok) {
+        const Aff<Fq> gs = jac_to_aff(j29_to_sat(sj)), gd = jac_to_aff(j29_to_sat(dj)), rs = jac_to_aff(es), rd = jac_to_aff(ed);
+        bad += !(fq_eq(gs.x, rs.x) && fq_eq(gs.y, rs.y) && fq_eq(gd.x, rd.x) && fq_eq(gd.y, rd.y));
+      } else {
+        bad += !(jac_is_inf(es) || jac_is_inf(ed));       // refused only for u = +-v (k = 1 and k = r - 1 above)
+      }
+      // the same point in two Jacobian representations (a + p and p + a: Z differs by the sign of H), and its negative: both refused
+      if (!jac_is_inf(es)) {
+        const Jac<Fq> q1 = es, q2 = jac_add(a, p);
+        Jac<Fq> nq2 = q2;
+        nq2.y = -nq2.y;
+        bad += j29_addsub(j29_from_sat(q1), j29_from_sat(q2), sj, dj) ? 1u : 0u;
+        bad += j29_addsub(j29_from_sat(q1), j29_from_sat(nq2), sj, dj) ? 1u : 0u;
+      }
+    }
     p = jac_is_inf(a) ? jac_dbl(p) : jac_add(a, p);      // next base: some other multiple, non-trivial Z
   }
   if (bad) atomicAdd(mismatches, bad);
