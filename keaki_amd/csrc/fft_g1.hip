@@ -294,10 +294,10 @@ namespace keaki_internal {
 using namespace bn254;
 
 // ---- launching the kernels whose lanes run the per-lane-scalar ladder --------------------------------------------------------------------
-// Their window tables live in a workspace of the context, one 2 KB slot per lane of a launch (jac29.hip.h: jac_scalar_mul_gtab_u29): at most
-// FK_TAB_LANES lanes per launch, i.e. 2 GB. When the workspace cannot be had (or option fk_gtab = 0) the kernels keep the table in private
+// Their window tables live in a workspace of the context, one 1 KB slot per lane of a launch (jac29.hip.h: jac_scalar_mul_gtab_u29: eight
+// effective-affine entries of 128 bytes): at most FK_TAB_LANES lanes per launch, i.e. 2 GB. When the workspace cannot be had (or option fk_gtab = 0) the kernels keep the table in private
 // memory, one launch for all lanes.
-constexpr u32 FK_TAB_LANES = 1u << 20;
+constexpr u32 FK_TAB_LANES = 1u << 21;
 static uint4* fk_table(keaki_hip_ctx* ctx, u32 lanes) {
   if (!ctx->tune.fk_gtab || lanes == 0) return nullptr;
   const size_t want = (size_t)std::min(lanes, FK_TAB_LANES) * GTAB_UINT4_PER_LANE * sizeof(uint4);

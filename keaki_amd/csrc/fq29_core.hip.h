@@ -192,6 +192,8 @@ KDEV U29 u29_sub3(const U29& a, const U29& b, const U29& c) {
 }
 // cheap necessary condition for x == 0 (mod p) when x < 18p and limb 0 is exact (after u29_carry): x = k p => l[0] * p^-1 = k
 KDEV bool u29_maybe_zero(const U29& x) { return ((x.l[0] * Q29::PINV) & Q29::MASK) <= 17u; }
+// the same for x < 35p (the H of a mixed addition: U2 - X1 + 32p with X1 < 19p)
+KDEV bool u29_maybe_zero34(const U29& x) { return ((x.l[0] * Q29::PINV) & Q29::MASK) <= 34u; }
 
 // t < 2p with exact limbs (a product's output) -> the canonical integer below p, packed into 8 x 32 bits
 KDEV void fq_cond_sub_p_asm(u32* __restrict__ r, const u32* __restrict__ t);   // bn254_field_asm.hip.h (included after this file)

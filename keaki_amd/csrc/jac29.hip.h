@@ -234,71 +234,147 @@ KDEV void glv_decompose(const u32* k, u32* k1, bool& neg1, u32* k2, bool& neg2) 
   }
 }
 
-// general Jacobian + Jacobian in the lazy arithmetic (the addend comes from a table: its Z^2, Z^3 are stored with it)
-struct J29T {            // table entry: multiple m P with everything an addition needs, and beta X for phi(m P)
-  U29 x, xb, y, z, zz, zcu;
+// ---- effective-affine window tables (round 3) ------------------------------------------------------------------------------------
+// The ladders add table entries to a running point ~43 .. 66 times. With Jacobian entries that is a general addition (12M + 4S); with AFFINE
+// entries a mixed one (8M + 3S). An inversion per lane to normalise the entries costs more than that saves -- but no inversion is needed:
+// a Jacobian point (X, Y, Z) of E: y^2 = x^3 + b IS the affine point (X, Y) of the isomorphic curve E_Z: y^2 = x^3 + b Z^6, and neither the
+// doubling (a = 0) nor the mixed addition reads b. So: build the table with every entry brought to ONE common Z_g (the build records the
+// ratio Z_(i+1) / Z_i of every step -- the H of the mixed addition -- and rescales entry i by the product of the later ratios: 4M + 1S per
+// entry), run the whole ladder on E_(Z_g) with the entries as affine points, and multiply the result's Z by Z_g at the end (the trick of
+// libsecp256k1's ecmult, here per lane). phi((x, y)) = (beta x, y) holds on every E_Z. An entry is (x, beta x, y): 27 words instead of 54.
+// models/model_jac29.py runs these builds and ladders limb by limb.
+struct J29A {            // table entry: affine on the working curve, with beta x for phi
+  U29 x, xb, y;
 };
+// a (Jacobian on the working curve: X < 19 p, Y <= 4 p, limbs carried) + (x2, y2) affine. 8M + 3S without factors of two, Y3 as one dual
+// stream. special as j29_add. H (= Z3 / Z1) goes to *ratio when the build asks for it.
+KDEV J29 j29_madd(const J29& a, const U29& x2, const U29& y2, int& special, U29* ratio = nullptr) {
+  const U29 Z1Z1 = u29_sqr(a.z);
+  const U29 U2 = u29_mul(x2, Z1Z1);
+  const U29 S2 = u29_mul(y2, u29_mul(a.z, Z1Z1));
+  const U29 H = u29_sub(U2, a.x, Q29::K32);
+  special = 0;
+  if (u29_maybe_zero34(H)) {
+    if (u29_is_zero(H)) {
+      special = u29_is_zero(u29_sub(S2, a.y, Q29::K4)) ? 1 : 2;
+      return a;
+    }
+  }
+  if (ratio) *ratio = H;
+  const U29 HH = u29_sqr(H), HHH = u29_mul(H, HH), V = u29_mul(a.x, HH);
+  const U29 rr = u29_sub(S2, a.y, Q29::K4);
+  J29 r;
+  r.x = u29_sub3(u29_sqr(rr), HHH, V);
+  const U29 T = u29_sub(V, r.x, Q29::K16);
+  U29 ns;                                   // raw 8p - Y1: Y1 <= 4p with carried limbs, so every limb stays positive and below 1.5 * 2^30
+#pragma unroll
+  for (int i = 0; i < 9; i++) ns.l[i] = Q29::K8[i] - a.y.l[i];
+  r.y = u29_mul2(rr, T, ns, HHH);
+  r.z = u29_mul(a.z, H);
+  return r;
+}
+// Table builds. `St` is where the entries wait: raw(i, x, y, ratio) keeps entry i as the chain produced it together with Z_i / Z_(i-1);
+// get(i, x, y, ratio) reads it back; fin(i, x, y) stores the final entry (the store adds beta x). Both chains are LINEAR (entry i + 1 =
+// entry i + one fixed affine point), so only the last entry is alive while the chain runs. Returns zfix: Z on E = Z on the working curve * zfix.
+//   multiples: entries m P, m = 1..8, on the curve where P = (X, Y) is affine (isomorphic by Z_P): 2P = dbl(P), then + P six times
+//   odd:       entries (2i + 1) P, i = 0..7, on the curve where D = 2P is affine (isomorphic by Z_D): P -> (X Z_D^2, Y Z_D^3, Z_P), then + D
+template <bool ODD, class St>
+KDEV U29 j29_build_table(const Jac<Fq>& p, St& st) {
+  J29 m1;
+  m1.x = u29_from_fq(p.x); m1.y = u29_from_fq(p.y); m1.z = u29_from_fq(p.z);
+  U29 ax, ay, zbase;                        // the affine point the chain adds, and the Z of the isomorphism
+  J29 run;
+  int special;
+  if constexpr (ODD) {
+    const J29 d = j29_dbl(m1);
+    const U29 zd2 = u29_sqr(d.z), zd3 = u29_mul(d.z, zd2);
+    ax = d.x; ay = d.y; zbase = d.z;
+    run.x = u29_mul(m1.x, zd2); run.y = u29_mul(m1.y, zd3); run.z = m1.z;
+    st.raw(0, run.x, run.y, run.z);
+#pragma unroll 1
+    for (int i = 1; i < 8; i++) {
+      U29 h;
+      run = j29_madd(run, ax, ay, special, &h);
+      st.raw(i, run.x, run.y, h);
+    }
+  } else {
+    ax = m1.x; ay = m1.y; zbase = m1.z;
+    run.x = m1.x; run.y = m1.y; run.z = u29_one();
+    st.raw(0, run.x, run.y, run.z);
+    run = j29_dbl(run);
+    st.raw(1, run.x, run.y, run.z);         // Z_2 / Z_1 = Z_2 (Z_1 = 1)
+#pragma unroll 1
+    for (int i = 2; i < 8; i++) {
+      U29 h;
+      run = j29_madd(run, ax, ay, special, &h);
+      st.raw(i, run.x, run.y, h);
+    }
+  }
+  // every entry to the last one's Z: zs = Z_7 / Z_i, x_i zs^2, y_i zs^3
+  const U29 zfix = u29_mul(run.z, zbase);
+  U29 zs, nextratio;
+  {
+    U29 x, y;
+    st.get(7, x, y, nextratio);             // before fin(7): the ratio waits in the slot of beta x
+  }
+  st.fin(7, run.x, run.y);
+#pragma unroll 1
+  for (int i = 6; i >= 0; i--) {
+    zs = (i == 6) ? nextratio : u29_mul(zs, nextratio);
+    U29 x, y, ratio;
+    st.get(i, x, y, ratio);
+    const U29 zs2 = u29_sqr(zs);
+    st.fin(i, u29_mul(x, zs2), u29_mul(y, u29_mul(zs, zs2)));
+    nextratio = ratio;
+  }
+  return zfix;
+}
+
+// signed 4-bit digits of a 127-bit magnitude: d_j in [-8, 8], j = 0..32 (digit 32 is the carry); magnitudes packed 8 per word, signs apart
+KDEV void glv_fixed_digits(const u32* k, u32* dig, u32* sg) {
+#pragma unroll
+  for (int w = 0; w < 5; w++) dig[w] = 0;
+  sg[0] = sg[1] = 0;
+  u32 car = 0;
+#pragma unroll 1
+  for (int j = 0; j < 33; j++) {
+    u32 d = ((j < 32) ? ((k[j >> 3] >> ((j & 7) * 4)) & 15u) : 0u) + car;
+    car = d > 8u ? 1u : 0u;
+    const u32 mag = car ? 16u - d : d;
+    dig[j >> 3] |= mag << ((j & 7) * 4);
+    sg[j >> 5] |= car << (j & 31);
+  }
+}
+
 // k * P, P Jacobian (saturated, any Z), k a Montgomery Fr below r. P of prime order or infinity.
 // GLV split k = k1 + k2 lambda (128-bit halves), then fixed signed 4-bit windows on both halves over ONE table {1..8} P (phi of an entry
-// is the same entry with beta X): 33 windows x (4 doublings + 2 additions) = 129 doublings + 66 additions + 11 table operations. Every
+// is the same entry with beta x): 33 windows x (4 doublings + 2 mixed additions) = 129 doublings + 66 additions + the table build. Every
 // lane of a wave does the same work whatever its scalar -- a NAF ladder with per-lane scalars executes its addition in nearly every
 // iteration (some lane always has a non-zero digit): 258 additions. The table lives in private memory (per-lane index).
 // The *_j forms return the running point in the lazy limbs (false: the product is the identity): the FK23 butterflies add and subtract it
 // without a detour through the saturated words.
+struct J29PrivTable {
+  J29A T[8];
+  U29 beta;
+  KDEV void raw(int i, const U29& x, const U29& y, const U29& ratio) { T[i].x = x; T[i].y = y; T[i].xb = ratio; }
+  KDEV void get(int i, U29& x, U29& y, U29& ratio) const { x = T[i].x; y = T[i].y; ratio = T[i].xb; }
+  KDEV void fin(int i, const U29& x, const U29& y) { T[i].x = x; T[i].y = y; T[i].xb = u29_mul(x, beta); }
+};
 KDEV bool jac_scalar_mul_u29_j(const Jac<Fq>& p, const Fr& k_mont, J29& out) {
   if (jac_is_inf(p)) return false;
   u32 k[8], k1[5], k2[5];
   bool neg1, neg2;
   fp_from_mont<FrParams>(k, k_mont);
   glv_decompose(k, k1, neg1, k2, neg2);
-  // table T[m - 1] = m P, m = 1..8
-  J29T T[8];
-  const U29 beta = u29_const(GlvParams::BETA29);
-  {
-    J29 m1;
-    m1.x = u29_from_fq(p.x); m1.y = u29_from_fq(p.y); m1.z = u29_from_fq(p.z);
-    auto put = [&](int idx, const J29& q) {
-      T[idx].x = q.x; T[idx].y = q.y; T[idx].z = q.z;
-      T[idx].xb = u29_mul(q.x, beta);
-      T[idx].zz = u29_sqr(q.z);
-      T[idx].zcu = u29_mul(q.z, T[idx].zz);
-    };
-    put(0, m1);
-    int special;
-    const J29 m2 = j29_dbl(m1);                                                                put(1, m2);
-    const J29 m3 = j29_add(m2, T[0].x, T[0].y, T[0].z, T[0].zz, T[0].zcu, special);            put(2, m3);
-    const J29 m4 = j29_dbl(m2);                                                                put(3, m4);
-    const J29 m5 = j29_add(m4, T[0].x, T[0].y, T[0].z, T[0].zz, T[0].zcu, special);            put(4, m5);
-    const J29 m6 = j29_dbl(m3);                                                                put(5, m6);
-    const J29 m7 = j29_add(m6, T[0].x, T[0].y, T[0].z, T[0].zz, T[0].zcu, special);            put(6, m7);
-    const J29 m8 = j29_dbl(m4);                                                                put(7, m8);
-  }
+  J29PrivTable tb;
+  tb.beta = u29_const(GlvParams::BETA29);
+  const U29 zfix = j29_build_table<false>(p, tb);
   U29 zero;
 #pragma unroll
   for (int i = 0; i < 9; i++) zero.l[i] = 0;
-  // signed digits d_j in [-8, 8] of |k1|, |k2| (bits 4j .. 4j+3 plus carry), top down: j = 32 .. 0  (|k_i| < 2^127: digit 32 is the carry)
-  u32 dig1[5], dig2[5], car = 0;                // digits packed 8 per word as 4-bit magnitudes | sign flags kept apart
-  u32 sg1[2] = {0, 0}, sg2[2] = {0, 0};
-#pragma unroll
-  for (int w = 0; w < 5; w++) { dig1[w] = 0; dig2[w] = 0; }
-  car = 0;
-#pragma unroll 1
-  for (int j = 0; j < 33; j++) {
-    u32 d = ((j < 32) ? ((k1[j >> 3] >> ((j & 7) * 4)) & 15u) : 0u) + car;
-    car = d > 8u ? 1u : 0u;
-    const u32 mag = car ? 16u - d : d;
-    dig1[j >> 3] |= mag << ((j & 7) * 4);
-    sg1[j >> 5] |= car << (j & 31);
-  }
-  car = 0;
-#pragma unroll 1
-  for (int j = 0; j < 33; j++) {
-    u32 d = ((j < 32) ? ((k2[j >> 3] >> ((j & 7) * 4)) & 15u) : 0u) + car;
-    car = d > 8u ? 1u : 0u;
-    const u32 mag = car ? 16u - d : d;
-    dig2[j >> 3] |= mag << ((j & 7) * 4);
-    sg2[j >> 5] |= car << (j & 31);
-  }
+  u32 dig1[5], dig2[5], sg1[2], sg2[2];
+  glv_fixed_digits(k1, dig1, sg1);
+  glv_fixed_digits(k2, dig2, sg2);
   J29 acc;
   acc.x = zero; acc.y = zero; acc.z = zero;
   bool empty = true;
@@ -310,15 +386,15 @@ KDEV bool jac_scalar_mul_u29_j(const Jac<Fq>& p, const Fr& k_mont, J29& out) {
       const u32 mag = ((which ? dig2[j >> 3] : dig1[j >> 3]) >> ((j & 7) * 4)) & 15u;
       if (mag) {
         const bool neg = (((which ? sg2[j >> 5] : sg1[j >> 5]) >> (j & 31)) & 1u) != (which ? neg2 : neg1);
-        const J29T& e = T[mag - 1];
+        const J29A& e = tb.T[mag - 1];
         const U29 ex = which ? e.xb : e.x;
-        const U29 ey = neg ? u29_sub(zero, e.y, Q29::K4) : e.y;      // table y < 3.8 p; the negation may become the running point's y: j29_dbl wants it < 19 p
+        const U29 ey = neg ? u29_sub(zero, e.y, Q29::K4) : e.y;      // table y < 2 p (a product's output)
         if (empty) {
-          acc.x = ex; acc.y = ey; acc.z = e.z;
+          acc.x = ex; acc.y = ey; acc.z = u29_one();
           empty = false;
         } else {
           int special;
-          acc = j29_add(acc, ex, ey, e.z, e.zz, e.zcu, special);
+          acc = j29_madd(acc, ex, ey, special);
           if (special == 1) acc = j29_dbl(acc);
           if (special == 2) empty = true;
         }
@@ -326,7 +402,7 @@ KDEV bool jac_scalar_mul_u29_j(const Jac<Fq>& p, const Fr& k_mont, J29& out) {
     }
   }
   if (empty) return false;
-  out = acc;
+  out.x = acc.x; out.y = acc.y; out.z = u29_mul(acc.z, zfix);
   return true;
 }
 KDEV Jac<Fq> jac_scalar_mul_u29(const Jac<Fq>& p, const Fr& k_mont) {
@@ -338,94 +414,48 @@ KDEV Jac<Fq> jac_scalar_mul_u29(const Jac<Fq>& p, const Fr& k_mont) {
 
 // ---- the same ladder with the window table in GLOBAL memory, one contiguous slot per lane (round 3) --------------------------------------
 // With a scalar per lane every lane indexes its table differently. In private (scratch) memory the hardware interleaves the lanes dword by
-// dword, so the 45 dwords of "entry e of lane l" lie in 45 different 256-byte rows, and a wave whose lanes ask for up to 8 different entries
-// touches up to 8 x 45 rows per addition: 48 - 64 GB of fabric traffic per butterfly stage of 2^20 lanes (profiles/
-// r03_fk_pairing_hbm_traffic_pmc.json), and the same ladder runs 19 % slower than with one scalar per wave (16.5 vs 13.9 ms per 2^20
-// scalar-mults, bench_tools/ab_ladder_table_traffic.py). Here lane l owns 8 x 256 contiguous bytes of a workspace: an entry is two cache
-// lines whatever the other lanes read. Entry layout in 16-byte units: [0..8] y z zz zcu (36 words), [9..11] x (+ 3 pad), [12..14] beta x
-// (+ 3 pad), [15] unused. `tab`: this lane's 128 x 16 bytes.
-constexpr u32 GTAB_UINT4_PER_LANE = 128;
-KDEV void gtab_store9(uint4* dst, const U29& a) {
-  dst[0] = make_uint4(a.l[0], a.l[1], a.l[2], a.l[3]);
-  dst[1] = make_uint4(a.l[4], a.l[5], a.l[6], a.l[7]);
-  dst[2] = make_uint4(a.l[8], 0u, 0u, 0u);
-}
-KDEV U29 gtab_load9(const uint4* src) {
-  const uint4 a = src[0], b = src[1], c = src[2];
-  U29 r;
-  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w; r.l[8] = c.x;
-  return r;
-}
+// dword, so the 27 dwords of "entry e of lane l" lie in 27 different 256-byte rows, and a wave whose lanes ask for up to 8 different entries
+// touches up to 8 x 27 rows per addition (with the 45-dword Jacobian entries of the first version: 48 - 64 GB of fabric traffic per butterfly
+// stage of 2^20 lanes, profiles/r03_fk_pairing_hbm_traffic_pmc.json, and the ladder 19 % slower than with one scalar per wave). Here lane l
+// owns 8 x 128 contiguous bytes of a workspace: an entry is ONE cache line whatever the other lanes read. Entry layout in words: [0..8] y,
+// [9..17] x, [18..26] beta x (while the table is built: the ratio Z_i / Z_(i-1)), [27..31] unused. `tab`: this lane's 64 x 16 bytes.
+constexpr u32 GTAB_UINT4_PER_LANE = 64;
 KDEV void st9(u32* __restrict__ p, const U29& a) {
 #pragma unroll
   for (int i = 0; i < 9; i++) p[i] = a.l[i];
 }
-KDEV void gtab_put(uint4* e4, const J29& q, const U29& beta, U29* zz_out, U29* zcu_out) {
-  u32* e = reinterpret_cast<u32*>(e4);
-  st9(e + 36, q.x); st9(e, q.y); st9(e + 9, q.z);
-  st9(e + 48, u29_mul(q.x, beta));
-  const U29 zz = u29_sqr(q.z);
-  st9(e + 18, zz);
-  const U29 zcu = u29_mul(q.z, zz);
-  st9(e + 27, zcu);
-  if (zz_out) { *zz_out = zz; *zcu_out = zcu; }
-}
+struct J29GlobTable {
+  u32* base;                 // this lane's 8 x 32 words
+  U29 beta;
+  // the fences keep the compiler from forwarding the stored values to the loads, i.e. from keeping the whole table alive in registers
+  KDEV void raw(int i, const U29& x, const U29& y, const U29& ratio) { u32* e = base + 32 * i; st9(e + 9, x); st9(e, y); st9(e + 18, ratio); }
+  KDEV void get(int i, U29& x, U29& y, U29& ratio) const {
+    asm volatile("" ::: "memory");
+    const u32* e = base + 32 * i;
+    x = ld9(e + 9); y = ld9(e); ratio = ld9(e + 18);
+  }
+  KDEV void fin(int i, const U29& x, const U29& y) { u32* e = base + 32 * i; st9(e + 9, x); st9(e, y); st9(e + 18, u29_mul(x, beta)); }
+};
 KDEV bool jac_scalar_mul_gtab_u29_j(const Jac<Fq>& p, const Fr& k_mont, uint4* __restrict__ tab, J29& out) {
   if (jac_is_inf(p)) return false;
   u32 k[8], k1[5], k2[5];
   bool neg1, neg2;
   fp_from_mont<FrParams>(k, k_mont);
   glv_decompose(k, k1, neg1, k2, neg2);
-  const U29 beta = u29_const(GlvParams::BETA29);
+  U29 zfix;
   {
-    // table entry m - 1 = m P, m = 1..8 (the same chain as jac_scalar_mul_u29); P and its Z^2, Z^3 stay in registers while it is built
-    J29 m1;
-    m1.x = u29_from_fq(p.x); m1.y = u29_from_fq(p.y); m1.z = u29_from_fq(p.z);
-    U29 zz1, zcu1;
-    gtab_put(tab, m1, beta, &zz1, &zcu1);
-    // every multiple goes to the table as soon as it exists and is read back (x, y, z) when a later one needs it: only P itself stays in
-    // registers across the build (the fences keep the compiler from forwarding the stored values, i.e. from keeping them alive)
-    auto back = [&](int idx) {
-      asm volatile("" ::: "memory");
-      const u32* e = reinterpret_cast<const u32*>(tab + idx * 16);
-      J29 q;
-      q.x = ld9(e + 36); q.y = ld9(e); q.z = ld9(e + 9);
-      return q;
-    };
-    int special;
-    { const J29 m2 = j29_dbl(m1);                                                   gtab_put(tab + 16, m2, beta, nullptr, nullptr); }
-    { const J29 m3 = j29_add(back(1), m1.x, m1.y, m1.z, zz1, zcu1, special);         gtab_put(tab + 32, m3, beta, nullptr, nullptr); }
-    { const J29 m4 = j29_dbl(back(1));                                               gtab_put(tab + 48, m4, beta, nullptr, nullptr); }
-    { const J29 m5 = j29_add(back(3), m1.x, m1.y, m1.z, zz1, zcu1, special);         gtab_put(tab + 64, m5, beta, nullptr, nullptr); }
-    { const J29 m6 = j29_dbl(back(2));                                               gtab_put(tab + 80, m6, beta, nullptr, nullptr); }
-    { const J29 m7 = j29_add(back(5), m1.x, m1.y, m1.z, zz1, zcu1, special);         gtab_put(tab + 96, m7, beta, nullptr, nullptr); }
-    { const J29 m8 = j29_dbl(back(3));                                               gtab_put(tab + 112, m8, beta, nullptr, nullptr); }
+    J29GlobTable tb;
+    tb.base = reinterpret_cast<u32*>(tab);
+    tb.beta = u29_const(GlvParams::BETA29);
+    zfix = j29_build_table<false>(p, tb);
     asm volatile("" ::: "memory");
   }
   U29 zero;
 #pragma unroll
   for (int i = 0; i < 9; i++) zero.l[i] = 0;
-  u32 dig1[5], dig2[5], car = 0;
-  u32 sg1[2] = {0, 0}, sg2[2] = {0, 0};
-#pragma unroll
-  for (int w = 0; w < 5; w++) { dig1[w] = 0; dig2[w] = 0; }
-#pragma unroll 1
-  for (int j = 0; j < 33; j++) {
-    u32 d = ((j < 32) ? ((k1[j >> 3] >> ((j & 7) * 4)) & 15u) : 0u) + car;
-    car = d > 8u ? 1u : 0u;
-    const u32 mag = car ? 16u - d : d;
-    dig1[j >> 3] |= mag << ((j & 7) * 4);
-    sg1[j >> 5] |= car << (j & 31);
-  }
-  car = 0;
-#pragma unroll 1
-  for (int j = 0; j < 33; j++) {
-    u32 d = ((j < 32) ? ((k2[j >> 3] >> ((j & 7) * 4)) & 15u) : 0u) + car;
-    car = d > 8u ? 1u : 0u;
-    const u32 mag = car ? 16u - d : d;
-    dig2[j >> 3] |= mag << ((j & 7) * 4);
-    sg2[j >> 5] |= car << (j & 31);
-  }
+  u32 dig1[5], dig2[5], sg1[2], sg2[2];
+  glv_fixed_digits(k1, dig1, sg1);
+  glv_fixed_digits(k2, dig2, sg2);
   J29 acc;
   acc.x = zero; acc.y = zero; acc.z = zero;
   bool empty = true;
@@ -437,16 +467,16 @@ KDEV bool jac_scalar_mul_gtab_u29_j(const Jac<Fq>& p, const Fr& k_mont, uint4* _
       const u32 mag = ((which ? dig2[j >> 3] : dig1[j >> 3]) >> ((j & 7) * 4)) & 15u;
       if (mag) {
         const bool neg = (((which ? sg2[j >> 5] : sg1[j >> 5]) >> (j & 31)) & 1u) != (which ? neg2 : neg1);
-        const u32* e32 = reinterpret_cast<const u32*>(tab + (mag - 1u) * 16u);
+        const u32* e32 = reinterpret_cast<const u32*>(tab) + (mag - 1u) * 32u;
+        const U29 ex = ld9(e32 + (which ? 18 : 9));
+        const U29 y = ld9(e32);
+        const U29 ey = neg ? u29_sub(zero, y, Q29::K4) : y;
         if (empty) {
-          acc.x = ld9(e32 + (which ? 48 : 36));
-          const U29 y = ld9(e32);
-          acc.y = neg ? u29_sub(zero, y, Q29::K4) : y;
-          acc.z = ld9(e32 + 9);
+          acc.x = ex; acc.y = ey; acc.z = u29_one();
           empty = false;
         } else {
           int special;
-          acc = j29_add_mem(acc, e32, which != 0, neg, special);
+          acc = j29_madd(acc, ex, ey, special);
           if (special == 1) acc = j29_dbl(acc);
           if (special == 2) empty = true;
         }
@@ -454,7 +484,7 @@ KDEV bool jac_scalar_mul_gtab_u29_j(const Jac<Fq>& p, const Fr& k_mont, uint4* _
     }
   }
   if (empty) return false;
-  out = acc;
+  out.x = acc.x; out.y = acc.y; out.z = u29_mul(acc.z, zfix);
   return true;
 }
 KDEV Jac<Fq> jac_scalar_mul_gtab_u29(const Jac<Fq>& p, const Fr& k_mont, uint4* __restrict__ tab) {
@@ -467,9 +497,9 @@ KDEV Jac<Fq> jac_scalar_mul_gtab_u29(const Jac<Fq>& p, const Fr& k_mont, uint4* 
 // ---- the same product when EVERY lane of the wave multiplies ITS point by the SAME k (the FK23 stages with at least 64 blocks: one
 // twiddle per wave). A uniform scalar costs no divergence whatever its digits are, so the windows may slide: width-5 NAF of both GLV
 // halves -- odd digits in [-15, 15], on average one non-zero digit in six positions -- over ONE table of the odd multiples 1, 3 .. 15
-// (phi of an entry is the entry with beta X): 129 doublings + ~43 additions + 9 table operations instead of 129 + 66 + 11. The digits are
+// (phi of an entry is the entry with beta x): 129 doublings + ~43 mixed additions + the table build instead of 129 + 66. The digits are
 // computed once per wave from the scalar's first-lane copy (scalar unit) and wait in LDS (`dig`: 2 x 132 bytes of this wave), one byte per
-// position: (|d| + 1) / 2 in the low bits, the sign in bit 7. Bounds: j29_dbl and j29_add map the running point's bound set into itself
+// position: (|d| + 1) / 2 in the low bits, the sign in bit 7. Bounds: j29_dbl and j29_madd map the running point's bound set into itself
 // (header of this file), so the order of the operations does not matter.
 constexpr int UNIFORM_DIG_STRIDE = 132;
 KDEV bool jac_scalar_mul_uniform_u29_j(const Jac<Fq>& p, const Fr& k_mont, unsigned char* dig, J29& out) {
@@ -504,29 +534,10 @@ KDEV bool jac_scalar_mul_uniform_u29_j(const Jac<Fq>& p, const Fr& k_mont, unsig
       a0 = (a0 >> 1) | (a1 << 31); a1 = (a1 >> 1) | (a2 << 31); a2 = (a2 >> 1) | (a3 << 31); a3 >>= 1;
     }
   }
-  // table T[i] = (2 i + 1) P
-  J29T T[8];
-  const U29 beta = u29_const(GlvParams::BETA29);
-  {
-    J29 m1;
-    m1.x = u29_from_fq(p.x); m1.y = u29_from_fq(p.y); m1.z = u29_from_fq(p.z);
-    auto put = [&](int idx, const J29& q) {
-      T[idx].x = q.x; T[idx].y = q.y; T[idx].z = q.z;
-      T[idx].xb = u29_mul(q.x, beta);
-      T[idx].zz = u29_sqr(q.z);
-      T[idx].zcu = u29_mul(q.z, T[idx].zz);
-    };
-    put(0, m1);
-    const J29 d2 = j29_dbl(m1);
-    const U29 d2zz = u29_sqr(d2.z), d2zcu = u29_mul(d2.z, d2zz);
-    J29 run = m1;
-#pragma unroll 1
-    for (int i = 1; i < 8; i++) {
-      int special;
-      run = j29_add(run, d2.x, d2.y, d2.z, d2zz, d2zcu, special);
-      put(i, run);
-    }
-  }
+  // table T[i] = (2 i + 1) P, affine on the working curve
+  J29PrivTable tb;
+  tb.beta = u29_const(GlvParams::BETA29);
+  const U29 zfix = j29_build_table<true>(p, tb);
   U29 zero;
 #pragma unroll
   for (int i = 0; i < 9; i++) zero.l[i] = 0;
@@ -541,15 +552,15 @@ KDEV bool jac_scalar_mul_uniform_u29_j(const Jac<Fq>& p, const Fr& k_mont, unsig
       const u32 byte = (u32)__builtin_amdgcn_readfirstlane((int)dig[which * UNIFORM_DIG_STRIDE + pos]);
       if (byte) {
         const bool neg = ((byte >> 7) != 0) != (which ? neg2 : neg1);
-        const J29T& e = T[(byte & 0x7Fu) - 1u];
+        const J29A& e = tb.T[(byte & 0x7Fu) - 1u];
         const U29 ex = which ? e.xb : e.x;
-        const U29 ey = neg ? u29_sub(zero, e.y, Q29::K4) : e.y;      // table y < 3.8 p; the negation may become the running point's y: j29_dbl wants it < 19 p
+        const U29 ey = neg ? u29_sub(zero, e.y, Q29::K4) : e.y;      // table y < 2 p; the negation may become the running point's y (<= 4 p)
         if (empty) {
-          acc.x = ex; acc.y = ey; acc.z = e.z;
+          acc.x = ex; acc.y = ey; acc.z = u29_one();
           empty = false;
         } else {
           int special;
-          acc = j29_add(acc, ex, ey, e.z, e.zz, e.zcu, special);
+          acc = j29_madd(acc, ex, ey, special);
           if (special == 1) acc = j29_dbl(acc);
           if (special == 2) empty = true;
         }
@@ -557,7 +568,7 @@ KDEV bool jac_scalar_mul_uniform_u29_j(const Jac<Fq>& p, const Fr& k_mont, unsig
     }
   }
   if (empty || jac_is_inf(p)) return false;
-  out = acc;
+  out.x = acc.x; out.y = acc.y; out.z = u29_mul(acc.z, zfix);
   return true;
 }
 KDEV Jac<Fq> jac_scalar_mul_uniform_u29(const Jac<Fq>& p, const Fr& k_mont, unsigned char* dig) {

@@ -36,7 +36,7 @@ def biased(c, bias_log=30):
     return out
 
 
-K2, K4, K16, K32 = (biased(c) for c in (2, 4, 16, 32))
+K2, K4, K8, K16, K32 = (biased(c) for c in (2, 4, 8, 16, 32))
 K8W, K16W = biased(8, 31), biased(16, 31)
 maxima = {}
 
@@ -171,6 +171,73 @@ def j29_addsub(u, v):
     return out
 
 
+# ---- effective-affine window tables: every entry affine on ONE isomorphic curve, mixed additions in the ladder ---------------------
+ONE = None  # set below (limbs of 2^261 mod p)
+
+
+def j29_madd(a, x2, y2):
+    """a (Jacobian, X < 19 p, Y <= 4 p, Z < 2.1 p) + (x2, y2) affine, both on the working curve: madd without factors of two (8M + 3S, Y3 one
+    dual stream). Returns (point, H) -- H = Z3 / Z1 is the ratio the table build records -- or None when the points are equal or opposite."""
+    x, y, z = a
+    Z1Z1 = sqr(z)
+    U2 = mul(x2, Z1Z1)
+    S2 = mul(y2, mul(z, Z1Z1))
+    H = note("madd.H", sub(U2, x, K32), 34.01)
+    if val(H) % P == 0:
+        return None
+    HH = sqr(H)
+    HHH, V = note("madd.HHH", mul(H, HH), 2.7), note("madd.V", mul(x, HH), 1.9)
+    rr = note("madd.r", sub(S2, y, K4), 6.01)
+    x3 = note("madd.x", sub3(sqr(rr), HHH, V), 9.3)
+    T = note("madd.T", sub(V, x3, K16), 17.9)
+    N = u32s([k - v for k, v in zip(K8, y)], "madd.N")                       # raw 8p - Y1 (Y1 <= 4p, limbs carried)
+    chk(N, W15, "madd.N")
+    y3 = note("madd.y", mul2(rr, T, N, HHH), 1.8)
+    z3 = note("madd.z", mul(z, H), 1.5)
+    return (x3, y3, z3), H
+
+
+def table_multiples(Pj):
+    """entries m P, m = 1..8, affine on the curve isomorphic to E by Z_g; returns (entries [(x, y)], Zfix) with Z_E = Z_acc * Zfix.
+    Base curve: the one on which P itself is affine (X, Y) -- isomorphic by Z_P."""
+    X, Y, ZP = Pj
+    e = [(X, Y, ONE)]
+    zr = [None]
+    d = j29_dbl(e[0])                                                        # Z = 2 Y: the ratio to the previous Z = 1
+    e.append(d); zr.append(d[2])
+    for m in range(3, 9):
+        r, H = j29_madd(e[-1], X, Y)
+        e.append(r); zr.append(H)
+    return globalz(e, zr, ZP)
+
+
+def table_odd(Pj):
+    """entries (2i + 1) P, i = 0..7, built on the curve on which 2P is affine"""
+    X, Y, ZP = Pj
+    d = j29_dbl(Pj)
+    zd2 = sqr(d[2]); zd3 = mul(d[2], zd2)
+    e = [(mul(X, zd2), mul(Y, zd3), ZP)]                                      # P on E_d: (X Zd^2, Y Zd^3, Z_P)
+    zr = [None]
+    for i in range(1, 8):
+        r, H = j29_madd(e[-1], d[0], d[1])
+        e.append(r); zr.append(H)
+    return globalz(e, zr, d[2])
+
+
+def globalz(e, zr, zbase):
+    """bring every entry to the last one's Z: x_i *= zs^2, y_i *= zs^3 with zs = Z_last / Z_i (the product of the recorded ratios)"""
+    out = [None] * len(e)
+    out[-1] = (e[-1][0], e[-1][1])
+    zs = None
+    for i in range(len(e) - 2, -1, -1):
+        zs = zr[i + 1] if zs is None else mul(zs, zr[i + 1])                 # zr: H (carried, < 34 p) or 2Y-type Z (exact)
+        zs2 = sqr(zs) if max(zs[:8]) <= C else mul(zs, zs)
+        out[i] = (mul(e[i][0], zs2), mul(e[i][1], mul(zs, zs2)))
+        note("tab.x", out[i][0], 4.3); note("tab.y", out[i][1], 2.0)
+    zfix = mul(e[-1][2], zbase)
+    return out, zfix
+
+
 # ---- plain arithmetic to compare with -------------------------------------------------------------------------------------------
 def aff_add(p, q):
     if p is None: return q
@@ -255,6 +322,44 @@ def run(seed=1, ladders=6, bits=127):
             continue
         accv %= R_ORDER
         assert to_aff(acc) == aff_mul(accv, base)
+    # ---- the same ladders over effective-affine tables (mixed additions), both table shapes
+    global ONE
+    ONE = mont(1)
+    for it in range(ladders):
+        while True:
+            x = rnd.randrange(P); y2 = (x * x * x + 3) % P
+            y = pow(y2, (P + 1) // 4, P)
+            if y * y % P == y2: break
+        base = (x, y)
+        zz = rnd.randrange(1, P)
+        Pj = (mont(x * zz * zz % P), mont(y * zz * zz * zz % P), mont(zz))
+        for shape in ("multiples", "odd"):
+            tab, zfix = (table_multiples if shape == "multiples" else table_odd)(Pj)
+            mult = (lambda i: i + 1) if shape == "multiples" else (lambda i: 2 * i + 1)
+            zero = [0] * 9
+            acc, accv = None, 0
+            for step in range(40):
+                if acc is not None:
+                    for _ in range(rnd.randrange(1, 5)):
+                        acc = j29_dbl(acc); accv *= 2
+                i = rnd.randrange(8)
+                neg = rnd.random() < 0.5
+                ex, ey = tab[i]
+                if neg: ey = sub(zero, ey, K4)
+                sm = -mult(i) if neg else mult(i)
+                if acc is None:
+                    acc, accv = (ex, ey, ONE), sm
+                else:
+                    r = j29_madd(acc, ex, ey)
+                    if r is None:
+                        if (accv - sm) % R_ORDER == 0: acc = j29_dbl(acc); accv *= 2
+                        else: acc, accv = None, 0
+                    else:
+                        acc, accv = r[0], accv + sm
+            if acc is not None:
+                final = (acc[0], acc[1], mul(acc[2], zfix))
+                assert to_aff(final) == aff_mul(accv % R_ORDER, base), shape
+
     # the butterflies' (u + v, u - v): inputs are canonical residues in the 2^256 form shifted by 5 bits (values up to 32 p), or a ladder's output
     for it in range(4 * ladders):
         pts = []
