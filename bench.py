@@ -443,12 +443,12 @@ def main():
               "roofline": {"bound": "hbm", "kernel": "k_g1_fft_stage_map (2 x %d launches: one butterfly = one 254-bit scalar-mult + add + sub)" % lg,
                            "algorithmic_bytes": fk_algo, "kernel_ms": stages_ms, "kernel_ms_stat": "all butterfly stages of one call, HIP events on the ctx stream",
                            "achieved": fk_algo / (stages_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fk_algo / (stages_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "note": "integer-issue bound like every kernel of the path: d log2 d butterfly scalar-mults of ~129 doublings + 43..66 additions each"},
+                           "note": "integer-issue bound like every kernel of the path: d log2 d butterfly scalar-mults of ~129 doublings + 43..66 mixed additions each"},
               "alu": {"scalar_mults_per_s_in_stages": d * lg / (stages_ms * 1e-3), "simd_cycles_per_butterfly": stages_ms * 1e-3 * 2.4e9 / (d * lg / 64.0 / 1024.0),
-                      "note": "SIMD cycles one wave (64 butterflies) spends per butterfly stage step = scalar-mult + add + sub, at 2.4 GHz on 1024 SIMDs. Counted "
-                              "(SQ_INSTS_VALU, profiles/r03_pairing_pmc_sq_insts.csv): 300 K VALU instructions per wave-butterfly in the stages with one twiddle per wave "
-                              "(129 doublings + 43 additions), 425 K in the six with a twiddle per lane (66 additions) = 1.37 / 1.93 M cycles at the product stream's "
-                              "issue rate, 1.53 M over the 21 stages of a transform at d = 2^21 (DESIGN 4.2b, 7.3)"}}
+                      "note": "SIMD cycles one wave (64 butterflies) spends per butterfly stage step = scalar-mult + add + sub, at 2.4 GHz on 1024 SIMDs. The ladder: "
+                              "129 doublings + 43 mixed additions (one twiddle per wave: sliding windows) or 66 (a twiddle per lane: fixed windows) on an "
+                              "effective-affine window table; valu_per_wave_butterfly = SQ_INSTS_VALU / SQ_WAVES of the stage kernels from the committed counter "
+                              "pass (DESIGN 4.2b, 7.3)"}}
         # fabric traffic of one call from the committed counter passes (bench_tools/collect_pmc_fk_pairing.sh), when they were made on this build
         fk_traffic, fk_traffic_note = None, None
         try:
@@ -461,11 +461,14 @@ def main():
                 fk_traffic_note = "committed PMC figure is for another domain size"
             else:
                 fk_traffic = pj["fk_one_call"]["fetch_bytes"] + pj["fk_one_call"]["write_bytes"]
+                ipw = pj.get("fk_instructions_per_wave", {})
+                pick = lambda tag: next((round(v["insts_valu"]) for k, v in ipw.items() if "stage_map<true, " + tag in k), None)
+                fk["alu"]["valu_per_wave_butterfly"] = {"one_twiddle_per_wave": pick("true, false"), "twiddle_per_lane": pick("false, true")}
         except (OSError, ValueError, KeyError) as e:
             fk_traffic_note = "no committed PMC figure (%s)" % type(e).__name__
         fk["roofline"]["traffic"] = fk_traffic
-        fk["roofline"]["traffic_note"] = fk_traffic_note or ("FETCH_SIZE + WRITE_SIZE of ONE call, all FK23 kernels: the per-lane window tables of the ladders (2 KB written, "
-                                                             "43..66 x 256 B read per scalar-mult) and the 96-byte points, not the algorithmic 96 B per opening")
+        fk["roofline"]["traffic_note"] = fk_traffic_note or ("FETCH_SIZE + WRITE_SIZE of ONE call, all FK23 kernels: the per-lane window tables of the ladders (1 KB written, "
+                                                             "43..66 x 128 B read per scalar-mult) and the 96-byte points, not the algorithmic 96 B per opening")
         fk_check = (fsrs, coeffs, proofs, om)
     # ---- Laconic OT, one GPU: the three phases the reference's test prints (tests/laconic_ot.rs:143-188) at 2^--laconic-log2n bits --------
     laconic = None
