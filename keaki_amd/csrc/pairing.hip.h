@@ -5,16 +5,16 @@
 //
 // The reduced pairing value is independent of the Miller-loop addition chain and of subfield scalings of the line functions, so the
 // kernel is free to (a) compute the lines on the fly (or read a table when Q is constant), (b) use the proper NAF of 6z + 2 (22
-// additions instead of arkworks' 26) and a width-3 NAF of z in the hard part. The final exponent is arkworks' exactly:
+// additions instead of arkworks' 26) and a width-4 NAF of z in the hard part. The final exponent is arkworks' exactly:
 // (p^12 - 1)/r * 2z(6z^2 + 3z + 1). The tower arithmetic is pair261.hip.h (2^261 Montgomery form, lane pairs, multi-product streams).
 //
 // Structure (round 2): the round-1 kernel inlined ~45 Fq12 products and kept up to five Fq12 values alive in the hard part: 459 KB of
 // code, 630 spilled VGPRs. Now
 //   * the Miller loop is a flat loop over the 88 line steps of MILLER_STEPS with ONE instance of the Fq12 squaring and ONE of the
 //     sparse line product;
-//   * the final exponentiation is a PROGRAM (FE_PROG, 289 one-byte ops, generated and checked against the big-int oracle on the CPU:
+//   * the final exponentiation is a PROGRAM (FE_PROG, 292 one-byte ops, generated and checked against the big-int oracle on the CPU:
 //     tests/test_pair261_model.py) run by an accumulator machine: one Fq12 accumulator in registers, every other value in a per-item
-//     slot in HBM (10 slots x 384 B, structure-of-arrays so that a wave's loads are contiguous), ONE instance each of the Fq12
+//     slot in HBM (12 slots x 384 B, structure-of-arrays so that a wave's loads are contiguous), ONE instance each of the Fq12
 //     product, the cyclotomic squaring, the Frobenius maps and the inversion. Control flow is wave-uniform (the program counter is scalar).
 // Slot traffic: ~60 loads / stores of 384 B per pairing (23 KB) against ~2.6 M instructions: noise, and mostly served by the LLC.
 #pragma once

@@ -49,7 +49,8 @@ def test_final_exponentiation_program_equals_oracle(py):
             elif code == 7: acc = py.f12_inv(acc)
             else: raise AssertionError(code)
         assert acc == py.final_exponentiation(f)
-        assert max(slots) < 10
+        nslots = int(re.search(r"FE_NSLOTS = (\d+)", open(os.path.join(ROOT, "keaki_amd", "csrc", "pair261_constants.hip.h")).read()).group(1))
+        assert max(slots) < nslots <= 16                # the slot index travels in the high four bits of an op
 
 
 def test_miller_steps_follow_the_naf(py):
