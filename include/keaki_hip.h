@@ -92,7 +92,7 @@ const char* keaki_hip_version(void);
 /* keaki_hip_last_error: the returned string is a copy private to the calling thread (valid until its next call of this function). */
 /* Tuning / A-B switches of a context (profiling and tests; defaults are what ships). Initial values come from the environment variable
  * KEAKI_<NAME> at keaki_hip_ctx_create; afterwards only this call changes them. Names: "msm_c", "msm_c_shared" (window bits, 0 = automatic),
- * "reduce_l", "part_shift", "p1_sub", "p2_small", "acc_u29", "acc_u29_g2", "acc_nt", "fk_uniform", "fk_gtab", "fk_addsub29", "fb_occ1", "gt_wb_b" (window bits of the table of
+ * "reduce_l", "part_shift", "p1_sub", "p2_small", "acc_u29", "acc_u29_g2", "acc_nt", "fk_uniform", "fk_gtab", "fk_addsub29", "fk_radix4", "fb_occ1", "gt_wb_b" (window bits of the table of
  * e(g1, g2), 0 = automatic; a change rebuilds the table on the next use), "encap_gt" (batch size from which encap_batch takes the GT
  * fixed-base path and below which it never does; -1 = the automatic policy). Unknown name -> KEAKI_ERR_BAD_ARG. */
 keaki_status keaki_hip_ctx_set_option(keaki_hip_ctx* ctx, const char* name, int64_t value);

@@ -121,6 +121,154 @@ static __global__ void __launch_bounds__(64, 3) k_g1_fft_stage_map(G1Jac* __rest
     a[i1] = t;
   }
 }
+// ---- TWO consecutive stages in one pass (radix 4) for stages with one twiddle per wave (option fk_radix4) -------------------------------------
+// Two radix-2 stages over the four points p0, p0 + h, p0 + 2h, p0 + 3h cost four scalar-mults = four chains of 129 doublings. Written out,
+//   DIT (spans h, then 2h):  y0, y2 = (e0 + w1 e1) +- L1,   y1, y3 = (e0 - w1 e1) +- L2,   L1 = w2 e2 + (w2 w1) e3,   L2 = w2' e2 - (w2' w1) e3
+//   DIF (spans 2h, then h):  c0 = S02 + S13,  c1 = w2 (S02 - S13),  c2 = w1 D02 + w1' D13,  c3 = (w2 w1) D02 - (w2 w1') D13   (S, D = e0 +- e2, e1 +- e3)
+// (w2' / w1' = the twiddle of offset j + h) the two-term sums run as ONE chain each over a PAIR of window tables on one working curve
+// (jac29.hip.h: j29_build_pair, j29_mul2_uniform): three chains instead of four, the pair of tables built once for both sums, and three
+// add / subtract pairs instead of four. Lanes with a trivial twiddle (offset 0) or an identity among their points take the radix-2 sequence.
+template <bool DIT, bool AS29>
+static __global__ void __launch_bounds__(64, 3) k_g1_fft_stage4(G1Jac* __restrict__ a, const Fr* __restrict__ tw, u32 m, u32 h, u32 A, u32 B, u32 stride_h,
+                                                                u32 stride_2h) {
+  const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= m / 4) return;
+  const u32 nb4 = m / (4 * h);                   // >= 64 (host): the lanes of a wave share the offset j
+  const u32 blk = g % nb4, j = g / nb4;
+  const u32 p0 = blk * 4 * h + j, p1 = p0 + h, p2 = p0 + 2 * h, p3 = p0 + 3 * h;
+  __shared__ unsigned char dig[4 * UNIFORM_DIG_STRIDE];
+  J29A T[16];                                    // ONE table storage for every ladder of this lane (16 entries: the pair tables)
+  auto ladder1 = [&](const G1Jac& pt, const Fr& w, J29& out) { return jac_scalar_mul_uniform_u29_t(pt, w, dig, out, T); };
+  auto addsub = [&](const G1Jac& u, bool v_inf, const J29& vj, G1Jac& sum, G1Jac& diff) {
+    if constexpr (AS29) {
+      J29 sj, dj;
+      if (!v_inf && !jac_is_inf(u) && j29_addsub(j29_from_sat(u), vj, sj, dj)) {
+        sum = j29_to_sat(sj);
+        diff = j29_to_sat(dj);
+        return;
+      }
+    }
+    G1Jac v = v_inf ? jac_inf<Fq>() : j29_to_sat(vj);
+    sum = jac_add(u, v);
+    v.y = -v.y;
+    diff = jac_add(u, v);
+  };
+  // one radix-2 butterfly (the fallback sequence): DIT (u, v) -> (u + w v, u - w v), DIF (u, v) -> (u + v, w (u - v))
+  auto butterfly2 = [&](u32 i0, u32 i1, const Fr& w) {
+    if (DIT) {
+      const G1Jac v = a[i1];
+      J29 vj;
+      bool v_inf;
+      if (fr_is_one(w)) { v_inf = jac_is_inf(v); vj = j29_from_sat(v); }
+      else v_inf = !ladder1(v, w, vj);
+      const G1Jac u = a[i0];
+      G1Jac s_, d_;
+      addsub(u, v_inf, vj, s_, d_);
+      a[i0] = s_; a[i1] = d_;
+    } else {
+      const G1Jac u = a[i0], v = a[i1];
+      G1Jac s_, t;
+      addsub(u, jac_is_inf(v), j29_from_sat(v), s_, t);
+      a[i0] = s_;
+      if (!fr_is_one(w)) {
+        J29 tj;
+        t = ladder1(t, w, tj) ? j29_to_sat(tj) : jac_inf<Fq>();
+      }
+      a[i1] = t;
+    }
+  };
+  // the four radix-2 butterflies of the two stages, ONE instance of the butterfly (a loop): the fallback of lanes with a trivial twiddle or an identity
+  auto plain_pass = [&](const Fr* t0, const Fr* t1, const Fr* t2, const Fr* t3) {
+#pragma unroll 1
+    for (int q = 0; q < 4; q++) {
+      u32 i0, i1;
+      const Fr* w;
+      if (DIT) { i0 = q == 0 ? p0 : q == 1 ? p2 : q == 2 ? p0 : p1; i1 = q == 0 ? p1 : q == 1 ? p3 : q == 2 ? p2 : p3; }
+      else { i0 = q == 0 ? p0 : q == 1 ? p1 : q == 2 ? p0 : p2; i1 = q == 0 ? p2 : q == 1 ? p3 : q == 2 ? p1 : p3; }
+      w = q == 0 ? t0 : q == 1 ? t1 : q == 2 ? t2 : t3;
+      butterfly2(i0, i1, *w);
+    }
+  };
+  // the three twiddles are read where they are used (24 registers each otherwise live across the ladders):
+  //   ta: offset j of the span-h stage, tb: offset j of the span-2h stage, tc: offset j + h of the span-2h stage
+  const Fr* ta = tw + ((size_t)j * A + B) * stride_h;
+  const Fr* tb = tw + ((size_t)j * A + B) * stride_2h;
+  const Fr* tc = tw + ((size_t)(j + h) * A + B) * stride_2h;
+  auto z_is_zero = [&](u32 idx) { return fq_is_zero(a[idx].z); };
+  bool plain = j == 0 || z_is_zero(p0) || z_is_zero(p1) || z_is_zero(p2) || z_is_zero(p3);
+  if (DIT) {
+    if (plain) {
+      plain_pass(ta, ta, tb, tc);
+      return;
+    }
+    {                                                            // x0, x1 = e0 +- w1 e1 -> a[p0], a[p1]
+      J29 mj;
+      const bool m_inf = !ladder1(a[p1], *ta, mj);
+      G1Jac x0, x1;
+      addsub(a[p0], m_inf, mj, x0, x1);
+      a[p0] = x0; a[p1] = x1;
+    }
+    J29PairTables t = {T, T + 8, {}};
+    j29_build_pair(a[p2], a[p3], t);
+    // L1 = w2 e2 + w2 w1 e3 -> y0, y2 = x0 +- L1;   L2 = w2' e2 - w2' w1 e3 -> y1, y3 = x1 +- L2   (ONE instance of the two-term ladder: a loop)
+#pragma unroll 1
+    for (int q = 0; q < 2; q++) {
+      const Fr w = q ? *tc : *tb;
+      J29 lj;
+      const bool l_inf = !j29_mul2_uniform(t, w, fp_mul<FrParams>(w, *ta), q != 0, dig, lj);
+      const u32 iu = q ? p1 : p0, iv = q ? p3 : p2;
+      G1Jac ys, yd;
+      addsub(a[iu], l_inf, lj, ys, yd);
+      a[iu] = ys; a[iv] = yd;
+    }
+  } else {
+    // here stride_2h belongs to the FIRST stage (span 2h: twiddles tb, tc), stride_h to the second (span h: ta)
+    if (plain) {
+      plain_pass(tb, tc, ta, ta);
+      return;
+    }
+#pragma unroll 1
+    for (int q = 0; q < 2; q++) {                                 // S02, D02 -> a[p0], a[p2];  S13, D13 -> a[p1], a[p3]
+      const u32 iu = q ? p1 : p0, iv = q ? p3 : p2;
+      G1Jac s_, d_;
+      addsub(a[iu], false, j29_from_sat(a[iv]), s_, d_);
+      a[iu] = s_; a[iv] = d_;
+      plain = plain || jac_is_inf(s_) || jac_is_inf(d_);
+    }
+    if (plain) {                                                  // e0 = +-e2 or e1 = +-e3: finish with radix-2 steps
+#pragma unroll 1
+      for (int q = 0; q < 2; q++) {
+        const Fr w = q ? *tc : *tb;
+        const u32 i = q ? p3 : p2;
+        if (!fr_is_one(w)) { J29 tj; a[i] = ladder1(a[i], w, tj) ? j29_to_sat(tj) : jac_inf<Fq>(); }
+      }
+#pragma unroll 1
+      for (int q = 0; q < 2; q++) butterfly2(q ? p2 : p0, q ? p3 : p1, *ta);
+      return;
+    }
+    {
+      G1Jac c0, tdiff;
+      addsub(a[p0], false, j29_from_sat(a[p1]), c0, tdiff);
+      a[p0] = c0;
+      J29 tj;
+      a[p1] = ladder1(tdiff, *ta, tj) ? j29_to_sat(tj) : jac_inf<Fq>();       // c1 = w2 (S02 - S13)
+    }
+    J29PairTables t = {T, T + 8, {}};
+    j29_build_pair(a[p2], a[p3], t);
+    J29 c2j, c3j;
+    bool ok2 = false, ok3 = false;
+    // c2 = w1 D02 + w1' D13,  c3 = w2 w1 D02 - w2 w1' D13  (ONE instance of the two-term ladder: a loop; both read the tables, so the results wait)
+#pragma unroll 1
+    for (int q = 0; q < 2; q++) {
+      const Fr kA = q ? fp_mul<FrParams>(*ta, *tb) : *tb, kB = q ? fp_mul<FrParams>(*ta, *tc) : *tc;
+      J29 cj;
+      const bool ok = j29_mul2_uniform(t, kA, kB, q != 0, dig, cj);
+      if (q) { c3j = cj; ok3 = ok; } else { c2j = cj; ok2 = ok; }
+    }
+    a[p2] = ok2 ? j29_to_sat(c2j) : jac_inf<Fq>();
+    a[p3] = ok3 ? j29_to_sat(c3j) : jac_inf<Fq>();
+  }
+}
 // reversed SRS padded with identities, the cyclic slice of rank r: out[k] = S[k R + r]
 static __global__ void __launch_bounds__(256) k_fk_load_cyclic(const G1Aff* __restrict__ srs, u32 d, u32 R, u32 r, u32 m, G1Jac* __restrict__ out) {
   u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -344,6 +492,42 @@ static void stage_map(keaki_hip_ctx* ctx, bool dit, G1Jac* a, const Fr* tw, u32 
     launch_stage(dit, false, tab != nullptr, as29, grid, block, ctx->stream, a, tw, m, half, A, B, stride, tab, first);
   });
 }
+// The stages of a transform over m local points with spans 2 * half, half = first .. last (doubling for the inverse DIT transform, halving for the
+// forward DIF one); stride_of(half) is the twiddle stride of that stage. Two consecutive stages that both have one twiddle per wave (at least 64
+// blocks of the LARGER span), none of them the all-trivial span-2 stage, run as one radix-4 pass (option fk_radix4).
+template <class StrideOf>
+static void run_stages(keaki_hip_ctx* ctx, bool dit, G1Jac* a, const Fr* tw, u32 m, u32 first, u32 last, u32 A, u32 B, StrideOf stride_of) {
+  const bool r4 = ctx->tune.fk_radix4 && ctx->tune.fk_uniform;
+  // h: the smaller half of the pair. h >= 8: the twiddles of the first stages are short scalars (their ladders skip most of the doublings:
+  // 94 K / 198 K / 256 K instructions per wave-butterfly at spans 4 / 8 / 16 against 312 K), a radix-4 pass over them costs MORE than two
+  // radix-2 stages (738 K against 584 K per group at h = 2); from h = 8 on it saves 2.4 % .. 7.7 % (bench_tools/pmc_fk_radix4.sh).
+  auto pairable = [&](u32 h) { return r4 && h >= 8 && m / (4 * h) >= 64 && (m / 4) % 64 == 0; };
+  if (dit) {
+    for (u32 half = first; half <= last;) {
+      if (2 * half <= last && pairable(half)) {
+        if (ctx->tune.fk_addsub29) hipLaunchKernelGGL((k_g1_fft_stage4<true, true>), dim3(cdiv(m / 4, 64)), dim3(64), 0, ctx->stream, a, tw, m, half, A, B, stride_of(half), stride_of(2 * half));
+        else hipLaunchKernelGGL((k_g1_fft_stage4<true, false>), dim3(cdiv(m / 4, 64)), dim3(64), 0, ctx->stream, a, tw, m, half, A, B, stride_of(half), stride_of(2 * half));
+        half <<= 2;
+      } else {
+        stage_map(ctx, true, a, tw, m, half, A, B, stride_of(half));
+        half <<= 1;
+      }
+    }
+  } else {
+    for (u32 half = first; half >= last && half >= 1;) {
+      const u32 h = half / 2;                       // the pair: spans 2 * half (first) and 2 * h
+      if (h >= last && h >= 1 && pairable(h)) {
+        if (ctx->tune.fk_addsub29) hipLaunchKernelGGL((k_g1_fft_stage4<false, true>), dim3(cdiv(m / 4, 64)), dim3(64), 0, ctx->stream, a, tw, m, h, A, B, stride_of(h), stride_of(half));
+        else hipLaunchKernelGGL((k_g1_fft_stage4<false, false>), dim3(cdiv(m / 4, 64)), dim3(64), 0, ctx->stream, a, tw, m, h, A, B, stride_of(h), stride_of(half));
+        half >>= 2;
+      } else {
+        stage_map(ctx, false, a, tw, m, half, A, B, stride_of(half));
+        half >>= 1;
+      }
+      if (half == 0) break;
+    }
+  }
+}
 static void launch_pointwise(keaki_hip_ctx* ctx, const G1Jac* hs_even, const G1Jac* hs_odd, const Fr* a, u32 log2d, u32 base, u32 m, G1Jac* out_e, G1Jac* out_o) {
   ladder_launches(ctx, 2 * m, [&](uint4* tab, u32 first, u32 cnt) {
     if (tab) hipLaunchKernelGGL(k_fk_pointwise<true>, dim3(cdiv(cnt, 64)), dim3(64), 0, ctx->stream, hs_even, hs_odd, a, log2d, base, m, out_e, out_o, tab, first);
@@ -385,9 +569,9 @@ keaki_status open_fk_run(keaki_hip_ctx* ctx, const void* d_hat_s, u32 log2d, con
   if (timed) (void)hipEventRecord(ctx->fk_ev[0], st);
   launch_pointwise(ctx, hs, hs + d, (const Fr*)d_hat_a, log2d, 0u, d, e, o);
   if (timed) (void)hipEventRecord(ctx->fk_ev[1], st);
-  for (u32 half = 1; 2 * half <= d; half <<= 1) stage_map(ctx, true, o, twi, d, half, 1, 0, 2 * (d / (2 * half)));
+  run_stages(ctx, true, o, twi, d, 1u, d / 2, 1, 0, [&](u32 half) { return 2 * (d / (2 * half)); });
   launch_mul_strided(ctx, o, twi, 1u, 0u, d);
-  for (u32 half = d / 2; half >= 1; half >>= 1) stage_map(ctx, false, o, tw, d, half, 1, 0, 2 * (d / (2 * half)));
+  run_stages(ctx, false, o, tw, d, d / 2, 1u, 1, 0, [&](u32 half) { return 2 * (d / (2 * half)); });
   if (timed) (void)hipEventRecord(ctx->fk_ev[2], st);
   hipLaunchKernelGGL(k_fk_finish, dim3(cdiv(d, 64)), dim3(64), 0, st, (const G1Jac*)e, (const G1Jac*)o, d, log2d, true, (G1Aff*)d_proofs_aff);
   if (timed) { (void)hipEventRecord(ctx->fk_ev[3], st); ctx->fk_timing_pending = true; }

@@ -35,6 +35,7 @@ struct Tuning {
   bool acc_nt = false;           // KEAKI_ACC_NT / "acc_nt": non-temporal loads of the table rows in the G1 bucket kernel
   bool fk_uniform = true;        // KEAKI_FK_UNIFORM / "fk_uniform": sliding-window ladder in the wave-uniform FK23 stages
   bool fk_gtab = true;           // KEAKI_FK_GTAB / "fk_gtab": window tables of the per-lane-scalar ladders in a lane-contiguous workspace (0: private memory)
+  bool fk_radix4 = true;        // KEAKI_FK_RADIX4 / "fk_radix4": two wave-uniform stages in one radix-4 pass (three doubling chains instead of four)
   bool fk_addsub29 = true;      // KEAKI_FK_ADDSUB29 / "fk_addsub29": the butterflies' add + subtract in the lazy limbs, shared products once (A/B switch)
   bool fb_occ1 = false;          // KEAKI_FB_OCC1 / "fb_occ1": one wave per SIMD for the G2 fixed-base kernel at any batch size
   int gt_wb_b = 0;               // KEAKI_GT_WB_B / "gt_wb_b": window bits of the table of e(g1, g2), 0 = automatic (20 / 16)

@@ -278,10 +278,10 @@ KDEV J29 j29_madd(const J29& a, const U29& x2, const U29& y2, int& special, U29*
 // entry i + one fixed affine point), so only the last entry is alive while the chain runs. Returns zfix: Z on E = Z on the working curve * zfix.
 //   multiples: entries m P, m = 1..8, on the curve where P = (X, Y) is affine (isomorphic by Z_P): 2P = dbl(P), then + P six times
 //   odd:       entries (2i + 1) P, i = 0..7, on the curve where D = 2P is affine (isomorphic by Z_D): P -> (X Z_D^2, Y Z_D^3, Z_P), then + D
+// m1: the point in Jacobian limbs on the CURRENT working curve (E itself, or any curve of the family: the pair tables below build the second
+// table on the curve of the first); the returned zfix is relative to that curve.
 template <bool ODD, class St>
-KDEV U29 j29_build_table(const Jac<Fq>& p, St& st) {
-  J29 m1;
-  m1.x = u29_from_fq(p.x); m1.y = u29_from_fq(p.y); m1.z = u29_from_fq(p.z);
+KDEV U29 j29_build_table_j(const J29& m1, St& st) {
   U29 ax, ay, zbase;                        // the affine point the chain adds, and the Z of the isomorphism
   J29 run;
   int special;
@@ -330,6 +330,13 @@ KDEV U29 j29_build_table(const Jac<Fq>& p, St& st) {
   return zfix;
 }
 
+template <bool ODD, class St>
+KDEV U29 j29_build_table(const Jac<Fq>& p, St& st) {
+  J29 m1;
+  m1.x = u29_from_fq(p.x); m1.y = u29_from_fq(p.y); m1.z = u29_from_fq(p.z);
+  return j29_build_table_j<ODD>(m1, st);
+}
+
 // signed 4-bit digits of a 127-bit magnitude: d_j in [-8, 8], j = 0..32 (digit 32 is the carry); magnitudes packed 8 per word, signs apart
 KDEV void glv_fixed_digits(const u32* k, u32* dig, u32* sg) {
 #pragma unroll
@@ -353,6 +360,13 @@ KDEV void glv_fixed_digits(const u32* k, u32* dig, u32* sg) {
 // iteration (some lane always has a non-zero digit): 258 additions. The table lives in private memory (per-lane index).
 // The *_j forms return the running point in the lazy limbs (false: the product is the identity): the FK23 butterflies add and subtract it
 // without a detour through the saturated words.
+struct J29ArrTable {
+  J29A* T;
+  U29 beta;
+  KDEV void raw(int i, const U29& x, const U29& y, const U29& ratio) { T[i].x = x; T[i].y = y; T[i].xb = ratio; }
+  KDEV void get(int i, U29& x, U29& y, U29& ratio) const { x = T[i].x; y = T[i].y; ratio = T[i].xb; }
+  KDEV void fin(int i, const U29& x, const U29& y) { T[i].x = x; T[i].y = y; T[i].xb = u29_mul(x, beta); }
+};
 struct J29PrivTable {
   J29A T[8];
   U29 beta;
@@ -502,9 +516,9 @@ KDEV Jac<Fq> jac_scalar_mul_gtab_u29(const Jac<Fq>& p, const Fr& k_mont, uint4* 
 // position: (|d| + 1) / 2 in the low bits, the sign in bit 7. Bounds: j29_dbl and j29_madd map the running point's bound set into itself
 // (header of this file), so the order of the operations does not matter.
 constexpr int UNIFORM_DIG_STRIDE = 132;
-KDEV bool jac_scalar_mul_uniform_u29_j(const Jac<Fq>& p, const Fr& k_mont, unsigned char* dig, J29& out) {
+// width-5 NAF digits of the two GLV halves of a wave-uniform scalar into dig[0 .. 2 * UNIFORM_DIG_STRIDE) (the first lane's copy decides)
+KDEV void glv_uniform_digits(const Fr& k_mont, unsigned char* dig, bool& neg1, bool& neg2) {
   u32 k[8], k1[5], k2[5];
-  bool neg1, neg2;
   fp_from_mont<FrParams>(k, k_mont);
 #pragma unroll
   for (int i = 0; i < 8; i++) k[i] = (u32)__builtin_amdgcn_readfirstlane((int)k[i]);
@@ -534,9 +548,13 @@ KDEV bool jac_scalar_mul_uniform_u29_j(const Jac<Fq>& p, const Fr& k_mont, unsig
       a0 = (a0 >> 1) | (a1 << 31); a1 = (a1 >> 1) | (a2 << 31); a2 = (a2 >> 1) | (a3 << 31); a3 >>= 1;
     }
   }
+}
+// T: eight entries of table storage (the radix-4 kernel hands every ladder of a lane the same ones)
+KDEV bool jac_scalar_mul_uniform_u29_t(const Jac<Fq>& p, const Fr& k_mont, unsigned char* dig, J29& out, J29A* T) {
+  bool neg1, neg2;
+  glv_uniform_digits(k_mont, dig, neg1, neg2);
   // table T[i] = (2 i + 1) P, affine on the working curve
-  J29PrivTable tb;
-  tb.beta = u29_const(GlvParams::BETA29);
+  J29ArrTable tb = {T, u29_const(GlvParams::BETA29)};
   const U29 zfix = j29_build_table<true>(p, tb);
   U29 zero;
 #pragma unroll
@@ -552,7 +570,7 @@ KDEV bool jac_scalar_mul_uniform_u29_j(const Jac<Fq>& p, const Fr& k_mont, unsig
       const u32 byte = (u32)__builtin_amdgcn_readfirstlane((int)dig[which * UNIFORM_DIG_STRIDE + pos]);
       if (byte) {
         const bool neg = ((byte >> 7) != 0) != (which ? neg2 : neg1);
-        const J29A& e = tb.T[(byte & 0x7Fu) - 1u];
+        const J29A& e = T[(byte & 0x7Fu) - 1u];
         const U29 ex = which ? e.xb : e.x;
         const U29 ey = neg ? u29_sub(zero, e.y, Q29::K4) : e.y;      // table y < 2 p; the negation may become the running point's y (<= 4 p)
         if (empty) {
@@ -571,10 +589,83 @@ KDEV bool jac_scalar_mul_uniform_u29_j(const Jac<Fq>& p, const Fr& k_mont, unsig
   out.x = acc.x; out.y = acc.y; out.z = u29_mul(acc.z, zfix);
   return true;
 }
+KDEV bool jac_scalar_mul_uniform_u29_j(const Jac<Fq>& p, const Fr& k_mont, unsigned char* dig, J29& out) {
+  J29A T[8];
+  return jac_scalar_mul_uniform_u29_t(p, k_mont, dig, out, T);
+}
 KDEV Jac<Fq> jac_scalar_mul_uniform_u29(const Jac<Fq>& p, const Fr& k_mont, unsigned char* dig) {
   J29 a;
   if (!jac_scalar_mul_uniform_u29_j(p, k_mont, dig, a)) return jac_inf<Fq>();
   return {u29_to_fq(a.x), u29_to_fq(a.y), u29_to_fq(a.z)};
+}
+
+// ---- two-term products kA A + kB B with ONE doubling chain (the radix-4 butterflies of the FK23 stages with one twiddle per wave) ----------
+// Straus: the odd-multiple tables of A and of B on ONE working curve, one running point, the width-5 NAF digits of the four GLV half-scalars
+// in LDS (4 x UNIFORM_DIG_STRIDE bytes per product). A's table is built first (-> the curve isomorphic to E by zA), B is moved there as
+// (X zA^2, Y zA^3, Z) and its table built on that curve (-> isomorphic by zA zB'), A's entries are rescaled by zB' (2M + the product by beta
+// each). Two products over the same pair of points (the radix-4 butterfly needs w2 e2 + w2 w1 e3 and w2' e2 - w2' w1 e3) share the tables.
+// models/model_jac29.py: tables_pair and the two-term ladders.
+struct J29PairTables {
+  J29A* TA;                 // 8 entries each (caller's storage)
+  J29A* TB;
+  U29 zfix;
+};
+// A, B: saturated Jacobian, neither the identity
+KDEV void j29_build_pair(const Jac<Fq>& A, const Jac<Fq>& B, J29PairTables& t) {
+  const U29 beta = u29_const(GlvParams::BETA29);
+  J29ArrTable sa = {t.TA, beta}, sb = {t.TB, beta};
+  const U29 zA = j29_build_table<true>(A, sa);
+  const U29 zA2 = u29_sqr(zA), zA3 = u29_mul(zA, zA2);
+  J29 bc;
+  bc.x = u29_mul(u29_from_fq(B.x), zA2); bc.y = u29_mul(u29_from_fq(B.y), zA3); bc.z = u29_from_fq(B.z);
+  const U29 zB = j29_build_table_j<true>(bc, sb);
+  const U29 zB2 = u29_sqr(zB), zB3 = u29_mul(zB, zB2);
+#pragma unroll 1
+  for (int i = 0; i < 8; i++) {
+    t.TA[i].x = u29_mul(t.TA[i].x, zB2);
+    t.TA[i].xb = u29_mul(t.TA[i].xb, zB2);
+    t.TA[i].y = u29_mul(t.TA[i].y, zB3);
+  }
+  t.zfix = u29_mul(zA, zB);
+}
+// kA A + kB B (both scalars wave-uniform; negB: the second term is subtracted). dig: 4 * UNIFORM_DIG_STRIDE bytes of this wave's LDS.
+KDEV bool j29_mul2_uniform(const J29PairTables& t, const Fr& kA, const Fr& kB, bool negB, unsigned char* dig, J29& out) {
+  bool neg[4];
+  glv_uniform_digits(kA, dig, neg[0], neg[1]);
+  glv_uniform_digits(kB, dig + 2 * UNIFORM_DIG_STRIDE, neg[2], neg[3]);
+  if (negB) { neg[2] = !neg[2]; neg[3] = !neg[3]; }
+  U29 zero;
+#pragma unroll
+  for (int i = 0; i < 9; i++) zero.l[i] = 0;
+  J29 acc;
+  acc.x = zero; acc.y = zero; acc.z = zero;
+  bool empty = true;
+#pragma unroll 1
+  for (int pos = 128; pos >= 0; pos--) {
+    if (!empty) acc = j29_dbl(acc);
+#pragma unroll 1
+    for (int which = 0; which < 4; which++) {
+      const u32 byte = (u32)__builtin_amdgcn_readfirstlane((int)dig[which * UNIFORM_DIG_STRIDE + pos]);
+      if (byte) {
+        const bool ng = ((byte >> 7) != 0) != neg[which];
+        const J29A& e = (which & 2) ? t.TB[(byte & 0x7Fu) - 1u] : t.TA[(byte & 0x7Fu) - 1u];
+        const U29 ex = (which & 1) ? e.xb : e.x;
+        const U29 ey = ng ? u29_sub(zero, e.y, Q29::K4) : e.y;
+        if (empty) {
+          acc.x = ex; acc.y = ey; acc.z = u29_one();
+          empty = false;
+        } else {
+          int special;
+          acc = j29_madd(acc, ex, ey, special);
+          if (special == 1) acc = j29_dbl(acc);
+          if (special == 2) empty = true;
+        }
+      }
+    }
+  }
+  if (empty) return false;
+  out.x = acc.x; out.y = acc.y; out.z = u29_mul(acc.z, t.zfix);
+  return true;
 }
 
 }  // namespace bn254

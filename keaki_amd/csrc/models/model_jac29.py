@@ -238,6 +238,33 @@ def globalz(e, zr, zbase):
     return out, zfix
 
 
+def table_odd_on(m1):
+    """table_odd for a point m1 given as Jacobian limbs ON THE CURRENT WORKING CURVE (any curve of the family): entries affine on the curve
+    isomorphic to it by the returned zfix"""
+    X, Y, ZP = m1
+    d = j29_dbl(m1)
+    zd2 = sqr(d[2]); zd3 = mul(d[2], zd2)
+    e = [(mul(X, zd2), mul(Y, zd3), ZP)]
+    zr = [None]
+    for i in range(1, 8):
+        r, H = j29_madd(e[-1], d[0], d[1])
+        e.append(r); zr.append(H)
+    return globalz(e, zr, d[2])
+
+
+def tables_pair(Aj, Bj):
+    """odd-multiple tables of TWO points on ONE working curve (the two-term ladders of the radix-4 butterflies): A's table on E_(zA); B moved
+    to that curve as (X zA^2, Y zA^3, Z), its table built there (-> the curve isomorphic by zA zB'); A's entries rescaled by zB'.
+    Returns (TA, TB, zfix)."""
+    TA, zA = table_odd_on(Aj)
+    zA2 = sqr(zA); zA3 = mul(zA, zA2)
+    Bc = (mul(Bj[0], zA2), mul(Bj[1], zA3), Bj[2])
+    TB, zB = table_odd_on(Bc)
+    zB2 = sqr(zB); zB3 = mul(zB, zB2)
+    TA2 = [(note("pair.x", mul(x, zB2), 2.0), note("pair.y", mul(y, zB3), 2.0)) for x, y in TA]
+    return TA2, TB, mul(zA, zB)
+
+
 # ---- plain arithmetic to compare with -------------------------------------------------------------------------------------------
 def aff_add(p, q):
     if p is None: return q
@@ -359,6 +386,41 @@ def run(seed=1, ladders=6, bits=127):
             if acc is not None:
                 final = (acc[0], acc[1], mul(acc[2], zfix))
                 assert to_aff(final) == aff_mul(accv % R_ORDER, base), shape
+
+    # ---- two-term ladders kA A + kB B over a pair of tables on one curve
+    for it in range(max(2, ladders // 2)):
+        pts = []
+        for _ in range(2):
+            while True:
+                x = rnd.randrange(P); y2 = (x * x * x + 3) % P
+                y = pow(y2, (P + 1) // 4, P)
+                if y * y % P == y2: break
+            zz = rnd.randrange(1, P)
+            pts.append(((x, y), (mont(x * zz * zz % P), mont(y * zz * zz * zz % P), mont(zz))))
+        (Aa, Aj), (Ba, Bj) = pts
+        TA, TB, zfix = tables_pair(Aj, Bj)
+        zero = [0] * 9
+        acc, va, vb = None, 0, 0
+        for step in range(60):
+            if acc is not None:
+                for _ in range(rnd.randrange(1, 4)):
+                    acc = j29_dbl(acc); va *= 2; vb *= 2
+            which = rnd.randrange(2)
+            i = rnd.randrange(8)
+            neg = rnd.random() < 0.5
+            ex, ey = (TA if which == 0 else TB)[i]
+            if neg: ey = sub(zero, ey, K4)
+            sm = -(2 * i + 1) if neg else (2 * i + 1)
+            if acc is None:
+                acc = (ex, ey, ONE)
+            else:
+                r = j29_madd(acc, ex, ey)
+                assert r is not None
+                acc = r[0]
+            if which == 0: va += sm
+            else: vb += sm
+        final = (acc[0], acc[1], mul(acc[2], zfix))
+        assert to_aff(final) == aff_add(aff_mul(va % R_ORDER, Aa), aff_mul(vb % R_ORDER, Ba))
 
     # the butterflies' (u + v, u - v): inputs are canonical residues in the 2^256 form shifted by 5 bits (values up to 32 p), or a ladder's output
     for it in range(4 * ladders):

@@ -345,12 +345,13 @@ def test_new_from_file_ptau_fixture(K, oc, py, tmp_path):
 # FK23 at d = 2^9 .. 2^18 against the ORACLE's per-point opening: tests/test_gpu_config5.py::test_open_fk_large_domains_vs_oracle
 
 
-def test_open_fk_zero_and_sparse_polynomials(K):
+@pytest.mark.parametrize("d", [512, 4096])
+def test_open_fk_zero_and_sparse_polynomials(K, d):
     """FK23 with scalars that vanish: the zero polynomial (every product of the pipeline is the identity: every proof is the identity),
     a constant (the quotient is zero: identity proofs again) and single monomials (most of hat_a's inputs are zero) -- the ladders'
-    empty-accumulator paths, at a size where the wave-uniform ladder runs."""
-    d = 512
-    rng = K.Rng(3500)
+    empty-accumulator paths, at a size where the wave-uniform ladder runs (512) and at one where the radix-4 passes run (4096: their
+    lanes with an identity among the four points, or with equal / opposite points, take the radix-2 sequence)."""
+    rng = K.Rng(3500 + d)
     s = K.KZGSetup.setup(rng.fr_rand(), d)
     el = K.domain_elements(d)
     zero = np.zeros((d, 4), np.uint64)
