@@ -553,7 +553,7 @@ keaki_status fk_hat_s_run(keaki_hip_ctx* ctx, const void* d_srs, u32 log2d, cons
   const u32 d = 1u << log2d, N = 2 * d;
   G1Jac* s = (G1Jac*)d_hat_s;
   hipLaunchKernelGGL(k_fk_load, dim3(cdiv(N, 256)), dim3(256), 0, ctx->stream, (const G1Aff*)d_srs, d, s);
-  for (u32 half = d; half >= 1; half >>= 1) stage_map(ctx, false, s, (const Fr*)d_tw2d, N, half, 1, 0, N / (2 * half));
+  run_stages(ctx, false, s, (const Fr*)d_tw2d, N, d, 1u, 1, 0, [&](u32 half) { return N / (2 * half); });
   return launch_check(ctx, "fk_hat_s");
 }
 // d = 2^log2d openings from the cached hat_s. d_work: 2d Jacobian points. d_hat_a: 2d Fr, natural order, already divided by 2d.
@@ -641,10 +641,10 @@ static void fk_shard_tables(keaki_hip_ctx* ctx, FkShard& fk) {
 // one size-d transform, forward (decimation in frequency), distributed: spans d..2R on the cyclic layout, spans R..2 on the block layout
 static void dif_cyclic(keaki_hip_ctx* ctx, G1Jac* a, const Fr* tw, u32 d, u32 R, u32 r) {
   const u32 Md = d / R;
-  for (u32 half = Md / 2; half >= 1; half >>= 1) stage_map(ctx, false, a, tw, Md, half, R, r, 2 * (d / (2 * half * R)));
+  run_stages(ctx, false, a, tw, Md, Md / 2, 1u, R, r, [&](u32 half) { return 2 * (d / (2 * half * R)); });
 }
 static void dif_block(keaki_hip_ctx* ctx, G1Jac* a, u32 m, const Fr* tw, u32 d, u32 R) {      // m: local points (a multiple of R)
-  for (u32 half = R / 2; half >= 1; half >>= 1) stage_map(ctx, false, a, tw, m, half, 1, 0, 2 * (d / (2 * half)));
+  if (R >= 2) run_stages(ctx, false, a, tw, m, R / 2, 1u, 1, 0, [&](u32 half) { return 2 * (d / (2 * half)); });
 }
 // hat_s of this rank: even entries = DFT_d(S), odd entries = DFT_d(S_i omega_2d^i), both at bit-reversed positions, block layout.
 // step 0: the cyclic slices, spans d..2R, packed [even | odd] per peer -> d_send; step 1: d_recv -> block layout, spans R..2 -> fk.hat_s.
@@ -686,13 +686,13 @@ keaki_status fk_shard_open_run(keaki_hip_ctx* ctx, FkShard& fk, int step, void* 
     const G1Jac* hs = (const G1Jac*)fk.hat_s;
     G1Jac* o = (G1Jac*)fk.work;
     launch_pointwise(ctx, hs, hs + Md, (const Fr*)hat_a, fk.log2d, r * Md, Md, (G1Jac*)fk.e, o);
-    for (u32 half = 1; 2 * half <= Md; half <<= 1) stage_map(ctx, true, o, twi, Md, half, 1, 0, 2 * (d / (2 * half)));
+    if (Md >= 2) run_stages(ctx, true, o, twi, Md, 1u, Md / 2, 1, 0, [&](u32 half) { return 2 * (d / (2 * half)); });
     hipLaunchKernelGGL(k_jac_transpose, dim3(cdiv(Md, 256)), dim3(256), 0, st, (const G1Jac*)o, Md / R, R, (G1Jac*)d_send);
     return launch_check(ctx, "fk_shard_open 0");
   }
   if (step == 1) {
     G1Jac* a = (G1Jac*)d_recv;
-    for (u32 half = Md / R; 2 * half <= Md; half <<= 1) stage_map(ctx, true, a, twi, Md, half, R, r, 2 * (d / (2 * half * R)));
+    if (2 * (Md / R) <= Md) run_stages(ctx, true, a, twi, Md, Md / R, Md / 2, R, r, [&](u32 half) { return 2 * (d / (2 * half * R)); });
     launch_mul_strided(ctx, a, twi, R, r, Md);
     dif_cyclic(ctx, a, tw, d, R, r);
     HIP_TRY(ctx, hipMemcpyAsync(d_send, a, (size_t)Md * sizeof(G1Jac), hipMemcpyDeviceToDevice, st));
