@@ -440,14 +440,14 @@ def main():
               "call_note": "keaki_hip_open_fk_poly: coefficients from host memory in (%d MiB), affine proofs to host memory out (%d MiB)" % (d * 32 >> 20, d * 64 >> 20),
               "device_ms": st_ms[best]["device_ms"], "pointwise_ms": st_ms[best]["pointwise_ms"], "setup_hat_s_s": round(fk_setup_s, 3),
               "scalar_mults": d * lg + 3 * d,
-              "roofline": {"bound": "hbm", "kernel": "k_g1_fft_stage_map (2 x %d launches: one butterfly = one 254-bit scalar-mult + add + sub)" % lg,
+              "roofline": {"bound": "hbm", "kernel": "k_g1_fft_stage_map / k_g1_fft_stage4 (the 2 x %d butterfly stages: one butterfly = one 254-bit scalar-mult + add + sub; from span 16 on two stages per radix-4 pass)" % lg,
                            "algorithmic_bytes": fk_algo, "kernel_ms": stages_ms, "kernel_ms_stat": "all butterfly stages of one call, HIP events on the ctx stream",
                            "achieved": fk_algo / (stages_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fk_algo / (stages_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "note": "integer-issue bound like every kernel of the path: d log2 d butterfly scalar-mults of ~129 doublings + 43..66 mixed additions each"},
               "alu": {"scalar_mults_per_s_in_stages": d * lg / (stages_ms * 1e-3), "simd_cycles_per_butterfly": stages_ms * 1e-3 * 2.4e9 / (d * lg / 64.0 / 1024.0),
                       "note": "SIMD cycles one wave (64 butterflies) spends per butterfly stage step = scalar-mult + add + sub, at 2.4 GHz on 1024 SIMDs. The ladder: "
                               "129 doublings + 43 mixed additions (one twiddle per wave: sliding windows) or 66 (a twiddle per lane: fixed windows) on an "
-                              "effective-affine window table; valu_per_wave_butterfly = SQ_INSTS_VALU / SQ_WAVES of the stage kernels from the committed counter "
+                              "effective-affine window table; valu_per_wave = SQ_INSTS_VALU / SQ_WAVES of the stage kernels from the committed counter "
                               "pass (DESIGN 4.2b, 7.3)"}}
         # fabric traffic of one call from the committed counter passes (bench_tools/collect_pmc_fk_pairing.sh), when they were made on this build
         fk_traffic, fk_traffic_note = None, None
@@ -462,8 +462,11 @@ def main():
             else:
                 fk_traffic = pj["fk_one_call"]["fetch_bytes"] + pj["fk_one_call"]["write_bytes"]
                 ipw = pj.get("fk_instructions_per_wave", {})
-                pick = lambda tag: next((round(v["insts_valu"]) for k, v in ipw.items() if "stage_map<true, " + tag in k), None)
-                fk["alu"]["valu_per_wave_butterfly"] = {"one_twiddle_per_wave": pick("true, false"), "twiddle_per_lane": pick("false, true")}
+                pick = lambda tag: next((round(v["insts_valu"]) for k, v in ipw.items() if tag in k), None)
+                # averages over the launches of each kernel (the first stages' twiddles are short scalars: their ladders are cheaper)
+                fk["alu"]["valu_per_wave"] = {"radix4_pass_per_group_of_four_points": pick("fft_stage4<true"),
+                                              "radix2_one_twiddle_per_wave_per_butterfly": pick("stage_map<true, true, false"),
+                                              "radix2_twiddle_per_lane_per_butterfly": pick("stage_map<true, false, true")}
         except (OSError, ValueError, KeyError) as e:
             fk_traffic_note = "no committed PMC figure (%s)" % type(e).__name__
         fk["roofline"]["traffic"] = fk_traffic

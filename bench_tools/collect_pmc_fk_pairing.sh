@@ -32,7 +32,7 @@ res = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; KB x
 for tag in ("fk", "pair"):
     f, w = per_kernel(tag + "_FETCH_SIZE", "FETCH_SIZE"), per_kernel(tag + "_WRITE_SIZE", "WRITE_SIZE")
     for k in sorted(set(f) | set(w)):
-        if any(x in k for x in ("stage_map", "pointwise", "mul_jac", "fk_finish", "k_pairing", "k_miller", "k_final")):
+        if any(x in k for x in ("fft_stage", "pointwise", "mul_jac", "fk_finish", "k_pairing", "k_miller", "k_final")):
             res["kernels"][k] = {"launches": len(f.get(k, [])), "fetch_bytes_total": sum(f.get(k, [])), "write_bytes_total": sum(w.get(k, [])),
                                  "fetch_bytes_per_launch": sum(f.get(k, [])) / max(1, len(f.get(k, []))), "write_bytes_per_launch": sum(w.get(k, [])) / max(1, len(w.get(k, [])))}
 # instruction counters of the FK23 kernels, per wave (sums over all launches / SQ_WAVES)
@@ -40,7 +40,7 @@ sq = {}
 for path in glob.glob("%s/fk_SQ/**/*counter_collection.csv" % O, recursive=True):
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"].split("(")[0][-48:]
-        if any(x in k for x in ("stage_map", "pointwise", "mul_jac")):
+        if any(x in k for x in ("fft_stage", "pointwise", "mul_jac")):
             sq.setdefault(k, {}).setdefault(r["Counter_Name"], 0.0)
             sq[k][r["Counter_Name"]] += float(r["Counter_Value"])
 res["fk_instructions_per_wave"] = {k: {c.lower()[3:]: v[c] / v["SQ_WAVES"] for c in v if c != "SQ_WAVES"} for k, v in sq.items() if v.get("SQ_WAVES")}
@@ -48,7 +48,7 @@ for k, v in res["fk_instructions_per_wave"].items():
     print("%-50s per wave: %s" % (k, {c: int(x) for c, x in v.items()}))
 # one call = (setup + 2 calls) - (setup + 1 call), summed over the FK23 kernels
 def total(tag, counter):
-    return sum(sum(v) for k, v in per_kernel(tag + "_" + counter, counter).items() if any(x in k for x in ("stage_map", "pointwise", "mul_jac", "fk_finish", "k_fr_", "k_fk_")))
+    return sum(sum(v) for k, v in per_kernel(tag + "_" + counter, counter).items() if any(x in k for x in ("fft_stage", "pointwise", "mul_jac", "fk_finish", "k_fr_", "k_fk_")))
 res["fk_one_call"] = {"fetch_bytes": total("fk", "FETCH_SIZE") - total("fk1", "FETCH_SIZE"), "write_bytes": total("fk", "WRITE_SIZE") - total("fk1", "WRITE_SIZE"), "log2d": 21}
 print("one call of open_fk at d = 2^21: fetch %.1f GB, write %.1f GB" % (res["fk_one_call"]["fetch_bytes"] / 1e9, res["fk_one_call"]["write_bytes"] / 1e9))
 json.dump(res, open(O + "/r03_fk_pairing_hbm_traffic_pmc.json", "w"), indent=1)
