@@ -1,8 +1,9 @@
 // Jacobian scalar multiplication of BN254 G1 points in the 9 x 29-bit lazy representation (fq29.hip.h): the inner loop of the FK23
 // butterflies (fft_g1.hip; reference src/kzg.rs:182-200 = ark-poly group FFTs, every butterfly one `Group * ScalarField`).
-// GLV split k = k1 + k2 lambda (128-bit halves, phi(P) = (beta X, Y, Z)), fixed signed 4-bit windows over one table of 8 multiples, doubling dbl-2009-l with
-// D = 4 X Y^2 taken as a product (keeps every value small), addition add-1998-cmo-2 (no factors of two) with the addend's Z^2, Z^3 precomputed; the Y
-// coordinate of both formulas is one dual stream (two products, one reduction).
+// GLV split k = k1 + k2 lambda (128-bit halves, phi(x, y) = (beta x, y)), windows over ONE effective-affine table per point (every entry on one
+// isomorphic curve: mixed additions without an inversion, see below), doubling dbl-2009-l with D = 4 X Y^2 taken as a product (keeps every value
+// small) and no scaling passes, mixed addition madd without factors of two; the Y coordinate of both formulas is one dual stream (two products,
+// one reduction). The butterflies' add / subtract pair shares its products (j29_addsub); two-term sums share their doubling chain (j29_mul2_uniform).
 // Value bounds (multiples of p) on the running point: X < 17.6, Y < 3.8 (a dual stream's output), Z < 2.1; the addend is below 1.2
 // (u29_from_fq). A limb-exact model with 64-bit overflow assertions (models/model_jac29.py, run by the CPU suite) executes whole ladders
 // with these formulas; tests: k_selftest_j29 and the FK23 parity tests.
@@ -20,13 +21,6 @@ KDEV U29 u29_scale(const U29& a, u32 k) {
   U29 t;
 #pragma unroll
   for (int i = 0; i < 9; i++) t.l[i] = k * a.l[i];
-  return u29_carry(t);
-}
-// carry(a - 2 b + K), K biased by 2^31
-KDEV U29 u29_sub2x(const U29& a, const U29& b, const u32 (&K)[9]) {
-  U29 t;
-#pragma unroll
-  for (int i = 0; i < 9; i++) t.l[i] = a.l[i] - 2u * b.l[i] + K[i];
   return u29_carry(t);
 }
 KDEV J29 j29_dbl(const J29& p) {
@@ -51,82 +45,12 @@ KDEV J29 j29_dbl(const J29& p) {
   r.z = u29_mul(y2, p.z);                                // (2Y) Z
   return r;
 }
-// a + (X2, Y2, Z2) with Z2Z2 = Z2^2, Z2cu = Z2^3. special: 0 = ordinary sum (returned), 1 = the two points are equal (the caller doubles),
-// 2 = they are opposite (the sum is the identity). In a ladder k P with k < r that only happens for k = r - 2 (running multiple -P,
-// last digit -1), but it costs three instructions to notice (zero filter of fq29_core.hip.h).
-KDEV J29 j29_add(const J29& a, const U29& X2, const U29& Y2, const U29& Z2, const U29& Z2Z2, const U29& Z2cu, int& special) {
-  const U29 Z1Z1 = u29_sqr(a.z), U1 = u29_mul(a.x, Z2Z2), U2 = u29_mul(X2, Z1Z1), S1 = u29_mul(a.y, Z2cu);
-  const U29 S2 = u29_mul(Y2, u29_mul(a.z, Z1Z1));
-  const U29 H = u29_sub(U2, U1, Q29::K2);
-  special = 0;
-  if (u29_maybe_zero(H)) {
-    if (u29_is_zero(H)) {
-      special = u29_is_zero(u29_sub(S2, S1, Q29::K2)) ? 1 : 2;
-      return a;
-    }
-  }
-  const U29 HH = u29_sqr(H), HHH = u29_mul(H, HH);
-  const U29 rr = u29_sub(S2, S1, Q29::K2);
-  const U29 V = u29_mul(U1, HH);
-  J29 r;
-  r.x = u29_sub3(u29_sqr(rr), HHH, V);
-  const U29 T = u29_sub(V, r.x, Q29::K16);
-  // Y3 = r T - S1 H^3 as ONE dual stream: r T + (2p - S1) H^3, the second factor raw (S1 is a stream output below 1.1 p with exact limbs: 2p - S1
-  // stays positive in every limb and below 1.5 * 2^30)
-  U29 ns;
-#pragma unroll
-  for (int i = 0; i < 9; i++) ns.l[i] = Q29::K2[i] - S1.l[i];
-  r.y = u29_mul2(rr, T, ns, HHH);
-  r.z = u29_mul(u29_mul(a.z, Z2), H);
-  return r;
-}
-
-// j29_add with the addend in MEMORY (a window-table entry of jac_scalar_mul_gtab_u29: words [0..8] y, [9..17] z, [18..26] z^2, [27..35] z^3,
-// [36..44] x, [48..56] beta x): every field is loaded where the formula first needs it, so that at most one of them is alive beside the
-// running point (loading all five up front costs 55 registers: the kernels then drop to two waves per SIMD or spill).
 KDEV U29 ld9(const u32* __restrict__ p) {
   U29 r;
 #pragma unroll
   for (int i = 0; i < 9; i++) r.l[i] = p[i];
   return r;
 }
-KDEV J29 j29_add_mem(const J29& a, const u32* __restrict__ e, bool phi, bool neg, int& special) {
-  const U29 Z1Z1 = u29_sqr(a.z);
-  const U29 U1 = u29_mul(a.x, ld9(e + 18));
-  const U29 U2 = u29_mul(ld9(e + (phi ? 48 : 36)), Z1Z1);
-  const U29 S1 = u29_mul(a.y, ld9(e + 27));
-  U29 Y2 = ld9(e);
-  if (neg) {
-    U29 zero;
-#pragma unroll
-    for (int i = 0; i < 9; i++) zero.l[i] = 0;
-    Y2 = u29_sub(zero, Y2, Q29::K4);          // table y < 3.8 p (a dual stream's output or the input point)
-  }
-  const U29 S2 = u29_mul(Y2, u29_mul(a.z, Z1Z1));
-  const U29 H = u29_sub(U2, U1, Q29::K2);
-  special = 0;
-  if (u29_maybe_zero(H)) {
-    if (u29_is_zero(H)) {
-      special = u29_is_zero(u29_sub(S2, S1, Q29::K2)) ? 1 : 2;
-      return a;
-    }
-  }
-  const U29 HH = u29_sqr(H), HHH = u29_mul(H, HH);
-  const U29 rr = u29_sub(S2, S1, Q29::K2);
-  const U29 V = u29_mul(U1, HH);
-  J29 r;
-  r.x = u29_sub3(u29_sqr(rr), HHH, V);
-  const U29 T = u29_sub(V, r.x, Q29::K16);
-  // Y3 = r T - S1 H^3 as ONE dual stream: r T + (2p - S1) H^3, the second factor raw (S1 is a stream output below 1.1 p with exact limbs: 2p - S1
-  // stays positive in every limb and below 1.5 * 2^30)
-  U29 ns;
-#pragma unroll
-  for (int i = 0; i < 9; i++) ns.l[i] = Q29::K2[i] - S1.l[i];
-  r.y = u29_mul2(rr, T, ns, HHH);
-  r.z = u29_mul(u29_mul(a.z, ld9(e + 9)), H);
-  return r;
-}
-
 // (u + v, u - v) of an FK23 butterfly in the lazy limbs. u, v: Jacobian, every coordinate below 32 p with carried limbs (a saturated residue
 // through u29_from_sat_shift5, or a ladder's running point), neither the identity. The products up to H = U2 - U1 and Z3 = Z1 Z2 H are shared
 // by the two results; r^2 and the dual stream of Y are per result (add-1998-cmo-2, r' = -S2 - S1 for the difference). Returns false when
@@ -247,7 +171,9 @@ struct J29A {            // table entry: affine on the working curve, with beta 
   U29 x, xb, y;
 };
 // a (Jacobian on the working curve: X < 19 p, Y <= 4 p, limbs carried) + (x2, y2) affine. 8M + 3S without factors of two, Y3 as one dual
-// stream. special as j29_add. H (= Z3 / Z1) goes to *ratio when the build asks for it.
+// stream. special: 0 = ordinary sum (returned), 1 = the two points are equal (the caller doubles), 2 = they are opposite (the sum is the identity);
+// in a ladder k P with k < r that only happens for k = r - 2, but it costs three instructions to notice. H (= Z3 / Z1) goes to *ratio when the
+// build asks for it.
 KDEV J29 j29_madd(const J29& a, const U29& x2, const U29& y2, int& special, U29* ratio = nullptr) {
   const U29 Z1Z1 = u29_sqr(a.z);
   const U29 U2 = u29_mul(x2, Z1Z1);

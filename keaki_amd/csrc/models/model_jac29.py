@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Limb-exact model of the Jacobian doubling and addition of jac29.hip.h (the ladders of the FK23 butterflies) in the 9 x 29-bit lazy
-arithmetic: the same operations in the same order on Python integers, with assertions on every limb (no negative value, no 32-bit overflow,
-stream operands within their budgets) and on every value bound, checked against plain affine arithmetic. Round 3's form: Y3 of the doubling
-(E T - 8 B^2) and of the addition (r T - 2 S1 J) are ONE dual stream each (u29_mul2: two products, one reduction) -- the square C = B^2
-and one product disappear as separate streams. tests/test_pair261_model.py runs this in the CPU suite.
+"""Limb-exact model of the point arithmetic of jac29.hip.h (the ladders of the FK23 butterflies) in the 9 x 29-bit lazy arithmetic: the same
+operations in the same order on Python integers, with assertions on every limb (no negative value, no 32-bit overflow, stream operands
+within their budgets) and on every value bound, checked against plain affine arithmetic: the doubling (Y3 = E T - 8 B^2 as ONE dual stream,
+no scaling passes), the mixed addition (Y3 = r T - Y1 H^3 as one dual stream), the shared add / subtract pair of the butterflies, the
+effective-affine window tables (every entry on one isomorphic curve) in both shapes, whole ladders over them, and the pair of tables and
+two-term ladders of the radix-4 passes. tests/test_pair261_model.py runs this in the CPU suite.
 
 Streams (fq29_asm.hip.h): limbs exact on output, value < (sum of products) / 2^261 + p.
   mul(a, b):      a <= 2^30 + 16, b <= 2^29 + 8          sqr(a): a <= 2^29 + 8
@@ -116,28 +117,6 @@ def j29_dbl(p):
     y3 = note("dbl.y", mul2(E, T, B2, N4), 3.8)                              # E T - 8 B^2
     Y2 = u32s([2 * v for v in y], "dbl.2y")
     z3 = note("dbl.z", mul(Y2, z), 2.01)
-    return (x3, y3, z3)
-
-
-def j29_add(a, X2, Y2, Z2, Z2Z2, Z2cu):
-    """add-1998-cmo-2 (no factors of two anywhere): H = U2 - U1, r = S2 - S1, X3 = r^2 - H^3 - 2 U1 H^2, Y3 = r (U1 H^2 - X3) - S1 H^3, Z3 = Z1 Z2 H"""
-    x, y, z = a
-    Z1Z1 = sqr(z)
-    U1, U2, S1 = mul(x, Z2Z2), mul(X2, Z1Z1), mul(y, Z2cu)
-    S2 = mul(Y2, mul(z, Z1Z1))
-    H = sub(U2, U1, K2)
-    if val(H) % P == 0:
-        return None
-    HH = sqr(H)
-    HHH = mul(H, HH)
-    V = mul(U1, HH)
-    rr = sub(S2, S1, K2)
-    x3 = note("add.x", sub3(sqr(rr), HHH, V), 12)
-    T = note("add.T", sub(V, x3, K16), 19)
-    N = u32s([k - s1 for k, s1 in zip(K2, S1)], "add.N")                     # raw 2p - S1: limbs below 1.5 * 2^30, S1 < 1.1 p
-    note("add.S1", S1, 1.2)
-    y3 = note("add.y", mul2(rr, T, N, HHH), 3)                               # r T - S1 H^3
-    z3 = note("add.z", mul(mul(z, Z2), H), 2.01)
     return (x3, y3, z3)
 
 
@@ -300,56 +279,7 @@ def mont(v):
 
 def run(seed=1, ladders=6, bits=127):
     rnd = random.Random(seed)
-    for it in range(ladders):
-        # a point in the bounds the ladders start from (u29_from_fq: < 1.2 p after the conversion product; here canonical)
-        while True:
-            x = rnd.randrange(P); y2 = (x * x * x + 3) % P
-            y = pow(y2, (P + 1) // 4, P)
-            if y * y % P == y2: break
-        base = (x, y)
-        P1 = (mont(x), mont(y), mont(1))
-        # window table 1..8 as the kernels build it: 2P by doubling, then +P each
-        tab = [P1, j29_dbl(P1)]
-        for m in range(3, 9):
-            q = tab[0]
-            tab.append(j29_add(tab[-1], q[0], q[1], q[2], sqr(q[2]), mul(q[2], sqr(q[2]))))
-        for m, t in enumerate(tab, 1):
-            assert to_aff(t) == aff_mul(m, base), m
-        k = rnd.getrandbits(bits) | (1 << (bits - 1))
-        digs = []
-        kk = k
-        while kk:
-            digs.append(kk & 15); kk >>= 4
-        acc, accv = None, 0
-        zero = [0] * 9
-        for d in reversed(digs):
-            if acc is not None:
-                for _ in range(4):
-                    acc = j29_dbl(acc)
-                accv *= 16
-            if d:
-                m = (d - 1) % 8 + 1                       # every table entry meets every kind of running point
-                neg = rnd.random() < 0.5                  # signed digits / negative half-scalars: the entry's y negated with 4p
-                e = tab[m - 1]
-                note("table.y", e[1], 3.8)
-                ey = sub(zero, e[1], K4) if neg else e[1]
-                sm = -m if neg else m
-                if acc is None:
-                    acc, accv = (e[0], ey, e[2]), sm
-                else:
-                    r = j29_add(acc, e[0], ey, e[2], sqr(e[2]), mul(e[2], sqr(e[2])))
-                    if r is None:
-                        if (accv - sm) % R_ORDER == 0:
-                            acc = j29_dbl(acc); accv *= 2
-                        else:
-                            acc, accv = None, 0
-                    else:
-                        acc, accv = r, accv + sm
-        if acc is None:
-            continue
-        accv %= R_ORDER
-        assert to_aff(acc) == aff_mul(accv, base)
-    # ---- the same ladders over effective-affine tables (mixed additions), both table shapes
+    # ---- ladders over effective-affine tables (mixed additions), both table shapes
     global ONE
     ONE = mont(1)
     for it in range(ladders):

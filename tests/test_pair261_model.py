@@ -149,16 +149,18 @@ def test_g2_lazy_mixed_addition_model():
 
 
 def test_jacobian_ladder_formulas_model():
-    """keaki_amd/csrc/models/model_jac29.py: the Jacobian doubling and addition of jac29.hip.h (FK23 ladders) operation by operation on Python
-    integers -- Y3 of both formulas as ONE dual stream -- with assertions on every limb and every value bound; whole 127-bit window ladders
-    (table of eight multiples, four doublings and an addition per window) against plain affine arithmetic."""
+    """keaki_amd/csrc/models/model_jac29.py: the point arithmetic of jac29.hip.h (FK23 ladders) operation by operation on Python integers --
+    the doubling and the mixed addition with Y3 as ONE dual stream each, the butterflies' shared add / subtract pair, the effective-affine
+    window tables in both shapes, the pair of tables and the two-term ladders of the radix-4 passes -- with assertions on every limb and every
+    value bound; whole ladders against plain affine arithmetic."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("model_jac29", os.path.join(ROOT, "keaki_amd", "csrc", "models", "model_jac29.py"))
     m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
     maxima = m.run(seed=5, ladders=4)
-    assert maxima["dbl.x"] < 17.6 and maxima["dbl.y"] < 3.8 and maxima["add.y"] < 3.0 and maxima["dbl.z"] < 2.1 and maxima["add.z"] < 2.1
+    assert maxima["dbl.x"] < 17.6 and maxima["dbl.y"] < 3.8 and maxima["dbl.z"] < 2.1 and maxima["madd.y"] < 1.8 and maxima["madd.z"] < 1.5
+    assert maxima["tab.y"] < 2.0 and maxima["pair.y"] < 2.0 and maxima["as.y"] < 1.45
     # worst cases by the stream rule value < (sum of products) / 2^261 + p, 2^261 / p > 169:
-    #   dbl: A < 19^2/169 + 1 = 3.14, E = 3A < 9.5, S < 19 * 3.2/169 + 1 = 1.4, D < 5.5, T < D + 32 = 37.5, B < 3.2 (the old Y bound), 2B (16 - 4B) <= 6.4 * 16
+    #   dbl: A < 19^2/169 + 1 = 3.14, E = 3A < 9.5, T < 4 X B + 32 < 37.5, B < 3.2 (Y < 19), 2B (16 - 4B) <= 6.4 * 16
     assert (9.5 * 37.5 + 6.4 * 16) / 169 + 1 < 3.8
-    #   add: r < 2 (1.3 + 2) = 6.6, V < 1.3, T < 17.3, 4p - 2 S1 < 4, J < 1.3
-    assert (6.6 * 17.3 + 4 * 1.3) / 169 + 1 < 3.0
+    #   madd: H < 2 + 32 = 34, HH < 34^2/169 + 1 = 7.9, H^3 < 34 * 7.9/169 + 1 = 2.6, V < 19 * 7.9/169 + 1 = 1.9, r < 2 + 4 = 6, T < V + 16 = 17.9, 8p - Y1 <= 8
+    assert (6 * 17.9 + 8 * 2.6) / 169 + 1 < 1.8
