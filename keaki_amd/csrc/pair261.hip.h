@@ -143,6 +143,21 @@ KDEV Fq2d fq2d_load(const Fq2* a) {
   return {reinterpret_cast<const Fq*>(a)[odd]};
 }
 KDEV Fq2d fq2_mul_fq(const Fq2d& a, const Fq& k) { return {fq_mul261(a.v, k)}; }
+// a / 2 (any Montgomery radix: halving commutes with it): a canonical word value v < p is v / 2 when even, (v + p) / 2 when odd (v + p < 2^255).
+// Branch-free: p masked by the low bit, one carry chain, one funnel shift per word -- ~30 instructions where the product by 1/2 took ~275.
+KDEV Fq fq_half(const Fq& a) {
+  const u32 m = 0u - (a.l[0] & 1u);
+  u32 t[8];
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { c += (u64)a.l[i] + (FqParams::MOD[i] & m); t[i] = (u32)c; c >>= 32; }
+  Fq r;
+#pragma unroll
+  for (int i = 0; i < 7; i++) r.l[i] = __builtin_amdgcn_alignbit(t[i + 1], t[i], 1);
+  r.l[7] = t[7] >> 1;
+  return r;
+}
+KDEV Fq2d fq2_half(const Fq2d& a) { return {fq_half(a.v)}; }
 
 // ---- product operands in limb form ---------------------------------------------------------------------------------------------
 // x side: this lane's component and the partner's (limbs <= 2^29 + 8)

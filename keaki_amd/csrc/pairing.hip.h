@@ -28,11 +28,11 @@ struct G2Hom { Fq2d x, y, z; };
 struct Line { Fq2d c0, c1, c2; };  // evaluated as c0 * P.y + (c1 * P.x + c2 v) w
 
 static KTOWER void line_double(G2Hom* r, Line* l) {
-  Fq2d a = fq2_mul_fq(M2(r->x, r->y), TWO_INV);
+  Fq2d a = fq2_half(M2(r->x, r->y));
   Fq2d b = S2(r->y), c = S2(r->z);
   Fq2d e = M2(fq2d_load(&p261::G2_B), fq2_dbl(c) + c);
   Fq2d f = fq2_dbl(e) + e;
-  Fq2d g = fq2_mul_fq(b + f, TWO_INV);
+  Fq2d g = fq2_half(b + f);
   Fq2d h = S2(r->y + r->z) - (b + c);
   Fq2d i = e - b;
   Fq2d j = S2(r->x);

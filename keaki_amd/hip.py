@@ -45,6 +45,32 @@ def lib_path() -> str:
     return os.path.join(_HERE, "libkeaki_hip.so")
 
 
+def share_torch_runtime(names=("libamdhip64.so",)):
+    """A process must end up with ONE HIP runtime. PyTorch wheels bundle their own copy (torch/lib/libamdhip64.so, the same SONAME as the
+    system's): when torch is imported FIRST, libkeaki_hip.so binds to that copy and everything shares it; the other way round the process
+    would hold two runtimes and torch fails with "No HIP GPUs are available". So, when PyTorch is installed but not loaded yet, its copy
+    of the named libraries is loaded here (by path, without importing torch) before ours. KEAKI_HIP_RUNTIME=system keeps the system's
+    runtime (a process that never imports torch does not care)."""
+    import sys
+    if os.environ.get("KEAKI_HIP_RUNTIME", "") == "system" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in names:
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass        # an unusable bundle: the system's runtime serves
+
+
 def load_library():
     """Loads libkeaki_hip.so. Raises (never falls back) when the HIP extension is missing."""
     global _LIB
@@ -53,6 +79,7 @@ def load_library():
         if not os.path.exists(path):
             raise KeakiHipError(-100, f"{path} not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
                                       f"or `make -C keaki_amd/csrc`. There is no CPU fallback.")
+        share_torch_runtime()
         lib = C.CDLL(path)
         vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int32
         lib.keaki_hip_version.restype = C.c_char_p

@@ -1,5 +1,7 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
 Bit-exact: integer work, so every comparison is equality of canonical limbs / bytes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -882,3 +884,18 @@ def test_optional_memory_is_optional(oc, py, rand_fr, monkeypatch):
         assert np.array_equal(ct[idx], ect) and np.array_equal(gt[idx], egt) and np.array_equal(key[idx], ekey)
     finally:
         h.close()
+
+
+def test_pytorch_can_start_after_the_library():
+    """One HIP runtime per process whatever the import order: a fresh interpreter that creates a context FIRST and imports PyTorch
+    afterwards (PyTorch wheels bundle their own libamdhip64: loaded second it would be a second runtime and torch would report
+    "No HIP GPUs are available") can still allocate on the GPU, and the library's results are unchanged."""
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from keaki_amd.hip import KeakiHip\n"
+            "h = KeakiHip(0); assert h.selftest_field(4, 2, 1) == 0\n"
+            "import torch\n"
+            "x = torch.arange(8, device='cuda'); assert int(x.sum().item()) == 28\n"
+            "assert h.selftest_field(4, 2, 2) == 0; h.close(); print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
