@@ -109,13 +109,23 @@ KDEV Fq fq_sqr261(const Fq& a) { return pack(u29_sqr(cut(a))); }
 KDEV Fq to261(const Fq& a256) { return pack(u29_mul(cut(a256), u29_const(Conv::C266))); }     // x 2^256 -> x 2^261
 KDEV Fq to256(const Fq& a261) { return pack(u29_mul(cut(a261), u29_const(Q29::R256))); }      // x 2^261 -> x 2^256
 KDEV void canon_words(u32* out8, const Fq& a261) { u29_pack_canonical(out8, u29_mul(cut(a261), u29_const(Conv::PLAIN_ONE))); }   // -> x itself
-// a^(p-2): 254 squarings + ~127 products in the lazy limbs (every intermediate < 2p). Once per pairing (easy part of the final exponentiation).
+// a^(p-2): 254 squarings + 60 products in the lazy limbs (every intermediate < 2p): sliding windows of three bits over the constant exponent
+// with the odd powers a, a^3, a^5, a^7 (the plain square-and-multiply took 110 products). The exponent is a constant: control flow is uniform.
+// Once per pairing (easy part of the final exponentiation).
 static KNOINLINE Fq fq_inv261(const Fq a) {
-  const U29 base = cut(a);
+  const U29 a1 = cut(a), a2 = u29_sqr(a1), a3 = u29_mul(a2, a1), a5 = u29_mul(a3, a2), a7 = u29_mul(a5, a2);
+  auto bit = [](int i) { return (FQ_PM2[i >> 5] >> (i & 31)) & 1u; };
   U29 acc = u29_const(Q29::ONE);
-  for (int i = 253; i >= 0; i--) {
-    acc = u29_sqr(acc);
-    if ((FQ_PM2[i >> 5] >> (i & 31)) & 1) acc = u29_mul(acc, base);
+  int i = 253;
+#pragma unroll 1
+  while (i >= 0) {
+    if (!bit(i)) { acc = u29_sqr(acc); i--; continue; }
+    int l = i >= 2 ? 3 : i + 1;
+    while (!bit(i - l + 1)) l--;                      // the window ends in a set bit: its value is odd
+    u32 v = 0;
+    for (int k = 0; k < l; k++) { acc = u29_sqr(acc); v = (v << 1) | bit(i - k); }
+    acc = u29_mul(acc, v == 1 ? a1 : v == 3 ? a3 : v == 5 ? a5 : a7);
+    i -= l;
   }
   return pack(acc);
 }
@@ -229,10 +239,47 @@ static KNOINLINE Fq2d fq2d_sqr(const Fq2d a) {
 KDEV Fq2d operator*(const Fq2d& a, const Fq2d& b) { return fq2d_mul(a, b); }
 KDEV Fq2d fq2_sqr(const Fq2d& a) { return fq2d_sqr(a); }
 // (9 + u) a in the saturated words (only where a single value is needed outside a product)
+// This lane's component of (9 + u)(a0 + a1 u): even 9 a0 - a1, odd 9 a1 + a0, as ONE multi-word expression with ONE reduction:
+// r = 9 own + s with s = p - partner (even) | partner (odd), r < 10 p < 2^258; quotient estimate q = floor(floor(r / 2^227) * 42 / 2^32)
+// (42 < 2^32 / (p / 2^227 + 1): q <= floor(r / p), and >= floor(r / p) - 1 because 42 p / 2^259 = 0.9937 and r / p < 10), so r - q p lies
+// in [0, 2p) and one conditional subtraction makes it canonical. ~90 instructions where three doublings, two additions and a conditional
+// negation of the saturated arithmetic took ~170 (390 uses per pairing).
 KDEV Fq2d fq2_mul_xi(const Fq2d& a) {
-  Fq t = fq_dbl(fq_dbl(fq_dbl(a.v))) + a.v;   // 9 * self
-  Fq o = fq_partner(a.v);
-  return {t + fp_cneg<FqParams>(o, lane_odd() == 0)};
+  const bool even = lane_odd() == 0;
+  const Fq o = fq_partner(a.v);
+  u32 s[8], t[9], r[9], cy;
+  // s = p - partner (even) | partner (odd): one borrow chain, one select per word
+  cy = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { const u32 d = __builtin_subc(FqParams::MOD[i], o.l[i], cy, &cy); s[i] = even ? d : o.l[i]; }
+  // r = (own << 3) + own + s: funnel shifts and two carry chains over nine words
+  t[0] = a.v.l[0] << 3;
+#pragma unroll
+  for (int i = 1; i < 8; i++) t[i] = __builtin_amdgcn_alignbit(a.v.l[i], a.v.l[i - 1], 29);
+  t[8] = a.v.l[7] >> 29;
+  cy = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r[i] = __builtin_addc(t[i], a.v.l[i], cy, &cy);
+  r[8] = t[8] + cy;
+  cy = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r[i] = __builtin_addc(r[i], s[i], cy, &cy);
+  r[8] += cy;
+  const u32 q = __umulhi(__builtin_amdgcn_alignbit(r[8], r[7], 3), 42u);
+  // r - q p: the eight word products stand alone (no carry between the multiplications), one carry chain joins them, one borrow chain subtracts
+  u32 lo[8], hi[8], w[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { const u64 pr = (u64)FqParams::MOD[i] * q; lo[i] = (u32)pr; hi[i] = (u32)(pr >> 32); }
+  cy = 0;
+  w[0] = lo[0];
+#pragma unroll
+  for (int i = 1; i < 8; i++) w[i] = __builtin_addc(lo[i], hi[i - 1], cy, &cy);
+  cy = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) t[i] = __builtin_subc(r[i], w[i], cy, &cy);
+  Fq2d out;
+  fq_cond_sub_p_asm(out.v.l, t);
+  return out;
 }
 // 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + a1^2); the norm's inverse is computed redundantly in both lanes
 KDEV Fq2d fq2_inv(const Fq2d& a) {

@@ -99,6 +99,22 @@ __global__ void __launch_bounds__(64) k_selftest_fq2d(u32 seed, u32 iters, unsig
     bad += !eq(ad * bd, a * b);
     bad += !eq(fq2_sqr(ad), bn254::fq2_sqr(a));
     bad += !eq(fq2_mul_xi(ad), bn254::fq2_mul_xi(a));
+    {  // (9 + u) a and a / 2 on WORD values at the ends of the range (0, 1, p - 1, p - 2): the single-reduction forms against plain arithmetic
+      const u32 c = (sh >> 9) & 15u;
+      Fq w0 = fq_zero(), w1 = fq_zero();
+      if (c & 1u) w0.l[0] = 1u;
+      if (c & 2u) { for (int j = 0; j < 8; j++) w0.l[j] = FqParams::MOD[j]; w0.l[0] -= (c & 1u) ? 2u : 1u; }
+      if (c & 4u) w1.l[0] = 1u;
+      if (c & 8u) { for (int j = 0; j < 8; j++) w1.l[j] = FqParams::MOD[j]; w1.l[0] -= (c & 4u) ? 2u : 1u; }
+      const Fq2d e = {par ? w1 : w0};
+      const Fq2d got = fq2_mul_xi(e);
+      const Fq2d other = {fq_partner(e.v)};
+      const Fq nine = fq_dbl(fq_dbl(fq_dbl(e.v))) + e.v;
+      const Fq want = par ? nine + other.v : nine - other.v;
+      bad += !fq_eq(got.v, want);
+      bad += !fq_eq(fq_dbl(fq_half(e.v)), e.v);
+      bad += !fq_eq(fq_half(ad.v) + fq_half(ad.v), ad.v);
+    }
     bad += !eq(fq2_conj(ad), bn254::fq2_conj(a));
     bad += !eq(fq2_inv(ad), bn254::fq2_inv(a));
     bad += !eq(fq2_mul_fq(ad, to261(k)), bn254::fq2_mul_fq(a, k));
