@@ -45,7 +45,7 @@ def lib_path() -> str:
     return os.path.join(_HERE, "libkeaki_hip.so")
 
 
-def share_torch_runtime(names=("libamdhip64.so",)):
+def share_torch_runtime(names=("libamdhip64.so",)):    # the HIP runtime only: loading PyTorch's librccl ahead of torch aborts at exit
     """A process must end up with ONE HIP runtime. PyTorch wheels bundle their own copy (torch/lib/libamdhip64.so, the same SONAME as the
     system's): when torch is imported FIRST, libkeaki_hip.so binds to that copy and everything shares it; the other way round the process
     would hold two runtimes and torch fails with "No HIP GPUs are available". So, when PyTorch is installed but not loaded yet, its copy
@@ -66,7 +66,7 @@ def share_torch_runtime(names=("libamdhip64.so",)):
         path = os.path.join(libdir, name)
         if os.path.exists(path):
             try:
-                C.CDLL(path, mode=C.RTLD_GLOBAL)
+                C.CDLL(path)        # local scope is enough: later NEEDED entries resolve to a loaded object by its SONAME
             except OSError:
                 pass        # an unusable bundle: the system's runtime serves
 

@@ -7,7 +7,7 @@ import os
 
 import numpy as np
 
-from .hip import KeakiHip, KeakiHipError, load_library, share_torch_runtime
+from .hip import KeakiHip, KeakiHipError, load_library
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -20,7 +20,6 @@ def load_rccl_library():
     global _LIB
     if _LIB is None:
         load_library()
-        share_torch_runtime(("librccl.so",))      # PyTorch bundles its own RCCL: one copy per process, like the HIP runtime
         path = os.path.join(_HERE, "libkeaki_hip_rccl.so")
         if not os.path.exists(path):
             raise KeakiHipError(-100, "%s not built (make -C keaki_amd/csrc)" % path)

@@ -18,7 +18,9 @@ class DevMem:
     """raw device buffers for the test (the ABI's *_dev entries take plain device pointers)"""
 
     def __init__(self):
-        self.rt = C.CDLL("libamdhip64.so")
+        from keaki_amd.hip import load_library
+        load_library()                                  # the process's ONE HIP runtime is loaded by now (PyTorch's copy when PyTorch is installed)
+        self.rt = C.CDLL("libamdhip64.so.7")            # by SONAME: the loader hands back the copy that is already in the process
         self.rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.rt.hipFree.argtypes = [C.c_void_p]
