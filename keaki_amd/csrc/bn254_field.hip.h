@@ -240,9 +240,9 @@ template <> KDEV void fp_from_mont<FrParams>(u32* out, const Fr& a) { fr_from_mo
 #endif
 namespace bn254 {
 
-// a^(p-2). Not inlined: 254 squarings + ~127 products, in the 29-bit lazy limbs of fq29_core.hip.h (813 / 933 SIMD-cycles each against
-// 1,198 for the saturated stream; every intermediate stays below 2p); called once per affine conversion / per pairing.
-static __device__ __noinline__ Fq fq_inv(const Fq& a) {
+// a^(p-2). Not inlined: 254 squarings + 110 products, in the 29-bit lazy limbs of fq29_core.hip.h (every intermediate stays below 2p). The
+// reference the division-step inverse below is tested against (the shipped fq_inv since round 3).
+static __device__ __noinline__ Fq fq_inv_fermat(const Fq& a) {
   const U29 one = u29_const(Fq29Params::ONE);
   const U29 base = u29_mul(u29_from_sat_shift5(a.l), one);        // 2^261-form, below 2p
   U29 acc = one;
@@ -305,6 +305,108 @@ static __device__ __noinline__ Fq fq_inv_xgcd(const Fq& a) {
   for (int i = 0; i < 8; i++) r3.l[i] = FqParams::R3[i];
   return fp_mul<FqParams>(y, r3);
 }
+
+// Inverse by Bernstein-Yang division steps ("safegcd": the constant-time form libsecp256k1 uses, here for BN254's p): 20 rounds of 30 divsteps
+// on the low 30 bits of (f, g) -- each round yields a 2 x 2 transition matrix that is then applied to the full (f, g) and, modulo p, to (d, e)
+// -- bring g to 0 and f to +-1 whatever the input is (590 steps suffice for 256-bit inputs), and d to +-1/x. No branch depends on the data:
+// every lane of a wave does the same ~16 K plain 32-bit instructions, where the Fermat ladder spends 254 squarings + 60 products (~57 K, most
+// of them multiply-adds). Values are nine signed 30-bit limbs. `a`: a canonical word value x < p (whatever form the caller reads into it); returns x^-1 mod p as canonical words (0 for 0).
+// (csrc/models: the same loop in Python against pow(x, -1, p); the device self-test compares it with the ladder.)
+static __device__ __noinline__ Fq fq_inv_safegcd_words(const Fq a) {      // by value: pointers to the caller's registers would send them to scratch memory
+  constexpr int32_t M30 = (int32_t)(0xFFFFFFFFu >> 2);
+  constexpr int32_t P30[9] = {0x187cfd47, 0x3082305b, 0x071ca8d3, 0x205aa45a, 0x01585d97, 0x0116da06, 0x1a029b85, 0x139cb84c, 0x00003064};
+  constexpr u32 PINV30 = 0x1b799c77u;                 // p^-1 mod 2^30
+  int32_t d[9], e[9], f[9], g[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const int s = 30 * i, w = s >> 5, o = s & 31;
+    const u32 lo = a.l[w], hi = (w + 1 < 8) ? a.l[w + 1] : 0u;
+    const u32 v = o ? __builtin_amdgcn_alignbit(hi, lo, o) : lo;
+    g[i] = (int32_t)(i < 8 ? (v & (u32)M30) : v);
+    f[i] = P30[i]; d[i] = 0; e[i] = i == 0 ? 1 : 0;
+  }
+  int32_t zeta = -1;
+#pragma unroll 1
+  for (int it = 0; it < 20; it++) {
+    // 30 division steps on the low bits: the transition matrix (u v; q r), scaled by 2^30
+    u32 u = 1, v = 0, q = 0, r = 1, ff = (u32)f[0], gg = (u32)g[0];
+#pragma unroll 1
+    for (int i = 0; i < 30; i++) {
+      u32 c1 = (u32)(zeta >> 31);
+      const u32 c2 = 0u - (gg & 1u);
+      const u32 x = (ff ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;
+      gg += x & c2; q += y & c2; r += z & c2;
+      c1 &= c2;
+      zeta = (int32_t)((u32)zeta ^ c1) - 1;
+      ff += gg & c1; u += q & c1; v += r & c1;
+      gg >>= 1; u <<= 1; v <<= 1;
+    }
+    const int32_t tu = (int32_t)u, tv = (int32_t)v, tq = (int32_t)q, tr = (int32_t)r;
+    {  // (d, e) <- (u d + v e, q d + r e) / 2^30 mod p: a multiple of p makes the low 30 bits vanish
+      const int32_t sd = d[8] >> 31, se = e[8] >> 31;
+      int32_t md = (tu & sd) + (tv & se), me = (tq & sd) + (tr & se);
+      long long cd = (long long)tu * d[0] + (long long)tv * e[0], ce = (long long)tq * d[0] + (long long)tr * e[0];
+      md -= (int32_t)((PINV30 * (u32)cd + (u32)md) & (u32)M30);
+      me -= (int32_t)((PINV30 * (u32)ce + (u32)me) & (u32)M30);
+      cd += (long long)P30[0] * md; ce += (long long)P30[0] * me;
+      cd >>= 30; ce >>= 30;
+#pragma unroll
+      for (int i = 1; i < 9; i++) {
+        cd += (long long)tu * d[i] + (long long)tv * e[i] + (long long)P30[i] * md;
+        ce += (long long)tq * d[i] + (long long)tr * e[i] + (long long)P30[i] * me;
+        d[i - 1] = (int32_t)cd & M30; cd >>= 30;
+        e[i - 1] = (int32_t)ce & M30; ce >>= 30;
+      }
+      d[8] = (int32_t)cd; e[8] = (int32_t)ce;
+    }
+    {  // (f, g) <- (u f + v g, q f + r g) / 2^30 (exact)
+      long long cf = (long long)tu * f[0] + (long long)tv * g[0], cg = (long long)tq * f[0] + (long long)tr * g[0];
+      cf >>= 30; cg >>= 30;
+#pragma unroll
+      for (int i = 1; i < 9; i++) {
+        cf += (long long)tu * f[i] + (long long)tv * g[i];
+        cg += (long long)tq * f[i] + (long long)tr * g[i];
+        f[i - 1] = (int32_t)cf & M30; cf >>= 30;
+        g[i - 1] = (int32_t)cg & M30; cg >>= 30;
+      }
+      f[8] = (int32_t)cf; g[8] = (int32_t)cg;
+    }
+  }
+  // d = +-1/x with the sign of f: add p if negative, negate if f < 0, carry, add p again if still negative -> [0, p)
+  {
+    const int32_t neg = f[8] >> 31;
+    int32_t add = d[8] >> 31;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = ((d[i] + (P30[i] & add)) ^ neg) - neg;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { d[i + 1] += d[i] >> 30; d[i] &= M30; }
+    add = d[8] >> 31;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] += P30[i] & add;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { d[i + 1] += d[i] >> 30; d[i] &= M30; }
+  }
+  // nine 30-bit limbs -> eight words
+  Fq out;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int s = 32 * j, k = s / 30, o = s % 30;
+    unsigned long long x = ((unsigned long long)(u32)d[k + 1] << 30) | (u32)d[k];
+    if (k + 2 < 9) x |= (unsigned long long)(u32)d[k + 2] << 60;
+    out.l[j] = (u32)(x >> o);
+  }
+  return out;
+}
+// a^-1 in the 2^256 Montgomery form through the division steps: the integer a R has the inverse a^-1 R^-1; one product by R^3 brings the form back
+static __device__ __noinline__ Fq fq_inv_safegcd(const Fq& a) {
+  Fq r3;
+  const Fq y = fq_inv_safegcd_words(a);
+#pragma unroll
+  for (int i = 0; i < 8; i++) r3.l[i] = FqParams::R3[i];
+  return fp_mul<FqParams>(y, r3);
+}
+// the inverse every affine conversion uses (one per item in the batched scalar-mult and encapsulation kernels)
+KDEV Fq fq_inv(const Fq& a) { return fq_inv_safegcd(a); }
 
 // shorthand for Fq
 KDEV Fq operator+(const Fq& a, const Fq& b) { return fp_add<FqParams>(a, b); }

@@ -109,10 +109,10 @@ KDEV Fq fq_sqr261(const Fq& a) { return pack(u29_sqr(cut(a))); }
 KDEV Fq to261(const Fq& a256) { return pack(u29_mul(cut(a256), u29_const(Conv::C266))); }     // x 2^256 -> x 2^261
 KDEV Fq to256(const Fq& a261) { return pack(u29_mul(cut(a261), u29_const(Q29::R256))); }      // x 2^261 -> x 2^256
 KDEV void canon_words(u32* out8, const Fq& a261) { u29_pack_canonical(out8, u29_mul(cut(a261), u29_const(Conv::PLAIN_ONE))); }   // -> x itself
-// a^(p-2): 254 squarings + 60 products in the lazy limbs (every intermediate < 2p): sliding windows of three bits over the constant exponent
-// with the odd powers a, a^3, a^5, a^7 (the plain square-and-multiply took 110 products). The exponent is a constant: control flow is uniform.
-// Once per pairing (easy part of the final exponentiation).
-static KNOINLINE Fq fq_inv261(const Fq a) {
+// 1 / a in the 2^261 form: the division-step inverse of bn254_field.hip.h (constant time, ~22 K plain instructions) on the integer a 2^261, whose
+// inverse is a^-1 2^-261; one product by 2^783 brings the form back. Once per pairing (easy part of the final exponentiation). The Fermat
+// ladder it replaced (254 squarings + 110 products, then 60 with sliding windows: ~57 K instructions) is kept for the self-test.
+static KNOINLINE Fq fq_inv261_fermat(const Fq a) {
   const U29 a1 = cut(a), a2 = u29_sqr(a1), a3 = u29_mul(a2, a1), a5 = u29_mul(a3, a2), a7 = u29_mul(a5, a2);
   auto bit = [](int i) { return (FQ_PM2[i >> 5] >> (i & 31)) & 1u; };
   U29 acc = u29_const(Q29::ONE);
@@ -128,6 +128,9 @@ static KNOINLINE Fq fq_inv261(const Fq a) {
     i -= l;
   }
   return pack(acc);
+}
+KDEV Fq fq_inv261(const Fq& a) {
+  return pack(u29_mul(cut(fq_inv_safegcd_words(a)), u29_const(Conv::C783)));
 }
 
 // ---- Fq2d: saturated front (same interface as round 1) ---------------------------------------------------------------------------

@@ -113,6 +113,9 @@ __global__ void __launch_bounds__(64) k_selftest_fq2d(u32 seed, u32 iters, unsig
       const Fq want = par ? nine + other.v : nine - other.v;
       bad += !fq_eq(got.v, want);
       bad += !fq_eq(fq_dbl(fq_half(e.v)), e.v);
+      bad += !fq_eq(fq_inv_safegcd(e.v), fq_inv_fermat(e.v));                            // division steps against the Fermat ladder: ends of the range ...
+      bad += !fq_eq(fq_inv_safegcd(k), fq_inv_fermat(k));
+      bad += !fq_eq(fq_inv261(to261(k)), fq_inv261_fermat(to261(k)));              // the 2^261-form wrapper of the pairing tower                                // ... and a random residue (0 -> 0 in both)
       bad += !fq_eq(fq_half(ad.v) + fq_half(ad.v), ad.v);
     }
     bad += !eq(fq2_conj(ad), bn254::fq2_conj(a));
