@@ -164,3 +164,12 @@ def test_jacobian_ladder_formulas_model():
     assert (9.5 * 37.5 + 6.4 * 16) / 169 + 1 < 3.8
     #   madd: H < 2 + 32 = 34, HH < 34^2/169 + 1 = 7.9, H^3 < 34 * 7.9/169 + 1 = 2.6, V < 19 * 7.9/169 + 1 = 1.9, r < 2 + 4 = 6, T < V + 16 = 17.9, 8p - Y1 <= 8
     assert (6 * 17.9 + 8 * 2.6) / 169 + 1 < 1.8
+
+
+def test_division_step_inverse_model():
+    """keaki_amd/csrc/models/model_safegcd.py: the constant-time division-step inverse of bn254_field.hip.h (20 x 30 steps on nine signed 30-bit
+    limbs) statement by statement, with the exactness of every shift asserted, against pow(x, -1, p) on random and boundary values"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("model_safegcd", os.path.join(ROOT, "keaki_amd", "csrc", "models", "model_safegcd.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    assert m.run(n=120, seed=9)
