@@ -897,5 +897,5 @@ def test_pytorch_can_start_after_the_library():
             "import torch\n"
             "x = torch.arange(8, device='cuda'); assert int(x.sum().item()) == 28\n"
             "assert h.selftest_field(4, 2, 2) == 0; h.close(); print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)      # a fresh box pages PyTorch in for a minute or two
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
