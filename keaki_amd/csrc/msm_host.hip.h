@@ -60,10 +60,12 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   }
   ctx->last_c = (int)s.c;
   if ((double)n * s.W >= 4294967295.0) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: n * windows overflows 32-bit positions");
-  // reduce chunk length: the kernel is a serial chain of 2L additions (+ a scalar multiplication by the chunk index) per lane; measured:
-  // 16 is best from 2^19 buckets on (2^20 .. 2^24 points), 8 below (2^18 points: 1.01 vs 1.09 ms)
+  // reduce chunk length: the kernel is a serial chain of 2L additions (+ a scalar multiplication by the chunk index) per lane; measured
+  // (bench_tools/sweep_reduce_l.py, round 3, whole MSM with tables): 2^21 buckets (2^23, 2^24 points): 32 -- 9.42 / 17.69 ms against 9.60 /
+  // 17.88 with 16; 2^19 buckets (2^21, 2^22 points): 8 -- 2.92 / 5.31 ms against 2.99 / 5.41; 16 in between; 8 below
   // (G2, whose additions cost 2.3 x as much: 8 from 2^19 buckets on as well -- 5.10 vs 5.34 ms at 2^20 points)
-  u32 L = plan.max_b >= (1u << 19) ? (sizeof(F) > sizeof(Fq) ? 8 : 16) : (plan.max_b >= 64 ? 8 : plan.max_b);
+  u32 L = sizeof(F) > sizeof(Fq) ? (plan.max_b >= 64 ? 8 : plan.max_b)
+                                 : plan.max_b >= (1u << 21) ? 32 : plan.max_b >= (1u << 20) ? 16 : (plan.max_b >= 64 ? 8 : plan.max_b);
   if (ctx->tune.reduce_l >= 1 && ctx->tune.reduce_l <= 4096 && (u32)ctx->tune.reduce_l <= plan.max_b) L = (u32)ctx->tune.reduce_l;
   const u32 chunks = cdiv(plan.max_b, L);
   ST_TRY(reserve(ctx, ctx->wsums, (size_t)rs.W * sizeof(Xyzz<F>)));
