@@ -206,8 +206,6 @@ void tune_from_env(Tuning& t) {
   if (geti("KEAKI_MSM_C_SHARED", v)) t.msm_c_shared = (int)v;
   if (geti("KEAKI_REDUCE_L", v)) t.reduce_l = (int)v;
   if (geti("KEAKI_PART_SHIFT", v)) t.part_shift = (int)v;
-  if (geti("KEAKI_P1_SUB", v)) t.p1_sub = v > 0 ? (uint32_t)v : 1u;
-  if (geti("KEAKI_P2_SMALL", v)) t.p2_small = v != 0;
   if (geti("KEAKI_ACC_U29", v)) t.acc_u29 = v != 0;
   if (geti("KEAKI_ACC_U29_G2", v)) t.acc_u29_g2 = v != 0;
   if (geti("KEAKI_ACC_NT", v)) t.acc_nt = v != 0;
@@ -298,8 +296,6 @@ keaki_status keaki_hip_ctx_set_option(keaki_hip_ctx* ctx, const char* name, int6
   else if (k == "msm_c_shared") t.msm_c_shared = (int)value;
   else if (k == "reduce_l") t.reduce_l = (int)value;
   else if (k == "part_shift") t.part_shift = (int)value;
-  else if (k == "p1_sub") t.p1_sub = value > 0 ? (uint32_t)value : 1u;
-  else if (k == "p2_small") t.p2_small = value != 0;
   else if (k == "acc_u29") t.acc_u29 = value != 0;
   else if (k == "acc_u29_g2") t.acc_u29_g2 = value != 0;
   else if (k == "acc_nt") t.acc_nt = value != 0;

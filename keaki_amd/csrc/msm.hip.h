@@ -3,10 +3,10 @@
 // Replaces `<E::G1 as VariableBaseMSM>::msm_unchecked(&setup.g1_aff, p)` (reference src/kzg.rs:98;
 // ark-ec 0.4.2 msm_bigint_wnaf). The *result* is the same group element; the schedule is GPU-native:
 //
-//   K1 part_count / K2 scan / K3 part_scatter / K3b part_fine
+//   K1 tile_sort / K2 cell_prefix, bin_scan / K3 chunk_sort
 //                 one lane per scalar: Montgomery -> canonical, signed radix-2^c digits; the n*W
-//                 (bucket, point) pairs are bucket-sorted by an LDS-staged two-pass radix partition
-//                 (no global atomics)                                        [coalesced 32 B/lane]
+//                 (bucket, point) pairs are bucket-sorted by two LDS counting sorts whose outputs are
+//                 contiguous images (no global atomics, no histogram pre-pass) [coalesced 32 B/lane]
 //   K3c cnt_*    counting sort of the buckets by size (largest first) so waves have equal trip counts
 //   K4 accumulate one lane per bucket: gather affine points (64 B rows), XYZZ mixed adds -- the
 //                 dominant kernel: n * windows adds of 8M+2S
@@ -24,6 +24,7 @@
 
 namespace bn254 {
 
+typedef uint16_t u16;
 constexpr u32 DIGIT_NONE = 0xFFFFFFFFu;
 
 // Window plan. The 254 scalar bits are spread over W windows as evenly as possible: the first `k`
@@ -107,54 +108,59 @@ KDEV void msm_for_each_digit(const Fr& k, const MsmShape& s, Emit emit) {
   msm_for_each_digit_canon(v, s, emit);
 }
 
-// ---- two-pass radix partition of the (bucket, point) pairs, every tile sorted in LDS before it is written ----------
-// Global bucket id g = w * B + bucket (shared-bucket mode: g = bucket). Pass 1 partitions all n*W pairs by the coarse key
-// g >> shift: a workgroup stages the <= P1_CAP pairs of its tile of scalars in LDS (160 KB per workgroup on gfx950), counting-
-// sorts them there by coarse bin and writes every (bin, workgroup) cell as one contiguous run. Pass 2 gives each coarse bin
-// to one workgroup: a histogram of the bin's 2^shift fine buckets fixes the per-bucket offsets, then P2_CAP pairs at a time
-// are counting-sorted in LDS and every bucket's share of the chunk is written as one run (16 lanes per bucket). Output: the
-// bucket-ordered index stream plus per-bucket offsets and counts. No global atomics; writes are runs, not single words
-// (scattered 4- and 8-byte stores had cost 3x / 7x write amplification in HBM).
-constexpr u32 P1_THREADS = 1024;
-constexpr u32 P1_CAP = 16384;          // pairs staged per pass-1 tile (8 B each = 128 KB of LDS)
-constexpr u32 PART_MAX_BINS = 2048;    // coarse bins
-constexpr u32 P2_THREADS = 1024;
-constexpr u32 P2_CAP_BIG = 32768;      // payloads staged per pass-2 chunk (4 B each = 128 KB of LDS: one workgroup per CU)
-constexpr u32 P2_CAP_SMALL = 15360;    // 60 KB: two workgroups per CU, their phases overlap
+// ---- bucket sort of the (bucket, point) pairs: two LDS counting sorts, every pair read from HBM once per pass ---------------------
+// Global bucket id g = w * B + bucket (shared-bucket mode: g = bucket) = bin << shift | fine.
+//   pass 1, k_tile_sort   one workgroup per TILE of <= 3072 scalars: Montgomery -> canonical once, the digit walk twice (count,
+//                         place); the tile's <= 36 K pairs are counting-sorted by bin in 144 KB of LDS and leave as ONE contiguous
+//                         image of 4-byte entries (fine | sign | window | index inside the tile) plus the bins' start positions.
+//                         No global histogram, no scan, no second read of the scalars.
+//   k_cell_prefix / k_bin_scan   per bin: running position of its cell in every tile; per-bin totals -> image base, chunk ids
+//   pass 2, k_chunk_sort  one workgroup per BIN: the bin's cells (tile by tile, ~36 entries each) are gathered 32 K pairs at a time,
+//                         counting-sorted by fine bucket in 128 KB of LDS and written as ONE contiguous image per chunk, plus the
+//                         2^shift + 1 bucket offsets of the chunk (u16). The tile a cell came from completes the point index, so
+//                         the entries of pass 1 need only 4 bytes.
+// A bucket's pairs therefore lie in one SEGMENT per chunk of its bin (about six at 2^24 points); the bucket kernels walk them
+// (SegWalker). No global atomics; every global store of both passes is part of a contiguous image.
+constexpr u32 T1_THREADS = 1024;
+constexpr u32 T1_PER = 3;                 // scalars per lane of a pass-1 tile
+constexpr u32 T1_CAP = 36864;             // pairs staged per pass-1 tile (4 B each = 144 KB of LDS)
+constexpr u32 PART_MAX_BINS = 2048;       // coarse bins
+constexpr u32 C2_THREADS = 1024;
+constexpr u32 C2_CAP = 32768;             // pairs per pass-2 chunk (4 B each = 128 KB of LDS)
 constexpr u32 PART_MAX_FINE_SHIFT = 11;
 constexpr u32 PART_MAX_FINE = 1u << PART_MAX_FINE_SHIFT;
+// pass-1 entry: index inside the tile (12 bits: tile <= 3072) | window (7 bits: W <= 85) | sign | fine bucket (<= 11 bits)
+constexpr u32 TE_WPOS = 12, TE_SIGN = 19, TE_FINE = 20;
 
 struct PartShape {
-  u32 nbins;    // coarse bins = ceil(total buckets >> shift)
-  u32 nwg;      // pass-1 workgroups = ceil(ntiles / sub)
-  u32 shift;    // fine bits: a coarse bin covers 2^shift buckets
-  u32 tile;     // scalars per pass-1 tile (<= P1_THREADS, tile * W <= P1_CAP)
-  u32 ntiles;   // ceil(n / tile)
-  u32 sub;      // consecutive tiles per workgroup: the (bin, workgroup) table -- written bin-major, scanned, read back with a stride of nwg words --
-                // shrinks by this factor; the per-tile histograms stay (workgroup-major, contiguous)
+  u32 nbins;       // coarse bins = ceil(total buckets >> shift)
+  u32 shift;       // fine bits: a bin covers 2^shift buckets
+  u32 tile;        // scalars per pass-1 tile (<= T1_THREADS * T1_PER, tile * W <= T1_CAP)
+  u32 ntiles;      // ceil(n / tile)
+  u32 te;          // entry slots per tile image = tile * W
+  u32 seg_stride;  // u16 offsets per chunk: 2^shift + 1, padded to a multiple of 8
 };
-inline bool part_make_shape(size_t n, u32 W, size_t nb, PartShape* ps, int shift_override = -1, u32 sub_max = 8) {
+inline bool part_make_shape(size_t n, u32 W, size_t nb, PartShape* ps, int shift_override = -1) {
   u32 lg = 0;
   while (((size_t)1 << lg) < nb) lg++;
-  int shift = (int)(lg + 1) / 2 + 1;              // fine side one bit wider than the coarse side (4-byte vs 8-byte runs)
+  int shift = (int)(lg + 1) / 2 + 1;
   if (shift_override >= 0) shift = shift_override;
   if (shift > (int)PART_MAX_FINE_SHIFT) shift = PART_MAX_FINE_SHIFT;
   if (shift < 0) shift = 0;
   while ((int)lg - shift > 11 && shift < (int)PART_MAX_FINE_SHIFT) shift++;
   ps->shift = (u32)shift;
   ps->nbins = (u32)((nb + ((size_t)1 << shift) - 1) >> shift);
-  u32 tile = W ? P1_CAP / W : P1_THREADS;
-  if (tile > P1_THREADS) tile = P1_THREADS;
-  if (tile == 0) return false;
+  u32 tile = W ? T1_CAP / W : T1_THREADS * T1_PER;
+  if (tile > T1_THREADS * T1_PER) tile = T1_THREADS * T1_PER;
+  if (tile == 0 || W >= (1u << (TE_SIGN - TE_WPOS))) return false;
   ps->tile = tile;
   ps->ntiles = (u32)((n + tile - 1) / tile);
-  u32 sub = ps->ntiles / 1024u;                   // keep >= 1024 workgroups (4 per CU) when the input allows
-  if (sub > sub_max) sub = sub_max;
-  if (sub < 1) sub = 1;
-  ps->sub = sub;
-  ps->nwg = (ps->ntiles + sub - 1) / sub;
+  ps->te = tile * W;
+  ps->seg_stride = (((1u << shift) + 1u) + 7u) & ~7u;
   return ps->nbins >= 1 && ps->nbins <= PART_MAX_BINS;
 }
+// chunks the second pass can produce for `pairs` pairs in `nbins` bins (every bin's last chunk may be partial)
+inline size_t part_max_chunks(size_t pairs, u32 nbins) { return pairs / C2_CAP + nbins + 1; }
 
 // exclusive scan, in place, of a[0..len) in LDS, len <= 2 * blockDim.x = 2048; returns the total. Whole workgroup calls it.
 __device__ __forceinline__ u32 lds_exclusive_scan(u32* a, u32 len, u32* wsum) {
@@ -175,148 +181,222 @@ __device__ __forceinline__ u32 lds_exclusive_scan(u32* a, u32 len, u32* wsum) {
   return tot;
 }
 
-// pass 1a: counts_t[tile * nbins + bin], one workgroup per tile (contiguous rows; read back, coalesced, by pass 1b) ...
-static __global__ void __launch_bounds__(P1_THREADS) k_part_count(const Fr* __restrict__ scalars, MsmShape s, PartShape ps, u32* __restrict__ counts_t) {
-  __shared__ u32 hist[PART_MAX_BINS];
-  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) hist[b] = 0;
-  __syncthreads();
-  const u32 i = blockIdx.x * ps.tile + threadIdx.x;
-  if (threadIdx.x < ps.tile && i < s.n) {
-    msm_for_each_digit(scalars[i], s, [&](u32 w, u32 code) {
-      u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
-      atomicAdd(&hist[g >> ps.shift], 1u);
-    });
-  }
-  __syncthreads();
-  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) counts_t[(size_t)blockIdx.x * ps.nbins + b] = hist[b];
-}
-// ... and counts[bin * nwg + wg] (the order of the global scan): one cell per bin and pass-1b WORKGROUP = ps.sub consecutive tiles
-static __global__ void __launch_bounds__(256) k_part_supercount(const u32* __restrict__ counts_t, PartShape ps, u32* __restrict__ counts) {
-  const u32 wg = blockIdx.y;
-  const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= ps.nbins) return;
-  u32 tot = 0;
-  for (u32 t = 0; t < ps.sub; t++) {
-    const u32 tile = wg * ps.sub + t;
-    if (tile < ps.ntiles) tot += counts_t[(size_t)tile * ps.nbins + b];
-  }
-  counts[(size_t)b * ps.nwg + wg] = tot;
-}
-// pass 1b: entries[pos] = bucket id g << 32 | sign << 31 | point (table row) index
-static __global__ void __launch_bounds__(P1_THREADS) k_part_scatter(const Fr* __restrict__ scalars, MsmShape s, PartShape ps,
-                                                                    const u32* __restrict__ offsets, const u32* __restrict__ counts_t,
-                                                                    u64* __restrict__ entries) {
-  __shared__ u64 ent[P1_CAP];
+// pass 1: tiles[tile * te + q], q < m = the tile's pairs ordered by bin; tstart[tile * (nbins + 1) + b] = first position of bin b, [nbins] = m
+static __global__ void __launch_bounds__(T1_THREADS) k_tile_sort(const Fr* __restrict__ scalars, MsmShape s, PartShape ps, u32* __restrict__ tiles,
+                                                                 u16* __restrict__ tstart) {
+  __shared__ u32 ent[T1_CAP];
   __shared__ u32 cur[PART_MAX_BINS];
-  __shared__ u32 goff[PART_MAX_BINS];
-  __shared__ u32 wsum[P1_THREADS / 64];
-  for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) goff[b] = offsets[(size_t)b * ps.nwg + blockIdx.x];
-  for (u32 t = 0; t < ps.sub; t++) {
-    const u32 tile = blockIdx.x * ps.sub + t;
-    if (tile >= ps.ntiles) break;
-    // the tile's histogram was made by pass 1a: no second digit walk for it
-    for (u32 b = threadIdx.x; b < ps.nbins; b += P1_THREADS) cur[b] = counts_t[(size_t)tile * ps.nbins + b];
-    const u32 i = tile * ps.tile + threadIdx.x;
-    const bool act = threadIdx.x < ps.tile && i < s.n;
-    Fr k;
-    if (act) k = scalars[i];
-    const u32 m = lds_exclusive_scan(cur, ps.nbins, wsum);     // cur[b] = start of bin b inside the tile
-    if (act) {
-      msm_for_each_digit(k, s, [&](u32 w, u32 code) {
-        u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
-        u32 pos = atomicAdd(&cur[g >> ps.shift], 1u);           // afterwards cur[b] = end of bin b = start of bin b + 1
-        ent[pos] = ((u64)g << 32) | (code & 0x80000000u) | (i + w * s.stride);
+  __shared__ u32 wsum[T1_THREADS / 64];
+  const u32 tile = blockIdx.x, t = threadIdx.x;
+  for (u32 b = t; b < ps.nbins; b += T1_THREADS) cur[b] = 0;
+  __syncthreads();
+  u32 canon[T1_PER][8];
+  bool act[T1_PER];
+  const u32 mask = (1u << ps.shift) - 1u;
+#pragma unroll
+  for (u32 p = 0; p < T1_PER; p++) {
+    const u32 li = p * T1_THREADS + t;
+    const size_t i = (size_t)tile * ps.tile + li;
+    act[p] = li < ps.tile && i < s.n;
+    if (act[p]) {
+      const Fr k = scalars[i];
+      fp_from_mont<FrParams>(canon[p], k);
+      msm_for_each_digit_canon(canon[p], s, [&](u32 w, u32 code) {
+        const u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
+        atomicAdd(&cur[g >> ps.shift], 1u);
       });
     }
-    __syncthreads();
-    for (u32 q = threadIdx.x; q < m; q += P1_THREADS) {
-      u64 v = ent[q];
-      u32 b = (u32)(v >> 32) >> ps.shift;
-      u32 st = b ? cur[b - 1] : 0u;
-      entries[goff[b] + (q - st)] = v;
-    }
-    __syncthreads();
-    if (t + 1 < ps.sub) {                                       // the next tile of this workgroup continues every bin's run
-      u32 add0 = 0, add1 = 0;
-      const u32 b0 = threadIdx.x, b1 = threadIdx.x + P1_THREADS;
-      if (b0 < ps.nbins) add0 = cur[b0] - (b0 ? cur[b0 - 1] : 0u);
-      if (b1 < ps.nbins) add1 = cur[b1] - cur[b1 - 1];
-      __syncthreads();
-      if (b0 < ps.nbins) goff[b0] += add0;
-      if (b1 < ps.nbins) goff[b1] += add1;
-      __syncthreads();
+  }
+  const u32 m = lds_exclusive_scan(cur, ps.nbins, wsum);       // cur[b] = start of bin b inside the tile
+  u16* ts = tstart + (size_t)tile * (ps.nbins + 1);
+  for (u32 b = t; b < ps.nbins; b += T1_THREADS) ts[b] = (u16)cur[b];
+  if (t == 0) ts[ps.nbins] = (u16)m;
+  __syncthreads();
+#pragma unroll
+  for (u32 p = 0; p < T1_PER; p++) {
+    if (act[p]) {
+      const u32 li = p * T1_THREADS + t;
+      msm_for_each_digit_canon(canon[p], s, [&](u32 w, u32 code) {
+        const u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
+        const u32 pos = atomicAdd(&cur[g >> ps.shift], 1u);
+        ent[pos] = ((g & mask) << TE_FINE) | ((code >> 31) << TE_SIGN) | (w << TE_WPOS) | li;
+      });
     }
   }
+  __syncthreads();
+  u32* dst = tiles + (size_t)tile * ps.te;
+  for (u32 q = t; q < m; q += T1_THREADS) dst[q] = ent[q];
 }
-// grand total of entries = exclusive offset of the last (bin, workgroup) cell + its count
-static __global__ void k_part_total(const u32* __restrict__ counts, const u32* __restrict__ offsets, u32 ncounts, u32* __restrict__ total) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *total = offsets[ncounts - 1] + counts[ncounts - 1];
-}
-// pass 2: one workgroup per coarse bin. bin b covers global buckets [b << shift, (b + 1) << shift).
-template <u32 P2_CAP>
-static __global__ void __launch_bounds__(P2_THREADS) k_part_fine(const u64* __restrict__ entries, const u32* __restrict__ offsets, PartShape ps,
-                                                                 const u32* __restrict__ total_ptr, u32 nbuckets_total, u32* __restrict__ bucket_offsets,
-                                                                 u32* __restrict__ bucket_counts, u32* __restrict__ sorted) {
-  __shared__ u32 pay[P2_CAP];
-  __shared__ u32 hist[PART_MAX_FINE];
-  __shared__ u32 cursor[PART_MAX_FINE];
-  __shared__ u32 wsum[P2_THREADS / 64];
-  const u32 bin = blockIdx.x, nf = 1u << ps.shift, mask = nf - 1u, t = threadIdx.x;
-  const u32 lo = offsets[(size_t)bin * ps.nwg];
-  const u32 hi = (bin + 1 < ps.nbins) ? offsets[(size_t)(bin + 1) * ps.nwg] : *total_ptr;
-  const u32 m = hi - lo;
-  // whole-bin histogram -> per-bucket counts and offsets
-  for (u32 f = t; f < nf; f += P2_THREADS) hist[f] = 0;
-  __syncthreads();
-  for (u32 q = t; q < m; q += P2_THREADS) atomicAdd(&hist[(u32)(entries[lo + q] >> 32) & mask], 1u);
-  __syncthreads();
-  const u32 c0 = 2 * t < nf ? hist[2 * t] : 0u, c1 = 2 * t + 1 < nf ? hist[2 * t + 1] : 0u;
-  lds_exclusive_scan(hist, nf, wsum);
-  {
-    const u32 g0 = (bin << ps.shift) + 2 * t;
-    if (2 * t < nf) { cursor[2 * t] = hist[2 * t]; if (g0 < nbuckets_total) { bucket_offsets[g0] = lo + hist[2 * t]; bucket_counts[g0] = c0; } }
-    if (2 * t + 1 < nf) { cursor[2 * t + 1] = hist[2 * t + 1]; if (g0 + 1 < nbuckets_total) { bucket_offsets[g0 + 1] = lo + hist[2 * t + 1]; bucket_counts[g0 + 1] = c1; } }
-  }
-  __syncthreads();
-  constexpr u32 PER = P2_CAP / P2_THREADS;
-  for (u32 cb = 0; cb < m; cb += P2_CAP) {
-    const u32 mc = m - cb < P2_CAP ? m - cb : P2_CAP;
-    const u64* src = entries + lo + cb;
-    u64 e[PER];                                     // the chunk stays in registers between the two LDS phases
+
+// per bin: where its cell of every tile begins in the bin's own order (tile after tile), and how many pairs the bin holds
+static __global__ void __launch_bounds__(1024) k_cell_prefix(const u16* __restrict__ tstart, PartShape ps, uint2* __restrict__ cellmeta,
+                                                             u32* __restrict__ bin_total) {
+  __shared__ u32 a[2048];
+  __shared__ u32 wsum[16];
+  const u32 b = blockIdx.x, t = threadIdx.x;
+  u32 carry = 0;
+  for (u32 base = 0; base < ps.ntiles; base += 2048) {
+    u32 st[2], ln[2];
 #pragma unroll
-    for (u32 k = 0; k < PER; k++) { u32 q = k * P2_THREADS + t; e[k] = q < mc ? src[q] : 0ull; }
-    if (m > P2_CAP) {                               // a single chunk reuses the whole-bin scan that is already in hist
-      for (u32 f = t; f < nf; f += P2_THREADS) hist[f] = 0;
-      __syncthreads();
-#pragma unroll
-      for (u32 k = 0; k < PER; k++) if (k * P2_THREADS + t < mc) atomicAdd(&hist[(u32)(e[k] >> 32) & mask], 1u);
-      lds_exclusive_scan(hist, nf, wsum);
-    }
-#pragma unroll
-    for (u32 k = 0; k < PER; k++) {
-      if (k * P2_THREADS + t < mc) {
-        u32 pos = atomicAdd(&hist[(u32)(e[k] >> 32) & mask], 1u);   // afterwards hist[f] = end of bucket f inside the chunk
-        pay[pos] = (u32)e[k];
+    for (u32 k = 0; k < 2; k++) {
+      const u32 tile = base + 2 * t + k;
+      st[k] = 0; ln[k] = 0;
+      if (tile < ps.ntiles) {
+        const u16* row = tstart + (size_t)tile * (ps.nbins + 1) + b;
+        st[k] = row[0];
+        ln[k] = (u32)row[1] - st[k];
       }
+      a[2 * t + k] = ln[k];
     }
-    __syncthreads();
-    if (m <= P2_CAP) {                              // the chunk is the bin: the LDS image is the output
-      for (u32 q = t; q < mc; q += P2_THREADS) sorted[lo + q] = pay[q];
-      return;
+    const u32 tot = lds_exclusive_scan(a, 2048, wsum);
+#pragma unroll
+    for (u32 k = 0; k < 2; k++) {
+      const u32 tile = base + 2 * t + k;
+      if (tile < ps.ntiles) cellmeta[(size_t)b * ps.ntiles + tile] = make_uint2(carry + a[2 * t + k], st[k] | (ln[k] << 16));
     }
-    for (u32 f = t >> 4; f < nf; f += P2_THREADS / 16) {       // 16 lanes per bucket: one run per (bucket, chunk)
-      u32 st = f ? hist[f - 1] : 0u, len = hist[f] - st, gb = lo + cursor[f];
-      for (u32 j = t & 15; j < len; j += 16) sorted[gb + j] = pay[st + j];
-    }
+    carry += tot;
     __syncthreads();
-    for (u32 f = t; f < nf; f += P2_THREADS) cursor[f] += hist[f] - (f ? hist[f - 1] : 0u);
-    __syncthreads();
+  }
+  if (t == 0) bin_total[b] = carry;
+}
+// where a bin's chunk images begin in `sorted`, and which chunk ids (rows of the offset table) it owns
+struct BinMeta {
+  u32 img_base, chunk_first, nch, total;
+};
+static __global__ void __launch_bounds__(1024) k_bin_scan(const u32* __restrict__ bin_total, u32 nbins, BinMeta* __restrict__ bins) {
+  __shared__ u32 a[2048];
+  __shared__ u32 c[2048];
+  __shared__ u32 wsum[16];
+  const u32 t = threadIdx.x;
+  u32 tt[2];
+#pragma unroll
+  for (u32 k = 0; k < 2; k++) {
+    const u32 b = 2 * t + k;
+    tt[k] = b < nbins ? bin_total[b] : 0u;
+    a[b] = tt[k];
+    c[b] = (tt[k] + C2_CAP - 1) / C2_CAP;
+  }
+  lds_exclusive_scan(a, 2048, wsum);
+  lds_exclusive_scan(c, 2048, wsum);
+#pragma unroll
+  for (u32 k = 0; k < 2; k++) {
+    const u32 b = 2 * t + k;
+    if (b < nbins) bins[b] = {a[b], c[b], (tt[k] + C2_CAP - 1) / C2_CAP, tt[k]};
   }
 }
 
-// ---- exclusive scan over `len` counters, restarted at every multiple of `seg` (one window) ----
-// pass 1: per-block sums (block handles SCAN_ELEMS contiguous elements)
-constexpr u32 SCAN_THREADS = 256, SCAN_PER_THREAD = 8, SCAN_ELEMS = SCAN_THREADS * SCAN_PER_THREAD;
+// pass 2: one workgroup per bin
+static __global__ void __launch_bounds__(C2_THREADS) k_chunk_sort(const u32* __restrict__ tiles, const uint2* __restrict__ cellmeta,
+                                                                  const BinMeta* __restrict__ bins, MsmShape s, PartShape ps, u32 nbuckets_total,
+                                                                  u32* __restrict__ sorted, u16* __restrict__ segoff, u32* __restrict__ bucket_counts) {
+  __shared__ u32 pay[C2_CAP];
+  __shared__ u32 hist[PART_MAX_FINE];
+  __shared__ u32 tot[PART_MAX_FINE];
+  __shared__ u32 wsum[C2_THREADS / 64];
+  __shared__ u32 sh_next;
+  const u32 b = blockIdx.x, t = threadIdx.x, nf = 1u << ps.shift;
+  const u32 grp = t >> 4, l16 = t & 15;
+  const BinMeta bm = bins[b];
+  const uint2* cm = cellmeta + (size_t)b * ps.ntiles;
+  for (u32 f = t; f < nf; f += C2_THREADS) tot[f] = 0;
+  u32 c0 = 0;                                               // first cell that reaches into the chunk
+  for (u32 k = 0; k < bm.nch; k++) {
+    const u32 lo = k * C2_CAP, hi = bm.total - lo < C2_CAP ? bm.total : lo + C2_CAP;
+    for (u32 f = t; f < nf; f += C2_THREADS) hist[f] = 0;
+    if (t == 0) sh_next = ps.ntiles;
+    __syncthreads();
+    // sweep 1: per-bucket counts of the chunk (16 lanes per cell)
+    for (u32 c = c0 + grp; c < ps.ntiles; c += C2_THREADS / 16) {
+      const uint2 m = cm[c];
+      const u32 len = m.y >> 16;
+      const bool past = m.x + len > hi;                           // the first cell that reaches past the chunk opens the next one
+      if (past && l16 == 0) atomicMin(&sh_next, c);
+      if (m.x > hi || (past && m.x == hi)) break;                 // (an EMPTY cell that sits exactly at the chunk's end is stepped over)
+      const u32 j0 = m.x < lo ? lo - m.x : 0u, j1 = hi - m.x < len ? hi - m.x : len;
+      const u32* src = tiles + (size_t)c * ps.te + (m.y & 0xFFFFu);
+      for (u32 j = j0 + l16; j < j1; j += 16) atomicAdd(&hist[src[j] >> TE_FINE], 1u);
+    }
+    __syncthreads();
+    const u32 c_next = sh_next;
+    for (u32 f = t; f < nf; f += C2_THREADS) tot[f] += hist[f];
+    lds_exclusive_scan(hist, nf, wsum);                     // hist[f] = first position of bucket f inside the chunk
+    u16* so = segoff + (size_t)(bm.chunk_first + k) * ps.seg_stride;
+    for (u32 f = t; f < nf; f += C2_THREADS) so[f] = (u16)hist[f];
+    if (t == 0) so[nf] = (u16)(hi - lo);
+    __syncthreads();
+    // sweep 2: the same walk (the chunk's cells are in L2 now); the tile of a cell completes the point index
+    for (u32 c = c0 + grp; c < ps.ntiles; c += C2_THREADS / 16) {
+      const uint2 m = cm[c];
+      const u32 len = m.y >> 16;
+      if (m.x > hi || (m.x == hi && len)) break;
+      const u32 j0 = m.x < lo ? lo - m.x : 0u, j1 = hi - m.x < len ? hi - m.x : len;
+      const u32* src = tiles + (size_t)c * ps.te + (m.y & 0xFFFFu);
+      const u32 ibase = c * ps.tile;
+      for (u32 j = j0 + l16; j < j1; j += 16) {
+        const u32 e = src[j];
+        const u32 pos = atomicAdd(&hist[e >> TE_FINE], 1u);
+        pay[pos] = (((e >> TE_SIGN) & 1u) << 31) | (ibase + (e & ((1u << TE_WPOS) - 1u)) + ((e >> TE_WPOS) & ((1u << (TE_SIGN - TE_WPOS)) - 1u)) * s.stride);
+      }
+    }
+    __syncthreads();
+    u32* dst = sorted + bm.img_base + lo;
+    for (u32 q = t; q < hi - lo; q += C2_THREADS) dst[q] = pay[q];
+    c0 = c_next;
+  }
+  __syncthreads();
+  for (u32 f = t; f < nf; f += C2_THREADS) {
+    const u32 g = (b << ps.shift) + f;
+    if (g < nbuckets_total) bucket_counts[g] = tot[f];
+  }
+}
+
+// ---- the bucket kernels' view of the sorted pairs ----------------------------------------------------------------------------------
+// Bucket t = bin << shift | f owns, in chunk c of its bin, the entries [off[f], off[f + 1]) of the image at img_base + c * C2_CAP, where
+// off = segoff + (chunk_first + c) * seg_stride. The walker keeps the NEXT segment's pair of offsets loaded one step ahead: its loads
+// travel with the entry load of the current segment, so a bucket's walk adds no dependent memory access to the loop.
+struct SortView {
+  const u32* sorted;
+  const BinMeta* bins;
+  const u16* segoff;
+  u32 shift, seg_stride;
+};
+struct SegWalker {
+  u32 pos, left;        // next entry of the current segment, entries left in it
+  u32 nx_s, nx_e;       // offsets of the next segment (prefetched)
+  u32 c, nch;           // chunks consumed (incl. the prefetched one), chunks of the bin
+  u32 img_base, o;      // image base of the bin in `sorted`; index of this bucket's offset pair of chunk 0 in `segoff`
+};
+KDEV void seg_init(SegWalker& w, const SortView& v, u32 t) {
+  const BinMeta bm = v.bins[t >> v.shift];
+  w.img_base = bm.img_base;
+  w.o = bm.chunk_first * v.seg_stride + (t & ((1u << v.shift) - 1u));
+  w.nch = bm.nch;
+  w.c = 0; w.left = 0; w.pos = 0; w.nx_s = 0; w.nx_e = 0;
+  if (w.nch) { w.nx_s = v.segoff[w.o]; w.nx_e = v.segoff[w.o + 1]; }
+}
+// next entry of the bucket; the caller asks for exactly counts[t] of them
+KDEV u32 seg_next(SegWalker& w, const SortView& v) {
+  if (w.left == 0) {
+    u32 s, e, ci;
+    do {
+      s = w.nx_s; e = w.nx_e; ci = w.c;
+      w.c++;
+      if (w.c < w.nch) {
+        const u32 oo = w.o + w.c * v.seg_stride;
+        w.nx_s = v.segoff[oo]; w.nx_e = v.segoff[oo + 1];
+      } else {
+        w.nx_s = 0; w.nx_e = 0;
+      }
+    } while (e == s && w.c <= w.nch);
+    w.pos = w.img_base + ci * C2_CAP + s;
+    w.left = e - s;
+  }
+  w.left--;
+  return v.sorted[w.pos++];
+}
+
+// block-wide exclusive scan of one value per lane, 256 lanes
+constexpr u32 SCAN_THREADS = 256;
 __device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32* total) {
   __shared__ u32 wsum[SCAN_THREADS / 64];
   u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -338,55 +418,6 @@ __device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32* total) {
   __syncthreads();
   *total = tot;
   return base + x - v;
-}
-static __global__ void __launch_bounds__(SCAN_THREADS) k_scan_block_sums(const u32* __restrict__ in, u32 len, u32* __restrict__ block_sums) {
-  u32 base = blockIdx.x * SCAN_ELEMS + threadIdx.x * SCAN_PER_THREAD;
-  u32 s = 0;
-#pragma unroll
-  for (u32 k = 0; k < SCAN_PER_THREAD; k++) s += (base + k < len) ? in[base + k] : 0u;
-  u32 tot;
-  block_exclusive_scan(s, &tot);
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
-}
-// pass 2: one block scans the block sums; restart at segment boundaries (seg is a multiple of SCAN_ELEMS
-// or the whole array is one block)
-static __global__ void __launch_bounds__(SCAN_THREADS) k_scan_top(u32* __restrict__ block_sums, u32 nblocks, u32 blocks_per_seg) {
-  // serial over chunks of SCAN_THREADS blocks; nblocks is small (<= len / 2048)
-  __shared__ u32 carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (u32 start = 0; start < nblocks; start += SCAN_THREADS) {
-    u32 idx = start + threadIdx.x;
-    u32 v = idx < nblocks ? block_sums[idx] : 0u;
-    u32 tot;
-    u32 ex = block_exclusive_scan(v, &tot);
-    u32 c0 = carry;
-    if (idx < nblocks) block_sums[idx] = ex + c0;
-    __syncthreads();
-    if (threadIdx.x == 0) carry = c0 + tot;
-    __syncthreads();
-  }
-  (void)blocks_per_seg;
-}
-// pass 3: final offsets. offsets are GLOBAL positions into the sorted array (no per-window restart:
-// the sorted array is one dense stream, windows follow each other).
-static __global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(const u32* __restrict__ in, u32 len, const u32* __restrict__ block_sums,
-                                                             u32* __restrict__ out) {
-  u32 base = blockIdx.x * SCAN_ELEMS + threadIdx.x * SCAN_PER_THREAD;
-  u32 v[SCAN_PER_THREAD];
-  u32 s = 0;
-#pragma unroll
-  for (u32 k = 0; k < SCAN_PER_THREAD; k++) {
-    v[k] = (base + k < len) ? in[base + k] : 0u;
-    s += v[k];
-  }
-  u32 tot;
-  u32 ex = block_exclusive_scan(s, &tot) + block_sums[blockIdx.x];
-#pragma unroll
-  for (u32 k = 0; k < SCAN_PER_THREAD; k++) {
-    if (base + k < len) out[base + k] = ex;
-    ex += v[k];
-  }
 }
 
 
@@ -479,28 +510,57 @@ static __global__ void __launch_bounds__(256) k_cnt_scatter(const u32* __restric
 // the slices of each bucket (one wave per bucket), and k_msm_accumulate* skip those buckets. Uniformly random scalars never trigger
 // it (buckets hold tens to hundreds of points): the grids then exit after one load.
 constexpr u32 HEAVY_GRID = 2048, HEAVY_COMBINE_GRID = 512;
+// A slice is the range [lo, hi) of a bucket's pairs in the order of its segments. The workgroup finds the segments that meet the slice
+// 256 chunks at a time (their lengths scanned across the lanes), then walks each of them with all lanes.
 template <class F>
-__global__ void __launch_bounds__(256) k_msm_heavy(const Aff<F>* __restrict__ points, const u32* __restrict__ sorted, const u32* __restrict__ offsets,
-                                                   const u32* __restrict__ counts, const HeavyList* __restrict__ hv, u32 hv_slice_cap,
-                                                   const u32* __restrict__ hv_bucket, const u32* __restrict__ hv_first, const u32* __restrict__ hv_owner,
-                                                   Xyzz<F>* __restrict__ slices) {
+__global__ void __launch_bounds__(256) k_msm_heavy(const Aff<F>* __restrict__ points, SortView v, const u32* __restrict__ counts,
+                                                   const HeavyList* __restrict__ hv, u32 hv_slice_cap, const u32* __restrict__ hv_bucket,
+                                                   const u32* __restrict__ hv_first, const u32* __restrict__ hv_owner, Xyzz<F>* __restrict__ slices) {
   __shared__ Xyzz<F> sh[256];
+  __shared__ u32 seg_pos[256], seg_n[256];
+  __shared__ u32 nlist;
   const u32 total = min(hv->nslices, hv_slice_cap);
   for (u32 sid = blockIdx.x; sid < total; sid += gridDim.x) {        // block-uniform
     const u32 slot = hv_owner[sid];
     const u32 t = hv_bucket[slot];
-    const u32 cnt = counts[t], start = offsets[t];
+    const u32 cnt = counts[t];
     const u32 lo = (sid - hv_first[slot]) * HEAVY_SLICE, hi = min(cnt, lo + HEAVY_SLICE);
+    const BinMeta bm = v.bins[t >> v.shift];
+    const u32 o = bm.chunk_first * v.seg_stride + (t & ((1u << v.shift) - 1u));
     Xyzz<F> acc = xyzz_inf<F>();
-    for (u32 k = lo + threadIdx.x; k < hi; k += 256) {
-      u32 e = sorted[start + k];
-      Aff<F> p = points[e & 0x7FFFFFFFu];
-      acc = xyzz_add_mixed(acc, aff_cneg(p, (e >> 31) != 0));
+    u32 vbase = 0;                                                    // pairs of the bucket in the chunks before cb
+    for (u32 cb = 0; cb < bm.nch && vbase < hi; cb += 256) {
+      const u32 c = cb + threadIdx.x;
+      u32 s = 0, e = 0;
+      if (c < bm.nch) { s = v.segoff[o + c * v.seg_stride]; e = v.segoff[o + c * v.seg_stride + 1]; }
+      const u32 len = e - s;
+      u32 tot;
+      const u32 v0 = vbase + block_exclusive_scan(len, &tot), v1 = v0 + len;
+      if (threadIdx.x == 0) nlist = 0;
+      __syncthreads();
+      if (len && v1 > lo && v0 < hi) {
+        const u32 a0 = v0 > lo ? v0 : lo, a1 = v1 < hi ? v1 : hi;
+        const u32 k = atomicAdd(&nlist, 1u);
+        seg_pos[k] = bm.img_base + c * C2_CAP + s + (a0 - v0);
+        seg_n[k] = a1 - a0;
+      }
+      __syncthreads();
+      const u32 nl = nlist;
+      for (u32 j = 0; j < nl; j++) {
+        const u32 p0 = seg_pos[j], nn = seg_n[j];
+        for (u32 q = threadIdx.x; q < nn; q += 256) {
+          u32 en = v.sorted[p0 + q];
+          Aff<F> p = points[en & 0x7FFFFFFFu];
+          acc = xyzz_add_mixed(acc, aff_cneg(p, (en >> 31) != 0));
+        }
+      }
+      __syncthreads();
+      vbase += tot;
     }
     sh[threadIdx.x] = acc;
     __syncthreads();
-    for (u32 o = 128; o > 0; o >>= 1) {
-      if (threadIdx.x < o) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], sh[threadIdx.x + o]);
+    for (u32 o2 = 128; o2 > 0; o2 >>= 1) {
+      if (threadIdx.x < o2) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], sh[threadIdx.x + o2]);
       __syncthreads();
     }
     if (threadIdx.x == 0) slices[sid] = sh[0];
@@ -534,17 +594,18 @@ KDEV bool msm_bucket_is_heavy(u32 cnt) { return cnt >= HEAVY_MIN; }
 
 // ---- K4: bucket accumulation (dominant kernel) ----------------------------------------------------
 template <class F>
-__global__ void __launch_bounds__(256) k_msm_accumulate(const Aff<F>* __restrict__ points, const u32* __restrict__ sorted,
-                                                        const u32* __restrict__ offsets, const u32* __restrict__ counts,
+__global__ void __launch_bounds__(256) k_msm_accumulate(const Aff<F>* __restrict__ points, SortView v, const u32* __restrict__ counts,
                                                         const u32* __restrict__ perm, u32 nbuckets_total, Xyzz<F>* __restrict__ buckets) {
   u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= nbuckets_total) return;
   u32 t = perm[lane];
-  u32 start = offsets[t], cnt = counts[t];
+  u32 cnt = counts[t];
   if (msm_bucket_is_heavy(cnt)) return;   // done by k_msm_heavy / k_msm_heavy_combine
+  SegWalker sw;
+  seg_init(sw, v, t);
   Xyzz<F> acc = xyzz_inf<F>();
   for (u32 k = 0; k < cnt; k++) {
-    u32 e = sorted[start + k];
+    u32 e = seg_next(sw, v);
     Aff<F> p = points[e & 0x7FFFFFFFu];
     acc = xyzz_add_mixed(acc, aff_cneg(p, (e >> 31) != 0));
   }
@@ -575,18 +636,20 @@ KDEV Aff<Fq> msm_load_row(const Aff<Fq>* __restrict__ p) {
   }
 }
 template <int NT>
-static __global__ void __launch_bounds__(256) k_msm_accumulate_g1_u29(const Aff<Fq>* __restrict__ points, const u32* __restrict__ sorted,
-                                                                      const u32* __restrict__ offsets, const u32* __restrict__ counts,
-                                                                      const u32* __restrict__ perm, u32 nbuckets_total, Xyzz<Fq>* __restrict__ buckets) {
+static __global__ void __launch_bounds__(256) k_msm_accumulate_g1_u29(const Aff<Fq>* __restrict__ points, SortView v,
+                                                                      const u32* __restrict__ counts, const u32* __restrict__ perm,
+                                                                      u32 nbuckets_total, Xyzz<Fq>* __restrict__ buckets) {
   u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= nbuckets_total) return;
   u32 t = perm[lane];
-  u32 start = offsets[t], cnt = counts[t];
+  u32 cnt = counts[t];
   if (msm_bucket_is_heavy(cnt)) return;   // done by k_msm_heavy / k_msm_heavy_combine
+  SegWalker sw;
+  seg_init(sw, v, t);
   U29 X1, Y1, ZZ, ZZZ;
   bool empty = true;
   for (u32 k = 0; k < cnt; k++) {
-    u32 e = sorted[start + k];
+    u32 e = seg_next(sw, v);
     Aff<Fq> q = msm_load_row<NT>(points + (e & 0x7FFFFFFFu));
     if (aff_is_inf(q)) continue;
     q.y = f_cneg(q.y, (e >> 31) != 0);
@@ -633,17 +696,19 @@ static __global__ void __launch_bounds__(256) k_msm_accumulate_g1_u29(const Aff<
 
 // G2 bucket accumulation in the lazy limbs (xyzz29_g2.hip.h): same schedule, ~5,600 instead of ~9,000 instructions per mixed addition.
 // Buckets are written back saturated and canonical (the tail keeps the generic arithmetic).
-static __global__ void __launch_bounds__(256) k_msm_accumulate_g2_u29(const Aff<Fq2>* __restrict__ points, const u32* __restrict__ sorted,
-                                                                      const u32* __restrict__ offsets, const u32* __restrict__ counts,
-                                                                      const u32* __restrict__ perm, u32 nbuckets_total, Xyzz<Fq2>* __restrict__ buckets) {
+static __global__ void __launch_bounds__(256) k_msm_accumulate_g2_u29(const Aff<Fq2>* __restrict__ points, SortView v,
+                                                                      const u32* __restrict__ counts, const u32* __restrict__ perm,
+                                                                      u32 nbuckets_total, Xyzz<Fq2>* __restrict__ buckets) {
   u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= nbuckets_total) return;
   u32 t = perm[lane];
-  u32 start = offsets[t], cnt = counts[t];
+  u32 cnt = counts[t];
   if (msm_bucket_is_heavy(cnt)) return;   // done by k_msm_heavy / k_msm_heavy_combine
+  SegWalker sw;
+  seg_init(sw, v, t);
   X29G2 acc = x29g2_inf();
   for (u32 k = 0; k < cnt; k++) {
-    u32 e = sorted[start + k];
+    u32 e = seg_next(sw, v);
     Aff<Fq2> q = points[e & 0x7FFFFFFFu];
     x29g2_add_mixed(acc, aff_cneg(q, (e >> 31) != 0));
   }

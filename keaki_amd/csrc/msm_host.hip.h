@@ -25,17 +25,6 @@ inline int choose_window(size_t n, int forced = 0) {
   return bc;
 }
 
-// exclusive scan of `len` u32 counters in[] -> out[] (global positions)
-inline keaki_status device_scan(keaki_hip_ctx* ctx, const u32* in, u32 len, u32* out) {
-  u32 nblocks = cdiv(len, SCAN_ELEMS);
-  ST_TRY(reserve(ctx, ctx->bsums, (size_t)nblocks * 4));
-  u32* bs = (u32*)ctx->bsums.p;
-  hipLaunchKernelGGL(k_scan_block_sums, dim3(nblocks), dim3(SCAN_THREADS), 0, ctx->stream, in, len, bs);
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, bs, nblocks, 0u);
-  hipLaunchKernelGGL(k_scan_apply, dim3(nblocks), dim3(SCAN_THREADS), 0, ctx->stream, in, len, (const u32*)bs, out);
-  return launch_check(ctx, "scan");
-}
-
 // d_table != nullptr: precomputed path (tables built by msm_build_tables with window target c_table for N = srs_len points)
 template <class F>
 keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len, const void* d_scalars, size_t n, void* d_out_jac,
@@ -78,38 +67,38 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
     return launch_check(ctx, "msm_final");
   }
   PartShape ps;
-  const int shift_override = ctx->tune.part_shift;
-  const u32 sub_max = ctx->tune.p1_sub;
-  if (!part_make_shape(n, s.W, nb, &ps, shift_override, sub_max ? sub_max : 1u))
+  if (!part_make_shape(n, s.W, nb, &ps, ctx->tune.part_shift))
     return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: %zu buckets / %u windows exceed the partition's LDS budget (window too large)", nb, s.W);
-  const size_t ncounts = (size_t)ps.nbins * ps.nwg;
-  if (ncounts >= 4294967295ull) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: partition table too large");
-  ST_TRY(reserve(ctx, ctx->digits, n * s.W * 8));      // coarse-partitioned (fine | sign | index) entries
-  ST_TRY(reserve(ctx, ctx->sorted, n * s.W * 4));
-  ST_TRY(reserve(ctx, ctx->hist, nb * 4));             // per-bucket counts
-  ST_TRY(reserve(ctx, ctx->offsets, nb * 4));          // per-bucket start offsets
-  ST_TRY(reserve(ctx, ctx->cursor, (ncounts * 2 + 4 + (size_t)ps.nbins * ps.ntiles) * 4));  // [counts | exclusive scan | total] of the (bin, workgroup) table | per-tile counts, tile-major
+  const size_t pairs = n * (size_t)s.W;
+  const size_t max_chunks = part_max_chunks(pairs, ps.nbins);
+  // pass-1 images | bucket-ordered index stream | per-bucket counts | per-chunk bucket offsets (u16)
+  ST_TRY(reserve(ctx, ctx->digits, (size_t)ps.ntiles * ps.te * 4));
+  ST_TRY(reserve(ctx, ctx->sorted, pairs * 4));
+  ST_TRY(reserve(ctx, ctx->hist, nb * 4));
+  ST_TRY(reserve(ctx, ctx->offsets, max_chunks * ps.seg_stride * 2));
+  // [cell table: (position in the bin, start | length in the tile) per bin and tile | bin totals | bin descriptors | tile starts (u16)]
+  const size_t cm_bytes = (size_t)ps.nbins * ps.ntiles * sizeof(uint2);
+  const size_t bt_bytes = ((size_t)ps.nbins * 4 + 15) & ~(size_t)15, bm_bytes = (size_t)ps.nbins * sizeof(BinMeta);
+  const size_t ts_bytes = (size_t)ps.ntiles * (ps.nbins + 1) * 2;
+  ST_TRY(reserve(ctx, ctx->cursor, cm_bytes + bt_bytes + bm_bytes + ts_bytes));
   ST_TRY(reserve(ctx, ctx->buckets, nb * sizeof(Xyzz<F>)));
   ST_TRY(reserve(ctx, ctx->partials, ((size_t)rs.W * chunks + (size_t)rs.W * 256) * sizeof(Xyzz<F>)));
-  u64* entries = (u64*)ctx->digits.p;
-  u32 *sorted = (u32*)ctx->sorted.p, *hist = (u32*)ctx->hist.p, *offsets = (u32*)ctx->offsets.p;
-  u32 *pcounts = (u32*)ctx->cursor.p, *poffsets = pcounts + ncounts, *pcounts_t = poffsets + ncounts + 4;
+  u32 *tiles = (u32*)ctx->digits.p, *sorted = (u32*)ctx->sorted.p, *hist = (u32*)ctx->hist.p;
+  u16* segoff = (u16*)ctx->offsets.p;
+  uint2* cellmeta = (uint2*)ctx->cursor.p;
+  u32* bin_total = (u32*)((char*)ctx->cursor.p + cm_bytes);
+  BinMeta* bins = (BinMeta*)((char*)bin_total + bt_bytes);
+  u16* tstart = (u16*)((char*)bins + bm_bytes);
   Xyzz<F>* buckets = (Xyzz<F>*)ctx->buckets.p;
   Xyzz<F>* partials = (Xyzz<F>*)ctx->partials.p;
-  hipLaunchKernelGGL(k_part_count, dim3(ps.ntiles), dim3(P1_THREADS), 0, st, (const Fr*)d_scalars, s, ps, pcounts_t);
-  hipLaunchKernelGGL(k_part_supercount, dim3(cdiv(ps.nbins, 256), ps.nwg), dim3(256), 0, st, (const u32*)pcounts_t, ps, pcounts);
-  ST_TRY(launch_check(ctx, "part_count"));
-  ST_TRY(device_scan(ctx, pcounts, (u32)ncounts, poffsets));
-  hipLaunchKernelGGL(k_part_scatter, dim3(ps.nwg), dim3(P1_THREADS), 0, st, (const Fr*)d_scalars, s, ps, (const u32*)poffsets, (const u32*)pcounts_t, entries);
-  ST_TRY(launch_check(ctx, "part_scatter"));
-  hipLaunchKernelGGL(k_part_total, dim3(1), dim3(64), 0, st, (const u32*)pcounts, (const u32*)poffsets, (u32)ncounts, poffsets + ncounts);
-  if (ctx->tune.p2_small)
-    hipLaunchKernelGGL((k_part_fine<P2_CAP_SMALL>), dim3(ps.nbins), dim3(P2_THREADS), 0, st, (const u64*)entries, (const u32*)poffsets, ps,
-                       (const u32*)(poffsets + ncounts), (u32)nb, offsets, hist, sorted);
-  else
-    hipLaunchKernelGGL((k_part_fine<P2_CAP_BIG>), dim3(ps.nbins), dim3(P2_THREADS), 0, st, (const u64*)entries, (const u32*)poffsets, ps,
-                       (const u32*)(poffsets + ncounts), (u32)nb, offsets, hist, sorted);
-  ST_TRY(launch_check(ctx, "part_fine"));
+  hipLaunchKernelGGL(k_tile_sort, dim3(ps.ntiles), dim3(T1_THREADS), 0, st, (const Fr*)d_scalars, s, ps, tiles, tstart);
+  ST_TRY(launch_check(ctx, "tile_sort"));
+  hipLaunchKernelGGL(k_cell_prefix, dim3(ps.nbins), dim3(1024), 0, st, (const u16*)tstart, ps, cellmeta, bin_total);
+  hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, (const u32*)bin_total, ps.nbins, bins);
+  hipLaunchKernelGGL(k_chunk_sort, dim3(ps.nbins), dim3(C2_THREADS), 0, st, (const u32*)tiles, (const uint2*)cellmeta, (const BinMeta*)bins, s, ps, (u32)nb,
+                     sorted, segoff, hist);
+  ST_TRY(launch_check(ctx, "chunk_sort"));
+  const SortView view = {sorted, bins, segoff, ps.shift, ps.seg_stride};
   // bucket schedule: descending size
   ST_TRY(reserve(ctx, ctx->perm, nb * 4 + 2 * CNT_BINS * 4 + sizeof(HeavyList)));
   u32* perm = (u32*)ctx->perm.p;
@@ -133,24 +122,24 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   if constexpr (std::is_same<F, Fq>::value) {
     u29 = ctx->tune.acc_u29;                                 // A/B switch for profiling
     if (u29 && ctx->tune.acc_nt)
-      hipLaunchKernelGGL(k_msm_accumulate_g1_u29<1>, dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
-                         (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
+      hipLaunchKernelGGL(k_msm_accumulate_g1_u29<1>, dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, view, (const u32*)hist,
+                         (const u32*)perm, (u32)nb, buckets);
     else if (u29)
-      hipLaunchKernelGGL(k_msm_accumulate_g1_u29<0>, dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
-                         (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
+      hipLaunchKernelGGL(k_msm_accumulate_g1_u29<0>, dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, view, (const u32*)hist,
+                         (const u32*)perm, (u32)nb, buckets);
   }
   if constexpr (std::is_same<F, Fq2>::value) {
     u29 = ctx->tune.acc_u29_g2;                              // A/B switch for profiling
     if (u29)
-      hipLaunchKernelGGL(k_msm_accumulate_g2_u29, dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
-                         (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
+      hipLaunchKernelGGL(k_msm_accumulate_g2_u29, dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, view, (const u32*)hist,
+                         (const u32*)perm, (u32)nb, buckets);
   }
   if (!u29)
-    hipLaunchKernelGGL((k_msm_accumulate<F>), dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets,
-                       (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
+    hipLaunchKernelGGL((k_msm_accumulate<F>), dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, view, (const u32*)hist,
+                       (const u32*)perm, (u32)nb, buckets);
   ST_TRY(launch_check(ctx, "msm_accumulate"));
   // heavy buckets (structured scalars only; the grids exit after one load otherwise)
-  hipLaunchKernelGGL((k_msm_heavy<F>), dim3(HEAVY_GRID), dim3(256), 0, st, d_points, (const u32*)sorted, (const u32*)offsets, (const u32*)hist,
+  hipLaunchKernelGGL((k_msm_heavy<F>), dim3(HEAVY_GRID), dim3(256), 0, st, d_points, view, (const u32*)hist,
                      (const HeavyList*)hv, hv_slice_cap, (const u32*)hv_bucket, (const u32*)hv_first, (const u32*)hv_owner, hv_slices);
   hipLaunchKernelGGL((k_msm_heavy_combine<F>), dim3(HEAVY_COMBINE_GRID), dim3(64), 0, st, (const u32*)hist, (const HeavyList*)hv, hv_cap, hv_slice_cap,
                      (const u32*)hv_bucket, (const u32*)hv_first, (const Xyzz<F>*)hv_slices, buckets);
