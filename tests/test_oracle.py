@@ -75,6 +75,32 @@ def test_final_exponent_and_bilinearity(py):
     assert hashlib.sha256(py.gt_serialize(e)).hexdigest() == "e109983de6d3ff0d8d4e1236dd4d91d2a313d7e7a22e3a15062b6759ad70331c"
 
 
+def test_pairing_against_an_independent_derivation(py):
+    """oracle/bn254_indep.py computes the same pairing with nothing in common with bn254_py's (and bn254_ref.c's) pairing code: one flat
+    extension Fq[w]/(w^12 - 18 w^6 + 82) instead of the tower, Q untwisted to y^2 = x^3 + 3 over Fq12 (asserted on the curve: the twist
+    type and the embedding are checked there), the textbook affine Miller loop over the plain binary expansion of 6z + 2 with dense
+    tangent / chord lines, pi(Q) by a generic p-th power, one square-and-multiply by (p^12 - 1)/r * 2z(6z^2 + 3z + 1).
+    What this leaves recalled: that multiple, and the order / encoding of the twelve coefficients in serialize_uncompressed."""
+    import inspect
+    import random
+    import bn254_indep as ind
+    src = inspect.getsource(ind)
+    assert "import bn254_py" not in src and "bn254_ref" not in src.split('"""')[2]      # shares no code with the oracle it checks
+    pairs = [(py.G1_GEN, py.G2_GEN)]
+    blob = open(os.path.join(GOLDEN, "ppot_0080_01.ptau.test"), "rb").read()
+    pts = py.ptau_points(blob)
+    pairs += [(pts["tau_g1"][1], pts["tau_g2"][1]), (pts["tau_g1"][2], pts["beta_g2"][0]), (pts["alpha_tau_g1"][1], pts["tau_g2"][1]),
+              (pts["beta_tau_g1"][1], py.G2_GEN)]
+    rng = random.Random(20261003)
+    for _ in range(8):
+        pairs.append((py.g1_mul(py.G1_GEN, rng.randrange(1, py.R)), py.g2_mul(py.G2_GEN, rng.randrange(1, py.R))))
+    for p1, q2 in pairs:
+        assert ind.flat_to_tower(ind.pairing_flat(p1, q2)) == py.pairing(p1, q2)
+    e = ind.flat_to_tower(ind.pairing_flat(py.G1_GEN, py.G2_GEN))
+    assert hashlib.sha256(py.gt_serialize(e)).hexdigest() == "e109983de6d3ff0d8d4e1236dd4d91d2a313d7e7a22e3a15062b6759ad70331c"
+    assert ind.pairing_flat(None, py.G2_GEN) == ind.ONE
+
+
 def test_cyclotomic_square_matches_plain_square(py, oc):
     # C oracle uses Granger-Scott squaring inside final_exp; Python uses plain squaring
     g1, g2 = oc.generators()
