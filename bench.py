@@ -548,9 +548,9 @@ def main():
             if "k_msm_accumulate" in kname:
                 traffic = kv["fetch_bytes"] + kv["write_bytes"]
     # integer roofline: one XYZZ mixed add = 8M + 2S = 10 Montgomery products; instruction count of the loop body from the shipped
-    # ISA (bench_tools/count_isa.py -> profiles/r03_accumulate_isa.json), issue rate from the committed micro-benchmark
+    # ISA (bench_tools/count_isa.py -> profiles/r04_accumulate_isa.json), issue rate from the committed micro-benchmark
     alu = None
-    isa, isa_why = stamped_profile("r03_accumulate_isa.json", MSM_KERNEL_SOURCES)
+    isa, isa_why = stamped_profile("r04_accumulate_isa.json", MSM_KERNEL_SOURCES)
     mul_cyc, simple_cyc, cyc_src = stream_cycles_from_ubench(3)
     if isa is not None and mul_cyc is not None and simple_cyc is not None:
         ipa, mads = float(isa["loop_instructions"]), float(isa["loop_v_mad_u64_u32"])
@@ -563,7 +563,7 @@ def main():
         alu = {"bound": "integer issue (v_mad_u64_u32 streams)", "achieved": modmuls / 1e9, "peak": modmuls / 1e9 * measured_cycles / model_cycles, "unit": "G modmul/s",
                "frac": model_cycles / measured_cycles, "simd_cycles_per_mixed_add_measured": measured_cycles, "simd_cycles_per_mixed_add_at_stream_rate": model_cycles,
                "issues_per_mixed_add": ipa, "v_mad_u64_u32_per_mixed_add": mads, "product_stream_cycles": mul_cyc, "plain_valu_cycles": simple_cyc,
-               "sources": ["profiles/r03_accumulate_isa.json", cyc_src],
+               "sources": ["profiles/r04_accumulate_isa.json", cyc_src],
                "note": "a schedule diagnostic (how close the kernel runs to the issue rate of ITS OWN instruction stream at 3 waves per SIMD and "
                        "2.4 GHz), not a claim that the stream is minimal"}
     else:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Instruction counts of the bucket kernel's loop body from the ISA hipcc emits for THIS tree (runs on the CPU box: hipcc cross-compiles).
 
-    python bench_tools/count_isa.py            # writes profiles/r03_accumulate_isa.json
+    python bench_tools/count_isa.py            # writes profiles/r04_accumulate_isa.json
 
 Compiles keaki_amd/csrc/msm_g1.hip to gfx950 assembly (the flags of the Makefile), cuts k_msm_accumulate_g1_u29 into basic blocks and
 reports, per block, the number of instructions and of v_mad_u64_u32. The loop body of one mixed addition = the two consecutive blocks
@@ -59,7 +59,7 @@ def main():
            "loop_blocks": [pair[0]["block"], pair[1]["block"]], "loop_instructions": pair[0]["instructions"] + pair[1]["instructions"],
            "loop_v_mad_u64_u32": best, "registers": meta, "blocks": table,
            "rule": "two consecutive basic blocks with the largest combined v_mad_u64_u32 count among blocks of < 2000 instructions"}
-    dst = os.path.join(ROOT, "profiles", "r03_accumulate_isa.json")
+    dst = os.path.join(ROOT, "profiles", "r04_accumulate_isa.json")
     json.dump(out, open(dst, "w"), indent=1)
     print("loop: %s = %d instructions, %d v_mad_u64_u32; registers %s -> %s" % (out["loop_blocks"], out["loop_instructions"], best, meta, dst))
 

@@ -246,6 +246,7 @@ keaki_status keaki_hip_ctx_create(int32_t device, void* stream, keaki_hip_ctx** 
     return fail(nullptr, KEAKI_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
   keaki_hip_ctx* ctx = new keaki_hip_ctx();
   ctx->device = device;
+  ctx->n_cu = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
   tune_from_env(ctx->tune);
   if (stream) {
     ctx->stream = (hipStream_t)stream;

@@ -44,6 +44,7 @@ struct Tuning {
 
 struct keaki_hip_ctx {
   int device = 0;
+  uint32_t n_cu = 256;           // compute units of the device (grid size of the persistent kernels)
   keaki_internal::Tuning tune;
   // bytes this context allocated and still holds, by class (keaki_hip_ctx_memory): SRS window tables + FK23 transforms of handles built
   // through it | grow-only workspaces | GT / fixed-base tables of encapsulate

@@ -25,7 +25,11 @@
 namespace bn254 {
 
 typedef uint16_t u16;
+typedef u32 v4u_t __attribute__((ext_vector_type(4)));
 constexpr u32 DIGIT_NONE = 0xFFFFFFFFu;
+#ifndef STAMP            // bench_tools/dbg/sort_harness.hip defines it: in-kernel phase stamps of one workgroup
+#define STAMP(cond, i) do { } while (0)
+#endif
 
 // Window plan. The 254 scalar bits are spread over W windows as evenly as possible: the first `k`
 // windows are `c` bits wide, the remaining W - k are c - 1 bits wide (k >= 1, k*c + (W-k)*(c-1) = 254).
@@ -101,6 +105,37 @@ KDEV void msm_for_each_digit_canon(const u32 (&canon)[8], const MsmShape& s, Emi
   }
 }
 
+// The same digits for a plan that is known at compile time. msm_make_plan derives c and k from the number of windows alone, so W fixes
+// every bit offset: a digit is one funnel shift of two NAMED limbs and a mask (the run-time walk above shifts the whole 256-bit value
+// per window, or -- cut limb by limb -- spends ~45 scalar instructions per window on the bookkeeping; the CU's one scalar unit was the
+// limit of the first tile sort). code[w] = bucket | sign << 31, DIGIT_NONE for a zero digit.
+template <u32 W> struct StaticPlan {
+  static constexpr u32 base = 254 / W, rem = 254 % W;
+  static constexpr u32 c = rem ? base + 1 : base, k = rem ? rem : W;
+  static constexpr u32 width(u32 w) { return w < k ? c : c - 1; }
+  static constexpr u32 offset(u32 w) { return w < k ? w * c : k * c + (w - k) * (c - 1); }
+};
+template <u32 W>
+KDEV void msm_digits_static(const u32 (&v)[8], u32 (&code)[W]) {
+  typedef StaticPlan<W> P;
+  u32 carry = 0;
+#pragma unroll
+  for (u32 w = 0; w < W; w++) {
+    const u32 off = P::offset(w), wd = P::width(w), j = off >> 5, sh = off & 31;
+    const u32 lo = v[j], hi = j + 1 < 8 ? v[j + 1] : 0u;
+    const u32 d = (sh + wd <= 32 ? lo >> sh : __builtin_amdgcn_alignbit(hi, lo, sh)) & ((1u << wd) - 1u);
+    const u32 full = 1u << wd, half = full >> 1;
+    const u32 coef = d + carry;
+    if (w == W - 1) {
+      code[w] = coef ? coef - 1u : DIGIT_NONE;
+    } else {
+      const bool neg = coef > half;
+      carry = neg ? 1u : 0u;
+      code[w] = neg ? (coef != full ? ((full - coef - 1u) | 0x80000000u) : DIGIT_NONE) : (coef ? coef - 1u : DIGIT_NONE);
+    }
+  }
+}
+
 template <class Emit>
 KDEV void msm_for_each_digit(const Fr& k, const MsmShape& s, Emit emit) {
   u32 v[8];
@@ -108,158 +143,226 @@ KDEV void msm_for_each_digit(const Fr& k, const MsmShape& s, Emit emit) {
   msm_for_each_digit_canon(v, s, emit);
 }
 
-// ---- bucket sort of the (bucket, point) pairs: two LDS counting sorts, every pair read from HBM once per pass ---------------------
-// Global bucket id g = w * B + bucket (shared-bucket mode: g = bucket) = bin << shift | fine.
-//   pass 1, k_tile_sort   one workgroup per TILE of <= 3072 scalars: Montgomery -> canonical once, the digit walk twice (count,
-//                         place); the tile's <= 36 K pairs are counting-sorted by bin in 144 KB of LDS and leave as ONE contiguous
-//                         image of 4-byte entries (fine | sign | window | index inside the tile) plus the bins' start positions.
-//                         No global histogram, no scan, no second read of the scalars.
+// ---- bucket sort of the (bucket, point) pairs: two LDS counting sorts, every global store part of a contiguous image -------------------
+// Global bucket id g = w * B + bucket (shared-bucket mode: g = bucket). Its MIDDLE bits are the bin, the bits around them the fine index:
+//     g = [ hb high bits | lb bin bits | shift low bits ],  fine = high << shift | low   (nf = 2^(shift + hb) buckets per bin)
+// so every bin holds a slice of each 2^(shift + lb)-aligned stretch of the bucket range: with window tables the low half of the buckets
+// takes the digits of all twelve windows and the high half those of two, and bins of consecutive buckets would differ elevenfold.
+//   pass 1, k_tile_sort   one workgroup per TILE of <= 3072 scalars: Montgomery -> canonical once, the digits cut twice (count, place);
+//                         the tile's <= 36 K pairs are counting-sorted by bin in 144 KB of LDS and leave as ONE contiguous image of 4-byte
+//                         entries (fine | sign | window | index inside the tile) plus the bins' start positions. No global histogram,
+//                         no scan, no second read of the scalars.
 //   k_cell_prefix / k_bin_scan   per bin: running position of its cell in every tile; per-bin totals -> image base, chunk ids
-//   pass 2, k_chunk_sort  one workgroup per BIN: the bin's cells (tile by tile, ~36 entries each) are gathered 32 K pairs at a time,
-//                         counting-sorted by fine bucket in 128 KB of LDS and written as ONE contiguous image per chunk, plus the
-//                         2^shift + 1 bucket offsets of the chunk (u16). The tile a cell came from completes the point index, so
-//                         the entries of pass 1 need only 4 bytes.
-// A bucket's pairs therefore lie in one SEGMENT per chunk of its bin (about six at 2^24 points); the bucket kernels walk them
-// (SegWalker). No global atomics; every global store of both passes is part of a contiguous image.
+//   pass 2, k_chunk_sort  one workgroup per BIN: the bin's cells (tile by tile) are gathered 32 K pairs at a time, counting-sorted by fine
+//                         bucket in 128 KB of LDS and written as ONE contiguous image per chunk; the tile a cell came from completes the
+//                         point index, which is why 4-byte entries suffice. Per bucket and chunk one word first | end << 16.
+// A bucket's pairs therefore lie in one SEGMENT per chunk of its bin (three at 2^24 points); the bucket kernels walk them (SegWalker).
+// No global atomics. Barriers inside the two passes wait for LDS only (lds_barrier): __syncthreads also waits for the workgroup's global
+// stores, i.e. for the image that is still draining to HBM -- with one workgroup per CU nothing else hides that.
 constexpr u32 T1_THREADS = 1024;
 constexpr u32 T1_PER = 3;                 // scalars per lane of a pass-1 tile
 constexpr u32 T1_CAP = 36864;             // pairs staged per pass-1 tile (4 B each = 144 KB of LDS)
 constexpr u32 PART_MAX_BINS = 2048;       // coarse bins
 constexpr u32 C2_THREADS = 1024;
-constexpr u32 C2_CAP = 32768;             // pairs per pass-2 chunk (4 B each = 128 KB of LDS)
+constexpr u32 C2_CAP = 32768;             // pairs per pass-2 chunk (4 B each = 128 KB of LDS). Long chunks: the bucket kernel pays for every segment
+                                          // (15 K chunks, 13 segments per bucket: +0.5 ms at 2^24 points)
 constexpr u32 PART_MAX_FINE_SHIFT = 11;
 constexpr u32 PART_MAX_FINE = 1u << PART_MAX_FINE_SHIFT;
-// pass-1 entry: index inside the tile (12 bits: tile <= 3072) | window (7 bits: W <= 85) | sign | fine bucket (<= 11 bits)
-constexpr u32 TE_WPOS = 12, TE_SIGN = 19, TE_FINE = 20;
+constexpr u32 SEG_INLINE = 4;             // segment words kept per bucket in the bucket-major table (bins of more chunks: chunk-major rows behind them)
+// pass-1 entry: index inside the tile (12 bits: tile <= 3072) | window (7 bits: W <= 85) | sign | fine bucket (<= 11 bits) | 1: a word that is
+// zero -- what an out-of-range buffer load returns -- is no entry
+constexpr u32 TE_WPOS = 12, TE_SIGN = 19, TE_FINE = 20, TE_VALID = 0x80000000u;
 
 struct PartShape {
-  u32 nbins;       // coarse bins = ceil(total buckets >> shift)
-  u32 shift;       // fine bits: a bin covers 2^shift buckets
+  u32 nbins, lb;   // coarse bins = 2^lb
+  u32 shift, hb;   // low / high fine bits
+  u32 nf;          // buckets per bin = 2^(shift + hb)
   u32 tile;        // scalars per pass-1 tile (<= T1_THREADS * T1_PER, tile * W <= T1_CAP)
   u32 ntiles;      // ceil(n / tile)
   u32 te;          // entry slots per tile image = tile * W
-  u32 seg_stride;  // u16 offsets per chunk: 2^shift + 1, padded to a multiple of 8
+  u32 geom;        // pass-2 gather shape for the expected cell length te / nbins (k_chunk_sort)
 };
-inline bool part_make_shape(size_t n, u32 W, size_t nb, PartShape* ps, int shift_override = -1) {
+KDEV u32 part_bin(const PartShape& ps, u32 g) { return (g >> ps.shift) & (ps.nbins - 1u); }
+KDEV u32 part_fine(const PartShape& ps, u32 g) { return ((g >> (ps.shift + ps.lb)) << ps.shift) | (g & ((1u << ps.shift) - 1u)); }
+KDEV u32 part_bucket(const PartShape& ps, u32 bin, u32 f) { return ((f >> ps.shift) << (ps.shift + ps.lb)) | (bin << ps.shift) | (f & ((1u << ps.shift) - 1u)); }
+inline bool part_make_shape(size_t n, u32 W, size_t nb, PartShape* ps, int lb_override = -1, int hb_override = -1, int geom_override = -1) {
   u32 lg = 0;
   while (((size_t)1 << lg) < nb) lg++;
-  int shift = (int)(lg + 1) / 2 + 1;
-  if (shift_override >= 0) shift = shift_override;
-  if (shift > (int)PART_MAX_FINE_SHIFT) shift = PART_MAX_FINE_SHIFT;
-  if (shift < 0) shift = 0;
-  while ((int)lg - shift > 11 && shift < (int)PART_MAX_FINE_SHIFT) shift++;
-  ps->shift = (u32)shift;
-  ps->nbins = (u32)((nb + ((size_t)1 << shift) - 1) >> shift);
+  const size_t pairs = n * (size_t)W;
+  u32 lb = 0;                                                   // about one chunk per bin where the input allows: one segment per bucket
+  while (lb < 11 && ((size_t)C2_CAP << lb) < pairs) lb++;
+  if (lb_override >= 0 && lb_override <= 11) lb = (u32)lb_override;
+  if (lb > lg) lb = lg;
+  if (lg - lb > PART_MAX_FINE_SHIFT) lb = lg - PART_MAX_FINE_SHIFT;
+  if (lb > 11) return false;
+  const u32 fb = lg - lb;
+  ps->lb = lb; ps->nbins = 1u << lb;
+  ps->hb = fb < 3 ? fb : 3u;
+  if (hb_override >= 0 && (u32)hb_override <= fb) ps->hb = (u32)hb_override;
+  ps->shift = fb - ps->hb;
+  ps->nf = 1u << fb;
   u32 tile = W ? T1_CAP / W : T1_THREADS * T1_PER;
   if (tile > T1_THREADS * T1_PER) tile = T1_THREADS * T1_PER;
   if (tile == 0 || W >= (1u << (TE_SIGN - TE_WPOS))) return false;
   ps->tile = tile;
   ps->ntiles = (u32)((n + tile - 1) / tile);
   ps->te = tile * W;
-  ps->seg_stride = (((1u << shift) + 1u) + 7u) & ~7u;
-  return ps->nbins >= 1 && ps->nbins <= PART_MAX_BINS;
+  const u32 mean = ps->te / ps->nbins;
+  ps->geom = mean <= 24 ? 0u : mean <= 48 ? 1u : mean <= 100 ? 2u : 3u;
+  if (geom_override >= 0) ps->geom = (u32)geom_override;
+  return true;
 }
 // chunks the second pass can produce for `pairs` pairs in `nbins` bins (every bin's last chunk may be partial)
 inline size_t part_max_chunks(size_t pairs, u32 nbins) { return pairs / C2_CAP + nbins + 1; }
 
-// exclusive scan, in place, of a[0..len) in LDS, len <= 2 * blockDim.x = 2048; returns the total. Whole workgroup calls it.
-__device__ __forceinline__ u32 lds_exclusive_scan(u32* a, u32 len, u32* wsum) {
+// barrier that orders LDS traffic only
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// exclusive scan, in place, of a[0..len) in LDS, len <= 4 * blockDim.x (four consecutive elements per lane); returns the total.
+// Whole workgroup calls it; LDS-only barriers.
+__device__ __forceinline__ u32 lds_exclusive_scan4(u32* a, u32 len, u32* wsum) {
   const u32 t = threadIdx.x, lane = t & 63, wid = t >> 6, nw = blockDim.x >> 6;
-  __syncthreads();
-  u32 x0 = 2 * t < len ? a[2 * t] : 0u, x1 = 2 * t + 1 < len ? a[2 * t + 1] : 0u;
-  u32 sum = x0 + x1, x = sum;
+  lds_barrier();
+  u32 x[4], sum = 0;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { u32 y = __shfl_up(x, o, 64); if (lane >= (u32)o) x += y; }
-  if (lane == 63) wsum[wid] = x;
-  __syncthreads();
+  for (u32 i = 0; i < 4; i++) { x[i] = 4 * t + i < len ? a[4 * t + i] : 0u; sum += x[i]; }
+  u32 v = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { u32 y = __shfl_up(v, o, 64); if (lane >= (u32)o) v += y; }
+  if (lane == 63) wsum[wid] = v;
+  lds_barrier();
   u32 base = 0, tot = 0;
   for (u32 k = 0; k < nw; k++) { u32 sv = wsum[k]; if (k < wid) base += sv; tot += sv; }
-  u32 ex = base + x - sum;
-  if (2 * t < len) a[2 * t] = ex;
-  if (2 * t + 1 < len) a[2 * t + 1] = ex + x0;
-  __syncthreads();
+  u32 ex = base + v - sum;
+#pragma unroll
+  for (u32 i = 0; i < 4; i++) { if (4 * t + i < len) a[4 * t + i] = ex; ex += x[i]; }
+  lds_barrier();
   return tot;
 }
 
-// pass 1: tiles[tile * te + q], q < m = the tile's pairs ordered by bin; tstart[tile * (nbins + 1) + b] = first position of bin b, [nbins] = m
+// pass 1: tiles[tile * te + q], q < m = the tile's pairs ordered by bin; tstart[tile * (nbins + 1) + b] = first position of bin b, [nbins] = m.
+// A workgroup walks tiles blockIdx.x, + gridDim.x, ...: the stores of a finished image drain under the next tile's loads and arithmetic.
+// WS > 0: the plan with WS windows, digits cut by msm_digits_static; WS = 0: any plan, the run-time digit walk. Either way the canonical
+// scalars stay in registers and the digits are cut twice, for the counting and for the placing pass.
+template <u32 WS>
 static __global__ void __launch_bounds__(T1_THREADS) k_tile_sort(const Fr* __restrict__ scalars, MsmShape s, PartShape ps, u32* __restrict__ tiles,
                                                                  u16* __restrict__ tstart) {
-  __shared__ u32 ent[T1_CAP];
-  __shared__ u32 cur[PART_MAX_BINS];
+  __shared__ u32 ent[T1_CAP + 64];         // [T1_CAP + lane]: where the (rare) zero digits of the branch-free loops go
+  __shared__ u32 cur[PART_MAX_BINS + 64];  // [PART_MAX_BINS + lane]: their bin (one word per lane: same-address LDS atomics of a wave are serial)
   __shared__ u32 wsum[T1_THREADS / 64];
-  const u32 tile = blockIdx.x, t = threadIdx.x;
-  for (u32 b = t; b < ps.nbins; b += T1_THREADS) cur[b] = 0;
-  __syncthreads();
-  u32 canon[T1_PER][8];
-  bool act[T1_PER];
-  const u32 mask = (1u << ps.shift) - 1u;
+  const u32 t = threadIdx.x;
+  constexpr u32 NC = WS ? WS : 1u;
+  for (u32 tile = blockIdx.x; tile < ps.ntiles; tile += gridDim.x) {
+    const u32 sk = (tile - blockIdx.x) / gridDim.x;
+    STAMP(blockIdx.x == 100 && t == 0 && sk < 4, 2048 + sk * 16 + 0);
+    u32 canon[T1_PER][8];          // the canonical scalars; the digits are cut twice (count, place): 24 registers instead of 3 W
+    bool act[T1_PER];
+    {
+      Fr nxt[T1_PER];
 #pragma unroll
-  for (u32 p = 0; p < T1_PER; p++) {
-    const u32 li = p * T1_THREADS + t;
-    const size_t i = (size_t)tile * ps.tile + li;
-    act[p] = li < ps.tile && i < s.n;
-    if (act[p]) {
-      const Fr k = scalars[i];
-      fp_from_mont<FrParams>(canon[p], k);
-      msm_for_each_digit_canon(canon[p], s, [&](u32 w, u32 code) {
-        const u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
-        atomicAdd(&cur[g >> ps.shift], 1u);
-      });
+      for (u32 p = 0; p < T1_PER; p++) {                   // branch-free: a lane without a scalar reads the last one and drops its digits
+        const u32 li = p * T1_THREADS + t;
+        const size_t i = (size_t)tile * ps.tile + li;
+        act[p] = li < ps.tile && i < s.n;
+        nxt[p] = scalars[act[p] ? i : (size_t)s.n - 1];
+      }
+#pragma unroll
+      for (u32 p = 0; p < T1_PER; p++) fp_from_mont<FrParams>(canon[p], nxt[p]);
     }
-  }
-  const u32 m = lds_exclusive_scan(cur, ps.nbins, wsum);       // cur[b] = start of bin b inside the tile
-  u16* ts = tstart + (size_t)tile * (ps.nbins + 1);
-  for (u32 b = t; b < ps.nbins; b += T1_THREADS) ts[b] = (u16)cur[b];
-  if (t == 0) ts[ps.nbins] = (u16)m;
-  __syncthreads();
+    STAMP(blockIdx.x == 100 && t == 0 && sk < 4, 2048 + sk * 16 + 1);
+    for (u32 b = t; b < ps.nbins; b += T1_THREADS) cur[b] = 0;
+    if (t < 64) cur[PART_MAX_BINS + t] = 0;
+    lds_barrier();
+    STAMP(blockIdx.x == 100 && t == 0 && sk < 4, 2048 + sk * 16 + 2);
 #pragma unroll
-  for (u32 p = 0; p < T1_PER; p++) {
-    if (act[p]) {
+    for (u32 p = 0; p < T1_PER; p++) {
+      if constexpr (WS != 0) {
+        u32 code[NC];
+        msm_digits_static<NC>(canon[p], code);
+#pragma unroll
+        for (u32 w = 0; w < NC; w++) {            // no branch per digit: a zero digit (one in 2^c) counts into the dummy bin
+          const u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code[w] & 0x7FFFFFFFu);
+          atomicAdd(&cur[act[p] && code[w] != DIGIT_NONE ? part_bin(ps, g) : PART_MAX_BINS + (t & 63u)], 1u);
+        }
+      } else if (act[p]) {
+        msm_for_each_digit_canon(canon[p], s, [&](u32 w, u32 cd) {
+          const u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (cd & 0x7FFFFFFFu);
+          atomicAdd(&cur[part_bin(ps, g)], 1u);
+        });
+      }
+    }
+    STAMP(blockIdx.x == 100 && t == 0 && sk < 4, 2048 + sk * 16 + 3);
+    const u32 m = lds_exclusive_scan4(cur, ps.nbins, wsum);      // cur[b] = start of bin b inside the tile
+    u16* ts = tstart + (size_t)tile * (ps.nbins + 1);
+    for (u32 b = t; b < ps.nbins; b += T1_THREADS) ts[b] = (u16)cur[b];
+    if (t == 0) ts[ps.nbins] = (u16)m;
+    lds_barrier();
+    STAMP(blockIdx.x == 100 && t == 0 && sk < 4, 2048 + sk * 16 + 4);
+#pragma unroll
+    for (u32 p = 0; p < T1_PER; p++) {
       const u32 li = p * T1_THREADS + t;
-      msm_for_each_digit_canon(canon[p], s, [&](u32 w, u32 code) {
-        const u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (code & 0x7FFFFFFFu);
-        const u32 pos = atomicAdd(&cur[g >> ps.shift], 1u);
-        ent[pos] = ((g & mask) << TE_FINE) | ((code >> 31) << TE_SIGN) | (w << TE_WPOS) | li;
-      });
+      if constexpr (WS != 0) {
+        u32 code[NC];
+        msm_digits_static<NC>(canon[p], code);
+#pragma unroll
+        for (u32 w = 0; w < NC; w++) {
+          const u32 cd = code[w];
+          const bool ok = act[p] && cd != DIGIT_NONE;
+          const u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (cd & 0x7FFFFFFFu);
+          const u32 pos = atomicAdd(&cur[ok ? part_bin(ps, g) : PART_MAX_BINS + (t & 63u)], 1u);
+          ent[ok ? pos : T1_CAP + (t & 63u)] = TE_VALID | (part_fine(ps, g) << TE_FINE) | ((cd >> 31) << TE_SIGN) | (w << TE_WPOS) | li;
+        }
+      } else if (act[p]) {
+        msm_for_each_digit_canon(canon[p], s, [&](u32 w, u32 cd) {
+          const u32 g = (s.stride ? 0u : msm_bucket_base(s, w)) + (cd & 0x7FFFFFFFu);
+          const u32 pos = atomicAdd(&cur[part_bin(ps, g)], 1u);
+          ent[pos] = TE_VALID | (part_fine(ps, g) << TE_FINE) | ((cd >> 31) << TE_SIGN) | (w << TE_WPOS) | li;
+        });
+      }
     }
+    STAMP(blockIdx.x == 100 && t == 0 && sk < 4, 2048 + sk * 16 + 5);
+    lds_barrier();
+    STAMP(blockIdx.x == 100 && t == 0 && sk < 4, 2048 + sk * 16 + 6);
+    u32* dst = tiles + (size_t)tile * ps.te;
+#pragma unroll 4
+    for (u32 q = t; q < m; q += T1_THREADS) dst[q] = ent[q];
+    STAMP(blockIdx.x == 100 && t == 0 && sk < 4, 2048 + sk * 16 + 7);
+    // no barrier here: the next tile touches `ent` again only behind two more barriers
   }
-  __syncthreads();
-  u32* dst = tiles + (size_t)tile * ps.te;
-  for (u32 q = t; q < m; q += T1_THREADS) dst[q] = ent[q];
 }
 
 // per bin: where its cell of every tile begins in the bin's own order (tile after tile), and how many pairs the bin holds
 static __global__ void __launch_bounds__(1024) k_cell_prefix(const u16* __restrict__ tstart, PartShape ps, uint2* __restrict__ cellmeta,
                                                              u32* __restrict__ bin_total) {
-  __shared__ u32 a[2048];
+  __shared__ u32 a[4096];
   __shared__ u32 wsum[16];
   const u32 b = blockIdx.x, t = threadIdx.x;
   u32 carry = 0;
-  for (u32 base = 0; base < ps.ntiles; base += 2048) {
-    u32 st[2], ln[2];
+  for (u32 base = 0; base < ps.ntiles; base += 4096) {
+    u32 st[4], ln[4];
 #pragma unroll
-    for (u32 k = 0; k < 2; k++) {
-      const u32 tile = base + 2 * t + k;
+    for (u32 k = 0; k < 4; k++) {
+      const u32 tile = base + 4 * t + k;
       st[k] = 0; ln[k] = 0;
       if (tile < ps.ntiles) {
         const u16* row = tstart + (size_t)tile * (ps.nbins + 1) + b;
         st[k] = row[0];
         ln[k] = (u32)row[1] - st[k];
       }
-      a[2 * t + k] = ln[k];
+      a[4 * t + k] = ln[k];
     }
-    const u32 tot = lds_exclusive_scan(a, 2048, wsum);
+    const u32 tot = lds_exclusive_scan4(a, 4096, wsum);
 #pragma unroll
-    for (u32 k = 0; k < 2; k++) {
-      const u32 tile = base + 2 * t + k;
-      if (tile < ps.ntiles) cellmeta[(size_t)b * ps.ntiles + tile] = make_uint2(carry + a[2 * t + k], st[k] | (ln[k] << 16));
+    for (u32 k = 0; k < 4; k++) {
+      const u32 tile = base + 4 * t + k;
+      if (tile < ps.ntiles) cellmeta[(size_t)b * ps.ntiles + tile] = make_uint2(carry + a[4 * t + k], st[k] | (ln[k] << 16));
     }
     carry += tot;
-    __syncthreads();
+    lds_barrier();
   }
   if (t == 0) bin_total[b] = carry;
 }
-// where a bin's chunk images begin in `sorted`, and which chunk ids (rows of the offset table) it owns
+// where a bin's chunk images begin in `sorted`, and which chunk ids (rows of the chunk-major offset table) it owns
 struct BinMeta {
   u32 img_base, chunk_first, nch, total;
 };
@@ -276,8 +379,8 @@ static __global__ void __launch_bounds__(1024) k_bin_scan(const u32* __restrict_
     a[b] = tt[k];
     c[b] = (tt[k] + C2_CAP - 1) / C2_CAP;
   }
-  lds_exclusive_scan(a, 2048, wsum);
-  lds_exclusive_scan(c, 2048, wsum);
+  lds_exclusive_scan4(a, 2048, wsum);
+  lds_exclusive_scan4(c, 2048, wsum);
 #pragma unroll
   for (u32 k = 0; k < 2; k++) {
     const u32 b = 2 * t + k;
@@ -285,114 +388,283 @@ static __global__ void __launch_bounds__(1024) k_bin_scan(const u32* __restrict_
   }
 }
 
-// pass 2: one workgroup per bin
-static __global__ void __launch_bounds__(C2_THREADS) k_chunk_sort(const u32* __restrict__ tiles, const uint2* __restrict__ cellmeta,
-                                                                  const BinMeta* __restrict__ bins, MsmShape s, PartShape ps, u32 nbuckets_total,
-                                                                  u32* __restrict__ sorted, u16* __restrict__ segoff, u32* __restrict__ bucket_counts) {
-  __shared__ u32 pay[C2_CAP];
-  __shared__ u32 hist[PART_MAX_FINE];
-  __shared__ u32 tot[PART_MAX_FINE];
-  __shared__ u32 wsum[C2_THREADS / 64];
-  __shared__ u32 sh_next;
-  const u32 b = blockIdx.x, t = threadIdx.x, nf = 1u << ps.shift;
-  const u32 grp = t >> 4, l16 = t & 15;
-  const BinMeta bm = bins[b];
-  const uint2* cm = cellmeta + (size_t)b * ps.ntiles;
-  for (u32 f = t; f < nf; f += C2_THREADS) tot[f] = 0;
-  u32 c0 = 0;                                               // first cell that reaches into the chunk
-  for (u32 k = 0; k < bm.nch; k++) {
-    const u32 lo = k * C2_CAP, hi = bm.total - lo < C2_CAP ? bm.total : lo + C2_CAP;
-    for (u32 f = t; f < nf; f += C2_THREADS) hist[f] = 0;
-    if (t == 0) sh_next = ps.ntiles;
-    __syncthreads();
-    // sweep 1: per-bucket counts of the chunk (16 lanes per cell)
-    for (u32 c = c0 + grp; c < ps.ntiles; c += C2_THREADS / 16) {
-      const uint2 m = cm[c];
-      const u32 len = m.y >> 16;
-      const bool past = m.x + len > hi;                           // the first cell that reaches past the chunk opens the next one
-      if (past && l16 == 0) atomicMin(&sh_next, c);
-      if (m.x > hi || (past && m.x == hi)) break;                 // (an EMPTY cell that sits exactly at the chunk's end is stepped over)
-      const u32 j0 = m.x < lo ? lo - m.x : 0u, j1 = hi - m.x < len ? hi - m.x : len;
-      const u32* src = tiles + (size_t)c * ps.te + (m.y & 0xFFFFu);
-      for (u32 j = j0 + l16; j < j1; j += 16) atomicAdd(&hist[src[j] >> TE_FINE], 1u);
-    }
-    __syncthreads();
-    const u32 c_next = sh_next;
-    for (u32 f = t; f < nf; f += C2_THREADS) tot[f] += hist[f];
-    lds_exclusive_scan(hist, nf, wsum);                     // hist[f] = first position of bucket f inside the chunk
-    u16* so = segoff + (size_t)(bm.chunk_first + k) * ps.seg_stride;
-    for (u32 f = t; f < nf; f += C2_THREADS) so[f] = (u16)hist[f];
-    if (t == 0) so[nf] = (u16)(hi - lo);
-    __syncthreads();
-    // sweep 2: the same walk (the chunk's cells are in L2 now); the tile of a cell completes the point index
-    for (u32 c = c0 + grp; c < ps.ntiles; c += C2_THREADS / 16) {
-      const uint2 m = cm[c];
-      const u32 len = m.y >> 16;
-      if (m.x > hi || (m.x == hi && len)) break;
-      const u32 j0 = m.x < lo ? lo - m.x : 0u, j1 = hi - m.x < len ? hi - m.x : len;
-      const u32* src = tiles + (size_t)c * ps.te + (m.y & 0xFFFFu);
-      const u32 ibase = c * ps.tile;
-      for (u32 j = j0 + l16; j < j1; j += 16) {
-        const u32 e = src[j];
-        const u32 pos = atomicAdd(&hist[e >> TE_FINE], 1u);
-        pay[pos] = (((e >> TE_SIGN) & 1u) << 31) | (ibase + (e & ((1u << TE_WPOS) - 1u)) + ((e >> TE_WPOS) & ((1u << (TE_SIGN - TE_WPOS)) - 1u)) * s.stride);
+// pass 2: one workgroup per bin. A lane's chain of dependent loads, not the bandwidth, set the time of the first version, and 4-byte gathers
+// ran at ~40 cycles per wave instruction in the texture addresser (20 us per chunk and pass). So a chunk costs TWO dependent loads:
+// the descriptors of its cells come in with coalesced loads -- requested while the previous chunk is still being scanned and placed -- and go
+// through LDS to the groups of L lanes that own a cell each; then every lane requests R 16-byte pieces (4 entries each) of each of its
+// group's Q cells at once, through a buffer descriptor (one offset register per load; a slot without entries asks for an offset out of
+// range and gets zeros). The placing pass asks again (from L2): kept in registers across the scan the entries were spilled.
+// The gather shape <L, R, Q> follows the expected cell length te / nbins (PartShape::geom): a cell holds up to 4 L R entries, a chunk up to
+// Q * 1024 / L cells. Longer cells go on a short list whose tails all lanes walk together; a chunk with more cells, or a list that
+// overflows, takes chunk_slow for both passes: the plain walk, cell after cell (skewed scalars only).
+constexpr u32 C2_META = 2048, C2_OVF = 64;
+KDEV u32 chunk_payload(u32 en, u32 ibase, u32 stride) {
+  return (((en >> TE_SIGN) & 1u) << 31) | (ibase + (en & ((1u << TE_WPOS) - 1u)) + ((en >> TE_WPOS) & ((1u << (TE_SIGN - TE_WPOS)) - 1u)) * stride);
+}
+template <int PHASE>   // 0 counts, 1 places
+KDEV void chunk_slow(const u32* __restrict__ tiles, const uint2* __restrict__ cm, const PartShape& ps, u32 stride, u32 c0, u32 lo, u32 hi, u32* hist,
+                     u32* pay, u32* sh_next) {
+  const u32 grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+  for (u32 c = c0 + grp; c < ps.ntiles; c += C2_THREADS / 16) {
+    const uint2 m = cm[c];
+    const u32 len = m.y >> 16;
+    if (PHASE == 0 && m.x + len > hi && l16 == 0) atomicMin(sh_next, c);     // the first cell that reaches past the chunk opens the next one
+    if (m.x > hi || (m.x == hi && len)) break;                               // (an EMPTY cell that sits exactly at the chunk's end is stepped over)
+    const u32 j0 = m.x < lo ? lo - m.x : 0u, j1 = hi - m.x < len ? hi - m.x : len;
+    const u32* src = tiles + (size_t)c * ps.te + (m.y & 0xFFFFu);
+    for (u32 j = j0 + l16; j < j1; j += 16) {
+      const u32 en = src[j];
+      const u32 f = (en >> TE_FINE) & (PART_MAX_FINE - 1u);
+      if (PHASE == 0) {
+        atomicAdd(&hist[f], 1u);
+      } else {
+        const u32 pos = atomicAdd(&hist[f], 1u);
+        pay[pos] = chunk_payload(en, c * ps.tile, stride);
       }
     }
-    __syncthreads();
+  }
+}
+template <u32 L, u32 R, u32 Q>
+static __global__ void __launch_bounds__(C2_THREADS) k_chunk_sort(const u32* __restrict__ tiles, const uint2* __restrict__ cellmeta,
+                                                                  const BinMeta* __restrict__ bins, MsmShape s, PartShape ps, u32 nbuckets_total,
+                                                                  u32* __restrict__ sorted, v4u_t* __restrict__ segtab, u32* __restrict__ segoff,
+                                                                  u32* __restrict__ bucket_counts) {
+  constexpr u32 GROUPS = C2_THREADS / L, CELLS = GROUPS * Q, CAPC = 4 * L * R, NFT = PART_MAX_FINE / C2_THREADS;
+  static_assert(CELLS <= C2_META && Q * R * 4 <= 64, "gather shape");
+  // [C2_CAP + lane], hist[PART_MAX_FINE + lane]: where the empty slots of the branch-free loops go. One word PER LANE: LDS atomics of a wave to
+  // one address are executed one after the other (with a single dummy counter the ~40 % empty slots of a wave instruction cost ~60 cycles
+  // instead of 7, and the counting and placing passes ran at a tenth of their speed)
+  __shared__ u32 pay[C2_CAP + 64];
+  __shared__ uint2 meta[C2_META];
+  __shared__ u32 hist[PART_MAX_FINE + 64];
+  __shared__ u32 ovf[C2_OVF];
+  __shared__ u32 wsum[C2_THREADS / 64];
+  __shared__ u32 sh_next, sh_novf, sh_odd;
+  const u32 b = blockIdx.x, t = threadIdx.x, nf = ps.nf;
+  const BinMeta bm = bins[b];
+  const uint2* cm = cellmeta + (size_t)b * ps.ntiles;
+  u32 tot[NFT];                                             // the bin's per-bucket totals: buckets t, t + 1024 of this lane
+  u32 seg[NFT][SEG_INLINE];                                 // and their first SEG_INLINE segment words
+#pragma unroll
+  for (u32 i = 0; i < NFT; i++) {
+    tot[i] = 0;
+#pragma unroll
+    for (u32 k = 0; k < SEG_INLINE; k++) seg[i][k] = 0;
+  }
+  u32 c0 = 0;                                               // first cell that reaches into the chunk
+  uint2 mnext[C2_META / C2_THREADS];
+#pragma unroll
+  for (u32 i = 0; i < C2_META / C2_THREADS; i++) mnext[i] = t + i * C2_THREADS < ps.ntiles && t + i * C2_THREADS < CELLS ? cm[t + i * C2_THREADS] : make_uint2(0xFFFFFFFFu, 0u);
+  for (u32 k = 0; k < bm.nch; k++) {
+    const u32 lo = k * C2_CAP, hi = bm.total - lo < C2_CAP ? bm.total : lo + C2_CAP;
+    u32 tk = t;
+    asm volatile("" : "+v"(tk));                            // per-cell invariants are re-formed per chunk, not kept (and spilled) across it
+    const u32 grp = tk / L, ll = tk % L, dummy = PART_MAX_FINE + (tk & 63u);
+    STAMP(b == 100 && t == 0 && k < 8, k * 16 + 0);
+    for (u32 f = t; f < nf; f += C2_THREADS) hist[f] = 0;
+#pragma unroll
+    for (u32 i = 0; i < C2_META / C2_THREADS; i++) if (t + i * C2_THREADS < CELLS) meta[t + i * C2_THREADS] = mnext[i];      // descriptor of cell c0 + index
+    if (t == 0) { sh_next = ps.ntiles; sh_novf = 0; sh_odd = 0; }
+    lds_barrier();
+    STAMP(b == 100 && t == 0 && k < 8, k * 16 + 1);
+    // does the chunk fit the gather shape? which cells are longer than a group's slots? which cell opens the next chunk?
+    bool odd = false;
+    u32 cand = ps.ntiles;
+#pragma unroll
+    for (u32 q = 0; q < Q; q++) {
+      const u32 ci = grp + q * GROUPS;
+      const uint2 m = meta[ci];
+      const u32 len = m.y >> 16;
+      const bool beyond = m.x > hi || (m.x == hi && len);           // (an EMPTY cell that sits exactly at the chunk's end is stepped over)
+      if (m.x != 0xFFFFFFFFu && m.x + len > hi && c0 + ci < cand) cand = c0 + ci;
+      const u32 j0 = m.x < lo ? lo - m.x : 0u;
+      const u32 j1 = beyond ? 0u : (hi - m.x < len ? hi - m.x : len);
+      if (j1 > j0 + CAPC && ll == 0) {
+        const u32 slot = atomicAdd(&sh_novf, 1u);
+        if (slot < C2_OVF) ovf[slot] = ci;
+      }
+      if (q == Q - 1) odd |= !beyond && m.x != 0xFFFFFFFFu;         // more cells than the shape holds
+    }
+    if (ll == 0 && cand < ps.ntiles) atomicMin(&sh_next, cand);
+    if (odd) sh_odd = 1;
+    lds_barrier();
+    const u32 novf = sh_novf;
+    const bool slow = sh_odd != 0 || novf > C2_OVF;
+    STAMP(b == 100 && t == 0 && k < 8, k * 16 + 2);
+    // the tails of the long cells, all lanes together
+    auto tails = [&](auto use) {
+      for (u32 i = 0; i < novf; i++) {
+        const u32 ci = ovf[i];
+        const uint2 m = meta[ci];
+        const u32 len = m.y >> 16;
+        const u32 j0 = m.x < lo ? lo - m.x : 0u, j1 = hi - m.x < len ? hi - m.x : len;
+        const u32* src = tiles + (size_t)(c0 + ci) * ps.te + (m.y & 0xFFFFu);
+        for (u32 j = j0 + CAPC + t; j < j1; j += C2_THREADS) use(src[j], (c0 + ci) * ps.tile);
+      }
+    };
+    // after the counting pass: the next chunk's descriptors, the totals, the scan, the chunk's bucket offsets
+    auto between = [&]() {
+      STAMP(b == 100 && t == 0 && k < 8, k * 16 + 4);
+      lds_barrier();
+      STAMP(b == 100 && t == 0 && k < 8, k * 16 + 5);
+      const u32 c_next = sh_next;
+      if (k + 1 < bm.nch) {                                 // in flight under the scan and the placing pass
+#pragma unroll
+        for (u32 i = 0; i < C2_META / C2_THREADS; i++) {
+          const u32 ci = t + i * C2_THREADS;
+          mnext[i] = ci < CELLS && c_next + ci < ps.ntiles ? cm[c_next + ci] : make_uint2(0xFFFFFFFFu, 0u);
+        }
+      }
+#pragma unroll
+      for (u32 i = 0; i < NFT; i++) if (t + i * C2_THREADS < nf) tot[i] += hist[t + i * C2_THREADS];
+      lds_exclusive_scan4(hist, nf, wsum);                  // hist[f] = first position of bucket f inside the chunk
+#pragma unroll
+      for (u32 i = 0; i < NFT; i++) {
+        const u32 f = t + i * C2_THREADS;
+        if (f < nf) {
+          const u32 word = hist[f] | ((f + 1 < nf ? hist[f + 1] : hi - lo) << 16);      // <= 32768 each
+#pragma unroll
+          for (u32 kk = 0; kk < SEG_INLINE; kk++) if (kk == k) seg[i][kk] = word;
+          if (k >= SEG_INLINE) segoff[(size_t)(bm.chunk_first + k) * nf + f] = word;
+        }
+      }
+      lds_barrier();
+      STAMP(b == 100 && t == 0 && k < 8, k * 16 + 6);
+      return c_next;
+    };
+    u32 c_next;
+    if (!slow) {
+      const size_t span = (size_t)(ps.ntiles - c0) * ps.te * 4;
+      const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc((void*)(tiles + (size_t)c0 * ps.te), 0,
+                                                                         span < 0xFFFFFFF0ull ? (u32)span : 0xFFFFFFF0u, 0x00020000);
+      auto fetch = [&](u32 (&e)[Q][R][4]) {
+#pragma unroll
+        for (u32 q = 0; q < Q; q++) {
+          const u32 ci = grp + q * GROUPS;
+          const uint2 m = meta[ci];
+          const u32 len = m.y >> 16;
+          const bool beyond = m.x > hi || (m.x == hi && len);
+          const u32 j0 = m.x < lo ? lo - m.x : 0u;
+          const u32 j1 = beyond ? 0u : (hi - m.x < len ? hi - m.x : len);
+          const u32 off = ci * ps.te + (m.y & 0xFFFFu);             // relative to the image of cell c0: < 2048 * 36864 entries
+#pragma unroll
+          for (u32 r = 0; r < R; r++) {                             // a cell's image is dword-aligned, which is all a buffer load asks for
+            const u32 j = j0 + 4 * (ll + r * L);
+            const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(img, j < j1 ? (off + j) * 4u : 0xFFFFFFFFu, 0, 0);
+#pragma unroll
+            for (u32 x = 0; x < 4; x++) e[q][r][x] = j + x < j1 ? v[x] : 0u;      // the image goes on with other bins' entries
+          }
+        }
+      };
+      {
+        u32 e[Q][R][4];
+        fetch(e);
+        STAMP(b == 100 && t == 0 && k < 8, k * 16 + 3);
+#pragma unroll
+        for (u32 q = 0; q < Q; q++)
+#pragma unroll
+          for (u32 r = 0; r < R; r++)
+#pragma unroll
+            for (u32 x = 0; x < 4; x++) {
+              const u32 en = e[q][r][x];
+              atomicAdd(&hist[en ? (en >> TE_FINE) & (PART_MAX_FINE - 1u) : dummy], 1u);      // an entry: its fine bucket; 0: the lane's dummy counter
+            }
+      }
+      tails([&](u32 en, u32) { atomicAdd(&hist[(en >> TE_FINE) & (PART_MAX_FINE - 1u)], 1u); });
+      c_next = between();
+      {
+        u32 e[Q][R][4];
+        fetch(e);
+        STAMP(b == 100 && t == 0 && k < 8, k * 16 + 7);
+#pragma unroll
+        for (u32 q = 0; q < Q; q++) {
+          const u32 ibase = (c0 + grp + q * GROUPS) * ps.tile;      // the tile of a cell completes the point index
+#pragma unroll
+          for (u32 r = 0; r < R; r++)
+#pragma unroll
+            for (u32 x = 0; x < 4; x++) {
+              const u32 en = e[q][r][x];
+              const u32 pos = atomicAdd(&hist[en ? (en >> TE_FINE) & (PART_MAX_FINE - 1u) : dummy], 1u);
+              pay[en ? pos : C2_CAP + (t & 63u)] = chunk_payload(en, ibase, s.stride);
+            }
+          __builtin_amdgcn_sched_barrier(0);                // a cell's returning atomics in flight, not 64
+        }
+      }
+      tails([&](u32 en, u32 ibase) {
+        const u32 pos = atomicAdd(&hist[(en >> TE_FINE) & (PART_MAX_FINE - 1u)], 1u);
+        pay[pos] = chunk_payload(en, ibase, s.stride);
+      });
+    } else {
+      chunk_slow<0>(tiles, cm, ps, s.stride, c0, lo, hi, hist, pay, &sh_next);
+      c_next = between();
+      chunk_slow<1>(tiles, cm, ps, s.stride, c0, lo, hi, hist, pay, &sh_next);
+    }
+    STAMP(b == 100 && t == 0 && k < 8, k * 16 + 8);
+    lds_barrier();
+    STAMP(b == 100 && t == 0 && k < 8, k * 16 + 9);
     u32* dst = sorted + bm.img_base + lo;
+#pragma unroll 4
     for (u32 q = t; q < hi - lo; q += C2_THREADS) dst[q] = pay[q];
+    STAMP(b == 100 && t == 0 && k < 8, k * 16 + 10);
     c0 = c_next;
   }
-  __syncthreads();
-  for (u32 f = t; f < nf; f += C2_THREADS) {
-    const u32 g = (b << ps.shift) + f;
-    if (g < nbuckets_total) bucket_counts[g] = tot[f];
+#pragma unroll
+  for (u32 i = 0; i < NFT; i++) {
+    const u32 f = t + i * C2_THREADS, g = part_bucket(ps, b, f);
+    if (f < nf && g < nbuckets_total) {
+      bucket_counts[g] = tot[i];
+      segtab[g] = v4u_t{seg[i][0], seg[i][1], seg[i][2], seg[i][3]};
+    }
   }
 }
 
 // ---- the bucket kernels' view of the sorted pairs ----------------------------------------------------------------------------------
-// Bucket t = bin << shift | f owns, in chunk c of its bin, the entries [off[f], off[f + 1]) of the image at img_base + c * C2_CAP, where
-// off = segoff + (chunk_first + c) * seg_stride. The walker keeps the NEXT segment's pair of offsets loaded one step ahead: its loads
-// travel with the entry load of the current segment, so a bucket's walk adds no dependent memory access to the loop.
+// Bucket t of bin b, fine index f, owns in chunk c of its bin the entries [first, end) of the image at img_base + c * C2_CAP, where
+// first | end << 16 = segtab[t][c] for c < SEG_INLINE and segoff[(chunk_first + c) * nf + f] beyond (bins of more than SEG_INLINE chunks:
+// skewed scalars, or more than ~2^25 pairs per bin count). The walker holds the bucket's next four words in registers: a bucket's walk
+// adds no memory access to the loop for uniform scalars.
 struct SortView {
   const u32* sorted;
   const BinMeta* bins;
-  const u16* segoff;
-  u32 shift, seg_stride;
+  const v4u_t* segtab;
+  const u32* segoff;
+  PartShape ps;
 };
 struct SegWalker {
   u32 pos, left;        // next entry of the current segment, entries left in it
-  u32 nx_s, nx_e;       // offsets of the next segment (prefetched)
-  u32 c, nch;           // chunks consumed (incl. the prefetched one), chunks of the bin
-  u32 img_base, o;      // image base of the bin in `sorted`; index of this bucket's offset pair of chunk 0 in `segoff`
+  u32 w0, w1, w2, w3;   // the next segment words
+  u32 c, nch;           // chunks consumed, chunks of the bin
+  u32 img_base, o;      // image base of the bin in `sorted`; index of this bucket's word of chunk 0 in the chunk-major table
 };
 KDEV void seg_init(SegWalker& w, const SortView& v, u32 t) {
-  const BinMeta bm = v.bins[t >> v.shift];
+  const BinMeta bm = v.bins[part_bin(v.ps, t)];
+  const v4u_t sw = v.segtab[t];
+  w.w0 = sw[0]; w.w1 = sw[1]; w.w2 = sw[2]; w.w3 = sw[3];
   w.img_base = bm.img_base;
-  w.o = bm.chunk_first * v.seg_stride + (t & ((1u << v.shift) - 1u));
+  w.o = bm.chunk_first * v.ps.nf + part_fine(v.ps, t);
   w.nch = bm.nch;
-  w.c = 0; w.left = 0; w.pos = 0; w.nx_s = 0; w.nx_e = 0;
-  if (w.nch) { w.nx_s = v.segoff[w.o]; w.nx_e = v.segoff[w.o + 1]; }
+  w.c = 0; w.left = 0; w.pos = 0;
 }
 // next entry of the bucket; the caller asks for exactly counts[t] of them
 KDEV u32 seg_next(SegWalker& w, const SortView& v) {
   if (w.left == 0) {
     u32 s, e, ci;
     do {
-      s = w.nx_s; e = w.nx_e; ci = w.c;
+      s = w.w0 & 0xFFFFu; e = w.w0 >> 16; ci = w.c;
+      w.w0 = w.w1; w.w1 = w.w2; w.w2 = w.w3;
+      w.w3 = w.c + SEG_INLINE < w.nch ? v.segoff[w.o + (w.c + SEG_INLINE) * v.ps.nf] : 0u;
       w.c++;
-      if (w.c < w.nch) {
-        const u32 oo = w.o + w.c * v.seg_stride;
-        w.nx_s = v.segoff[oo]; w.nx_e = v.segoff[oo + 1];
-      } else {
-        w.nx_s = 0; w.nx_e = 0;
-      }
     } while (e == s && w.c <= w.nch);
     w.pos = w.img_base + ci * C2_CAP + s;
     w.left = e - s;
   }
   w.left--;
   return v.sorted[w.pos++];
+}
+// segment word of bucket t in chunk c (random access: the heavy-bucket kernel)
+KDEV u32 seg_word(const SortView& v, u32 t, const BinMeta& bm, u32 c) {
+  if (c < SEG_INLINE) return ((const u32*)v.segtab)[(size_t)t * SEG_INLINE + c];
+  return v.segoff[(size_t)(bm.chunk_first + c) * v.ps.nf + part_fine(v.ps, t)];
 }
 
 // block-wide exclusive scan of one value per lane, 256 lanes
@@ -525,14 +797,13 @@ __global__ void __launch_bounds__(256) k_msm_heavy(const Aff<F>* __restrict__ po
     const u32 t = hv_bucket[slot];
     const u32 cnt = counts[t];
     const u32 lo = (sid - hv_first[slot]) * HEAVY_SLICE, hi = min(cnt, lo + HEAVY_SLICE);
-    const BinMeta bm = v.bins[t >> v.shift];
-    const u32 o = bm.chunk_first * v.seg_stride + (t & ((1u << v.shift) - 1u));
+    const BinMeta bm = v.bins[part_bin(v.ps, t)];
     Xyzz<F> acc = xyzz_inf<F>();
     u32 vbase = 0;                                                    // pairs of the bucket in the chunks before cb
     for (u32 cb = 0; cb < bm.nch && vbase < hi; cb += 256) {
       const u32 c = cb + threadIdx.x;
       u32 s = 0, e = 0;
-      if (c < bm.nch) { s = v.segoff[o + c * v.seg_stride]; e = v.segoff[o + c * v.seg_stride + 1]; }
+      if (c < bm.nch) { const u32 se = seg_word(v, t, bm, c); s = se & 0xFFFFu; e = se >> 16; }
       const u32 len = e - s;
       u32 tot;
       const u32 v0 = vbase + block_exclusive_scan(len, &tot), v1 = v0 + len;
@@ -620,7 +891,6 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const Aff<F>* __restrict
 // One 64-byte table row. A plain load makes the vector L1 fill the whole 128-byte line the row sits in: two 64-byte requests to L2 per
 // row, the second one for a neighbour row nobody wants (profiles/r03_msm_2p24_l2_counters.json: 404.9 M L1->L2 read requests for 201.3 M
 // rows, 1.48 fabric requests per row). NT = 1: non-temporal loads (the rows are used exactly once).
-typedef u32 v4u_t __attribute__((ext_vector_type(4)));
 template <int NT>
 KDEV Aff<Fq> msm_load_row(const Aff<Fq>* __restrict__ p) {
   if constexpr (NT == 0) {

@@ -68,37 +68,62 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   }
   PartShape ps;
   if (!part_make_shape(n, s.W, nb, &ps, ctx->tune.part_shift))
-    return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: %zu buckets / %u windows exceed the partition's LDS budget (window too large)", nb, s.W);
+    return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: %zu buckets / %u windows exceed the bucket sort's LDS budget (window too large)", nb, s.W);
   const size_t pairs = n * (size_t)s.W;
   const size_t max_chunks = part_max_chunks(pairs, ps.nbins);
-  // pass-1 images | bucket-ordered index stream | per-bucket counts | per-chunk bucket offsets (u16)
+  // pass-1 images | bucket-ordered index stream | per-bucket counts | chunk-major segment words of the chunks beyond SEG_INLINE
   ST_TRY(reserve(ctx, ctx->digits, (size_t)ps.ntiles * ps.te * 4));
   ST_TRY(reserve(ctx, ctx->sorted, pairs * 4));
   ST_TRY(reserve(ctx, ctx->hist, nb * 4));
-  ST_TRY(reserve(ctx, ctx->offsets, max_chunks * ps.seg_stride * 2));
-  // [cell table: (position in the bin, start | length in the tile) per bin and tile | bin totals | bin descriptors | tile starts (u16)]
+  ST_TRY(reserve(ctx, ctx->offsets, max_chunks * ps.nf * 4));
+  // [cell table: (position in the bin, start | length in the tile) per bin and tile | bin totals | bin descriptors | bucket-major segment
+  //  words | tile starts (u16)]
   const size_t cm_bytes = (size_t)ps.nbins * ps.ntiles * sizeof(uint2);
   const size_t bt_bytes = ((size_t)ps.nbins * 4 + 15) & ~(size_t)15, bm_bytes = (size_t)ps.nbins * sizeof(BinMeta);
-  const size_t ts_bytes = (size_t)ps.ntiles * (ps.nbins + 1) * 2;
-  ST_TRY(reserve(ctx, ctx->cursor, cm_bytes + bt_bytes + bm_bytes + ts_bytes));
+  const size_t sg_bytes = nb * sizeof(v4u_t), ts_bytes = (size_t)ps.ntiles * (ps.nbins + 1) * 2;
+  ST_TRY(reserve(ctx, ctx->cursor, cm_bytes + bt_bytes + bm_bytes + sg_bytes + ts_bytes));
   ST_TRY(reserve(ctx, ctx->buckets, nb * sizeof(Xyzz<F>)));
   ST_TRY(reserve(ctx, ctx->partials, ((size_t)rs.W * chunks + (size_t)rs.W * 256) * sizeof(Xyzz<F>)));
   u32 *tiles = (u32*)ctx->digits.p, *sorted = (u32*)ctx->sorted.p, *hist = (u32*)ctx->hist.p;
-  u16* segoff = (u16*)ctx->offsets.p;
+  u32* segoff = (u32*)ctx->offsets.p;
   uint2* cellmeta = (uint2*)ctx->cursor.p;
   u32* bin_total = (u32*)((char*)ctx->cursor.p + cm_bytes);
   BinMeta* bins = (BinMeta*)((char*)bin_total + bt_bytes);
-  u16* tstart = (u16*)((char*)bins + bm_bytes);
+  v4u_t* segtab = (v4u_t*)((char*)bins + bm_bytes);
+  u16* tstart = (u16*)((char*)segtab + sg_bytes);
   Xyzz<F>* buckets = (Xyzz<F>*)ctx->buckets.p;
   Xyzz<F>* partials = (Xyzz<F>*)ctx->partials.p;
-  hipLaunchKernelGGL(k_tile_sort, dim3(ps.ntiles), dim3(T1_THREADS), 0, st, (const Fr*)d_scalars, s, ps, tiles, tstart);
+  {
+    const dim3 g1(ps.ntiles < ctx->n_cu ? ps.ntiles : ctx->n_cu), b1(T1_THREADS);
+#define KEAKI_TILE_SORT(WS) hipLaunchKernelGGL(k_tile_sort<WS>, g1, b1, 0, st, (const Fr*)d_scalars, s, ps, tiles, tstart)
+    switch (s.W) {                    // plans with 11..16 windows (what 2^16..2^26 points choose) have their digit cuts compiled in
+      case 11: KEAKI_TILE_SORT(11); break;
+      case 12: KEAKI_TILE_SORT(12); break;
+      case 13: KEAKI_TILE_SORT(13); break;
+      case 14: KEAKI_TILE_SORT(14); break;
+      case 15: KEAKI_TILE_SORT(15); break;
+      case 16: KEAKI_TILE_SORT(16); break;
+      default: KEAKI_TILE_SORT(0); break;
+    }
+#undef KEAKI_TILE_SORT
+  }
   ST_TRY(launch_check(ctx, "tile_sort"));
   hipLaunchKernelGGL(k_cell_prefix, dim3(ps.nbins), dim3(1024), 0, st, (const u16*)tstart, ps, cellmeta, bin_total);
   hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, (const u32*)bin_total, ps.nbins, bins);
-  hipLaunchKernelGGL(k_chunk_sort, dim3(ps.nbins), dim3(C2_THREADS), 0, st, (const u32*)tiles, (const uint2*)cellmeta, (const BinMeta*)bins, s, ps, (u32)nb,
-                     sorted, segoff, hist);
+  {
+#define KEAKI_CHUNK_SORT(L, R, Q)                                                                                                                       \
+  hipLaunchKernelGGL((k_chunk_sort<L, R, Q>), dim3(ps.nbins), dim3(C2_THREADS), 0, st, (const u32*)tiles, (const uint2*)cellmeta, (const BinMeta*)bins, s, \
+                     ps, (u32)nb, sorted, segtab, segoff, hist)
+    switch (ps.geom) {                // lanes per cell, 16-byte pieces per lane and cell, cells per group: for cells of about 18 / 36 / 72 / 144+ entries
+      case 0: KEAKI_CHUNK_SORT(8, 1, 16); break;
+      case 1: KEAKI_CHUNK_SORT(16, 1, 16); break;
+      case 2: KEAKI_CHUNK_SORT(16, 2, 8); break;
+      default: KEAKI_CHUNK_SORT(16, 4, 4); break;
+    }
+#undef KEAKI_CHUNK_SORT
+  }
   ST_TRY(launch_check(ctx, "chunk_sort"));
-  const SortView view = {sorted, bins, segoff, ps.shift, ps.seg_stride};
+  const SortView view = {sorted, bins, segtab, segoff, ps};
   // bucket schedule: descending size
   ST_TRY(reserve(ctx, ctx->perm, nb * 4 + 2 * CNT_BINS * 4 + sizeof(HeavyList)));
   u32* perm = (u32*)ctx->perm.p;

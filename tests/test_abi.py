@@ -156,11 +156,11 @@ def test_host_scalar_field_and_domain(py):
 
 
 def test_committed_isa_counts_belong_to_this_tree():
-    """profiles/r03_accumulate_isa.json (bench.py's `alu` diagnostic reads it) must have been made from the kernel sources of this tree:
+    """profiles/r04_accumulate_isa.json (bench.py's `alu` diagnostic reads it) must have been made from the kernel sources of this tree:
     re-run `python bench_tools/count_isa.py` after touching the MSM kernels."""
     import json
     from bench_tools.srchash import source_hash, MSM_KERNEL_SOURCES
-    j = json.load(open(os.path.join(ROOT, "profiles", "r03_accumulate_isa.json")))
+    j = json.load(open(os.path.join(ROOT, "profiles", "r04_accumulate_isa.json")))
     assert j["kernel_source_sha256"] == source_hash(MSM_KERNEL_SOURCES), "stale: run python bench_tools/count_isa.py"
     assert j["registers"].get("private_seg_size", 0) == 0, "the bucket kernel must not spill"
     assert 1500 < j["loop_instructions"] < 4000 and j["loop_v_mad_u64_u32"] > 1000
