@@ -27,7 +27,7 @@ struct Tuning {
   int msm_c = 0;                 // KEAKI_MSM_C / "msm_c": window bits of the generic MSM, 0 = choose_window
   int msm_c_shared = 0;          // KEAKI_MSM_C_SHARED / "msm_c_shared": window target of the SRS window tables, 0 = choose_window_shared
   int reduce_l = 0;              // KEAKI_REDUCE_L / "reduce_l": chunk length of the bucket reduction, 0 = automatic
-  int part_shift = -1;           // KEAKI_PART_SHIFT / "part_shift": fine bits of the bucket sort (buckets per bin = 2^shift), -1 = automatic
+  int part_shift = -1;           // KEAKI_PART_SHIFT / "part_shift": log2 of the bucket sort's bin count, -1 = automatic
   bool acc_u29 = true;           // KEAKI_ACC_U29 / "acc_u29": G1 bucket kernel in the 29-bit lazy limbs (A/B switch for profiling)
   bool acc_u29_g2 = true;        // KEAKI_ACC_U29_G2 / "acc_u29_g2"
   bool acc_nt = false;           // KEAKI_ACC_NT / "acc_nt": non-temporal loads of the table rows in the G1 bucket kernel

@@ -189,8 +189,12 @@ inline bool part_make_shape(size_t n, u32 W, size_t nb, PartShape* ps, int lb_ov
   u32 lg = 0;
   while (((size_t)1 << lg) < nb) lg++;
   const size_t pairs = n * (size_t)W;
-  u32 lb = 0;                                                   // about one chunk per bin where the input allows: one segment per bucket
-  while (lb < 11 && ((size_t)C2_CAP << lb) < pairs) lb++;
+  // about one chunk per bin where the input allows (one segment per bucket), at most 1024 bins below 2^28 pairs: measured at 2^24 points, 1024
+  // bins (six segments per bucket, 36-entry cells) against 2048 (three, 18): pass 2 0.84 vs 0.95 ms, cell table 0.055 vs 0.10 ms, bucket
+  // kernel +0.06 ms
+  const u32 lb_max = pairs > ((size_t)C2_CAP << 13) ? 11u : 10u;
+  u32 lb = 0;
+  while (lb < lb_max && ((size_t)C2_CAP << lb) < pairs) lb++;
   if (lb_override >= 0 && lb_override <= 11) lb = (u32)lb_override;
   if (lb > lg) lb = lg;
   if (lg - lb > PART_MAX_FINE_SHIFT) lb = lg - PART_MAX_FINE_SHIFT;
@@ -393,11 +397,14 @@ static __global__ void __launch_bounds__(1024) k_bin_scan(const u32* __restrict_
 // the descriptors of its cells come in with coalesced loads -- requested while the previous chunk is still being scanned and placed -- and go
 // through LDS to the groups of L lanes that own a cell each; then every lane requests R 16-byte pieces (4 entries each) of each of its
 // group's Q cells at once, through a buffer descriptor (one offset register per load; a slot without entries asks for an offset out of
-// range and gets zeros). The placing pass asks again (from L2): kept in registers across the scan the entries were spilled.
-// The gather shape <L, R, Q> follows the expected cell length te / nbins (PartShape::geom): a cell holds up to 4 L R entries, a chunk up to
-// Q * 1024 / L cells. Longer cells go on a short list whose tails all lanes walk together; a chunk with more cells, or a list that
-// overflows, takes chunk_slow for both passes: the plain walk, cell after cell (skewed scalars only).
-constexpr u32 C2_META = 2048, C2_OVF = 64;
+// range and gets zeros). The placing pass asks again (L2): kept in registers across the scan the entries were spilled.
+// The gather shape <L, R, Q> follows the expected cell length te / nbins (PartShape::geom): a group's slots hold 4 L R entries of a cell,
+// a chunk up to Q * 1024 / L cells. The tail of a longer cell is fetched by its own group in a (divergent, rare) loop; a chunk with more
+// cells takes chunk_slow for both passes: the plain walk, cell after cell (skewed scalars only).
+// Five LDS-only barriers per chunk; the empty slots of the branch-free loops go to one dummy word PER LANE (hist[PART_MAX_FINE + lane],
+// pay[C2_CAP + lane]): LDS atomics of a wave to one address are executed one after the other -- with a single dummy counter the ~40 %
+// empty slots of a wave instruction cost ~60 cycles instead of 7, and both passes ran at a tenth of their speed.
+constexpr u32 C2_META = 2048;
 KDEV u32 chunk_payload(u32 en, u32 ibase, u32 stride) {
   return (((en >> TE_SIGN) & 1u) << 31) | (ibase + (en & ((1u << TE_WPOS) - 1u)) + ((en >> TE_WPOS) & ((1u << (TE_SIGN - TE_WPOS)) - 1u)) * stride);
 }
@@ -429,188 +436,198 @@ static __global__ void __launch_bounds__(C2_THREADS) k_chunk_sort(const u32* __r
                                                                   const BinMeta* __restrict__ bins, MsmShape s, PartShape ps, u32 nbuckets_total,
                                                                   u32* __restrict__ sorted, v4u_t* __restrict__ segtab, u32* __restrict__ segoff,
                                                                   u32* __restrict__ bucket_counts) {
-  constexpr u32 GROUPS = C2_THREADS / L, CELLS = GROUPS * Q, CAPC = 4 * L * R, NFT = PART_MAX_FINE / C2_THREADS;
-  static_assert(CELLS <= C2_META && Q * R * 4 <= 64, "gather shape");
-  // [C2_CAP + lane], hist[PART_MAX_FINE + lane]: where the empty slots of the branch-free loops go. One word PER LANE: LDS atomics of a wave to
-  // one address are executed one after the other (with a single dummy counter the ~40 % empty slots of a wave instruction cost ~60 cycles
-  // instead of 7, and the counting and placing passes ran at a tenth of their speed)
+  constexpr u32 GROUPS = C2_THREADS / L, CELLS = GROUPS * Q, CAPC = 4 * L * R, NB = 4, QB = Q / NB;
+  static_assert(CELLS <= C2_META && Q * R * 4 <= 64 && Q <= 32 && Q % NB == 0 && PART_MAX_FINE == 2 * C2_THREADS, "gather shape");
   __shared__ u32 pay[C2_CAP + 64];
   __shared__ uint2 meta[C2_META];
   __shared__ u32 hist[PART_MAX_FINE + 64];
-  __shared__ u32 ovf[C2_OVF];
   __shared__ u32 wsum[C2_THREADS / 64];
-  __shared__ u32 sh_next, sh_novf, sh_odd;
+  __shared__ u32 sh_next, sh_odd;
   const u32 b = blockIdx.x, t = threadIdx.x, nf = ps.nf;
   const BinMeta bm = bins[b];
   const uint2* cm = cellmeta + (size_t)b * ps.ntiles;
-  u32 tot[NFT];                                             // the bin's per-bucket totals: buckets t, t + 1024 of this lane
-  u32 seg[NFT][SEG_INLINE];                                 // and their first SEG_INLINE segment words
-#pragma unroll
-  for (u32 i = 0; i < NFT; i++) {
-    tot[i] = 0;
-#pragma unroll
-    for (u32 k = 0; k < SEG_INLINE; k++) seg[i][k] = 0;
-  }
+  u32 tot[2] = {0, 0};                                      // the bin's per-bucket totals: buckets 2 t, 2 t + 1 of this lane
+  u32 seg[2][SEG_INLINE] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // and their first SEG_INLINE segment words
   u32 c0 = 0;                                               // first cell that reaches into the chunk
-  uint2 mnext[C2_META / C2_THREADS];
+  // prologue: counters cleared, descriptors of the first chunk's cells staged
+  for (u32 f = t; f < PART_MAX_FINE + 64; f += C2_THREADS) hist[f] = 0;
 #pragma unroll
-  for (u32 i = 0; i < C2_META / C2_THREADS; i++) mnext[i] = t + i * C2_THREADS < ps.ntiles && t + i * C2_THREADS < CELLS ? cm[t + i * C2_THREADS] : make_uint2(0xFFFFFFFFu, 0u);
+  for (u32 i = 0; i < C2_META / C2_THREADS; i++) {
+    const u32 ci = t + i * C2_THREADS;
+    if (ci < CELLS) meta[ci] = ci < ps.ntiles ? cm[ci] : make_uint2(0xFFFFFFFFu, 0u);
+  }
+  if (t == 0) { sh_next = ps.ntiles; sh_odd = 0; }
+  lds_barrier();
   for (u32 k = 0; k < bm.nch; k++) {
     const u32 lo = k * C2_CAP, hi = bm.total - lo < C2_CAP ? bm.total : lo + C2_CAP;
     u32 tk = t;
     asm volatile("" : "+v"(tk));                            // per-cell invariants are re-formed per chunk, not kept (and spilled) across it
     const u32 grp = tk / L, ll = tk % L, dummy = PART_MAX_FINE + (tk & 63u);
     STAMP(b == 100 && t == 0 && k < 8, k * 16 + 0);
-    for (u32 f = t; f < nf; f += C2_THREADS) hist[f] = 0;
+    const size_t span = (size_t)(ps.ntiles - c0) * ps.te * 4;
+    const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc((void*)(tiles + (size_t)c0 * ps.te), 0,
+                                                                       span < 0xFFFFFFF0ull ? (u32)span : 0xFFFFFFF0u, 0x00020000);
+    // the entries of the group's cells; which cells are longer than the group's slots; which cell opens the next chunk; more cells than the shape holds?
+    auto fetch = [&](u32 tt, u32 q0, u32 (&e)[QB][R][4], u32& longcells, u32& cand, bool& odd) {
+      const u32 grp = tt / L, ll = tt % L;
 #pragma unroll
-    for (u32 i = 0; i < C2_META / C2_THREADS; i++) if (t + i * C2_THREADS < CELLS) meta[t + i * C2_THREADS] = mnext[i];      // descriptor of cell c0 + index
-    if (t == 0) { sh_next = ps.ntiles; sh_novf = 0; sh_odd = 0; }
-    lds_barrier();
-    STAMP(b == 100 && t == 0 && k < 8, k * 16 + 1);
-    // does the chunk fit the gather shape? which cells are longer than a group's slots? which cell opens the next chunk?
-    bool odd = false;
-    u32 cand = ps.ntiles;
+      for (u32 qq = 0; qq < QB; qq++) {
+        const u32 q = q0 + qq;
+        const u32 ci = grp + q * GROUPS;
+        const uint2 m = meta[ci];
+        const u32 len = m.y >> 16;
+        const bool beyond = m.x > hi || (m.x == hi && len);         // (an EMPTY cell that sits exactly at the chunk's end is stepped over)
+        if (m.x != 0xFFFFFFFFu && m.x + len > hi && c0 + ci < cand) cand = c0 + ci;
+        const u32 j0 = m.x < lo ? lo - m.x : 0u;
+        const u32 j1 = beyond ? 0u : (hi - m.x < len ? hi - m.x : len);
+        const u32 off = ci * ps.te + (m.y & 0xFFFFu);               // relative to the image of cell c0: < 2048 * 36864 entries
 #pragma unroll
-    for (u32 q = 0; q < Q; q++) {
-      const u32 ci = grp + q * GROUPS;
-      const uint2 m = meta[ci];
-      const u32 len = m.y >> 16;
-      const bool beyond = m.x > hi || (m.x == hi && len);           // (an EMPTY cell that sits exactly at the chunk's end is stepped over)
-      if (m.x != 0xFFFFFFFFu && m.x + len > hi && c0 + ci < cand) cand = c0 + ci;
-      const u32 j0 = m.x < lo ? lo - m.x : 0u;
-      const u32 j1 = beyond ? 0u : (hi - m.x < len ? hi - m.x : len);
-      if (j1 > j0 + CAPC && ll == 0) {
-        const u32 slot = atomicAdd(&sh_novf, 1u);
-        if (slot < C2_OVF) ovf[slot] = ci;
+        for (u32 r = 0; r < R; r++) {                               // a cell's image is dword-aligned, which is all a buffer load asks for
+          const u32 j = j0 + 4 * (ll + r * L);
+          const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(img, j < j1 ? (off + j) * 4u : 0xFFFFFFFFu, 0, 0);
+#pragma unroll
+          for (u32 x = 0; x < 4; x++) e[qq][r][x] = j + x < j1 ? v[x] : 0u;     // the image goes on with other bins' entries
+        }
+        if (j1 > j0 + CAPC) longcells |= 1u << q;
+        if (q == Q - 1) odd = !beyond && m.x != 0xFFFFFFFFu;
       }
-      if (q == Q - 1) odd |= !beyond && m.x != 0xFFFFFFFFu;         // more cells than the shape holds
-    }
-    if (ll == 0 && cand < ps.ntiles) atomicMin(&sh_next, cand);
-    if (odd) sh_odd = 1;
-    lds_barrier();
-    const u32 novf = sh_novf;
-    const bool slow = sh_odd != 0 || novf > C2_OVF;
-    STAMP(b == 100 && t == 0 && k < 8, k * 16 + 2);
-    // the tails of the long cells, all lanes together
-    auto tails = [&](auto use) {
-      for (u32 i = 0; i < novf; i++) {
-        const u32 ci = ovf[i];
+    };
+    // the tails of the group's long cells (rare; the group alone)
+    auto tails = [&](u32 longcells, auto use) {
+      while (longcells) {
+        const u32 q = __builtin_ctz(longcells);
+        longcells &= longcells - 1u;
+        const u32 ci = grp + q * GROUPS;
         const uint2 m = meta[ci];
         const u32 len = m.y >> 16;
         const u32 j0 = m.x < lo ? lo - m.x : 0u, j1 = hi - m.x < len ? hi - m.x : len;
         const u32* src = tiles + (size_t)(c0 + ci) * ps.te + (m.y & 0xFFFFu);
-        for (u32 j = j0 + CAPC + t; j < j1; j += C2_THREADS) use(src[j], (c0 + ci) * ps.tile);
+        for (u32 j = j0 + CAPC + ll; j < j1; j += L) use(src[j], (c0 + ci) * ps.tile);
       }
     };
-    // after the counting pass: the next chunk's descriptors, the totals, the scan, the chunk's bucket offsets
-    auto between = [&]() {
-      STAMP(b == 100 && t == 0 && k < 8, k * 16 + 4);
-      lds_barrier();
-      STAMP(b == 100 && t == 0 && k < 8, k * 16 + 5);
-      const u32 c_next = sh_next;
-      if (k + 1 < bm.nch) {                                 // in flight under the scan and the placing pass
+    u32 longcells = 0;
+    {
+      u32 cand = ps.ntiles;
+      bool odd = false;
+      // in batches of QB cells, the next batch's loads in flight while this one's are counted (64 entry registers at once were spilled)
+      u32 ea[QB][R][4], eb[QB][R][4];
+      u32 th = t;
+      asm volatile("" : "+v"(th));
+      fetch(th, 0, ea, longcells, cand, odd);
+      STAMP(b == 100 && t == 0 && k < 8, k * 16 + 1);
 #pragma unroll
-        for (u32 i = 0; i < C2_META / C2_THREADS; i++) {
-          const u32 ci = t + i * C2_THREADS;
-          mnext[i] = ci < CELLS && c_next + ci < ps.ntiles ? cm[c_next + ci] : make_uint2(0xFFFFFFFFu, 0u);
-        }
-      }
+      for (u32 h = 0; h < NB; h++) {
+        u32 (&cur)[QB][R][4] = h % 2 ? eb : ea;
+        if (h + 1 < NB) fetch(th, (h + 1) * QB, h % 2 ? ea : eb, longcells, cand, odd);
 #pragma unroll
-      for (u32 i = 0; i < NFT; i++) if (t + i * C2_THREADS < nf) tot[i] += hist[t + i * C2_THREADS];
-      lds_exclusive_scan4(hist, nf, wsum);                  // hist[f] = first position of bucket f inside the chunk
-#pragma unroll
-      for (u32 i = 0; i < NFT; i++) {
-        const u32 f = t + i * C2_THREADS;
-        if (f < nf) {
-          const u32 word = hist[f] | ((f + 1 < nf ? hist[f + 1] : hi - lo) << 16);      // <= 32768 each
-#pragma unroll
-          for (u32 kk = 0; kk < SEG_INLINE; kk++) if (kk == k) seg[i][kk] = word;
-          if (k >= SEG_INLINE) segoff[(size_t)(bm.chunk_first + k) * nf + f] = word;
-        }
-      }
-      lds_barrier();
-      STAMP(b == 100 && t == 0 && k < 8, k * 16 + 6);
-      return c_next;
-    };
-    u32 c_next;
-    if (!slow) {
-      const size_t span = (size_t)(ps.ntiles - c0) * ps.te * 4;
-      const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc((void*)(tiles + (size_t)c0 * ps.te), 0,
-                                                                         span < 0xFFFFFFF0ull ? (u32)span : 0xFFFFFFF0u, 0x00020000);
-      auto fetch = [&](u32 (&e)[Q][R][4]) {
-#pragma unroll
-        for (u32 q = 0; q < Q; q++) {
-          const u32 ci = grp + q * GROUPS;
-          const uint2 m = meta[ci];
-          const u32 len = m.y >> 16;
-          const bool beyond = m.x > hi || (m.x == hi && len);
-          const u32 j0 = m.x < lo ? lo - m.x : 0u;
-          const u32 j1 = beyond ? 0u : (hi - m.x < len ? hi - m.x : len);
-          const u32 off = ci * ps.te + (m.y & 0xFFFFu);             // relative to the image of cell c0: < 2048 * 36864 entries
-#pragma unroll
-          for (u32 r = 0; r < R; r++) {                             // a cell's image is dword-aligned, which is all a buffer load asks for
-            const u32 j = j0 + 4 * (ll + r * L);
-            const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(img, j < j1 ? (off + j) * 4u : 0xFFFFFFFFu, 0, 0);
-#pragma unroll
-            for (u32 x = 0; x < 4; x++) e[q][r][x] = j + x < j1 ? v[x] : 0u;      // the image goes on with other bins' entries
-          }
-        }
-      };
-      {
-        u32 e[Q][R][4];
-        fetch(e);
-        STAMP(b == 100 && t == 0 && k < 8, k * 16 + 3);
-#pragma unroll
-        for (u32 q = 0; q < Q; q++)
+        for (u32 q = 0; q < QB; q++)
 #pragma unroll
           for (u32 r = 0; r < R; r++)
 #pragma unroll
             for (u32 x = 0; x < 4; x++) {
-              const u32 en = e[q][r][x];
-              atomicAdd(&hist[en ? (en >> TE_FINE) & (PART_MAX_FINE - 1u) : dummy], 1u);      // an entry: its fine bucket; 0: the lane's dummy counter
+              const u32 en = cur[q][r][x];
+              atomicAdd(&hist[en ? (en >> TE_FINE) & (PART_MAX_FINE - 1u) : dummy], 1u);    // an entry: its fine bucket; 0: the lane's dummy counter
             }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      tails([&](u32 en, u32) { atomicAdd(&hist[(en >> TE_FINE) & (PART_MAX_FINE - 1u)], 1u); });
-      c_next = between();
-      {
-        u32 e[Q][R][4];
-        fetch(e);
-        STAMP(b == 100 && t == 0 && k < 8, k * 16 + 7);
+      tails(longcells, [&](u32 en, u32) { atomicAdd(&hist[(en >> TE_FINE) & (PART_MAX_FINE - 1u)], 1u); });
+      if (ll == 0 && cand < ps.ntiles) atomicMin(&sh_next, cand);
+      if (odd) sh_odd = 1;
+    }
+    STAMP(b == 100 && t == 0 && k < 8, k * 16 + 2);
+    lds_barrier();                                                                                  // ---- 1: counts complete
+    STAMP(b == 100 && t == 0 && k < 8, k * 16 + 3);
+    const bool slow = sh_odd != 0;
+    if (slow) {                                             // count again, the plain way
+      lds_barrier();
+      for (u32 f = t; f < nf; f += C2_THREADS) hist[f] = 0;
+      lds_barrier();
+      chunk_slow<0>(tiles, cm, ps, s.stride, c0, lo, hi, hist, pay, &sh_next);
+      lds_barrier();
+    }
+    const u32 c_next = sh_next;
+    uint2 mnext[C2_META / C2_THREADS];
+    if (k + 1 < bm.nch) {                                   // the next chunk's descriptors: in flight under the scan and the placing pass
 #pragma unroll
-        for (u32 q = 0; q < Q; q++) {
-          const u32 ibase = (c0 + grp + q * GROUPS) * ps.tile;      // the tile of a cell completes the point index
+      for (u32 i = 0; i < C2_META / C2_THREADS; i++) {
+        const u32 ci = t + i * C2_THREADS;
+        mnext[i] = ci < CELLS && c_next + ci < ps.ntiles ? cm[c_next + ci] : make_uint2(0xFFFFFFFFu, 0u);
+      }
+    }
+    // exclusive scan of the 2048 counters: two per lane, wave scan, wave totals through LDS
+    const u32 x0 = hist[2 * t], x1 = hist[2 * t + 1], sum = x0 + x1;
+    tot[0] += x0; tot[1] += x1;
+    u32 v = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up(v, o, 64); if ((t & 63u) >= (u32)o) v += y; }
+    if ((t & 63u) == 63u) wsum[t >> 6] = v;
+    lds_barrier();                                                                                  // ---- 2: wave totals
+    u32 base = 0;
+#pragma unroll
+    for (u32 w = 0; w < C2_THREADS / 64; w++) base += w < (t >> 6) ? wsum[w] : 0u;
+    const u32 ex = base + v - sum;
+    hist[2 * t] = ex; hist[2 * t + 1] = ex + x0;            // first position of buckets 2 t, 2 t + 1 inside the chunk
+    {
+      const u32 w0 = ex | ((ex + x0) << 16), w1 = (ex + x0) | ((ex + sum) << 16);                   // first | end << 16, <= 32768 each
+#pragma unroll
+      for (u32 kk = 0; kk < SEG_INLINE; kk++) if (kk == k) { seg[0][kk] = w0; seg[1][kk] = w1; }
+      if (k >= SEG_INLINE && 2 * t < nf) { u32* so = segoff + (size_t)(bm.chunk_first + k) * nf + 2 * t; so[0] = w0; so[1] = w1; }
+    }
+    STAMP(b == 100 && t == 0 && k < 8, k * 16 + 4);
+    lds_barrier();                                                                                  // ---- 3: positions complete
+    STAMP(b == 100 && t == 0 && k < 8, k * 16 + 5);
+    if (!slow) {
+      u32 lc2 = 0, cand = 0;                                // the entries are asked for again (L2): kept across the scan they were spilled
+      bool odd = false;
+      u32 ea[QB][R][4], eb[QB][R][4];
+      u32 th = t;
+      asm volatile("" : "+v"(th));                          // (or hipcc keeps the first pass's offsets in scratch for this one)
+      fetch(th, 0, ea, lc2, cand, odd);
+#pragma unroll
+      for (u32 h = 0; h < NB; h++) {
+        u32 (&cur)[QB][R][4] = h % 2 ? eb : ea;
+        if (h + 1 < NB) fetch(th, (h + 1) * QB, h % 2 ? ea : eb, lc2, cand, odd);
+#pragma unroll
+        for (u32 q = 0; q < QB; q++) {
+          const u32 ibase = (c0 + th / L + (h * QB + q) * GROUPS) * ps.tile;     // the tile of a cell completes the point index
 #pragma unroll
           for (u32 r = 0; r < R; r++)
 #pragma unroll
             for (u32 x = 0; x < 4; x++) {
-              const u32 en = e[q][r][x];
+              const u32 en = cur[q][r][x];
               const u32 pos = atomicAdd(&hist[en ? (en >> TE_FINE) & (PART_MAX_FINE - 1u) : dummy], 1u);
               pay[en ? pos : C2_CAP + (t & 63u)] = chunk_payload(en, ibase, s.stride);
             }
-          __builtin_amdgcn_sched_barrier(0);                // a cell's returning atomics in flight, not 64
         }
+        __builtin_amdgcn_sched_barrier(0);                  // a batch's returning atomics in flight, not all
       }
-      tails([&](u32 en, u32 ibase) {
+      tails(lc2, [&](u32 en, u32 ibase) {
         const u32 pos = atomicAdd(&hist[(en >> TE_FINE) & (PART_MAX_FINE - 1u)], 1u);
         pay[pos] = chunk_payload(en, ibase, s.stride);
       });
     } else {
-      chunk_slow<0>(tiles, cm, ps, s.stride, c0, lo, hi, hist, pay, &sh_next);
-      c_next = between();
       chunk_slow<1>(tiles, cm, ps, s.stride, c0, lo, hi, hist, pay, &sh_next);
     }
-    STAMP(b == 100 && t == 0 && k < 8, k * 16 + 8);
-    lds_barrier();
-    STAMP(b == 100 && t == 0 && k < 8, k * 16 + 9);
+    STAMP(b == 100 && t == 0 && k < 8, k * 16 + 6);
+    lds_barrier();                                                                                  // ---- 4: image complete
+    STAMP(b == 100 && t == 0 && k < 8, k * 16 + 7);
     u32* dst = sorted + bm.img_base + lo;
 #pragma unroll 4
     for (u32 q = t; q < hi - lo; q += C2_THREADS) dst[q] = pay[q];
-    STAMP(b == 100 && t == 0 && k < 8, k * 16 + 10);
+    // ready the next chunk: counters cleared, descriptors staged
+    for (u32 f = t; f < PART_MAX_FINE + 64; f += C2_THREADS) hist[f] = 0;
+    if (k + 1 < bm.nch) {
+#pragma unroll
+      for (u32 i = 0; i < C2_META / C2_THREADS; i++) if (t + i * C2_THREADS < CELLS) meta[t + i * C2_THREADS] = mnext[i];
+    }
+    if (t == 0) { sh_next = ps.ntiles; sh_odd = 0; }
     c0 = c_next;
+    STAMP(b == 100 && t == 0 && k < 8, k * 16 + 8);
+    lds_barrier();                                                                                  // ---- 0 of the next chunk
   }
 #pragma unroll
-  for (u32 i = 0; i < NFT; i++) {
-    const u32 f = t + i * C2_THREADS, g = part_bucket(ps, b, f);
+  for (u32 i = 0; i < 2; i++) {
+    const u32 f = 2 * t + i, g = part_bucket(ps, b, f);
     if (f < nf && g < nbuckets_total) {
       bucket_counts[g] = tot[i];
       segtab[g] = v4u_t{seg[i][0], seg[i][1], seg[i][2], seg[i][3]};
