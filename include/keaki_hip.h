@@ -281,9 +281,13 @@ void keaki_hip_group_destroy(keaki_hip_group* g);
 size_t keaki_hip_group_size(const keaki_hip_group* g);
 keaki_hip_ctx* keaki_hip_group_ctx(const keaki_hip_group* g, size_t member);   /* member's ctx, e.g. for verify / open_fk on member 0 */
 const char* keaki_hip_group_last_error(const keaki_hip_group* g);               /* g may be NULL: last create error */
+/* keaki_hip_group_create enables peer access between every pair of distinct devices (the exchanges of the sharded FK23 are then device-to-device
+ * copies on the members' streams, ordered by events). "" when every pair has it; otherwise the pairs whose copies the runtime stages. */
+const char* keaki_hip_group_peer_note(const keaki_hip_group* g);
 /* precompute != 0: also build every chunk's window tables (KEAKI_ERR_OOM of a table is tolerated: that member runs the generic MSM) */
 keaki_status keaki_hip_group_srs_g1_upload(keaki_hip_group* g, const uint64_t* points_aff, size_t n, int32_t precompute, keaki_hip_group_srs_g1** out);
 size_t keaki_hip_group_srs_g1_len(const keaki_hip_group_srs_g1* srs);
+int32_t keaki_hip_group_srs_g1_has_tables(const keaki_hip_group_srs_g1* srs);  /* 1: every member that holds points holds their window tables */
 void keaki_hip_group_srs_g1_free(keaki_hip_group* g, keaki_hip_group_srs_g1* srs);
 keaki_status keaki_hip_group_msm_g1(keaki_hip_group* g, const keaki_hip_group_srs_g1* srs, const uint64_t* scalars, size_t n, uint64_t* out_jac);
 keaki_status keaki_hip_group_kzg_open(keaki_hip_group* g, const keaki_hip_group_srs_g1* srs, const uint64_t* coeffs, size_t n, const uint64_t* point,

@@ -20,8 +20,14 @@ keaki_status keaki_hip_rccl_unique_id(uint8_t out128[128]);
 keaki_status keaki_hip_rccl_create(keaki_hip_ctx* ctx, const uint8_t id128[128], int32_t rank, int32_t world, keaki_hip_rccl** out);
 void keaki_hip_rccl_destroy(keaki_hip_rccl* rc);
 const char* keaki_hip_rccl_last_error(const keaki_hip_rccl* rc); /* rc may be NULL: last create error */
-/* d_out_jac (96 bytes of device memory) = sum over all ranks of MSM(srs_chunk, d_scalars[0..n)): asynchronous on the ctx stream */
+/* d_out_jac (96 bytes of device memory) = sum over all ranks of MSM(srs_chunk, d_scalars[0..n)): asynchronous on the ctx stream.
+ * Failure is collective-safe: a rank whose own share fails (bad handle, out of memory) returns its error at once but STILL takes part in the
+ * exchange with the identity as its partial, so the other ranks never wait for it; they learn of it from keaki_hip_rccl_collective_status.
+ * After KEAKI_ERR_RCCL from any entry point the communicator is dead: destroy it. */
 keaki_status keaki_hip_rccl_msm_g1(keaki_hip_rccl* rc, const keaki_hip_srs_g1* srs_chunk, const void* d_scalars, size_t n, void* d_out_jac);
+/* Waits for the stream; KEAKI_OK when every rank's share of the last keaki_hip_rccl_msm_g1 succeeded, else the first failing rank's status
+ * (its index in *bad_rank unless NULL; -1 when none): d_out_jac then lacks that rank's chunk. */
+keaki_status keaki_hip_rccl_collective_status(keaki_hip_rccl* rc, int32_t* bad_rank);
 /* d_send: world chunks of bytes_per_peer, chunk q for rank q; d_recv: the chunks received, in rank order. Asynchronous on the ctx stream. */
 keaki_status keaki_hip_rccl_all_to_all(keaki_hip_rccl* rc, const void* d_send, void* d_recv, size_t bytes_per_peer);
 /* d_recv = every rank's bytes_per_rank of d_send, in rank order */

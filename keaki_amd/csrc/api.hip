@@ -4,6 +4,7 @@
 #include "internal.h"
 
 #include <algorithm>
+#include <set>
 #include <utility>
 #include <vector>
 
@@ -65,6 +66,19 @@ struct RoctxScope {
 };
 #define TRACE_SCOPE(name) RoctxScope roctx_scope_(name)
 thread_local std::string g_create_error;
+// The contexts that are alive: an SRS handle is shared by every context of its device, and whoever frees it (or rebuilds its FK23 transform)
+// must be able to undo the byte accounting on the context that built the tables -- if that context still exists.
+std::mutex g_live_mu;
+std::set<keaki_hip_ctx*> g_live_ctx;
+// runs `f(acct)` under acct's lock when acct is a live context
+template <class Fn>
+void with_live_ctx(keaki_hip_ctx* acct, Fn f) {
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  if (acct && g_live_ctx.count(acct)) {
+    std::lock_guard<std::recursive_mutex> lock_(acct->mu);
+    f(acct);
+  }
+}
 constexpr size_t G1_AFF_BYTES = 64, G2_AFF_BYTES = 128;
 }  // namespace
 
@@ -154,7 +168,9 @@ std::pair<const void*, int> srs_tables(const H* srs) {
 void fk_account(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs) {
   const size_t now = srs->fk_hat_s && srs->fk_log2d >= 0 ? ((size_t)2 << srs->fk_log2d) * 96 : 0;
   if (now == srs->fk_bytes) return;
-  if (srs->acct == ctx || !srs->acct) { srs->acct = ctx; ctx->mem_tables -= std::min(ctx->mem_tables, srs->fk_bytes); ctx->mem_tables += now; }
+  if (!srs->acct) srs->acct = ctx;
+  const size_t before = srs->fk_bytes;
+  with_live_ctx(srs->acct, [&](keaki_hip_ctx* a) { a->mem_tables -= std::min(a->mem_tables, before); a->mem_tables += now; });   // whichever context rebuilt it
   srs->fk_bytes = now;
 }
 template <class H>
@@ -258,12 +274,14 @@ keaki_status keaki_hip_ctx_create(int32_t device, void* stream, keaki_hip_ctx** 
     ctx->own_stream = true;
   }
   for (auto& e : ctx->ev) (void)hipEventCreate(&e);
+  { std::lock_guard<std::mutex> lk(g_live_mu); g_live_ctx.insert(ctx); }
   *out = ctx;
   return KEAKI_OK;
 }
 
 void keaki_hip_ctx_destroy(keaki_hip_ctx* ctx) {
   if (!ctx) return;
+  { std::lock_guard<std::mutex> lk(g_live_mu); g_live_ctx.erase(ctx); }
   {
   keaki_internal::DeviceScope dev_(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
@@ -411,11 +429,8 @@ void keaki_hip_srs_g1_free(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs) {
   if (srs->owned && srs->d) (void)hipFree((void*)srs->d);
   if (srs->table) (void)hipFree(srs->table);
   if (srs->fk_hat_s) (void)hipFree(srs->fk_hat_s);
-  if (ctx && ctx == srs->acct) {
-    std::lock_guard<std::recursive_mutex> lock_(ctx->mu);
-    const size_t held = srs->table_bytes + srs->fk_bytes;
-    ctx->mem_tables -= std::min(ctx->mem_tables, held);
-  }
+  const size_t held = srs->table_bytes + srs->fk_bytes;          // booked on the context that built them, whichever context (or NULL) frees the handle
+  with_live_ctx(srs->acct, [&](keaki_hip_ctx* a) { a->mem_tables -= std::min(a->mem_tables, held); });
   delete srs;
 }
 keaki_status keaki_hip_srs_g1_precompute(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, size_t* table_bytes_out) {
@@ -460,10 +475,8 @@ void keaki_hip_srs_g2_free(keaki_hip_ctx* ctx, keaki_hip_srs_g2* srs) {
   keaki_internal::DeviceScope dev_(srs->device);
   if (srs->owned && srs->d) (void)hipFree((void*)srs->d);
   if (srs->table) (void)hipFree(srs->table);
-  if (ctx && ctx == srs->acct) {
-    std::lock_guard<std::recursive_mutex> lock_(ctx->mu);
-    ctx->mem_tables -= std::min(ctx->mem_tables, srs->table_bytes);
-  }
+  const size_t held = srs->table_bytes;
+  with_live_ctx(srs->acct, [&](keaki_hip_ctx* a) { a->mem_tables -= std::min(a->mem_tables, held); });
   delete srs;
 }
 keaki_status keaki_hip_srs_g2_precompute(keaki_hip_ctx* ctx, keaki_hip_srs_g2* srs, size_t* table_bytes_out) {

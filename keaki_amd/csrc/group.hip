@@ -22,6 +22,7 @@ struct Worker {
   std::function<keaki_status()> job;
   bool has_job = false, done = false, quit = false;
   keaki_status result = KEAKI_OK;
+  std::string what;              // set when the job ended in a C++ exception: the context's last_error knows nothing of it
   void loop() {
     std::unique_lock<std::mutex> lk(mu);
     for (;;) {
@@ -31,9 +32,12 @@ struct Worker {
       has_job = false;
       lk.unlock();
       keaki_status r;
-      try { r = j(); } catch (...) { r = KEAKI_ERR_OOM; }       // std::bad_alloc of a host vector: no exception leaves the thread
+      std::string w;
+      try { r = j(); } catch (const std::bad_alloc&) { r = KEAKI_ERR_OOM; w = "host allocation failed in the member's worker thread"; }
+      catch (const std::exception& e) { r = KEAKI_ERR_OOM; w = std::string("exception in the member's worker thread: ") + e.what(); }
+      catch (...) { r = KEAKI_ERR_OOM; w = "unknown exception in the member's worker thread"; }       // no exception leaves the thread
       lk.lock();
-      result = r;
+      result = r; what = std::move(w);
       done = true;
       cv.notify_all();
     }
@@ -54,6 +58,8 @@ struct Worker {
 struct keaki_hip_group {
   std::vector<keaki_hip_ctx*> ctx;
   std::vector<Worker*> workers;
+  std::vector<hipEvent_t> sent;  // member i's outgoing copies of the exchange in flight are done (recorded on its stream)
+  std::string peer_note;         // which pairs of devices have no direct access (their copies are staged by the runtime); empty: all direct
   std::mutex mu;                 // calls on one group run one after another
   std::string err;
 };
@@ -61,6 +67,7 @@ struct keaki_hip_group_srs_g1 {
   size_t n = 0;
   std::vector<keaki_hip_srs_g1*> chunk;   // member i: points [lo(i), hi(i))
   std::vector<size_t> lo, hi;
+  std::vector<uint8_t> tabled;            // member i's chunk has its window tables (an out-of-memory table build is tolerated)
 };
 
 namespace {
@@ -88,7 +95,8 @@ keaki_status run_all(keaki_hip_group* g, const char* what, const std::function<k
     const keaki_status st = g->workers[i]->wait();
     if (st != KEAKI_OK && first == KEAKI_OK) {
       first = st;
-      gfail(g, st, "%s: member %zu (device %d): %s", what, i, g->ctx[i]->device, keaki_hip_last_error(g->ctx[i]));
+      const std::string w = g->workers[i]->what;     // a C++ exception in the worker: the context's own message is stale then
+      gfail(g, st, "%s: member %zu (device %d): %s", what, i, g->ctx[i]->device, w.empty() ? keaki_hip_last_error(g->ctx[i]) : w.c_str());
     }
   }
   return first;
@@ -119,9 +127,37 @@ keaki_status keaki_hip_group_create(const int32_t* devices, size_t n_devices, ke
     w->th = std::thread([w, device] { (void)hipSetDevice(device); w->loop(); });     // the member's GPU is its thread's current device throughout
     g->workers.push_back(w);
   }
+  // Direct access between every pair of distinct devices (xGMI on one node), so that the exchanges of the sharded FK23 are device-to-device
+  // DMA on the members' own streams. A pair that cannot have it keeps working -- hipMemcpyPeerAsync then goes through host memory -- and is named
+  // in keaki_hip_group_peer_note.
+  g->sent.assign(n_devices, nullptr);
+  for (size_t i = 0; i < n_devices; i++) {
+    keaki_internal::DeviceScope dev_(g->ctx[i]->device);
+    (void)hipEventCreateWithFlags(&g->sent[i], hipEventDisableTiming);
+    for (size_t j = 0; j < n_devices; j++) {
+      const int a = g->ctx[i]->device, b = g->ctx[j]->device;
+      if (a == b) continue;
+      bool seen = false;
+      for (size_t k = 0; k < j; k++) seen |= g->ctx[k]->device == b;
+      if (seen) continue;
+      int can = 0;
+      hipError_t e = hipDeviceCanAccessPeer(&can, a, b);
+      if (e == hipSuccess && can) {
+        e = hipDeviceEnablePeerAccess(b, 0);
+        if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+      }
+      if (e != hipSuccess || !can) {
+        char buf[96];
+        snprintf(buf, sizeof buf, "%sdevice %d -> %d: %s", g->peer_note.empty() ? "" : "; ", a, b, can ? hipGetErrorString(e) : "no peer access");
+        g->peer_note += buf;
+        (void)hipGetLastError();
+      }
+    }
+  }
   *out = g;
   return KEAKI_OK;
 }
+const char* keaki_hip_group_peer_note(const keaki_hip_group* g) { return g ? g->peer_note.c_str() : ""; }
 
 void keaki_hip_group_destroy(keaki_hip_group* g) {
   if (!g) return;
@@ -130,6 +166,8 @@ void keaki_hip_group_destroy(keaki_hip_group* g) {
     w->th.join();
     delete w;
   }
+  for (size_t i = 0; i < g->sent.size(); i++)
+    if (g->sent[i]) { keaki_internal::DeviceScope dev_(g->ctx[i]->device); (void)hipEventDestroy(g->sent[i]); }
   for (keaki_hip_ctx* c : g->ctx) keaki_hip_ctx_destroy(c);
   delete g;
 }
@@ -153,13 +191,15 @@ keaki_status keaki_hip_group_srs_g1_upload(keaki_hip_group* g, const uint64_t* p
   const size_t N = g->ctx.size();
   auto* s = new keaki_hip_group_srs_g1();
   s->n = n;
-  s->chunk.assign(N, nullptr); s->lo.resize(N); s->hi.resize(N);
+  s->chunk.assign(N, nullptr); s->lo.resize(N); s->hi.resize(N); s->tabled.assign(N, 0);
   for (size_t i = 0; i < N; i++) range_of(n, N, i, &s->lo[i], &s->hi[i]);
   const keaki_status st = run_all(g, "group_srs_g1_upload", [&](size_t i) -> keaki_status {
     const size_t m = s->hi[i] - s->lo[i];
     keaki_status r = keaki_hip_srs_g1_upload(g->ctx[i], m ? points_aff + 8 * s->lo[i] : nullptr, m, &s->chunk[i]);
     if (r != KEAKI_OK || !precompute || !m) return r;
-    r = keaki_hip_srs_g1_precompute(g->ctx[i], s->chunk[i], nullptr);
+    size_t bytes = 0;
+    r = keaki_hip_srs_g1_precompute(g->ctx[i], s->chunk[i], &bytes);
+    s->tabled[i] = r == KEAKI_OK && bytes > 0;
     return r == KEAKI_ERR_OOM ? KEAKI_OK : r;          // tables are optional: that member keeps the generic per-window MSM
   });
   if (st != KEAKI_OK) {
@@ -171,6 +211,12 @@ keaki_status keaki_hip_group_srs_g1_upload(keaki_hip_group* g, const uint64_t* p
   return KEAKI_OK;
 }
 size_t keaki_hip_group_srs_g1_len(const keaki_hip_group_srs_g1* srs) { return srs ? srs->n : 0; }
+int32_t keaki_hip_group_srs_g1_has_tables(const keaki_hip_group_srs_g1* srs) {
+  if (!srs) return 0;
+  for (size_t i = 0; i < srs->chunk.size(); i++)
+    if (srs->hi[i] > srs->lo[i] && !srs->tabled[i]) return 0;
+  return 1;
+}
 void keaki_hip_group_srs_g1_free(keaki_hip_group* g, keaki_hip_group_srs_g1* srs) {
   if (!srs) return;
   for (size_t i = 0; i < srs->chunk.size(); i++) keaki_hip_srs_g1_free(g && i < g->ctx.size() ? g->ctx[i] : nullptr, srs->chunk[i]);
@@ -264,31 +310,48 @@ struct keaki_hip_group_fk {
 };
 
 namespace {
+// One asynchronous copy on the SOURCE member's stream (behind the step that filled the buffer): a device-to-device DMA where the two devices
+// have peer access (keaki_hip_group_create enabled it), a plain device copy when both members share a GPU.
 keaki_status copy_between(keaki_hip_group* g, size_t dst_m, void* dst, size_t src_m, const void* src, size_t bytes) {
   const int dd = g->ctx[dst_m]->device, sd = g->ctx[src_m]->device;
-  hipError_t e;
-  if (dd == sd) { keaki_internal::DeviceScope dev_(dd); e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice); }
-  else e = hipMemcpyPeer(dst, dd, src, sd, bytes);
+  keaki_internal::DeviceScope dev_(sd);
+  const hipStream_t st = g->ctx[src_m]->stream;
+  const hipError_t e = dd == sd ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st) : hipMemcpyPeerAsync(dst, dd, src, sd, bytes, st);
   if (e != hipSuccess) return gfail(g, KEAKI_ERR_HIP, "group_fk: copy member %zu -> member %zu failed: %s", src_m, dst_m, hipGetErrorString(e));
   return KEAKI_OK;
 }
-// A device-to-device hipMemcpy may return before the copy has run (it is ordered on the null stream only), and the members' streams are
-// non-blocking, i.e. NOT ordered behind the null stream: wait for every member's device before the next step reads the buffers.
-keaki_status copies_done(keaki_hip_group* g) {
-  for (size_t i = 0; i < g->ctx.size(); i++) {
+// Every member has issued its outgoing copies on its own stream: an event per source, and every destination's stream waits for the sources
+// that wrote into its buffer. No host thread blocks; the next step's kernels start when their inputs have landed.
+keaki_status copies_ordered(keaki_hip_group* g, const std::vector<size_t>& dests) {
+  const size_t N = g->ctx.size();
+  for (size_t i = 0; i < N; i++) {
     keaki_internal::DeviceScope dev_(g->ctx[i]->device);
-    const hipError_t e = hipDeviceSynchronize();
-    if (e != hipSuccess) return gfail(g, KEAKI_ERR_HIP, "group_fk: hipDeviceSynchronize on member %zu failed: %s", i, hipGetErrorString(e));
+    const hipError_t e = hipEventRecord(g->sent[i], g->ctx[i]->stream);
+    if (e != hipSuccess) return gfail(g, KEAKI_ERR_HIP, "group_fk: hipEventRecord on member %zu failed: %s", i, hipGetErrorString(e));
+  }
+  for (size_t j : dests) {
+    keaki_internal::DeviceScope dev_(g->ctx[j]->device);
+    for (size_t i = 0; i < N; i++) {
+      if (i == j) continue;                               // its own stream is ordered already
+      const hipError_t e = hipStreamWaitEvent(g->ctx[j]->stream, g->sent[i], 0);
+      if (e != hipSuccess) return gfail(g, KEAKI_ERR_HIP, "group_fk: hipStreamWaitEvent on member %zu failed: %s", j, hipGetErrorString(e));
+    }
   }
   return KEAKI_OK;
 }
-// chunk j of member i's send buffer -> chunk i of member j's receive buffer (every member has finished its step: run_all waited and synchronised)
+// chunk j of member i's send buffer -> chunk i of member j's receive buffer. Every member has finished the step before (step_all waits for
+// the members' streams), so the receive buffers are free to be written.
 keaki_status all_to_all(keaki_hip_group* g, keaki_hip_group_fk* f, size_t per_peer) {
   const size_t N = g->ctx.size();
-  for (size_t i = 0; i < N; i++)
-    for (size_t j = 0; j < N; j++)
+  std::vector<size_t> all(N);
+  for (size_t i = 0; i < N; i++) {
+    all[i] = i;
+    for (size_t k = 0; k < N; k++) {
+      const size_t j = (i + k) % N;                       // every source starts with a different destination: the links are used at once
       ST_TRY(copy_between(g, j, (char*)f->recv[j] + i * per_peer, i, (const char*)f->send[i] + j * per_peer, per_peer));
-  return copies_done(g);
+    }
+  }
+  return copies_ordered(g, all);
 }
 void group_fk_release(keaki_hip_group* g, keaki_hip_group_fk* f) {
   for (size_t i = 0; i < f->fk.size(); i++) keaki_hip_fk_shard_free(g && i < g->ctx.size() ? g->ctx[i] : nullptr, f->fk[i]);
@@ -375,7 +438,7 @@ keaki_status keaki_hip_group_fk_open(keaki_hip_group* g, keaki_hip_group_fk* f, 
   ST_TRY(step_all(g, "group_fk_open (step 2)", [&](size_t i) { return keaki_hip_fk_shard_open(g->ctx[i], f->fk[i], 2, nullptr, f->send[i], f->recv[i], nullptr); }));
   // the all-gather of the d / N affine proofs of every member, into member 0 only (it alone writes the host output)
   for (size_t i = 0; i < N; i++) ST_TRY(copy_between(g, 0, (char*)f->recv[0] + i * f->sizes[3], i, f->send[i], f->sizes[3]));
-  ST_TRY(copies_done(g));
+  ST_TRY(copies_ordered(g, {0}));
   const keaki_status st = keaki_hip_fk_shard_open(g->ctx[0], f->fk[0], 3, nullptr, nullptr, f->recv[0], proofs_out_aff);
   if (st != KEAKI_OK) return gfail(g, st, "group_fk_open (step 3): member 0: %s", keaki_hip_last_error(g->ctx[0]));
   return KEAKI_OK;

@@ -64,7 +64,7 @@ struct keaki_hip_ctx {
   uint32_t seen_com_runs = 0;
   uint32_t gt_a_wb = 0, gt_b_wb = 0;      // window widths of the GT tables in gt_tab_a / gt_tab_b
   keaki_internal::DevBuf pair_ws;                   // per-item slots of the final exponentiation (pairing.hip.h)
-  keaki_internal::DevBuf fk_tab;                    // window tables of the per-lane-scalar ladders of FK23: 2 KB per lane of a launch, at most 2 GB (fft_g1.hip)
+  keaki_internal::DevBuf fk_tab;                    // window tables of the per-lane-scalar ladders of FK23: 1 KB per lane of a launch (64 x 16 B), at most 2 GB (fft_g1.hip)
   keaki_internal::DevBuf verify_lines, verify_io;   // kzg verify: [lines of g2 | lines of [tau]_2], small in/out block
   bool verify_ready = false;              // set only after every init step of kzg verify succeeded
   bool verify_tau_valid = false;

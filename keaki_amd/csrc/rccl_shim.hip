@@ -17,6 +17,8 @@ struct keaki_hip_rccl {
   int rank = 0, world = 1;
   void* gathered = nullptr;      // world x 96 bytes: the partials of the sharded MSM
   void* partial = nullptr;       // 96 bytes
+  void* d_status = nullptr;      // world + 1 int32: [this rank's status of the collective in flight | every rank's, gathered]
+  int32_t* h_status = nullptr;   // pinned copy of the gathered ones (keaki_hip_rccl_collective_status)
   std::mutex mu;
   std::string err;
 };
@@ -79,7 +81,8 @@ keaki_status keaki_hip_rccl_create(keaki_hip_ctx* ctx, const uint8_t id128[128],
   memcpy(&id, id128, 128);
   ncclResult_t r = ncclCommInitRank(&rc->comm, world, id, rank);
   if (r != ncclSuccess) { rfail(nullptr, KEAKI_ERR_RCCL, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, ncclGetErrorString(r)); delete rc; return KEAKI_ERR_RCCL; }
-  if (hipMalloc(&rc->gathered, (size_t)world * 96) != hipSuccess || hipMalloc(&rc->partial, 96) != hipSuccess) {
+  if (hipMalloc(&rc->gathered, (size_t)world * 96) != hipSuccess || hipMalloc(&rc->partial, 96) != hipSuccess ||
+      hipMalloc(&rc->d_status, (size_t)(world + 1) * 4) != hipSuccess || hipHostMalloc((void**)&rc->h_status, (size_t)world * 4) != hipSuccess) {
     rfail(nullptr, KEAKI_ERR_OOM, "rccl_create: hipMalloc failed");
     keaki_hip_rccl_destroy(rc);
     return KEAKI_ERR_OOM;
@@ -95,6 +98,8 @@ void keaki_hip_rccl_destroy(keaki_hip_rccl* rc) {
   if (rc->comm) (void)ncclCommDestroy(rc->comm);
   if (rc->gathered) (void)hipFree(rc->gathered);
   if (rc->partial) (void)hipFree(rc->partial);
+  if (rc->d_status) (void)hipFree(rc->d_status);
+  if (rc->h_status) (void)hipHostFree(rc->h_status);
   delete rc;
 }
 
@@ -107,6 +112,8 @@ const char* keaki_hip_rccl_last_error(const keaki_hip_rccl* rc) {
   return copy.c_str();
 }
 
+// (A NULL buffer is a caller error on EVERY rank alike -- the buffers are allocated from the same sizes on all of them --, so returning
+// before the enqueue cannot split the ranks; any other failure here comes from RCCL itself, after which the communicator is dead.)
 keaki_status keaki_hip_rccl_all_gather(keaki_hip_rccl* rc, const void* d_send, void* d_recv, size_t bytes_per_rank) {
   if (!rc) return KEAKI_ERR_BAD_ARG;
   std::lock_guard<std::mutex> lk(rc->mu);
@@ -125,17 +132,49 @@ keaki_status keaki_hip_rccl_all_to_all(keaki_hip_rccl* rc, const void* d_send, v
   return KEAKI_OK;
 }
 
+// A rank-local failure must not leave the other ranks waiting in a collective this rank never enqueued: the all-gather is ALWAYS enqueued --
+// a failing rank contributes the identity (96 zero bytes: z = 0) -- and a second, 4-byte all-gather carries every rank's status, which
+// keaki_hip_rccl_collective_status reports after the stream has drained. The failing rank itself returns its error at once.
 keaki_status keaki_hip_rccl_msm_g1(keaki_hip_rccl* rc, const keaki_hip_srs_g1* srs_chunk, const void* d_scalars, size_t n, void* d_out_jac) {
   if (!rc) return KEAKI_ERR_BAD_ARG;
   std::lock_guard<std::mutex> lk(rc->mu);
-  if (!srs_chunk || !d_out_jac) return rfail(rc, KEAKI_ERR_BAD_ARG, "rccl_msm_g1: null pointer");
   DeviceScope dev_(rc->ctx);
-  keaki_status st = keaki_hip_msm_g1_dev(rc->ctx, srs_chunk, d_scalars, n, rc->partial);
-  if (st != KEAKI_OK) return rfail(rc, st, "rccl_msm_g1: %s", keaki_hip_last_error(rc->ctx));
+  hipStream_t st_ = (hipStream_t)keaki_hip_ctx_stream(rc->ctx);
+  keaki_status local = KEAKI_OK;
+  if (!srs_chunk || !d_out_jac) local = rfail(rc, KEAKI_ERR_BAD_ARG, "rccl_msm_g1: null pointer");
+  if (local == KEAKI_OK) {
+    local = keaki_hip_msm_g1_dev(rc->ctx, srs_chunk, d_scalars, n, rc->partial);
+    if (local != KEAKI_OK) rfail(rc, local, "rccl_msm_g1: %s", keaki_hip_last_error(rc->ctx));
+  }
+  if (local != KEAKI_OK && hipMemsetAsync(rc->partial, 0, 96, st_) != hipSuccess) local = KEAKI_ERR_HIP;   // the identity: the sum ignores it
+  const int32_t mine = (int32_t)local;
+  if (hipMemcpyAsync(rc->d_status, &mine, 4, hipMemcpyHostToDevice, st_) != hipSuccess) return rfail(rc, KEAKI_ERR_HIP, "rccl_msm_g1: status upload failed");
+  (void)hipStreamSynchronize(st_);            // `mine` lives on this stack frame (4 bytes, once per MSM)
   // EC addition is not an RCCL reduction operator: all-gather the 96-byte partials, add them on every rank
-  NCCL_TRY(rc, ncclAllGather(rc->partial, rc->gathered, 96, ncclUint8, rc->comm, (hipStream_t)keaki_hip_ctx_stream(rc->ctx)));
-  st = keaki_hip_g1_sum_dev(rc->ctx, rc->gathered, (size_t)rc->world, d_out_jac);
+  NCCL_TRY(rc, ncclAllGather(rc->partial, rc->gathered, 96, ncclUint8, rc->comm, st_));
+  NCCL_TRY(rc, ncclAllGather(rc->d_status, (char*)rc->d_status + 4, 4, ncclUint8, rc->comm, st_));
+  if (hipMemcpyAsync(rc->h_status, (char*)rc->d_status + 4, (size_t)rc->world * 4, hipMemcpyDeviceToHost, st_) != hipSuccess)
+    return rfail(rc, KEAKI_ERR_HIP, "rccl_msm_g1: status download failed");
+  if (local != KEAKI_OK) return local;
+  keaki_status st = keaki_hip_g1_sum_dev(rc->ctx, rc->gathered, (size_t)rc->world, d_out_jac);
   if (st != KEAKI_OK) return rfail(rc, st, "rccl_msm_g1: %s", keaki_hip_last_error(rc->ctx));
+  return KEAKI_OK;
+}
+
+// Waits for the context's stream, then: KEAKI_OK when every rank's share of the last keaki_hip_rccl_msm_g1 succeeded, otherwise the first
+// failing rank's status (its index in *bad_rank when that is not NULL): the result in d_out_jac then lacks that rank's chunk.
+keaki_status keaki_hip_rccl_collective_status(keaki_hip_rccl* rc, int32_t* bad_rank) {
+  if (!rc) return KEAKI_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(rc->mu);
+  DeviceScope dev_(rc->ctx);
+  keaki_status st = keaki_hip_synchronize(rc->ctx);
+  if (st != KEAKI_OK) return rfail(rc, st, "rccl_collective_status: %s", keaki_hip_last_error(rc->ctx));
+  for (int r = 0; r < rc->world; r++)
+    if (rc->h_status[r] != 0) {
+      if (bad_rank) *bad_rank = r;
+      return rfail(rc, (keaki_status)rc->h_status[r], "rank %d failed its share of the last collective MSM (status %d)", r, (int)rc->h_status[r]);
+    }
+  if (bad_rank) *bad_rank = -1;
   return KEAKI_OK;
 }
 

@@ -213,7 +213,7 @@ def sharded_vec_commit(K, rng, setup, v, shard: Shard, fk: "ShardedFk | None" = 
     """vec_commit (src/vec.rs:22-49) on every rank: padding draw and iFFT replicated (same rng seed -> same values), the commit MSM sharded by
     point range with one all-gather of the partials, and -- given a ShardedFk -- the FK23 openings sharded as well (without one they are
     replicated). Returns (commitment, proofs) on every rank."""
-    if shard.world == 1 and fk is None:
+    if not shard.collective and fk is None:
         return K.vec_commit(rng, setup, v)              # one rank: the un-sharded call (one device call behind the padding draw)
     if fk is not None:
         part, proofs = fk.vec_commit_partial(rng, v)

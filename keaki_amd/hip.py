@@ -26,7 +26,7 @@ EXPORTS = [
     "keaki_hip_selftest_field", "keaki_hip_open_fk", "keaki_hip_open_fk_poly", "keaki_hip_srs_g1_precompute_fk", "keaki_hip_fk_shard_create", "keaki_hip_fk_shard_free", "keaki_hip_fk_shard_sizes", "keaki_hip_fk_shard_setup", "keaki_hip_fk_shard_open", "keaki_hip_fr_fft", "keaki_hip_srs_g1_check", "keaki_hip_g2_check", "keaki_hip_kzg_open", "keaki_hip_kzg_verify", "keaki_hip_final_exp_batch", "keaki_hip_miller_loop_batch", "keaki_hip_g2_prepare", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
     "keaki_hip_last_fk_ms", "keaki_hip_ctx_stream", "keaki_hip_ctx_device", "keaki_hip_ctx_set_option", "keaki_hip_debug_set_alloc_limit", "keaki_hip_ctx_memory", "keaki_hip_ctx_trim", "keaki_hip_kzg_quotient", "keaki_hip_vec_commit", "keaki_hip_encap_prepare",
     "keaki_hip_group_create", "keaki_hip_group_destroy", "keaki_hip_group_size", "keaki_hip_group_ctx", "keaki_hip_group_last_error",
-    "keaki_hip_group_srs_g1_upload", "keaki_hip_group_srs_g1_len", "keaki_hip_group_srs_g1_free", "keaki_hip_group_msm_g1",
+    "keaki_hip_group_peer_note", "keaki_hip_group_srs_g1_upload", "keaki_hip_group_srs_g1_len", "keaki_hip_group_srs_g1_has_tables", "keaki_hip_group_srs_g1_free", "keaki_hip_group_msm_g1",
     "keaki_hip_group_kzg_open", "keaki_hip_group_encap_batch", "keaki_hip_group_decap_batch",
     "keaki_hip_group_fk_create", "keaki_hip_group_fk_open", "keaki_hip_group_fk_free",
 ]
@@ -158,6 +158,10 @@ def load_library():
         lib.keaki_hip_group_srs_g1_upload.argtypes = [vp, vp, sz, i32, C.POINTER(vp)]
         lib.keaki_hip_group_srs_g1_len.argtypes = [vp]
         lib.keaki_hip_group_srs_g1_len.restype = sz
+        lib.keaki_hip_group_peer_note.argtypes = [vp]
+        lib.keaki_hip_group_peer_note.restype = C.c_char_p
+        lib.keaki_hip_group_srs_g1_has_tables.argtypes = [vp]
+        lib.keaki_hip_group_srs_g1_has_tables.restype = C.c_int32
         lib.keaki_hip_group_srs_g1_free.argtypes = [vp, vp]
         lib.keaki_hip_group_srs_g1_free.restype = None
         lib.keaki_hip_group_msm_g1.argtypes = [vp, vp, vp, sz, vp]
@@ -547,6 +551,10 @@ class KeakiHipGroup:
     def _ck(self, st):
         if st != 0:
             raise KeakiHipError(st, self.lib.keaki_hip_group_last_error(self.g).decode())
+
+    def peer_note(self) -> str:
+        """Empty when every pair of distinct devices of the group has direct (peer) access; otherwise the pairs whose copies the runtime stages."""
+        return self.lib.keaki_hip_group_peer_note(self.g).decode()
 
     def member_memory(self, i: int) -> dict:
         out = (C.c_size_t * 4)()

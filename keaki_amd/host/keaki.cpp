@@ -184,7 +184,7 @@ KZGSetup KZGSetup::from_powers(std::shared_ptr<Device> dev, std::vector<G1> g1_a
   if (s.dev_->group()) {
     // several GPUs in this process: chunk i of the SRS and its window tables live on member i from now on (src/kzg.rs:98 reads them)
     s.dev_->check_group(keaki_hip_group_srs_g1_upload(s.dev_->group(), s.g1_aff_.empty() ? nullptr : s.g1_aff_[0].w.data(), s.g1_aff_.size(), 1, &s.gsrs_));
-    s.tables_ = true;
+    s.tables_ = keaki_hip_group_srs_g1_has_tables(s.gsrs_) != 0;    // a member whose table build ran out of memory keeps the generic MSM
     return s;
   }
   s.dev_->check(keaki_hip_srs_g1_upload(s.dev_->ctx(), s.g1_aff_.empty() ? nullptr : s.g1_aff_[0].w.data(), s.g1_aff_.size(), &s.srs_));

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 EXPORTS = ["keaki_hip_rccl_unique_id", "keaki_hip_rccl_create", "keaki_hip_rccl_destroy", "keaki_hip_rccl_last_error", "keaki_hip_rccl_msm_g1",
-           "keaki_hip_rccl_all_to_all", "keaki_hip_rccl_all_gather"]
+           "keaki_hip_rccl_all_to_all", "keaki_hip_rccl_all_gather", "keaki_hip_rccl_collective_status"]
 
 
 def load_rccl_library():
@@ -34,6 +34,7 @@ def load_rccl_library():
         lib.keaki_hip_rccl_msm_g1.argtypes = [vp, vp, vp, sz, vp]
         lib.keaki_hip_rccl_all_to_all.argtypes = [vp, vp, vp, sz]
         lib.keaki_hip_rccl_all_gather.argtypes = [vp, vp, vp, sz]
+        lib.keaki_hip_rccl_collective_status.argtypes = [vp, C.POINTER(i32)]
         _LIB = lib
     return _LIB
 
@@ -64,6 +65,12 @@ class KeakiRccl:
 
     def msm_g1(self, srs_chunk, d_scalars: int, n: int, d_out: int):
         self._ck(self.lib.keaki_hip_rccl_msm_g1(self.h, srs_chunk.handle, C.c_void_p(d_scalars), n, C.c_void_p(d_out)))
+
+    def collective_status(self) -> int:
+        """Waits for the stream; -1 when every rank's share of the last msm_g1 succeeded, else raises with the first failing rank."""
+        bad = C.c_int32(-1)
+        self._ck(self.lib.keaki_hip_rccl_collective_status(self.h, C.byref(bad)))
+        return bad.value
 
     def all_to_all(self, d_send: int, d_recv: int, per_peer: int):
         self._ck(self.lib.keaki_hip_rccl_all_to_all(self.h, C.c_void_p(d_send), C.c_void_p(d_recv), per_peer))

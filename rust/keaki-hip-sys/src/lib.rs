@@ -152,7 +152,9 @@ extern "C" {
     pub fn keaki_hip_group_last_error(g: *const keaki_hip_group) -> *const c_char;
     pub fn keaki_hip_group_srs_g1_upload(g: *mut keaki_hip_group, points_aff: *const u64, n: usize, precompute: i32,
                                          out: *mut *mut keaki_hip_group_srs_g1) -> keaki_status;
+    pub fn keaki_hip_group_peer_note(g: *const keaki_hip_group) -> *const c_char;
     pub fn keaki_hip_group_srs_g1_len(srs: *const keaki_hip_group_srs_g1) -> usize;
+    pub fn keaki_hip_group_srs_g1_has_tables(srs: *const keaki_hip_group_srs_g1) -> i32;
     pub fn keaki_hip_group_srs_g1_free(g: *mut keaki_hip_group, srs: *mut keaki_hip_group_srs_g1);
     pub fn keaki_hip_group_msm_g1(g: *mut keaki_hip_group, srs: *const keaki_hip_group_srs_g1, scalars: *const u64, n: usize, out_jac: *mut u64) -> keaki_status;
     pub fn keaki_hip_group_kzg_open(g: *mut keaki_hip_group, srs: *const keaki_hip_group_srs_g1, coeffs: *const u64, n: usize, point: *const u64,

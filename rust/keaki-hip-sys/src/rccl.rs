@@ -18,4 +18,5 @@ extern "C" {
     pub fn keaki_hip_rccl_msm_g1(rc: *mut keaki_hip_rccl, srs_chunk: *const keaki_hip_srs_g1, d_scalars: *const c_void, n: usize, d_out_jac: *mut c_void) -> keaki_status;
     pub fn keaki_hip_rccl_all_to_all(rc: *mut keaki_hip_rccl, d_send: *const c_void, d_recv: *mut c_void, bytes_per_peer: usize) -> keaki_status;
     pub fn keaki_hip_rccl_all_gather(rc: *mut keaki_hip_rccl, d_send: *const c_void, d_recv: *mut c_void, bytes_per_rank: usize) -> keaki_status;
+    pub fn keaki_hip_rccl_collective_status(rc: *mut keaki_hip_rccl, bad_rank: *mut i32) -> keaki_status;
 }

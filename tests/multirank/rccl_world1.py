@@ -66,6 +66,21 @@ def main():
         rc.msm_g1(sm.srs, d_s.data_ptr(), n, d_out2.data_ptr())
     hip.synchronize()
     out["shim_msm_ok"] = bool(np.array_equal(jac_to_affine_words(d_out2.cpu().numpy().view(np.uint64)), exp))
+    out["shim_status_ok"] = rc.collective_status() == -1
+    # a rank-local failure (more scalars than the chunk holds) still takes part in the exchange -- with one rank: still completes --, returns its
+    # own error at once, and the collective status names the rank
+    from keaki_amd.hip import KeakiHipError
+    try:
+        rc.msm_g1(sm.srs, d_s.data_ptr(), n + 1, d_out2.data_ptr())
+        out["shim_local_failure_ok"] = False
+    except KeakiHipError:
+        try:
+            rc.collective_status()
+            out["shim_local_failure_ok"] = False
+        except KeakiHipError as e:
+            out["shim_local_failure_ok"] = "rank 0" in str(e)
+    rc.msm_g1(sm.srs, d_s.data_ptr(), n, d_out2.data_ptr())                       # and the communicator is still usable
+    out["shim_after_failure_ok"] = rc.collective_status() == -1 and bool(np.array_equal(jac_to_affine_words(d_out2.cpu().numpy().view(np.uint64)), exp))
     recv.zero_()
     rc.all_to_all(send.data_ptr(), recv.data_ptr(), send.numel())
     hip.synchronize()

@@ -36,7 +36,7 @@ def test_rccl_companion_library_exports_its_header():
     lib = rccl.load_rccl_library()
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "keaki_hip_rccl.h")).read(), flags=re.S)
     syms = sorted(set(re.findall(r"\b(keaki_hip_rccl_[a-z0-9_]+)\s*\(", hdr)))
-    assert syms == sorted(rccl.EXPORTS) and len(syms) == 7
+    assert syms == sorted(rccl.EXPORTS) and len(syms) == 8
     for s in syms:
         assert hasattr(lib, s), s
     rs = open(os.path.join(ROOT, "rust", "keaki-hip-sys", "src", "rccl.rs")).read()

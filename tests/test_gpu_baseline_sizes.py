@@ -125,3 +125,93 @@ def test_config4_chunk_2p23_of_2p26_identity(oc, hip, q):
         srs.free()
         del d_pts, d_s
         torch.cuda.empty_cache()
+
+
+def test_headline_msm_2p24_with_tables(oc, hip):
+    """The headline configuration as a test (bench.py's own checks): 2^24-point G1 MSM over SRS window tables -- the O(n) identity
+    MSM(s, k_i G) == (sum s_i k_i) G at full size, the generic path on the same input, and the first 2^20 pairs bit-exact against the
+    CPU restatement of ark-ec's Pippenger (src/kzg.rs:98)."""
+    from bench import random_fr_limbs, SEED
+    from keaki_amd.hip import jac_to_affine_words
+    torch, dev = _torch_dev()
+    n = 1 << 24
+    k = random_fr_limbs(n, SEED + 1)
+    s = random_fr_limbs(n, SEED + 104729)
+    d_pts = _gen_points_dev(hip, torch, dev, k)
+    d_s = torch.from_numpy(s.view(np.int64)).to(dev)
+    d_out = torch.zeros(12, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(dev)
+    g1, _ = oc.generators()
+    exp = oc.g1_mul_batch(g1, oc.fr_dot(s, k).reshape(1, 4))[0]
+    srs = hip.srs_g1_wrap_dev(d_pts.data_ptr(), n)
+    sub = hip.srs_g1_wrap_dev(d_pts.data_ptr(), 1 << 20)
+    try:
+        hip.msm_g1_dev(srs, d_s.data_ptr(), n, d_out.data_ptr())          # generic per-window path
+        hip.synchronize()
+        assert np.array_equal(jac_to_affine_words(d_out.cpu().numpy().view(np.uint64)), exp)
+        assert hip.srs_g1_precompute(srs) >= 10 * n * 64
+        d_out.zero_()
+        torch.cuda.synchronize(dev)
+        hip.msm_g1_dev(srs, d_s.data_ptr(), n, d_out.data_ptr())          # the headline path: one shared bucket set over the window tables
+        hip.synchronize()
+        assert hip.last_msm_stats()["window_bits"] == 22
+        assert np.array_equal(jac_to_affine_words(d_out.cpu().numpy().view(np.uint64)), exp)
+        ns = 1 << 20
+        ref = oc.msm_g1(d_pts[:ns].cpu().numpy().view(np.uint64), s[:ns], threads=os.cpu_count() or 1)
+        d_out.zero_()
+        torch.cuda.synchronize(dev)
+        hip.msm_g1_dev(sub, d_s.data_ptr(), ns, d_out.data_ptr())
+        hip.synchronize()
+        assert np.array_equal(jac_to_affine_words(d_out.cpu().numpy().view(np.uint64)), ref)
+    finally:
+        sub.free()
+        srs.free()
+        del d_pts, d_s
+        torch.cuda.empty_cache()
+
+
+def test_g2_msm_2p20_identity_with_and_without_tables(oc, hip):
+    """G2 MSM at the size DESIGN quotes timings for: 2^20 points k_i G2, by the O(n) identity MSM == (sum s_i k_i) G2, on the generic path
+    and over the window tables of the G2 basis."""
+    from bench import random_fr_limbs
+    from keaki_amd.hip import jac_to_affine_words
+    n = 1 << 20
+    _, g2 = oc.generators()
+    k = random_fr_limbs(n, 0x62A1)
+    s = random_fr_limbs(n, 0x62A2)
+    s[3] = 0
+    pts = hip.g2_mul_batch(g2, k)
+    exp = oc.g2_mul_batch(g2, oc.fr_dot(s, k).reshape(1, 4))[0]
+    srs = hip.srs_g2_upload(pts)
+    try:
+        assert np.array_equal(jac_to_affine_words(hip.msm_g2(srs, s)), exp)
+        assert hip.srs_g2_precompute(srs) >= n * 128
+        assert np.array_equal(jac_to_affine_words(hip.msm_g2(srs, s)), exp)
+    finally:
+        srs.free()
+
+
+def test_config1_degree_128_commit_open_verify_through_the_mirror(oc, py):
+    """BASELINE config 1 to the letter: KZGSetup::setup(secret, 129) -- `max_d` is a COUNT of powers, so a degree-128 polynomial needs
+    129 (src/kzg.rs:55-70) --, commit / open / verify of a degree-128 polynomial through the host mirror of keaki's API, every value
+    against the big-integer oracle's restatement of src/kzg.rs:89-151; 130 coefficients are PolynomialTooLarge(130, 129)."""
+    from keaki_amd import keaki as K
+    rng = K.Rng(128)
+    secret = rng.fr_rand()
+    setup = K.KZGSetup.setup(secret, 129)
+    coeffs_m = np.stack([rng.fr_rand() for _ in range(129)])
+    point = rng.fr_rand()
+    canon = lambda a: oc.limbs_to_ints(oc.fr_from_mont(np.asarray(a).reshape(-1, 4)))
+    tau, z, coeffs = canon(secret)[0], canon(point)[0], canon(coeffs_m)
+    g1p, tau_g2 = py.kzg_setup(tau, 129)
+    assert oc.g1_to_ints(setup.g1_pow()) == g1p and oc.g2_to_ints(setup.tau_g2())[0] == tau_g2
+    com, proof, value = K.commit(setup, coeffs_m), K.open(setup, coeffs_m, point), K.poly_evaluate(coeffs_m, point)
+    assert oc.g1_to_ints(com)[0] == py.kzg_commit(g1p, coeffs)
+    assert oc.g1_to_ints(proof)[0] == py.kzg_open(g1p, coeffs, z)
+    assert canon(value)[0] == py.poly_eval(coeffs, z)
+    assert K.verify(setup, com, point, value, proof)
+    assert py.kzg_verify(tau_g2, oc.g1_to_ints(com)[0], z, canon(value)[0], oc.g1_to_ints(proof)[0])
+    assert not K.verify(setup, com, point, rng.fr_rand(), proof)
+    with pytest.raises(K.KZGError) as e:
+        K.commit(setup, np.vstack([coeffs_m, rng.fr_rand()]))
+    assert e.value == K.KZGError(130, 129)
