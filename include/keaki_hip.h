@@ -262,6 +262,21 @@ keaki_status keaki_hip_decap_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_af
 keaki_status keaki_hip_decap_batch_dev(keaki_hip_ctx* ctx, const void* d_proofs_aff, const void* d_cts_aff, size_t n,
                                        void* d_gt_out, void* d_key_out, size_t msg_len);
 
+/* ---- enc::encrypt / enc::decrypt over a batch: KEM + the XOR DEM on the device ---------------------------------------------
+ * Replaces the body of the loops of vec_encrypt / vec_decrypt (src/vec.rs:63-66, :75-78), i.e. src/enc.rs:19-40 and :44-55 per item:
+ * encapsulate / decapsulate as above, then `key XOR message` (src/enc.rs:32-36, :48-52) inside the KDF kernel -- neither the 384 GT bytes nor
+ * the key leave the device. n messages of msg_len (1..65536) bytes each, contiguous. r[i] drawn by the caller as for encap_batch.
+ * _dev: d_body_inout holds the messages on entry and the ciphertext bodies on exit (decrypt: bodies in, messages out). */
+keaki_status keaki_hip_encrypt_batch(keaki_hip_ctx* ctx, const uint64_t* com_aff, const uint64_t* tau_g2_aff, const uint64_t* points,
+                                     const uint64_t* values, const uint64_t* r, const uint8_t* msgs, size_t n, uint64_t* ct_out_aff,
+                                     uint8_t* body_out, size_t msg_len);
+keaki_status keaki_hip_encrypt_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff, const void* d_tau_g2_aff, const void* d_points,
+                                         const void* d_values, const void* d_r, size_t n, void* d_ct_out_aff, void* d_body_inout, size_t msg_len);
+keaki_status keaki_hip_decrypt_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_aff, const uint64_t* cts_aff, const uint8_t* bodies, size_t n,
+                                     uint8_t* msgs_out, size_t msg_len);
+keaki_status keaki_hip_decrypt_batch_dev(keaki_hip_ctx* ctx, const void* d_proofs_aff, const void* d_cts_aff, size_t n, void* d_body_inout,
+                                         size_t msg_len);
+
 /* ---- device group: in-process multi-GPU (SURVEY 8b `_create(n_devices)`, 8e "single process, one host thread per GPU") -----------------
  * What a Rust caller of keaki gets with more than one GPU and no PyTorch / RCCL: the library keeps one ctx and one host worker thread per
  * entry of `devices` (an ordinal may repeat: several contexts on one GPU, which is how the single-GPU test box exercises it), the SRS is
@@ -297,6 +312,12 @@ keaki_status keaki_hip_group_encap_batch(keaki_hip_group* g, const uint64_t* com
                                          uint8_t* key_out, size_t msg_len);
 keaki_status keaki_hip_group_decap_batch(keaki_hip_group* g, const uint64_t* proofs_aff, const uint64_t* cts_aff, size_t n, uint8_t* gt_out,
                                          uint8_t* key_out, size_t msg_len);
+/* the same split for keaki_hip_encrypt_batch / keaki_hip_decrypt_batch (KEM + XOR DEM on the members) */
+keaki_status keaki_hip_group_encrypt_batch(keaki_hip_group* g, const uint64_t* com_aff, const uint64_t* tau_g2_aff, const uint64_t* points,
+                                           const uint64_t* values, const uint64_t* r, const uint8_t* msgs, size_t n, uint64_t* ct_out_aff,
+                                           uint8_t* body_out, size_t msg_len);
+keaki_status keaki_hip_group_decrypt_batch(keaki_hip_group* g, const uint64_t* proofs_aff, const uint64_t* cts_aff, const uint8_t* bodies, size_t n,
+                                           uint8_t* msgs_out, size_t msg_len);
 
 /* kzg::open_fk (src/kzg.rs:157-203) over the members of a group: the sharded FK23 pipeline (keaki_hip_fk_shard_*, member i = rank i) with the
  * exchanges done inside the library -- device-to-device copies between the members' buffers (hipMemcpyPeer), no collective, no RCCL. The

@@ -638,7 +638,7 @@ static keaki_status gt_table_of(keaki_hip_ctx* ctx, const void* d_p_aff, void* d
 // batches of n items, and stop: keaki_hip_encap_prepare. Nothing per item, nothing per commitment.
 static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_aff, const void* d_tau_g2_aff, const void* d_points,
                                const void* d_values, const void* d_r, size_t n, void* d_ct_out_aff, void* d_gt_out, void* d_key_out,
-                               size_t msg_len) {
+                               size_t msg_len, bool xor_into = false) {
   if (!prep) ST_TRY(reserve(ctx, ctx->tmp_a, n * G1_AFF_BYTES));
   ST_TRY(reserve(ctx, ctx->tmp_c, G2_AFF_BYTES));
   void* gt = d_gt_out;
@@ -784,7 +784,7 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
     }
     ST_TRY(pairing_run(ctx, ctx->tmp_a.p, ctx->tmp_c.p, 0, n, gt, ctx->g2gen_lines.p));
   }
-  if (d_key_out && msg_len) ST_TRY(blake3_gt_run(ctx, gt, n, d_key_out, msg_len));
+  if (d_key_out && msg_len) ST_TRY(blake3_gt_run(ctx, gt, n, d_key_out, msg_len, xor_into));
   return KEAKI_OK;
 }
 keaki_status keaki_hip_encap_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff, const void* d_tau_g2_aff, const void* d_points,
@@ -864,6 +864,71 @@ keaki_status keaki_hip_decap_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_af
   prefault_out(gt_out, gt_out ? n * 384 : 0); prefault_out(key_out, key_out ? n * msg_len : 0);
   if (gt_out) HIP_TRY(ctx, hipMemcpyAsync(gt_out, base + off_gt, n * 384, hipMemcpyDeviceToHost, st));
   if (key_out && msg_len) HIP_TRY(ctx, hipMemcpyAsync(key_out, base + off_key, n * msg_len, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return KEAKI_OK;
+}
+
+// ---- enc::encrypt / enc::decrypt over a batch (src/enc.rs:19-55 inside the loops of src/vec.rs:63-66, :75-78): KEM + the XOR DEM on the device ----
+// d_body_inout: n x msg_len bytes, the messages on entry and the ciphertext bodies on exit (decrypt: the other way round). The key is
+// XORed in by the KDF kernel itself; neither GT bytes nor keys exist outside the device.
+keaki_status keaki_hip_encrypt_batch_dev(keaki_hip_ctx* ctx, const void* d_com_aff, const void* d_tau_g2_aff, const void* d_points,
+                                         const void* d_values, const void* d_r, size_t n, void* d_ct_out_aff, void* d_body_inout, size_t msg_len) {
+  CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.encrypt");
+  if (n == 0) return KEAKI_OK;
+  if (!d_com_aff || !d_tau_g2_aff || !d_points || !d_values || !d_r || !d_ct_out_aff || !d_body_inout || msg_len == 0 || msg_len > 65536)
+    return fail(ctx, KEAKI_ERR_BAD_ARG, "encrypt_batch: bad argument");
+  return encap_impl(ctx, false, d_com_aff, d_tau_g2_aff, d_points, d_values, d_r, n, d_ct_out_aff, nullptr, d_body_inout, msg_len, true);
+}
+keaki_status keaki_hip_decrypt_batch_dev(keaki_hip_ctx* ctx, const void* d_proofs_aff, const void* d_cts_aff, size_t n, void* d_body_inout, size_t msg_len) {
+  CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.decrypt");
+  if (n == 0) return KEAKI_OK;
+  if (!d_proofs_aff || !d_cts_aff || !d_body_inout || msg_len == 0 || msg_len > 65536) return fail(ctx, KEAKI_ERR_BAD_ARG, "decrypt_batch: bad argument");
+  ST_TRY(reserve(ctx, ctx->tmp_b, n * 384));
+  ST_TRY(pairing_run(ctx, d_proofs_aff, d_cts_aff, 1, n, ctx->tmp_b.p));
+  return blake3_gt_run(ctx, ctx->tmp_b.p, n, d_body_inout, msg_len, true);
+}
+keaki_status keaki_hip_encrypt_batch(keaki_hip_ctx* ctx, const uint64_t* com_aff, const uint64_t* tau_g2_aff, const uint64_t* points,
+                                     const uint64_t* values, const uint64_t* r, const uint8_t* msgs, size_t n, uint64_t* ct_out_aff, uint8_t* body_out,
+                                     size_t msg_len) {
+  CTX_GUARD(ctx);
+  if (n == 0) return KEAKI_OK;
+  if (!com_aff || !tau_g2_aff || !points || !values || !r || !msgs || !ct_out_aff || !body_out || msg_len == 0 || msg_len > 65536)
+    return fail(ctx, KEAKI_ERR_BAD_ARG, "encrypt_batch: bad argument");
+  const size_t off_tau = 64, off_pts = off_tau + 128, off_val = off_pts + n * 32, off_r = off_val + n * 32, off_ct = off_r + n * 32,
+               off_body = off_ct + n * 128, total = off_body + n * msg_len + 16;
+  ST_TRY(reserve(ctx, ctx->io_a, total));
+  char* base = (char*)ctx->io_a.p;
+  hipStream_t st = ctx->stream;
+  HIP_TRY(ctx, hipMemcpyAsync(base, com_aff, 64, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(base + off_tau, tau_g2_aff, 128, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(base + off_pts, points, n * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(base + off_val, values, n * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(base + off_r, r, n * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(base + off_body, msgs, n * msg_len, hipMemcpyHostToDevice, st));
+  ST_TRY(keaki_hip_encrypt_batch_dev(ctx, base, base + off_tau, base + off_pts, base + off_val, base + off_r, n, base + off_ct, base + off_body, msg_len));
+  prefault_out(ct_out_aff, n * 128); prefault_out(body_out, n * msg_len);       // while the kernels run
+  HIP_TRY(ctx, hipMemcpyAsync(ct_out_aff, base + off_ct, n * 128, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(body_out, base + off_body, n * msg_len, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return KEAKI_OK;
+}
+keaki_status keaki_hip_decrypt_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_aff, const uint64_t* cts_aff, const uint8_t* bodies, size_t n,
+                                     uint8_t* msgs_out, size_t msg_len) {
+  CTX_GUARD(ctx);
+  if (n == 0) return KEAKI_OK;
+  if (!proofs_aff || !cts_aff || !bodies || !msgs_out || msg_len == 0 || msg_len > 65536) return fail(ctx, KEAKI_ERR_BAD_ARG, "decrypt_batch: bad argument");
+  const size_t off_ct = n * 64, off_body = off_ct + n * 128, total = off_body + n * msg_len + 16;
+  ST_TRY(reserve(ctx, ctx->io_a, total));
+  char* base = (char*)ctx->io_a.p;
+  hipStream_t st = ctx->stream;
+  HIP_TRY(ctx, hipMemcpyAsync(base, proofs_aff, n * 64, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(base + off_ct, cts_aff, n * 128, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(base + off_body, bodies, n * msg_len, hipMemcpyHostToDevice, st));
+  ST_TRY(keaki_hip_decrypt_batch_dev(ctx, base, base + off_ct, n, base + off_body, msg_len));
+  prefault_out(msgs_out, n * msg_len);
+  HIP_TRY(ctx, hipMemcpyAsync(msgs_out, base + off_body, n * msg_len, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   return KEAKI_OK;
 }

@@ -292,6 +292,39 @@ keaki_status keaki_hip_group_decap_batch(keaki_hip_group* g, const uint64_t* pro
   });
 }
 
+// enc::encrypt / enc::decrypt over the batch (KEM + XOR DEM on the devices), by item range
+keaki_status keaki_hip_group_encrypt_batch(keaki_hip_group* g, const uint64_t* com_aff, const uint64_t* tau_g2_aff, const uint64_t* points,
+                                           const uint64_t* values, const uint64_t* r, const uint8_t* msgs, size_t n, uint64_t* ct_out_aff,
+                                           uint8_t* body_out, size_t msg_len) {
+  if (!g) return KEAKI_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (n == 0) return KEAKI_OK;
+  if (!com_aff || !tau_g2_aff || !points || !values || !r || !msgs || !ct_out_aff || !body_out || msg_len == 0 || msg_len > 65536)
+    return gfail(g, KEAKI_ERR_BAD_ARG, "group_encrypt_batch: bad argument");
+  const size_t N = g->ctx.size();
+  return run_all(g, "group_encrypt_batch", [&](size_t i) -> keaki_status {
+    size_t lo, hi;
+    range_of(n, N, i, &lo, &hi);
+    if (hi == lo) return KEAKI_OK;
+    return keaki_hip_encrypt_batch(g->ctx[i], com_aff, tau_g2_aff, points + 4 * lo, values + 4 * lo, r + 4 * lo, msgs + msg_len * lo, hi - lo,
+                                   ct_out_aff + 16 * lo, body_out + msg_len * lo, msg_len);
+  });
+}
+keaki_status keaki_hip_group_decrypt_batch(keaki_hip_group* g, const uint64_t* proofs_aff, const uint64_t* cts_aff, const uint8_t* bodies, size_t n,
+                                           uint8_t* msgs_out, size_t msg_len) {
+  if (!g) return KEAKI_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (n == 0) return KEAKI_OK;
+  if (!proofs_aff || !cts_aff || !bodies || !msgs_out || msg_len == 0 || msg_len > 65536) return gfail(g, KEAKI_ERR_BAD_ARG, "group_decrypt_batch: bad argument");
+  const size_t N = g->ctx.size();
+  return run_all(g, "group_decrypt_batch", [&](size_t i) -> keaki_status {
+    size_t lo, hi;
+    range_of(n, N, i, &lo, &hi);
+    if (hi == lo) return KEAKI_OK;
+    return keaki_hip_decrypt_batch(g->ctx[i], proofs_aff + 8 * lo, cts_aff + 16 * lo, bodies + msg_len * lo, hi - lo, msgs_out + msg_len * lo, msg_len);
+  });
+}
+
 // ---- FK23 (kzg::open_fk, src/kzg.rs:157-203) over the members of a group -------------------------------------------------------------------
 // The sharded pipeline of keaki_hip_fk_shard_* (member i = rank i: 1/N of the butterflies of both size-d transforms and of the 2d scalar-mults)
 // with the exchanges done HERE, in-process: an all-to-all is N^2 device-to-device copies between the members' buffers (hipMemcpyPeer; plain

@@ -159,7 +159,7 @@ keaki_status miller_only_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d
 keaki_status final_exp_only_run(keaki_hip_ctx* ctx, const void* d_in, size_t n, void* d_gt);
 keaki_status g2_prepare_run(keaki_hip_ctx* ctx, const void* d_q, void* d_lines);   // line sequence of a fixed Q (2^261 form: internal)
 keaki_status lines_to256_run(keaki_hip_ctx* ctx, const void* d_lines261, void* d_lines256);   // the same table in the ABI's 2^256 form (test hook)
-keaki_status blake3_gt_run(keaki_hip_ctx* ctx, const void* d_gt, size_t n, void* d_key, size_t msg_len);
+keaki_status blake3_gt_run(keaki_hip_ctx* ctx, const void* d_gt, size_t n, void* d_key, size_t msg_len, bool xor_into = false);   // xor_into: key ^= in place (the DEM)
 keaki_status g2_generator_to(keaki_hip_ctx* ctx, void* d_dst);  // writes the affine G2 generator (128 B)
 keaki_status g1_generator_to(keaki_hip_ctx* ctx, void* d_dst);  // affine G1 generator (64 B)
 size_t fb_table_entries(uint32_t wb);                                                          // window-table entries per base at window width wb

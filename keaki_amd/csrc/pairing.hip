@@ -72,8 +72,9 @@ keaki_status miller_only_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d
 keaki_status final_exp_only_run(keaki_hip_ctx* ctx, const void* d_in, size_t n, void* d_gt) {
   return pairing_launch(ctx, PAIR_FINAL_EXP | PAIR_OUT_BYTES, nullptr, nullptr, 0, d_in, n, d_gt, 384, nullptr, 0, "final_exp_only");
 }
-keaki_status blake3_gt_run(keaki_hip_ctx* ctx, const void* d_gt, size_t n, void* d_key, size_t msg_len) {
-  hipLaunchKernelGGL(k_blake3_gt_xof, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const u32*)d_gt, (u32)n, (unsigned char*)d_key, (u32)msg_len);
+keaki_status blake3_gt_run(keaki_hip_ctx* ctx, const void* d_gt, size_t n, void* d_key, size_t msg_len, bool xor_into) {
+  hipLaunchKernelGGL(k_blake3_gt_xof, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (const u32*)d_gt, (u32)n, (unsigned char*)d_key, (u32)msg_len,
+                     xor_into ? 1u : 0u);
   return launch_check(ctx, "blake3_gt_xof");
 }
 }  // namespace keaki_internal

@@ -431,7 +431,9 @@ KDEV void b3_compress(u32* out16, const u32* cv, const u32* blk, u64 counter, u3
 #pragma unroll
   for (int i = 0; i < 8; i++) { out16[i] = s[i] ^ s[i + 8]; out16[i + 8] = s[i + 8] ^ cv[i]; }
 }
-static __global__ void __launch_bounds__(256) k_blake3_gt_xof(const u32* __restrict__ gt, u32 n, unsigned char* __restrict__ key_out, u32 msg_len) {
+// xor_into != 0: the DEM of src/enc.rs:32-36 / :48-52 behind the KDF -- key_out holds the messages (ciphertext bodies) on entry and the
+// ciphertext bodies (messages) on exit; the key never leaves the device.
+static __global__ void __launch_bounds__(256) k_blake3_gt_xof(const u32* __restrict__ gt, u32 n, unsigned char* __restrict__ key_out, u32 msg_len, u32 xor_into) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u32* in = gt + (size_t)96 * i;
@@ -452,7 +454,8 @@ static __global__ void __launch_bounds__(256) k_blake3_gt_xof(const u32* __restr
   for (u32 t = 0; t * 64 < msg_len; t++) {
     b3_compress(o, cv, blk, t, 64, 2u | 8u);  // CHUNK_END | ROOT, output block counter t
     u32 nb = msg_len - t * 64; if (nb > 64) nb = 64;
-    for (u32 k = 0; k < nb; k++) dst[t * 64 + k] = (unsigned char)(o[k >> 2] >> (8 * (k & 3)));
+    if (xor_into) { for (u32 k = 0; k < nb; k++) dst[t * 64 + k] ^= (unsigned char)(o[k >> 2] >> (8 * (k & 3))); }
+    else { for (u32 k = 0; k < nb; k++) dst[t * 64 + k] = (unsigned char)(o[k >> 2] >> (8 * (k & 3))); }
   }
 }
 

@@ -23,6 +23,8 @@ EXPORTS = [
     "keaki_hip_g1_mul_batch", "keaki_hip_g2_mul_batch", "keaki_hip_g1_mul_batch_dev", "keaki_hip_g2_mul_batch_dev",
     "keaki_hip_pairing_batch", "keaki_hip_pairing_batch_dev",
     "keaki_hip_encap_batch", "keaki_hip_encap_batch_dev", "keaki_hip_decap_batch", "keaki_hip_decap_batch_dev",
+    "keaki_hip_encrypt_batch", "keaki_hip_encrypt_batch_dev", "keaki_hip_decrypt_batch", "keaki_hip_decrypt_batch_dev",
+    "keaki_hip_group_encrypt_batch", "keaki_hip_group_decrypt_batch",
     "keaki_hip_selftest_field", "keaki_hip_open_fk", "keaki_hip_open_fk_poly", "keaki_hip_srs_g1_precompute_fk", "keaki_hip_fk_shard_create", "keaki_hip_fk_shard_free", "keaki_hip_fk_shard_sizes", "keaki_hip_fk_shard_setup", "keaki_hip_fk_shard_open", "keaki_hip_fr_fft", "keaki_hip_srs_g1_check", "keaki_hip_g2_check", "keaki_hip_kzg_open", "keaki_hip_kzg_verify", "keaki_hip_final_exp_batch", "keaki_hip_miller_loop_batch", "keaki_hip_g2_prepare", "keaki_hip_set_timing", "keaki_hip_last_msm_bucket_ms", "keaki_hip_last_msm_total_ms", "keaki_hip_last_msm_window_bits",
     "keaki_hip_last_fk_ms", "keaki_hip_ctx_stream", "keaki_hip_ctx_device", "keaki_hip_ctx_set_option", "keaki_hip_debug_set_alloc_limit", "keaki_hip_ctx_memory", "keaki_hip_ctx_trim", "keaki_hip_kzg_quotient", "keaki_hip_vec_commit", "keaki_hip_encap_prepare",
     "keaki_hip_group_create", "keaki_hip_group_destroy", "keaki_hip_group_size", "keaki_hip_group_ctx", "keaki_hip_group_last_error",
@@ -168,6 +170,12 @@ def load_library():
         lib.keaki_hip_group_kzg_open.argtypes = [vp, vp, vp, sz, vp, vp, vp]
         lib.keaki_hip_group_encap_batch.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, sz]
         lib.keaki_hip_group_decap_batch.argtypes = [vp, vp, vp, sz, vp, vp, sz]
+        lib.keaki_hip_encrypt_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, sz]
+        lib.keaki_hip_encrypt_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, vp, sz]
+        lib.keaki_hip_decrypt_batch.argtypes = [vp, vp, vp, vp, sz, vp, sz]
+        lib.keaki_hip_decrypt_batch_dev.argtypes = [vp, vp, vp, sz, vp, sz]
+        lib.keaki_hip_group_encrypt_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, sz]
+        lib.keaki_hip_group_decrypt_batch.argtypes = [vp, vp, vp, vp, sz, vp, sz]
         lib.keaki_hip_group_fk_create.argtypes = [vp, vp, C.c_uint32, vp, vp, vp, C.POINTER(vp)]
         lib.keaki_hip_group_fk_open.argtypes = [vp, vp, vp, vp]
         lib.keaki_hip_group_fk_free.argtypes = [vp, vp]
@@ -508,6 +516,25 @@ class KeakiHip:
         self._ck(self.lib.keaki_hip_decap_batch(self.ctx, _ptr(p), _ptr(c), n, _ptr(gt), _ptr(key) if msg_len else None, msg_len))
         return gt, key[:, :msg_len]
 
+    def encrypt_batch(self, com, tau_g2, points, values, rs, msgs):
+        """enc::encrypt over a batch (src/enc.rs:19-40 in the loop of src/vec.rs:63-66): msgs is an (n, msg_len) uint8 array.
+        Returns (ct points (n, 16) u64, ciphertext bodies (n, msg_len) u8); the XOR runs on the device behind the KDF."""
+        p, v, r = _np(points, 4), _np(values, 4), _np(rs, 4)
+        m = np.ascontiguousarray(msgs, dtype=np.uint8)
+        n, msg_len = m.shape
+        ct = np.zeros((n, 16), np.uint64); body = np.zeros((n, msg_len), np.uint8)
+        self._ck(self.lib.keaki_hip_encrypt_batch(self.ctx, _ptr(_np(com)), _ptr(_np(tau_g2)), _ptr(p), _ptr(v), _ptr(r), _ptr(m), n, _ptr(ct), _ptr(body), msg_len))
+        return ct, body
+
+    def decrypt_batch(self, proofs, cts, bodies):
+        """enc::decrypt over a batch (src/enc.rs:44-55 in the loop of src/vec.rs:75-78): returns the (n, msg_len) messages."""
+        pr, c = _np(proofs, 8), _np(cts, 16)
+        b = np.ascontiguousarray(bodies, dtype=np.uint8)
+        n, msg_len = b.shape
+        out = np.zeros((n, msg_len), np.uint8)
+        self._ck(self.lib.keaki_hip_decrypt_batch(self.ctx, _ptr(pr), _ptr(c), _ptr(b), n, _ptr(out), msg_len))
+        return out
+
     def decap_batch_dev(self, d_proofs, d_cts, n, d_gt, d_key, msg_len):
         v = lambda x: C.c_void_p(x) if x else None
         self._ck(self.lib.keaki_hip_decap_batch_dev(self.ctx, v(d_proofs), v(d_cts), n, v(d_gt), v(d_key), msg_len))
@@ -604,6 +631,22 @@ class KeakiHipGroup:
         self._ck(self.lib.keaki_hip_group_encap_batch(self.g, _ptr(com), _ptr(tau), _ptr(pts), _ptr(vals), _ptr(rs), n,
                                                       _ptr(ct), _ptr(gt), _ptr(key) if msg_len else None, msg_len))
         return ct, gt, key[:, :msg_len]
+
+    def encrypt_batch(self, com, tau_g2, points, values, rs, msgs):
+        p, v, r = _np(points, 4), _np(values, 4), _np(rs, 4)
+        m = np.ascontiguousarray(msgs, dtype=np.uint8)
+        n, msg_len = m.shape
+        ct = np.zeros((n, 16), np.uint64); body = np.zeros((n, msg_len), np.uint8)
+        self._ck(self.lib.keaki_hip_group_encrypt_batch(self.g, _ptr(_np(com)), _ptr(_np(tau_g2)), _ptr(p), _ptr(v), _ptr(r), _ptr(m), n, _ptr(ct), _ptr(body), msg_len))
+        return ct, body
+
+    def decrypt_batch(self, proofs, cts, bodies):
+        pr, c = _np(proofs, 8), _np(cts, 16)
+        b = np.ascontiguousarray(bodies, dtype=np.uint8)
+        n, msg_len = b.shape
+        out = np.zeros((n, msg_len), np.uint8)
+        self._ck(self.lib.keaki_hip_group_decrypt_batch(self.g, _ptr(pr), _ptr(c), _ptr(b), n, _ptr(out), msg_len))
+        return out
 
     def decap_batch(self, proofs, cts, msg_len: int = 32):
         p = _np(proofs, 8); c = _np(cts, 16); n = p.shape[0]

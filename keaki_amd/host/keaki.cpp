@@ -348,6 +348,20 @@ void encap_many(const kzg::KZGSetup& setup, const G1& com, const uint64_t* point
   else
     dev.check(keaki_hip_encap_batch(dev.ctx(), com.w.data(), setup.tau_g2().w.data(), points, values, rs, n, ct, nullptr, key, msg_len));
 }
+// enc::encrypt / enc::decrypt per item (src/enc.rs:19-55) as one batched call: KEM + the XOR DEM on the device(s)
+void encrypt_many(const kzg::KZGSetup& setup, const G1& com, const uint64_t* points, const uint64_t* values, const uint64_t* rs, const uint8_t* msgs,
+                  size_t n, uint64_t* ct, uint8_t* body, size_t msg_len) {
+  const Device& dev = *setup.device();
+  if (dev.group() && n >= GROUP_MIN_ITEMS)
+    dev.check_group(keaki_hip_group_encrypt_batch(dev.group(), com.w.data(), setup.tau_g2().w.data(), points, values, rs, msgs, n, ct, body, msg_len));
+  else
+    dev.check(keaki_hip_encrypt_batch(dev.ctx(), com.w.data(), setup.tau_g2().w.data(), points, values, rs, msgs, n, ct, body, msg_len));
+}
+void decrypt_many(const kzg::KZGSetup& setup, const uint64_t* proofs, const uint64_t* cts, const uint8_t* bodies, size_t n, uint8_t* msgs, size_t msg_len) {
+  const Device& dev = *setup.device();
+  if (dev.group() && n >= GROUP_MIN_ITEMS) dev.check_group(keaki_hip_group_decrypt_batch(dev.group(), proofs, cts, bodies, n, msgs, msg_len));
+  else dev.check(keaki_hip_decrypt_batch(dev.ctx(), proofs, cts, bodies, n, msgs, msg_len));
+}
 void decap_many(const kzg::KZGSetup& setup, const uint64_t* proofs, const uint64_t* cts, size_t n, uint8_t* key, size_t msg_len) {
   const Device& dev = *setup.device();
   if (dev.group() && n >= GROUP_MIN_ITEMS)
@@ -492,13 +506,13 @@ void vec_encrypt_flat(Rng& rng, const kzg::KZGSetup& setup, const G1& com, const
     std::thread ahead;
     if (k + 1 < pieces) ahead = std::thread(draw, hi, bound(k + 2));
     try {
-      if (m && msg_len) encap_many(setup, com, points[lo].l, values[lo].l, rs[lo].l, m, ct_g2_out + 16 * lo, ct_msg_out + msg_len * lo, msg_len);
+      if (m && msg_len)                                                                                         // src/enc.rs:32-36 on the device
+        encrypt_many(setup, com, points[lo].l, values[lo].l, rs[lo].l, msgs + msg_len * lo, m, ct_g2_out + 16 * lo, ct_msg_out + msg_len * lo, msg_len);
       else if (m) {
         gt_unused.resize(m * 384);       // the ABI wants at least one of gt / key
         setup.device()->check(keaki_hip_encap_batch(setup.device()->ctx(), com.w.data(), setup.tau_g2().w.data(), points[lo].l, values[lo].l, rs[lo].l, m,
                                                     ct_g2_out + 16 * lo, gt_unused.data(), nullptr, 0));
       }
-      for (size_t i = lo * msg_len; i < hi * msg_len; i++) ct_msg_out[i] ^= msgs[i];                            // src/enc.rs:32-36
     } catch (...) {
       if (ahead.joinable()) ahead.join();
       throw;
@@ -509,8 +523,7 @@ void vec_encrypt_flat(Rng& rng, const kzg::KZGSetup& setup, const G1& com, const
 void vec_decrypt_flat(const kzg::KZGSetup& setup, const uint64_t* proofs, const uint64_t* ct_g2, const uint8_t* ct_msgs, size_t n, size_t msg_len,
                       uint8_t* msgs_out) {
   if (!n || !msg_len) return;
-  decap_many(setup, proofs, ct_g2, n, msgs_out, msg_len);
-  for (size_t i = 0; i < n * msg_len; i++) msgs_out[i] ^= ct_msgs[i];                                         // src/enc.rs:48-52
+  decrypt_many(setup, proofs, ct_g2, ct_msgs, n, msgs_out, msg_len);                                          // src/enc.rs:48-52 on the device
 }
 std::vector<std::vector<uint8_t>> vec_decrypt(const kzg::KZGSetup& setup, const std::vector<G1>& proofs,
                                               const std::vector<const enc::Ciphertext*>& cts) {

@@ -143,6 +143,16 @@ extern "C" {
                                  msg_len: usize) -> keaki_status;
     pub fn keaki_hip_decap_batch_dev(ctx: *mut keaki_hip_ctx, d_proofs_aff: *const c_void, d_cts_aff: *const c_void, n: usize, d_gt_out: *mut c_void,
                                      d_key_out: *mut c_void, msg_len: usize) -> keaki_status;
+    // enc::encrypt / enc::decrypt over a batch: KEM + the XOR DEM on the device (src/enc.rs:19-55 inside src/vec.rs:63-66, :75-78)
+    pub fn keaki_hip_encrypt_batch(ctx: *mut keaki_hip_ctx, com_aff: *const u64, tau_g2_aff: *const u64, points: *const u64, values: *const u64,
+                                   r: *const u64, msgs: *const u8, n: usize, ct_out_aff: *mut u64, body_out: *mut u8, msg_len: usize) -> keaki_status;
+    pub fn keaki_hip_encrypt_batch_dev(ctx: *mut keaki_hip_ctx, d_com_aff: *const c_void, d_tau_g2_aff: *const c_void, d_points: *const c_void,
+                                       d_values: *const c_void, d_r: *const c_void, n: usize, d_ct_out_aff: *mut c_void, d_body_inout: *mut c_void,
+                                       msg_len: usize) -> keaki_status;
+    pub fn keaki_hip_decrypt_batch(ctx: *mut keaki_hip_ctx, proofs_aff: *const u64, cts_aff: *const u64, bodies: *const u8, n: usize, msgs_out: *mut u8,
+                                   msg_len: usize) -> keaki_status;
+    pub fn keaki_hip_decrypt_batch_dev(ctx: *mut keaki_hip_ctx, d_proofs_aff: *const c_void, d_cts_aff: *const c_void, n: usize,
+                                       d_body_inout: *mut c_void, msg_len: usize) -> keaki_status;
 
     // ---- device group: several GPUs of ONE process (one context + one host thread per member inside the library)
     pub fn keaki_hip_group_create(devices: *const i32, n_devices: usize, out: *mut *mut keaki_hip_group) -> keaki_status;
@@ -163,6 +173,10 @@ extern "C" {
                                        r: *const u64, n: usize, ct_out_aff: *mut u64, gt_out: *mut u8, key_out: *mut u8, msg_len: usize) -> keaki_status;
     pub fn keaki_hip_group_decap_batch(g: *mut keaki_hip_group, proofs_aff: *const u64, cts_aff: *const u64, n: usize, gt_out: *mut u8, key_out: *mut u8,
                                        msg_len: usize) -> keaki_status;
+    pub fn keaki_hip_group_encrypt_batch(g: *mut keaki_hip_group, com_aff: *const u64, tau_g2_aff: *const u64, points: *const u64, values: *const u64,
+                                         r: *const u64, msgs: *const u8, n: usize, ct_out_aff: *mut u64, body_out: *mut u8, msg_len: usize) -> keaki_status;
+    pub fn keaki_hip_group_decrypt_batch(g: *mut keaki_hip_group, proofs_aff: *const u64, cts_aff: *const u64, bodies: *const u8, n: usize,
+                                         msgs_out: *mut u8, msg_len: usize) -> keaki_status;
 
     pub fn keaki_hip_group_fk_create(g: *mut keaki_hip_group, points_aff: *const u64, log2d: u32, omega_2d: *const u64, omega_2d_inv: *const u64,
                                      inv_2d: *const u64, out: *mut *mut keaki_hip_group_fk) -> keaki_status;

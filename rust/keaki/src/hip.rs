@@ -555,6 +555,53 @@ pub fn decap_batch(proofs: &[G1Projective], cts: &[G2Projective], msg_len: usize
     key
 }
 
+/// `enc::encrypt` for all items of `vec_encrypt` at once (src/vec.rs:63-66 -> src/enc.rs:19-40): equal-length messages, contiguous. The XOR of
+/// src/enc.rs:32-36 runs on the device behind the KDF: neither GT bytes nor keys come back. Returns the ciphertext points and the bodies.
+pub fn encrypt_batch(commitment: &G1Projective, tau_g2: &G2Projective, points: &[Fr], values: &[Fr], rs: &[Fr], msgs: &[u8], msg_len: usize) -> (Vec<G2Projective>, Vec<u8>) {
+    let dev = Device::global();
+    let n = points.len();
+    assert!(values.len() >= n && rs.len() == n && msg_len > 0 && msgs.len() == n * msg_len);
+    let (c, t) = (g1_words(&commitment.into_affine()), g2_words(&tau_g2.into_affine()));
+    let mut ct = vec![0u64; 16 * n];
+    let mut body = vec![0u8; n * msg_len];
+    if !dev.group.is_null() && n >= GROUP_MIN_ITEMS {
+        dev.check_group(
+            unsafe {
+                sys::keaki_hip_group_encrypt_batch(dev.group, c.as_ptr(), t.as_ptr(), fr_ptr(points), fr_ptr(values), fr_ptr(rs), msgs.as_ptr(), n, ct.as_mut_ptr(), body.as_mut_ptr(), msg_len)
+            },
+            "group_encrypt_batch",
+        );
+    } else {
+        dev.check(
+            unsafe { sys::keaki_hip_encrypt_batch(dev.ctx, c.as_ptr(), t.as_ptr(), fr_ptr(points), fr_ptr(values), fr_ptr(rs), msgs.as_ptr(), n, ct.as_mut_ptr(), body.as_mut_ptr(), msg_len) },
+            "encrypt_batch",
+        );
+    }
+    (ct.chunks_exact(16).map(|w| g2_from_words(w).into()).collect(), body)
+}
+
+/// `enc::decrypt` for all items of `vec_decrypt` at once (src/vec.rs:75-78 -> src/enc.rs:44-55): the messages.
+pub fn decrypt_batch(proofs: &[G1Projective], cts: &[G2Projective], bodies: &[u8], msg_len: usize) -> Vec<u8> {
+    let dev = Device::global();
+    let n = cts.len();
+    if n == 0 || msg_len == 0 {
+        return Vec::new();
+    }
+    assert!(bodies.len() == n * msg_len);
+    let p: Vec<u64> = G1Projective::normalize_batch(&proofs[..n]).iter().flat_map(|a| g1_words(a)).collect();
+    let q: Vec<u64> = G2Projective::normalize_batch(cts).iter().flat_map(|a| g2_words(a)).collect();
+    let mut out = vec![0u8; n * msg_len];
+    if !dev.group.is_null() && n >= GROUP_MIN_ITEMS {
+        dev.check_group(
+            unsafe { sys::keaki_hip_group_decrypt_batch(dev.group, p.as_ptr(), q.as_ptr(), bodies.as_ptr(), n, out.as_mut_ptr(), msg_len) },
+            "group_decrypt_batch",
+        );
+    } else {
+        dev.check(unsafe { sys::keaki_hip_decrypt_batch(dev.ctx, p.as_ptr(), q.as_ptr(), bodies.as_ptr(), n, out.as_mut_ptr(), msg_len) }, "decrypt_batch");
+    }
+    out
+}
+
 /// `serialize_uncompressed(E::pairing(p, q))` for a batch (tests and callers that want GT itself).
 pub fn pairing_bytes(ps: &[G1Affine], qs: &[G2Affine]) -> Vec<u8> {
     let dev = Device::global();

@@ -234,3 +234,34 @@ fn vec_flow_matches_serial_arkworks_loop() {
     assert_eq!(d1, m1, "messages recovered");
     let _ = (open_fk::<Bn254>, decapsulate::<Bn254>, Fq2::new(Fq::from(0u64), Fq::from(0u64)), G2Projective::default());
 }
+
+#[test]
+fn vec_flow_equal_length_messages_device_dem_matches_serial_arkworks_loop() {
+    gpu_for_small_batches();
+    // Laconic OT's own shape (tests/laconic_ot.rs:121-124): 32-byte messages of equal length -> keaki_hip_encrypt_batch / _decrypt_batch, the XOR of
+    // src/enc.rs:32-36 / :48-52 on the device behind the KDF (with KEAKI_HIP_DEVICES set: the group variants, by item range)
+    let n = 15usize;
+    let run = |hip_on: bool| {
+        if !hip_on {
+            std::env::set_var("KEAKI_HIP", "off");
+        }
+        let rng = &mut test_rng();
+        let setup = KZGSetup::<Bn254>::setup(Fr::rand(rng), 16);
+        let v: Vec<Fr> = (0..n).map(|i| Fr::from((i % 2) as u64)).collect();
+        let (com, proofs) = vec_commit(rng, &setup, &v).unwrap();
+        let dom = Radix2EvaluationDomain::<Fr>::new(n + 1).unwrap();
+        let points: Vec<Fr> = dom.elements().collect();
+        let msgs: Vec<Vec<u8>> = (0..n).map(|i| (0..32u8).map(|j| j.wrapping_mul(i as u8 + 3)).collect()).collect();
+        let refs: Vec<&[u8]> = msgs.iter().map(|m| m.as_slice()).collect();
+        let cts = vec_encrypt(rng, &setup, com, &points, &v, &refs);
+        let ct_refs: Vec<_> = cts.iter().collect();
+        let dec = vec_decrypt::<Bn254>(&proofs, &ct_refs);
+        std::env::remove_var("KEAKI_HIP");
+        (cts.iter().map(|c| (c.0.into_affine(), c.1.clone())).collect::<Vec<_>>(), dec, msgs)
+    };
+    let (e1, d1, m1) = run(true);
+    let (e0, d0, _) = run(false);
+    assert_eq!(e1, e0, "ciphertext points and bodies");
+    assert_eq!(d1, d0);
+    assert_eq!(d1, m1, "messages recovered");
+}

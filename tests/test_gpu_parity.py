@@ -899,3 +899,37 @@ def test_pytorch_can_start_after_the_library():
             "assert h.selftest_field(4, 2, 2) == 0; h.close(); print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)      # a fresh box pages PyTorch in for a minute or two
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("msg_len", [1, 31, 32, 33, 64, 65, 200])
+def test_encrypt_decrypt_batch_device_dem_vs_oracle(oc, hip, msg_len):
+    """keaki_hip_encrypt_batch / _decrypt_batch = enc::encrypt / enc::decrypt per item (src/enc.rs:19-55 inside src/vec.rs:63-66, :75-78) with
+    the XOR DEM on the device: ciphertext points as encap_batch, bodies == the oracle's key XOR message, and the round trip through the
+    proofs' pairing relation (a valid opening decrypts, a wrong proof does not)."""
+    from bench import random_fr_limbs
+    n = 777
+    g1, g2 = oc.generators()
+    rng = np.random.default_rng(msg_len)
+    com = hip.g1_mul_batch(g1, random_fr_limbs(1, 91))[0]
+    tau_g2 = hip.g2_mul_batch(g2, random_fr_limbs(1, 92))[0]
+    A, V, R = random_fr_limbs(n, 93), random_fr_limbs(n, 94), random_fr_limbs(n, 95)
+    msgs = rng.integers(0, 256, (n, msg_len), dtype=np.uint8)
+    ct, body = hip.encrypt_batch(com, tau_g2, A, V, R, msgs)
+    ect, _, ekey = oc.encap_batch(com, tau_g2, A, V, R, msg_len, threads=os.cpu_count() or 1)
+    assert np.array_equal(ct, ect) and np.array_equal(body, ekey ^ msgs)
+    ct2, key2 = hip.encap_batch(com, tau_g2, A, V, R, msg_len, want_gt=False)
+    assert np.array_equal(ct2, ct) and np.array_equal(key2 ^ msgs, body)
+    # decrypt: any (proof, ct) pair decapsulates to H(e(proof, ct)); compare with the oracle's decapsulation on the same pairs
+    proofs = hip.g1_mul_batch(g1, random_fr_limbs(n, 96))
+    out = hip.decrypt_batch(proofs, ct, body)
+    _, dkey = oc.decap_batch(proofs, ct, msg_len, threads=os.cpu_count() or 1)
+    assert np.array_equal(out, dkey ^ body)
+    # the in-process group splits the items by range: same bytes
+    from keaki_amd.hip import KeakiHipGroup
+    g = KeakiHipGroup([0, 0, 0])
+    try:
+        gct, gbody = g.encrypt_batch(com, tau_g2, A, V, R, msgs)
+        assert np.array_equal(gct, ct) and np.array_equal(gbody, body)
+        assert np.array_equal(g.decrypt_batch(proofs, ct, body), out)
+    finally:
+        g.close()
