@@ -539,7 +539,7 @@ def main():
     # HBM traffic of the dominant kernel from PMC counters (separate rocprofv3 --pmc passes, committed under profiles/, stamped with
     # the kernel sources they were measured on)
     traffic, traffic_note = None, None
-    tj, why = stamped_profile("r03_msm_2p24_hbm_traffic_pmc.json", MSM_KERNEL_SOURCES)
+    tj, why = stamped_profile("r04_msm_2p24_hbm_traffic_pmc.json", MSM_KERNEL_SOURCES)
     if tj is None:
         traffic_note = why
     elif tj.get("log2n") != args.log2n or bool(tj.get("precompute", True)) != (not args.no_precompute):

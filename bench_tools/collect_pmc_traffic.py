@@ -51,7 +51,7 @@ def main():
                        "x 2^24 x 64 B = 12.9 GB of table rows + 0.8 GB of sorted indices; writes = 2^21 buckets x 128 B.",
                "kernels": kernels}, open(dst, "w"), indent=1)
     for k, v in kernels.items():
-        if "part_" in k or "accumulate" in k:
+        if "part_" in k or "_sort" in k or "accumulate" in k:
             print(k[:60], v)
 
 

@@ -1052,9 +1052,11 @@ __global__ void __launch_bounds__(64) k_msm_partial_groups(const Xyzz<F>* __rest
 }
 
 // ---- K6a: sum the chunk partials of each window, then scale by 2^(w c) ---------------------------------
+template <class F> KDEV void store_norm_jac(F* out, const Xyzz<F>& p);
+// out_jac != nullptr (one window: the shared-bucket path): the window sum IS the result -- normalised and written here, no k_msm_final launch
 template <class F>
 __global__ void __launch_bounds__(64) k_msm_window_finish(const Xyzz<F>* __restrict__ partials, MsmShape s, u32 chunks_per_window,
-                                                          Xyzz<F>* __restrict__ window_sums) {
+                                                          Xyzz<F>* __restrict__ window_sums, F* __restrict__ out_jac) {
   typedef TailOps<F> O;
   __shared__ typename O::P sh[64];
   u32 w = blockIdx.x, l = threadIdx.x;
@@ -1069,7 +1071,9 @@ __global__ void __launch_bounds__(64) k_msm_window_finish(const Xyzz<F>* __restr
   if (l == 0) {
     typename O::P r = sh[0];
     for (u32 k = 0, nd = msm_bit_offset(s, w); k < nd; k++) r = O::dbl(r);
-    window_sums[w] = O::store(r);
+    const Xyzz<F> rs = O::store(r);
+    if (out_jac) store_norm_jac(out_jac, rs);
+    else window_sums[w] = rs;
   }
 }
 
@@ -1077,7 +1081,7 @@ __global__ void __launch_bounds__(64) k_msm_window_finish(const Xyzz<F>* __restr
 template <class F> KDEV Aff<F> xyzz_to_aff_tail(const Xyzz<F>& p) { return xyzz_to_aff(p); }
 template <> KDEV Aff<Fq> xyzz_to_aff_tail<Fq>(const Xyzz<Fq>& p) {   // single lane: the binary-GCD inverse instead of the Fermat ladder
   if (xyzz_is_inf(p)) return aff_inf<Fq>();
-  Fq izzz = fq_inv_xgcd(p.zzz);
+  Fq izzz = fq_inv(p.zzz);            // division steps (safegcd): ~22 K plain instructions, no data-dependent trip count
   Fq izz = fq_sqr(izzz) * fq_sqr(p.zz);
   return {p.x * izz, p.y * izzz};
 }

@@ -181,8 +181,8 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
     hipLaunchKernelGGL((k_msm_partial_groups<F>), dim3(chunks2, rs.W), dim3(64), 0, st, (const Xyzz<F>*)partials, chunks, G, chunks2, partials2);
     fin_in = partials2; fin_chunks = chunks2;
   }
-  hipLaunchKernelGGL((k_msm_window_finish<F>), dim3(rs.W), dim3(64), 0, st, fin_in, rs, fin_chunks, wsums);
-  hipLaunchKernelGGL((k_msm_final<F>), dim3(1), dim3(64), 0, st, (const Xyzz<F>*)wsums, rs.W, out);
+  hipLaunchKernelGGL((k_msm_window_finish<F>), dim3(rs.W), dim3(64), 0, st, fin_in, rs, fin_chunks, wsums, rs.W == 1 ? out : (F*)nullptr);
+  if (rs.W != 1) hipLaunchKernelGGL((k_msm_final<F>), dim3(1), dim3(64), 0, st, (const Xyzz<F>*)wsums, rs.W, out);
   ST_TRY(launch_check(ctx, "msm_reduce/final"));
   if (ctx->timing) {
     (void)hipEventRecord(ctx->ev[3], st);
