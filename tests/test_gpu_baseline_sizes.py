@@ -215,3 +215,46 @@ def test_config1_degree_128_commit_open_verify_through_the_mirror(oc, py):
     with pytest.raises(K.KZGError) as e:
         K.commit(setup, np.vstack([coeffs_m, rng.fr_rand()]))
     assert e.value == K.KZGError(130, 129)
+
+
+@pytest.mark.parametrize("bits,log2n", [(11, 22), (20, 21), (34, 20)])
+def test_msm_skewed_digits_exercise_the_sort_slow_paths(oc, hip, bits, log2n):
+    """Scalars below 2^bits put every pair into a few bins of the bucket sort (round 4's two-pass sort, csrc/msm.hip.h):
+      11 bits: 2,048 buckets of 2,048 pairs each -- cells of hundreds of entries, finished by the groups' tail loops (and chunk after chunk of one bin);
+      20 bits: one pair per scalar, cells of ~3 entries -- chunks with more cells than the gather shape holds take the plain walk;
+      34 bits: two windows, the second one sparse.
+    With and without window tables, by the O(n) identity MSM(s, k_i G) == (sum s_i k_i) G; must not take longer than a few ordinary MSMs."""
+    import time
+    from bench import random_fr_limbs
+    from keaki_amd.hip import jac_to_affine_words
+    torch, dev = _torch_dev()
+    n = 1 << log2n
+    k = random_fr_limbs(n, 0x5CE0 + bits)
+    rng = np.random.default_rng(bits)
+    vals = rng.integers(0, 1 << bits, n, dtype=np.uint64)
+    vals[::7] = 0                                                          # zero scalars in between
+    canon = np.zeros((n, 4), np.uint64); canon[:, 0] = vals
+    s = oc.fr_to_mont(canon)
+    d_pts = _gen_points_dev(hip, torch, dev, k)
+    d_s = torch.from_numpy(s.view(np.int64)).to(dev)
+    d_out = torch.zeros(12, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(dev)
+    g1, _ = oc.generators()
+    exp = oc.g1_mul_batch(g1, oc.fr_dot(s, k).reshape(1, 4))[0]
+    srs = hip.srs_g1_wrap_dev(d_pts.data_ptr(), n)
+    try:
+        for tables in (False, True):
+            if tables:
+                assert hip.srs_g1_precompute(srs) > 0
+            d_out.zero_()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            hip.msm_g1_dev(srs, d_s.data_ptr(), n, d_out.data_ptr())
+            hip.synchronize()
+            dt = time.perf_counter() - t0
+            assert np.array_equal(jac_to_affine_words(d_out.cpu().numpy().view(np.uint64)), exp), (bits, tables)
+            assert dt < 0.5, "skewed scalars took %.3f s (tables: %s)" % (dt, tables)
+    finally:
+        srs.free()
+        del d_pts, d_s
+        torch.cuda.empty_cache()
