@@ -42,6 +42,7 @@ struct keaki_hip_srs_g2 {
 };
 
 #include <dlfcn.h>
+#include <sys/mman.h>
 namespace {
 // roctx ranges around the kernel families (tracing), visible to `rocprofv3 --marker-trace`. The marker library is
 // looked up at run time so that the ABI has no link-time dependency on the profiler; without it the scopes are no-ops.
@@ -188,8 +189,16 @@ H* new_srs(keaki_hip_ctx* ctx, const void* d, size_t n, bool owned) {
 // device-to-host copy into such pages crawls (160 MB of ciphertexts: 30 ms instead of 3). Touch one byte per page from the host WHILE the
 // kernels that produce the data are still running: the faults are taken off the critical path. The whole range is overwritten by the copy
 // that follows. (Resident pages cost ~2 ns each.)
+// Fresh pages are also asked to be transparent HUGE pages (madvise(MADV_HUGEPAGE) on the 2 MB-aligned interior: a hint, ignored where the
+// kernel does not offer it): first touch of 160 MB takes 20.5 ms in 4 KB pages and 6.5 ms in 2 MB pages on the GPU boxes
+// (bench_tools/ubench_thp_touch.py). At 2^20 items the faults hide behind the kernels either way (vec_encrypt 52.6 vs 52.0 ms); the hint matters
+// where the output is large against the kernel time (GT bytes out: 384 B per item).
 void prefault_out(void* p, size_t bytes) {
   if (!p || bytes < (1u << 20)) return;
+  {
+    const uintptr_t HP = (uintptr_t)2 << 20, a = ((uintptr_t)p + HP - 1) & ~(HP - 1), e = ((uintptr_t)p + bytes) & ~(HP - 1);
+    if (e > a) (void)madvise((void*)a, e - a, MADV_HUGEPAGE);
+  }
   volatile unsigned char* c = (volatile unsigned char*)p;
   for (size_t off = 0; off < bytes; off += 4096) c[off] = 0;
   c[bytes - 1] = 0;
