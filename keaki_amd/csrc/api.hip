@@ -43,6 +43,9 @@ struct keaki_hip_srs_g2 {
 
 #include <dlfcn.h>
 #include <sys/mman.h>
+#include <memory>
+#include <thread>
+#include <atomic>
 namespace {
 // roctx ranges around the kernel families (tracing), visible to `rocprofv3 --marker-trace`. The marker library is
 // looked up at run time so that the ABI has no link-time dependency on the profiler; without it the scopes are no-ops.
@@ -204,6 +207,79 @@ void prefault_out(void* p, size_t bytes) {
   c[bytes - 1] = 0;
 }
 
+// ---- host-pointer batches in CHUNKS ------------------------------------------------------------------------------------------
+// A batch call that takes host arrays is upload -> kernels -> download; done in that order the device idles during both copies and the host
+// thread during the kernels (vec_encrypt of 2^20 items: 8.1 ms per 2^18-item piece for 7.0 ms of kernels, profiles/r04_vec_encrypt_timeline.txt).
+// Batches of two chunks or more run as a pipeline over two buffer halves: the upload of chunk k + 1 and the download of chunk k - 1 go
+// through a copy stream of the context's own while the kernels of chunk k run on the context's stream. The host arrays are pageable, so a
+// copy call returns when the runtime has staged (upload) or delivered (download) the bytes: one host thread is enough, and the order of its
+// calls -- upload k, launch k, download k - 1 -- is what keeps the device busy. `up(lo, m, half, stream)` enqueues the uploads of items
+// [lo, lo + m) into buffer half `half`, `run(lo, m, half)` the kernels (on ctx->stream), `down(lo, m, half, stream)` first-touches the
+// caller's output pages and enqueues the downloads.
+constexpr size_t PIPE_CHUNK = 65536;
+static keaki_status pipe_ready(keaki_hip_ctx* ctx) {
+  if (ctx->copy_stream) return KEAKI_OK;
+  hipStream_t cs = nullptr;
+  HIP_TRY(ctx, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+  for (int i = 0; i < 2; i++) {
+    if (!ctx->pipe_in[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pipe_in[i], hipEventDisableTiming));
+    if (!ctx->pipe_done[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pipe_done[i], hipEventDisableTiming));
+  }
+  ctx->copy_stream = cs;
+  return KEAKI_OK;
+}
+// chunk size of a batch of n items: `unit` items (PIPE_CHUNK: two rounds of the GT exponentiation kernel; the pairing path passes its own launch
+// size -- 16 launches of 2^16 pairings take 3.6 ms longer than 8 of 2^17), the whole batch below two units
+inline size_t pipe_chunk_items(size_t n, size_t unit = PIPE_CHUNK) { return n >= 2 * unit ? unit : n; }
+// `touch(lo, m)`: first-touch the caller's output ranges of items [lo, lo + m) (prefault_out). A download into pages that do not exist yet runs
+// at 5 GB/s instead of 56 (bench_tools/ubench_pageable_copy_sizes.py), and touching them costs the host 40-125 us per MB: with one chunk that
+// happens on the calling thread while the kernels run; with more, helper threads walk the chunks ahead of the downloads (one thread, three
+// when the outputs exceed 64 MB: GT bytes out are 384 B per item) and a download waits for its chunk's flag, so no touch can land on delivered bytes.
+template <class Up, class Run, class Touch, class Down>
+static keaki_status pipelined(keaki_hip_ctx* ctx, size_t n, size_t ch, size_t out_bytes_per_item, Up up, Run run, Touch touch, Down down) {
+  ST_TRY(pipe_ready(ctx));
+  const size_t chunks = (n + ch - 1) / ch;
+  hipStream_t cs = ctx->copy_stream, st = ctx->stream;
+  const size_t n_helpers = chunks < 2 ? 0 : (n * out_bytes_per_item >= ((size_t)64 << 20) ? std::min<size_t>(3, chunks) : 1);
+  std::unique_ptr<std::atomic<unsigned char>[]> touched(new std::atomic<unsigned char>[chunks]);
+  for (size_t k = 0; k < chunks; k++) touched[k].store(0, std::memory_order_relaxed);
+  struct Helpers {
+    std::vector<std::thread> t;
+    ~Helpers() { for (auto& x : t) if (x.joinable()) x.join(); }
+  } helpers;
+  for (size_t h = 0; h < n_helpers; h++)
+    helpers.t.emplace_back([&, h] {
+      for (size_t k = h; k < chunks; k += n_helpers) {
+        touch(k * ch, std::min(ch, n - k * ch));
+        touched[k].store(1, std::memory_order_release);
+      }
+    });
+  // the copy stream starts behind whatever the context's stream holds (an earlier call's kernels may still read the buffers)
+  HIP_TRY(ctx, hipEventRecord(ctx->pipe_done[0], st));
+  HIP_TRY(ctx, hipStreamWaitEvent(cs, ctx->pipe_done[0], 0));
+  for (size_t k = 0; k <= chunks; k++) {
+    if (k < chunks) {
+      const size_t lo = k * ch, m = std::min(ch, n - lo);
+      const int h = (int)(k & 1);
+      ST_TRY(up(lo, m, h, cs));
+      HIP_TRY(ctx, hipEventRecord(ctx->pipe_in[h], cs));
+      HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->pipe_in[h], 0));
+      ST_TRY(run(lo, m, h));
+      HIP_TRY(ctx, hipEventRecord(ctx->pipe_done[h], st));
+    }
+    if (k >= 1) {
+      const size_t lo = (k - 1) * ch, m = std::min(ch, n - lo);
+      const int h = (int)((k - 1) & 1);
+      if (!n_helpers) touch(lo, m);
+      else while (!touched[k - 1].load(std::memory_order_acquire)) std::this_thread::yield();
+      HIP_TRY(ctx, hipStreamWaitEvent(cs, ctx->pipe_done[h], 0));
+      ST_TRY(down(lo, m, h, cs));
+    }
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(cs));
+  return KEAKI_OK;
+}
+
 #define CTX_GUARD(ctx)                                \
   if (!(ctx)) return KEAKI_ERR_BAD_ARG;               \
   std::lock_guard<std::recursive_mutex> lock_((ctx)->mu);       \
@@ -298,6 +374,9 @@ void keaki_hip_ctx_destroy(keaki_hip_ctx* ctx) {
     if (bc.b->p) (void)hipFree(bc.b->p);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : ctx->fk_ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ctx->pipe_in) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ctx->pipe_done) if (e) (void)hipEventDestroy(e);
+  if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   }
   delete ctx;
@@ -645,9 +724,15 @@ static keaki_status gt_table_of(keaki_hip_ctx* ctx, const void* d_p_aff, void* d
 // ---- KEM composites ------------------------------------------------------------------------------------------
 // `prep`: build what depends on the SETUP only (generator tables, the line sequence of g2, the table of [tau]_2, the GT table of e(g1, g2)) for
 // batches of n items, and stop: keaki_hip_encap_prepare. Nothing per item, nothing per commitment.
+// what a host-pointer entry point knows without asking the device: the two constants of the batch (no read-back, no stream synchronisation
+// between the upload and the kernels), the size of the WHOLE batch this chunk belongs to, and whether it is its first chunk
+struct EncapHost { const uint64_t* com; const uint64_t* tau; size_t n_batch; bool first; };
 static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_aff, const void* d_tau_g2_aff, const void* d_points,
                                const void* d_values, const void* d_r, size_t n, void* d_ct_out_aff, void* d_gt_out, void* d_key_out,
-                               size_t msg_len, bool xor_into = false) {
+                               size_t msg_len, bool xor_into = false, const EncapHost* host = nullptr) {
+  // a chunk of a larger batch takes the decisions of the whole batch (table widths, the GT path) and counts as ONE call with its commitment
+  const size_t n_policy = host ? host->n_batch : n;
+  const bool first_of_batch = !host || host->first;
   if (!prep) ST_TRY(reserve(ctx, ctx->tmp_a, n * G1_AFF_BYTES));
   ST_TRY(reserve(ctx, ctx->tmp_c, G2_AFF_BYTES));
   void* gt = d_gt_out;
@@ -658,7 +743,7 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
   // 13 bits for the commitment's table (rebuilt per batch in the per-item-pairing path)
   constexpr uint32_t FB_WB_LONG = 16, FB_WB_BATCH = 13;
   const size_t FBL = fb_table_entries(FB_WB_LONG), FBS = fb_table_entries(FB_WB_BATCH);
-  const bool use_tables = n >= 256;
+  const bool use_tables = n_policy >= 256;
   if (use_tables && !ctx->fb_ready) {
     ST_TRY(reserve(ctx, ctx->fb_scalars, (FBL + FBS) * 32));                        // [16-bit scalars | 13-bit scalars]
     ST_TRY(reserve(ctx, ctx->fb_g1_gen, FBL * G1_AFF_BYTES + G1_AFF_BYTES));
@@ -685,8 +770,12 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
   // 64 mixed additions per item instead of two 254-step ladders (a single `encapsulate` call: 20.5 -> 10 ms).
   {
     uint64_t tau_host[16];
-    HIP_TRY(ctx, hipMemcpyAsync(tau_host, d_tau_g2_aff, 128, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (host) {
+      memcpy(tau_host, host->tau, 128);
+    } else {
+      HIP_TRY(ctx, hipMemcpyAsync(tau_host, d_tau_g2_aff, 128, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     const bool big_has_tau = ctx->fb_ready && ctx->fb_tau_valid && memcmp(tau_host, ctx->fb_tau_pt, 128) == 0;
     if (use_tables || big_has_tau) {
       if (!big_has_tau) {
@@ -732,23 +821,27 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
   uint64_t com_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool a_cached = false;
   if (!prep) {
-    HIP_TRY(ctx, hipMemcpyAsync(com_host, d_com_aff, 64, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (host) {
+      memcpy(com_host, host->com, 64);
+    } else {
+      HIP_TRY(ctx, hipMemcpyAsync(com_host, d_com_aff, 64, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if (ctx->seen_com_runs && memcmp(com_host, ctx->seen_com, 64) == 0) {
-      if (ctx->seen_com_runs < 1000000) ctx->seen_com_runs++;
+      if (first_of_batch && ctx->seen_com_runs < 1000000) ctx->seen_com_runs++;
     } else {
       memcpy(ctx->seen_com, com_host, 64);
       ctx->seen_com_runs = 1;
     }
     a_cached = ctx->gt_b_ready && ctx->gt_a_valid && memcmp(com_host, ctx->gt_a_com, 64) == 0;
   }
-  const bool use_gt = n >= gt_threshold || (!prep && !gt_env && (a_cached || ctx->seen_com_runs >= 3));
+  const bool use_gt = n_policy >= gt_threshold || (!prep && !gt_env && (a_cached || ctx->seen_com_runs >= 3));
   if (use_gt) {
     // GT_i = A^(r_i) B^(-beta_i r_i) with A = e(C, g2), B = e(g1, g2) (see pairing.hip.h): no pairing per item
     ST_TRY(reserve(ctx, ctx->gt_base, G1_AFF_BYTES + 320 * (G1_AFF_BYTES + 384)));   // a point | 2^s multiples | their pairings
     char* gb = (char*)ctx->gt_base.p;
     // B: 20-bit windows for a context that runs large batches, 16-bit (201 MB) for one that only ever made small calls; widened once when a large batch comes
-    const uint32_t wb_b_req = wbb_env ? (uint32_t)ctx->tune.gt_wb_b : (n >= 65536 ? 20u : 16u);
+    const uint32_t wb_b_req = wbb_env ? (uint32_t)ctx->tune.gt_wb_b : (n_policy >= 65536 ? 20u : 16u);
     if (!ctx->gt_b_ready || (!wbb_env && wb_b_req > ctx->gt_b_wb && !ctx->gt_b_fallback)) {
       if (wb_b_req < 8 || wb_b_req > 22 || gt_table_powers(wb_b_req) > 320) return fail(ctx, KEAKI_ERR_BAD_ARG, "gt_wb_b = %u out of range", wb_b_req);
       ctx->gt_b_ready = false;
@@ -835,46 +928,80 @@ keaki_status keaki_hip_decap_batch_dev(keaki_hip_ctx* ctx, const void* d_proofs_
 keaki_status keaki_hip_encap_batch(keaki_hip_ctx* ctx, const uint64_t* com_aff, const uint64_t* tau_g2_aff, const uint64_t* points,
                                    const uint64_t* values, const uint64_t* r, size_t n, uint64_t* ct_out_aff, uint8_t* gt_out, uint8_t* key_out,
                                    size_t msg_len) {
-  CTX_GUARD(ctx);                 // one lock from staging to the last download (the *_dev call below re-enters it)
+  CTX_GUARD(ctx);                 // one lock from staging to the last download
+  TRACE_SCOPE("keaki.encap");
   if (n == 0) return KEAKI_OK;
   if (!com_aff || !tau_g2_aff || !points || !values || !r || !ct_out_aff || (!gt_out && !key_out) || msg_len > 65536)
     return fail(ctx, KEAKI_ERR_BAD_ARG, "encap_batch: bad argument");
-  const size_t off_tau = 64, off_pts = off_tau + 128, off_val = off_pts + n * 32, off_r = off_val + n * 32, off_ct = off_r + n * 32,
-               off_gt = off_ct + n * 128, off_key = off_gt + n * 384, total = off_key + n * msg_len + 16;
-  ST_TRY(reserve(ctx, ctx->io_a, total));
+  const size_t ch = pipe_chunk_items(n);
+  const size_t off_pts = 0, off_val = off_pts + ch * 32, off_r = off_val + ch * 32, off_ct = off_r + ch * 32, off_gt = off_ct + ch * 128,
+               off_key = off_gt + ch * 384, half = (off_key + ch * msg_len + 255) & ~(size_t)255;
+  ST_TRY(reserve(ctx, ctx->io_a, 256 + 2 * half));
   char* base = (char*)ctx->io_a.p;
-  hipStream_t st = ctx->stream;
-  HIP_TRY(ctx, hipMemcpyAsync(base, com_aff, 64, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(base + off_tau, tau_g2_aff, 128, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(base + off_pts, points, n * 32, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(base + off_val, values, n * 32, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(base + off_r, r, n * 32, hipMemcpyHostToDevice, st));
-  ST_TRY(keaki_hip_encap_batch_dev(ctx, base, base + off_tau, base + off_pts, base + off_val, base + off_r, n, base + off_ct, base + off_gt,
-                                   key_out ? base + off_key : nullptr, msg_len));
-  prefault_out(ct_out_aff, n * 128); prefault_out(gt_out, gt_out ? n * 384 : 0); prefault_out(key_out, key_out ? n * msg_len : 0);   // while the kernels run
-  HIP_TRY(ctx, hipMemcpyAsync(ct_out_aff, base + off_ct, n * 128, hipMemcpyDeviceToHost, st));
-  if (gt_out) HIP_TRY(ctx, hipMemcpyAsync(gt_out, base + off_gt, n * 384, hipMemcpyDeviceToHost, st));
-  if (key_out && msg_len) HIP_TRY(ctx, hipMemcpyAsync(key_out, base + off_key, n * msg_len, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
-  return KEAKI_OK;
+  HIP_TRY(ctx, hipMemcpyAsync(base, com_aff, 64, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(base + 64, tau_g2_aff, 128, hipMemcpyHostToDevice, ctx->stream));
+  const bool want_key = key_out && msg_len;
+  return pipelined(ctx, n, ch, 128 + (gt_out ? 384 : 0) + (want_key ? msg_len : 0),
+    [&](size_t lo, size_t m, int h, hipStream_t cs) -> keaki_status {
+      char* b = base + 256 + h * half;
+      HIP_TRY(ctx, hipMemcpyAsync(b + off_pts, points + 4 * lo, m * 32, hipMemcpyHostToDevice, cs));
+      HIP_TRY(ctx, hipMemcpyAsync(b + off_val, values + 4 * lo, m * 32, hipMemcpyHostToDevice, cs));
+      HIP_TRY(ctx, hipMemcpyAsync(b + off_r, r + 4 * lo, m * 32, hipMemcpyHostToDevice, cs));
+      return KEAKI_OK;
+    },
+    [&](size_t lo, size_t m, int h) -> keaki_status {
+      char* b = base + 256 + h * half;
+      const EncapHost eh = {com_aff, tau_g2_aff, n, lo == 0};
+      return encap_impl(ctx, false, base, base + 64, b + off_pts, b + off_val, b + off_r, m, b + off_ct, b + off_gt, want_key ? b + off_key : nullptr,
+                        msg_len, false, &eh);
+    },
+    [&](size_t lo, size_t m) {
+      prefault_out(ct_out_aff + 16 * lo, m * 128);
+      if (gt_out) prefault_out(gt_out + 384 * lo, m * 384);
+      if (want_key) prefault_out(key_out + msg_len * lo, m * msg_len);
+    },
+    [&](size_t lo, size_t m, int h, hipStream_t cs) -> keaki_status {
+      char* b = base + 256 + h * half;
+      HIP_TRY(ctx, hipMemcpyAsync(ct_out_aff + 16 * lo, b + off_ct, m * 128, hipMemcpyDeviceToHost, cs));
+      if (gt_out) HIP_TRY(ctx, hipMemcpyAsync(gt_out + 384 * lo, b + off_gt, m * 384, hipMemcpyDeviceToHost, cs));
+      if (want_key) HIP_TRY(ctx, hipMemcpyAsync(key_out + msg_len * lo, b + off_key, m * msg_len, hipMemcpyDeviceToHost, cs));
+      return KEAKI_OK;
+    });
 }
 keaki_status keaki_hip_decap_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_aff, const uint64_t* cts_aff, size_t n, uint8_t* gt_out,
                                    uint8_t* key_out, size_t msg_len) {
   CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.decap");
   if (n == 0) return KEAKI_OK;
   if (!proofs_aff || !cts_aff || (!gt_out && !key_out) || msg_len > 65536) return fail(ctx, KEAKI_ERR_BAD_ARG, "decap_batch: bad argument");
-  const size_t off_ct = n * 64, off_gt = off_ct + n * 128, off_key = off_gt + n * 384, total = off_key + n * msg_len + 16;
-  ST_TRY(reserve(ctx, ctx->io_a, total));
+  const size_t ch = pipe_chunk_items(n, pairing_launch_items());
+  const size_t off_ct = ch * 64, off_gt = off_ct + ch * 128, off_key = off_gt + ch * 384, half = (off_key + ch * msg_len + 255) & ~(size_t)255;
+  ST_TRY(reserve(ctx, ctx->io_a, 2 * half));
   char* base = (char*)ctx->io_a.p;
-  hipStream_t st = ctx->stream;
-  HIP_TRY(ctx, hipMemcpyAsync(base, proofs_aff, n * 64, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(base + off_ct, cts_aff, n * 128, hipMemcpyHostToDevice, st));
-  ST_TRY(keaki_hip_decap_batch_dev(ctx, base, base + off_ct, n, base + off_gt, key_out ? base + off_key : nullptr, msg_len));
-  prefault_out(gt_out, gt_out ? n * 384 : 0); prefault_out(key_out, key_out ? n * msg_len : 0);
-  if (gt_out) HIP_TRY(ctx, hipMemcpyAsync(gt_out, base + off_gt, n * 384, hipMemcpyDeviceToHost, st));
-  if (key_out && msg_len) HIP_TRY(ctx, hipMemcpyAsync(key_out, base + off_key, n * msg_len, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
-  return KEAKI_OK;
+  const bool want_key = key_out && msg_len;
+  return pipelined(ctx, n, ch, (gt_out ? 384 : 0) + (want_key ? msg_len : 0),
+    [&](size_t lo, size_t m, int h, hipStream_t cs) -> keaki_status {
+      char* b = base + h * half;
+      HIP_TRY(ctx, hipMemcpyAsync(b, proofs_aff + 8 * lo, m * 64, hipMemcpyHostToDevice, cs));
+      HIP_TRY(ctx, hipMemcpyAsync(b + off_ct, cts_aff + 16 * lo, m * 128, hipMemcpyHostToDevice, cs));
+      return KEAKI_OK;
+    },
+    [&](size_t, size_t m, int h) -> keaki_status {
+      char* b = base + h * half;
+      ST_TRY(pairing_run(ctx, b, b + off_ct, 1, m, b + off_gt));
+      if (want_key) ST_TRY(blake3_gt_run(ctx, b + off_gt, m, b + off_key, msg_len));
+      return KEAKI_OK;
+    },
+    [&](size_t lo, size_t m) {
+      if (gt_out) prefault_out(gt_out + 384 * lo, m * 384);
+      if (want_key) prefault_out(key_out + msg_len * lo, m * msg_len);
+    },
+    [&](size_t lo, size_t m, int h, hipStream_t cs) -> keaki_status {
+      char* b = base + h * half;
+      if (gt_out) HIP_TRY(ctx, hipMemcpyAsync(gt_out + 384 * lo, b + off_gt, m * 384, hipMemcpyDeviceToHost, cs));
+      if (want_key) HIP_TRY(ctx, hipMemcpyAsync(key_out + msg_len * lo, b + off_key, m * msg_len, hipMemcpyDeviceToHost, cs));
+      return KEAKI_OK;
+    });
 }
 
 // ---- enc::encrypt / enc::decrypt over a batch (src/enc.rs:19-55 inside the loops of src/vec.rs:63-66, :75-78): KEM + the XOR DEM on the device ----
@@ -902,44 +1029,72 @@ keaki_status keaki_hip_encrypt_batch(keaki_hip_ctx* ctx, const uint64_t* com_aff
                                      const uint64_t* values, const uint64_t* r, const uint8_t* msgs, size_t n, uint64_t* ct_out_aff, uint8_t* body_out,
                                      size_t msg_len) {
   CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.encrypt");
   if (n == 0) return KEAKI_OK;
   if (!com_aff || !tau_g2_aff || !points || !values || !r || !msgs || !ct_out_aff || !body_out || msg_len == 0 || msg_len > 65536)
     return fail(ctx, KEAKI_ERR_BAD_ARG, "encrypt_batch: bad argument");
-  const size_t off_tau = 64, off_pts = off_tau + 128, off_val = off_pts + n * 32, off_r = off_val + n * 32, off_ct = off_r + n * 32,
-               off_body = off_ct + n * 128, total = off_body + n * msg_len + 16;
-  ST_TRY(reserve(ctx, ctx->io_a, total));
+  const size_t ch = pipe_chunk_items(n);
+  const size_t off_pts = 0, off_val = off_pts + ch * 32, off_r = off_val + ch * 32, off_ct = off_r + ch * 32, off_body = off_ct + ch * 128,
+               half = (off_body + ch * msg_len + 255) & ~(size_t)255;
+  ST_TRY(reserve(ctx, ctx->io_a, 256 + 2 * half));
   char* base = (char*)ctx->io_a.p;
-  hipStream_t st = ctx->stream;
-  HIP_TRY(ctx, hipMemcpyAsync(base, com_aff, 64, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(base + off_tau, tau_g2_aff, 128, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(base + off_pts, points, n * 32, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(base + off_val, values, n * 32, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(base + off_r, r, n * 32, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(base + off_body, msgs, n * msg_len, hipMemcpyHostToDevice, st));
-  ST_TRY(keaki_hip_encrypt_batch_dev(ctx, base, base + off_tau, base + off_pts, base + off_val, base + off_r, n, base + off_ct, base + off_body, msg_len));
-  prefault_out(ct_out_aff, n * 128); prefault_out(body_out, n * msg_len);       // while the kernels run
-  HIP_TRY(ctx, hipMemcpyAsync(ct_out_aff, base + off_ct, n * 128, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipMemcpyAsync(body_out, base + off_body, n * msg_len, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
-  return KEAKI_OK;
+  HIP_TRY(ctx, hipMemcpyAsync(base, com_aff, 64, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(base + 64, tau_g2_aff, 128, hipMemcpyHostToDevice, ctx->stream));
+  return pipelined(ctx, n, ch, 128 + msg_len,
+    [&](size_t lo, size_t m, int h, hipStream_t cs) -> keaki_status {
+      char* b = base + 256 + h * half;
+      HIP_TRY(ctx, hipMemcpyAsync(b + off_pts, points + 4 * lo, m * 32, hipMemcpyHostToDevice, cs));
+      HIP_TRY(ctx, hipMemcpyAsync(b + off_val, values + 4 * lo, m * 32, hipMemcpyHostToDevice, cs));
+      HIP_TRY(ctx, hipMemcpyAsync(b + off_r, r + 4 * lo, m * 32, hipMemcpyHostToDevice, cs));
+      HIP_TRY(ctx, hipMemcpyAsync(b + off_body, msgs + msg_len * lo, m * msg_len, hipMemcpyHostToDevice, cs));
+      return KEAKI_OK;
+    },
+    [&](size_t lo, size_t m, int h) -> keaki_status {
+      char* b = base + 256 + h * half;
+      const EncapHost eh = {com_aff, tau_g2_aff, n, lo == 0};
+      return encap_impl(ctx, false, base, base + 64, b + off_pts, b + off_val, b + off_r, m, b + off_ct, nullptr, b + off_body, msg_len, true, &eh);
+    },
+    [&](size_t lo, size_t m) {
+      prefault_out(ct_out_aff + 16 * lo, m * 128);
+      prefault_out(body_out + msg_len * lo, m * msg_len);
+    },
+    [&](size_t lo, size_t m, int h, hipStream_t cs) -> keaki_status {
+      char* b = base + 256 + h * half;
+      HIP_TRY(ctx, hipMemcpyAsync(ct_out_aff + 16 * lo, b + off_ct, m * 128, hipMemcpyDeviceToHost, cs));
+      HIP_TRY(ctx, hipMemcpyAsync(body_out + msg_len * lo, b + off_body, m * msg_len, hipMemcpyDeviceToHost, cs));
+      return KEAKI_OK;
+    });
 }
 keaki_status keaki_hip_decrypt_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_aff, const uint64_t* cts_aff, const uint8_t* bodies, size_t n,
                                      uint8_t* msgs_out, size_t msg_len) {
   CTX_GUARD(ctx);
+  TRACE_SCOPE("keaki.decrypt");
   if (n == 0) return KEAKI_OK;
   if (!proofs_aff || !cts_aff || !bodies || !msgs_out || msg_len == 0 || msg_len > 65536) return fail(ctx, KEAKI_ERR_BAD_ARG, "decrypt_batch: bad argument");
-  const size_t off_ct = n * 64, off_body = off_ct + n * 128, total = off_body + n * msg_len + 16;
-  ST_TRY(reserve(ctx, ctx->io_a, total));
+  const size_t ch = pipe_chunk_items(n, pairing_launch_items());
+  const size_t off_ct = ch * 64, off_body = off_ct + ch * 128, half = (off_body + ch * msg_len + 255) & ~(size_t)255;
+  ST_TRY(reserve(ctx, ctx->io_a, 2 * half));
+  ST_TRY(reserve(ctx, ctx->tmp_b, ch * 384));
   char* base = (char*)ctx->io_a.p;
-  hipStream_t st = ctx->stream;
-  HIP_TRY(ctx, hipMemcpyAsync(base, proofs_aff, n * 64, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(base + off_ct, cts_aff, n * 128, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(base + off_body, bodies, n * msg_len, hipMemcpyHostToDevice, st));
-  ST_TRY(keaki_hip_decrypt_batch_dev(ctx, base, base + off_ct, n, base + off_body, msg_len));
-  prefault_out(msgs_out, n * msg_len);
-  HIP_TRY(ctx, hipMemcpyAsync(msgs_out, base + off_body, n * msg_len, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
-  return KEAKI_OK;
+  return pipelined(ctx, n, ch, msg_len,
+    [&](size_t lo, size_t m, int h, hipStream_t cs) -> keaki_status {
+      char* b = base + h * half;
+      HIP_TRY(ctx, hipMemcpyAsync(b, proofs_aff + 8 * lo, m * 64, hipMemcpyHostToDevice, cs));
+      HIP_TRY(ctx, hipMemcpyAsync(b + off_ct, cts_aff + 16 * lo, m * 128, hipMemcpyHostToDevice, cs));
+      HIP_TRY(ctx, hipMemcpyAsync(b + off_body, bodies + msg_len * lo, m * msg_len, hipMemcpyHostToDevice, cs));
+      return KEAKI_OK;
+    },
+    [&](size_t, size_t m, int h) -> keaki_status {
+      char* b = base + h * half;
+      ST_TRY(pairing_run(ctx, b, b + off_ct, 1, m, ctx->tmp_b.p));
+      return blake3_gt_run(ctx, ctx->tmp_b.p, m, b + off_body, msg_len, true);
+    },
+    [&](size_t lo, size_t m) { prefault_out(msgs_out + msg_len * lo, m * msg_len); },
+    [&](size_t lo, size_t m, int h, hipStream_t cs) -> keaki_status {
+      char* b = base + h * half;
+      HIP_TRY(ctx, hipMemcpyAsync(msgs_out + msg_len * lo, b + off_body, m * msg_len, hipMemcpyDeviceToHost, cs));
+      return KEAKI_OK;
+    });
 }
 
 // ---- FK23 batch openings: replaces kzg::open_fk (src/kzg.rs:157-203) ----------------------------------------------------------

@@ -87,6 +87,10 @@ struct keaki_hip_ctx {
   hipEvent_t fk_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool fk_timing_pending = false;
   float last_fk_ms[3] = {-1.f, -1.f, -1.f};      // pointwise products, butterfly stages (k_g1_fft_stage_map), whole device pipeline
+  // host-pointer batches run in chunks (api.hip: pipelined): uploads and downloads of the neighbouring chunks on a stream of their own.
+  // Created on first use. [in: chunk staged | done: chunk computed], one pair per buffer half
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t pipe_in[2] = {nullptr, nullptr}, pipe_done[2] = {nullptr, nullptr};
 };
 
 namespace keaki_internal {
@@ -143,6 +147,7 @@ keaki_status g1_sum_run(keaki_hip_ctx* ctx, const void* d_points_jac, size_t k, 
 keaki_status g1_mul_batch_run(keaki_hip_ctx* ctx, const void* d_pts, int stride, const void* d_scalars, size_t n, void* d_out);
 keaki_status g2_mul_batch_run(keaki_hip_ctx* ctx, const void* d_pts, int stride, const void* d_scalars, size_t n, void* d_out);
 keaki_status encap_g1_run(keaki_hip_ctx* ctx, const void* d_com, const void* d_values, const void* d_r, size_t n, void* d_out);
+size_t pairing_launch_items();      // items per k_pairing launch (the slots of the final exponentiation bound it)
 keaki_status pairing_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, int g2_stride, size_t n, void* d_gt, const void* d_fixed_lines = nullptr,
                          uint32_t lines_stride = 0);
 uint32_t g2_prepared_lines();                 // Line entries of one table

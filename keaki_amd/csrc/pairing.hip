@@ -35,6 +35,7 @@ keaki_status pairing_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2,
   return pairing_launch(ctx, PAIR_MILLER | PAIR_FINAL_EXP | PAIR_OUT_BYTES, d_g1, d_g2, g2_stride, nullptr, n, d_gt, 384, d_fixed_lines, lines_stride,
                         "pairing_batch");
 }
+size_t pairing_launch_items() { return PAIR_CHUNK; }
 uint32_t g2_prepared_lines() { return (uint32_t)MILLER_MAX_LINES * 2; }
 size_t g2_prepared_bytes() { return (size_t)MILLER_MAX_LINES * 2 * sizeof(Line); }
 keaki_status g2_prepare_run(keaki_hip_ctx* ctx, const void* d_q, void* d_lines) {

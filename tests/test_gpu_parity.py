@@ -933,3 +933,46 @@ def test_encrypt_decrypt_batch_device_dem_vs_oracle(oc, hip, msg_len):
         assert np.array_equal(g.decrypt_batch(proofs, ct, body), out)
     finally:
         g.close()
+
+
+def test_host_array_batches_in_chunks_equal_the_unchunked_calls(oc, hip):
+    """api.hip `pipelined`: host-array batches of two chunks or more (2^16 items on the KEM side, the pairing kernel's 2^17-item launch on
+    the decapsulation side) overlap their copies with the neighbouring chunks' kernels. Same bytes as the same items sent in calls that are
+    below the chunking threshold, a ragged last chunk included; a sample against the oracle; outputs into FRESH pages (numpy.zeros inside
+    the wrapper) with the helper threads touching them."""
+    from bench import random_fr_limbs
+    g1, g2 = oc.generators()
+    com = hip.g1_mul_batch(g1, random_fr_limbs(1, 191))[0]
+    tau_g2 = hip.g2_mul_batch(g2, random_fr_limbs(1, 192))[0]
+    n = 3 * 65536 + 777                      # four chunks, the last one ragged
+    A, V, R = random_fr_limbs(n, 193), random_fr_limbs(n, 194), random_fr_limbs(n, 195)
+    msgs = np.random.default_rng(7).integers(0, 256, (n, 48), dtype=np.uint8)
+    ct, body = hip.encrypt_batch(com, tau_g2, A, V, R, msgs)
+    ect, egt, ekey = hip.encap_batch(com, tau_g2, A, V, R, 48)
+    assert np.array_equal(ect, ct) and np.array_equal(ekey ^ msgs, body)
+    step = 100000                            # below two chunks: one upload, one launch sequence, one download
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        c1, b1 = hip.encrypt_batch(com, tau_g2, A[lo:hi], V[lo:hi], R[lo:hi], msgs[lo:hi])
+        assert np.array_equal(c1, ct[lo:hi]) and np.array_equal(b1, body[lo:hi]), lo
+        c2, g2_, k2 = hip.encap_batch(com, tau_g2, A[lo:hi], V[lo:hi], R[lo:hi], 48)
+        assert np.array_equal(g2_, egt[lo:hi]) and np.array_equal(k2, ekey[lo:hi]), lo
+    idx = np.array([0, 1, 65535, 65536, 131071, 131072, 196607, 196608, n - 1])
+    oct_, ogt, okey = oc.encap_batch(com, tau_g2, A[idx], V[idx], R[idx], 48, threads=os.cpu_count() or 1)
+    assert np.array_equal(oct_, ct[idx]) and np.array_equal(ogt, egt[idx]) and np.array_equal(okey ^ msgs[idx], body[idx])
+    # the pairing side: 2 * 2^17 + 5 items = three chunks
+    m = 2 * 131072 + 5
+    proofs = np.ascontiguousarray(np.tile(hip.g1_mul_batch(g1, random_fr_limbs(4096, 196)), (m // 4096 + 1, 1))[:m])
+    cts = np.ascontiguousarray(np.tile(ct[:8192], (m // 8192 + 1, 1))[:m])
+    bodies = np.ascontiguousarray(np.tile(body[:8192], (m // 8192 + 1, 1))[:m])
+    out = hip.decrypt_batch(proofs, cts, bodies)
+    dgt, dkey = hip.decap_batch(proofs, cts, 48)
+    assert np.array_equal(dkey ^ bodies, out)
+    for lo in range(0, m, 200000):
+        hi = min(m, lo + 200000)
+        assert np.array_equal(hip.decrypt_batch(proofs[lo:hi], cts[lo:hi], bodies[lo:hi]), out[lo:hi]), lo
+        g3, k3 = hip.decap_batch(proofs[lo:hi], cts[lo:hi], 48)
+        assert np.array_equal(g3, dgt[lo:hi]) and np.array_equal(k3, dkey[lo:hi]), lo
+    jdx = np.array([0, 131071, 131072, 262143, 262144, m - 1])
+    _, odk = oc.decap_batch(proofs[jdx], cts[jdx], 48, threads=os.cpu_count() or 1)
+    assert np.array_equal(odk ^ bodies[jdx], out[jdx])
