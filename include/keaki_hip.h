@@ -245,7 +245,12 @@ keaki_status keaki_hip_pairing_batch_dev(keaki_hip_ctx* ctx, const void* d_g1_af
  *     gt[i]  = serialize(e(r[i] * (com - values[i] * g1), g2))        (384 bytes)
  *     key[i] = BLAKE3-XOF(gt[i])[0..msg_len]   if key_out != NULL     (src/kem.rs:42-46)
  * r[i] are drawn by the caller (one Fr::rand per item in index order, src/kem.rs:26) so the
- * randomness stream is the caller's. gt_out may be NULL when only keys are wanted. msg_len <= 1<<16. */
+ * randomness stream is the caller's. gt_out may be NULL when only keys are wanted. msg_len <= 1<<16.
+ * The host-array forms (no _dev suffix) of encap / decap / encrypt / decrypt_batch run batches of two chunks or more (2^16 items; the
+ * pairing side: 2^17) as a pipeline -- uploads and downloads on a stream of the context's own under the neighbouring chunks' kernels --
+ * and first-touch the caller's output pages from up to three short-lived helper threads ahead of the downloads (a download into pages
+ * that do not exist yet runs at a tenth of the link rate). Results are those of one call per chunk; the call returns when every byte
+ * has been delivered and every helper has been joined. */
 keaki_status keaki_hip_encap_batch(keaki_hip_ctx* ctx, const uint64_t* com_aff, const uint64_t* tau_g2_aff,
                                    const uint64_t* points, const uint64_t* values, const uint64_t* r, size_t n,
                                    uint64_t* ct_out_aff, uint8_t* gt_out, uint8_t* key_out, size_t msg_len);
