@@ -2,14 +2,27 @@
 #define KEAKI_FQ2_OUTLINE 1
 #include "internal.h"
 #include "pairing.hip.h"
+#include "pairing_wide.hip.h"
 namespace keaki_internal {
 using namespace bn254;
 // One launch of k_pairing per chunk of at most PAIR_CHUNK items: the final exponentiation keeps FE_NSLOTS Fq12 values per item in HBM
 // (3.75 KB per item; 2^17 items = 480 MB, grow-only in the context).
 constexpr size_t PAIR_CHUNK = (size_t)1 << 17;
+constexpr size_t PAIR_WIDE_AUTO = 4096;
 static keaki_status pairing_launch(keaki_hip_ctx* ctx, u32 mode, const void* d_g1, const void* d_g2, int g2_stride, const void* d_f_in, size_t n,
                                    void* d_out, size_t out_item_bytes, const void* d_fixed_lines, uint32_t lines_stride, const char* what) {
   if (n == 0) return KEAKI_OK;
+  // Few pairings: the twelve-lanes-per-pairing kernel (pairing_wide.hip.h) -- a quarter of the latency for 1.65 x the wave-instructions, so only
+  // while its waves (four pairings each) find the device not full: automatic = up to PAIR_WIDE_AUTO items.
+  const size_t wide_max = ctx->tune.pair_wide_max < 0 ? PAIR_WIDE_AUTO : (size_t)ctx->tune.pair_wide_max;
+  if (n <= wide_max) {
+    PairArgs a;
+    a.ps = (const G1Aff*)d_g1; a.qs = (const G2Aff*)d_g2; a.q_stride = g2_stride; a.n = (u32)n;
+    a.fixed_lines = (const Line*)d_fixed_lines; a.lines_stride = lines_stride; a.f_in = (const Fq*)d_f_in;
+    a.ws = nullptr; a.ws_n = 0; a.out = d_out; a.mode = mode;
+    hipLaunchKernelGGL(pw::k_pairing_wide, dim3(cdiv(n, 4)), dim3(64), 0, ctx->stream, a);
+    return launch_check(ctx, what);
+  }
   const size_t ch = n < PAIR_CHUNK ? n : PAIR_CHUNK;
   if (mode & PAIR_FINAL_EXP) ST_TRY(reserve(ctx, ctx->pair_ws, (size_t)FE_NSLOTS * 12 * sizeof(Fq) * ch));
   for (size_t lo = 0; lo < n; lo += ch) {

@@ -976,3 +976,30 @@ def test_host_array_batches_in_chunks_equal_the_unchunked_calls(oc, hip):
     jdx = np.array([0, 131071, 131072, 262143, 262144, m - 1])
     _, odk = oc.decap_batch(proofs[jdx], cts[jdx], 48, threads=os.cpu_count() or 1)
     assert np.array_equal(odk ^ bodies[jdx], out[jdx])
+
+
+@pytest.mark.parametrize("wide_max", [0, 1 << 20])
+def test_both_pairing_kernels_at_small_and_ragged_sizes(oc, py, rand_fr, wide_max):
+    """pairing_launch picks between two kernels by batch size: k_pairing (one lane pair per pairing) and pw::k_pairing_wide (twelve lanes per
+    pairing, a third of the latency: a single verify / decapsulate / encapsulate, the table of a new commitment). Both forms, forced by
+    `pair_wide_max`, through the pairing / KEM / stage-wise tests above and at ragged sizes (partial rows and waves of the wide kernel,
+    identities in either slot), against the oracle."""
+    from keaki_amd.hip import KeakiHip
+    h = KeakiHip(0)
+    try:
+        h.set_option("pair_wide_max", wide_max)
+        test_pairing_batch_vs_oracle(oc, py, h, rand_fr)
+        test_encap_decap_vs_oracle(oc, py, h, rand_fr)
+        test_miller_and_final_exp_stages(oc, h, rand_fr)
+        g1, g2 = oc.generators()
+        n = 131
+        P = h.g1_mul_batch(g1, mont(oc, rand_fr(n, 131)))
+        Q = h.g2_mul_batch(g2, mont(oc, rand_fr(n, 132)))
+        P[7] = 0; Q[64] = 0; Q[130] = 0
+        exp = oc.pairing_batch(P, Q, threads=os.cpu_count() or 1)
+        for m in (1, 2, 3, 4, 5, 63, 64, 65, 131):
+            assert np.array_equal(h.pairing_batch(P[:m], Q[:m]), exp[:m]), m
+        # the fixed second slot (tabulated lines of g2: the encapsulation side) and the verify composite
+        assert np.array_equal(h.pairing_batch(P[:9], g2), oc.pairing_batch(P[:9], g2, threads=8))
+    finally:
+        h.close()
