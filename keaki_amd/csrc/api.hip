@@ -324,7 +324,7 @@ std::vector<BufClass> all_bufs(keaki_hip_ctx* ctx) {
   std::vector<BufClass> v;
   for (DevBuf* b : {&ctx->digits, &ctx->hist, &ctx->offsets, &ctx->cursor, &ctx->sorted, &ctx->buckets, &ctx->partials, &ctx->wsums, &ctx->bsums,
                     &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->io_a, &ctx->io_b, &ctx->io_c, &ctx->io_d, &ctx->io_e, &ctx->perm, &ctx->heavy,
-                    &ctx->pair_ws, &ctx->verify_lines, &ctx->verify_io, &ctx->g2gen_lines, &ctx->fk_tab})
+                    &ctx->pair_ws, &ctx->verify_lines, &ctx->verify_io, &ctx->g2gen_lines, &ctx->fk_tab, &ctx->g2pow_lines, &ctx->g2pow_pts})
     v.push_back({b, 1});
   for (DevBuf* b : {&ctx->fb_scalars, &ctx->fb_g1_gen, &ctx->fb_g2_gen, &ctx->fb_com, &ctx->fb_tau, &ctx->gt_tab_a, &ctx->gt_tab_b, &ctx->gt_base,
                     &ctx->fbs_scalars, &ctx->fbs_g2_gen, &ctx->fbs_tau})
@@ -378,6 +378,8 @@ void keaki_hip_ctx_destroy(keaki_hip_ctx* ctx) {
   for (auto& e : ctx->pipe_in) if (e) (void)hipEventDestroy(e);
   for (auto& e : ctx->pipe_done) if (e) (void)hipEventDestroy(e);
   if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+  for (auto& e : ctx->aux_ev) if (e) (void)hipEventDestroy(e);
+  if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   }
   delete ctx;
@@ -437,7 +439,7 @@ keaki_status keaki_hip_ctx_trim(keaki_hip_ctx* ctx) {
   ctx->gt_b_ready = ctx->gt_a_valid = ctx->gt_b_fallback = false;
   ctx->seen_com_runs = 0;
   ctx->verify_ready = ctx->verify_tau_valid = false;
-  ctx->fb_tau_valid = ctx->g2gen_lines_ready = ctx->fb_ready = false;
+  ctx->fb_tau_valid = ctx->g2gen_lines_ready = ctx->fb_ready = ctx->g2pow_ready = false;
   ctx->fbs_ready = ctx->fbs_tau_valid = false;
   return KEAKI_OK;
 }
@@ -711,15 +713,48 @@ keaki_status keaki_hip_pairing_batch(keaki_hip_ctx* ctx, const uint64_t* g1_aff,
   return download(ctx, gt_out, ctx->io_c.p, n * 384);
 }
 
-// signed-window table of e(P, g2) for a G1 point P in device memory: the powers of two e(P, g2)^(2^s) = e(2^s P, g2) come from one
-// pairing launch over the doubling chain of P (latency of one pairing), the rest of every window by products (pairing.hip.h)
+// a second stream of the context for work that is bound by latency, not by the device (the table of a new commitment), and the means to
+// send the launchers -- which all enqueue on ctx->stream -- there for a scope (the caller holds the context lock)
+static keaki_status aux_ready(keaki_hip_ctx* ctx) {
+  if (ctx->aux_stream) return KEAKI_OK;
+  hipStream_t s = nullptr;
+  HIP_TRY(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  for (auto& e : ctx->aux_ev) if (!e) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  ctx->aux_stream = s;
+  return KEAKI_OK;
+}
+struct StreamSwap {
+  keaki_hip_ctx* ctx;
+  hipStream_t saved;
+  StreamSwap(keaki_hip_ctx* c, hipStream_t s) : ctx(c), saved(c->stream) { c->stream = s; }
+  ~StreamSwap() { ctx->stream = saved; }
+};
+// signed-window table of e(P, g2) for a G1 point P in device memory: the powers of two e(P, g2)^(2^s) = e(P, 2^s g2) come from ONE pairing
+// launch of P against the tabulated line sequences of the multiples 2^s g2 (the latency of one pairing; the tables -- 320 x 18 KB -- are built
+// once per context: 2^s as scalars, one batched G2 multiplication, one k_g2_prepare workgroup per multiple). Until round 4 the chain ran on the
+// G1 side (2^s P by 260 doublings one after the other: 1.4 ms with the device idle, in every call with a new commitment).
+constexpr uint32_t GT_POWERS_MAX = 320;
+static keaki_status g2pow_tables(keaki_hip_ctx* ctx) {
+  if (ctx->g2pow_ready) return KEAKI_OK;
+  ST_TRY(reserve(ctx, ctx->g2pow_lines, (size_t)GT_POWERS_MAX * g2_prepared_bytes()));
+  ST_TRY(reserve(ctx, ctx->g2pow_pts, (size_t)GT_POWERS_MAX * (32 + G2_AFF_BYTES) + G2_AFF_BYTES));
+  char* sc = (char*)ctx->g2pow_pts.p;
+  char* gen = sc + (size_t)GT_POWERS_MAX * 32;
+  char* pts = gen + G2_AFF_BYTES;
+  ST_TRY(pow2_scalars_run(ctx, sc, GT_POWERS_MAX));
+  ST_TRY(g2_generator_to(ctx, gen));
+  ST_TRY(keaki_hip_g2_mul_batch_dev(ctx, gen, 0, sc, GT_POWERS_MAX, pts));
+  ST_TRY(g2_prepare_run(ctx, pts, ctx->g2pow_lines.p, GT_POWERS_MAX));
+  ctx->g2pow_ready = true;
+  return KEAKI_OK;
+}
 static keaki_status gt_table_of(keaki_hip_ctx* ctx, const void* d_p_aff, void* d_table, uint32_t wb) {
   char* gb = (char*)ctx->gt_base.p;
   const uint32_t cnt = gt_table_powers(wb);
-  void* pts = gb + G1_AFF_BYTES;
+  if (cnt > GT_POWERS_MAX) return fail(ctx, KEAKI_ERR_BAD_ARG, "gt_table_of: %u powers", cnt);
   void* pows = gb + G1_AFF_BYTES + 320 * G1_AFF_BYTES;
-  ST_TRY(g1_pow2_chain_run(ctx, d_p_aff, cnt, pts));
-  ST_TRY(pairing_raw_fixed_run(ctx, pts, cnt, ctx->g2gen_lines.p, pows));
+  ST_TRY(g2pow_tables(ctx));
+  ST_TRY(pairing_raw_fixed_run(ctx, d_p_aff, 0, cnt, ctx->g2pow_lines.p, g2_prepared_lines(), pows));
   return gt_table_run(ctx, pows, d_table, wb);
 }
 
@@ -766,18 +801,93 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
     ST_TRY(g2_prepare_run(ctx, ctx->tmp_c.p, ctx->g2gen_lines.p));
     ctx->g2gen_lines_ready = true;
   }
+  // the two constants of the batch on the host (one read-back, one synchronisation; none when the caller's host copies came along)
+  uint64_t tau_host[16], com_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (host) {
+    memcpy(tau_host, host->tau, 128);
+    memcpy(com_host, host->com, 64);
+  } else {
+    HIP_TRY(ctx, hipMemcpyAsync(tau_host, d_tau_g2_aff, 128, hipMemcpyDeviceToHost, ctx->stream));
+    if (!prep) HIP_TRY(ctx, hipMemcpyAsync(com_host, d_com_aff, 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  // window widths of the GT tables. The constant B = e(g1, g2) is tabulated once per context: 20-bit windows (13 products per item, 2.6 GB;
+  // KEAKI_GT_WB_B picks another width). A = e(C, g2) per commitment: 13 bits on first sight (20 products per item, 31.5 MB: one launch of the
+  // twelve-lane pairing kernel over the tabulated multiples of g2 + the fills, 1.7 ms); when the SAME commitment comes back, its 16-bit table
+  // (16 products, 201 MB) is filled from the powers of two still lying in gt_base (0.5 ms, no pairing).
+  // Which calls take this path: batches of >= 65,536 items (KEAKI_ENCAP_GT overrides the threshold and then decides alone); and ANY batch once the
+  // caller keeps encrypting to one commitment -- from the third consecutive call with the same commitment on, or whenever its table is
+  // already there: keaki's own loops (src/vec.rs:63-66) and a caller of the single `encapsulate` do exactly that, and an item then costs
+  // ~30 Fq12 products instead of two G1 ladders and a pairing (single call: 9.2 -> 2.6 ms).
+  constexpr uint32_t GT_WB_A_FIRST = 13, GT_WB_A_REPEAT = 16;
+  const bool wbb_env = ctx->tune.gt_wb_b != 0;          // Tuning::gt_wb_b / encap_gt (the environment is read in keaki_hip_ctx_create only)
+  const bool gt_env = ctx->tune.encap_gt >= 0;
+  const size_t gt_threshold = gt_env ? (size_t)ctx->tune.encap_gt : (size_t)65536;
+  bool a_cached = false;
+  if (!prep) {
+    if (ctx->seen_com_runs && memcmp(com_host, ctx->seen_com, 64) == 0) {
+      if (first_of_batch && ctx->seen_com_runs < 1000000) ctx->seen_com_runs++;
+    } else {
+      memcpy(ctx->seen_com, com_host, 64);
+      ctx->seen_com_runs = 1;
+    }
+    a_cached = ctx->gt_b_ready && ctx->gt_a_valid && memcmp(com_host, ctx->gt_a_com, 64) == 0;
+  }
+  const bool use_gt = n_policy >= gt_threshold || (!prep && !gt_env && (a_cached || ctx->seen_com_runs >= 3));
+  bool a_on_aux = false;
+  if (use_gt) {
+    // GT_i = A^(r_i) B^(-beta_i r_i) with A = e(C, g2), B = e(g1, g2) (see pairing.hip.h): no pairing per item
+    ST_TRY(reserve(ctx, ctx->gt_base, G1_AFF_BYTES + 320 * (G1_AFF_BYTES + 384)));   // a point | (unused since round 4) | the powers' pairings
+    char* gb = (char*)ctx->gt_base.p;
+    // B: 20-bit windows for a context that runs large batches, 16-bit (201 MB) for one that only ever made small calls; widened once when a large batch comes
+    const uint32_t wb_b_req = wbb_env ? (uint32_t)ctx->tune.gt_wb_b : (n_policy >= 65536 ? 20u : 16u);
+    if (!ctx->gt_b_ready || (!wbb_env && wb_b_req > ctx->gt_b_wb && !ctx->gt_b_fallback)) {
+      if (wb_b_req < 8 || wb_b_req > 22 || gt_table_powers(wb_b_req) > 320) return fail(ctx, KEAKI_ERR_BAD_ARG, "gt_wb_b = %u out of range", wb_b_req);
+      ctx->gt_b_ready = false;
+      ctx->gt_b_wb = wb_b_req;
+      keaki_status st_b = reserve(ctx, ctx->gt_tab_b, gt_table_bytes(ctx->gt_b_wb));
+      if (st_b == KEAKI_ERR_OOM && ctx->gt_b_wb > 16) {          // no room for the wide table: the 16-bit one is 201 MB
+        (void)hipGetLastError();
+        ctx->gt_b_wb = 16;
+        ctx->gt_b_fallback = true;
+        st_b = reserve(ctx, ctx->gt_tab_b, gt_table_bytes(ctx->gt_b_wb));
+      }
+      ST_TRY(st_b);
+      ST_TRY(g1_generator_to(ctx, gb));
+      ST_TRY(gt_table_of(ctx, gb, ctx->gt_tab_b.p, ctx->gt_b_wb));
+      ctx->gt_b_ready = true;
+      ctx->gt_a_valid = false;                    // gt_base now holds B's powers
+    }
+    // A depends on the commitment only: reuse the table while the caller keeps encrypting to the same commitment. A NEW commitment's table is
+    // a latency-bound job (65 waves for 1.4 ms, then the fills): it goes to a stream of its own, IN FRONT of the ciphertext kernel below, which
+    // fills the device for 0.56 ms at 2^16 items -- the two run side by side and the exponentiation waits for both.
+    if (!prep && (!ctx->gt_a_valid || memcmp(com_host, ctx->gt_a_com, 64) != 0)) {
+      ctx->gt_a_valid = false;
+      ST_TRY(reserve(ctx, ctx->gt_tab_a, gt_table_bytes(GT_WB_A_REPEAT)));
+      ST_TRY(aux_ready(ctx));
+      HIP_TRY(ctx, hipEventRecord(ctx->aux_ev[0], ctx->stream));          // behind every earlier reader of the table and of gt_base
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_ev[0], 0));
+      {
+        StreamSwap on_aux(ctx, ctx->aux_stream);
+        ST_TRY(gt_table_of(ctx, d_com_aff, ctx->gt_tab_a.p, GT_WB_A_FIRST));
+      }
+      HIP_TRY(ctx, hipEventRecord(ctx->aux_ev[1], ctx->aux_stream));
+      a_on_aux = true;
+      memcpy(ctx->gt_a_com, com_host, 64);
+      ctx->gt_a_wb = GT_WB_A_FIRST;
+      ctx->gt_a_valid = true;
+    } else if (!prep && ctx->gt_a_wb != GT_WB_A_REPEAT) {
+      // same commitment again: the powers A^(2^s), s < 260, of the first build cover the 256 the wider table needs
+      ST_TRY(gt_table_run(ctx, gb + G1_AFF_BYTES + 320 * G1_AFF_BYTES, ctx->gt_tab_a.p, GT_WB_A_REPEAT));
+      static_assert(GT_WB_A_REPEAT == 16 && GT_WB_A_FIRST == 13, "the power count of the first table must cover the second");
+      ctx->gt_a_wb = GT_WB_A_REPEAT;
+    }
+  }
   // ciphertexts ct_i = r_i [tau]_2 - (r_i alpha_i) g2: two fixed-base sums. [tau]_2 belongs to the setup, not to the batch: its window table
   // is rebuilt only when the point changes. Batches of >= 256 items use (and build) the 16-bit tables; smaller ones use them when they are
   // there for this [tau]_2, else SMALL 8-bit tables (32 x 129 entries per base, 0.5 MB, built in the latency of one G2 scalar-mult):
   // 64 mixed additions per item instead of two 254-step ladders (a single `encapsulate` call: 20.5 -> 10 ms).
   {
-    uint64_t tau_host[16];
-    if (host) {
-      memcpy(tau_host, host->tau, 128);
-    } else {
-      HIP_TRY(ctx, hipMemcpyAsync(tau_host, d_tau_g2_aff, 128, hipMemcpyDeviceToHost, ctx->stream));
-      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    }
     const bool big_has_tau = ctx->fb_ready && ctx->fb_tau_valid && memcmp(tau_host, ctx->fb_tau_pt, 128) == 0;
     if (use_tables || big_has_tau) {
       if (!big_has_tau) {
@@ -808,77 +918,11 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
       if (!prep) ST_TRY(encap_g2_fixed_run(ctx, ctx->fbs_tau.p, FB_WB_SMALL, ctx->fbs_g2_gen.p, FB_WB_SMALL, d_points, d_r, n, d_ct_out_aff));
     }
   }
-  // window widths of the GT tables. The constant B = e(g1, g2) is tabulated once per context: 20-bit windows (13 products per item, 2.6 GB;
-  // KEAKI_GT_WB_B picks another width). A = e(C, g2) per commitment: 13 bits on first sight (20 products per item, 31.5 MB, ~8.6 ms to
-  // build: the latency of one pairing launch + the fills); when the SAME commitment comes back, its 16-bit table (16 products, 201 MB) is
-  // filled from the powers of two still lying in gt_base (0.5 ms, no pairing).
-  // Which calls take this path: batches of >= 65,536 items (KEAKI_ENCAP_GT overrides the threshold and then decides alone); and ANY batch once the
-  // caller keeps encrypting to one commitment -- from the third consecutive call with the same commitment on, or whenever its table is
-  // already there: keaki's own loops (src/vec.rs:63-66) and a caller of the single `encapsulate` do exactly that, and an item then costs
-  // ~30 Fq12 products instead of two G1 ladders and a pairing (single call: 9.2 -> 2.6 ms).
-  constexpr uint32_t GT_WB_A_FIRST = 13, GT_WB_A_REPEAT = 16;
-  const bool wbb_env = ctx->tune.gt_wb_b != 0;          // Tuning::gt_wb_b / encap_gt (the environment is read in keaki_hip_ctx_create only)
-  const bool gt_env = ctx->tune.encap_gt >= 0;
-  const size_t gt_threshold = gt_env ? (size_t)ctx->tune.encap_gt : (size_t)65536;
-  uint64_t com_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  bool a_cached = false;
-  if (!prep) {
-    if (host) {
-      memcpy(com_host, host->com, 64);
-    } else {
-      HIP_TRY(ctx, hipMemcpyAsync(com_host, d_com_aff, 64, hipMemcpyDeviceToHost, ctx->stream));
-      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    if (ctx->seen_com_runs && memcmp(com_host, ctx->seen_com, 64) == 0) {
-      if (first_of_batch && ctx->seen_com_runs < 1000000) ctx->seen_com_runs++;
-    } else {
-      memcpy(ctx->seen_com, com_host, 64);
-      ctx->seen_com_runs = 1;
-    }
-    a_cached = ctx->gt_b_ready && ctx->gt_a_valid && memcmp(com_host, ctx->gt_a_com, 64) == 0;
-  }
-  const bool use_gt = n_policy >= gt_threshold || (!prep && !gt_env && (a_cached || ctx->seen_com_runs >= 3));
+  if (prep) return KEAKI_OK;
   if (use_gt) {
-    // GT_i = A^(r_i) B^(-beta_i r_i) with A = e(C, g2), B = e(g1, g2) (see pairing.hip.h): no pairing per item
-    ST_TRY(reserve(ctx, ctx->gt_base, G1_AFF_BYTES + 320 * (G1_AFF_BYTES + 384)));   // a point | 2^s multiples | their pairings
-    char* gb = (char*)ctx->gt_base.p;
-    // B: 20-bit windows for a context that runs large batches, 16-bit (201 MB) for one that only ever made small calls; widened once when a large batch comes
-    const uint32_t wb_b_req = wbb_env ? (uint32_t)ctx->tune.gt_wb_b : (n_policy >= 65536 ? 20u : 16u);
-    if (!ctx->gt_b_ready || (!wbb_env && wb_b_req > ctx->gt_b_wb && !ctx->gt_b_fallback)) {
-      if (wb_b_req < 8 || wb_b_req > 22 || gt_table_powers(wb_b_req) > 320) return fail(ctx, KEAKI_ERR_BAD_ARG, "gt_wb_b = %u out of range", wb_b_req);
-      ctx->gt_b_ready = false;
-      ctx->gt_b_wb = wb_b_req;
-      keaki_status st_b = reserve(ctx, ctx->gt_tab_b, gt_table_bytes(ctx->gt_b_wb));
-      if (st_b == KEAKI_ERR_OOM && ctx->gt_b_wb > 16) {          // no room for the wide table: the 16-bit one is 201 MB
-        (void)hipGetLastError();
-        ctx->gt_b_wb = 16;
-        ctx->gt_b_fallback = true;
-        st_b = reserve(ctx, ctx->gt_tab_b, gt_table_bytes(ctx->gt_b_wb));
-      }
-      ST_TRY(st_b);
-      ST_TRY(g1_generator_to(ctx, gb));
-      ST_TRY(gt_table_of(ctx, gb, ctx->gt_tab_b.p, ctx->gt_b_wb));
-      ctx->gt_b_ready = true;
-      ctx->gt_a_valid = false;                    // gt_base now holds B's powers
-    }
-    if (prep) return KEAKI_OK;
-    // A depends on the commitment only: reuse the table while the caller keeps encrypting to the same commitment
-    if (!ctx->gt_a_valid || memcmp(com_host, ctx->gt_a_com, 64) != 0) {
-      ctx->gt_a_valid = false;
-      ST_TRY(reserve(ctx, ctx->gt_tab_a, gt_table_bytes(GT_WB_A_REPEAT)));
-      ST_TRY(gt_table_of(ctx, d_com_aff, ctx->gt_tab_a.p, GT_WB_A_FIRST));
-      memcpy(ctx->gt_a_com, com_host, 64);
-      ctx->gt_a_wb = GT_WB_A_FIRST;
-      ctx->gt_a_valid = true;
-    } else if (ctx->gt_a_wb != GT_WB_A_REPEAT) {
-      // same commitment again: the powers A^(2^s), s < 260, of the first build cover the 256 the wider table needs
-      ST_TRY(gt_table_run(ctx, gb + G1_AFF_BYTES + 320 * G1_AFF_BYTES, ctx->gt_tab_a.p, GT_WB_A_REPEAT));
-      static_assert(GT_WB_A_REPEAT == 16 && GT_WB_A_FIRST == 13, "the power count of the first table must cover the second");
-      ctx->gt_a_wb = GT_WB_A_REPEAT;
-    }
+    if (a_on_aux) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_ev[1], 0));
     ST_TRY(gt_encap_exp_run(ctx, ctx->gt_tab_a.p, ctx->gt_a_wb, ctx->gt_tab_b.p, ctx->gt_b_wb, d_values, d_r, n, gt));
   } else {
-    if (prep) return KEAKI_OK;
     // per-item pairing e(r_i (C - beta_i g1), g2) with the tabulated lines of g2
     if (use_tables) {
       ST_TRY(g1_fb_table_run(ctx, d_com_aff, (char*)ctx->fb_scalars.p + FBL * 32, ctx->fb_com.p, FB_WB_BATCH));

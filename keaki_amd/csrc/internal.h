@@ -64,6 +64,10 @@ struct keaki_hip_ctx {
   uint64_t seen_com[8] = {};              // commitment of the last encap call and how many consecutive calls carried it
   uint32_t seen_com_runs = 0;
   uint32_t gt_a_wb = 0, gt_b_wb = 0;      // window widths of the GT tables in gt_tab_a / gt_tab_b
+  // line tables of 2^s g2, s < 320 (built once per context): e(C, g2)^(2^s) = e(C, 2^s g2) -- the powers behind a commitment's GT table are
+  // pairings of ONE point with fixed second arguments, no doubling chain of C in front of them
+  keaki_internal::DevBuf g2pow_lines, g2pow_pts;
+  bool g2pow_ready = false;
   keaki_internal::DevBuf pair_ws;                   // per-item slots of the final exponentiation (pairing.hip.h)
   keaki_internal::DevBuf fk_tab;                    // window tables of the per-lane-scalar ladders of FK23: 1 KB per lane of a launch (64 x 16 B), at most 2 GB (fft_g1.hip)
   keaki_internal::DevBuf verify_lines, verify_io;   // kzg verify: [lines of g2 | lines of [tau]_2], small in/out block
@@ -90,6 +94,8 @@ struct keaki_hip_ctx {
   float last_fk_ms[3] = {-1.f, -1.f, -1.f};      // pointwise products, butterfly stages (k_g1_fft_stage_map), whole device pipeline
   // host-pointer batches run in chunks (api.hip: pipelined): uploads and downloads of the neighbouring chunks on a stream of their own.
   // Created on first use. [in: chunk staged | done: chunk computed], one pair per buffer half
+  hipStream_t aux_stream = nullptr;              // latency-bound side jobs (api.hip: the GT table of a new commitment), with [go | done]
+  hipEvent_t aux_ev[2] = {nullptr, nullptr};
   hipStream_t copy_stream = nullptr;
   hipEvent_t pipe_in[2] = {nullptr, nullptr}, pipe_done[2] = {nullptr, nullptr};
 };
@@ -154,7 +160,9 @@ keaki_status pairing_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2,
 uint32_t g2_prepared_lines();                 // Line entries of one table
 keaki_status verify_combine_run(keaki_hip_ctx* ctx, const void* d_com, const void* d_proof, const void* d_value, const void* d_point, void* d_out2);
 size_t g2_prepared_bytes();
-keaki_status pairing_raw_fixed_run(keaki_hip_ctx* ctx, const void* d_g1, size_t n, const void* d_lines, void* d_out);
+// out[i] = e(P_(i * p_stride), Q_i) as 12 Fq in the 2^261 form, Q_i given by its line table d_lines + i * lines_stride lines
+keaki_status pairing_raw_fixed_run(keaki_hip_ctx* ctx, const void* d_g1, uint32_t p_stride, size_t n, const void* d_lines, uint32_t lines_stride, void* d_out);
+keaki_status pow2_scalars_run(keaki_hip_ctx* ctx, void* d_scalars, uint32_t count);          // 2^s as Montgomery Fr, s < count
 size_t gt_table_bytes(uint32_t wb);
 uint32_t gt_table_powers(uint32_t wb);      // powers of two a table needs: wb * windows
 keaki_status gt_table_run(keaki_hip_ctx* ctx, const void* d_pows, void* d_table, uint32_t wb);   // d_pows: base^(2^s), 12 Fq each
@@ -163,7 +171,7 @@ keaki_status gt_encap_exp_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t 
                               const void* d_rs, size_t n, void* d_gt);
 keaki_status miller_only_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, size_t n, void* d_out);
 keaki_status final_exp_only_run(keaki_hip_ctx* ctx, const void* d_in, size_t n, void* d_gt);
-keaki_status g2_prepare_run(keaki_hip_ctx* ctx, const void* d_q, void* d_lines);   // line sequence of a fixed Q (2^261 form: internal)
+keaki_status g2_prepare_run(keaki_hip_ctx* ctx, const void* d_q, void* d_lines, uint32_t n_points = 1);   // line sequence of a fixed Q (2^261 form: internal)
 keaki_status lines_to256_run(keaki_hip_ctx* ctx, const void* d_lines261, void* d_lines256);   // the same table in the ABI's 2^256 form (test hook)
 keaki_status blake3_gt_run(keaki_hip_ctx* ctx, const void* d_gt, size_t n, void* d_key, size_t msg_len, bool xor_into = false);   // xor_into: key ^= in place (the DEM)
 keaki_status g2_generator_to(keaki_hip_ctx* ctx, void* d_dst);  // writes the affine G2 generator (128 B)

@@ -10,14 +10,15 @@ using namespace bn254;
 constexpr size_t PAIR_CHUNK = (size_t)1 << 17;
 constexpr size_t PAIR_WIDE_AUTO = 4096;
 static keaki_status pairing_launch(keaki_hip_ctx* ctx, u32 mode, const void* d_g1, const void* d_g2, int g2_stride, const void* d_f_in, size_t n,
-                                   void* d_out, size_t out_item_bytes, const void* d_fixed_lines, uint32_t lines_stride, const char* what) {
+                                   void* d_out, size_t out_item_bytes, const void* d_fixed_lines, uint32_t lines_stride, const char* what,
+                                   uint32_t p_stride = 1) {
   if (n == 0) return KEAKI_OK;
   // Few pairings: the twelve-lanes-per-pairing kernel (pairing_wide.hip.h) -- a quarter of the latency for 1.65 x the wave-instructions, so only
   // while its waves (four pairings each) find the device not full: automatic = up to PAIR_WIDE_AUTO items.
   const size_t wide_max = ctx->tune.pair_wide_max < 0 ? PAIR_WIDE_AUTO : (size_t)ctx->tune.pair_wide_max;
   if (n <= wide_max) {
     PairArgs a;
-    a.ps = (const G1Aff*)d_g1; a.qs = (const G2Aff*)d_g2; a.q_stride = g2_stride; a.n = (u32)n;
+    a.ps = (const G1Aff*)d_g1; a.p_stride = p_stride; a.qs = (const G2Aff*)d_g2; a.q_stride = g2_stride; a.n = (u32)n;
     a.fixed_lines = (const Line*)d_fixed_lines; a.lines_stride = lines_stride; a.f_in = (const Fq*)d_f_in;
     a.ws = nullptr; a.ws_n = 0; a.out = d_out; a.mode = mode;
     hipLaunchKernelGGL(pw::k_pairing_wide, dim3(cdiv(n, 4)), dim3(64), 0, ctx->stream, a);
@@ -28,7 +29,8 @@ static keaki_status pairing_launch(keaki_hip_ctx* ctx, u32 mode, const void* d_g
   for (size_t lo = 0; lo < n; lo += ch) {
     const size_t m = n - lo < ch ? n - lo : ch;
     PairArgs a;
-    a.ps = d_g1 ? (const G1Aff*)d_g1 + lo : nullptr;
+    a.ps = d_g1 ? (const G1Aff*)d_g1 + lo * (size_t)p_stride : nullptr;
+    a.p_stride = p_stride;
     a.qs = d_g2 ? (const G2Aff*)d_g2 + lo * (size_t)g2_stride : nullptr;
     a.q_stride = g2_stride;
     a.n = (u32)m;
@@ -51,9 +53,13 @@ keaki_status pairing_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2,
 size_t pairing_launch_items() { return PAIR_CHUNK; }
 uint32_t g2_prepared_lines() { return (uint32_t)MILLER_MAX_LINES * 2; }
 size_t g2_prepared_bytes() { return (size_t)MILLER_MAX_LINES * 2 * sizeof(Line); }
-keaki_status g2_prepare_run(keaki_hip_ctx* ctx, const void* d_q, void* d_lines) {
-  hipLaunchKernelGGL(k_g2_prepare, dim3(1), dim3(64), 0, ctx->stream, (const G2Aff*)d_q, (Line*)d_lines);
+keaki_status g2_prepare_run(keaki_hip_ctx* ctx, const void* d_q, void* d_lines, uint32_t n_points) {
+  hipLaunchKernelGGL(k_g2_prepare, dim3(n_points), dim3(64), 0, ctx->stream, (const G2Aff*)d_q, (Line*)d_lines, g2_prepared_lines());
   return launch_check(ctx, "g2_prepare");
+}
+keaki_status pow2_scalars_run(keaki_hip_ctx* ctx, void* d_scalars, uint32_t count) {
+  hipLaunchKernelGGL(k_pow2_scalars, dim3(1), dim3(64), 0, ctx->stream, (Fr*)d_scalars, count);
+  return launch_check(ctx, "pow2_scalars");
 }
 // test hook: the table in the 2^256 Montgomery form of the ABI (the kernels keep it in the 2^261 form)
 keaki_status lines_to256_run(keaki_hip_ctx* ctx, const void* d_lines261, void* d_lines256) {
@@ -61,8 +67,9 @@ keaki_status lines_to256_run(keaki_hip_ctx* ctx, const void* d_lines261, void* d
   hipLaunchKernelGGL(k_lines_to256, dim3(cdiv(count, 64)), dim3(64), 0, ctx->stream, (const Fq*)d_lines261, (Fq*)d_lines256, count);
   return launch_check(ctx, "lines_to256");
 }
-keaki_status pairing_raw_fixed_run(keaki_hip_ctx* ctx, const void* d_g1, size_t n, const void* d_lines, void* d_out) {
-  return pairing_launch(ctx, PAIR_MILLER | PAIR_FINAL_EXP | PAIR_OUT_RAW261, d_g1, nullptr, 0, nullptr, n, d_out, 12 * sizeof(Fq), d_lines, 0, "pairing_raw_fixed");
+keaki_status pairing_raw_fixed_run(keaki_hip_ctx* ctx, const void* d_g1, uint32_t p_stride, size_t n, const void* d_lines, uint32_t lines_stride, void* d_out) {
+  return pairing_launch(ctx, PAIR_MILLER | PAIR_FINAL_EXP | PAIR_OUT_RAW261, d_g1, nullptr, 0, nullptr, n, d_out, 12 * sizeof(Fq), d_lines, lines_stride,
+                        "pairing_raw_fixed", p_stride);
 }
 size_t gt_table_bytes(uint32_t wb) { GtShape g = gt_shape(wb); return (size_t)g.windows * g.entries * 12 * sizeof(Fq); }
 uint32_t gt_table_powers(uint32_t wb) { GtShape g = gt_shape(wb); return g.wb * g.windows; }

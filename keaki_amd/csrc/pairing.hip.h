@@ -216,7 +216,8 @@ enum : u32 {
   PAIR_OUT_RAW261 = 16,   // out = 12 Fq per item, 2^261 form (feeds the GT window tables)
 };
 struct PairArgs {
-  const G1Aff* ps;          // P_i, affine, 2^256 form ((0, 0) = identity)
+  const G1Aff* ps;          // P_(i * p_stride), affine, 2^256 form ((0, 0) = identity); p_stride 0: one point for every item
+  u32 p_stride;
   const G2Aff* qs;          // Q_(i * q_stride); ignored when fixed_lines
   int q_stride;
   u32 n;
@@ -240,7 +241,7 @@ static __global__ void __launch_bounds__(64, 2) k_pairing(PairArgs a) {
   Fq12 f;
   bool ident = false;
   if (a.mode & PAIR_MILLER) {
-    const G1Aff p = a.ps[i];
+    const G1Aff p = a.ps[(size_t)i * a.p_stride];
     const Fq* qw = nullptr;
     u32 qz = 0;
     if (!a.fixed_lines) {
@@ -280,12 +281,23 @@ static __global__ void __launch_bounds__(64, 2) k_pairing(PairArgs a) {
     }
   }
 }
-// the line sequence of a fixed Q (2^256 form in); every lane pair of the single wave computes the same values, pair 0's layout is the table
-static __global__ void __launch_bounds__(64) k_g2_prepare(const G2Aff* __restrict__ q, Line* __restrict__ lines_out) {
+// the line sequence of a fixed Q (2^256 form in), one workgroup per point: table b of lines_per_table lines for the point q[b]; every lane
+// pair of the wave computes the same values, pair 0's layout is the table
+static __global__ void __launch_bounds__(64) k_g2_prepare(const G2Aff* __restrict__ q, Line* __restrict__ lines_out, u32 lines_per_table) {
+  q += blockIdx.x;
+  lines_out += (size_t)blockIdx.x * lines_per_table;
   const Fq* qxw = reinterpret_cast<const Fq*>(&q->x);
   const Fq* qyw = reinterpret_cast<const Fq*>(&q->y);
   Fq2d qx = {to261(qxw[lane_odd()])}, qy = {to261(qyw[lane_odd()])};
   miller_lines(&qx, &qy, lines_out);
+}
+// out[s] = 2^s (Montgomery Fr), s < count: doubling is an addition in any Montgomery radix
+static __global__ void __launch_bounds__(64) k_pow2_scalars(Fr* __restrict__ out, u32 count) {
+  if (blockIdx.x || threadIdx.x) return;
+  Fr acc;
+#pragma unroll
+  for (int j = 0; j < 8; j++) acc.l[j] = FrParams::ONE[j];
+  for (u32 s = 0; s < count; s++) { out[s] = acc; acc = fp_add<FrParams>(acc, acc); }
 }
 // test hook: a line table in the 2^256 form (what the oracle tabulates)
 static __global__ void __launch_bounds__(64) k_lines_to256(const Fq* __restrict__ in, Fq* __restrict__ out, u32 count) {

@@ -323,7 +323,7 @@ static __global__ void __launch_bounds__(64) k_pairing_wide(PairArgs a) {
   Fq f;
   bool ident = false;
   if (a.mode & PAIR_MILLER) {
-    const G1Aff p = a.ps[i];
+    const G1Aff p = a.ps[(size_t)i * a.p_stride];
     const Fq* qw = nullptr;
     u32 qz = 0;
     if (!a.fixed_lines) {
