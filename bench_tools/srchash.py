@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MSM_KERNEL_SOURCES = ["msm.hip.h", "msm_host.hip.h", "msm_g1.hip", "fq29.hip.h", "fq29_core.hip.h", "fq29_asm.hip.h", "xyzz29.hip.h", "jac29.hip.h",
                       "bn254_field.hip.h", "bn254_field_asm.hip.h", "bn254_curve.hip.h"]
 FK_KERNEL_SOURCES = ["fft_g1.hip", "jac29.hip.h", "fq29.hip.h", "fq29_core.hip.h", "fq29_asm.hip.h", "bn254_field.hip.h", "bn254_field_asm.hip.h", "bn254_curve.hip.h"]
-PAIRING_KERNEL_SOURCES = ["pairing.hip.h", "pairing.hip", "pair261.hip.h", "pair261_constants.hip.h", "fq29.hip.h", "fq29_core.hip.h", "fq29_asm.hip.h",
+PAIRING_KERNEL_SOURCES = ["pairing.hip.h", "pairing_wide.hip.h", "pairing.hip", "pair261.hip.h", "pair261_constants.hip.h", "fq29.hip.h", "fq29_core.hip.h", "fq29_asm.hip.h",
                           "fq29_dot_asm.hip.h", "bn254_field.hip.h", "bn254_field_asm.hip.h", "bn254_curve.hip.h"]
 
 

@@ -83,33 +83,6 @@ static __global__ void __launch_bounds__(64) k_verify_combine(const G1Aff* __res
     out2[1] = *proof;
   }
 }
-// out[s] = 2^s * base (affine), s < count <= 320. Lane 0 walks the doubling chain in the 29-bit arithmetic, then lane s normalises its
-// multiple. Feeds the GT window tables: e(2^s C, g2) = e(C, g2)^(2^s), so all powers of two of a table come out of ONE pairing launch
-// (count lane pairs, the latency of a single pairing) instead of a serial chain of count GT squarings behind the pairing.
-static __global__ void __launch_bounds__(320) k_g1_pow2_chain(const G1Aff* __restrict__ base, u32 count, G1Aff* __restrict__ out) {
-  __shared__ Fq sh[320 * 3];
-  const u32 t = threadIdx.x;
-  if (t == 0) {
-    const G1Aff b = *base;
-    J29 j;
-    j.x = u29_from_fq(b.x); j.y = u29_from_fq(b.y); j.z = u29_one();
-    if (aff_is_inf(b)) {
-#pragma unroll
-      for (int i = 0; i < 9; i++) j.z.l[i] = 0;
-    }
-#pragma unroll 1
-    for (u32 s = 0; s < count; s++) {
-      sh[3 * s] = u29_to_fq(j.x); sh[3 * s + 1] = u29_to_fq(j.y); sh[3 * s + 2] = u29_to_fq(j.z);
-      j = j29_dbl(j);
-    }
-  }
-  __syncthreads();
-  if (t < count) {
-    G1Jac q = {sh[3 * t], sh[3 * t + 1], sh[3 * t + 2]};
-    out[t] = jac_to_aff(q);
-  }
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // Fixed-base path for encapsulate. In the batch loop of src/vec.rs:63-66 every item uses the SAME

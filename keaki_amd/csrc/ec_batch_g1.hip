@@ -18,11 +18,6 @@ keaki_status verify_combine_run(keaki_hip_ctx* ctx, const void* d_com, const voi
                      (const Fr*)d_point, (G1Aff*)d_out2);
   return launch_check(ctx, "verify_combine");
 }
-keaki_status g1_pow2_chain_run(keaki_hip_ctx* ctx, const void* d_base, uint32_t count, void* d_out) {
-  if (count > 320) return fail(ctx, KEAKI_ERR_BAD_ARG, "g1_pow2_chain: %u > 320 multiples", count);
-  hipLaunchKernelGGL(k_g1_pow2_chain, dim3(1), dim3(320), 0, ctx->stream, (const G1Aff*)d_base, count, (G1Aff*)d_out);
-  return launch_check(ctx, "g1_pow2_chain");
-}
 keaki_status fb_table_scalars_run(keaki_hip_ctx* ctx, void* d_scalars, uint32_t wb) {
   const FbShape g = fb_shape(wb);
   hipLaunchKernelGGL(k_fb_table_scalars, dim3(cdiv(g.windows * g.entries, 256)), dim3(256), 0, ctx->stream, (Fr*)d_scalars, g);

@@ -166,7 +166,6 @@ keaki_status pow2_scalars_run(keaki_hip_ctx* ctx, void* d_scalars, uint32_t coun
 size_t gt_table_bytes(uint32_t wb);
 uint32_t gt_table_powers(uint32_t wb);      // powers of two a table needs: wb * windows
 keaki_status gt_table_run(keaki_hip_ctx* ctx, const void* d_pows, void* d_table, uint32_t wb);   // d_pows: base^(2^s), 12 Fq each
-keaki_status g1_pow2_chain_run(keaki_hip_ctx* ctx, const void* d_base, uint32_t count, void* d_out);   // out[s] = 2^s base, affine
 keaki_status gt_encap_exp_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t wb_a, const void* d_tab_b, uint32_t wb_b, const void* d_betas,
                               const void* d_rs, size_t n, void* d_gt);
 keaki_status miller_only_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, size_t n, void* d_out);

@@ -331,7 +331,7 @@ KDEV void gt_store(Fq* __restrict__ dst, const Fq12* f) {
   for (int k = 0; k < 6; k++) dst[2 * k + par] = c[k].v;
 }
 // table[j * entries + d] = base^(d 2^(wb j)).  Step 1: the powers of two base^(2^s), s < wb * windows (pows[s]: 12 Fq each, from
-// k_pairing over the multiples 2^s P of k_g1_pow2_chain -- base = e(P, Q)) go to slot 2^(s mod wb) of window s / wb.
+// one pairing launch of P against the tabulated multiples 2^s g2: e(P, g2)^(2^s) = e(P, 2^s g2)) go to slot 2^(s mod wb) of window s / wb.
 static __global__ void __launch_bounds__(256) k_gt_table_scatter(const Fq* __restrict__ pows, Fq* __restrict__ table, GtShape g) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= g.wb * g.windows * 12) return;
