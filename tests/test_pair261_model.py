@@ -173,3 +173,61 @@ def test_division_step_inverse_model():
     spec = importlib.util.spec_from_file_location("model_safegcd", os.path.join(ROOT, "keaki_amd", "csrc", "models", "model_safegcd.py"))
     m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
     assert m.run(n=120, seed=9)
+
+
+def test_twelve_lane_kernel_flat_basis_formulas(py):
+    """pairing_wide.hip.h, in integers: pair k of a row holds the coefficient of w^k (Fq12 = Fq2[w]/(w^6 - xi), tower coefficient c_e.c_j at
+    k = 2j + e). The schoolbook product with xi where the index wraps, the sparse line product (c0 at w^0, d0 at w^1, d1 at w^3), the
+    Granger-Scott squaring by pairs (a0,a3), (a1,a4), (a2,a5) with the signs of the kernel, the replicated-T line rounds, and the value bounds
+    of the streams as the header states them."""
+    rng = random.Random(11)
+    r2 = lambda: (rng.randrange(py.P), rng.randrange(py.P))
+    xi, m, add, sub, dbl = py.f2_mul_xi, py.f2_mul, py.f2_add, py.f2_sub, py.f2_dbl
+    flat = lambda f: [f[k & 1][k >> 1] for k in range(6)]
+    tower = lambda a: ((a[0], a[2], a[4]), (a[1], a[3], a[5]))
+    zero = (0, 0)
+    for _ in range(3):
+        f, g = rand_f12(py, rng), rand_f12(py, rng)
+        a, b = flat(f), flat(g)
+        c = []
+        for k in range(6):
+            acc = zero
+            for i in range(6):
+                wrap = k < i
+                j = k + 6 - i if wrap else k - i
+                acc = add(acc, m(a[i], xi(b[j]) if wrap else b[j]))
+            c.append(acc)
+        assert tower(c) == py.f12_mul(f, g)
+        # line product
+        lc0, d0, d1 = r2(), r2(), r2()
+        c = []
+        for k in range(6):
+            i1, i3 = (k - 1 if k >= 1 else 5), (k - 3 if k >= 3 else k + 3)
+            c.append(add(add(m(a[k], lc0), m(a[i1], d0 if k >= 1 else xi(d0))), m(a[i3], d1 if k >= 3 else xi(d1))))
+        assert tower(c) == py.f12_mul_by_034(f, lc0, d0, d1)
+        # memory position of w^k in the tower's (and ark-serialize's) order c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2
+        mem = [f[0][0], f[0][1], f[0][2], f[1][0], f[1][1], f[1][2]]
+        assert all(mem[(k & 1) * 3 + (k >> 1)] == a[k] for k in range(6))
+        # Frobenius: coefficient-wise (the constants are indexed by the power of w)
+        assert tower([py.f2_mul(py.f2_conj(a[k]), py._FROB_W[1][k]) for k in range(6)]) == py.f12_frob(f, 1)
+        assert tower([py.f2_mul(a[k], py._FROB_W[2][k]) for k in range(6)]) == py.f12_frob(f, 2)
+        # conjugation f^(p^6): the odd powers of w change sign
+        assert tower([py.f2_neg(a[k]) if k & 1 else a[k] for k in range(6)]) == py.f12_conj(f)
+    # cyclotomic squaring: only valid on the cyclotomic subgroup -- take an element of it (easy part of the final exponentiation)
+    f = rand_f12(py, rng)
+    u = py.f12_mul(py.f12_conj(f), py.f12_inv(f))
+    u = py.f12_mul(py.f12_frob(u, 2), u)
+    a = flat(u)
+    out = []
+    for k in range(6):
+        xs = 0 if k in (0, 3) else (1 if k in (2, 5) else 2)
+        x, y = a[xs], a[xs + 3]
+        te = add(m(x, x), m(xi(y), y)); to = dbl(m(x, y))
+        t = te if k % 2 == 0 else (xi(to) if k == 1 else to)
+        d = sub(t, a[k]) if k % 2 == 0 else add(t, a[k])
+        out.append(add(dbl(d), t))
+    assert tower(out) == py.f12_sqr(u)
+    # bounds (multiples of p, over 169 = 2^261 / p): general product 3 per plain term, 27 per wrapped term, at most three wrapped terms per stream;
+    # line product c0 4 + xi d0 54 + xi d1 27; cyclotomic 6 + 33
+    plain, wrapped = 1 * 1 + 1 * 2, 1 * 11 + 1 * 16
+    assert 3 * wrapped <= 169 and plain + 2 * wrapped <= 169 and 4 + (22 + 32) + (11 + 16) <= 169 and 6 + 33 <= 169
