@@ -815,14 +815,14 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
   // KEAKI_GT_WB_B picks another width). A = e(C, g2) per commitment: 13 bits on first sight (20 products per item, 31.5 MB: one launch of the
   // twelve-lane pairing kernel over the tabulated multiples of g2 + the fills, 1.7 ms); when the SAME commitment comes back, its 16-bit table
   // (16 products, 201 MB) is filled from the powers of two still lying in gt_base (0.5 ms, no pairing).
-  // Which calls take this path: batches of >= 65,536 items (KEAKI_ENCAP_GT overrides the threshold and then decides alone); and ANY batch once the
-  // caller keeps encrypting to one commitment -- from the third consecutive call with the same commitment on, or whenever its table is
-  // already there: keaki's own loops (src/vec.rs:63-66) and a caller of the single `encapsulate` do exactly that, and an item then costs
-  // ~30 Fq12 products instead of two G1 ladders and a pairing (single call: 9.2 -> 2.6 ms).
+  // Which calls take this path: ALL of them since the table of a new commitment costs 1.7 ms beside the ciphertext kernel (round 4; until then
+  // batches of >= 65,536 items and callers that kept encrypting to one commitment, from the third consecutive call on): an item costs ~30 Fq12
+  // products instead of two G1 ladders and a pairing, and a single `encapsulate` to a NEW commitment 2.0 ms instead of 4.2 (the G1 ladders alone
+  // took 1.8). KEAKI_ENCAP_GT / option encap_gt = N keeps the per-item pairing path for batches below N items whose commitment has no table yet.
   constexpr uint32_t GT_WB_A_FIRST = 13, GT_WB_A_REPEAT = 16;
   const bool wbb_env = ctx->tune.gt_wb_b != 0;          // Tuning::gt_wb_b / encap_gt (the environment is read in keaki_hip_ctx_create only)
   const bool gt_env = ctx->tune.encap_gt >= 0;
-  const size_t gt_threshold = gt_env ? (size_t)ctx->tune.encap_gt : (size_t)65536;
+  const size_t gt_threshold = gt_env ? (size_t)ctx->tune.encap_gt : (size_t)0;
   bool a_cached = false;
   if (!prep) {
     if (ctx->seen_com_runs && memcmp(com_host, ctx->seen_com, 64) == 0) {

@@ -9,6 +9,7 @@ using namespace bn254;
 // (3.75 KB per item; 2^17 items = 480 MB, grow-only in the context).
 constexpr size_t PAIR_CHUNK = (size_t)1 << 17;
 constexpr size_t PAIR_WIDE_AUTO = 4096;
+constexpr size_t GT_EXP_WIDE_AUTO = 2048;      // items of an encapsulation batch whose GT exponentiations run twelve lanes per item
 static keaki_status pairing_launch(keaki_hip_ctx* ctx, u32 mode, const void* d_g1, const void* d_g2, int g2_stride, const void* d_f_in, size_t n,
                                    void* d_out, size_t out_item_bytes, const void* d_fixed_lines, uint32_t lines_stride, const char* what,
                                    uint32_t p_stride = 1) {
@@ -77,14 +78,26 @@ uint32_t gt_table_powers(uint32_t wb) { GtShape g = gt_shape(wb); return g.wb * 
 keaki_status gt_table_run(keaki_hip_ctx* ctx, const void* d_pows, void* d_table, uint32_t wb) {
   const GtShape g = gt_shape(wb);
   hipLaunchKernelGGL(k_gt_table_scatter, dim3(cdiv(g.wb * g.windows * 12, 256)), dim3(256), 0, ctx->stream, (const Fq*)d_pows, (Fq*)d_table, g);
-  for (u32 L = 1; L + 2 <= g.wb; L++)
-    hipLaunchKernelGGL(k_gt_table_fill, dim3(cdiv(2 * g.windows * ((1u << L) - 1u), 64)), dim3(64), 0, ctx->stream, (Fq*)d_table, L, g);
+  // the first levels hold a few entries each and wait for the latency of ONE product: twelve lanes per product there, a lane pair per product
+  // once a level fills the device
+  for (u32 L = 1; L + 2 <= g.wb; L++) {
+    const u32 entries = g.windows * ((1u << L) - 1u);
+    if (entries <= PAIR_WIDE_AUTO && ctx->tune.pair_wide_max != 0)
+      hipLaunchKernelGGL(pw::k_gt_table_fill_wide, dim3(cdiv(entries, 4)), dim3(64), 0, ctx->stream, (Fq*)d_table, L, g);
+    else
+      hipLaunchKernelGGL(k_gt_table_fill, dim3(cdiv(2 * entries, 64)), dim3(64), 0, ctx->stream, (Fq*)d_table, L, g);
+  }
   return launch_check(ctx, "gt_table");
 }
 keaki_status gt_encap_exp_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t wb_a, const void* d_tab_b, uint32_t wb_b, const void* d_betas,
                               const void* d_rs, size_t n, void* d_gt) {
-  hipLaunchKernelGGL(k_gt_encap_exp, dim3(cdiv(2 * n, 64)), dim3(64), 0, ctx->stream, (const Fq*)d_tab_a, gt_shape(wb_a), (const Fq*)d_tab_b, gt_shape(wb_b),
-                     (const Fr*)d_betas, (const Fr*)d_rs, (u32)n, (u32*)d_gt);
+  const size_t wide_max = ctx->tune.pair_wide_max < 0 ? GT_EXP_WIDE_AUTO : (size_t)ctx->tune.pair_wide_max;
+  if (n <= wide_max)
+    hipLaunchKernelGGL(pw::k_gt_encap_exp_wide, dim3(cdiv(n, 4)), dim3(64), 0, ctx->stream, (const Fq*)d_tab_a, gt_shape(wb_a), (const Fq*)d_tab_b,
+                       gt_shape(wb_b), (const Fr*)d_betas, (const Fr*)d_rs, (u32)n, (u32*)d_gt);
+  else
+    hipLaunchKernelGGL(k_gt_encap_exp, dim3(cdiv(2 * n, 64)), dim3(64), 0, ctx->stream, (const Fq*)d_tab_a, gt_shape(wb_a), (const Fq*)d_tab_b, gt_shape(wb_b),
+                       (const Fr*)d_betas, (const Fr*)d_rs, (u32)n, (u32*)d_gt);
   return launch_check(ctx, "gt_encap_exp");
 }
 keaki_status miller_only_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, size_t n, void* d_out) {

@@ -353,3 +353,74 @@ static __global__ void __launch_bounds__(64) k_pairing_wide(PairArgs a) {
 
 }  // namespace pw
 }  // namespace bn254
+
+// ---- the GT side of a SMALL encapsulation batch and of a table's first levels in the twelve-lane form ------------------------------------
+// (k_gt_encap_exp / k_gt_table_fill of pairing.hip.h, same tables -- 12 Fq per element, slot 2m + parity -- same digits, same products: an item's
+// ~30 Fq12 products run 1,800 instructions each instead of ~8,000, which is what a single `encapsulate` call and the first, latency-bound fill
+// levels of a new commitment's table wait for.)
+namespace bn254 {
+namespace pw {
+
+static KTOWER Fq w_gt_table_exp(Fq acc, const Fq* __restrict__ tab, GtShape g, const u32 (&kx)[8], uint4* ex, u32* kw) {
+  const u32 par = lane_odd(), k = my_pair(), m = (k & 1u) * 3u + (k >> 1);
+#pragma unroll
+  for (int w = 0; w < 8; w++) kw[w * 64 + threadIdx.x] = kx[w];          // a window's bits are read from LDS: the word index is a run-time value
+  auto word = [&](u32 w) -> u32 { return w < 8u ? kw[w * 64u + threadIdx.x] : 0u; };
+  u32 carry_d = 0;
+  const u32 half = 1u << (g.wb - 1);
+#pragma unroll 1
+  for (u32 j = 0; j < g.windows; j++) {
+    const u32 off = j * g.wb, w = off >> 5, sh = off & 31u;
+    u32 d = (__builtin_amdgcn_alignbit(word(w + 1), word(w), sh) & (2u * half - 1u)) + carry_d;
+    const bool neg = d > half;
+    carry_d = neg ? 1u : 0u;
+    if (neg) d = 2u * half - d;
+    Fq b = w12_one();                                                     // a zero digit multiplies by one: the rows of a wave hold different digits
+    if (d) b = tab[((size_t)j * g.entries + d) * 12 + 2 * m + par];
+    if (neg) b = w12_conj(b);                                             // unitary: the inverse is the conjugate
+    acc = w12_mul(acc, b, ex);
+  }
+  return acc;
+}
+static __global__ void __launch_bounds__(64) k_gt_encap_exp_wide(const Fq* __restrict__ tab_a, GtShape ga, const Fq* __restrict__ tab_b, GtShape gb,
+                                                                const Fr* __restrict__ betas, const Fr* __restrict__ rs, u32 n, u32* __restrict__ gt_out) {
+  __shared__ uint4 ex[EX_UINT4];
+  __shared__ u32 kw[8 * 64];
+  const u32 item = blockIdx.x * 4u + (threadIdx.x >> 4);
+  const bool live = item < n;
+  const u32 i = live ? item : (n - 1);
+  Fq acc = w12_one();
+  {
+    u32 u[8];
+    fp_from_mont<FrParams>(u, rs[i]);
+    acc = w_gt_table_exp(acc, tab_a, ga, u, ex, kw);
+  }
+  {
+    u32 v[8];
+    fp_from_mont<FrParams>(v, fp_neg<FrParams>(fp_mul<FrParams>(rs[i], betas[i])));
+    acc = w_gt_table_exp(acc, tab_b, gb, v, ex, kw);
+  }
+  if (!live || !real_lane()) return;
+  const u32 k = my_pair(), m = (k & 1u) * 3u + (k >> 1);
+  u32 w[8];
+  canon_words(w, acc);
+  u32* o = gt_out + (size_t)96 * item + 8 * (2 * m + lane_odd());
+#pragma unroll
+  for (int j = 0; j < 8; j++) o[j] = w[j];
+}
+// table[j][2^L + x] = table[j][2^L] * table[j][x], 1 <= x < 2^L: one row per entry
+static __global__ void __launch_bounds__(64) k_gt_table_fill_wide(Fq* __restrict__ table, u32 L, GtShape g) {
+  __shared__ uint4 ex[EX_UINT4];
+  const u32 e = blockIdx.x * 4u + (threadIdx.x >> 4);
+  const u32 per = (1u << L) - 1u;
+  const bool live = e < g.windows * per;
+  const u32 pi = live ? e : 0u;
+  const u32 j = pi / per, x = 1u + pi % per;
+  const u32 k = my_pair(), m = (k & 1u) * 3u + (k >> 1), c = 2 * m + lane_odd();
+  const Fq a = table[((size_t)j * g.entries + (1u << L)) * 12 + c], b = table[((size_t)j * g.entries + x) * 12 + c];
+  const Fq r = w12_mul(a, b, ex);
+  if (live && real_lane()) table[((size_t)j * g.entries + (1u << L) + x) * 12 + c] = r;
+}
+
+}  // namespace pw
+}  // namespace bn254

@@ -999,7 +999,19 @@ def test_both_pairing_kernels_at_small_and_ragged_sizes(oc, py, rand_fr, wide_ma
         exp = oc.pairing_batch(P, Q, threads=os.cpu_count() or 1)
         for m in (1, 2, 3, 4, 5, 63, 64, 65, 131):
             assert np.array_equal(h.pairing_batch(P[:m], Q[:m]), exp[:m]), m
-        # the fixed second slot (tabulated lines of g2: the encapsulation side) and the verify composite
+        # the fixed second slot (tabulated lines of g2: the encapsulation side)
         assert np.array_equal(h.pairing_batch(P[:9], g2), oc.pairing_batch(P[:9], g2, threads=8))
+        # encapsulation: the automatic policy takes the GT fixed-base path for every batch (the exponentiations and the first fill levels of a
+        # table in either form); option encap_gt keeps the per-item pairing path alive below its threshold: both, small and ragged
+        tau_g2 = h.g2_mul_batch(g2, mont(oc, rand_fr(1, 133)))[0]
+        for gt_opt in (-1, 1 << 30):
+            h.set_option("encap_gt", gt_opt)
+            for it, m in enumerate((1, 5, 67, 300)):
+                com = h.g1_mul_batch(g1, mont(oc, rand_fr(1, 140 + it)))[0]
+                A, V, Rr = (mont(oc, rand_fr(m, 150 + 3 * it + t)) for t in range(3))
+                ect, egt, ekey = oc.encap_batch(com, tau_g2, A, V, Rr, 32, threads=os.cpu_count() or 1)
+                for rep in range(2):                      # new commitment, then the same one again (its table is there / widened)
+                    ct, gt, key = h.encap_batch(com, tau_g2, A, V, Rr, 32)
+                    assert np.array_equal(ct, ect) and np.array_equal(gt, egt) and np.array_equal(key, ekey), (gt_opt, m, rep)
     finally:
         h.close()
