@@ -26,6 +26,7 @@ namespace keaki_internal {
 struct Tuning {
   int msm_c = 0;                 // KEAKI_MSM_C / "msm_c": window bits of the generic MSM, 0 = choose_window
   int msm_c_shared = 0;          // KEAKI_MSM_C_SHARED / "msm_c_shared": window target of the SRS window tables, 0 = choose_window_shared
+  int msm_short_tables = -1;     // KEAKI_MSM_SHORT_TABLES / "msm_short_tables": an MSM over less than half of an SRS with window tables uses them (1, and automatic = -1) or the generic path (0)
   int reduce_l = 0;              // KEAKI_REDUCE_L / "reduce_l": chunk length of the bucket reduction, 0 = automatic
   int part_shift = -1;           // KEAKI_PART_SHIFT / "part_shift": log2 of the bucket sort's bin count, -1 = automatic
   bool acc_u29 = true;           // KEAKI_ACC_U29 / "acc_u29": G1 bucket kernel in the 29-bit lazy limbs (A/B switch for profiling)

@@ -32,7 +32,11 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   if (!d_out_jac || (n && (!d_points || !d_scalars))) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: null pointer");
   if (n > srs_len) return fail(ctx, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", n, srs_len);
   if (n >= (1ull << 31)) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: n must be < 2^31 per device");
-  const bool shared = d_table != nullptr && n * 2 > srs_len;   // short polynomials: the generic path with its own window size is faster
+  // An SRS with window tables uses them for EVERY length. Until round 4 a polynomial shorter than half of the SRS took the generic path ("its own
+  // window size is faster"): true for the additions, but the generic tail is a chain of ~250 doublings and W additions in one lane -- 1.8-2.3 ms
+  // whatever n is, against 0.4-0.7 ms for the one shared window (bench_tools/ab_short_msm.py: SRS 2^10 ... 2^24, n = 1 ... srs/2: the tables win
+  // every cell, 3-5 x at the lengths of BASELINE config 1). Option msm_short_tables = 0 brings the old rule back (A/B, tests).
+  const bool shared = d_table != nullptr && (n * 2 > srs_len || ctx->tune.msm_short_tables != 0);
   const MsmPlan plan = shared ? msm_make_plan(n, c_table) : msm_make_plan(n, choose_window(n, ctx->tune.msm_c));
   MsmShape s = plan.s;
   // reduction shape: generic = the plan itself; shared = ONE window holding max_b = 2^cr buckets (top-window rule: 2^width buckets)
