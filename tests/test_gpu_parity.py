@@ -320,7 +320,14 @@ def test_msm_precomputed_tables(oc, hip, rand_fr, N):
         assert np.array_equal(jac_to_aff(hip.msm_g1(srs, sc)), plain)
         z = hip.msm_g1(srs, np.zeros((N, 4), np.uint64))
         assert not np.any(jac_to_aff(z))
+        # lengths below half of the SRS use the tables too since round 4 (one shared window: no 250-doubling tail); the old rule behind the option
+        hip.set_option("msm_short_tables", 0)
+        for n in (N // 2, 7, 1):
+            assert np.array_equal(jac_to_aff(hip.msm_g1(srs, sc[:n])), oc.msm_g1(pts[:n], sc[:n], threads=8)), n
+        hip.set_option("msm_short_tables", -1)
+        assert np.array_equal(jac_to_aff(hip.msm_g1(srs, sc[:1])), oc.msm_g1(pts[:1], sc[:1], threads=1))
     finally:
+        hip.set_option("msm_short_tables", -1)
         srs.free()
 
 
