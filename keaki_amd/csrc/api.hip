@@ -327,8 +327,8 @@ std::vector<BufClass> all_bufs(keaki_hip_ctx* ctx) {
                     &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->io_a, &ctx->io_b, &ctx->io_c, &ctx->io_d, &ctx->io_e, &ctx->perm, &ctx->heavy,
                     &ctx->pair_ws, &ctx->verify_lines, &ctx->verify_io, &ctx->g2gen_lines, &ctx->fk_tab, &ctx->g2pow_lines, &ctx->g2pow_pts})
     v.push_back({b, 1});
-  for (DevBuf* b : {&ctx->fb_scalars, &ctx->fb_g1_gen, &ctx->fb_g2_gen, &ctx->fb_com, &ctx->fb_tau, &ctx->gt_tab_a, &ctx->gt_tab_b, &ctx->gt_base,
-                    &ctx->fbs_scalars, &ctx->fbs_g2_gen, &ctx->fbs_tau})
+  for (DevBuf* b : {&ctx->fb_bases, &ctx->fb_g1_gen, &ctx->fb_g2_gen, &ctx->fb_com, &ctx->fb_tau, &ctx->gt_tab_a, &ctx->gt_tab_b, &ctx->gt_base,
+                    &ctx->fbs_g2_gen, &ctx->fbs_tau})
     v.push_back({b, 2});
   return v;
 }
@@ -733,19 +733,17 @@ struct StreamSwap {
 };
 // signed-window table of e(P, g2) for a G1 point P in device memory: the powers of two e(P, g2)^(2^s) = e(P, 2^s g2) come from ONE pairing
 // launch of P against the tabulated line sequences of the multiples 2^s g2 (the latency of one pairing; the tables -- 320 x 18 KB -- are built
-// once per context: 2^s as scalars, one batched G2 multiplication, one k_g2_prepare workgroup per multiple). Until round 4 the chain ran on the
+// once per context: lane s doubles g2 s times, one k_g2_prepare workgroup per multiple). Until round 4 the chain ran on the
 // G1 side (2^s P by 260 doublings one after the other: 1.4 ms with the device idle, in every call with a new commitment).
 constexpr uint32_t GT_POWERS_MAX = 320;
 static keaki_status g2pow_tables(keaki_hip_ctx* ctx) {
   if (ctx->g2pow_ready) return KEAKI_OK;
   ST_TRY(reserve(ctx, ctx->g2pow_lines, (size_t)GT_POWERS_MAX * g2_prepared_bytes()));
-  ST_TRY(reserve(ctx, ctx->g2pow_pts, (size_t)GT_POWERS_MAX * (32 + G2_AFF_BYTES) + G2_AFF_BYTES));
-  char* sc = (char*)ctx->g2pow_pts.p;
-  char* gen = sc + (size_t)GT_POWERS_MAX * 32;
+  ST_TRY(reserve(ctx, ctx->g2pow_pts, (size_t)(GT_POWERS_MAX + 1) * G2_AFF_BYTES));
+  char* gen = (char*)ctx->g2pow_pts.p;
   char* pts = gen + G2_AFF_BYTES;
-  ST_TRY(pow2_scalars_run(ctx, sc, GT_POWERS_MAX));
   ST_TRY(g2_generator_to(ctx, gen));
-  ST_TRY(keaki_hip_g2_mul_batch_dev(ctx, gen, 0, sc, GT_POWERS_MAX, pts));
+  ST_TRY(g2_pow2_multiples_run(ctx, gen, GT_POWERS_MAX, pts));
   ST_TRY(g2_prepare_run(ctx, pts, ctx->g2pow_lines.p, GT_POWERS_MAX));
   ctx->g2pow_ready = true;
   return KEAKI_OK;
@@ -784,17 +782,14 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
   const size_t FBL = fb_table_entries(FB_WB_LONG), FBS = fb_table_entries(FB_WB_BATCH);
   const bool use_tables = n_policy >= 256;
   if (use_tables && !ctx->fb_ready) {
-    ST_TRY(reserve(ctx, ctx->fb_scalars, (FBL + FBS) * 32));                        // [16-bit scalars | 13-bit scalars]
     ST_TRY(reserve(ctx, ctx->fb_g1_gen, FBL * G1_AFF_BYTES + G1_AFF_BYTES));
     ST_TRY(reserve(ctx, ctx->fb_g2_gen, FBL * G2_AFF_BYTES));
     ST_TRY(reserve(ctx, ctx->fb_com, FBS * G1_AFF_BYTES));
     ST_TRY(reserve(ctx, ctx->fb_tau, FBL * G2_AFF_BYTES));
-    ST_TRY(fb_table_scalars_run(ctx, ctx->fb_scalars.p, FB_WB_LONG));
-    ST_TRY(fb_table_scalars_run(ctx, (char*)ctx->fb_scalars.p + FBL * 32, FB_WB_BATCH));
     void* g1pt = (char*)ctx->fb_g1_gen.p + FBL * G1_AFF_BYTES;   // scratch slot behind the table
     ST_TRY(g1_generator_to(ctx, g1pt));
-    ST_TRY(g1_fb_table_run(ctx, g1pt, ctx->fb_scalars.p, ctx->fb_g1_gen.p, FB_WB_LONG));
-    ST_TRY(g2_fb_table_run(ctx, ctx->tmp_c.p, ctx->fb_scalars.p, ctx->fb_g2_gen.p, FB_WB_LONG));
+    ST_TRY(g1_fb_table_run(ctx, g1pt, ctx->fb_g1_gen.p, FB_WB_LONG));
+    ST_TRY(g2_fb_table_run(ctx, ctx->tmp_c.p, ctx->fb_g2_gen.p, FB_WB_LONG));
     ctx->fb_ready = true;
   }
   // the second pairing slot is the constant generator g2: its line sequence (ark-ec's G2Prepared) is built once per context
@@ -894,7 +889,7 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
     if (use_tables || big_has_tau) {
       if (!big_has_tau) {
         ctx->fb_tau_valid = false;
-        ST_TRY(g2_fb_table_run(ctx, d_tau_g2_aff, ctx->fb_scalars.p, ctx->fb_tau.p, FB_WB_LONG));
+        ST_TRY(g2_fb_table_run(ctx, d_tau_g2_aff, ctx->fb_tau.p, FB_WB_LONG));
         memcpy(ctx->fb_tau_pt, tau_host, 128);
         ctx->fb_tau_valid = true;
       }
@@ -903,17 +898,15 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
       constexpr uint32_t FB_WB_SMALL = 8;
       const size_t FBX = fb_table_entries(FB_WB_SMALL);
       if (!ctx->fbs_ready) {
-        ST_TRY(reserve(ctx, ctx->fbs_scalars, FBX * 32));
         ST_TRY(reserve(ctx, ctx->fbs_g2_gen, FBX * G2_AFF_BYTES));
         ST_TRY(reserve(ctx, ctx->fbs_tau, FBX * G2_AFF_BYTES));
-        ST_TRY(fb_table_scalars_run(ctx, ctx->fbs_scalars.p, FB_WB_SMALL));
-        ST_TRY(g2_fb_table_run(ctx, ctx->tmp_c.p, ctx->fbs_scalars.p, ctx->fbs_g2_gen.p, FB_WB_SMALL));
+        ST_TRY(g2_fb_table_run(ctx, ctx->tmp_c.p, ctx->fbs_g2_gen.p, FB_WB_SMALL));
         ctx->fbs_ready = true;
         ctx->fbs_tau_valid = false;
       }
       if (!ctx->fbs_tau_valid || memcmp(tau_host, ctx->fbs_tau_pt, 128) != 0) {
         ctx->fbs_tau_valid = false;
-        ST_TRY(g2_fb_table_run(ctx, d_tau_g2_aff, ctx->fbs_scalars.p, ctx->fbs_tau.p, FB_WB_SMALL));
+        ST_TRY(g2_fb_table_run(ctx, d_tau_g2_aff, ctx->fbs_tau.p, FB_WB_SMALL));
         memcpy(ctx->fbs_tau_pt, tau_host, 128);
         ctx->fbs_tau_valid = true;
       }
@@ -927,7 +920,7 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
   } else {
     // per-item pairing e(r_i (C - beta_i g1), g2) with the tabulated lines of g2
     if (use_tables) {
-      ST_TRY(g1_fb_table_run(ctx, d_com_aff, (char*)ctx->fb_scalars.p + FBL * 32, ctx->fb_com.p, FB_WB_BATCH));
+      ST_TRY(g1_fb_table_run(ctx, d_com_aff, ctx->fb_com.p, FB_WB_BATCH));
       ST_TRY(encap_g1_fixed_run(ctx, ctx->fb_com.p, FB_WB_BATCH, ctx->fb_g1_gen.p, FB_WB_LONG, d_values, d_r, n, ctx->tmp_a.p));
     } else {
       ST_TRY(encap_g1_run(ctx, d_com_aff, d_values, d_r, n, ctx->tmp_a.p));

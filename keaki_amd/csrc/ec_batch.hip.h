@@ -90,7 +90,7 @@ static __global__ void __launch_bounds__(64) k_verify_combine(const G1Aff* __res
 //     r (C - beta g1)       = r C + (-(r beta)) g1          (src/kem.rs:22,30)
 //     r ([tau]_2 - alpha g2) = r [tau]_2 + (-(r alpha)) g2   (src/kem.rs:36-37)
 // are sums of two FIXED-base multiples: with signed 13-bit window tables T[j][d] = d 2^(13j) B, d = 1..4096 (20 x 4097
-// affine entries per base, built by k_mul_batch; negative digits negate y) each costs at most 20 mixed additions and
+// affine entries per base, built by k_fb_window_bases + k_fb_table_entries: a ladder over the bits of d; negative digits negate y) each costs at most 20 mixed additions and
 // no doublings, instead of a 254-step double-and-add ladder per scalar-mult.
 // ------------------------------------------------------------------------------------------------
 // window width per table: 16 bits (16 windows x 32768 entries) for bases that outlive a batch (the generators: per context; [tau]_2: per
@@ -98,38 +98,32 @@ static __global__ void __launch_bounds__(64) k_verify_combine(const G1Aff* __res
 struct FbShape { u32 wb, windows, entries; };
 __host__ __device__ inline FbShape fb_shape(u32 wb) { return {wb, (254u + wb - 1u) / wb + ((254u % wb) == 0u ? 1u : 0u), (1u << (wb - 1)) + 1u}; }
 
-// scalars[j * entries + d] = Montgomery(d * 2^(wb j) mod r)
-static __global__ void __launch_bounds__(256) k_fb_table_scalars(Fr* __restrict__ out, FbShape g) {
-  u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+// Table build: T[j][d] = d * base_j with base_j = 2^(wb j) * base. Two launches: the window bases (lane j doubles wb * j times: the longest lane
+// is the only chain there is), then one lane per entry with a ladder over the BITS OF d -- at most wb - 1 doublings and additions. (Until round 4
+// an entry was a full 254-bit scalar multiplication by d 2^(wb j) mod r: 20 ms for a 16-bit G2 table, 2 x that in the first call of a context.)
+template <class F>
+__global__ void __launch_bounds__(64) k_fb_window_bases(const Aff<F>* __restrict__ base, FbShape g, Aff<F>* __restrict__ out) {
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= g.windows) return;
+  Jac<F> a = jac_from_aff(*base);
+  for (u32 t = 0; t < g.wb * j; t++) a = jac_dbl(a);
+  out[j] = jac_to_aff(a);
+}
+template <class F>
+__global__ void __launch_bounds__(64) k_fb_table_entries(const Aff<F>* __restrict__ bases, FbShape g, Aff<F>* __restrict__ table) {
+  const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= g.windows * g.entries) return;
-  u32 j = idx / g.entries, d = idx % g.entries;
-  u32 v[8];
-#pragma unroll
-  for (int t = 0; t < 8; t++) v[t] = 0;
-  const u32 bit = g.wb * j, word = bit >> 5;
-  const u64 sh = (u64)d << (bit & 31);               // at most 16 + 31 bits: two words
-#pragma unroll
-  for (int t = 0; t < 8; t++) {
-    if (word == (u32)t) v[t] = (u32)sh;
-    if (word + 1 == (u32)t) v[t] = (u32)(sh >> 32);
-  }
-  if (word == 7 && (sh >> 32) != 0) {                // beyond 256 bits: never indexed (the top digit is small)
-#pragma unroll
-    for (int t = 0; t < 8; t++) v[t] = 0;
-  }
-  // reduce mod r: with signed digits the top term d 2^(wb (windows-1)) alone may exceed r although the whole sum is below it
-  for (int rounds = 0; rounds < 6; rounds++) {
-    bool ge = true;
-#pragma unroll
-    for (int t = 7; t >= 0; t--) {
-      if (v[t] != FrParams::MOD[t]) { ge = v[t] > FrParams::MOD[t]; break; }
+  const u32 j = idx / g.entries, d = idx % g.entries;
+  const Aff<F> p = bases[j];
+  Jac<F> acc = jac_inf<F>();
+  if (d && !aff_is_inf(p)) {
+#pragma unroll 1
+    for (int b = 31 - __clz((int)d); b >= 0; b--) {
+      acc = jac_dbl(acc);
+      if ((d >> b) & 1u) acc = jac_add_mixed(acc, p);
     }
-    if (!ge) break;
-    u64 b = 0;
-#pragma unroll
-    for (int t = 0; t < 8; t++) { u64 dd = (u64)v[t] - FrParams::MOD[t] - b; v[t] = (u32)dd; b = (dd >> 32) & 1u; }
   }
-  out[idx] = fp_to_mont<FrParams>(v);
+  table[idx] = jac_to_aff(acc);                      // d = 0: the identity (the slot is never indexed)
 }
 
 // acc += sign_j * T[j][|digit_j(k)|] for all windows, signed wb-bit digits in (-2^(wb-1), 2^(wb-1)]; k canonical (consumed)

@@ -18,20 +18,17 @@ keaki_status verify_combine_run(keaki_hip_ctx* ctx, const void* d_com, const voi
                      (const Fr*)d_point, (G1Aff*)d_out2);
   return launch_check(ctx, "verify_combine");
 }
-keaki_status fb_table_scalars_run(keaki_hip_ctx* ctx, void* d_scalars, uint32_t wb) {
-  const FbShape g = fb_shape(wb);
-  hipLaunchKernelGGL(k_fb_table_scalars, dim3(cdiv(g.windows * g.entries, 256)), dim3(256), 0, ctx->stream, (Fr*)d_scalars, g);
-  return launch_check(ctx, "fb_table_scalars");
-}
 keaki_status g1_generator_to(keaki_hip_ctx* ctx, void* d_dst) {
   HIP_TRY(ctx, hipMemcpyFromSymbolAsync(d_dst, HIP_SYMBOL(G1_GEN_X), sizeof(Fq), 0, hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyFromSymbolAsync((char*)d_dst + sizeof(Fq), HIP_SYMBOL(G1_GEN_Y), sizeof(Fq), 0, hipMemcpyDeviceToDevice, ctx->stream));
   return KEAKI_OK;
 }
 // table[j * entries + d] = d 2^(wb j) * base
-keaki_status g1_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void* d_table_scalars, void* d_table, uint32_t wb) {
-  const u32 cnt = (u32)fb_table_entries(wb);
-  hipLaunchKernelGGL((k_mul_batch<Fq>), dim3(cdiv(cnt, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)d_base, 0, (const Fr*)d_table_scalars, cnt,
+keaki_status g1_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, void* d_table, uint32_t wb) {
+  const FbShape g = fb_shape(wb);
+  ST_TRY(reserve(ctx, ctx->fb_bases, 64 * sizeof(G2Aff)));
+  hipLaunchKernelGGL((k_fb_window_bases<Fq>), dim3(1), dim3(64), 0, ctx->stream, (const G1Aff*)d_base, g, (G1Aff*)ctx->fb_bases.p);
+  hipLaunchKernelGGL((k_fb_table_entries<Fq>), dim3(cdiv((size_t)g.windows * g.entries, 64)), dim3(64), 0, ctx->stream, (const G1Aff*)ctx->fb_bases.p, g,
                      (G1Aff*)d_table);
   return launch_check(ctx, "g1_fb_table");
 }

@@ -16,11 +16,18 @@ keaki_status g2_generator_to(keaki_hip_ctx* ctx, void* d_dst) {
   return KEAKI_OK;
 }
 // table[j*256+d] = d 2^(8j) * base   (8192 affine entries)
-keaki_status g2_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void* d_table_scalars, void* d_table, uint32_t wb) {
-  const u32 cnt = (u32)fb_table_entries(wb);
-  hipLaunchKernelGGL((k_mul_batch<Fq2>), dim3(cdiv(cnt, 64)), dim3(64), 0, ctx->stream, (const G2Aff*)d_base, 0, (const Fr*)d_table_scalars, cnt,
+keaki_status g2_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, void* d_table, uint32_t wb) {
+  const FbShape g = fb_shape(wb);
+  ST_TRY(reserve(ctx, ctx->fb_bases, 64 * sizeof(G2Aff)));
+  hipLaunchKernelGGL((k_fb_window_bases<Fq2>), dim3(1), dim3(64), 0, ctx->stream, (const G2Aff*)d_base, g, (G2Aff*)ctx->fb_bases.p);
+  hipLaunchKernelGGL((k_fb_table_entries<Fq2>), dim3(cdiv((size_t)g.windows * g.entries, 64)), dim3(64), 0, ctx->stream, (const G2Aff*)ctx->fb_bases.p, g,
                      (G2Aff*)d_table);
   return launch_check(ctx, "g2_fb_table");
+}
+keaki_status g2_pow2_multiples_run(keaki_hip_ctx* ctx, const void* d_base, uint32_t count, void* d_out) {
+  const FbShape g = {1u, count, 0u};                 // "windows" of one bit: base_s = 2^s base
+  hipLaunchKernelGGL((k_fb_window_bases<Fq2>), dim3(cdiv(count, 64)), dim3(64), 0, ctx->stream, (const G2Aff*)d_base, g, (G2Aff*)d_out);
+  return launch_check(ctx, "g2_pow2_multiples");
 }
 keaki_status encap_g2_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t wb_a, const void* d_tab_b, uint32_t wb_b, const void* d_xs,
                                 const void* d_rs, size_t n, void* d_out) {

@@ -58,7 +58,7 @@ struct keaki_hip_ctx {
   // grow-only workspaces (all used in stream order)
   keaki_internal::DevBuf digits, hist, offsets, cursor, sorted, buckets, partials, wsums, bsums, tmp_a, tmp_b, tmp_c, io_a, io_b, io_c, io_d, io_e;
   // fixed-base window tables for encapsulate: generator tables are built once per context, the C / [tau]_2 tables per batch
-  keaki_internal::DevBuf fb_scalars, fb_g1_gen, fb_g2_gen, fb_com, fb_tau, perm, g2gen_lines, gt_tab_a, gt_tab_b, gt_base, heavy;
+  keaki_internal::DevBuf fb_bases, fb_g1_gen, fb_g2_gen, fb_com, fb_tau, perm, g2gen_lines, gt_tab_a, gt_tab_b, gt_base, heavy;
   bool gt_b_ready = false;
   bool gt_a_valid = false;
   bool gt_b_fallback = false;             // the wide table of B did not fit once: stay at 16 bits
@@ -80,7 +80,7 @@ struct keaki_hip_ctx {
   uint64_t gt_a_com[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // commitment the cached A-table belongs to
   bool g2gen_lines_ready = false;
   bool fb_ready = false;
-  keaki_internal::DevBuf fbs_scalars, fbs_g2_gen, fbs_tau;     // small (8-bit) tables of g2 and [tau]_2 for batches below 256 items
+  keaki_internal::DevBuf fbs_g2_gen, fbs_tau;     // small (8-bit) tables of g2 and [tau]_2 for batches below 256 items
   bool fbs_ready = false, fbs_tau_valid = false;
   uint64_t fbs_tau_pt[16] = {};
   // instrumentation
@@ -163,7 +163,6 @@ keaki_status verify_combine_run(keaki_hip_ctx* ctx, const void* d_com, const voi
 size_t g2_prepared_bytes();
 // out[i] = e(P_(i * p_stride), Q_i) as 12 Fq in the 2^261 form, Q_i given by its line table d_lines + i * lines_stride lines
 keaki_status pairing_raw_fixed_run(keaki_hip_ctx* ctx, const void* d_g1, uint32_t p_stride, size_t n, const void* d_lines, uint32_t lines_stride, void* d_out);
-keaki_status pow2_scalars_run(keaki_hip_ctx* ctx, void* d_scalars, uint32_t count);          // 2^s as Montgomery Fr, s < count
 size_t gt_table_bytes(uint32_t wb);
 uint32_t gt_table_powers(uint32_t wb);      // powers of two a table needs: wb * windows
 keaki_status gt_table_run(keaki_hip_ctx* ctx, const void* d_pows, void* d_table, uint32_t wb);   // d_pows: base^(2^s), 12 Fq each
@@ -177,9 +176,9 @@ keaki_status blake3_gt_run(keaki_hip_ctx* ctx, const void* d_gt, size_t n, void*
 keaki_status g2_generator_to(keaki_hip_ctx* ctx, void* d_dst);  // writes the affine G2 generator (128 B)
 keaki_status g1_generator_to(keaki_hip_ctx* ctx, void* d_dst);  // affine G1 generator (64 B)
 size_t fb_table_entries(uint32_t wb);                                                          // window-table entries per base at window width wb
-keaki_status fb_table_scalars_run(keaki_hip_ctx* ctx, void* d_scalars, uint32_t wb);          // d * 2^(wb j) mod r
-keaki_status g1_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void* d_table_scalars, void* d_table, uint32_t wb);
-keaki_status g2_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, const void* d_table_scalars, void* d_table, uint32_t wb);
+keaki_status g1_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, void* d_table, uint32_t wb);    // table[j * entries + d] = d 2^(wb j) base
+keaki_status g2_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, void* d_table, uint32_t wb);
+keaki_status g2_pow2_multiples_run(keaki_hip_ctx* ctx, const void* d_base, uint32_t count, void* d_out);   // out[s] = 2^s base (affine), lane s doubles s times
 keaki_status encap_g1_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t wb_a, const void* d_tab_b, uint32_t wb_b, const void* d_xs, const void* d_rs, size_t n, void* d_out);
 keaki_status encap_g2_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t wb_a, const void* d_tab_b, uint32_t wb_b, const void* d_xs, const void* d_rs, size_t n, void* d_out);
 keaki_status g1_curve_check_run(keaki_hip_ctx* ctx, const void* d_pts, size_t n, void* d_bad2);   // d_bad2: u64 count, u64 first index

@@ -58,10 +58,6 @@ keaki_status g2_prepare_run(keaki_hip_ctx* ctx, const void* d_q, void* d_lines, 
   hipLaunchKernelGGL(k_g2_prepare, dim3(n_points), dim3(64), 0, ctx->stream, (const G2Aff*)d_q, (Line*)d_lines, g2_prepared_lines());
   return launch_check(ctx, "g2_prepare");
 }
-keaki_status pow2_scalars_run(keaki_hip_ctx* ctx, void* d_scalars, uint32_t count) {
-  hipLaunchKernelGGL(k_pow2_scalars, dim3(1), dim3(64), 0, ctx->stream, (Fr*)d_scalars, count);
-  return launch_check(ctx, "pow2_scalars");
-}
 // test hook: the table in the 2^256 Montgomery form of the ABI (the kernels keep it in the 2^261 form)
 keaki_status lines_to256_run(keaki_hip_ctx* ctx, const void* d_lines261, void* d_lines256) {
   const u32 count = (u32)(g2_prepared_bytes() / sizeof(Fq));

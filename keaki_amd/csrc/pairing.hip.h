@@ -291,14 +291,6 @@ static __global__ void __launch_bounds__(64) k_g2_prepare(const G2Aff* __restric
   Fq2d qx = {to261(qxw[lane_odd()])}, qy = {to261(qyw[lane_odd()])};
   miller_lines(&qx, &qy, lines_out);
 }
-// out[s] = 2^s (Montgomery Fr), s < count: doubling is an addition in any Montgomery radix
-static __global__ void __launch_bounds__(64) k_pow2_scalars(Fr* __restrict__ out, u32 count) {
-  if (blockIdx.x || threadIdx.x) return;
-  Fr acc;
-#pragma unroll
-  for (int j = 0; j < 8; j++) acc.l[j] = FrParams::ONE[j];
-  for (u32 s = 0; s < count; s++) { out[s] = acc; acc = fp_add<FrParams>(acc, acc); }
-}
 // test hook: a line table in the 2^256 form (what the oracle tabulates)
 static __global__ void __launch_bounds__(64) k_lines_to256(const Fq* __restrict__ in, Fq* __restrict__ out, u32 count) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
