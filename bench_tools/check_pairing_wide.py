@@ -16,9 +16,20 @@ P = h.g1_mul_batch(g1, random_fr_limbs(N, 11)); Q = h.g2_mul_batch(g2, random_fr
 P[3] = 0; Q[5] = 0                                   # identities in either slot
 for n in (1, 2, 3, 4, 5, 63, 64, 65, 257, 1000):
     h.set_option("pair_wide_max", 0); a = h.pairing_batch(P[:n], Q[:n])
-    h.set_option("pair_wide_max", 1 << 20); b = h.pairing_batch(P[:n], Q[:n])
-    print("n=%5d wide == lane-pair: %s" % (n, np.array_equal(a, b)), flush=True)
-    assert np.array_equal(a, b)
+    h.set_option("pair_wide_max", 1 << 20); h.set_option("pair_two_waves", 0); b = h.pairing_batch(P[:n], Q[:n])
+    h.set_option("pair_two_waves", 1); c = h.pairing_batch(P[:n], Q[:n])
+    print("n=%5d wide == lane-pair: %s, two waves == lane-pair: %s" % (n, np.array_equal(a, b), np.array_equal(a, c)), flush=True)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+for n in (1, 64, 512, 1024):
+    out = []
+    for tw in (0, 1):
+        h.set_option("pair_two_waves", tw)
+        h.pairing_batch(P[:n], Q[:n])
+        t = []
+        for rep in range(4):
+            t0 = time.perf_counter(); h.pairing_batch(P[:n], Q[:n]); t.append(time.perf_counter() - t0)
+        out.append(min(t) * 1e3)
+    print("n=%5d  wide, one wave %.2f ms   two waves %.2f ms" % (n, out[0], out[1]), flush=True)
 for n in (1, 4, 64, 256, 1024, 2048, 4096, 8192, 16384):
     out = []
     for wide in (0, 1 << 20):

@@ -317,6 +317,7 @@ void tune_from_env(Tuning& t) {
   if (geti("KEAKI_FB_OCC1", v)) t.fb_occ1 = v != 0;
   if (geti("KEAKI_MSM_SHORT_TABLES", v)) t.msm_short_tables = (int)v;
   if (geti("KEAKI_PAIR_WIDE_MAX", v)) t.pair_wide_max = (int)v;
+  if (geti("KEAKI_PAIR_TWO_WAVES", v)) t.pair_two_waves = v != 0;
   if (geti("KEAKI_GT_WB_B", v)) t.gt_wb_b = (int)v;
   if (geti("KEAKI_ENCAP_GT", v)) t.encap_gt = v;
 }
@@ -417,6 +418,7 @@ keaki_status keaki_hip_ctx_set_option(keaki_hip_ctx* ctx, const char* name, int6
   else if (k == "fb_occ1") t.fb_occ1 = value != 0;
   else if (k == "msm_short_tables") t.msm_short_tables = (int)value;
   else if (k == "pair_wide_max") t.pair_wide_max = (int)value;
+  else if (k == "pair_two_waves") t.pair_two_waves = value != 0;
   else if (k == "gt_wb_b") {
     if (value != 0 && (value < 8 || value > 22 || gt_table_powers((uint32_t)value) > 320)) return fail(ctx, KEAKI_ERR_BAD_ARG, "ctx_set_option: gt_wb_b = %lld out of range", (long long)value);
     if ((int)value != t.gt_wb_b) { ctx->gt_b_ready = false; ctx->gt_b_fallback = false; }      // the table of B is rebuilt at the new width on the next use

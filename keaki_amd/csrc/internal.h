@@ -38,6 +38,7 @@ struct Tuning {
   bool fk_addsub29 = true;      // KEAKI_FK_ADDSUB29 / "fk_addsub29": the butterflies' add + subtract in the lazy limbs, shared products once (A/B switch)
   bool fb_occ1 = false;          // KEAKI_FB_OCC1 / "fb_occ1": one wave per SIMD for the G2 fixed-base kernel at any batch size
   int pair_wide_max = -1;        // KEAKI_PAIR_WIDE_MAX / "pair_wide_max": pairing batches up to this size run the twelve-lanes-per-pairing kernel; -1 = automatic, 0 = never
+  bool pair_two_waves = true;    // KEAKI_PAIR_TWO_WAVES / "pair_two_waves": up to 1,024 pairings with lines on the fly run the line functions on a second wave (A/B switch)
   int gt_wb_b = 0;               // KEAKI_GT_WB_B / "gt_wb_b": window bits of the table of e(g1, g2), 0 = automatic (20 / 16)
   long long encap_gt = -1;       // KEAKI_ENCAP_GT / "encap_gt": batch size from which encap takes the GT fixed-base path; -1 = automatic (always, since round 4)
   size_t alloc_limit = 0;        // keaki_hip_debug_set_alloc_limit: single allocations above it fail with KEAKI_ERR_OOM; 0 = none

@@ -9,6 +9,7 @@ using namespace bn254;
 // (3.75 KB per item; 2^17 items = 480 MB, grow-only in the context).
 constexpr size_t PAIR_CHUNK = (size_t)1 << 17;
 constexpr size_t PAIR_WIDE_AUTO = 4096;
+constexpr size_t PAIR_WIDE2_AUTO = 1024;       // 72 KB of LDS per two-wave workgroup: two per CU
 constexpr size_t GT_EXP_WIDE_AUTO = 2048;      // items of an encapsulation batch whose GT exponentiations run twelve lanes per item
 static keaki_status pairing_launch(keaki_hip_ctx* ctx, u32 mode, const void* d_g1, const void* d_g2, int g2_stride, const void* d_f_in, size_t n,
                                    void* d_out, size_t out_item_bytes, const void* d_fixed_lines, uint32_t lines_stride, const char* what,
@@ -22,7 +23,11 @@ static keaki_status pairing_launch(keaki_hip_ctx* ctx, u32 mode, const void* d_g
     a.ps = (const G1Aff*)d_g1; a.p_stride = p_stride; a.qs = (const G2Aff*)d_g2; a.q_stride = g2_stride; a.n = (u32)n;
     a.fixed_lines = (const Line*)d_fixed_lines; a.lines_stride = lines_stride; a.f_in = (const Fq*)d_f_in;
     a.ws = nullptr; a.ws_n = 0; a.out = d_out; a.mode = mode;
-    hipLaunchKernelGGL(pw::k_pairing_wide, dim3(cdiv(n, 4)), dim3(64), 0, ctx->stream, a);
+    // lines on the fly and few enough pairings that a second wave per workgroup finds room: the line functions on a wave of their own
+    if ((mode & PAIR_MILLER) && !d_fixed_lines && n <= PAIR_WIDE2_AUTO && ctx->tune.pair_two_waves)
+      hipLaunchKernelGGL(pw::k_pairing_wide2, dim3(cdiv(n, 4)), dim3(128), 0, ctx->stream, a);
+    else
+      hipLaunchKernelGGL(pw::k_pairing_wide, dim3(cdiv(n, 4)), dim3(64), 0, ctx->stream, a);
     return launch_check(ctx, what);
   }
   const size_t ch = n < PAIR_CHUNK ? n : PAIR_CHUNK;

@@ -27,20 +27,26 @@ namespace pw {
 using namespace p261;
 
 // ---- geometry ---------------------------------------------------------------------------------------------------------------------
+KDEV u32 wlane() { return threadIdx.x & 63u; }                      // lane inside the wave (k_pairing_wide2 runs two waves per workgroup)
 KDEV u32 row_base() { return threadIdx.x & 48u; }
 KDEV u32 my_pair() { const u32 p = (threadIdx.x & 15u) >> 1; return p >= 6u ? p - 6u : p; }       // lanes 12..15: shadows of pairs 0, 1
 KDEV bool real_lane() { return (threadIdx.x & 15u) < 12u; }
 KDEV u32 lane_of(u32 pair, u32 parity) { return row_base() + 2u * pair + parity; }
-// one wave per workgroup: the barrier costs nothing and orders the exchange area for the compiler and the LDS queue
-KDEV void wsync() { __syncthreads(); }
+// The exchange area belongs to ONE wave: its LDS operations execute in program order, so all that is needed between a publish and the fetches
+// of other lanes (and between those fetches and the next publish) is that the COMPILER keeps that order -- a wavefront-scope fence and a
+// scheduling barrier, no s_barrier (k_pairing_wide2 has two waves per workgroup that run different code between their common barriers).
+KDEV void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 
 // ---- exchange area: vector v (nine limbs in three 16-byte chunks) of lane l at ex[(v * 3 + c) * 64 + l] ---------------------------------
 constexpr int EX_VECS = 5;                       // limbs of a | y0, y1 of b | y0, y1 of xi b
 constexpr int EX_UINT4 = EX_VECS * 3 * 64;
 KDEV void publish9(uint4* ex, int v, const U29& x) {
-  ex[(v * 3 + 0) * 64 + threadIdx.x] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
-  ex[(v * 3 + 1) * 64 + threadIdx.x] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
-  ex[(v * 3 + 2) * 64 + threadIdx.x] = make_uint4(x.l[8], 0u, 0u, 0u);
+  ex[(v * 3 + 0) * 64 + wlane()] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+  ex[(v * 3 + 1) * 64 + wlane()] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+  ex[(v * 3 + 2) * 64 + wlane()] = make_uint4(x.l[8], 0u, 0u, 0u);
 }
 KDEV U29 fetch9(const uint4* ex, u32 v, u32 lane) {
   const uint4 a = ex[(v * 3u + 0u) * 64u + lane], b = ex[(v * 3u + 1u) * 64u + lane], c = ex[(v * 3u + 2u) * 64u + lane];
@@ -51,8 +57,8 @@ KDEV U29 fetch9(const uint4* ex, u32 v, u32 lane) {
 // the same area seen as Fq words: value i of lane l in chunks 2i, 2i + 1
 KDEV void publish_fq(uint4* ex, int i, const Fq& v) {
   const uint4* w = reinterpret_cast<const uint4*>(v.l);
-  ex[(2 * i) * 64 + threadIdx.x] = w[0];
-  ex[(2 * i + 1) * 64 + threadIdx.x] = w[1];
+  ex[(2 * i) * 64 + wlane()] = w[0];
+  ex[(2 * i + 1) * 64 + wlane()] = w[1];
 }
 KDEV Fq fetch_fq(const uint4* ex, u32 i, u32 lane) {
   Fq r;
@@ -130,7 +136,7 @@ static KNOINLINE Fq w12_mul_034(const Fq a, U29 c0, U29 d0, const U29 d1, uint4*
 //   out0 = 3 t_e(a0,a3) - 2 a0    out3 = 3 t_o(a0,a3) + 2 a3    out2 = 3 t_e(a1,a4) - 2 a2    out5 = 3 t_o(a1,a4) + 2 a5
 //   out4 = 3 t_e(a2,a5) - 2 a4    out1 = 3 xi t_o(a2,a5) + 2 a1
 // One stream per pair: the even pairs need t_e (three Fq products per lane: the square x^2 costs a lane one, (xi y) y two), the odd pairs t_o
-// (two), so everybody runs the three-product stream and the odd pairs feed a zero into the first product. Bounds: 6 + 33 | 2 + 4.
+// (two), so everybody runs the three-product stream and the odd pairs feed a zero into the first product. Bounds: 6 + 33 | 2 + 4 (pair 1: 22 + 44).
 static KNOINLINE Fq w12_cyc_sqr(const Fq a, uint4* ex) {
   const u32 q = lane_odd(), k = my_pair();
   const bool odd = q != 0, even_k = (k & 1u) == 0u;
@@ -142,24 +148,25 @@ static KNOINLINE Fq w12_cyc_sqr(const Fq a, uint4* ex) {
   const U29 ysl = fetch9(ex, 0, lane_of(xs + 3u, q)), yol = fetch9(ex, 0, lane_of(xs + 3u, q ^ 1u));
   const YF yy = y_of(ysl, Q29::K2);
   const XF xxy = x_of(xi_limbs(ysl, yol, Q29::K2));
+  // pair 1 needs xi t_o = 2 (xi x) y: xi goes onto x (limbs doubled: < 2^30, the wide side of a product; bound 22 + 44)
+  const XF xix = x_of(xi_limbs(xsl, xol, Q29::K2));
+  const bool k1 = k == 1u;
   U29 p0a, sy, p1a, p2a;
 #pragma unroll
   for (int i = 0; i < 9; i++) {
     const u32 sx = odd ? xol.l[i] : xsl.l[i] + xol.l[i];                              // limbs < 2^30: one side of a product may be that wide
     sy.l[i] = odd ? 2u * xsl.l[i] : xsl.l[i] - xol.l[i] + Q29::K2[i];
     p0a.l[i] = even_k ? sx : 0u;
-    p1a.l[i] = even_k ? xxy.s.l[i] : 2u * xsl.l[i];
-    p2a.l[i] = even_k ? xxy.o.l[i] : 2u * xol.l[i];
+    p1a.l[i] = even_k ? xxy.s.l[i] : 2u * (k1 ? xix.s.l[i] : xsl.l[i]);
+    p2a.l[i] = even_k ? xxy.o.l[i] : 2u * (k1 ? xix.o.l[i] : xol.l[i]);
   }
   sy = carry(sy);
   U29 r;
   u29_dot3_asm(r.l, p0a.l, sy.l, p1a.l, yy.y0.l, p2a.l, yy.y1.l);
-  Fq2d t = {pack(r)};
-  const Fq2d xt = fq2_mul_xi(t);
-  t.v = fq_select(k == 1u, xt.v, t.v);
-  const Fq2d own = {a};
-  const Fq2d d = {fq_select(even_k, (t - own).v, (t + own).v)};
-  return (fq2_dbl(d) + t).v;
+  const Fq2d t = {pack(r)};
+  // 3 t - 2 a (even pairs) | 3 t + 2 a (odd pairs)
+  const Fq2d own = {fp_cneg<FqParams>(a, even_k)};
+  return (fq2_dbl(t + own) + t).v;
 }
 
 // ---- Frobenius maps, conjugation ---------------------------------------------------------------------------------------------------
@@ -291,13 +298,13 @@ static KTOWER Fq w_final_exp(Fq acc, uint4* ex, uint4* slots) {
   for (int pc = 0; pc < FE_NOPS; pc++) {
     const u32 op = FE_PROG[pc], code = op & 15u, s = op >> 4;
     if (code == 0) {
-      acc = fetch_fq(slots, s, threadIdx.x);
+      acc = fetch_fq(slots, s, wlane());
     } else if (code == 1) {
       publish_fq(slots, (int)s, acc);
     } else if (code == 2) {
       acc = w12_cyc_sqr(acc, ex);
     } else if (code == 3 || code == 4) {
-      Fq b = fetch_fq(slots, s, threadIdx.x);
+      Fq b = fetch_fq(slots, s, wlane());
       if (code == 4) b = w12_conj(b);
       acc = w12_mul(acc, b, ex);
     } else if (code == 5) {
@@ -309,6 +316,82 @@ static KTOWER Fq w_final_exp(Fq acc, uint4* ex, uint4* slots) {
     }
   }
   return acc;
+}
+
+// ---- lines on the fly, TWO waves per workgroup: wave 1 runs the line functions one step AHEAD, wave 0 the f-updates ---------------------------
+// The line of step li + 1 (the rounds of w_line_double / w_line_add and the two products by P's coordinates) does not depend on f: with the running
+// point T in a wave of its own the Miller loop's critical path is the f-chain alone -- 64 x (product + line product) + 24 line products instead of
+// that PLUS 64 doubling and 24 addition steps of T. The line travels through a double-buffered mailbox in LDS (c0, d0, d1 as limbs of the lane's
+// parity; lane l of wave 0 reads what lane l of wave 1 wrote); one workgroup barrier per step.
+constexpr int MB_UINT4 = 2 * 3 * 3 * 64;
+KDEV void mailbox_put(uint4* mb, int buf, const U29& c0, const U29& d0, const U29& d1) {
+  publish9(mb + buf * (3 * 3 * 64), 0, c0); publish9(mb + buf * (3 * 3 * 64), 1, d0); publish9(mb + buf * (3 * 3 * 64), 2, d1);
+}
+static __global__ void __launch_bounds__(128) k_pairing_wide2(PairArgs a) {
+  __shared__ uint4 ex[2 * EX_UINT4];
+  __shared__ uint4 slots[FE_NSLOTS * 2 * 64];
+  __shared__ uint4 mb[MB_UINT4];
+  const u32 wave = threadIdx.x >> 6;
+  uint4* myex = ex + wave * EX_UINT4;
+  const u32 item = blockIdx.x * 4u + (wlane() >> 4);
+  const bool live = item < a.n;
+  const u32 i = live ? item : (a.n - 1);
+  const u32 par = lane_odd(), k = my_pair();
+  const u32 m = (k & 1u) * 3u + (k >> 1);
+  const G1Aff p = a.ps[(size_t)i * a.p_stride];
+  const Fq* qw = reinterpret_cast<const Fq*>(a.qs + (size_t)i * a.q_stride);
+  u32 qz = (fq_is_zero(qw[par]) && fq_is_zero(qw[2 + par])) ? 1u : 0u;
+  qz &= (u32)__builtin_amdgcn_update_dpp(0, (int)qz, 0xB1, 0xF, 0xF, true);
+  const bool ident = aff_is_inf(p) || qz != 0;
+  Fq f = w12_one();
+  if (wave == 1) {
+    // the line wave
+    const U29 pxl = cut(to261(p.x)), pyl = cut(to261(p.y));
+    G2Hom r;
+    r.x.v = to261(qw[par]); r.y.v = to261(qw[2 + par]); r.z = fq2d_one();
+#pragma unroll 1
+    for (int li = 0; li < MILLER_NSTEPS; li++) {
+      const int st = MILLER_STEPS[li];
+      Line l;
+      if (st <= 1) {
+        w_line_double(&r, &l, myex);
+      } else {
+        Fq2d ax = {to261(qw[par])}, ay = {to261(qw[2 + par])};
+        if (st == 3) ay = fq2_neg(ay);
+        if (st >= 4) {
+          ax = M2(fq2_conj(ax), fq2d_load(&p261::TWIST_MUL_BY_Q_X)); ay = M2(fq2_conj(ay), fq2d_load(&p261::TWIST_MUL_BY_Q_Y));
+          if (st == 5) { ax = M2(fq2_conj(ax), fq2d_load(&p261::TWIST_MUL_BY_Q_X)); ay = fq2_neg(M2(fq2_conj(ay), fq2d_load(&p261::TWIST_MUL_BY_Q_Y))); }
+        }
+        w_line_add(&r, ax, ay, &l, myex);
+      }
+      const U29 c0 = u29_mul(cut(l.c0.v), pyl), d0 = u29_mul(cut(l.c1.v), pxl);
+      mailbox_put(mb, li & 1, c0, d0, cut(l.c2.v));
+      __syncthreads();                                   // line li is there; wave 0 is done with the buffer of line li - 1
+    }
+    return;
+  }
+  // the f wave
+#pragma unroll 1
+  for (int li = 0; li < MILLER_NSTEPS; li++) {
+    if (MILLER_STEPS[li] == 1) f = w12_mul(f, f, myex);    // overlaps the line wave's work on line li
+    __syncthreads();
+    const uint4* box = mb + (li & 1) * (3 * 3 * 64);
+    const U29 c0 = fetch9(box, 0, wlane()), d0 = fetch9(box, 1, wlane()), d1 = fetch9(box, 2, wlane());
+    f = w12_mul_034(f, c0, d0, d1, myex);
+  }
+  if (a.mode & PAIR_FINAL_EXP) f = w_final_exp(f, myex, slots);
+  if (ident) f = w12_one();
+  if (!live || !real_lane()) return;
+  if (a.mode & PAIR_OUT_BYTES) {
+    u32 w[8];
+    canon_words(w, f);
+    u32* o = (u32*)a.out + (size_t)96 * item + 8 * (2 * m + par);
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = w[j];
+  } else {
+    Fq* o = (Fq*)a.out + (size_t)12 * item;
+    o[2 * m + par] = (a.mode & PAIR_OUT_RAW256) ? to256(f) : f;
+  }
 }
 
 // Same arguments and modes as k_pairing (PairArgs; `ws` is not used: the slots live in LDS). Sixteen lanes per item, four items per wave.
@@ -364,8 +447,8 @@ namespace pw {
 static KTOWER Fq w_gt_table_exp(Fq acc, const Fq* __restrict__ tab, GtShape g, const u32 (&kx)[8], uint4* ex, u32* kw) {
   const u32 par = lane_odd(), k = my_pair(), m = (k & 1u) * 3u + (k >> 1);
 #pragma unroll
-  for (int w = 0; w < 8; w++) kw[w * 64 + threadIdx.x] = kx[w];          // a window's bits are read from LDS: the word index is a run-time value
-  auto word = [&](u32 w) -> u32 { return w < 8u ? kw[w * 64u + threadIdx.x] : 0u; };
+  for (int w = 0; w < 8; w++) kw[w * 64 + wlane()] = kx[w];          // a window's bits are read from LDS: the word index is a run-time value
+  auto word = [&](u32 w) -> u32 { return w < 8u ? kw[w * 64u + wlane()] : 0u; };
   u32 carry_d = 0;
   const u32 half = 1u << (g.wb - 1);
 #pragma unroll 1

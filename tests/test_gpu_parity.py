@@ -1004,8 +1004,11 @@ def test_both_pairing_kernels_at_small_and_ragged_sizes(oc, py, rand_fr, wide_ma
         Q = h.g2_mul_batch(g2, mont(oc, rand_fr(n, 132)))
         P[7] = 0; Q[64] = 0; Q[130] = 0
         exp = oc.pairing_batch(P, Q, threads=os.cpu_count() or 1)
-        for m in (1, 2, 3, 4, 5, 63, 64, 65, 131):
-            assert np.array_equal(h.pairing_batch(P[:m], Q[:m]), exp[:m]), m
+        for two_waves in (1, 0):          # lines on the fly: the line functions on a second wave of the workgroup (pw::k_pairing_wide2), or not
+            h.set_option("pair_two_waves", two_waves)
+            for m in (1, 2, 3, 4, 5, 63, 64, 65, 131):
+                assert np.array_equal(h.pairing_batch(P[:m], Q[:m]), exp[:m]), (two_waves, m)
+        h.set_option("pair_two_waves", 1)
         # the fixed second slot (tabulated lines of g2: the encapsulation side)
         assert np.array_equal(h.pairing_batch(P[:9], g2), oc.pairing_batch(P[:9], g2, threads=8))
         # encapsulation: the automatic policy takes the GT fixed-base path for every batch (the exponentiations and the first fill levels of a
