@@ -23,9 +23,12 @@ static keaki_status pairing_launch(keaki_hip_ctx* ctx, u32 mode, const void* d_g
     a.ps = (const G1Aff*)d_g1; a.p_stride = p_stride; a.qs = (const G2Aff*)d_g2; a.q_stride = g2_stride; a.n = (u32)n;
     a.fixed_lines = (const Line*)d_fixed_lines; a.lines_stride = lines_stride; a.f_in = (const Fq*)d_f_in;
     a.ws = nullptr; a.ws_n = 0; a.out = d_out; a.mode = mode;
-    // lines on the fly and few enough pairings that a second wave per workgroup finds room: the line functions on a wave of their own
+    // few enough pairings that a second wave per workgroup finds room: the line functions (or, with tabulated lines, the line's product forms)
+    // on a wave of their own
     if ((mode & PAIR_MILLER) && !d_fixed_lines && n <= PAIR_WIDE2_AUTO && ctx->tune.pair_two_waves)
-      hipLaunchKernelGGL(pw::k_pairing_wide2, dim3(cdiv(n, 4)), dim3(128), 0, ctx->stream, a);
+      hipLaunchKernelGGL(pw::k_pairing_wide2<false>, dim3(cdiv(n, 4)), dim3(128), 0, ctx->stream, a);
+    else if ((mode & PAIR_MILLER) && d_fixed_lines && n <= PAIR_WIDE2_AUTO && ctx->tune.pair_two_waves)
+      hipLaunchKernelGGL(pw::k_pairing_wide2<true>, dim3(cdiv(n, 4)), dim3(128), 0, ctx->stream, a);
     else
       hipLaunchKernelGGL(pw::k_pairing_wide, dim3(cdiv(n, 4)), dim3(64), 0, ctx->stream, a);
     return launch_check(ctx, what);

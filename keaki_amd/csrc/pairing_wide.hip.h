@@ -109,13 +109,21 @@ static KNOINLINE Fq w12_mul(const Fq a, const Fq b, uint4* ex) {
 // ---- the sparse line product: f *= c0 + (d0 + d1 v) w = c0 + d0 w + d1 w^3 --------------------------------------------------------------
 //   c_k = a_k c0 + a_(k-1) d0 + a_(k-3) d1, indices mod 6, xi on the line's side where they wrap (k = 0; k < 3)
 // The line's coefficients are known to every pair as LIMBS of this lane's component: c0, d0 exact and < 2p, d1 exact and < p.
-// Bounds as fq12_mul_by_034_limbs: c0, d0 terms 4, d1 3, xi d1 27, xi d0 54: at most 4 + 54 + 27 = 85.
-static KNOINLINE Fq w12_mul_034(const Fq a, U29 c0, U29 d0, const U29 d1, uint4* ex) {
+// The line's side of it, for THIS lane's pair: the product forms of c0, of d0 or xi d0 (k = 0 wraps), of d1 or xi d1 (k < 3 wraps). The choice is
+// made on the limbs, before the forms: bounds c0 4 | d0 with the xi-sized bias 2 + 32 = 34, xi d0 54 | d1 1 + 16 = 17, xi d1 27: at most 85.
+struct LineForms { YF c0, y1, y3; };
+KDEV LineForms line_forms(U29 c0, U29 d0, const U29& d1) {
   fence9(c0); fence9(d0);
+  const u32 k = my_pair();
+  const U29 xd0 = xi_limbs(d0, quad<0xB1>(d0), Q29::K4), xd1 = xi_limbs(d1, quad<0xB1>(d1), Q29::K2);
+  LineForms r;
+  r.c0 = y_of(c0, Q29::K2);
+  r.y1 = y_of(sel9(k >= 1u, d0, xd0), Q29::K32);
+  r.y3 = y_of(sel9(k >= 3u, d1, xd1), Q29::K16);
+  return r;
+}
+static KNOINLINE Fq w12_mul_forms(const Fq a, const LineForms lf, uint4* ex) {
   const u32 q = lane_odd(), k = my_pair();
-  const U29 d0o = quad<0xB1>(d0), d1o = quad<0xB1>(d1);
-  const YF yc0 = y_of(c0, Q29::K2), yd0 = y_of(d0, Q29::K2), yd1 = y_of(d1, Q29::K2);
-  const YF yxd0 = y_of(xi_limbs(d0, d0o, Q29::K4), Q29::K32), yxd1 = y_of(xi_limbs(d1, d1o, Q29::K2), Q29::K16);
   const U29 A = cut(a);
   wsync();
   publish9(ex, 0, A);
@@ -125,10 +133,10 @@ static KNOINLINE Fq w12_mul_034(const Fq a, U29 c0, U29 d0, const U29 d1, uint4*
   XF x1, x3;
   x1.s = fetch9(ex, 0, lane_of(i1, q)); x1.o = fetch9(ex, 0, lane_of(i1, q ^ 1u));
   x3.s = fetch9(ex, 0, lane_of(i3, q)); x3.o = fetch9(ex, 0, lane_of(i3, q ^ 1u));
-  YF y1, y3;
-  y1.y0 = sel9(k >= 1u, yd0.y0, yxd0.y0); y1.y1 = sel9(k >= 1u, yd0.y1, yxd0.y1);
-  y3.y0 = sel9(k >= 3u, yd1.y0, yxd1.y0); y3.y1 = sel9(k >= 3u, yd1.y1, yxd1.y1);
-  return pack(dot3(x0, yc0, x1, y1, x3, y3));
+  return pack(dot3(x0, lf.c0, x1, lf.y1, x3, lf.y3));
+}
+static KNOINLINE Fq w12_mul_034(const Fq a, U29 c0, U29 d0, const U29 d1, uint4* ex) {
+  return w12_mul_forms(a, line_forms(c0, d0, d1), ex);
 }
 
 // ---- Granger-Scott squaring on the cyclotomic subgroup: one Fq4 squaring per pair ---------------------------------------------------------
@@ -323,14 +331,16 @@ static KTOWER Fq w_final_exp(Fq acc, uint4* ex, uint4* slots) {
 // point T in a wave of its own the Miller loop's critical path is the f-chain alone -- 64 x (product + line product) + 24 line products instead of
 // that PLUS 64 doubling and 24 addition steps of T. The line travels through a double-buffered mailbox in LDS (c0, d0, d1 as limbs of the lane's
 // parity; lane l of wave 0 reads what lane l of wave 1 wrote); one workgroup barrier per step.
-constexpr int MB_UINT4 = 2 * 3 * 3 * 64;
-KDEV void mailbox_put(uint4* mb, int buf, const U29& c0, const U29& d0, const U29& d1) {
-  publish9(mb + buf * (3 * 3 * 64), 0, c0); publish9(mb + buf * (3 * 3 * 64), 1, d0); publish9(mb + buf * (3 * 3 * 64), 2, d1);
-}
+// With TABULATED lines (FIXED: the second slot is g2, [tau]_2 or a multiple 2^s g2) the second wave has no T to walk: it loads the line, multiplies
+// it by P's coordinates and prepares its product forms for every lane's pair -- the mailbox then carries the six form vectors and the f wave's line
+// product is publish, fetch, one stream.
+constexpr int MB_VECS_LIMBS = 3, MB_VECS_FORMS = 6;
+template <bool FIXED>
 static __global__ void __launch_bounds__(128) k_pairing_wide2(PairArgs a) {
+  constexpr int MBV = FIXED ? MB_VECS_FORMS : MB_VECS_LIMBS;
   __shared__ uint4 ex[2 * EX_UINT4];
   __shared__ uint4 slots[FE_NSLOTS * 2 * 64];
-  __shared__ uint4 mb[MB_UINT4];
+  __shared__ uint4 mb[2 * MBV * 3 * 64];
   const u32 wave = threadIdx.x >> 6;
   uint4* myex = ex + wave * EX_UINT4;
   const u32 item = blockIdx.x * 4u + (wlane() >> 4);
@@ -339,21 +349,28 @@ static __global__ void __launch_bounds__(128) k_pairing_wide2(PairArgs a) {
   const u32 par = lane_odd(), k = my_pair();
   const u32 m = (k & 1u) * 3u + (k >> 1);
   const G1Aff p = a.ps[(size_t)i * a.p_stride];
-  const Fq* qw = reinterpret_cast<const Fq*>(a.qs + (size_t)i * a.q_stride);
-  u32 qz = (fq_is_zero(qw[par]) && fq_is_zero(qw[2 + par])) ? 1u : 0u;
-  qz &= (u32)__builtin_amdgcn_update_dpp(0, (int)qz, 0xB1, 0xF, 0xF, true);
+  const Fq* qw = nullptr;
+  u32 qz = 0;
+  if constexpr (!FIXED) {
+    qw = reinterpret_cast<const Fq*>(a.qs + (size_t)i * a.q_stride);
+    qz = (fq_is_zero(qw[par]) && fq_is_zero(qw[2 + par])) ? 1u : 0u;
+    qz &= (u32)__builtin_amdgcn_update_dpp(0, (int)qz, 0xB1, 0xF, 0xF, true);
+  }
   const bool ident = aff_is_inf(p) || qz != 0;
   Fq f = w12_one();
   if (wave == 1) {
     // the line wave
     const U29 pxl = cut(to261(p.x)), pyl = cut(to261(p.y));
+    const Line* lines = FIXED ? a.fixed_lines + (size_t)i * a.lines_stride : nullptr;
     G2Hom r;
-    r.x.v = to261(qw[par]); r.y.v = to261(qw[2 + par]); r.z = fq2d_one();
+    if constexpr (!FIXED) { r.x.v = to261(qw[par]); r.y.v = to261(qw[2 + par]); r.z = fq2d_one(); }
 #pragma unroll 1
     for (int li = 0; li < MILLER_NSTEPS; li++) {
       const int st = MILLER_STEPS[li];
       Line l;
-      if (st <= 1) {
+      if constexpr (FIXED) {
+        l = lines[li * 2 + par];
+      } else if (st <= 1) {
         w_line_double(&r, &l, myex);
       } else {
         Fq2d ax = {to261(qw[par])}, ay = {to261(qw[2 + par])};
@@ -364,8 +381,15 @@ static __global__ void __launch_bounds__(128) k_pairing_wide2(PairArgs a) {
         }
         w_line_add(&r, ax, ay, &l, myex);
       }
-      const U29 c0 = u29_mul(cut(l.c0.v), pyl), d0 = u29_mul(cut(l.c1.v), pxl);
-      mailbox_put(mb, li & 1, c0, d0, cut(l.c2.v));
+      const U29 c0 = u29_mul(cut(l.c0.v), pyl), d0 = u29_mul(cut(l.c1.v), pxl), d1 = cut(l.c2.v);
+      uint4* box = mb + (li & 1) * (MBV * 3 * 64);
+      if constexpr (FIXED) {
+        const LineForms lf = line_forms(c0, d0, d1);
+        publish9(box, 0, lf.c0.y0); publish9(box, 1, lf.c0.y1); publish9(box, 2, lf.y1.y0); publish9(box, 3, lf.y1.y1);
+        publish9(box, 4, lf.y3.y0); publish9(box, 5, lf.y3.y1);
+      } else {
+        publish9(box, 0, c0); publish9(box, 1, d0); publish9(box, 2, d1);
+      }
       __syncthreads();                                   // line li is there; wave 0 is done with the buffer of line li - 1
     }
     return;
@@ -375,9 +399,16 @@ static __global__ void __launch_bounds__(128) k_pairing_wide2(PairArgs a) {
   for (int li = 0; li < MILLER_NSTEPS; li++) {
     if (MILLER_STEPS[li] == 1) f = w12_mul(f, f, myex);    // overlaps the line wave's work on line li
     __syncthreads();
-    const uint4* box = mb + (li & 1) * (3 * 3 * 64);
-    const U29 c0 = fetch9(box, 0, wlane()), d0 = fetch9(box, 1, wlane()), d1 = fetch9(box, 2, wlane());
-    f = w12_mul_034(f, c0, d0, d1, myex);
+    const uint4* box = mb + (li & 1) * (MBV * 3 * 64);
+    if constexpr (FIXED) {
+      LineForms lf;
+      lf.c0.y0 = fetch9(box, 0, wlane()); lf.c0.y1 = fetch9(box, 1, wlane()); lf.y1.y0 = fetch9(box, 2, wlane()); lf.y1.y1 = fetch9(box, 3, wlane());
+      lf.y3.y0 = fetch9(box, 4, wlane()); lf.y3.y1 = fetch9(box, 5, wlane());
+      f = w12_mul_forms(f, lf, myex);
+    } else {
+      const U29 c0 = fetch9(box, 0, wlane()), d0 = fetch9(box, 1, wlane()), d1 = fetch9(box, 2, wlane());
+      f = w12_mul_034(f, c0, d0, d1, myex);
+    }
   }
   if (a.mode & PAIR_FINAL_EXP) f = w_final_exp(f, myex, slots);
   if (ident) f = w12_one();
