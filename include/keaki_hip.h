@@ -37,7 +37,9 @@
  *    lazily built members; a handle from another device is refused with KEAKI_ERR_BAD_ARG). Handles must not
  *    be freed while another thread still uses them.
  *  - Memory: keaki_hip_ctx_memory reports what a ctx holds. Per ctx: MSM workspaces (2.4 GB at 2^24 points),
- *    pairing slots (0.48 GB), the GT tables of encapsulate (2.6 GB + 0.2 GB once a batch >= 2^16 ran). Per SRS
+ *    pairing slots (0.48 GB), the GT tables of encapsulate (0.2 + 0.2 GB from the first encapsulation on, 2.6 + 0.2 GB once a batch >= 2^16 ran;
+ *    6 MB of line tables of the multiples of g2). A ctx creates up to three non-blocking streams (its own unless one was passed in, one for
+ *    the copies of chunked host-array batches, one for the table of a new commitment). Per SRS
  *    handle (shared by every ctx of the device): points (64 B each) + window tables (W x 64 B each: 12.9 GB at
  *    2^24) + the FK23 transform (192 B per opening). All optional tables fall back when they do not fit.
  *  - Current device: every call makes its ctx's GPU the calling thread's current HIP device for the duration of the
@@ -92,9 +94,12 @@ const char* keaki_hip_version(void);
 /* keaki_hip_last_error: the returned string is a copy private to the calling thread (valid until its next call of this function). */
 /* Tuning / A-B switches of a context (profiling and tests; defaults are what ships). Initial values come from the environment variable
  * KEAKI_<NAME> at keaki_hip_ctx_create; afterwards only this call changes them. Names: "msm_c", "msm_c_shared" (window bits, 0 = automatic),
- * "reduce_l", "part_shift", "p1_sub", "p2_small", "acc_u29", "acc_u29_g2", "acc_nt", "fk_uniform", "fk_gtab", "fk_addsub29", "fk_radix4", "fb_occ1", "gt_wb_b" (window bits of the table of
+ * "reduce_l", "part_shift", "acc_u29", "acc_u29_g2", "acc_nt", "fk_uniform", "fk_gtab", "fk_addsub29", "fk_radix4", "fb_occ1", "gt_wb_b" (window bits of the table of
  * e(g1, g2), 0 = automatic; a change rebuilds the table on the next use), "encap_gt" (batch size from which encap_batch takes the GT
- * fixed-base path and below which it never does; -1 = the automatic policy). Unknown name -> KEAKI_ERR_BAD_ARG. */
+ * fixed-base path and below which -- for a commitment that has no table yet -- it runs a pairing per item; -1 = automatic: always the GT path),
+ * "pair_wide_max" (pairing batches up to this size run the twelve-lanes-per-pairing kernel; -1 = automatic (4096), 0 = never), "pair_two_waves"
+ * (up to 1,024 pairings: the line side of the Miller loop on a second wave; 0 = one wave), "msm_short_tables" (an MSM over less than half of an SRS
+ * with window tables: 0 = the generic path as before round 4, 1 / -1 = the tables). Unknown name -> KEAKI_ERR_BAD_ARG. */
 keaki_status keaki_hip_ctx_set_option(keaki_hip_ctx* ctx, const char* name, int64_t value);
 /* Test hook: every single device allocation of this ctx above `bytes` fails with KEAKI_ERR_OOM (0 = no limit). This is how the tests
  * exercise the optional-memory fallbacks (SRS window tables, the wide GT table); nothing in the library sets it. */
