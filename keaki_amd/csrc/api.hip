@@ -917,8 +917,16 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
   }
   if (prep) return KEAKI_OK;
   if (use_gt) {
-    if (a_on_aux) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_ev[1], 0));
-    ST_TRY(gt_encap_exp_run(ctx, ctx->gt_tab_a.p, ctx->gt_a_wb, ctx->gt_tab_b.p, ctx->gt_b_wb, d_values, d_r, n, gt));
+    if (a_on_aux && n > 4096) {
+      // the factor of the constant base while the commitment's table is still on its way, the commitment's factor behind it
+      ST_TRY(reserve(ctx, ctx->tmp_a, n * 384));
+      ST_TRY(gt_encap_exp_run(ctx, nullptr, 0, ctx->gt_tab_b.p, ctx->gt_b_wb, d_values, d_r, n, nullptr, nullptr, ctx->tmp_a.p));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_ev[1], 0));
+      ST_TRY(gt_encap_exp_run(ctx, ctx->gt_tab_a.p, ctx->gt_a_wb, nullptr, 0, d_values, d_r, n, gt, ctx->tmp_a.p, nullptr));
+    } else {
+      if (a_on_aux) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_ev[1], 0));
+      ST_TRY(gt_encap_exp_run(ctx, ctx->gt_tab_a.p, ctx->gt_a_wb, ctx->gt_tab_b.p, ctx->gt_b_wb, d_values, d_r, n, gt));
+    }
   } else {
     // per-item pairing e(r_i (C - beta_i g1), g2) with the tabulated lines of g2
     if (use_tables) {

@@ -167,8 +167,9 @@ keaki_status pairing_raw_fixed_run(keaki_hip_ctx* ctx, const void* d_g1, uint32_
 size_t gt_table_bytes(uint32_t wb);
 uint32_t gt_table_powers(uint32_t wb);      // powers of two a table needs: wb * windows
 keaki_status gt_table_run(keaki_hip_ctx* ctx, const void* d_pows, void* d_table, uint32_t wb);   // d_pows: base^(2^s), 12 Fq each
+// gt[i] = serialize(acc_in[i] (or one) * A^(r_i) (tab_a given) * B^(-beta_i r_i) (tab_b given)); acc_out given: the product stays raw (12 Fq per item)
 keaki_status gt_encap_exp_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t wb_a, const void* d_tab_b, uint32_t wb_b, const void* d_betas,
-                              const void* d_rs, size_t n, void* d_gt);
+                              const void* d_rs, size_t n, void* d_gt, const void* d_acc_in = nullptr, void* d_acc_out = nullptr);
 keaki_status miller_only_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, size_t n, void* d_out);
 keaki_status final_exp_only_run(keaki_hip_ctx* ctx, const void* d_in, size_t n, void* d_gt);
 keaki_status g2_prepare_run(keaki_hip_ctx* ctx, const void* d_q, void* d_lines, uint32_t n_points = 1);   // line sequence of a fixed Q (2^261 form: internal)

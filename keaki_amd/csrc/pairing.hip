@@ -94,14 +94,15 @@ keaki_status gt_table_run(keaki_hip_ctx* ctx, const void* d_pows, void* d_table,
   return launch_check(ctx, "gt_table");
 }
 keaki_status gt_encap_exp_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t wb_a, const void* d_tab_b, uint32_t wb_b, const void* d_betas,
-                              const void* d_rs, size_t n, void* d_gt) {
+                              const void* d_rs, size_t n, void* d_gt, const void* d_acc_in, void* d_acc_out) {
   const size_t wide_max = ctx->tune.pair_wide_max < 0 ? GT_EXP_WIDE_AUTO : (size_t)ctx->tune.pair_wide_max;
-  if (n <= wide_max)
-    hipLaunchKernelGGL(pw::k_gt_encap_exp_wide, dim3(cdiv(n, 4)), dim3(64), 0, ctx->stream, (const Fq*)d_tab_a, gt_shape(wb_a), (const Fq*)d_tab_b,
-                       gt_shape(wb_b), (const Fr*)d_betas, (const Fr*)d_rs, (u32)n, (u32*)d_gt);
-  else
-    hipLaunchKernelGGL(k_gt_encap_exp, dim3(cdiv(2 * n, 64)), dim3(64), 0, ctx->stream, (const Fq*)d_tab_a, gt_shape(wb_a), (const Fq*)d_tab_b, gt_shape(wb_b),
+  const GtShape ga = d_tab_a ? gt_shape(wb_a) : GtShape{0, 0, 0}, gb = d_tab_b ? gt_shape(wb_b) : GtShape{0, 0, 0};
+  if (n <= wide_max && d_tab_a && d_tab_b && !d_acc_in && !d_acc_out)
+    hipLaunchKernelGGL(pw::k_gt_encap_exp_wide, dim3(cdiv(n, 4)), dim3(64), 0, ctx->stream, (const Fq*)d_tab_a, ga, (const Fq*)d_tab_b, gb,
                        (const Fr*)d_betas, (const Fr*)d_rs, (u32)n, (u32*)d_gt);
+  else
+    hipLaunchKernelGGL(k_gt_encap_exp, dim3(cdiv(2 * n, 64)), dim3(64), 0, ctx->stream, (const Fq*)d_tab_a, ga, (const Fq*)d_tab_b, gb,
+                       (const Fr*)d_betas, (const Fr*)d_rs, (u32)n, (u32*)d_gt, (const Fq*)d_acc_in, (Fq*)d_acc_out);
   return launch_check(ctx, "gt_encap_exp");
 }
 keaki_status miller_only_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, size_t n, void* d_out) {

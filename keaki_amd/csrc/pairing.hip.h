@@ -381,27 +381,34 @@ static KTOWER void gt_table_exp(Fq12* acc, const Fq* __restrict__ tab, GtShape g
   }
 }
 // gt_out[i] = serialize(A^(r_i) * B^(-(r_i * beta_i)))   (tables of A and B). Two lanes per item.
+// The two factors are independent, and only A's table belongs to the commitment: a batch to a NEW commitment runs the B factor first (tab_a null,
+// acc_out = 12 Fq per item in the lane-pair order) while A's table is still being built on the side stream, and the A factor behind it (tab_b null,
+// acc_in = what the first launch left). Both tables given: one launch, nothing parked.
 static __global__ void __launch_bounds__(64, 2) k_gt_encap_exp(const Fq* __restrict__ tab_a, GtShape ga, const Fq* __restrict__ tab_b, GtShape gb,
-                                                              const Fr* __restrict__ betas, const Fr* __restrict__ rs, u32 n, u32* __restrict__ gt_out) {
+                                                              const Fr* __restrict__ betas, const Fr* __restrict__ rs, u32 n, u32* __restrict__ gt_out,
+                                                              const Fq* __restrict__ acc_in, Fq* __restrict__ acc_out) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 item = t >> 1;
   const bool live = item < n;
   const u32 i = live ? item : (n - 1);
   __shared__ uint4 park[PARK_CHUNKS * 64];
   Fq12 acc;
-  fq12_set_one(&acc);
-  {
+  if (acc_in) gt_load(&acc, acc_in + (size_t)12 * i);
+  else fq12_set_one(&acc);
+  if (tab_a) {
     u32 u[8];
     fp_from_mont<FrParams>(u, rs[i]);
     gt_table_exp(&acc, tab_a, ga, u, park);
   }
   asm volatile("" ::: "memory");          // the second exponent is formed here, not carried across the first exponentiation
-  {
+  if (tab_b) {
     u32 v[8];
     fp_from_mont<FrParams>(v, fp_neg<FrParams>(fp_mul<FrParams>(rs[i], betas[i])));
     gt_table_exp(&acc, tab_b, gb, v, park);
   }
-  if (live) gt_serialize(gt_out + (size_t)96 * i, &acc, park);
+  if (!live) return;
+  if (acc_out) gt_store(acc_out + (size_t)12 * i, &acc);
+  else gt_serialize(gt_out + (size_t)96 * i, &acc, park);
 }
 
 // ---- BLAKE3 XOF of a 384-byte GT encoding (single chunk, 6 blocks): replaces src/kem.rs:42-46,65-69 ----
