@@ -394,8 +394,9 @@ def main():
                                       "decaps_per_s. encaps_per_s is the rate of ONE batch to a commitment seen for the first time (its table of e(C, g2): one "
                                       "pairing launch + fills, then two fixed-base GT exponentiations per item); encaps_same_commitment_per_s is the steady "
                                       "state of a caller that keeps encrypting to one commitment (vec_encrypt / Laconic OT): no pairing per item at all",
-               "note": "whole-job aggregate over all ranks; items sharded by rank, no collective. encaps: batches >= 2^16 use two fixed-base GT "
-                       "exponentiations per item (A = e(C, g2) tabulated once per commitment: rebuilt in every call in encaps_per_s, reused across "
+               "note": "whole-job aggregate over all ranks; items sharded by rank, no collective. encaps: every batch uses two fixed-base GT "
+                       "exponentiations per item (A = e(C, g2) tabulated once per commitment from ONE launch of the twelve-lane pairing kernel over the "
+                       "tabulated multiples of g2, on a side stream beside the ciphertext kernel: rebuilt in every call in encaps_per_s, reused across "
                        "calls in encaps_same_commitment_per_s) instead of a pairing; decaps: one full pairing per item.",
                "roofline_decap": {"bound": "hbm", "kernel": "k_pairing_batch (+ k_blake3_gt_xof)", "algorithmic_bytes": ALGO_BYTES_PER_PAIRING * m,
                                   "call_ms": dec_ms, "achieved": ALGO_BYTES_PER_PAIRING * m / (dec_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
