@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B on one box: the Laconic OT block of the bench line, round-3 library (ab_old/) against the tree, alternating.
+# A/B on one box: the Laconic OT block of the bench line, an earlier build (ab_old/: see bench_tools/README.md) against the tree, alternating.
 R=$PWD
 for side in old new old new; do
   D=$R; [ $side = old ] && D=$R/ab_old
