@@ -255,7 +255,8 @@ keaki_status keaki_hip_pairing_batch_dev(keaki_hip_ctx* ctx, const void* d_g1_af
  * pairing side: 2^17) as a pipeline -- uploads and downloads on a stream of the context's own under the neighbouring chunks' kernels --
  * and first-touch the caller's output pages from up to three short-lived helper threads ahead of the downloads (a download into pages
  * that do not exist yet runs at a tenth of the link rate). Results are those of one call per chunk; the call returns when every byte
- * has been delivered and every helper has been joined. */
+ * has been delivered and every helper has been joined. An output array may be one of the input arrays (messages in, bodies out): a chunk's
+ * output pages are touched only after its inputs have been read; arrays the HIP runtime knows (hipHostMalloc / hipHostRegister) are not touched. */
 keaki_status keaki_hip_encap_batch(keaki_hip_ctx* ctx, const uint64_t* com_aff, const uint64_t* tau_g2_aff,
                                    const uint64_t* points, const uint64_t* values, const uint64_t* r, size_t n,
                                    uint64_t* ct_out_aff, uint8_t* gt_out, uint8_t* key_out, size_t msg_len);

@@ -199,6 +199,16 @@ H* new_srs(keaki_hip_ctx* ctx, const void* d, size_t n, bool owned) {
 void prefault_out(void* p, size_t bytes) {
   if (!p || bytes < (1u << 20)) return;
   {
+    // memory the HIP runtime knows (hipHostMalloc / hipHostRegister: resident by construction, and copies from and to it are truly asynchronous,
+    // so a write from here could overtake an upload still reading the same array): nothing to touch
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) == hipSuccess) {
+      if (at.type == hipMemoryTypeHost || at.type == hipMemoryTypeManaged || at.type == hipMemoryTypeDevice) return;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  {
     const uintptr_t HP = (uintptr_t)2 << 20, a = ((uintptr_t)p + HP - 1) & ~(HP - 1), e = ((uintptr_t)p + bytes) & ~(HP - 1);
     if (e > a) (void)madvise((void*)a, e - a, MADV_HUGEPAGE);
   }
@@ -243,13 +253,23 @@ static keaki_status pipelined(keaki_hip_ctx* ctx, size_t n, size_t ch, size_t ou
   const size_t n_helpers = chunks < 2 ? 0 : (n * out_bytes_per_item >= ((size_t)64 << 20) ? std::min<size_t>(3, chunks) : 1);
   std::unique_ptr<std::atomic<unsigned char>[]> touched(new std::atomic<unsigned char>[chunks]);
   for (size_t k = 0; k < chunks; k++) touched[k].store(0, std::memory_order_relaxed);
+  // a helper touches (writes into) the output pages of chunk k only after chunk k's inputs have been read: a caller may pass one array as input
+  // and output (messages in, bodies out). `staged` = chunks whose upload calls have returned (pageable: the source has been consumed by then);
+  // `give_up` releases the helpers when the call leaves early.
+  std::atomic<size_t> staged{0};
+  std::atomic<bool> give_up{false};
   struct Helpers {
     std::vector<std::thread> t;
-    ~Helpers() { for (auto& x : t) if (x.joinable()) x.join(); }
-  } helpers;
+    std::atomic<bool>* give_up;
+    ~Helpers() { give_up->store(true); for (auto& x : t) if (x.joinable()) x.join(); }
+  } helpers{{}, &give_up};
   for (size_t h = 0; h < n_helpers; h++)
     helpers.t.emplace_back([&, h] {
       for (size_t k = h; k < chunks; k += n_helpers) {
+        while (staged.load(std::memory_order_acquire) <= k) {
+          if (give_up.load(std::memory_order_relaxed)) return;
+          std::this_thread::yield();
+        }
         touch(k * ch, std::min(ch, n - k * ch));
         touched[k].store(1, std::memory_order_release);
       }
@@ -262,6 +282,7 @@ static keaki_status pipelined(keaki_hip_ctx* ctx, size_t n, size_t ch, size_t ou
       const size_t lo = k * ch, m = std::min(ch, n - lo);
       const int h = (int)(k & 1);
       ST_TRY(up(lo, m, h, cs));
+      staged.store(k + 1, std::memory_order_release);
       HIP_TRY(ctx, hipEventRecord(ctx->pipe_in[h], cs));
       HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->pipe_in[h], 0));
       ST_TRY(run(lo, m, h));

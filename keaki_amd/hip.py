@@ -516,13 +516,14 @@ class KeakiHip:
         self._ck(self.lib.keaki_hip_decap_batch(self.ctx, _ptr(p), _ptr(c), n, _ptr(gt), _ptr(key) if msg_len else None, msg_len))
         return gt, key[:, :msg_len]
 
-    def encrypt_batch(self, com, tau_g2, points, values, rs, msgs):
+    def encrypt_batch(self, com, tau_g2, points, values, rs, msgs, in_place: bool = False):
         """enc::encrypt over a batch (src/enc.rs:19-40 in the loop of src/vec.rs:63-66): msgs is an (n, msg_len) uint8 array.
         Returns (ct points (n, 16) u64, ciphertext bodies (n, msg_len) u8); the XOR runs on the device behind the KDF."""
         p, v, r = _np(points, 4), _np(values, 4), _np(rs, 4)
         m = np.ascontiguousarray(msgs, dtype=np.uint8)
         n, msg_len = m.shape
-        ct = np.zeros((n, 16), np.uint64); body = np.zeros((n, msg_len), np.uint8)
+        ct = np.zeros((n, 16), np.uint64)
+        body = m if in_place else np.zeros((n, msg_len), np.uint8)      # in_place: the message array doubles as the output (the ABI allows it)
         self._ck(self.lib.keaki_hip_encrypt_batch(self.ctx, _ptr(_np(com)), _ptr(_np(tau_g2)), _ptr(p), _ptr(v), _ptr(r), _ptr(m), n, _ptr(ct), _ptr(body), msg_len))
         return ct, body
 

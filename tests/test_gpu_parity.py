@@ -964,6 +964,10 @@ def test_host_array_batches_in_chunks_equal_the_unchunked_calls(oc, hip):
         assert np.array_equal(c1, ct[lo:hi]) and np.array_equal(b1, body[lo:hi]), lo
         c2, g2_, k2 = hip.encap_batch(com, tau_g2, A[lo:hi], V[lo:hi], R[lo:hi], 48)
         assert np.array_equal(g2_, egt[lo:hi]) and np.array_equal(k2, ekey[lo:hi]), lo
+    # messages in, bodies out in ONE array: the helper threads may touch a chunk's output pages only after the chunk's inputs were read
+    buf = msgs.copy()
+    ct_ip, body_ip = hip.encrypt_batch(com, tau_g2, A, V, R, buf, in_place=True)
+    assert body_ip is buf and np.array_equal(ct_ip, ct) and np.array_equal(buf, body)
     idx = np.array([0, 1, 65535, 65536, 131071, 131072, 196607, 196608, n - 1])
     oct_, ogt, okey = oc.encap_batch(com, tau_g2, A[idx], V[idx], R[idx], 48, threads=os.cpu_count() or 1)
     assert np.array_equal(oct_, ct[idx]) and np.array_equal(ogt, egt[idx]) and np.array_equal(okey ^ msgs[idx], body[idx])
