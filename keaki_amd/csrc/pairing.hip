@@ -15,7 +15,7 @@ static keaki_status pairing_launch(keaki_hip_ctx* ctx, u32 mode, const void* d_g
                                    void* d_out, size_t out_item_bytes, const void* d_fixed_lines, uint32_t lines_stride, const char* what,
                                    uint32_t p_stride = 1) {
   if (n == 0) return KEAKI_OK;
-  // Few pairings: the twelve-lanes-per-pairing kernel (pairing_wide.hip.h) -- a quarter of the latency for 1.65 x the wave-instructions, so only
+  // Few pairings: the twelve-lanes-per-pairing kernel (pairing_wide.hip.h) -- a third of the latency for 2.5 x the wave-instructions, so only
   // while its waves (four pairings each) find the device not full: automatic = up to PAIR_WIDE_AUTO items.
   const size_t wide_max = ctx->tune.pair_wide_max < 0 ? PAIR_WIDE_AUTO : (size_t)ctx->tune.pair_wide_max;
   if (n <= wide_max) {

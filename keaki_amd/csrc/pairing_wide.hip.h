@@ -16,8 +16,8 @@
 //   * the line functions keep the running point T replicated in every pair and spread their Fq2 products over the pairs in rounds (three
 //     rounds for a doubling step, four for an addition step); the one inversion of the easy part runs replicated (every pair gathers the
 //     whole element and runs the lane-pair fq12_inv).
-// ~0.6 M instructions per pairing on the critical path with tabulated lines instead of 2.47 M; 1.65 x the wave-instructions per pairing
-// of k_pairing, so the launcher uses it while the device is not full (pairing.hip: pairing_launch).
+// 0.78 M instructions per pairing on one wave (0.54 M on the f wave of the two-wave form) instead of 2.47 M; 2.5 x the wave-instructions per
+// pairing of k_pairing (profiles/r04_pairing_kernels_pmc_sq_insts.txt), so the launcher uses it while the device is not full (pairing.hip: pairing_launch).
 // Same final-exponent program (FE_PROG), same Miller step table, same constants, bit-identical outputs (tests/test_gpu_parity.py).
 #pragma once
 #include "pairing.hip.h"
