@@ -186,6 +186,86 @@ __global__ void __launch_bounds__(64, OCC) k_encap_fixed(const Aff<F>* __restric
   }
 }
 
+// ---- the same sum for a FEW items: sixteen lanes per item ------------------------------------------------------------------------------
+// k_encap_fixed adds an item's 32-64 table entries one after the other in one lane: 0.96 ms for a single `encapsulate`, the device idle.
+// Here lane l of a 16-lane row takes the windows l, l + 16, ... of the two tables' concatenated window list (the digits come out of a cheap
+// serial walk every lane runs; the ADDITIONS of a step happen in all lanes at once), then the sixteen partial sums meet in a four-level tree of
+// general additions through LDS (x29g2_add, chunk-major layout: conflict-free 16-byte accesses). Same table entries, same group element, same
+// affine bytes; 2-4 mixed additions + 4 general ones + the conversion on the critical path instead of 32-64 + the conversion.
+constexpr u32 FBW_SLOTS = 5;                      // ceil((33 + 33) / 16): 8-bit tables have 32-33 windows each
+struct FbPick { u32 d[FBW_SLOTS]; u32 neg; };     // digit of slot t (0: nothing to add), bit t of neg: negative
+KDEV void fb_pick_digits(FbPick& pk, FbShape g, u32* v, u32 first_window, u32 lane16) {
+  u32 carry = 0;
+  const u32 half = 1u << (g.wb - 1);
+#pragma unroll 1
+  for (u32 j = 0; j < g.windows; j++) {
+    u32 d = (v[0] & (2u * half - 1u)) + carry;
+#pragma unroll
+    for (int t = 0; t < 7; t++) v[t] = (v[t] >> g.wb) | (v[t + 1] << (32u - g.wb));
+    v[7] >>= g.wb;
+    const bool neg = d > half;
+    carry = neg ? 1u : 0u;
+    if (neg) d = 2u * half - d;
+    const u32 w = first_window + j;
+    if ((w & 15u) == lane16) {
+      const u32 slot = w >> 4;
+#pragma unroll
+      for (u32 t = 0; t < FBW_SLOTS; t++) if (t == slot) pk.d[t] = d;
+      if (neg) pk.neg |= 1u << slot;
+    }
+  }
+}
+static __global__ void __launch_bounds__(64) k_encap_fixed_g2_wide(const Aff<Fq2>* __restrict__ tab_a, FbShape ga, const Aff<Fq2>* __restrict__ tab_b, FbShape gb,
+                                                                   const Fr* __restrict__ xs, const Fr* __restrict__ rs, u32 n, Aff<Fq2>* __restrict__ out) {
+  __shared__ uint4 sh[16 * 64];                   // one XYZZ point (4 Fq2 = 16 x 16 bytes) per lane, chunk c of lane l at sh[c * 64 + l]
+  const u32 lane = threadIdx.x, l16 = lane & 15u;
+  const u32 item = blockIdx.x * 4u + (lane >> 4);
+  const bool live = item < n;
+  const u32 i = live ? item : n - 1;
+  const Fr r = rs[i];
+  const Fr t = fp_neg<FrParams>(fp_mul<FrParams>(r, xs[i]));
+  u32 u[8], v[8];
+  fp_from_mont<FrParams>(u, r);
+  fp_from_mont<FrParams>(v, t);
+  FbPick pk;
+#pragma unroll
+  for (u32 s = 0; s < FBW_SLOTS; s++) pk.d[s] = 0;
+  pk.neg = 0;
+  fb_pick_digits(pk, ga, u, 0, l16);
+  fb_pick_digits(pk, gb, v, ga.windows, l16);
+  X29G2 acc = x29g2_inf();
+#pragma unroll 1
+  for (u32 s = 0; s < FBW_SLOTS; s++) {
+    const u32 w = s * 16u + l16;                   // this lane's window of the step: below ga.windows table A, else table B
+    u32 d = 0;
+#pragma unroll
+    for (u32 q = 0; q < FBW_SLOTS; q++) if (q == s) d = pk.d[q];
+    if (w >= ga.windows + gb.windows) d = 0;
+    if (d) {
+      const bool in_a = w < ga.windows;
+      const Aff<Fq2>* e = in_a ? tab_a + (size_t)w * ga.entries + d : tab_b + (size_t)(w - ga.windows) * gb.entries + d;
+      x29g2_add_mixed(acc, aff_cneg(*e, ((pk.neg >> s) & 1u) != 0));
+    }
+  }
+  // tree over the sixteen lanes of the row
+#pragma unroll 1
+  for (u32 step = 1; step < 16u; step <<= 1) {
+    const Xyzz<Fq2> mine = x29g2_store(acc);
+    const uint4* mw = reinterpret_cast<const uint4*>(&mine);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 16; c++) sh[c * 64 + lane] = mw[c];
+    __syncthreads();
+    Xyzz<Fq2> other;
+    uint4* ow = reinterpret_cast<uint4*>(&other);
+    const u32 src = lane ^ step;                   // inside the row: step < 16
+#pragma unroll
+    for (int c = 0; c < 16; c++) ow[c] = sh[c * 64 + src];
+    acc = x29g2_add(acc, x29g2_load(other));       // every lane adds (lanes that are not tree nodes carry values nobody reads)
+  }
+  const Aff<Fq2> res = xyzz_to_aff(x29g2_store(acc));
+  if (live && l16 == 0) out[item] = res;
+}
 
 // ---- on-curve check of affine points (SRS ingest, reference src/kzg/ptau.rs:266,314 deserialises *unchecked*) ----------------
 // counts points with y^2 != x^3 + b; (0, 0) is the identity and passes. b = 3 on G1, 3/(9+u) on the twist.

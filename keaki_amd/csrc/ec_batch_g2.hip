@@ -33,6 +33,13 @@ keaki_status encap_g2_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_
                                 const void* d_rs, size_t n, void* d_out) {
   // 285 registers per lane: one wave per SIMD. Batches that fill every SIMD more than once do better with two waves and 29 spilled
   // registers (2^20 items: 32.2 -> 29.1 ms per encap batch); up to one wave per SIMD (2^16 items) the unspilled kernel wins by 3 %.
+  const size_t wide_max = ctx->tune.pair_wide_max < 0 ? (size_t)2048 : (size_t)ctx->tune.pair_wide_max;
+  if (n <= wide_max && fb_shape(wb_a).windows + fb_shape(wb_b).windows <= FBW_SLOTS * 16u) {
+    // few items: sixteen lanes per item (the additions of an item side by side, then a tree): a single encapsulate 0.96 -> 0.3 ms
+    hipLaunchKernelGGL(k_encap_fixed_g2_wide, dim3(cdiv(n, 4)), dim3(64), 0, ctx->stream, (const G2Aff*)d_tab_a, fb_shape(wb_a), (const G2Aff*)d_tab_b,
+                       fb_shape(wb_b), (const Fr*)d_xs, (const Fr*)d_rs, (u32)n, (G2Aff*)d_out);
+    return launch_check(ctx, "encap_g2_fixed");
+  }
   if (n <= 65536 || ctx->tune.fb_occ1) {
     hipLaunchKernelGGL((k_encap_fixed<Fq2, 1>), dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, (const G2Aff*)d_tab_a, fb_shape(wb_a), (const G2Aff*)d_tab_b,
                      fb_shape(wb_b), (const Fr*)d_xs, (const Fr*)d_rs, (u32)n, (G2Aff*)d_out);
