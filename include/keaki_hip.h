@@ -216,9 +216,10 @@ keaki_status keaki_hip_kzg_quotient(keaki_hip_ctx* ctx, const uint64_t* coeffs, 
 
 /* ---- KZG `verify` in one call -------------------------------------------------------------------------------------
  * Replaces the body of `verify` (reference src/kzg.rs:127-146): e(com - value g1, g2) == e(proof, [tau]_2 - point g2).
- * Evaluated as e(com - value g1 + point proof, g2) == e(proof, [tau]_2): the same predicate by bilinearity, with both second
- * slots fixed per setup, so no G2 arithmetic runs and both Miller loops read tabulated lines (the table of [tau]_2 is cached
- * in the context until a different [tau]_2 is passed). com_aff, proof_aff: u64[8] affine G1 ((0,0) = identity);
+ * Evaluated exactly in that form: the two inner points are fixed-base sums over 8-bit window tables of g1 and g2 (built at the first
+ * call of a context), the two pairings one launch of the low-latency pairing kernel. (Until round 4: e(com - value g1 + point proof, g2)
+ * == e(proof, [tau]_2) -- the same predicate by bilinearity, tabulated lines, but a variable-base ladder in front.)
+ * com_aff, proof_aff: u64[8] affine G1 ((0,0) = identity);
  * tau_g2_aff: u64[16]; point, value: u64[4] Fr. *ok_out = 1 when the equation holds, else 0. */
 keaki_status keaki_hip_kzg_verify(keaki_hip_ctx* ctx, const uint64_t* com_aff, const uint64_t* tau_g2_aff, const uint64_t* point,
                                   const uint64_t* value, const uint64_t* proof_aff, int32_t* ok_out);

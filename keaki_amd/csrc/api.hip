@@ -347,10 +347,10 @@ std::vector<BufClass> all_bufs(keaki_hip_ctx* ctx) {
   std::vector<BufClass> v;
   for (DevBuf* b : {&ctx->digits, &ctx->hist, &ctx->offsets, &ctx->cursor, &ctx->sorted, &ctx->buckets, &ctx->partials, &ctx->wsums, &ctx->bsums,
                     &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->io_a, &ctx->io_b, &ctx->io_c, &ctx->io_d, &ctx->io_e, &ctx->perm, &ctx->heavy,
-                    &ctx->pair_ws, &ctx->verify_lines, &ctx->verify_io, &ctx->g2gen_lines, &ctx->fk_tab, &ctx->g2pow_lines, &ctx->g2pow_pts})
+                    &ctx->pair_ws, &ctx->verify_io, &ctx->g2gen_lines, &ctx->fk_tab, &ctx->g2pow_lines, &ctx->g2pow_pts})
     v.push_back({b, 1});
   for (DevBuf* b : {&ctx->fb_bases, &ctx->fb_g1_gen, &ctx->fb_g2_gen, &ctx->fb_com, &ctx->fb_tau, &ctx->gt_tab_a, &ctx->gt_tab_b, &ctx->gt_base,
-                    &ctx->fbs_g2_gen, &ctx->fbs_tau})
+                    &ctx->fbs_g2_gen, &ctx->fbs_tau, &ctx->fbs_g1_gen})
     v.push_back({b, 2});
   return v;
 }
@@ -463,7 +463,7 @@ keaki_status keaki_hip_ctx_trim(keaki_hip_ctx* ctx) {
     if (bc.b->p) { (void)hipFree(bc.b->p); bc.b->p = nullptr; bc.b->cap = 0; }
   ctx->gt_b_ready = ctx->gt_a_valid = ctx->gt_b_fallback = false;
   ctx->seen_com_runs = 0;
-  ctx->verify_ready = ctx->verify_tau_valid = false;
+  ctx->verify_ready = ctx->verify_tables_ready = false;
   ctx->fb_tau_valid = ctx->g2gen_lines_ready = ctx->fb_ready = ctx->g2pow_ready = false;
   ctx->fbs_ready = ctx->fbs_tau_valid = false;
   return KEAKI_OK;
@@ -1471,34 +1471,44 @@ keaki_status keaki_hip_kzg_verify(keaki_hip_ctx* ctx, const uint64_t* com_aff, c
   CTX_GUARD(ctx);
   TRACE_SCOPE("keaki.kzg_verify");
   if (!com_aff || !tau_g2_aff || !point || !value || !proof_aff || !ok_out) return fail(ctx, KEAKI_ERR_BAD_ARG, "kzg_verify: null pointer");
-  // io block: [g2 128 | tau_g2 128 | com 64 | proof 64 | value 32 | point 32 | pairing inputs 128 | gt 768]
-  constexpr size_t O_Q = 0, O_IN = 256, O_P = O_IN + 192, O_GT = O_P + 128, IO_BYTES = O_GT + 768;
-  const size_t LB = g2_prepared_bytes();
+  // The predicate exactly as src/kzg.rs:135-143 writes it: e(com - value g1, g2) == e(proof, [tau]_2 - point g2). Both inner points are fixed-base
+  // sums over the 8-bit tables of the generators (k_verify_points, 0.25 ms); the two pairings are ONE launch of the twelve-lane kernel with the
+  // lines computed on the fly (1.44 ms). (Rounds 2-4 moved point * proof across the pairing so that both second slots were tabulated: a variable-
+  // base ladder of 0.99 ms in front of 1.38 ms of pairings.)
+  // io block: [qs: g2 128 | Q 128] [in: com 64 | proof 64 | value 32 | point 32 | tau_g2 128] [ps: A 64 | proof 64] [gt 768]
+  constexpr size_t O_Q = 0, O_IN = 256, O_P = O_IN + 320, O_GT = O_P + 128, IO_BYTES = O_GT + 768;
+  constexpr uint32_t WB = 8;
   if (!ctx->verify_ready) {
-    ctx->verify_tau_valid = false;
-    ST_TRY(reserve(ctx, ctx->verify_lines, 2 * LB));
     ST_TRY(reserve(ctx, ctx->verify_io, IO_BYTES));
     ST_TRY(g2_generator_to(ctx, (char*)ctx->verify_io.p + O_Q));
-    ST_TRY(g2_prepare_run(ctx, (char*)ctx->verify_io.p + O_Q, ctx->verify_lines.p));
     ctx->verify_ready = true;               // only after every step succeeded (a failed init is retried by the next call)
   }
   char* io = (char*)ctx->verify_io.p;
-  if (!ctx->verify_tau_valid || memcmp(ctx->verify_tau_pt, tau_g2_aff, 128) != 0) {
-    ctx->verify_tau_valid = false;
-    HIP_TRY(ctx, hipMemcpyAsync(io + O_Q + 128, tau_g2_aff, 128, hipMemcpyHostToDevice, ctx->stream));
-    ST_TRY(g2_prepare_run(ctx, io + O_Q + 128, (char*)ctx->verify_lines.p + LB));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                              // tau_g2_aff is the caller's memory
-    memcpy(ctx->verify_tau_pt, tau_g2_aff, 128);
-    ctx->verify_tau_valid = true;
+  if (!ctx->verify_tables_ready) {
+    const size_t FBX = fb_table_entries(WB);
+    ST_TRY(reserve(ctx, ctx->fbs_g1_gen, FBX * G1_AFF_BYTES + G1_AFF_BYTES));
+    void* g1pt = (char*)ctx->fbs_g1_gen.p + FBX * G1_AFF_BYTES;
+    ST_TRY(g1_generator_to(ctx, g1pt));
+    ST_TRY(g1_fb_table_run(ctx, g1pt, ctx->fbs_g1_gen.p, WB));
+    if (!ctx->fbs_ready) {                  // shared with the small-batch path of encapsulate (which also keeps [tau]_2's table there)
+      ST_TRY(reserve(ctx, ctx->fbs_g2_gen, FBX * G2_AFF_BYTES));
+      ST_TRY(reserve(ctx, ctx->fbs_tau, FBX * G2_AFF_BYTES));
+      ST_TRY(g2_fb_table_run(ctx, io + O_Q, ctx->fbs_g2_gen.p, WB));
+      ctx->fbs_ready = true;
+      ctx->fbs_tau_valid = false;
+    }
+    ctx->verify_tables_ready = true;
   }
-  uint64_t in[24];
+  uint64_t in[40];
   memcpy(in, com_aff, 64);
   memcpy(in + 8, proof_aff, 64);
   memcpy(in + 16, value, 32);
   memcpy(in + 20, point, 32);
-  HIP_TRY(ctx, hipMemcpyAsync(io + O_IN, in, 192, hipMemcpyHostToDevice, ctx->stream));
-  ST_TRY(verify_combine_run(ctx, io + O_IN, io + O_IN + 64, io + O_IN + 128, io + O_IN + 160, io + O_P));
-  ST_TRY(pairing_run(ctx, io + O_P, io + O_Q, 1, 2, io + O_GT, ctx->verify_lines.p, g2_prepared_lines()));
+  memcpy(in + 24, tau_g2_aff, 128);
+  HIP_TRY(ctx, hipMemcpyAsync(io + O_IN, in, 320, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(io + O_P + 64, io + O_IN + 64, 64, hipMemcpyDeviceToDevice, ctx->stream));      // the proof into the pairing's first slot
+  ST_TRY(verify_points_run(ctx, ctx->fbs_g1_gen.p, ctx->fbs_g2_gen.p, WB, io + O_IN, io + O_IN + 192, io + O_IN + 128, io + O_IN + 160, io + O_P, io + O_Q + 128));
+  ST_TRY(pairing_run(ctx, io + O_P, io + O_Q, 1, 2, io + O_GT));
   uint8_t gt[768];
   ST_TRY(download(ctx, gt, io + O_GT, 768));                                       // synchronises: `in` stays alive until here
   *ok_out = memcmp(gt, gt + 384, 384) == 0 ? 1 : 0;

@@ -61,28 +61,6 @@ static __global__ void __launch_bounds__(64) k_encap_g1(const G1Aff* __restrict_
   G1Aff cb = jac_to_aff(jac_add_mixed(t, *com));
   out[i] = jac_to_aff(scalar_mul(cb, rs[i]));
 }
-// kzg verify, G1 side: out2 = [com - value g1 + point proof, proof]   (affine). src/kzg.rs:135-143 checks
-//   e(com - value g1, g2) == e(proof, [tau]_2 - point g2); moving point * proof across by bilinearity gives
-//   e(com - value g1 + point proof, g2) == e(proof, [tau]_2), the same predicate with both second slots FIXED per setup.
-// lanes 0 and 1 run the two scalar mults in lockstep (same ladder, different base and scalar); lane 0 combines.
-static __global__ void __launch_bounds__(64) k_verify_combine(const G1Aff* __restrict__ com, const G1Aff* __restrict__ proof,
-                                                       const Fr* __restrict__ value, const Fr* __restrict__ point, G1Aff* __restrict__ out2) {
-  __shared__ G1Jac sh;
-  const u32 t = threadIdx.x;
-  if (t >= 2) return;
-  G1Aff g = {G1_GEN_X, G1_GEN_Y};
-  G1Aff base = t == 0 ? g : *proof;
-  Fr k = t == 0 ? *value : *point;
-  G1Jac m = scalar_mul(base, k);
-  if (t == 0) m.y = -m.y;
-  if (t == 1) sh = m;
-  __syncthreads();
-  if (t == 0) {
-    m = jac_add(m, sh);
-    out2[0] = jac_to_aff(jac_add_mixed(m, *com));
-    out2[1] = *proof;
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // Fixed-base path for encapsulate. In the batch loop of src/vec.rs:63-66 every item uses the SAME
@@ -265,6 +243,85 @@ static __global__ void __launch_bounds__(64) k_encap_fixed_g2_wide(const Aff<Fq2
   }
   const Aff<Fq2> res = xyzz_to_aff(x29g2_store(acc));
   if (live && l16 == 0) out[item] = res;
+}
+// ---- kzg verify in the reference's own form (src/kzg.rs:135-143): e(com - value g1, g2) == e(proof, [tau]_2 - point g2) ----------------------
+// Both inner points are a caller's point plus a FIXED-base multiple: with the 8-bit window tables of g1 and g2 and sixteen lanes per sum they cost
+// 2-3 additions, a four-level tree and one conversion each (0.25 ms), where moving point * proof across the pairing (the form of rounds 2-4)
+// needs a variable-base ladder of 129 doublings in one lane (0.99 ms). Wave 0: Q = [tau]_2 + (-point) g2. Wave 1: A = com + (-value) g1.
+static __global__ void __launch_bounds__(128) k_verify_points(const Aff<Fq>* __restrict__ tab_g1, const Aff<Fq2>* __restrict__ tab_g2, FbShape g,
+                                                              const G1Aff* __restrict__ com, const G2Aff* __restrict__ tau_g2, const Fr* __restrict__ value,
+                                                              const Fr* __restrict__ point, G1Aff* __restrict__ out_a, G2Aff* __restrict__ out_q) {
+  __shared__ uint4 sh2[16 * 64];
+  __shared__ uint4 sh1[8 * 64];
+  const u32 lane = threadIdx.x & 63u, l16 = lane & 15u;
+  const bool g2side = threadIdx.x < 64u;
+  u32 k[8];
+  fp_from_mont<FrParams>(k, fp_neg<FrParams>(g2side ? *point : *value));
+  FbPick pk;
+#pragma unroll
+  for (u32 s = 0; s < FBW_SLOTS; s++) pk.d[s] = 0;
+  pk.neg = 0;
+  fb_pick_digits(pk, g, k, 0, l16);
+  if (g2side) {
+    X29G2 acc = x29g2_inf();
+#pragma unroll 1
+    for (u32 s = 0; s * 16u < g.windows; s++) {
+      const u32 w = s * 16u + l16;
+      u32 d = 0;
+#pragma unroll
+      for (u32 q = 0; q < FBW_SLOTS; q++) if (q == s) d = pk.d[q];
+      if (w >= g.windows) d = 0;
+      if (d) x29g2_add_mixed(acc, aff_cneg(tab_g2[(size_t)w * g.entries + d], ((pk.neg >> s) & 1u) != 0));
+    }
+#pragma unroll 1
+    for (u32 step = 1; step < 16u; step <<= 1) {
+      const Xyzz<Fq2> mine = x29g2_store(acc);
+      const uint4* mw = reinterpret_cast<const uint4*>(&mine);
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 16; c++) sh2[c * 64 + lane] = mw[c];
+      __syncthreads();
+      Xyzz<Fq2> other;
+      uint4* ow = reinterpret_cast<uint4*>(&other);
+#pragma unroll
+      for (int c = 0; c < 16; c++) ow[c] = sh2[c * 64 + (lane ^ step)];
+      acc = x29g2_add(acc, x29g2_load(other));
+    }
+    x29g2_add_mixed(acc, *tau_g2);
+    const Aff<Fq2> q = xyzz_to_aff(x29g2_store(acc));
+    if (lane == 0) *out_q = q;
+  } else {
+    X29 acc = x29_inf();
+#pragma unroll 1
+    for (u32 s = 0; s * 16u < g.windows; s++) {
+      const u32 w = s * 16u + l16;
+      u32 d = 0;
+#pragma unroll
+      for (u32 q = 0; q < FBW_SLOTS; q++) if (q == s) d = pk.d[q];
+      if (w >= g.windows) d = 0;
+      if (d) {
+        const Aff<Fq> e = aff_cneg(tab_g1[(size_t)w * g.entries + d], ((pk.neg >> s) & 1u) != 0);
+        acc = x29_add(acc, x29_load(xyzz_from_aff(e)));
+      }
+    }
+#pragma unroll 1
+    for (u32 step = 1; step < 16u; step <<= 1) {
+      const Xyzz<Fq> mine = x29_store(acc);
+      const uint4* mw = reinterpret_cast<const uint4*>(&mine);
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 8; c++) sh1[c * 64 + lane] = mw[c];
+      __syncthreads();
+      Xyzz<Fq> other;
+      uint4* ow = reinterpret_cast<uint4*>(&other);
+#pragma unroll
+      for (int c = 0; c < 8; c++) ow[c] = sh1[c * 64 + (lane ^ step)];
+      acc = x29_add(acc, x29_load(other));
+    }
+    if (!aff_is_inf(*com)) acc = x29_add(acc, x29_load(xyzz_from_aff(*com)));
+    const Aff<Fq> a = xyzz_to_aff(x29_store(acc));
+    if (lane == 0) *out_a = a;
+  }
 }
 
 // ---- on-curve check of affine points (SRS ingest, reference src/kzg/ptau.rs:266,314 deserialises *unchecked*) ----------------

@@ -13,11 +13,6 @@ keaki_status encap_g1_run(keaki_hip_ctx* ctx, const void* d_com, const void* d_v
                      (G1Aff*)d_out);
   return launch_check(ctx, "encap_g1");
 }
-keaki_status verify_combine_run(keaki_hip_ctx* ctx, const void* d_com, const void* d_proof, const void* d_value, const void* d_point, void* d_out2) {
-  hipLaunchKernelGGL(k_verify_combine, dim3(1), dim3(64), 0, ctx->stream, (const G1Aff*)d_com, (const G1Aff*)d_proof, (const Fr*)d_value,
-                     (const Fr*)d_point, (G1Aff*)d_out2);
-  return launch_check(ctx, "verify_combine");
-}
 keaki_status g1_generator_to(keaki_hip_ctx* ctx, void* d_dst) {
   HIP_TRY(ctx, hipMemcpyFromSymbolAsync(d_dst, HIP_SYMBOL(G1_GEN_X), sizeof(Fq), 0, hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyFromSymbolAsync((char*)d_dst + sizeof(Fq), HIP_SYMBOL(G1_GEN_Y), sizeof(Fq), 0, hipMemcpyDeviceToDevice, ctx->stream));

@@ -24,6 +24,12 @@ keaki_status g2_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, void* d_tab
                      (G2Aff*)d_table);
   return launch_check(ctx, "g2_fb_table");
 }
+keaki_status verify_points_run(keaki_hip_ctx* ctx, const void* d_tab_g1, const void* d_tab_g2, uint32_t wb, const void* d_com, const void* d_tau_g2,
+                               const void* d_value, const void* d_point, void* d_out_a, void* d_out_q) {
+  hipLaunchKernelGGL(k_verify_points, dim3(1), dim3(128), 0, ctx->stream, (const G1Aff*)d_tab_g1, (const G2Aff*)d_tab_g2, fb_shape(wb), (const G1Aff*)d_com,
+                     (const G2Aff*)d_tau_g2, (const Fr*)d_value, (const Fr*)d_point, (G1Aff*)d_out_a, (G2Aff*)d_out_q);
+  return launch_check(ctx, "verify_points");
+}
 keaki_status g2_pow2_multiples_run(keaki_hip_ctx* ctx, const void* d_base, uint32_t count, void* d_out) {
   const FbShape g = {1u, count, 0u};                 // "windows" of one bit: base_s = 2^s base
   hipLaunchKernelGGL((k_fb_window_bases<Fq2>), dim3(cdiv(count, 64)), dim3(64), 0, ctx->stream, (const G2Aff*)d_base, g, (G2Aff*)d_out);

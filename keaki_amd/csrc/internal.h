@@ -72,16 +72,15 @@ struct keaki_hip_ctx {
   bool g2pow_ready = false;
   keaki_internal::DevBuf pair_ws;                   // per-item slots of the final exponentiation (pairing.hip.h)
   keaki_internal::DevBuf fk_tab;                    // window tables of the per-lane-scalar ladders of FK23: 1 KB per lane of a launch (64 x 16 B), at most 2 GB (fft_g1.hip)
-  keaki_internal::DevBuf verify_lines, verify_io;   // kzg verify: [lines of g2 | lines of [tau]_2], small in/out block
-  bool verify_ready = false;              // set only after every init step of kzg verify succeeded
-  bool verify_tau_valid = false;
-  uint64_t verify_tau_pt[16] = {};
+  keaki_internal::DevBuf verify_io;                 // kzg verify: small in/out block
+  bool verify_ready = false;
+  bool verify_tables_ready = false;       // 8-bit window tables of g1 (fbs_g1_gen) and g2 (fbs_g2_gen) for the reference-form verify              // set only after every init step of kzg verify succeeded
   bool fb_tau_valid = false;          // window table of [tau]_2 (encap ciphertext side) is for this point
   uint64_t fb_tau_pt[16] = {};
   uint64_t gt_a_com[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // commitment the cached A-table belongs to
   bool g2gen_lines_ready = false;
   bool fb_ready = false;
-  keaki_internal::DevBuf fbs_g2_gen, fbs_tau;     // small (8-bit) tables of g2 and [tau]_2 for batches below 256 items
+  keaki_internal::DevBuf fbs_g2_gen, fbs_tau, fbs_g1_gen;     // small (8-bit) tables of g2 and [tau]_2 for batches below 256 items
   bool fbs_ready = false, fbs_tau_valid = false;
   uint64_t fbs_tau_pt[16] = {};
   // instrumentation
@@ -160,7 +159,9 @@ size_t pairing_launch_items();      // items per k_pairing launch (the slots of 
 keaki_status pairing_run(keaki_hip_ctx* ctx, const void* d_g1, const void* d_g2, int g2_stride, size_t n, void* d_gt, const void* d_fixed_lines = nullptr,
                          uint32_t lines_stride = 0);
 uint32_t g2_prepared_lines();                 // Line entries of one table
-keaki_status verify_combine_run(keaki_hip_ctx* ctx, const void* d_com, const void* d_proof, const void* d_value, const void* d_point, void* d_out2);
+// kzg verify: A = com - value g1, Q = [tau]_2 - point g2 from the wb-bit window tables of the generators (sixteen lanes per sum)
+keaki_status verify_points_run(keaki_hip_ctx* ctx, const void* d_tab_g1, const void* d_tab_g2, uint32_t wb, const void* d_com, const void* d_tau_g2,
+                               const void* d_value, const void* d_point, void* d_out_a, void* d_out_q);
 size_t g2_prepared_bytes();
 // out[i] = e(P_(i * p_stride), Q_i) as 12 Fq in the 2^261 form, Q_i given by its line table d_lines + i * lines_stride lines
 keaki_status pairing_raw_fixed_run(keaki_hip_ctx* ctx, const void* d_g1, uint32_t p_stride, size_t n, const void* d_lines, uint32_t lines_stride, void* d_out);

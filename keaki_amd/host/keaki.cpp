@@ -251,7 +251,7 @@ Result<G1> open(const KZGSetup& setup, const DensePolynomial& p_in, const Fr& po
 }
 
 Result<bool> verify(const KZGSetup& setup, const G1& commitment, const Fr& point, const Fr& value, const G1& proof) {
-  // src/kzg.rs:127-146; the device evaluates e(C - value g1 + point proof, g2) == e(proof, [tau]_2) (include/keaki_hip.h)
+  // src/kzg.rs:127-146, evaluated on the device in the same form (include/keaki_hip.h)
   const Device& dev = *setup.device();
   int32_t ok = 0;
   dev.check(keaki_hip_kzg_verify(dev.ctx(), commitment.w.data(), setup.tau_g2().w.data(), point.l, value.l, proof.w.data(), &ok));
