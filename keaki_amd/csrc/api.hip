@@ -916,7 +916,7 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
         memcpy(ctx->fb_tau_pt, tau_host, 128);
         ctx->fb_tau_valid = true;
       }
-      if (!prep) ST_TRY(encap_g2_fixed_run(ctx, ctx->fb_tau.p, FB_WB_LONG, ctx->fb_g2_gen.p, FB_WB_LONG, d_points, d_r, n, d_ct_out_aff));
+      if (!prep) ST_TRY(encap_g2_fixed_run(ctx, ctx->fb_tau.p, FB_WB_LONG, ctx->fb_g2_gen.p, FB_WB_LONG, d_points, d_r, n, d_ct_out_aff, a_on_aux));
     } else {
       constexpr uint32_t FB_WB_SMALL = 8;
       const size_t FBX = fb_table_entries(FB_WB_SMALL);

@@ -35,8 +35,10 @@ keaki_status g2_pow2_multiples_run(keaki_hip_ctx* ctx, const void* d_base, uint3
   hipLaunchKernelGGL((k_fb_window_bases<Fq2>), dim3(cdiv(count, 64)), dim3(64), 0, ctx->stream, (const G2Aff*)d_base, g, (G2Aff*)d_out);
   return launch_check(ctx, "g2_pow2_multiples");
 }
+// share_simds: a latency-bound job of this context runs beside this kernel (the table of a new commitment): the 256-register form, whose waves
+// can sit on a SIMD next to that job's, also for batches that would otherwise take the 285-register one
 keaki_status encap_g2_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t wb_a, const void* d_tab_b, uint32_t wb_b, const void* d_xs,
-                                const void* d_rs, size_t n, void* d_out) {
+                                const void* d_rs, size_t n, void* d_out, bool share_simds) {
   // 285 registers per lane: one wave per SIMD. Batches that fill every SIMD more than once do better with two waves and 29 spilled
   // registers (2^20 items: 32.2 -> 29.1 ms per encap batch); up to one wave per SIMD (2^16 items) the unspilled kernel wins by 3 %.
   const size_t wide_max = ctx->tune.pair_wide_max < 0 ? (size_t)2048 : (size_t)ctx->tune.pair_wide_max;
@@ -46,7 +48,7 @@ keaki_status encap_g2_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_
                        fb_shape(wb_b), (const Fr*)d_xs, (const Fr*)d_rs, (u32)n, (G2Aff*)d_out);
     return launch_check(ctx, "encap_g2_fixed");
   }
-  if (n <= 65536 || ctx->tune.fb_occ1) {
+  if ((n <= 65536 && !share_simds) || ctx->tune.fb_occ1) {
     hipLaunchKernelGGL((k_encap_fixed<Fq2, 1>), dim3(cdiv(n, 64)), dim3(64), 0, ctx->stream, (const G2Aff*)d_tab_a, fb_shape(wb_a), (const G2Aff*)d_tab_b,
                      fb_shape(wb_b), (const Fr*)d_xs, (const Fr*)d_rs, (u32)n, (G2Aff*)d_out);
   } else {

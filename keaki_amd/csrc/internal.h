@@ -183,7 +183,7 @@ keaki_status g1_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, void* d_tab
 keaki_status g2_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, void* d_table, uint32_t wb);
 keaki_status g2_pow2_multiples_run(keaki_hip_ctx* ctx, const void* d_base, uint32_t count, void* d_out);   // out[s] = 2^s base (affine), lane s doubles s times
 keaki_status encap_g1_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t wb_a, const void* d_tab_b, uint32_t wb_b, const void* d_xs, const void* d_rs, size_t n, void* d_out);
-keaki_status encap_g2_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t wb_a, const void* d_tab_b, uint32_t wb_b, const void* d_xs, const void* d_rs, size_t n, void* d_out);
+keaki_status encap_g2_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t wb_a, const void* d_tab_b, uint32_t wb_b, const void* d_xs, const void* d_rs, size_t n, void* d_out, bool share_simds = false);
 keaki_status g1_curve_check_run(keaki_hip_ctx* ctx, const void* d_pts, size_t n, void* d_bad2);   // d_bad2: u64 count, u64 first index
 keaki_status g2_curve_check_run(keaki_hip_ctx* ctx, const void* d_pts, size_t n, void* d_bad2);
 keaki_status open_quotient_run(keaki_hip_ctx* ctx, const void* d_c, size_t n, const uint64_t* z, void* d_q, void* d_value, void* d_work);
