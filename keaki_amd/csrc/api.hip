@@ -854,7 +854,7 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
     a_cached = ctx->gt_b_ready && ctx->gt_a_valid && memcmp(com_host, ctx->gt_a_com, 64) == 0;
   }
   const bool use_gt = n_policy >= gt_threshold || (!prep && !gt_env && (a_cached || ctx->seen_com_runs >= 3));
-  bool a_on_aux = false;
+  bool a_on_aux = false, b_factor_done = false;
   if (use_gt) {
     // GT_i = A^(r_i) B^(-beta_i r_i) with A = e(C, g2), B = e(g1, g2) (see pairing.hip.h): no pairing per item
     ST_TRY(reserve(ctx, ctx->gt_base, G1_AFF_BYTES + 320 * (G1_AFF_BYTES + 384)));   // a point | (unused since round 4) | the powers' pairings
@@ -893,6 +893,13 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
       }
       HIP_TRY(ctx, hipEventRecord(ctx->aux_ev[1], ctx->aux_stream));
       a_on_aux = true;
+      if (n > 4096) {
+        // the constant base's factor FIRST on the main stream: it fills every SIMD (two waves of 256 registers each) and must be out of the way
+        // when the table's fill levels arrive; the ciphertext kernel behind it leaves half of each SIMD's registers to them
+        ST_TRY(reserve(ctx, ctx->tmp_a, n * 384));
+        ST_TRY(gt_encap_exp_run(ctx, nullptr, 0, ctx->gt_tab_b.p, ctx->gt_b_wb, d_values, d_r, n, nullptr, nullptr, ctx->tmp_a.p));
+        b_factor_done = true;
+      }
       memcpy(ctx->gt_a_com, com_host, 64);
       ctx->gt_a_wb = GT_WB_A_FIRST;
       ctx->gt_a_valid = true;
@@ -938,10 +945,8 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
   }
   if (prep) return KEAKI_OK;
   if (use_gt) {
-    if (a_on_aux && n > 4096) {
-      // the factor of the constant base while the commitment's table is still on its way, the commitment's factor behind it
-      ST_TRY(reserve(ctx, ctx->tmp_a, n * 384));
-      ST_TRY(gt_encap_exp_run(ctx, nullptr, 0, ctx->gt_tab_b.p, ctx->gt_b_wb, d_values, d_r, n, nullptr, nullptr, ctx->tmp_a.p));
+    if (b_factor_done) {
+      // the factor of the constant base ran while the commitment's table was on its way; the commitment's factor behind it
       HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_ev[1], 0));
       ST_TRY(gt_encap_exp_run(ctx, ctx->gt_tab_a.p, ctx->gt_a_wb, nullptr, 0, d_values, d_r, n, gt, ctx->tmp_a.p, nullptr));
     } else {
