@@ -301,6 +301,68 @@ static keaki_status pipelined(keaki_hip_ctx* ctx, size_t n, size_t ch, size_t ou
   return KEAKI_OK;
 }
 
+
+// ---- MSM of a scalar vector in HOST memory -----------------------------------------------------------------------------------------
+// kzg::commit hands over a polynomial that lives in host memory (reference src/kzg.rs:89-101): the call is upload -> MSM, and done in
+// that order the 512 MiB of a 2^24-term polynomial cost 11.5 ms of copy in front of 16.7 ms of kernels (BENCH_r04: 5.96e8/s against
+// 1.007e9/s resident). From `msm_pipe_min` scalars on the vector goes up in point-range chunks through the copy stream and the MSM
+// runs chunk by chunk behind it (msm_host.hip.h: MsmPipe): the upload of chunk j + 1 hides under the kernels of chunk j, only the
+// first chunk's copy stays in front. Chunks GROW (the copy is faster than the kernels, so a short first chunk starts the device early
+// and every later copy still finishes before the device asks for it); `run(pipe)` enqueues the MSM over ctx->io_a.
+// A pageable source makes every copy call return once its bytes are staged; a pinned one returns at once -- the order of the host's
+// calls (copy j, kernels j, copy j + 1, ...) serves both.
+static std::vector<size_t> msm_pipe_bounds(const Tuning& t, size_t n) {
+  size_t k = 1;
+  if (t.msm_pipe_chunks >= 2) k = (size_t)t.msm_pipe_chunks;
+  else if (t.msm_pipe_chunks < 0 && n >= (size_t)t.msm_pipe_min) k = n >= ((size_t)1 << 22) ? 6 : 3;
+  if (k > 64) k = 64;
+  if (k > n) k = n ? n : 1;
+  std::vector<size_t> b{0};
+  if (k >= 2) {
+    const double g = std::max(100, std::min(400, t.msm_pipe_growth)) / 100.0;
+    double tot = 0, w = 1;
+    for (size_t j = 0; j < k; j++, w *= g) tot += w;
+    double acc = 0;
+    w = 1;
+    for (size_t j = 0; j + 1 < k; j++, w *= g) {
+      acc += w;
+      size_t e = (size_t)((double)n * acc / tot);
+      if (n >= 65536) e &= ~(size_t)4095;                   // whole pages of scalars, whole tiles of the first sort
+      if (e > b.back() && e < n) b.push_back(e);
+    }
+  }
+  b.push_back(n);
+  return b;
+}
+template <class Run>
+static keaki_status msm_from_host(keaki_hip_ctx* ctx, const uint64_t* scalars, size_t n, Run run) {
+  ST_TRY(reserve(ctx, ctx->io_a, n ? n * 32 : 16));
+  MsmPipe pipe;
+  pipe.bounds = msm_pipe_bounds(ctx->tune, n);
+  if (pipe.bounds.size() <= 2) {
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->io_a.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    return run(nullptr);
+  }
+  ST_TRY(pipe_ready(ctx));
+  hipStream_t cs = ctx->copy_stream, st = ctx->stream;
+  // the copy stream starts behind whatever the context's stream holds (an earlier call's kernels may still read io_a)
+  HIP_TRY(ctx, hipEventRecord(ctx->pipe_done[0], st));
+  HIP_TRY(ctx, hipStreamWaitEvent(cs, ctx->pipe_done[0], 0));
+  struct CopyFence {                                       // no copy may still read the caller's array when the call returns, whatever the exit
+    hipStream_t cs;
+    ~CopyFence() { (void)hipStreamSynchronize(cs); }
+  } fence{cs};
+  pipe.stage = [&](size_t j) -> keaki_status {
+    const size_t lo = pipe.bounds[j], m = pipe.bounds[j + 1] - lo;
+    const int h = (int)(j & 1);
+    HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->io_a.p + lo * 32, (const char*)scalars + lo * 32, m * 32, hipMemcpyHostToDevice, cs));
+    HIP_TRY(ctx, hipEventRecord(ctx->pipe_in[h], cs));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->pipe_in[h], 0));
+    return KEAKI_OK;
+  };
+  return run(&pipe);
+}
+
 #define CTX_GUARD(ctx)                                \
   if (!(ctx)) return KEAKI_ERR_BAD_ARG;               \
   std::lock_guard<std::recursive_mutex> lock_((ctx)->mu);       \
@@ -341,11 +403,14 @@ void tune_from_env(Tuning& t) {
   if (geti("KEAKI_PAIR_TWO_WAVES", v)) t.pair_two_waves = v != 0;
   if (geti("KEAKI_GT_WB_B", v)) t.gt_wb_b = (int)v;
   if (geti("KEAKI_ENCAP_GT", v)) t.encap_gt = v;
+  if (geti("KEAKI_MSM_PIPE_CHUNKS", v)) t.msm_pipe_chunks = (int)v;
+  if (geti("KEAKI_MSM_PIPE_MIN", v)) t.msm_pipe_min = v;
+  if (geti("KEAKI_MSM_PIPE_GROWTH", v)) t.msm_pipe_growth = (int)v;
 }
 struct BufClass { DevBuf* b; int cls; };   // cls: 1 = workspace, 2 = GT / fixed-base tables of encapsulate
 std::vector<BufClass> all_bufs(keaki_hip_ctx* ctx) {
   std::vector<BufClass> v;
-  for (DevBuf* b : {&ctx->digits, &ctx->hist, &ctx->offsets, &ctx->cursor, &ctx->sorted, &ctx->buckets, &ctx->partials, &ctx->wsums, &ctx->bsums,
+  for (DevBuf* b : {&ctx->digits, &ctx->hist, &ctx->offsets, &ctx->cursor, &ctx->sorted, &ctx->buckets, &ctx->acc29, &ctx->partials, &ctx->wsums, &ctx->bsums,
                     &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->io_a, &ctx->io_b, &ctx->io_c, &ctx->io_d, &ctx->io_e, &ctx->perm, &ctx->heavy,
                     &ctx->pair_ws, &ctx->verify_io, &ctx->g2gen_lines, &ctx->fk_tab, &ctx->g2pow_lines, &ctx->g2pow_pts})
     v.push_back({b, 1});
@@ -445,6 +510,9 @@ keaki_status keaki_hip_ctx_set_option(keaki_hip_ctx* ctx, const char* name, int6
     if ((int)value != t.gt_wb_b) { ctx->gt_b_ready = false; ctx->gt_b_fallback = false; }      // the table of B is rebuilt at the new width on the next use
     t.gt_wb_b = (int)value;
   } else if (k == "encap_gt") t.encap_gt = value;
+  else if (k == "msm_pipe_chunks") t.msm_pipe_chunks = (int)value;
+  else if (k == "msm_pipe_min") t.msm_pipe_min = value;
+  else if (k == "msm_pipe_growth") t.msm_pipe_growth = (int)value;
   else return fail(ctx, KEAKI_ERR_BAD_ARG, "ctx_set_option: unknown option '%s'", name);
   return KEAKI_OK;
 }
@@ -629,10 +697,11 @@ keaki_status keaki_hip_msm_g1(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, c
   if (!srs || !out_jac || (n && !scalars)) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm_g1: null pointer");
   SRS_CHECK(ctx, srs, "msm_g1");
   if (n > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", n, srs->n);
-  ST_TRY(upload(ctx, ctx->io_a, scalars, n * 32));
   ST_TRY(reserve(ctx, ctx->io_b, 96));
   const auto tb = srs_tables(srs);
-  ST_TRY(msm_g1_run(ctx, srs->d, srs->n, ctx->io_a.p, n, ctx->io_b.p, tb.first, tb.second));
+  ST_TRY(msm_from_host(ctx, scalars, n, [&](const MsmPipe* pipe) {
+    return msm_g1_run(ctx, srs->d, srs->n, ctx->io_a.p, n, ctx->io_b.p, tb.first, tb.second, pipe);
+  }));
   ST_TRY(download(ctx, out_jac, ctx->io_b.p, 96));
   resolve_timing(ctx);
   return KEAKI_OK;
@@ -651,10 +720,11 @@ keaki_status keaki_hip_msm_g2(keaki_hip_ctx* ctx, const keaki_hip_srs_g2* srs, c
   if (!srs || !out_jac || (n && !scalars)) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm_g2: null pointer");
   SRS_CHECK(ctx, srs, "msm_g2");
   if (n > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", n, srs->n);
-  ST_TRY(upload(ctx, ctx->io_a, scalars, n * 32));
   ST_TRY(reserve(ctx, ctx->io_b, 192));
   const auto tb = srs_tables(srs);
-  ST_TRY(msm_g2_run(ctx, srs->d, srs->n, ctx->io_a.p, n, ctx->io_b.p, tb.first, tb.second));
+  ST_TRY(msm_from_host(ctx, scalars, n, [&](const MsmPipe* pipe) {
+    return msm_g2_run(ctx, srs->d, srs->n, ctx->io_a.p, n, ctx->io_b.p, tb.first, tb.second, pipe);
+  }));
   ST_TRY(download(ctx, out_jac, ctx->io_b.p, 192));
   resolve_timing(ctx);
   return KEAKI_OK;

@@ -6,8 +6,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/keaki_hip.h"
 
@@ -41,6 +43,9 @@ struct Tuning {
   bool pair_two_waves = true;    // KEAKI_PAIR_TWO_WAVES / "pair_two_waves": up to 1,024 pairings with lines on the fly run the line functions on a second wave (A/B switch)
   int gt_wb_b = 0;               // KEAKI_GT_WB_B / "gt_wb_b": window bits of the table of e(g1, g2), 0 = automatic (20 / 16)
   long long encap_gt = -1;       // KEAKI_ENCAP_GT / "encap_gt": batch size from which encap takes the GT fixed-base path; -1 = automatic (always, since round 4)
+  int msm_pipe_chunks = -1;      // KEAKI_MSM_PIPE_CHUNKS / "msm_pipe_chunks": chunks of a host-pointer MSM (upload under the kernels); -1 = automatic, 0 / 1 = one copy in front, k = k chunks at any length
+  long long msm_pipe_min = 1 << 20;   // KEAKI_MSM_PIPE_MIN / "msm_pipe_min": automatic chunking from this many scalars on
+  int msm_pipe_growth = 140;     // KEAKI_MSM_PIPE_GROWTH / "msm_pipe_growth": size of chunk j + 1 in percent of chunk j (100 = equal chunks)
   size_t alloc_limit = 0;        // keaki_hip_debug_set_alloc_limit: single allocations above it fail with KEAKI_ERR_OOM; 0 = none
 };
 }  // namespace keaki_internal
@@ -57,7 +62,7 @@ struct keaki_hip_ctx {
   std::recursive_mutex mu;   // recursive: host-pointer entry points hold it across stage -> *_dev -> download
   std::string err;
   // grow-only workspaces (all used in stream order)
-  keaki_internal::DevBuf digits, hist, offsets, cursor, sorted, buckets, partials, wsums, bsums, tmp_a, tmp_b, tmp_c, io_a, io_b, io_c, io_d, io_e;
+  keaki_internal::DevBuf digits, hist, offsets, cursor, sorted, buckets, acc29, partials, wsums, bsums, tmp_a, tmp_b, tmp_c, io_a, io_b, io_c, io_d, io_e;
   // fixed-base window tables for encapsulate: generator tables are built once per context, the C / [tau]_2 tables per batch
   keaki_internal::DevBuf fb_bases, fb_g1_gen, fb_g2_gen, fb_com, fb_tau, perm, g2gen_lines, gt_tab_a, gt_tab_b, gt_base, heavy;
   bool gt_b_ready = false;
@@ -144,12 +149,22 @@ inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
     if (s_ != KEAKI_OK) return s_;   \
   } while (0)
 
+// Chunked form of one MSM (the host-pointer entries, api.hip): the (scalar, point) pairs are cut into point-range chunks; every chunk
+// runs its own tile sort -> chunk sort -> size order -> bucket pass, the bucket pass going on from what the earlier chunks left in the
+// buckets (msm.hip.h: Acc29 / `cont`), and ONE reduction tail closes the call. `stage(j)` is called right before the kernels of chunk j
+// are enqueued: the caller uploads that chunk's scalars there (on its copy stream) and makes the context's stream wait for them, so the
+// upload of chunk j + 1 runs under the kernels of chunk j. The sum is the same group element whatever the cut (exact arithmetic).
+struct MsmPipe {
+  std::vector<size_t> bounds;                        // chunk j = pairs [bounds[j], bounds[j + 1]); 0 = bounds[0] < ... < bounds.back() = n
+  std::function<keaki_status(size_t)> stage;
+};
+
 // launchers implemented in the kernel translation units (all enqueue on ctx->stream, no sync)
 keaki_status msm_g1_run(keaki_hip_ctx* ctx, const void* d_points, size_t srs_len, const void* d_scalars, size_t n, void* d_out_jac,
-                        const void* d_table = nullptr, int c_table = 0);
+                        const void* d_table = nullptr, int c_table = 0, const MsmPipe* pipe = nullptr);
 keaki_status msm_g1_precompute_run(keaki_hip_ctx* ctx, const void* d_points, size_t N, int* c_table_out, size_t* table_bytes_out, void** d_table_out);
 keaki_status msm_g2_run(keaki_hip_ctx* ctx, const void* d_points, size_t srs_len, const void* d_scalars, size_t n, void* d_out_jac,
-                        const void* d_table = nullptr, int c_table = 0);
+                        const void* d_table = nullptr, int c_table = 0, const MsmPipe* pipe = nullptr);
 keaki_status msm_g2_precompute_run(keaki_hip_ctx* ctx, const void* d_points, size_t N, int* c_table_out, size_t* table_bytes_out, void** d_table_out);
 keaki_status g1_sum_run(keaki_hip_ctx* ctx, const void* d_points_jac, size_t k, void* d_out_jac);
 keaki_status g1_mul_batch_run(keaki_hip_ctx* ctx, const void* d_pts, int stride, const void* d_scalars, size_t n, void* d_out);

@@ -16,6 +16,7 @@
 // Order of additions inside a bucket depends on LDS-atomic arrival order; EC addition is exact and
 // commutative, so the affine result is bit-identical run to run.
 #pragma once
+#include <type_traits>
 #include "bn254_curve.hip.h"
 #include "fq29.hip.h"
 #include "xyzz29.hip.h"
@@ -257,7 +258,7 @@ static __global__ void __launch_bounds__(T1_THREADS) k_tile_sort(const Fr* __res
   const u32 t = threadIdx.x;
   constexpr u32 NC = WS ? WS : 1u;
   for (u32 tile = blockIdx.x; tile < ps.ntiles; tile += gridDim.x) {
-    const u32 sk = (tile - blockIdx.x) / gridDim.x;
+    [[maybe_unused]] const u32 sk = (tile - blockIdx.x) / gridDim.x;     // (the STAMP harness reads it)
     STAMP(blockIdx.x == 100 && t == 0 && sk < 4, 2048 + sk * 16 + 0);
     u32 canon[T1_PER][8];          // the canonical scalars; the digits are cut twice (count, place): 24 registers instead of 3 W
     bool act[T1_PER];
@@ -855,10 +856,37 @@ __global__ void __launch_bounds__(256) k_msm_heavy(const Aff<F>* __restrict__ po
     __syncthreads();
   }
 }
+// Bucket state between the passes of a CHUNKED MSM (msm_host.hip.h: the host-pointer entries run the scalars in point-range chunks so
+// that the upload of chunk j + 1 hides behind the kernels of chunk j). G2 and the saturated G1 kernel keep the canonical XYZZ value in
+// `buckets`; the G1 kernel in the lazy limbs keeps its loop-carried registers AS THEY ARE (4 x 9 limbs, 144 B, no reduction, no
+// conversion) in a side array and writes the canonical value only in the last pass. All limbs zero = empty bucket (ZZ of a point is
+// never 0 mod p, and a lazy value with all limbs zero IS 0).
+struct Acc29 {
+  v4u_t q[9];
+};
+KDEV void acc29_store(Acc29* dst, const U29& X, const U29& Y, const U29& ZZ, const U29& ZZZ, bool empty) {
+  u32 w[36];
+#pragma unroll
+  for (int i = 0; i < 9; i++) { w[i] = empty ? 0u : X.l[i]; w[9 + i] = empty ? 0u : Y.l[i]; w[18 + i] = empty ? 0u : ZZ.l[i]; w[27 + i] = empty ? 0u : ZZZ.l[i]; }
+#pragma unroll
+  for (int i = 0; i < 9; i++) dst->q[i] = v4u_t{w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
+}
+KDEV bool acc29_load(const Acc29* src, U29& X, U29& Y, U29& ZZ, U29& ZZZ) {      // returns `empty`
+  u32 w[36];
+#pragma unroll
+  for (int i = 0; i < 9; i++) { const v4u_t v = src->q[i]; w[4 * i] = v[0]; w[4 * i + 1] = v[1]; w[4 * i + 2] = v[2]; w[4 * i + 3] = v[3]; }
+  u32 any = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { X.l[i] = w[i]; Y.l[i] = w[9 + i]; ZZ.l[i] = w[18 + i]; ZZZ.l[i] = w[27 + i]; any |= w[18 + i]; }
+  return any == 0;
+}
+// mode: 0 buckets[t] = sum (one-pass MSM) | 1 buckets[t] += sum (canonical state) | 2 state29[t] = sum | 3 state29[t] += sum (G1 only)
+enum { HV_SET = 0, HV_ADD = 1, HV_SET29 = 2, HV_ADD29 = 3 };
 template <class F>
 __global__ void __launch_bounds__(64) k_msm_heavy_combine(const u32* __restrict__ counts, const HeavyList* __restrict__ hv, u32 hv_cap, u32 hv_slice_cap,
                                                           const u32* __restrict__ hv_bucket, const u32* __restrict__ hv_first,
-                                                          const Xyzz<F>* __restrict__ slices, Xyzz<F>* __restrict__ buckets) {
+                                                          const Xyzz<F>* __restrict__ slices, Xyzz<F>* __restrict__ buckets, u32 mode,
+                                                          Acc29* __restrict__ state29) {
   __shared__ Xyzz<F> sh[64];
   const u32 nh = min(hv->n, hv_cap);
   for (u32 slot = blockIdx.x; slot < nh; slot += gridDim.x) {
@@ -873,7 +901,22 @@ __global__ void __launch_bounds__(64) k_msm_heavy_combine(const u32* __restrict_
       if (threadIdx.x < o) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], sh[threadIdx.x + o]);
       __syncthreads();
     }
-    if (threadIdx.x == 0) buckets[t] = sh[0];
+    if (threadIdx.x == 0) {
+      Xyzz<F> r = sh[0];
+      if (mode == HV_ADD) r = xyzz_add(buckets[t], r);
+      if constexpr (std::is_same<F, Fq>::value) {
+        if (mode == HV_ADD29) {
+          U29 X, Y, ZZ, ZZZ;
+          if (!acc29_load(state29 + t, X, Y, ZZ, ZZZ)) r = xyzz_add(Xyzz<Fq>{u29_to_fq(X), u29_to_fq(Y), u29_to_fq(ZZ), u29_to_fq(ZZZ)}, r);
+        }
+        if (mode == HV_SET29 || mode == HV_ADD29)
+          acc29_store(state29 + t, u29_from_fq(r.x), u29_from_fq(r.y), u29_from_fq(r.zz), u29_from_fq(r.zzz), xyzz_is_inf(r));
+        else
+          buckets[t] = r;
+      } else {
+        buckets[t] = r;
+      }
+    }
     __syncthreads();
   }
 }
@@ -881,17 +924,20 @@ __global__ void __launch_bounds__(64) k_msm_heavy_combine(const u32* __restrict_
 KDEV bool msm_bucket_is_heavy(u32 cnt) { return cnt >= HEAVY_MIN; }
 
 // ---- K4: bucket accumulation (dominant kernel) ----------------------------------------------------
+// cont != 0 (a later pass of a chunked MSM): the bucket goes on from the value the earlier passes left in buckets[t]
 template <class F>
 __global__ void __launch_bounds__(256) k_msm_accumulate(const Aff<F>* __restrict__ points, SortView v, const u32* __restrict__ counts,
-                                                        const u32* __restrict__ perm, u32 nbuckets_total, Xyzz<F>* __restrict__ buckets) {
+                                                        const u32* __restrict__ perm, u32 nbuckets_total, Xyzz<F>* __restrict__ buckets, u32 cont) {
   u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= nbuckets_total) return;
   u32 t = perm[lane];
   u32 cnt = counts[t];
   if (msm_bucket_is_heavy(cnt)) return;   // done by k_msm_heavy / k_msm_heavy_combine
+  if (cont && cnt == 0) return;
   SegWalker sw;
   seg_init(sw, v, t);
   Xyzz<F> acc = xyzz_inf<F>();
+  if (cont) acc = buckets[t];
   for (u32 k = 0; k < cnt; k++) {
     u32 e = seg_next(sw, v);
     Aff<F> p = points[e & 0x7FFFFFFFu];
@@ -922,19 +968,32 @@ KDEV Aff<Fq> msm_load_row(const Aff<Fq>* __restrict__ p) {
     return q;
   }
 }
-template <int NT>
+// MODE (passes of a chunked MSM, see Acc29): ACC_WHOLE the one-pass MSM: starts empty, writes the canonical bucket | ACC_FIRST starts
+// empty, leaves the registers in state29 | ACC_MIDDLE state29 -> state29 (buckets without pairs in this pass are not touched) |
+// ACC_LAST state29 -> canonical bucket (every bucket, also the ones the heavy path owns in this pass: k_msm_heavy_combine adds to them)
+enum { ACC_WHOLE = 0, ACC_FIRST = 1, ACC_MIDDLE = 2, ACC_LAST = 3 };
+template <int NT, int MODE>
 static __global__ void __launch_bounds__(256) k_msm_accumulate_g1_u29(const Aff<Fq>* __restrict__ points, SortView v,
                                                                       const u32* __restrict__ counts, const u32* __restrict__ perm,
-                                                                      u32 nbuckets_total, Xyzz<Fq>* __restrict__ buckets) {
+                                                                      u32 nbuckets_total, Xyzz<Fq>* __restrict__ buckets,
+                                                                      Acc29* __restrict__ state29) {
   u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= nbuckets_total) return;
   u32 t = perm[lane];
   u32 cnt = counts[t];
-  if (msm_bucket_is_heavy(cnt)) return;   // done by k_msm_heavy / k_msm_heavy_combine
+  if constexpr (MODE == ACC_LAST) {
+    if (msm_bucket_is_heavy(cnt)) cnt = 0;
+  } else {
+    if (msm_bucket_is_heavy(cnt)) return;   // done by k_msm_heavy / k_msm_heavy_combine
+  }
+  if constexpr (MODE == ACC_MIDDLE) {
+    if (cnt == 0) return;
+  }
   SegWalker sw;
   seg_init(sw, v, t);
   U29 X1, Y1, ZZ, ZZZ;
   bool empty = true;
+  if constexpr (MODE == ACC_MIDDLE || MODE == ACC_LAST) empty = acc29_load(state29 + t, X1, Y1, ZZ, ZZZ);
   for (u32 k = 0; k < cnt; k++) {
     u32 e = seg_next(sw, v);
     Aff<Fq> q = msm_load_row<NT>(points + (e & 0x7FFFFFFFu));
@@ -974,15 +1033,20 @@ static __global__ void __launch_bounds__(256) k_msm_accumulate_g1_u29(const Aff<
     ZZ = u29_mul(ZZ, PP);
     ZZZ = u29_mul(ZZZ, PPP);
   }
-  Xyzz<Fq> out = xyzz_inf<Fq>();
-  if (!empty) {
-    out.x = u29_to_fq(X1); out.y = u29_to_fq(Y1); out.zz = u29_to_fq(ZZ); out.zzz = u29_to_fq(ZZZ);
+  if constexpr (MODE == ACC_FIRST || MODE == ACC_MIDDLE) {
+    acc29_store(state29 + t, X1, Y1, ZZ, ZZZ, empty);
+  } else {
+    Xyzz<Fq> out = xyzz_inf<Fq>();
+    if (!empty) {
+      out.x = u29_to_fq(X1); out.y = u29_to_fq(Y1); out.zz = u29_to_fq(ZZ); out.zzz = u29_to_fq(ZZZ);
+    }
+    buckets[t] = out;
   }
-  buckets[t] = out;
 }
 
 // G2 bucket accumulation in the lazy limbs (xyzz29_g2.hip.h): same schedule, ~5,600 instead of ~9,000 instructions per mixed addition.
 // Buckets are written back saturated and canonical (the tail keeps the generic arithmetic).
+template <int CONT>
 static __global__ void __launch_bounds__(256) k_msm_accumulate_g2_u29(const Aff<Fq2>* __restrict__ points, SortView v,
                                                                       const u32* __restrict__ counts, const u32* __restrict__ perm,
                                                                       u32 nbuckets_total, Xyzz<Fq2>* __restrict__ buckets) {
@@ -991,9 +1055,11 @@ static __global__ void __launch_bounds__(256) k_msm_accumulate_g2_u29(const Aff<
   u32 t = perm[lane];
   u32 cnt = counts[t];
   if (msm_bucket_is_heavy(cnt)) return;   // done by k_msm_heavy / k_msm_heavy_combine
+  if (CONT && cnt == 0) return;
   SegWalker sw;
   seg_init(sw, v, t);
   X29G2 acc = x29g2_inf();
+  if constexpr (CONT != 0) acc = x29g2_load(buckets[t]);
   for (u32 k = 0; k < cnt; k++) {
     u32 e = seg_next(sw, v);
     Aff<Fq2> q = points[e & 0x7FFFFFFFu];

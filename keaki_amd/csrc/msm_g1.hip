@@ -2,8 +2,8 @@
 #include "msm_host.hip.h"
 namespace keaki_internal {
 keaki_status msm_g1_run(keaki_hip_ctx* ctx, const void* d_points, size_t srs_len, const void* d_scalars, size_t n, void* d_out_jac,
-                        const void* d_table, int c_table) {
-  return msm_dev<Fq>(ctx, (const G1Aff*)d_points, srs_len, d_scalars, n, d_out_jac, (const G1Aff*)d_table, c_table);
+                        const void* d_table, int c_table, const MsmPipe* pipe) {
+  return msm_dev<Fq>(ctx, (const G1Aff*)d_points, srs_len, d_scalars, n, d_out_jac, (const G1Aff*)d_table, c_table, pipe);
 }
 keaki_status msm_g1_precompute_run(keaki_hip_ctx* ctx, const void* d_points, size_t N, int* c_table_out, size_t* table_bytes_out, void** d_table_out) {
   const int c = choose_window_shared(N, ctx->tune.msm_c_shared);

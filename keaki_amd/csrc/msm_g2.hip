@@ -3,8 +3,8 @@
 #include "msm_host.hip.h"
 namespace keaki_internal {
 keaki_status msm_g2_run(keaki_hip_ctx* ctx, const void* d_points, size_t srs_len, const void* d_scalars, size_t n, void* d_out_jac, const void* d_table,
-                        int c_table) {
-  return msm_dev<Fq2>(ctx, (const G2Aff*)d_points, srs_len, d_scalars, n, d_out_jac, (const G2Aff*)d_table, c_table);
+                        int c_table, const MsmPipe* pipe) {
+  return msm_dev<Fq2>(ctx, (const G2Aff*)d_points, srs_len, d_scalars, n, d_out_jac, (const G2Aff*)d_table, c_table, pipe);
 }
 // window tables of a fixed G2 basis: all windows share one bucket set, and the per-window Horner doublings -- a serial chain of ~240
 // Fq2 doublings on one lane, 4.4 ms -- disappear (profiles/r02_msm_g2_kernel_stats.csv)

@@ -1,7 +1,10 @@
 // Host-side driver of the MSM pipeline (workspace sizing, window choice, kernel sequence), written
 // once and instantiated for G1 (msm_g1.hip) and G2 (msm_g2.hip).
 #pragma once
+#include <algorithm>
+#include <functional>
 #include <type_traits>
+#include <vector>
 #include "internal.h"
 #include "msm.hip.h"
 
@@ -28,7 +31,7 @@ inline int choose_window(size_t n, int forced = 0) {
 // d_table != nullptr: precomputed path (tables built by msm_build_tables with window target c_table for N = srs_len points)
 template <class F>
 keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len, const void* d_scalars, size_t n, void* d_out_jac,
-                     const Aff<F>* d_table = nullptr, int c_table = 0) {
+                     const Aff<F>* d_table = nullptr, int c_table = 0, const MsmPipe* pipe = nullptr) {
   if (!d_out_jac || (n && (!d_points || !d_scalars))) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: null pointer");
   if (n > srs_len) return fail(ctx, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", n, srs_len);
   if (n >= (1ull << 31)) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: n must be < 2^31 per device");
@@ -70,109 +73,150 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
     hipLaunchKernelGGL((k_msm_final<F>), dim3(1), dim3(64), 0, st, (const Xyzz<F>*)wsums, 0u, out);
     return launch_check(ctx, "msm_final");
   }
-  PartShape ps;
-  if (!part_make_shape(n, s.W, nb, &ps, ctx->tune.part_shift))
-    return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: %zu buckets / %u windows exceed the bucket sort's LDS budget (window too large)", nb, s.W);
-  const size_t pairs = n * (size_t)s.W;
-  const size_t max_chunks = part_max_chunks(pairs, ps.nbins);
+  // ---- the passes: one for a resident scalar vector, one per chunk of a pipelined call ----------------------------------------------
+  const size_t K = pipe ? pipe->bounds.size() - 1 : 1;
+  if (pipe && (K < 1 || pipe->bounds.front() != 0 || pipe->bounds.back() != n)) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: bad chunk bounds");
+  struct Pass {
+    size_t lo, m, pairs, max_chunks, cm_bytes, bt_bytes, bm_bytes, sg_bytes, ts_bytes;
+    PartShape ps;
+  };
+  std::vector<Pass> passes(K);
+  size_t w_digits = 0, w_sorted = 0, w_offsets = 0, w_cursor = 0, w_pairs = 0;
+  for (size_t j = 0; j < K; j++) {
+    Pass& q = passes[j];
+    q.lo = pipe ? pipe->bounds[j] : 0;
+    q.m = (pipe ? pipe->bounds[j + 1] : n) - q.lo;
+    if (q.m == 0 || q.m > n) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: bad chunk bounds");
+    if (!part_make_shape(q.m, s.W, nb, &q.ps, ctx->tune.part_shift))
+      return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: %zu buckets / %u windows exceed the bucket sort's LDS budget (window too large)", nb, s.W);
+    q.pairs = q.m * (size_t)s.W;
+    q.max_chunks = part_max_chunks(q.pairs, q.ps.nbins);
+    // [cell table: (position in the bin, start | length in the tile) per bin and tile | bin totals | bin descriptors | bucket-major segment
+    //  words | tile starts (u16)]
+    q.cm_bytes = (size_t)q.ps.nbins * q.ps.ntiles * sizeof(uint2);
+    q.bt_bytes = ((size_t)q.ps.nbins * 4 + 15) & ~(size_t)15;
+    q.bm_bytes = (size_t)q.ps.nbins * sizeof(BinMeta);
+    q.sg_bytes = nb * sizeof(v4u_t);
+    q.ts_bytes = (size_t)q.ps.ntiles * (q.ps.nbins + 1) * 2;
+    w_digits = std::max(w_digits, (size_t)q.ps.ntiles * q.ps.te * 4);
+    w_sorted = std::max(w_sorted, q.pairs * 4);
+    w_offsets = std::max(w_offsets, q.max_chunks * q.ps.nf * 4);
+    w_cursor = std::max(w_cursor, q.cm_bytes + q.bt_bytes + q.bm_bytes + q.sg_bytes + q.ts_bytes);
+    w_pairs = std::max(w_pairs, q.pairs);
+  }
+  bool u29 = false;
+  if constexpr (std::is_same<F, Fq>::value) u29 = ctx->tune.acc_u29;          // A/B switches for profiling
+  if constexpr (std::is_same<F, Fq2>::value) u29 = ctx->tune.acc_u29_g2;
+  const bool lazy_state = K > 1 && u29 && std::is_same<F, Fq>::value;         // the G1 kernel's registers stay in Acc29 between the passes
+  // every workspace is reserved BEFORE the first pass (sized for the largest one): a reserve that grows a buffer waits for the stream
   // pass-1 images | bucket-ordered index stream | per-bucket counts | chunk-major segment words of the chunks beyond SEG_INLINE
-  ST_TRY(reserve(ctx, ctx->digits, (size_t)ps.ntiles * ps.te * 4));
-  ST_TRY(reserve(ctx, ctx->sorted, pairs * 4));
+  ST_TRY(reserve(ctx, ctx->digits, w_digits));
+  ST_TRY(reserve(ctx, ctx->sorted, w_sorted));
   ST_TRY(reserve(ctx, ctx->hist, nb * 4));
-  ST_TRY(reserve(ctx, ctx->offsets, max_chunks * ps.nf * 4));
-  // [cell table: (position in the bin, start | length in the tile) per bin and tile | bin totals | bin descriptors | bucket-major segment
-  //  words | tile starts (u16)]
-  const size_t cm_bytes = (size_t)ps.nbins * ps.ntiles * sizeof(uint2);
-  const size_t bt_bytes = ((size_t)ps.nbins * 4 + 15) & ~(size_t)15, bm_bytes = (size_t)ps.nbins * sizeof(BinMeta);
-  const size_t sg_bytes = nb * sizeof(v4u_t), ts_bytes = (size_t)ps.ntiles * (ps.nbins + 1) * 2;
-  ST_TRY(reserve(ctx, ctx->cursor, cm_bytes + bt_bytes + bm_bytes + sg_bytes + ts_bytes));
+  ST_TRY(reserve(ctx, ctx->offsets, w_offsets));
+  ST_TRY(reserve(ctx, ctx->cursor, w_cursor));
   ST_TRY(reserve(ctx, ctx->buckets, nb * sizeof(Xyzz<F>)));
   ST_TRY(reserve(ctx, ctx->partials, ((size_t)rs.W * chunks + (size_t)rs.W * 256) * sizeof(Xyzz<F>)));
+  ST_TRY(reserve(ctx, ctx->perm, nb * 4 + 2 * CNT_BINS * 4 + sizeof(HeavyList)));
+  // heavy-bucket list: [bucket[cap] | first[cap] | owner[slice_cap]] then the slice sums
+  const u32 hv_cap = (u32)(w_pairs / HEAVY_MIN + 1), hv_slice_cap = (u32)(hv_cap + w_pairs / HEAVY_SLICE + 1);
+  const size_t hv_hdr = ((2 * (size_t)hv_cap + hv_slice_cap) * 4 + 255) & ~(size_t)255;
+  ST_TRY(reserve(ctx, ctx->heavy, hv_hdr + (size_t)hv_slice_cap * sizeof(Xyzz<F>)));
+  if (lazy_state) ST_TRY(reserve(ctx, ctx->acc29, nb * sizeof(Acc29)));
   u32 *tiles = (u32*)ctx->digits.p, *sorted = (u32*)ctx->sorted.p, *hist = (u32*)ctx->hist.p;
   u32* segoff = (u32*)ctx->offsets.p;
-  uint2* cellmeta = (uint2*)ctx->cursor.p;
-  u32* bin_total = (u32*)((char*)ctx->cursor.p + cm_bytes);
-  BinMeta* bins = (BinMeta*)((char*)bin_total + bt_bytes);
-  v4u_t* segtab = (v4u_t*)((char*)bins + bm_bytes);
-  u16* tstart = (u16*)((char*)segtab + sg_bytes);
   Xyzz<F>* buckets = (Xyzz<F>*)ctx->buckets.p;
   Xyzz<F>* partials = (Xyzz<F>*)ctx->partials.p;
-  {
-    const dim3 g1(ps.ntiles < ctx->n_cu ? ps.ntiles : ctx->n_cu), b1(T1_THREADS);
-#define KEAKI_TILE_SORT(WS) hipLaunchKernelGGL(k_tile_sort<WS>, g1, b1, 0, st, (const Fr*)d_scalars, s, ps, tiles, tstart)
-    switch (s.W) {                    // plans with 11..16 windows (what 2^16..2^26 points choose) have their digit cuts compiled in
-      case 11: KEAKI_TILE_SORT(11); break;
-      case 12: KEAKI_TILE_SORT(12); break;
-      case 13: KEAKI_TILE_SORT(13); break;
-      case 14: KEAKI_TILE_SORT(14); break;
-      case 15: KEAKI_TILE_SORT(15); break;
-      case 16: KEAKI_TILE_SORT(16); break;
-      default: KEAKI_TILE_SORT(0); break;
-    }
-#undef KEAKI_TILE_SORT
-  }
-  ST_TRY(launch_check(ctx, "tile_sort"));
-  hipLaunchKernelGGL(k_cell_prefix, dim3(ps.nbins), dim3(1024), 0, st, (const u16*)tstart, ps, cellmeta, bin_total);
-  hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, (const u32*)bin_total, ps.nbins, bins);
-  {
-#define KEAKI_CHUNK_SORT(L, R, Q)                                                                                                                       \
-  hipLaunchKernelGGL((k_chunk_sort<L, R, Q>), dim3(ps.nbins), dim3(C2_THREADS), 0, st, (const u32*)tiles, (const uint2*)cellmeta, (const BinMeta*)bins, s, \
-                     ps, (u32)nb, sorted, segtab, segoff, hist)
-    switch (ps.geom) {                // lanes per cell, 16-byte pieces per lane and cell, cells per group: for cells of about 18 / 36 / 72 / 144+ entries
-      case 0: KEAKI_CHUNK_SORT(8, 1, 16); break;
-      case 1: KEAKI_CHUNK_SORT(16, 1, 16); break;
-      case 2: KEAKI_CHUNK_SORT(16, 2, 8); break;
-      default: KEAKI_CHUNK_SORT(16, 4, 4); break;
-    }
-#undef KEAKI_CHUNK_SORT
-  }
-  ST_TRY(launch_check(ctx, "chunk_sort"));
-  const SortView view = {sorted, bins, segtab, segoff, ps};
-  // bucket schedule: descending size
-  ST_TRY(reserve(ctx, ctx->perm, nb * 4 + 2 * CNT_BINS * 4 + sizeof(HeavyList)));
+  Acc29* state29 = lazy_state ? (Acc29*)ctx->acc29.p : nullptr;
   u32* perm = (u32*)ctx->perm.p;
   u32 *gstart = perm + nb, *ghist = gstart + CNT_BINS;
   HeavyList* hv = (HeavyList*)(ghist + CNT_BINS);                        // right behind the histogram: one memset clears both
-  HIP_TRY(ctx, hipMemsetAsync(ghist, 0, CNT_BINS * 4 + sizeof(HeavyList), st));
-  // heavy-bucket list: [bucket[cap] | first[cap] | owner[slice_cap]] then the slice sums
-  const size_t total_pairs = n * (size_t)s.W;
-  const u32 hv_cap = (u32)(total_pairs / HEAVY_MIN + 1), hv_slice_cap = (u32)(hv_cap + total_pairs / HEAVY_SLICE + 1);
-  const size_t hv_hdr = ((2 * (size_t)hv_cap + hv_slice_cap) * 4 + 255) & ~(size_t)255;
-  ST_TRY(reserve(ctx, ctx->heavy, hv_hdr + (size_t)hv_slice_cap * sizeof(Xyzz<F>)));
   u32 *hv_bucket = (u32*)ctx->heavy.p, *hv_first = hv_bucket + hv_cap, *hv_owner = hv_first + hv_cap;
   Xyzz<F>* hv_slices = (Xyzz<F>*)((char*)ctx->heavy.p + hv_hdr);
-  hipLaunchKernelGGL(k_cnt_hist, dim3(cdiv(nb, 1024)), dim3(256), 0, st, (const u32*)hist, (u32)nb, ghist, hv, hv_cap, hv_slice_cap, hv_bucket, hv_first,
-                     hv_owner);
-  hipLaunchKernelGGL(k_cnt_offsets, dim3(1), dim3(CNT_BINS), 0, st, (const u32*)ghist, gstart);
-  hipLaunchKernelGGL(k_cnt_scatter, dim3(cdiv(nb, 1024)), dim3(256), 0, st, (const u32*)hist, (u32)nb, gstart, perm);
-  ST_TRY(launch_check(ctx, "cnt_sort"));
-  if (ctx->timing) (void)hipEventRecord(ctx->ev[1], st);
-  bool u29 = false;
-  if constexpr (std::is_same<F, Fq>::value) {
-    u29 = ctx->tune.acc_u29;                                 // A/B switch for profiling
-    if (u29 && ctx->tune.acc_nt)
-      hipLaunchKernelGGL(k_msm_accumulate_g1_u29<1>, dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, view, (const u32*)hist,
-                         (const u32*)perm, (u32)nb, buckets);
-    else if (u29)
-      hipLaunchKernelGGL(k_msm_accumulate_g1_u29<0>, dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, view, (const u32*)hist,
-                         (const u32*)perm, (u32)nb, buckets);
+  for (size_t j = 0; j < K; j++) {
+    const Pass& q = passes[j];
+    const PartShape& ps = q.ps;
+    if (pipe && pipe->stage) ST_TRY(pipe->stage(j));
+    MsmShape sj = s;
+    sj.n = (u32)q.m;
+    const Fr* scal = (const Fr*)d_scalars + q.lo;
+    const Aff<F>* pts = d_points + q.lo;                  // table row w of point lo + i = (table + lo)[w * stride + i]
+    const bool first = j == 0, last = j + 1 == K;
+    uint2* cellmeta = (uint2*)ctx->cursor.p;
+    u32* bin_total = (u32*)((char*)ctx->cursor.p + q.cm_bytes);
+    BinMeta* bins = (BinMeta*)((char*)bin_total + q.bt_bytes);
+    v4u_t* segtab = (v4u_t*)((char*)bins + q.bm_bytes);
+    u16* tstart = (u16*)((char*)segtab + q.sg_bytes);
+    {
+      const dim3 g1(ps.ntiles < ctx->n_cu ? ps.ntiles : ctx->n_cu), b1(T1_THREADS);
+#define KEAKI_TILE_SORT(WS) hipLaunchKernelGGL(k_tile_sort<WS>, g1, b1, 0, st, scal, sj, ps, tiles, tstart)
+      switch (s.W) {                    // plans with 11..16 windows (what 2^16..2^26 points choose) have their digit cuts compiled in
+        case 11: KEAKI_TILE_SORT(11); break;
+        case 12: KEAKI_TILE_SORT(12); break;
+        case 13: KEAKI_TILE_SORT(13); break;
+        case 14: KEAKI_TILE_SORT(14); break;
+        case 15: KEAKI_TILE_SORT(15); break;
+        case 16: KEAKI_TILE_SORT(16); break;
+        default: KEAKI_TILE_SORT(0); break;
+      }
+#undef KEAKI_TILE_SORT
+    }
+    ST_TRY(launch_check(ctx, "tile_sort"));
+    hipLaunchKernelGGL(k_cell_prefix, dim3(ps.nbins), dim3(1024), 0, st, (const u16*)tstart, ps, cellmeta, bin_total);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, (const u32*)bin_total, ps.nbins, bins);
+    {
+#define KEAKI_CHUNK_SORT(L, R, Q)                                                                                                                       \
+  hipLaunchKernelGGL((k_chunk_sort<L, R, Q>), dim3(ps.nbins), dim3(C2_THREADS), 0, st, (const u32*)tiles, (const uint2*)cellmeta, (const BinMeta*)bins, sj, \
+                     ps, (u32)nb, sorted, segtab, segoff, hist)
+      switch (ps.geom) {                // lanes per cell, 16-byte pieces per lane and cell, cells per group: for cells of about 18 / 36 / 72 / 144+ entries
+        case 0: KEAKI_CHUNK_SORT(8, 1, 16); break;
+        case 1: KEAKI_CHUNK_SORT(16, 1, 16); break;
+        case 2: KEAKI_CHUNK_SORT(16, 2, 8); break;
+        default: KEAKI_CHUNK_SORT(16, 4, 4); break;
+      }
+#undef KEAKI_CHUNK_SORT
+    }
+    ST_TRY(launch_check(ctx, "chunk_sort"));
+    const SortView view = {sorted, bins, segtab, segoff, ps};
+    // bucket schedule: descending size
+    HIP_TRY(ctx, hipMemsetAsync(ghist, 0, CNT_BINS * 4 + sizeof(HeavyList), st));
+    hipLaunchKernelGGL(k_cnt_hist, dim3(cdiv(nb, 1024)), dim3(256), 0, st, (const u32*)hist, (u32)nb, ghist, hv, hv_cap, hv_slice_cap, hv_bucket, hv_first,
+                       hv_owner);
+    hipLaunchKernelGGL(k_cnt_offsets, dim3(1), dim3(CNT_BINS), 0, st, (const u32*)ghist, gstart);
+    hipLaunchKernelGGL(k_cnt_scatter, dim3(cdiv(nb, 1024)), dim3(256), 0, st, (const u32*)hist, (u32)nb, gstart, perm);
+    ST_TRY(launch_check(ctx, "cnt_sort"));
+    if (ctx->timing && last) (void)hipEventRecord(ctx->ev[1], st);
+    const dim3 ga(cdiv(nb, 256)), ba(256);
+    bool done = false;
+    if constexpr (std::is_same<F, Fq>::value) {
+      if (u29) {
+#define KEAKI_ACC(NT, MODE) hipLaunchKernelGGL((k_msm_accumulate_g1_u29<NT, MODE>), ga, ba, 0, st, pts, view, (const u32*)hist, (const u32*)perm, (u32)nb, buckets, state29)
+        if (K == 1) { if (ctx->tune.acc_nt) KEAKI_ACC(1, ACC_WHOLE); else KEAKI_ACC(0, ACC_WHOLE); }
+        else if (first) KEAKI_ACC(0, ACC_FIRST);
+        else if (!last) KEAKI_ACC(0, ACC_MIDDLE);
+        else KEAKI_ACC(0, ACC_LAST);
+#undef KEAKI_ACC
+        done = true;
+      }
+    }
+    if constexpr (std::is_same<F, Fq2>::value) {
+      if (u29) {
+        if (first) hipLaunchKernelGGL(k_msm_accumulate_g2_u29<0>, ga, ba, 0, st, pts, view, (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
+        else hipLaunchKernelGGL(k_msm_accumulate_g2_u29<1>, ga, ba, 0, st, pts, view, (const u32*)hist, (const u32*)perm, (u32)nb, buckets);
+        done = true;
+      }
+    }
+    if (!done)
+      hipLaunchKernelGGL((k_msm_accumulate<F>), ga, ba, 0, st, pts, view, (const u32*)hist, (const u32*)perm, (u32)nb, buckets, first ? 0u : 1u);
+    ST_TRY(launch_check(ctx, "msm_accumulate"));
+    // heavy buckets (structured scalars only; the grids exit after one load otherwise)
+    const u32 hv_mode = lazy_state && !last ? (first ? HV_SET29 : HV_ADD29) : (first ? HV_SET : HV_ADD);
+    hipLaunchKernelGGL((k_msm_heavy<F>), dim3(HEAVY_GRID), dim3(256), 0, st, pts, view, (const u32*)hist,
+                       (const HeavyList*)hv, hv_slice_cap, (const u32*)hv_bucket, (const u32*)hv_first, (const u32*)hv_owner, hv_slices);
+    hipLaunchKernelGGL((k_msm_heavy_combine<F>), dim3(HEAVY_COMBINE_GRID), dim3(64), 0, st, (const u32*)hist, (const HeavyList*)hv, hv_cap, hv_slice_cap,
+                       (const u32*)hv_bucket, (const u32*)hv_first, (const Xyzz<F>*)hv_slices, buckets, hv_mode, state29);
+    ST_TRY(launch_check(ctx, "msm_heavy"));
   }
-  if constexpr (std::is_same<F, Fq2>::value) {
-    u29 = ctx->tune.acc_u29_g2;                              // A/B switch for profiling
-    if (u29)
-      hipLaunchKernelGGL(k_msm_accumulate_g2_u29, dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, view, (const u32*)hist,
-                         (const u32*)perm, (u32)nb, buckets);
-  }
-  if (!u29)
-    hipLaunchKernelGGL((k_msm_accumulate<F>), dim3(cdiv(nb, 256)), dim3(256), 0, st, d_points, view, (const u32*)hist,
-                       (const u32*)perm, (u32)nb, buckets);
-  ST_TRY(launch_check(ctx, "msm_accumulate"));
-  // heavy buckets (structured scalars only; the grids exit after one load otherwise)
-  hipLaunchKernelGGL((k_msm_heavy<F>), dim3(HEAVY_GRID), dim3(256), 0, st, d_points, view, (const u32*)hist,
-                     (const HeavyList*)hv, hv_slice_cap, (const u32*)hv_bucket, (const u32*)hv_first, (const u32*)hv_owner, hv_slices);
-  hipLaunchKernelGGL((k_msm_heavy_combine<F>), dim3(HEAVY_COMBINE_GRID), dim3(64), 0, st, (const u32*)hist, (const HeavyList*)hv, hv_cap, hv_slice_cap,
-                     (const u32*)hv_bucket, (const u32*)hv_first, (const Xyzz<F>*)hv_slices, buckets);
-  ST_TRY(launch_check(ctx, "msm_heavy"));
   if (ctx->timing) (void)hipEventRecord(ctx->ev[2], st);
   hipLaunchKernelGGL((k_msm_reduce<F>), dim3(cdiv((size_t)rs.W * chunks, 64)), dim3(64), 0, st, (const Xyzz<F>*)buckets, rs, L, chunks, partials);
   // chunk partials -> (at most 128 per window) -> window sums
