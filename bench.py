@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--strong-log2n", type=int, default=26)
     ap.add_argument("--no-extras", action="store_true", help="skip value_no_tables / value_incl_scalar_h2d / strong / fk / laconic")
     ap.add_argument("--fk-log2d", type=int, default=21, help="log2 of the FK23 domain of the `fk` block (BASELINE config 5: 2^21); 0 disables")
+    ap.add_argument("--g2-log2n", type=int, default=20, help="log2 of the points of the `msm_g2` block; 0 disables")
     ap.add_argument("--laconic-log2n", type=int, default=20, help="log2 of the receiver bits of the `laconic` block (BASELINE config 5: 2^20); 0 disables")
     args = ap.parse_args()
 
@@ -284,25 +285,103 @@ def main():
             checks["no_tables_equals_tables"] = bool(torch.equal(r_gen, r_tab))
             inst.count = 2                                       # the last table-path step used vector 1
             gen.close()
-        # (2) scalars start in (pinned) HOST memory: keaki_hip_msm_g1 copies them in -- the PCIe-inclusive rate, never `value`
-        h_pinned = torch.from_numpy(inst.s_host[0].view(np.int64)).pin_memory()
-        out_host = np.zeros(12, np.uint64)
+        # (2) scalars start in HOST memory: keaki_hip_msm_g1 copies them in -- the PCIe-inclusive rate, never `value`. Since round 5 the call
+        # uploads in point-range chunks on a copy stream and the kernels of chunk j run under the copy of chunk j + 1 (csrc/api.hip:
+        # msm_from_host). Three figures: pinned source (as rounds 1-4 measured it), pageable source (what a Rust Vec / numpy array is), and
+        # the pinned source with the chunking switched off (one copy in front of the kernels = the round-4 path).
         import ctypes as C
+        h_page = inst.s_host[0]
+        h_pinned = torch.from_numpy(h_page.view(np.int64)).pin_memory()
+        out_host = np.zeros(12, np.uint64)
 
-        def host_call():
-            st = hip.lib.keaki_hip_msm_g1(hip.ctx, inst.sm.srs.handle, C.c_void_p(h_pinned.data_ptr()), n, out_host.ctypes.data_as(C.c_void_p))
-            if st != 0:
-                raise SystemExit("keaki_hip_msm_g1 failed: %s" % hip.lib.keaki_hip_last_error(hip.ctx).decode())
-        host_call()
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(2):
+        host_calls_ms = {}
+
+        def host_rate(ptr, tag, calls=4):
+            def host_call():
+                st = hip.lib.keaki_hip_msm_g1(hip.ctx, inst.sm.srs.handle, C.c_void_p(ptr), n, out_host.ctypes.data_as(C.c_void_p))
+                if st != 0:
+                    raise SystemExit("keaki_hip_msm_g1 failed: %s" % hip.lib.keaki_hip_last_error(hip.ctx).decode())
             host_call()
-        sync_all()
-        el = max_over_ranks(time.perf_counter() - t0)
-        extras["value_incl_scalar_h2d"] = n * world * 2 / el
-        extras["value_incl_scalar_h2d_note"] = "host-pointer keaki_hip_msm_g1: %d MiB of scalars copied from pinned host memory inside every call" % (n * 32 >> 20)
+            sync_all()
+            per = []
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                t1 = time.perf_counter()
+                host_call()                                  # returns when the result is in out_host
+                per.append(round((time.perf_counter() - t1) * 1e3, 3))
+            sync_all()
+            host_calls_ms[tag] = per
+            return n * world * calls / max_over_ranks(time.perf_counter() - t0), out_host.copy()
+        inst.sm.run(inst.d_s[0].data_ptr())
+        torch.cuda.synchronize(dev)
+        want = jac_to_affine_words(inst.sm.part.cpu().numpy().view(np.uint64))      # this rank's resident-scalar result for vector 0
+        inst.count = 1
+        extras["value_incl_scalar_h2d"], o1 = host_rate(h_pinned.data_ptr(), "pinned")
+        extras["value_incl_scalar_h2d_pageable"], o2 = host_rate(h_page.ctypes.data, "pageable")
+        hip.set_option("msm_pipe_chunks", 0)
+        extras["value_incl_scalar_h2d_one_copy_in_front"], o3 = host_rate(h_pinned.data_ptr(), "one_copy_in_front", 2)
+        hip.set_option("msm_pipe_chunks", -1)
+        checks["host_pointer_equals_resident"] = bool(all(np.array_equal(jac_to_affine_words(o), want) for o in (o1, o2, o3)))
+        extras["value_incl_scalar_h2d_note"] = ("host-pointer keaki_hip_msm_g1 (kzg::commit's call, src/kzg.rs:89-101): %d MiB of scalars come from host memory inside every call, "
+                                                "uploaded in growing point-range chunks under the kernels of the chunk before (first key: pinned source; _pageable: a plain "
+                                                "numpy array; _one_copy_in_front: option msm_pipe_chunks = 0, the path of rounds 1-4)" % (n * 32 >> 20))
+        extras["value_incl_scalar_h2d_calls_ms"] = host_calls_ms
         del h_pinned
+
+    # ---- G2 MSM (north_star: "Pippenger variable-base MSM over BN254 G1/G2"; keaki itself only forms [tau]_2 and ciphertexts on G2) -------------
+    msm_g2 = None
+    if not args.no_extras and args.g2_log2n > 0 and rank == 0:
+        n2 = 1 << min(args.g2_log2n, args.log2n)
+        g2_words = []
+        for c in G2_GEN:
+            g2_words += mont_words(c)
+        d_g2gen = torch.from_numpy(np.array(g2_words, np.uint64).view(np.int64)).to(dev)
+        d_k2 = torch.from_numpy(inst.k_host[:n2].view(np.int64).copy()).to(dev)
+        d_pts2 = torch.empty((n2, 16), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)
+        hip.g2_mul_batch_dev(d_g2gen.data_ptr(), 0, d_k2.data_ptr(), n2, d_pts2.data_ptr())      # Q_i = k_i g2: valid r-torsion points
+        hip.synchronize()
+        del d_k2
+        srs2 = hip.srs_g2_wrap_dev(d_pts2.data_ptr(), n2)
+        d_out2 = torch.zeros(24, dtype=torch.int64, device=dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def g2_rate(reps=3):
+            hip.msm_g2_dev(srs2, inst.d_s[0].data_ptr(), n2, d_out2.data_ptr())
+            sync_all_local()
+            ev0.record(stream)
+            for i in range(reps):
+                hip.msm_g2_dev(srs2, inst.d_s[i & 1].data_ptr(), n2, d_out2.data_ptr())
+            ev1.record(stream)
+            sync_all_local()
+            return ev0.elapsed_time(ev1) / reps
+        sync_all_local = lambda: torch.cuda.synchronize(dev)
+        ms_gen = g2_rate()
+        hip.msm_g2_dev(srs2, inst.d_s[0].data_ptr(), n2, d_out2.data_ptr())
+        sync_all_local()
+        r_gen = d_out2.cpu().numpy().view(np.uint64).copy()
+        t0 = time.perf_counter()
+        g2_table_bytes = hip.srs_g2_precompute(srs2)
+        g2_setup_s = time.perf_counter() - t0
+        ms_tab = g2_rate()
+        hip.msm_g2_dev(srs2, inst.d_s[0].data_ptr(), n2, d_out2.data_ptr())
+        sync_all_local()
+        r_tab = d_out2.cpu().numpy().view(np.uint64).copy()
+        t0 = time.perf_counter()
+        r_host = hip.msm_g2(srs2, inst.s_host[0][:n2])
+        host_ms = (time.perf_counter() - t0) * 1e3
+        checks["msm_g2.tables_equals_no_tables_equals_host_pointer"] = bool(np.array_equal(r_gen, r_tab) and np.array_equal(r_host, r_tab))
+        ALGO_G2 = 160                                               # 32 B scalar + 128 B affine point
+        msm_g2 = {"workload": "2^%d-point BN254 G2 Pippenger MSM, points k_i g2 generated on the device, scalars resident (the first 2^%d of the G1 vectors)" % (int(np.log2(n2)), int(np.log2(n2))),
+                  "points": n2, "value": n2 / (ms_tab * 1e-3), "value_no_tables": n2 / (ms_gen * 1e-3), "unit": "scalar-mults/s",
+                  "ms_per_msm": ms_tab, "ms_per_msm_no_tables": ms_gen, "host_pointer_call_ms": host_ms, "window_tables_bytes": g2_table_bytes,
+                  "window_tables_setup_s": round(g2_setup_s, 3),
+                  "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate_g2_u29 (whole MSM timed, stream events)", "algorithmic_bytes": ALGO_G2 * n2,
+                               "achieved": ALGO_G2 * n2 / (ms_tab * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ALGO_G2 * n2 / (ms_tab * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "note": "integer-issue bound: ~5,600 instructions per mixed addition in Fq2 (4,700 v_mad_u64_u32), one wave per SIMD at 256 VGPRs"}}
+        g2_check = (r_tab, n2)
+        srs2.free()
+        del d_pts2
 
     # ---- BASELINE config 4: 2^26 points in TOTAL, split over the ranks (strong scaling) ----------------------------------------------
     strong = None
@@ -407,6 +486,38 @@ def main():
                                   "frac": ALGO_BYTES_PER_ENCAP * m / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                "algorithmic_bytes_per_encap": ALGO_BYTES_PER_ENCAP, "algorithmic_bytes_per_decap": ALGO_BYTES_PER_PAIRING}
         kem_check = (h_a, h_v, h_r, d_coms[0], d_tau, d_ct, d_gt, d_key, d_gt2, d_key2)
+        # integer-issue diagnostic of the throughput pairing kernel (k_pairing: a lane pair per pairing, 32 pairings per wave, 2 waves per SIMD at
+        # 255 VGPRs): VALU wave-instructions per wave from the committed counter pass x the waves of this launch / the SIMD-cycles it took
+        # = cycles per issued VALU instruction, against the issue rate of ITS mix (v_mad_u64_u32 share from the emitted ISA) at two waves per SIMD
+        try:
+            from bench_tools.srchash import library_hashes, source_hash, PAIRING_KERNEL_SOURCES
+            import ctypes as C
+            hip.lib.keaki_hip_version.restype = C.c_char_p
+            lib_pair = library_hashes(hip.lib.keaki_hip_version().decode()).get("pairing")
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r05_pairing_isa.json")))
+            cnt = json.load(open(os.path.join(ROOT, "profiles", "r05_pairing_pmc_sq_insts.json")))
+            if pj.get("kernel_source_sha256") != lib_pair or cnt.get("hashes", {}).get("pairing") != lib_pair:
+                kem["alu"] = {"note": "profiles/r05_pairing_isa.json / r05_pairing_pmc_sq_insts.json were made on other pairing kernel sources than the loaded library: refused"}
+            else:
+                valu_per_wave = float(cnt["k_pairing"]["valu_per_wave"])
+                waves = m / 32.0
+                cyc = dec_ms * 1e-3 * 2.4e9 * 1024.0 / (waves * valu_per_wave)
+                rates = {}
+                for line in open(os.path.join(ROOT, "profiles", "r01_ubench_u29_gfx950.txt")):
+                    mm = re.match(r"(v_mad_u64_u32 dependent|v_and_b32 dependent)\s+waves/SIMD=2\s.*?([0-9.]+) SIMD-cycles", line)
+                    if mm:
+                        rates[mm.group(1).split()[0]] = float(mm.group(2))
+                f_mad = float(pj["mad_fraction_static"])
+                model = f_mad * rates["v_mad_u64_u32"] + (1.0 - f_mad) * rates["v_and_b32"]
+                kem["alu"] = {"bound": "integer issue", "kernel": "k_pairing (decaps_per_s / pairings_per_s)", "valu_wave_instructions_per_pairing": valu_per_wave / 32.0,
+                              "valu_per_wave_of_32_pairings": valu_per_wave, "waves_per_simd": 2, "simd_cycles_per_valu_instruction_measured": cyc,
+                              "simd_cycles_per_valu_instruction_at_issue_rate": model, "frac": model / cyc, "v_mad_u64_u32_share": f_mad,
+                              "issue_cycles_at_two_waves": rates,
+                              "sources": ["profiles/r05_pairing_pmc_sq_insts.json", "profiles/r05_pairing_isa.json", "profiles/r01_ubench_u29_gfx950.txt"],
+                              "note": "dec_ms includes the KDF kernel (k_blake3_gt_xof, < 1 %); frac = how close the launch runs to the issue rate of its own "
+                                      "instruction mix at the two waves per SIMD its 255 registers allow -- a schedule diagnostic, not a claim that the stream is minimal"}
+        except (OSError, ValueError, KeyError) as e:
+            kem["alu"] = {"note": "no committed counter / ISA file (%s: %s)" % (type(e).__name__, e)}
 
     # ---- FK23 batch openings (kzg::open_fk, src/kzg.rs:157-203): the kernel family that dominates Receiver::new of BASELINE config 5 ----
     fk = None
@@ -469,6 +580,17 @@ def main():
                 fk["alu"]["valu_per_wave"] = {"radix4_pass_per_group_of_four_points": pick("fft_stage4<true"),
                                               "radix2_one_twiddle_per_wave_per_butterfly": pick("stage_map<true, true, false"),
                                               "radix2_twiddle_per_lane_per_butterfly": pick("stage_map<true, false, true")}
+                # cycles per issued VALU instruction of the stage kernels: the wave-instructions of one call (counter pass) over the SIMD-cycles of
+                # the stages (events of this run), against the plain / multiply-add issue rates at the stage kernels' occupancy (2 waves per SIMD)
+                sj = json.load(open(os.path.join(ROOT, "profiles", "r05_fk_sq_insts.json")))
+                tot_valu = sj.get("stage_kernels_valu_wave_instructions_one_call") if sj.get("hashes", {}).get("fk") == pj["hashes"]["fk"] and sj.get("log2d") == lg else None
+                if tot_valu:
+                    cyc = stages_ms * 1e-3 * 2.4e9 * 1024.0 / float(tot_valu)
+                    f_mad = 0.6                                  # share of v_mad_u64_u32 in the 29-bit product streams the ladders are made of (205-instruction product: 162)
+                    fk["alu"].update({"stage_valu_wave_instructions_per_call": float(tot_valu), "simd_cycles_per_valu_instruction_measured": cyc,
+                                      "simd_cycles_per_valu_instruction_at_issue_rate": f_mad * 4.8 + (1 - f_mad) * 4.1, "frac": (f_mad * 4.8 + (1 - f_mad) * 4.1) / cyc,
+                                      "frac_note": "SIMD-cycles of the butterfly stages of this run / VALU wave-instructions of the stage kernels in one call (profiles/r05_fk_sq_insts.json), "
+                                                   "against the issue rates of profiles/r01_ubench_u29_gfx950.txt at two waves per SIMD (4.8 multiply-add, 4.1 plain)"})
         except (OSError, ValueError, KeyError) as e:
             fk_traffic_note = "no committed PMC figure (%s)" % type(e).__name__
         fk["roofline"]["traffic"] = fk_traffic
@@ -566,7 +688,7 @@ def main():
     # HBM traffic of the dominant kernel from PMC counters (separate rocprofv3 --pmc passes, committed under profiles/, stamped with
     # the kernel sources they were measured on)
     traffic, traffic_note = None, None
-    tj, why = stamped_profile("r04_msm_2p24_hbm_traffic_pmc.json", MSM_KERNEL_SOURCES)
+    tj, why = stamped_profile("r05_msm_2p24_hbm_traffic_pmc.json", MSM_KERNEL_SOURCES)
     if tj is None:
         traffic_note = why
     elif tj.get("log2n") != args.log2n or bool(tj.get("precompute", True)) != (not args.no_precompute):
@@ -576,9 +698,9 @@ def main():
             if "k_msm_accumulate" in kname:
                 traffic = kv["fetch_bytes"] + kv["write_bytes"]
     # integer roofline: one XYZZ mixed add = 8M + 2S = 10 Montgomery products; instruction count of the loop body from the shipped
-    # ISA (bench_tools/count_isa.py -> profiles/r04_accumulate_isa.json), issue rate from the committed micro-benchmark
+    # ISA (bench_tools/count_isa.py -> profiles/r05_accumulate_isa.json), issue rate from the committed micro-benchmark
     alu = None
-    isa, isa_why = stamped_profile("r04_accumulate_isa.json", MSM_KERNEL_SOURCES)
+    isa, isa_why = stamped_profile("r05_accumulate_isa.json", MSM_KERNEL_SOURCES)
     mul_cyc, simple_cyc, cyc_src = stream_cycles_from_ubench(3)
     if isa is not None and mul_cyc is not None and simple_cyc is not None:
         ipa, mads = float(isa["loop_instructions"]), float(isa["loop_v_mad_u64_u32"])
@@ -591,7 +713,7 @@ def main():
         alu = {"bound": "integer issue (v_mad_u64_u32 streams)", "achieved": modmuls / 1e9, "peak": modmuls / 1e9 * measured_cycles / model_cycles, "unit": "G modmul/s",
                "frac": model_cycles / measured_cycles, "simd_cycles_per_mixed_add_measured": measured_cycles, "simd_cycles_per_mixed_add_at_stream_rate": model_cycles,
                "issues_per_mixed_add": ipa, "v_mad_u64_u32_per_mixed_add": mads, "product_stream_cycles": mul_cyc, "plain_valu_cycles": simple_cyc,
-               "sources": ["profiles/r04_accumulate_isa.json", cyc_src],
+               "sources": ["profiles/r05_accumulate_isa.json", cyc_src],
                "note": "a schedule diagnostic (how close the kernel runs to the issue rate of ITS OWN instruction stream at 3 waves per SIMD and "
                        "2.4 GHz), not a claim that the stream is minimal"}
     else:
@@ -625,6 +747,7 @@ def main():
         "kem": kem,
         "alu": alu,
         "fk": fk,
+        "msm_g2": msm_g2,
         "laconic": laconic,
         "single_calls": single,
     }
@@ -679,6 +802,41 @@ def main():
             checks["kem_bit_exact"] = bool(ok)
             kem["cpu_baseline"] = {"encaps_per_s": mc / ce, "decaps_per_s": mc / cd, "cores": 1, "kind": "port",
                                    "sample": "first %d items, CPU restatement of src/kem.rs:13-72; GPU ct/GT/key bytes bit-exact: %s" % (mc, bool(ok))}
+    if msm_g2 is not None and oc is not None:
+        r_tab, n2 = g2_check
+        _, g2g = oc.generators()
+        exp2 = oc.g2_mul_batch(g2g, oc.fr_dot(inst.s_host[0][:n2], inst.k_host[:n2]).reshape(1, 4))[0]
+        from keaki_amd.hip import jac_to_affine_words as _j2a
+        checks["msm_g2.full_size_check"] = bool(np.array_equal(_j2a(r_tab), exp2))
+        msm_g2["checked"] = "MSM(s, k_i g2) == (sum s_i k_i) g2 at full size, tables == no tables == host-pointer call: %s" % (
+            checks["msm_g2.full_size_check"] and checks["msm_g2.tables_equals_no_tables_equals_host_pointer"])
+    if single is not None and oc is not None:
+        # the same five calls on ONE host core through the CPU restatement (the stand-in for keaki's single-threaded arkworks path)
+        g1g, g2g = oc.generators()
+        cp = oc.g1_mul_batch(g1g, random_fr_limbs(129, 51), threads=os.cpu_count() or 1)
+        cs, cz = random_fr_limbs(129, 52), random_fr_limbs(1, 53)[0]
+        cq = oc.g2_mul_batch(g2g, random_fr_limbs(2, 54))
+        ca, cv, cr = random_fr_limbs(1, 55), random_fr_limbs(1, 56), random_fr_limbs(1, 57)
+
+        def cpu_ms(fn, reps=3):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            return round((time.perf_counter() - t0) / reps * 1e3, 3)
+
+        def cpu_open():
+            q, _ = oc.fr_quotient(cs, cz)
+            oc.msm_g1(cp[:128], q, threads=1)
+
+        def cpu_verify():                                        # two fixed-base mults + two pairings (src/kzg.rs:135-148)
+            oc.g1_mul_batch(g1g, cv, threads=1); oc.g2_mul_batch(g2g, ca, threads=1)
+            oc.pairing_batch(cp[:2], cq, threads=1)
+        c_ct = oc.encap_batch(cp[0], cq[0], ca, cv, cr, 32, threads=1)[0]
+        single["cpu_ms"] = {"commit": cpu_ms(lambda: oc.msm_g1(cp, cs, threads=1)), "open": cpu_ms(cpu_open), "verify": cpu_ms(cpu_verify),
+                            "encapsulate": cpu_ms(lambda: oc.encap_batch(cp[0], cq[0], ca, cv, cr, 32, threads=1)),
+                            "decapsulate": cpu_ms(lambda: oc.decap_batch(cp[:1], c_ct, 32, threads=1)), "cores": 1, "kind": "port",
+                            "note": "the same five calls through the CPU restatement (oracle/, the checker) on one host core, same shapes (129 coefficients, 32-byte key)"}
     if fk is not None and oc is not None:
         # two proofs against the oracle's per-point opening (its quotient, its MSM over the downloaded points)
         fsrs, coeffs, proofs, om = fk_check

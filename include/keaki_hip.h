@@ -99,7 +99,20 @@ const char* keaki_hip_version(void);
  * fixed-base path and below which -- for a commitment that has no table yet -- it runs a pairing per item; -1 = automatic: always the GT path),
  * "pair_wide_max" (pairing batches up to this size run the twelve-lanes-per-pairing kernel; -1 = automatic (4096), 0 = never), "pair_two_waves"
  * (up to 1,024 pairings: the line side of the Miller loop on a second wave; 0 = one wave), "msm_short_tables" (an MSM over less than half of an SRS
- * with window tables: 0 = the generic path as before round 4, 1 / -1 = the tables). Unknown name -> KEAKI_ERR_BAD_ARG. */
+ * with window tables: 0 = the generic path as before round 4, 1 / -1 = the tables).
+ * What the library does with HOST memory of the caller, and its off switches (round 5):
+ *   "host_prefault" (default 1): while the kernels of a host-array call run, the library first-touches the caller's OUTPUT arrays (writes a zero
+ *       into one byte per 4 KB page, the whole range being overwritten by the download that follows; outputs >= 1 MB only) and asks for transparent
+ *       huge pages on them (madvise(MADV_HUGEPAGE)); chunked batches do this on up to three helper std::threads that live for the duration of
+ *       the call. 0: no helper threads, no write into and no madvise on caller memory -- every byte that appears in an output array was put there
+ *       by a device-to-host copy. Results are identical; downloads into pages that do not exist yet are slower (160 MB: 30 ms instead of 3).
+ *   "pipe_chunks" (default 1): host-array batches (encap / decap / encrypt / decrypt from 2 x 65,536 items on; MSMs from "msm_pipe_min" scalars on)
+ *       run as chunk pipelines over a copy stream of the context's own. 0: upload, kernels, download, in that order, on the context's stream.
+ *   "msm_pipe_chunks" (-1 = automatic: 6 chunks from 2^22 scalars on, 3 from "msm_pipe_min" = 2^20 on; 0 / 1 = one copy in front; k >= 2 = k chunks at
+ *       any length), "msm_pipe_growth" (size of chunk j + 1 in percent of chunk j, default 140: a short first chunk starts the device early).
+ *   A host-array call that FAILS (status != KEAKI_OK) leaves its output arrays unspecified: any prefix may hold results, and with
+ *   "host_prefault" = 1 pages may hold the zeros of the first touch. Input arrays are never written.
+ * Unknown name -> KEAKI_ERR_BAD_ARG. */
 keaki_status keaki_hip_ctx_set_option(keaki_hip_ctx* ctx, const char* name, int64_t value);
 /* Test hook: every single device allocation of this ctx above `bytes` fails with KEAKI_ERR_OOM (0 = no limit). This is how the tests
  * exercise the optional-memory fallbacks (SRS window tables, the wide GT table); nothing in the library sets it. */
@@ -135,7 +148,12 @@ void keaki_hip_srs_g2_free(keaki_hip_ctx* ctx, keaki_hip_srs_g2* srs);
 /* ---- MSM: replaces <E::G1 as VariableBaseMSM>::msm_unchecked(&setup.g1_aff, p) (src/kzg.rs:98) -
  * out = sum_{i<n} scalars[i] * srs[i]; n <= len(srs) (zip-truncation as msm_unchecked).
  * n > len(srs) -> KEAKI_ERR_TOO_LARGE (the check of src/kzg.rs:93-95 lives in the caller, this is a guard).
- * out_jac: u64[12] normalised Jacobian. */
+ * out_jac: u64[12] normalised Jacobian.
+ * Host-pointer form (what kzg::commit calls, src/kzg.rs:89-101: the polynomial lives in host memory): from 2^20 scalars on the vector is
+ * uploaded in growing point-range chunks on the context's copy stream while the sort and bucket kernels of the chunk before run; every
+ * bucket pass goes on from the state the earlier chunks left, one reduction closes the call (2^24 scalars: 18.1 ms against 28 ms with
+ * the copy in front and 16.6 ms with resident scalars). The result is the same group element whatever the cut. Pageable and pinned
+ * sources both work; the call returns when out_jac holds the result and no copy reads `scalars` any more. */
 keaki_status keaki_hip_msm_g1(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, const uint64_t* scalars, size_t n, uint64_t* out_jac);
 /* device-resident scalars and output (d_out_jac: 96 bytes of device memory); asynchronous on the ctx stream */
 keaki_status keaki_hip_msm_g1_dev(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs, const void* d_scalars, size_t n, void* d_out_jac);

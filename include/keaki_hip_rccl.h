@@ -23,6 +23,8 @@ const char* keaki_hip_rccl_last_error(const keaki_hip_rccl* rc); /* rc may be NU
 /* d_out_jac (96 bytes of device memory) = sum over all ranks of MSM(srs_chunk, d_scalars[0..n)): asynchronous on the ctx stream.
  * Failure is collective-safe: a rank whose own share fails (bad handle, out of memory) returns its error at once but STILL takes part in the
  * exchange with the identity as its partial, so the other ranks never wait for it; they learn of it from keaki_hip_rccl_collective_status.
+ * A caller that consumes d_out_jac MUST call keaki_hip_rccl_collective_status first (it is the only place a peer's failure surfaces: without
+ * it a failed peer yields a sum that silently lacks its chunk); before the first MSM it reports KEAKI_OK.
  * After KEAKI_ERR_RCCL from any entry point the communicator is dead: destroy it. */
 keaki_status keaki_hip_rccl_msm_g1(keaki_hip_rccl* rc, const keaki_hip_srs_g1* srs_chunk, const void* d_scalars, size_t n, void* d_out_jac);
 /* Waits for the stream; KEAKI_OK when every rank's share of the last keaki_hip_rccl_msm_g1 succeeded, else the first failing rank's status

@@ -46,6 +46,7 @@ struct keaki_hip_srs_g2 {
 #include <memory>
 #include <thread>
 #include <atomic>
+#include <chrono>
 namespace {
 // roctx ranges around the kernel families (tracing), visible to `rocprofv3 --marker-trace`. The marker library is
 // looked up at run time so that the ABI has no link-time dependency on the profiler; without it the scopes are no-ops.
@@ -74,14 +75,18 @@ thread_local std::string g_create_error;
 // must be able to undo the byte accounting on the context that built the tables -- if that context still exists.
 std::mutex g_live_mu;
 std::set<keaki_hip_ctx*> g_live_ctx;
-// runs `f(acct)` under acct's lock when acct is a live context
+// runs `f(acct)` when acct is a live context. Under g_live_mu ONLY: the caller may already hold its own context's lock, and taking another
+// context's lock from here would order the two locks both ways (thread A: ctx1 -> live -> ctx2, thread B: ctx2 -> live). What f touches --
+// the byte count `mem_tables` -- is an atomic for that reason.
 template <class Fn>
 void with_live_ctx(keaki_hip_ctx* acct, Fn f) {
   std::lock_guard<std::mutex> lk(g_live_mu);
-  if (acct && g_live_ctx.count(acct)) {
-    std::lock_guard<std::recursive_mutex> lock_(acct->mu);
-    f(acct);
-  }
+  if (acct && g_live_ctx.count(acct)) f(acct);
+}
+// saturating subtraction on the byte count (a handle freed twice over, or booked before a trim, must not wrap it)
+void mem_sub(std::atomic<size_t>& m, size_t v) {
+  size_t cur = m.load();
+  while (!m.compare_exchange_weak(cur, cur - std::min(cur, v))) {}
 }
 constexpr size_t G1_AFF_BYTES = 64, G2_AFF_BYTES = 128;
 }  // namespace
@@ -174,7 +179,7 @@ void fk_account(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs) {
   if (now == srs->fk_bytes) return;
   if (!srs->acct) srs->acct = ctx;
   const size_t before = srs->fk_bytes;
-  with_live_ctx(srs->acct, [&](keaki_hip_ctx* a) { a->mem_tables -= std::min(a->mem_tables, before); a->mem_tables += now; });   // whichever context rebuilt it
+  with_live_ctx(srs->acct, [&](keaki_hip_ctx* a) { mem_sub(a->mem_tables, before); a->mem_tables += now; });   // whichever context rebuilt it
   srs->fk_bytes = now;
 }
 template <class H>
@@ -196,8 +201,8 @@ H* new_srs(keaki_hip_ctx* ctx, const void* d, size_t n, bool owned) {
 // kernel does not offer it): first touch of 160 MB takes 20.5 ms in 4 KB pages and 6.5 ms in 2 MB pages on the GPU boxes
 // (bench_tools/ubench_thp_touch.py). At 2^20 items the faults hide behind the kernels either way (vec_encrypt 52.6 vs 52.0 ms); the hint matters
 // where the output is large against the kernel time (GT bytes out: 384 B per item).
-void prefault_out(void* p, size_t bytes) {
-  if (!p || bytes < (1u << 20)) return;
+void prefault_out(const keaki_hip_ctx* ctx, void* p, size_t bytes) {
+  if (!ctx->tune.host_prefault || !p || bytes < (1u << 20)) return;    // option host_prefault = 0: the library never writes to (or madvises) caller memory itself
   {
     // memory the HIP runtime knows (hipHostMalloc / hipHostRegister: resident by construction, and copies from and to it are truly asynchronous,
     // so a write from here could overtake an upload still reading the same array): nothing to touch
@@ -240,7 +245,7 @@ static keaki_status pipe_ready(keaki_hip_ctx* ctx) {
 }
 // chunk size of a batch of n items: `unit` items (PIPE_CHUNK: two rounds of the GT exponentiation kernel; the pairing path passes its own launch
 // size -- 16 launches of 2^16 pairings take 3.6 ms longer than 8 of 2^17), the whole batch below two units
-inline size_t pipe_chunk_items(size_t n, size_t unit = PIPE_CHUNK) { return n >= 2 * unit ? unit : n; }
+inline size_t pipe_chunk_items(const keaki_hip_ctx* ctx, size_t n, size_t unit = PIPE_CHUNK) { return ctx->tune.pipe_chunks && n >= 2 * unit ? unit : n; }
 // `touch(lo, m)`: first-touch the caller's output ranges of items [lo, lo + m) (prefault_out). A download into pages that do not exist yet runs
 // at 5 GB/s instead of 56 (bench_tools/ubench_pageable_copy_sizes.py), and touching them costs the host 40-125 us per MB: with one chunk that
 // happens on the calling thread while the kernels run; with more, helper threads walk the chunks ahead of the downloads (one thread, three
@@ -250,7 +255,7 @@ static keaki_status pipelined(keaki_hip_ctx* ctx, size_t n, size_t ch, size_t ou
   ST_TRY(pipe_ready(ctx));
   const size_t chunks = (n + ch - 1) / ch;
   hipStream_t cs = ctx->copy_stream, st = ctx->stream;
-  const size_t n_helpers = chunks < 2 ? 0 : (n * out_bytes_per_item >= ((size_t)64 << 20) ? std::min<size_t>(3, chunks) : 1);
+  const size_t n_helpers = chunks < 2 || !ctx->tune.host_prefault ? 0 : (n * out_bytes_per_item >= ((size_t)64 << 20) ? std::min<size_t>(3, chunks) : 1);
   std::unique_ptr<std::atomic<unsigned char>[]> touched(new std::atomic<unsigned char>[chunks]);
   for (size_t k = 0; k < chunks; k++) touched[k].store(0, std::memory_order_relaxed);
   // a helper touches (writes into) the output pages of chunk k only after chunk k's inputs have been read: a caller may pass one array as input
@@ -266,9 +271,11 @@ static keaki_status pipelined(keaki_hip_ctx* ctx, size_t n, size_t ch, size_t ou
   for (size_t h = 0; h < n_helpers; h++)
     helpers.t.emplace_back([&, h] {
       for (size_t k = h; k < chunks; k += n_helpers) {
-        while (staged.load(std::memory_order_acquire) <= k) {          // yield, not sleep: sleep_for(50 us) wakes late enough under load to cost
-          if (give_up.load(std::memory_order_relaxed)) return;         // a 2^20-item call 20 ms (measured: encap with GT out 57 -> 73 ms)
-          std::this_thread::yield();
+        // yield first, not sleep: sleep_for(50 us) wakes late enough under load to cost a 2^20-item call 20 ms (measured: encap with GT out
+        // 57 -> 73 ms). A wait that outlasts ~2 ms (the device is far behind: nothing to gain from a hot loop) falls back to short sleeps.
+        for (unsigned spins = 0; staged.load(std::memory_order_acquire) <= k; spins++) {
+          if (give_up.load(std::memory_order_relaxed)) return;
+          if (spins < 20000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
         }
         touch(k * ch, std::min(ch, n - k * ch));
         touched[k].store(1, std::memory_order_release);
@@ -292,7 +299,9 @@ static keaki_status pipelined(keaki_hip_ctx* ctx, size_t n, size_t ch, size_t ou
       const size_t lo = (k - 1) * ch, m = std::min(ch, n - lo);
       const int h = (int)((k - 1) & 1);
       if (!n_helpers) touch(lo, m);
-      else while (!touched[k - 1].load(std::memory_order_acquire)) std::this_thread::yield();
+      else for (unsigned spins = 0; !touched[k - 1].load(std::memory_order_acquire); spins++) {
+        if (spins < 20000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
+      }
       HIP_TRY(ctx, hipStreamWaitEvent(cs, ctx->pipe_done[h], 0));
       ST_TRY(down(lo, m, h, cs));
     }
@@ -314,7 +323,7 @@ static keaki_status pipelined(keaki_hip_ctx* ctx, size_t n, size_t ch, size_t ou
 static std::vector<size_t> msm_pipe_bounds(const Tuning& t, size_t n) {
   size_t k = 1;
   if (t.msm_pipe_chunks >= 2) k = (size_t)t.msm_pipe_chunks;
-  else if (t.msm_pipe_chunks < 0 && n >= (size_t)t.msm_pipe_min) k = n >= ((size_t)1 << 22) ? 6 : 3;
+  else if (t.msm_pipe_chunks < 0 && t.pipe_chunks && n >= (size_t)t.msm_pipe_min) k = n >= ((size_t)1 << 22) ? 6 : 3;
   if (k > 64) k = 64;
   if (k > n) k = n ? n : 1;
   std::vector<size_t> b{0};
@@ -403,6 +412,8 @@ void tune_from_env(Tuning& t) {
   if (geti("KEAKI_PAIR_TWO_WAVES", v)) t.pair_two_waves = v != 0;
   if (geti("KEAKI_GT_WB_B", v)) t.gt_wb_b = (int)v;
   if (geti("KEAKI_ENCAP_GT", v)) t.encap_gt = v;
+  if (geti("KEAKI_HOST_PREFAULT", v)) t.host_prefault = v != 0;
+  if (geti("KEAKI_PIPE_CHUNKS", v)) t.pipe_chunks = v != 0;
   if (geti("KEAKI_MSM_PIPE_CHUNKS", v)) t.msm_pipe_chunks = (int)v;
   if (geti("KEAKI_MSM_PIPE_MIN", v)) t.msm_pipe_min = v;
   if (geti("KEAKI_MSM_PIPE_GROWTH", v)) t.msm_pipe_growth = (int)v;
@@ -510,6 +521,8 @@ keaki_status keaki_hip_ctx_set_option(keaki_hip_ctx* ctx, const char* name, int6
     if ((int)value != t.gt_wb_b) { ctx->gt_b_ready = false; ctx->gt_b_fallback = false; }      // the table of B is rebuilt at the new width on the next use
     t.gt_wb_b = (int)value;
   } else if (k == "encap_gt") t.encap_gt = value;
+  else if (k == "host_prefault") t.host_prefault = value != 0;
+  else if (k == "pipe_chunks") t.pipe_chunks = value != 0;
   else if (k == "msm_pipe_chunks") t.msm_pipe_chunks = (int)value;
   else if (k == "msm_pipe_min") t.msm_pipe_min = value;
   else if (k == "msm_pipe_growth") t.msm_pipe_growth = (int)value;
@@ -527,9 +540,12 @@ keaki_status keaki_hip_debug_set_alloc_limit(keaki_hip_ctx* ctx, size_t bytes) {
 keaki_status keaki_hip_ctx_trim(keaki_hip_ctx* ctx) {
   CTX_GUARD(ctx);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->aux_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->aux_stream));      // a table build a failed call left behind
+  if (ctx->copy_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
   for (const BufClass& bc : all_bufs(ctx))
     if (bc.b->p) { (void)hipFree(bc.b->p); bc.b->p = nullptr; bc.b->cap = 0; }
   ctx->gt_b_ready = ctx->gt_a_valid = ctx->gt_b_fallback = false;
+  ctx->gt_a_pending_aux = false;
   ctx->seen_com_runs = 0;
   ctx->verify_ready = ctx->verify_tables_ready = false;
   ctx->fb_tau_valid = ctx->g2gen_lines_ready = ctx->fb_ready = ctx->g2pow_ready = false;
@@ -615,7 +631,7 @@ void keaki_hip_srs_g1_free(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs) {
   if (srs->table) (void)hipFree(srs->table);
   if (srs->fk_hat_s) (void)hipFree(srs->fk_hat_s);
   const size_t held = srs->table_bytes + srs->fk_bytes;          // booked on the context that built them, whichever context (or NULL) frees the handle
-  with_live_ctx(srs->acct, [&](keaki_hip_ctx* a) { a->mem_tables -= std::min(a->mem_tables, held); });
+  with_live_ctx(srs->acct, [&](keaki_hip_ctx* a) { mem_sub(a->mem_tables, held); });
   delete srs;
 }
 keaki_status keaki_hip_srs_g1_precompute(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, size_t* table_bytes_out) {
@@ -661,7 +677,7 @@ void keaki_hip_srs_g2_free(keaki_hip_ctx* ctx, keaki_hip_srs_g2* srs) {
   if (srs->owned && srs->d) (void)hipFree((void*)srs->d);
   if (srs->table) (void)hipFree(srs->table);
   const size_t held = srs->table_bytes;
-  with_live_ctx(srs->acct, [&](keaki_hip_ctx* a) { a->mem_tables -= std::min(a->mem_tables, held); });
+  with_live_ctx(srs->acct, [&](keaki_hip_ctx* a) { mem_sub(a->mem_tables, held); });
   delete srs;
 }
 keaki_status keaki_hip_srs_g2_precompute(keaki_hip_ctx* ctx, keaki_hip_srs_g2* srs, size_t* table_bytes_out) {
@@ -770,7 +786,7 @@ keaki_status keaki_hip_g1_mul_batch(keaki_hip_ctx* ctx, const uint64_t* points_a
   ST_TRY(upload(ctx, ctx->io_b, scalars, n * 32));
   ST_TRY(reserve(ctx, ctx->io_c, n * 64));
   ST_TRY(keaki_hip_g1_mul_batch_dev(ctx, ctx->io_a.p, point_stride, ctx->io_b.p, n, ctx->io_c.p));
-  prefault_out(out_aff, n * 64);
+  prefault_out(ctx, out_aff, n * 64);
   return download(ctx, out_aff, ctx->io_c.p, n * 64);
 }
 keaki_status keaki_hip_g2_mul_batch(keaki_hip_ctx* ctx, const uint64_t* points_aff, int32_t point_stride, const uint64_t* scalars, size_t n,
@@ -782,7 +798,7 @@ keaki_status keaki_hip_g2_mul_batch(keaki_hip_ctx* ctx, const uint64_t* points_a
   ST_TRY(upload(ctx, ctx->io_b, scalars, n * 32));
   ST_TRY(reserve(ctx, ctx->io_c, n * 128));
   ST_TRY(keaki_hip_g2_mul_batch_dev(ctx, ctx->io_a.p, point_stride, ctx->io_b.p, n, ctx->io_c.p));
-  prefault_out(out_aff, n * 128);
+  prefault_out(ctx, out_aff, n * 128);
   return download(ctx, out_aff, ctx->io_c.p, n * 128);
 }
 
@@ -804,7 +820,7 @@ keaki_status keaki_hip_pairing_batch(keaki_hip_ctx* ctx, const uint64_t* g1_aff,
   ST_TRY(upload(ctx, ctx->io_b, g2_aff, (g2_stride ? n : 1) * 128));
   ST_TRY(reserve(ctx, ctx->io_c, n * 384));
   ST_TRY(keaki_hip_pairing_batch_dev(ctx, ctx->io_a.p, ctx->io_b.p, g2_stride, n, ctx->io_c.p));
-  prefault_out(gt_out, n * 384);
+  prefault_out(ctx, gt_out, n * 384);
   return download(ctx, gt_out, ctx->io_c.p, n * 384);
 }
 
@@ -925,7 +941,18 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
   }
   const bool use_gt = n_policy >= gt_threshold || (!prep && !gt_env && (a_cached || ctx->seen_com_runs >= 3));
   bool a_on_aux = false, b_factor_done = false;
+  // the table of a new commitment is built on the aux stream; `gt_a_pending_aux` says that the context's stream has not been made to wait for
+  // that build yet. It survives an early error return, so a later call that finds the table published (same commitment) or rewrites gt_base
+  // orders itself behind the build first -- whatever happened in between.
+  auto wait_aux = [&]() -> keaki_status {
+    if (ctx->gt_a_pending_aux) {
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_ev[1], 0));
+      ctx->gt_a_pending_aux = false;
+    }
+    return KEAKI_OK;
+  };
   if (use_gt) {
+    ST_TRY(wait_aux());                                   // a build an earlier (failed) call left unawaited
     // GT_i = A^(r_i) B^(-beta_i r_i) with A = e(C, g2), B = e(g1, g2) (see pairing.hip.h): no pairing per item
     ST_TRY(reserve(ctx, ctx->gt_base, G1_AFF_BYTES + 320 * (G1_AFF_BYTES + 384)));   // a point | (unused since round 4) | the powers' pairings
     char* gb = (char*)ctx->gt_base.p;
@@ -962,6 +989,7 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
         ST_TRY(gt_table_of(ctx, d_com_aff, ctx->gt_tab_a.p, GT_WB_A_FIRST));
       }
       HIP_TRY(ctx, hipEventRecord(ctx->aux_ev[1], ctx->aux_stream));
+      ctx->gt_a_pending_aux = true;
       a_on_aux = true;
       if (n > 4096) {
         // the constant base's factor FIRST on the main stream: it fills every SIMD (two waves of 256 registers each) and must be out of the way
@@ -973,8 +1001,9 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
       memcpy(ctx->gt_a_com, com_host, 64);
       ctx->gt_a_wb = GT_WB_A_FIRST;
       ctx->gt_a_valid = true;
-    } else if (!prep && ctx->gt_a_wb != GT_WB_A_REPEAT) {
-      // same commitment again: the powers A^(2^s), s < 260, of the first build cover the 256 the wider table needs
+    } else if (!prep && first_of_batch && ctx->gt_a_wb != GT_WB_A_REPEAT) {
+      // same commitment again IN A LATER CALL (the chunks of one host batch keep the table their first chunk found or built): the powers
+      // A^(2^s), s < 260, of the first build cover the 256 the wider table needs
       ST_TRY(gt_table_run(ctx, gb + G1_AFF_BYTES + 320 * G1_AFF_BYTES, ctx->gt_tab_a.p, GT_WB_A_REPEAT));
       static_assert(GT_WB_A_REPEAT == 16 && GT_WB_A_FIRST == 13, "the power count of the first table must cover the second");
       ctx->gt_a_wb = GT_WB_A_REPEAT;
@@ -1017,10 +1046,10 @@ static keaki_status encap_impl(keaki_hip_ctx* ctx, bool prep, const void* d_com_
   if (use_gt) {
     if (b_factor_done) {
       // the factor of the constant base ran while the commitment's table was on its way; the commitment's factor behind it
-      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_ev[1], 0));
+      ST_TRY(wait_aux());
       ST_TRY(gt_encap_exp_run(ctx, ctx->gt_tab_a.p, ctx->gt_a_wb, nullptr, 0, d_values, d_r, n, gt, ctx->tmp_a.p, nullptr));
     } else {
-      if (a_on_aux) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_ev[1], 0));
+      ST_TRY(wait_aux());
       ST_TRY(gt_encap_exp_run(ctx, ctx->gt_tab_a.p, ctx->gt_a_wb, ctx->gt_tab_b.p, ctx->gt_b_wb, d_values, d_r, n, gt));
     }
   } else {
@@ -1080,7 +1109,7 @@ keaki_status keaki_hip_encap_batch(keaki_hip_ctx* ctx, const uint64_t* com_aff, 
   if (n == 0) return KEAKI_OK;
   if (!com_aff || !tau_g2_aff || !points || !values || !r || !ct_out_aff || (!gt_out && !key_out) || msg_len > 65536)
     return fail(ctx, KEAKI_ERR_BAD_ARG, "encap_batch: bad argument");
-  const size_t ch = pipe_chunk_items(n);
+  const size_t ch = pipe_chunk_items(ctx, n);
   const size_t off_pts = 0, off_val = off_pts + ch * 32, off_r = off_val + ch * 32, off_ct = off_r + ch * 32, off_gt = off_ct + ch * 128,
                off_key = off_gt + ch * 384, half = (off_key + ch * msg_len + 255) & ~(size_t)255;
   ST_TRY(reserve(ctx, ctx->io_a, 256 + 2 * half));
@@ -1103,9 +1132,9 @@ keaki_status keaki_hip_encap_batch(keaki_hip_ctx* ctx, const uint64_t* com_aff, 
                         msg_len, false, &eh);
     },
     [&](size_t lo, size_t m) {
-      prefault_out(ct_out_aff + 16 * lo, m * 128);
-      if (gt_out) prefault_out(gt_out + 384 * lo, m * 384);
-      if (want_key) prefault_out(key_out + msg_len * lo, m * msg_len);
+      prefault_out(ctx, ct_out_aff + 16 * lo, m * 128);
+      if (gt_out) prefault_out(ctx, gt_out + 384 * lo, m * 384);
+      if (want_key) prefault_out(ctx, key_out + msg_len * lo, m * msg_len);
     },
     [&](size_t lo, size_t m, int h, hipStream_t cs) -> keaki_status {
       char* b = base + 256 + h * half;
@@ -1121,7 +1150,7 @@ keaki_status keaki_hip_decap_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_af
   TRACE_SCOPE("keaki.decap");
   if (n == 0) return KEAKI_OK;
   if (!proofs_aff || !cts_aff || (!gt_out && !key_out) || msg_len > 65536) return fail(ctx, KEAKI_ERR_BAD_ARG, "decap_batch: bad argument");
-  const size_t ch = pipe_chunk_items(n, pairing_launch_items());
+  const size_t ch = pipe_chunk_items(ctx, n, pairing_launch_items());
   const size_t off_ct = ch * 64, off_gt = off_ct + ch * 128, off_key = off_gt + ch * 384, half = (off_key + ch * msg_len + 255) & ~(size_t)255;
   ST_TRY(reserve(ctx, ctx->io_a, 2 * half));
   char* base = (char*)ctx->io_a.p;
@@ -1140,8 +1169,8 @@ keaki_status keaki_hip_decap_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_af
       return KEAKI_OK;
     },
     [&](size_t lo, size_t m) {
-      if (gt_out) prefault_out(gt_out + 384 * lo, m * 384);
-      if (want_key) prefault_out(key_out + msg_len * lo, m * msg_len);
+      if (gt_out) prefault_out(ctx, gt_out + 384 * lo, m * 384);
+      if (want_key) prefault_out(ctx, key_out + msg_len * lo, m * msg_len);
     },
     [&](size_t lo, size_t m, int h, hipStream_t cs) -> keaki_status {
       char* b = base + h * half;
@@ -1180,7 +1209,7 @@ keaki_status keaki_hip_encrypt_batch(keaki_hip_ctx* ctx, const uint64_t* com_aff
   if (n == 0) return KEAKI_OK;
   if (!com_aff || !tau_g2_aff || !points || !values || !r || !msgs || !ct_out_aff || !body_out || msg_len == 0 || msg_len > 65536)
     return fail(ctx, KEAKI_ERR_BAD_ARG, "encrypt_batch: bad argument");
-  const size_t ch = pipe_chunk_items(n);
+  const size_t ch = pipe_chunk_items(ctx, n);
   const size_t off_pts = 0, off_val = off_pts + ch * 32, off_r = off_val + ch * 32, off_ct = off_r + ch * 32, off_body = off_ct + ch * 128,
                half = (off_body + ch * msg_len + 255) & ~(size_t)255;
   ST_TRY(reserve(ctx, ctx->io_a, 256 + 2 * half));
@@ -1202,8 +1231,8 @@ keaki_status keaki_hip_encrypt_batch(keaki_hip_ctx* ctx, const uint64_t* com_aff
       return encap_impl(ctx, false, base, base + 64, b + off_pts, b + off_val, b + off_r, m, b + off_ct, nullptr, b + off_body, msg_len, true, &eh);
     },
     [&](size_t lo, size_t m) {
-      prefault_out(ct_out_aff + 16 * lo, m * 128);
-      prefault_out(body_out + msg_len * lo, m * msg_len);
+      prefault_out(ctx, ct_out_aff + 16 * lo, m * 128);
+      prefault_out(ctx, body_out + msg_len * lo, m * msg_len);
     },
     [&](size_t lo, size_t m, int h, hipStream_t cs) -> keaki_status {
       char* b = base + 256 + h * half;
@@ -1218,7 +1247,7 @@ keaki_status keaki_hip_decrypt_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_
   TRACE_SCOPE("keaki.decrypt");
   if (n == 0) return KEAKI_OK;
   if (!proofs_aff || !cts_aff || !bodies || !msgs_out || msg_len == 0 || msg_len > 65536) return fail(ctx, KEAKI_ERR_BAD_ARG, "decrypt_batch: bad argument");
-  const size_t ch = pipe_chunk_items(n, pairing_launch_items());
+  const size_t ch = pipe_chunk_items(ctx, n, pairing_launch_items());
   const size_t off_ct = ch * 64, off_body = off_ct + ch * 128, half = (off_body + ch * msg_len + 255) & ~(size_t)255;
   ST_TRY(reserve(ctx, ctx->io_a, 2 * half));
   ST_TRY(reserve(ctx, ctx->tmp_b, ch * 384));
@@ -1236,7 +1265,7 @@ keaki_status keaki_hip_decrypt_batch(keaki_hip_ctx* ctx, const uint64_t* proofs_
       ST_TRY(pairing_run(ctx, b, b + off_ct, 1, m, ctx->tmp_b.p));
       return blake3_gt_run(ctx, ctx->tmp_b.p, m, b + off_body, msg_len, true);
     },
-    [&](size_t lo, size_t m) { prefault_out(msgs_out + msg_len * lo, m * msg_len); },
+    [&](size_t lo, size_t m) { prefault_out(ctx, msgs_out + msg_len * lo, m * msg_len); },
     [&](size_t lo, size_t m, int h, hipStream_t cs) -> keaki_status {
       char* b = base + h * half;
       HIP_TRY(ctx, hipMemcpyAsync(msgs_out + msg_len * lo, b + off_body, m * msg_len, hipMemcpyDeviceToHost, cs));
@@ -1272,7 +1301,7 @@ keaki_status keaki_hip_open_fk(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, uint32
     fk_account(ctx, srs);
   }
   ST_TRY(open_fk_run(ctx, srs->fk_hat_s, log2d, b + o_ha, b + o_t1, b + o_t2, b + o_w, b + o_p));
-  prefault_out(proofs_out_aff, d * 64);
+  prefault_out(ctx, proofs_out_aff, d * 64);
   return download(ctx, proofs_out_aff, b + o_p, d * 64);
 }
 
@@ -1293,7 +1322,7 @@ keaki_status keaki_hip_open_fk_poly(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, u
   const keaki_status st_fk = open_fk_poly_run(ctx, srs->d, &srs->fk_hat_s, &srs->fk_log2d, log2d, b + o_p, omega_2d, omega_2d_inv, inv_2d, b + o_fr, b + o_g, b + o_out);
   fk_account(ctx, srs);
   ST_TRY(st_fk);
-  prefault_out(proofs_out_aff, d * 64);
+  prefault_out(ctx, proofs_out_aff, d * 64);
   return download(ctx, proofs_out_aff, b + o_out, d * 64);
 }
 // hat_s = DFT_2d(reversed SRS) for later open_fk calls with this d: setup-time work (the FK23 analogue of keaki_hip_srs_g1_precompute)
@@ -1352,7 +1381,7 @@ keaki_status keaki_hip_vec_commit(keaki_hip_ctx* ctx, keaki_hip_srs_g1* srs, con
   ST_TRY(st_fk);
   const auto tb = srs_tables(srs);
   ST_TRY(msm_g1_run(ctx, srs->d, srs->n, b + o_c, d, b + o_com, tb.first, tb.second));     // :46 (trailing zero coefficients contribute nothing)
-  prefault_out(proofs_out_aff, d * 64);
+  prefault_out(ctx, proofs_out_aff, d * 64);
   HIP_TRY(ctx, hipMemcpyAsync(com_out_jac, b + o_com, 96, hipMemcpyDeviceToHost, st));
   ST_TRY(download(ctx, proofs_out_aff, b + o_out, d * 64));
   resolve_timing(ctx);
@@ -1455,7 +1484,7 @@ keaki_status keaki_hip_fk_shard_open(keaki_hip_ctx* ctx, keaki_hip_fk_shard* fk,
   }
   ST_TRY(reserve(ctx, ctx->io_d, d * 64));
   ST_TRY(fk_shard_open_run(ctx, fk->plan, 3, nullptr, d_recv, ctx->io_d.p));
-  prefault_out(proofs_out_aff, d * 64);
+  prefault_out(ctx, proofs_out_aff, d * 64);
   fk->open_next = 0;
   return download(ctx, proofs_out_aff, ctx->io_d.p, d * 64);
 }

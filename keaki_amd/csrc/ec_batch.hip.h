@@ -248,6 +248,11 @@ static __global__ void __launch_bounds__(64) k_encap_fixed_g2_wide(const Aff<Fq2
 // Both inner points are a caller's point plus a FIXED-base multiple: with the 8-bit window tables of g1 and g2 and sixteen lanes per sum they cost
 // 2-3 additions, a four-level tree and one conversion each (0.25 ms), where moving point * proof across the pairing (the form of rounds 2-4)
 // needs a variable-base ladder of 129 doublings in one lane (0.99 ms). Wave 0: Q = [tau]_2 + (-point) g2. Wave 1: A = com + (-value) g1.
+// Orders the LDS traffic of ONE wave: its DS operations execute in order, so a row written by all lanes is complete for every lane's read once
+// the counter has drained; the clobber keeps the compiler from moving accesses across. The two waves of k_verify_points run DIFFERENT
+// code on disjoint LDS (sh1 / sh2): a workgroup barrier inside their arms would only work while both arms happen to execute the same number of
+// barriers -- none is needed.
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 static __global__ void __launch_bounds__(128) k_verify_points(const Aff<Fq>* __restrict__ tab_g1, const Aff<Fq2>* __restrict__ tab_g2, FbShape g,
                                                               const G1Aff* __restrict__ com, const G2Aff* __restrict__ tau_g2, const Fr* __restrict__ value,
                                                               const Fr* __restrict__ point, G1Aff* __restrict__ out_a, G2Aff* __restrict__ out_q) {
@@ -277,17 +282,17 @@ static __global__ void __launch_bounds__(128) k_verify_points(const Aff<Fq>* __r
     for (u32 step = 1; step < 16u; step <<= 1) {
       const Xyzz<Fq2> mine = x29g2_store(acc);
       const uint4* mw = reinterpret_cast<const uint4*>(&mine);
-      __syncthreads();
+      wave_lds_fence();
 #pragma unroll
       for (int c = 0; c < 16; c++) sh2[c * 64 + lane] = mw[c];
-      __syncthreads();
+      wave_lds_fence();
       Xyzz<Fq2> other;
       uint4* ow = reinterpret_cast<uint4*>(&other);
 #pragma unroll
       for (int c = 0; c < 16; c++) ow[c] = sh2[c * 64 + (lane ^ step)];
       acc = x29g2_add(acc, x29g2_load(other));
     }
-    x29g2_add_mixed(acc, *tau_g2);
+    x29g2_add_mixed(acc, *tau_g2);                 // (the identity in either slot is handled inside, as for `com` below)
     const Aff<Fq2> q = xyzz_to_aff(x29g2_store(acc));
     if (lane == 0) *out_q = q;
   } else {
@@ -308,10 +313,10 @@ static __global__ void __launch_bounds__(128) k_verify_points(const Aff<Fq>* __r
     for (u32 step = 1; step < 16u; step <<= 1) {
       const Xyzz<Fq> mine = x29_store(acc);
       const uint4* mw = reinterpret_cast<const uint4*>(&mine);
-      __syncthreads();
+      wave_lds_fence();
 #pragma unroll
       for (int c = 0; c < 8; c++) sh1[c * 64 + lane] = mw[c];
-      __syncthreads();
+      wave_lds_fence();
       Xyzz<Fq> other;
       uint4* ow = reinterpret_cast<uint4*>(&other);
 #pragma unroll

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -43,6 +44,8 @@ struct Tuning {
   bool pair_two_waves = true;    // KEAKI_PAIR_TWO_WAVES / "pair_two_waves": up to 1,024 pairings with lines on the fly run the line functions on a second wave (A/B switch)
   int gt_wb_b = 0;               // KEAKI_GT_WB_B / "gt_wb_b": window bits of the table of e(g1, g2), 0 = automatic (20 / 16)
   long long encap_gt = -1;       // KEAKI_ENCAP_GT / "encap_gt": batch size from which encap takes the GT fixed-base path; -1 = automatic (always, since round 4)
+  bool host_prefault = true;     // KEAKI_HOST_PREFAULT / "host_prefault": first-touch (write zeros into) and madvise(MADV_HUGEPAGE) the caller's OUTPUT arrays while the kernels run, on helper threads for chunked batches; 0 = the library never touches caller memory except through the device copies
+  bool pipe_chunks = true;       // KEAKI_PIPE_CHUNKS / "pipe_chunks": host-pointer batches (KEM, MSM) run as chunk pipelines over a copy stream; 0 = upload, kernels, download in that order on the context's stream
   int msm_pipe_chunks = -1;      // KEAKI_MSM_PIPE_CHUNKS / "msm_pipe_chunks": chunks of a host-pointer MSM (upload under the kernels); -1 = automatic, 0 / 1 = one copy in front, k = k chunks at any length
   long long msm_pipe_min = 1 << 20;   // KEAKI_MSM_PIPE_MIN / "msm_pipe_min": automatic chunking from this many scalars on
   int msm_pipe_growth = 140;     // KEAKI_MSM_PIPE_GROWTH / "msm_pipe_growth": size of chunk j + 1 in percent of chunk j (100 = equal chunks)
@@ -56,7 +59,7 @@ struct keaki_hip_ctx {
   keaki_internal::Tuning tune;
   // bytes this context allocated and still holds, by class (keaki_hip_ctx_memory): SRS window tables + FK23 transforms of handles built
   // through it | grow-only workspaces | GT / fixed-base tables of encapsulate
-  size_t mem_tables = 0;
+  std::atomic<size_t> mem_tables{0};
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::recursive_mutex mu;   // recursive: host-pointer entry points hold it across stage -> *_dev -> download
@@ -67,6 +70,7 @@ struct keaki_hip_ctx {
   keaki_internal::DevBuf fb_bases, fb_g1_gen, fb_g2_gen, fb_com, fb_tau, perm, g2gen_lines, gt_tab_a, gt_tab_b, gt_base, heavy;
   bool gt_b_ready = false;
   bool gt_a_valid = false;
+  bool gt_a_pending_aux = false;          // the A-table build on aux_stream has not been waited for by `stream` yet (api.hip: encap_impl)
   bool gt_b_fallback = false;             // the wide table of B did not fit once: stay at 16 bits
   uint64_t seen_com[8] = {};              // commitment of the last encap call and how many consecutive calls carried it
   uint32_t seen_com_runs = 0;

@@ -255,25 +255,33 @@ static __global__ void __launch_bounds__(T1_THREADS) k_tile_sort(const Fr* __res
   __shared__ u32 ent[T1_CAP + 64];         // [T1_CAP + lane]: where the (rare) zero digits of the branch-free loops go
   __shared__ u32 cur[PART_MAX_BINS + 64];  // [PART_MAX_BINS + lane]: their bin (one word per lane: same-address LDS atomics of a wave are serial)
   __shared__ u32 wsum[T1_THREADS / 64];
-  const u32 t = threadIdx.x;
   constexpr u32 NC = WS ? WS : 1u;
+  // the scalars of a workgroup's NEXT tile are requested while the current one is counted and placed (round 5: the kernel needs 83
+  // registers since the second cut stopped living in scratch, the 24 of a tile in flight fit)
+  Fr nxt[T1_PER];
+  auto request = [&](u32 tile, u32 tl) {
+#pragma unroll
+    for (u32 p = 0; p < T1_PER; p++) {                     // branch-free: a lane without a scalar reads the last one and drops its digits
+      const u32 li = p * T1_THREADS + tl;
+      const size_t i = (size_t)tile * ps.tile + li;
+      nxt[p] = scalars[li < ps.tile && i < s.n ? i : (size_t)s.n - 1];
+    }
+  };
+  if (blockIdx.x < ps.ntiles) request(blockIdx.x, threadIdx.x);
   for (u32 tile = blockIdx.x; tile < ps.ntiles; tile += gridDim.x) {
+    u32 t = threadIdx.x;
+    asm volatile("" : "+v"(t));                              // per-lane invariants are re-formed per tile, not kept (and spilled) across it
     [[maybe_unused]] const u32 sk = (tile - blockIdx.x) / gridDim.x;     // (the STAMP harness reads it)
     STAMP(blockIdx.x == 100 && t == 0 && sk < 4, 2048 + sk * 16 + 0);
     u32 canon[T1_PER][8];          // the canonical scalars; the digits are cut twice (count, place): 24 registers instead of 3 W
     bool act[T1_PER];
-    {
-      Fr nxt[T1_PER];
 #pragma unroll
-      for (u32 p = 0; p < T1_PER; p++) {                   // branch-free: a lane without a scalar reads the last one and drops its digits
-        const u32 li = p * T1_THREADS + t;
-        const size_t i = (size_t)tile * ps.tile + li;
-        act[p] = li < ps.tile && i < s.n;
-        nxt[p] = scalars[act[p] ? i : (size_t)s.n - 1];
-      }
-#pragma unroll
-      for (u32 p = 0; p < T1_PER; p++) fp_from_mont<FrParams>(canon[p], nxt[p]);
+    for (u32 p = 0; p < T1_PER; p++) {
+      const u32 li = p * T1_THREADS + t;
+      act[p] = li < ps.tile && (size_t)tile * ps.tile + li < s.n;
+      fp_from_mont<FrParams>(canon[p], nxt[p]);
     }
+    if (tile + gridDim.x < ps.ntiles) request(tile + gridDim.x, t);
     STAMP(blockIdx.x == 100 && t == 0 && sk < 4, 2048 + sk * 16 + 1);
     for (u32 b = t; b < ps.nbins; b += T1_THREADS) cur[b] = 0;
     if (t < 64) cur[PART_MAX_BINS + t] = 0;
@@ -303,6 +311,12 @@ static __global__ void __launch_bounds__(T1_THREADS) k_tile_sort(const Fr* __res
     if (t == 0) ts[ps.nbins] = (u16)m;
     lds_barrier();
     STAMP(blockIdx.x == 100 && t == 0 && sk < 4, 2048 + sk * 16 + 4);
+    // "cut twice" has to be said to the compiler: it recognises the second cut as the first one's value and keeps all 3 W codes alive across
+    // the scan -- in scratch (35 dwords per lane at W = 12). Behind this statement the canonical limbs are new values to it.
+#pragma unroll
+    for (u32 p = 0; p < T1_PER; p++)
+#pragma unroll
+      for (u32 j = 0; j < 8; j++) asm volatile("" : "+v"(canon[p][j]));
 #pragma unroll
     for (u32 p = 0; p < T1_PER; p++) {
       const u32 li = p * T1_THREADS + t;
@@ -626,9 +640,11 @@ static __global__ void __launch_bounds__(C2_THREADS) k_chunk_sort(const u32* __r
     STAMP(b == 100 && t == 0 && k < 8, k * 16 + 8);
     lds_barrier();                                                                                  // ---- 0 of the next chunk
   }
+  u32 te = threadIdx.x;
+  asm volatile("" : "+v"(te));                                // (2 t kept across the chunk loop lived in scratch)
 #pragma unroll
   for (u32 i = 0; i < 2; i++) {
-    const u32 f = 2 * t + i, g = part_bucket(ps, b, f);
+    const u32 f = 2 * te + i, g = part_bucket(ps, b, f);
     if (f < nf && g < nbuckets_total) {
       bucket_counts[g] = tot[i];
       segtab[g] = v4u_t{seg[i][0], seg[i][1], seg[i][2], seg[i][3]};
@@ -1137,9 +1153,8 @@ __global__ void __launch_bounds__(64) k_msm_window_finish(const Xyzz<F>* __restr
   if (l == 0) {
     typename O::P r = sh[0];
     for (u32 k = 0, nd = msm_bit_offset(s, w); k < nd; k++) r = O::dbl(r);
-    const Xyzz<F> rs = O::store(r);
-    if (out_jac) store_norm_jac(out_jac, rs);
-    else window_sums[w] = rs;
+    if (out_jac) store_norm_jac(out_jac, O::store(r));
+    else window_sums[w] = O::store(r);
   }
 }
 

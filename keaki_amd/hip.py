@@ -337,6 +337,11 @@ class KeakiHip:
         self._ck(self.lib.keaki_hip_srs_g2_upload(self.ctx, _ptr(pts), pts.shape[0], C.byref(h)))
         return SrsG2(self, h, pts.shape[0])
 
+    def srs_g2_wrap_dev(self, dptr: int, n: int) -> SrsG2:
+        h = C.c_void_p()
+        self._ck(self.lib.keaki_hip_srs_g2_wrap_dev(self.ctx, C.c_void_p(dptr), n, C.byref(h)))
+        return SrsG2(self, h, n)
+
     def srs_g1_precompute(self, srs: "SrsG1") -> int:
         """one-time window-table build for a fixed SRS; returns the table size in bytes"""
         nbytes = C.c_size_t(0)

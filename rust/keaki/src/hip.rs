@@ -644,14 +644,30 @@ pub fn active<E: Pairing>() -> bool {
     TypeId::of::<E>() == TypeId::of::<Bn254>() && std::env::var("KEAKI_HIP").map(|v| v != "off").unwrap_or(true)
 }
 
-/// Pairing work of fewer than `KEAKI_HIP_MIN_BATCH` items (default 8) stays on arkworks: ONE pairing on the GPU is bound by the instruction
-/// count of one lane pair (5.2 ms for a decapsulation, 5.3 ms for `verify`'s two pairings; profiles/r02_small_calls.txt) where a CPU core
-/// needs about a millisecond each -- the GPU wins from a handful of items on and by four orders of magnitude at 2^16. Used by the
-/// single-item `encapsulate` / `decapsulate` (1 item), `verify` (2 pairings) and the `vec_*` loops (their length). `KEAKI_HIP_MIN_BATCH=0`
-/// sends everything to the GPU (the parity test does that). MSM-shaped calls (`commit`, `open`, `open_fk`) always go to the GPU.
+/// Small calls. The thresholds follow the single-call figures of `bench.py`'s `single_calls` block (BENCH_r05: wall clock of one call through
+/// the library against the same call on ONE host core, degree-128 setup, 32-byte key):
+///
+/// | call | GPU | one CPU core | taken from |
+/// |---|---|---|---|
+/// | `encapsulate` (commitment seen before / new) | 0.48 ms / ~2.0 ms | 1.7 ms | 1 item |
+/// | `verify` (two pairings) | 1.68 ms | 2.2 ms | 2 pairings |
+/// | `decapsulate` (one pairing with a per-item Q) | 1.54 ms | 0.9 ms | 2 items |
+///
+/// A call with few pairings runs each of them on twelve lanes and two waves (`pairing_wide.hip.h`, 1.4 ms per pairing whatever their
+/// number up to ~1,000), so ONE decapsulation is the only call a CPU core still wins. `KEAKI_HIP_MIN_BATCH=n` overrides both thresholds
+/// (`0` sends everything to the GPU -- the parity test does that; a large value keeps all pairing-shaped small calls on arkworks).
+/// MSM-shaped calls (`commit`, `open`, `open_fk`) always go to the GPU (a 129-coefficient commit: 0.58 ms against 2.4 ms).
+/// (Rounds 1-4 kept fewer than 8 items on arkworks: one pairing then cost 5 ms on a lane pair.)
+fn min_batch_override() -> Option<usize> {
+    std::env::var("KEAKI_HIP_MIN_BATCH").ok().and_then(|v| v.parse::<usize>().ok())
+}
+/// pairing-shaped work of `items` pairings with per-item second arguments: `decapsulate` (1), `verify` (2), `vec_decrypt` (its length)
 pub fn active_batch<E: Pairing>(items: usize) -> bool {
-    let min = std::env::var("KEAKI_HIP_MIN_BATCH").ok().and_then(|v| v.parse::<usize>().ok()).unwrap_or(8);
-    active::<E>() && items >= min
+    active::<E>() && items >= min_batch_override().unwrap_or(2)
+}
+/// encapsulation work: `encapsulate` (1), `vec_encrypt` (its length) -- fixed-base sums and GT exponentiations, no pairing per item
+pub fn active_encap<E: Pairing>(items: usize) -> bool {
+    active::<E>() && items >= min_batch_override().unwrap_or(1)
 }
 
 /// Reinterpret `&A` as `&B` when they are the same type. The callers have established `E == Bn254`, which makes `E::G1` and

@@ -216,7 +216,7 @@ def test_g2_2p20_chunked_identity(oc, piped):
     _, g2 = oc.generators()
     exp = oc.g2_mul_batch(g2, oc.fr_dot(s, k).reshape(1, 4))[0]
     d_pts = _gen_points_dev(hip, torch, dev, k, g2=True)
-    srs = hip.srs_g2_upload(d_pts.cpu().numpy().view(np.uint64))
+    srs = hip.srs_g2_wrap_dev(d_pts.data_ptr(), n)
     try:
         for tables in (False, True):
             if tables:
@@ -287,3 +287,45 @@ def test_skewed_scalars_through_the_chunked_entry(oc, piped, bits, log2n):
         srs.free()
         del d_pts
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("prefault,chunks", [(0, 1), (1, 0), (0, 0)])
+def test_host_helper_off_switches_give_identical_results(oc, piped, prefault, chunks):
+    """options host_prefault = 0 (no helper threads, no first-touch writes, no madvise on caller memory) and pipe_chunks = 0 (upload, kernels,
+    download in that order): the same bytes as the defaults for a four-chunk encrypt_batch, a three-chunk decrypt_batch and a 2^20-scalar MSM
+    from a host array (include/keaki_hip.h: keaki_hip_ctx_set_option)"""
+    from bench import random_fr_limbs
+    hip = piped
+    g1, g2 = oc.generators()
+    com = hip.g1_mul_batch(g1, random_fr_limbs(1, 291))[0]
+    tau_g2 = hip.g2_mul_batch(g2, random_fr_limbs(1, 292))[0]
+    n = 3 * 65536 + 777
+    A, V, R = random_fr_limbs(n, 293), random_fr_limbs(n, 294), random_fr_limbs(n, 295)
+    msgs = np.random.default_rng(9).integers(0, 256, (n, 40), dtype=np.uint8)
+    m = 2 * 131072 + 5
+    nm = 1 << 20
+    pts = hip.g1_mul_batch(g1, random_fr_limbs(nm, 296))
+    sc = random_fr_limbs(nm, 297)
+    srs = hip.srs_g1_upload(pts)
+    try:
+        def run():
+            ct, body = hip.encrypt_batch(com, tau_g2, A, V, R, msgs)
+            proofs = np.ascontiguousarray(np.tile(pts[:4096], (m // 4096 + 1, 1))[:m])
+            cts = np.ascontiguousarray(np.tile(ct[:8192], (m // 8192 + 1, 1))[:m])
+            bodies = np.ascontiguousarray(np.tile(body[:8192], (m // 8192 + 1, 1))[:m])
+            return ct, body, hip.decrypt_batch(proofs, cts, bodies), hip.msm_g1(srs, sc)
+        ref = run()
+        hip.set_option("host_prefault", prefault)
+        hip.set_option("pipe_chunks", chunks)
+        try:
+            got = run()
+        finally:
+            hip.set_option("host_prefault", 1)
+            hip.set_option("pipe_chunks", 1)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b)
+        idx = np.array([0, 65535, 65536, n - 1])
+        oct_, _, okey = oc.encap_batch(com, tau_g2, A[idx], V[idx], R[idx], 40, threads=os.cpu_count() or 1)
+        assert np.array_equal(oct_, got[0][idx]) and np.array_equal(okey ^ msgs[idx], got[1][idx])
+    finally:
+        srs.free()
