@@ -108,7 +108,7 @@ const char* keaki_hip_version(void);
  *       by a device-to-host copy. Results are identical; downloads into pages that do not exist yet are slower (160 MB: 30 ms instead of 3).
  *   "pipe_chunks" (default 1): host-array batches (encap / decap / encrypt / decrypt from 2 x 65,536 items on; MSMs from "msm_pipe_min" scalars on)
  *       run as chunk pipelines over a copy stream of the context's own. 0: upload, kernels, download, in that order, on the context's stream.
- *   "msm_pipe_chunks" (-1 = automatic: 6 chunks from 2^22 scalars on, 3 from "msm_pipe_min" = 2^20 on; 0 / 1 = one copy in front; k >= 2 = k chunks at
+ *   "msm_pipe_chunks" (-1 = automatic: 6 chunks from 2^22 scalars on, 4 from 2^21, 3 from "msm_pipe_min" = 2^20 on; 0 / 1 = one copy in front; k >= 2 = k chunks at
  *       any length), "msm_pipe_growth" (size of chunk j + 1 in percent of chunk j, default 140: a short first chunk starts the device early).
  *   A host-array call that FAILS (status != KEAKI_OK) leaves its output arrays unspecified: any prefix may hold results, and with
  *   "host_prefault" = 1 pages may hold the zeros of the first touch. Input arrays are never written.

@@ -323,7 +323,7 @@ static keaki_status pipelined(keaki_hip_ctx* ctx, size_t n, size_t ch, size_t ou
 static std::vector<size_t> msm_pipe_bounds(const Tuning& t, size_t n) {
   size_t k = 1;
   if (t.msm_pipe_chunks >= 2) k = (size_t)t.msm_pipe_chunks;
-  else if (t.msm_pipe_chunks < 0 && t.pipe_chunks && n >= (size_t)t.msm_pipe_min) k = n >= ((size_t)1 << 22) ? 6 : 3;
+  else if (t.msm_pipe_chunks < 0 && t.pipe_chunks && n >= (size_t)t.msm_pipe_min) k = n >= ((size_t)1 << 22) ? 6 : n >= ((size_t)1 << 21) ? 4 : 3;      // measured: profiles/r05_msm_pipe_sweep_*.txt
   if (k > 64) k = 64;
   if (k > n) k = n ? n : 1;
   std::vector<size_t> b{0};
@@ -343,31 +343,44 @@ static std::vector<size_t> msm_pipe_bounds(const Tuning& t, size_t n) {
   b.push_back(n);
   return b;
 }
+// the copy-stream side of a chunked upload: `begin` orders the copy stream behind the context's stream, `chunk` copies one piece and makes
+// the context's stream wait for it; on every exit no copy reads the caller's array any more (the destructor drains the copy stream)
+struct ChunkUploader {
+  keaki_hip_ctx* ctx;
+  hipStream_t cs = nullptr;
+  explicit ChunkUploader(keaki_hip_ctx* c) : ctx(c) {}
+  ~ChunkUploader() { if (cs) (void)hipStreamSynchronize(cs); }
+  keaki_status begin() {
+    ST_TRY(pipe_ready(ctx));
+    // the copy stream starts behind whatever the context's stream holds (an earlier call's kernels may still read the destination)
+    HIP_TRY(ctx, hipEventRecord(ctx->pipe_done[0], ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->pipe_done[0], 0));
+    cs = ctx->copy_stream;
+    return KEAKI_OK;
+  }
+  keaki_status chunk(size_t j, void* dst, const void* src, size_t bytes) {
+    const int h = (int)(j & 1);
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cs));
+    HIP_TRY(ctx, hipEventRecord(ctx->pipe_in[h], cs));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_in[h], 0));
+    return KEAKI_OK;
+  }
+};
 template <class Run>
 static keaki_status msm_from_host(keaki_hip_ctx* ctx, const uint64_t* scalars, size_t n, Run run) {
   ST_TRY(reserve(ctx, ctx->io_a, n ? n * 32 : 16));
   MsmPipe pipe;
-  pipe.bounds = msm_pipe_bounds(ctx->tune, n);
-  if (pipe.bounds.size() <= 2) {
+  const std::vector<size_t> bounds = msm_pipe_bounds(ctx->tune, n);
+  for (size_t j = 0; j + 1 < bounds.size(); j++) pipe.ranges.push_back({bounds[j], bounds[j + 1] - bounds[j]});
+  if (pipe.ranges.size() <= 1) {
     if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->io_a.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
     return run(nullptr);
   }
-  ST_TRY(pipe_ready(ctx));
-  hipStream_t cs = ctx->copy_stream, st = ctx->stream;
-  // the copy stream starts behind whatever the context's stream holds (an earlier call's kernels may still read io_a)
-  HIP_TRY(ctx, hipEventRecord(ctx->pipe_done[0], st));
-  HIP_TRY(ctx, hipStreamWaitEvent(cs, ctx->pipe_done[0], 0));
-  struct CopyFence {                                       // no copy may still read the caller's array when the call returns, whatever the exit
-    hipStream_t cs;
-    ~CopyFence() { (void)hipStreamSynchronize(cs); }
-  } fence{cs};
+  ChunkUploader up(ctx);
+  ST_TRY(up.begin());
   pipe.stage = [&](size_t j) -> keaki_status {
-    const size_t lo = pipe.bounds[j], m = pipe.bounds[j + 1] - lo;
-    const int h = (int)(j & 1);
-    HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->io_a.p + lo * 32, (const char*)scalars + lo * 32, m * 32, hipMemcpyHostToDevice, cs));
-    HIP_TRY(ctx, hipEventRecord(ctx->pipe_in[h], cs));
-    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->pipe_in[h], 0));
-    return KEAKI_OK;
+    const size_t lo = pipe.ranges[j].first, m = pipe.ranges[j].second;
+    return up.chunk(j, (char*)ctx->io_a.p + lo * 32, (const char*)scalars + lo * 32, m * 32);
   };
   return run(&pipe);
 }
@@ -1535,15 +1548,43 @@ keaki_status keaki_hip_kzg_open(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs,
   SRS_CHECK(ctx, srs, "kzg_open");
   if (n && n - 1 > srs->n) return fail(ctx, KEAKI_ERR_TOO_LARGE, "msm: %zu scalars but the SRS holds %zu points", n - 1, srs->n);
   const size_t nq = n ? n - 1 : 0;
-  const size_t o_q = 0, o_v = o_q + (nq + 1) * 32, o_w = o_v + 32, total = o_w + (2 * (n / 255 + 8) + 8) * 32;
-  ST_TRY(upload(ctx, ctx->io_a, coeffs, n * 32));
+  const size_t o_q = 0, o_v = o_q + (nq + 1) * 32, o_w = o_v + 32, total = o_w + open_quotient_work_bytes(n + 1);
+  ST_TRY(reserve(ctx, ctx->io_a, n ? n * 32 : 16));
   ST_TRY(reserve(ctx, ctx->io_c, total));
   ST_TRY(reserve(ctx, ctx->io_b, 96));
   char* b = (char*)ctx->io_c.p;
   HIP_TRY(ctx, hipMemsetAsync(b + o_v, 0, 32, ctx->stream));                     // the zero polynomial evaluates to 0
-  if (n) ST_TRY(open_quotient_run(ctx, ctx->io_a.p, n, point, b + o_q, b + o_v, b + o_w));
   const auto tb = srs_tables(srs);
-  ST_TRY(msm_g1_run(ctx, srs->d, srs->n, b + o_q, nq, ctx->io_b.p, tb.first, tb.second));
+  // Long polynomials come up in chunks FROM THE TOP (the quotient's recurrence Q_i = c_i + z Q_(i+1) runs downwards): chunk j's coefficients are
+  // uploaded on the copy stream while chunk j - 1's quotient and MSM pass run; its quotient starts from the carry Q_hi the chunk above left
+  // (planted as one more "coefficient" behind the chunk), and the MSM consumes the quotient chunk by chunk (msm_host.hip.h: MsmPipe).
+  std::vector<std::pair<size_t, size_t>> cch;                                    // coefficient chunks [lo, hi), top first
+  // (automatic from 2^22 coefficients on: every chunk pays ~0.3 ms of dependent Horner levels, which a 2^20-coefficient call -- 2.56 ms with
+  // the copy in front, 2.89 ms in three chunks -- does not earn back; 2^24: 20.8 against 28.5 ms, profiles/r05_open_chunked.txt)
+  if (ctx->tune.msm_pipe_chunks >= 2 || n >= ((size_t)1 << 22)) {
+    const std::vector<size_t> bounds = msm_pipe_bounds(ctx->tune, n);
+    for (size_t j = 0; j + 1 < bounds.size(); j++) cch.push_back({n - bounds[j + 1], n - bounds[j]});
+    if (cch.size() >= 2 && cch.back().second == 1) { cch[cch.size() - 2].first = 0; cch.pop_back(); }     // the lowest chunk must leave a quotient coefficient
+  }
+  if (cch.size() <= 1 || nq == 0) {
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->io_a.p, coeffs, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (n) ST_TRY(open_quotient_run(ctx, ctx->io_a.p, n, point, b + o_q, b + o_v, b + o_w));
+    ST_TRY(msm_g1_run(ctx, srs->d, srs->n, b + o_q, nq, ctx->io_b.p, tb.first, tb.second));
+  } else {
+    ChunkUploader up(ctx);
+    ST_TRY(up.begin());
+    MsmPipe pipe;
+    for (const auto& c : cch) pipe.ranges.push_back({c.first ? c.first - 1 : 0, c.second - 1 - (c.first ? c.first - 1 : 0)});   // q_i = Q_(i+1): chunk [lo, hi) yields q_(lo-1) .. q_(hi-2)
+    char* a = (char*)ctx->io_a.p;
+    pipe.stage = [&](size_t j) -> keaki_status {
+      const size_t lo = cch[j].first, hi = cch[j].second;
+      ST_TRY(up.chunk(j, a + lo * 32, (const char*)coeffs + lo * 32, (hi - lo) * 32));
+      // the carry: Q_hi = q_(hi-1), written by the chunk above; it takes the place of c_hi, which that chunk has consumed
+      if (j) HIP_TRY(ctx, hipMemcpyAsync(a + hi * 32, b + o_q + (hi - 1) * 32, 32, hipMemcpyDeviceToDevice, ctx->stream));
+      return open_quotient_run(ctx, a + lo * 32, hi - lo + (j ? 1 : 0), point, b + o_q + lo * 32, lo ? b + o_q + (lo - 1) * 32 : b + o_v, b + o_w);
+    };
+    ST_TRY(msm_g1_run(ctx, srs->d, srs->n, b + o_q, nq, ctx->io_b.p, tb.first, tb.second, &pipe));
+  }
   ST_TRY(download(ctx, proof_out_jac, ctx->io_b.p, 96));
   if (value_out) ST_TRY(download(ctx, value_out, b + o_v, 32));
   resolve_timing(ctx);
@@ -1557,7 +1598,7 @@ keaki_status keaki_hip_kzg_quotient(keaki_hip_ctx* ctx, const uint64_t* coeffs, 
   TRACE_SCOPE("keaki.kzg_quotient");
   if (!point || (n && !coeffs) || (n > 1 && !quotient_out)) return fail(ctx, KEAKI_ERR_BAD_ARG, "kzg_quotient: null pointer");
   const size_t nq = n ? n - 1 : 0;
-  const size_t o_q = 0, o_v = o_q + (nq + 1) * 32, o_w = o_v + 32, total = o_w + (2 * (n / 255 + 8) + 8) * 32;
+  const size_t o_q = 0, o_v = o_q + (nq + 1) * 32, o_w = o_v + 32, total = o_w + open_quotient_work_bytes(n);
   ST_TRY(upload(ctx, ctx->io_a, coeffs, n * 32));
   ST_TRY(reserve(ctx, ctx->io_c, total));
   char* b = (char*)ctx->io_c.p;

@@ -400,13 +400,16 @@ static __global__ void __launch_bounds__(256) k_fr_stride2(const Fr* __restrict_
 //   up:   H_b = sum_{t < L} a[bL + t] w^t                       (one lane per block, Horner from the top of the block)
 //   top:  all suffix values of the last level by one lane
 //   down: a lane re-runs its block from the carry Q_((b+1)L) supplied by the level above and writes every Q of the block
-constexpr u32 HORNER_L = 256;
-static __global__ void k_fr_pow_chain(Fr z, u32 levels, Fr* __restrict__ w) {      // w[k] = z^(256^k)
+// Block length 32 (256 until round 5): a lane's chain is 2 x 32 steps per level instead of 2 x 256, so a CHUNK of a polynomial (`open` from host
+// memory runs the quotient chunk by chunk from the top, api.hip) costs ~0.15 ms of dependent steps instead of ~0.4, and a whole 2^24-coefficient
+// quotient keeps eight waves per SIMD busy instead of one.
+constexpr u32 HORNER_L = 32;
+static __global__ void k_fr_pow_chain(Fr z, u32 levels, Fr* __restrict__ w) {      // w[k] = z^(HORNER_L^k)
   if (threadIdx.x || blockIdx.x) return;
   Fr x = z;
   for (u32 k = 0; k < levels; k++) {
     w[k] = x;
-    for (int s = 0; s < 8; s++) x = fr_mul(x, x);
+    for (u32 s = 1; s < HORNER_L; s <<= 1) x = fr_mul(x, x);
   }
 }
 static __global__ void __launch_bounds__(64) k_fr_horner_up(const Fr* __restrict__ a, u32 m, const Fr* __restrict__ wp, Fr* __restrict__ H) {
@@ -726,7 +729,8 @@ keaki_status fk_precompute_run(keaki_hip_ctx* ctx, const void* d_srs, void** hat
 }
 
 // d_c: n coefficients (Fr). d_q: n - 1 quotient coefficients out (n >= 1; n == 1: nothing written). d_value: p(z) out (1 Fr).
-// d_work: room for 2 * (n / 255 + 8) + 8 Fr.
+// d_work: open_quotient_work_bytes(n).
+size_t open_quotient_work_bytes(size_t n) { return (2 * (n / (HORNER_L - 1) + 16) + 8) * sizeof(Fr); }
 keaki_status open_quotient_run(keaki_hip_ctx* ctx, const void* d_c, size_t n, const uint64_t* z, void* d_q, void* d_value, void* d_work) {
   hipStream_t st = ctx->stream;
   Fr zz;

@@ -10,6 +10,7 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/keaki_hip.h"
@@ -159,8 +160,8 @@ inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
 // are enqueued: the caller uploads that chunk's scalars there (on its copy stream) and makes the context's stream wait for them, so the
 // upload of chunk j + 1 runs under the kernels of chunk j. The sum is the same group element whatever the cut (exact arithmetic).
 struct MsmPipe {
-  std::vector<size_t> bounds;                        // chunk j = pairs [bounds[j], bounds[j + 1]); 0 = bounds[0] < ... < bounds.back() = n
-  std::function<keaki_status(size_t)> stage;
+  std::vector<std::pair<size_t, size_t>> ranges;     // chunk j = pairs [first, first + second); the ranges partition [0, n), in ANY order
+  std::function<keaki_status(size_t)> stage;         // (the quotient of `open` is produced from the top coefficient down: its chunks come last-first)
 };
 
 // launchers implemented in the kernel translation units (all enqueue on ctx->stream, no sync)
@@ -206,6 +207,7 @@ keaki_status encap_g2_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_
 keaki_status g1_curve_check_run(keaki_hip_ctx* ctx, const void* d_pts, size_t n, void* d_bad2);   // d_bad2: u64 count, u64 first index
 keaki_status g2_curve_check_run(keaki_hip_ctx* ctx, const void* d_pts, size_t n, void* d_bad2);
 keaki_status open_quotient_run(keaki_hip_ctx* ctx, const void* d_c, size_t n, const uint64_t* z, void* d_q, void* d_value, void* d_work);
+size_t open_quotient_work_bytes(size_t n);           // size of d_work for n coefficients
 keaki_status fr_fft_run(keaki_hip_ctx* ctx, void* d_data, uint32_t log2n, const uint64_t* omega, const uint64_t* scale_or_null, void* d_tw);
 keaki_status open_fk_poly_run(keaki_hip_ctx* ctx, const void* d_srs, void** hat_s_cache, int* hat_s_log2d, uint32_t log2d, const void* d_p,
                               const uint64_t* omega_2d, const uint64_t* omega_2d_inv, const uint64_t* inv_2d, void* d_fr_work, void* d_g_work,

@@ -74,19 +74,20 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
     return launch_check(ctx, "msm_final");
   }
   // ---- the passes: one for a resident scalar vector, one per chunk of a pipelined call ----------------------------------------------
-  const size_t K = pipe ? pipe->bounds.size() - 1 : 1;
-  if (pipe && (K < 1 || pipe->bounds.front() != 0 || pipe->bounds.back() != n)) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: bad chunk bounds");
+  const size_t K = pipe ? pipe->ranges.size() : 1;
+  if (pipe && K < 1) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: bad chunk bounds");
   struct Pass {
     size_t lo, m, pairs, max_chunks, cm_bytes, bt_bytes, bm_bytes, sg_bytes, ts_bytes;
     PartShape ps;
   };
   std::vector<Pass> passes(K);
-  size_t w_digits = 0, w_sorted = 0, w_offsets = 0, w_cursor = 0, w_pairs = 0;
+  size_t w_digits = 0, w_sorted = 0, w_offsets = 0, w_cursor = 0, w_pairs = 0, w_total = 0;
   for (size_t j = 0; j < K; j++) {
     Pass& q = passes[j];
-    q.lo = pipe ? pipe->bounds[j] : 0;
-    q.m = (pipe ? pipe->bounds[j + 1] : n) - q.lo;
-    if (q.m == 0 || q.m > n) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: bad chunk bounds");
+    q.lo = pipe ? pipe->ranges[j].first : 0;
+    q.m = pipe ? pipe->ranges[j].second : n;
+    if (q.m == 0 || q.lo > n || q.m > n - q.lo) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: bad chunk bounds");
+    w_total += q.m;
     if (!part_make_shape(q.m, s.W, nb, &q.ps, ctx->tune.part_shift))
       return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: %zu buckets / %u windows exceed the bucket sort's LDS budget (window too large)", nb, s.W);
     q.pairs = q.m * (size_t)s.W;
@@ -104,6 +105,7 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
     w_cursor = std::max(w_cursor, q.cm_bytes + q.bt_bytes + q.bm_bytes + q.sg_bytes + q.ts_bytes);
     w_pairs = std::max(w_pairs, q.pairs);
   }
+  if (w_total != n) return fail(ctx, KEAKI_ERR_BAD_ARG, "msm: the chunks cover %zu of %zu pairs", w_total, n);
   bool u29 = false;
   if constexpr (std::is_same<F, Fq>::value) u29 = ctx->tune.acc_u29;          // A/B switches for profiling
   if constexpr (std::is_same<F, Fq2>::value) u29 = ctx->tune.acc_u29_g2;

@@ -85,6 +85,18 @@ impl Device {
         })
     }
 
+    /// `keaki_hip_ctx_set_option` on every context behind this device (a group: each member's). The names the header lists, e.g.
+    /// `host_prefault` = 0 (the library never writes into or madvises caller memory itself), `pipe_chunks` = 0 (host-array calls run upload,
+    /// kernels, download in that order), `msm_pipe_chunks` = k (a host-pointer MSM / `open` uploads its scalars in k chunks under the kernels).
+    pub fn set_option(&self, name: &str, value: i64) {
+        let cname = std::ffi::CString::new(name).expect("option name without NUL");
+        for m in 0..self.members() {
+            let ctx = if self.group.is_null() { self.ctx } else { unsafe { sys::keaki_hip_group_ctx(self.group, m) } };
+            let st = unsafe { sys::keaki_hip_ctx_set_option(ctx, cname.as_ptr(), value) };
+            self.check(st, "ctx_set_option");
+        }
+    }
+
     /// number of GPUs (contexts) behind this device
     pub fn members(&self) -> usize {
         if self.group.is_null() { 1 } else { unsafe { sys::keaki_hip_group_size(self.group) } }

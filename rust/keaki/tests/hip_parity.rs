@@ -154,6 +154,34 @@ fn msm_commit_open_verify_match_arkworks() {
     }
 }
 
+/// The host-pointer `commit` / `open` upload their scalars in point-range chunks under the kernels (round 5: `keaki_hip_msm_g1` /
+/// `keaki_hip_kzg_open`, automatic from 2^20 scalars on). Forced here at a test-sized polynomial (`msm_pipe_chunks` = 5), with the library's
+/// host-side helpers switched off (`host_prefault` = 0, `pipe_chunks` = 0) and on: the same points as arkworks either way.
+#[test]
+fn chunked_commit_and_open_and_the_helper_off_switches_match_arkworks() {
+    gpu_for_small_batches();
+    let rng = &mut test_rng();
+    let n = (1usize << 12) + 17;
+    let setup = KZGSetup::<Bn254>::setup(Fr::rand(rng), n);
+    let p = DensePolynomial::from_coefficients_vec((0..n).map(|_| Fr::rand(rng)).collect());
+    let z = Fr::rand(rng);
+    let cpu = <G1Projective as VariableBaseMSM>::msm_unchecked(setup.g1_aff(), &p.coeffs).into_affine();
+    std::env::set_var("KEAKI_HIP", "off");
+    let proof_cpu = open(&setup, &p, &z).unwrap().into_affine();
+    std::env::remove_var("KEAKI_HIP");
+    let dev = keaki::hip::Device::global();
+    for &(chunks, prefault, pipe) in &[(5i64, 1i64, 1i64), (5, 0, 1), (0, 0, 0), (-1, 1, 1)] {
+        dev.set_option("msm_pipe_chunks", chunks);
+        dev.set_option("host_prefault", prefault);
+        dev.set_option("pipe_chunks", pipe);
+        assert_eq!(commit(&setup, &p).unwrap().into_affine(), cpu, "commit chunks={chunks} prefault={prefault} pipe={pipe}");
+        assert_eq!(open(&setup, &p, &z).unwrap().into_affine(), proof_cpu, "open chunks={chunks} prefault={prefault} pipe={pipe}");
+    }
+    dev.set_option("msm_pipe_chunks", -1);
+    dev.set_option("host_prefault", 1);
+    dev.set_option("pipe_chunks", 1);
+}
+
 /// In-process multi-GPU (`KEAKI_HIP_DEVICES=4`, or `0,0,0` to put three contexts on one GPU): `commit` / `open` are then the sharded
 /// MSM of `hip::ShardedCommit` -- every member sums its range of the SRS, the partials are added -- and must still equal arkworks.
 /// Run the whole file once more with the variable set: every test above then goes through the device group as well.

@@ -329,3 +329,65 @@ def test_host_helper_off_switches_give_identical_results(oc, piped, prefault, ch
         assert np.array_equal(oct_, got[0][idx]) and np.array_equal(okey ^ msgs[idx], got[1][idx])
     finally:
         srs.free()
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 34, 1000, 1057, 33000, 70000])
+def test_chunked_open_from_the_top_equals_oracle(oc, piped, rand_fr, n):
+    """keaki_hip_kzg_open with the coefficients uploaded in chunks from the TOP (api.hip: the quotient's recurrence runs downwards, every chunk
+    starts from the carry the chunk above left; Horner blocks of 32): value and proof against the oracle's quotient + MSM for forced chunk
+    counts, chunk sizes of one coefficient included; z = 0 and a zero top coefficient; with and without window tables"""
+    hip = piped
+    g1, _ = oc.generators()
+    pts = hip.g1_mul_batch(g1, _mont(oc, rand_fr(max(n, 2), 8800 + n)))
+    c = rand_fr(n, 8801 + n)
+    if n > 4:
+        c[1] = 0; c[n // 2] = 0
+    zs = [rand_fr(1, 8802 + n)[0], 0]
+    cm = _mont(oc, c)
+    srs = hip.srs_g1_upload(pts)
+    try:
+        for tables in (False, True):
+            if tables:
+                hip.srs_g1_precompute(srs)
+            for z in zs:
+                zm = _mont(oc, [z])[0]
+                q, v = oc.fr_quotient(cm, zm)
+                exp = oc.msm_g1(pts[:n - 1], q)
+                for chunks, growth in ((0, 140), (2, 100), (3, 140), (7, 100), (n, 100)):
+                    hip.set_option("msm_pipe_chunks", chunks)
+                    hip.set_option("msm_pipe_growth", growth)
+                    proof, val = hip.kzg_open(srs, cm, zm)
+                    assert np.array_equal(val.reshape(-1), v.reshape(-1)), (n, z != 0, tables, chunks)
+                    assert np.array_equal(_aff(proof), exp), (n, z != 0, tables, chunks)
+    finally:
+        srs.free()
+
+
+def test_open_2p22_chunked_equals_unchunked(oc, piped):
+    """`open` at 2^22 coefficients from (pageable) host memory: automatic chunking (six chunks from the top) gives the bytes of the call with one
+    copy in front; the proof equals the oracle's at the first 2^16 ... no: the O(n) check -- proof == MSM of the oracle's quotient by the identity
+    MSM(q, k_i G) == (sum q_i k_i) G"""
+    import torch
+    from bench import random_fr_limbs
+    hip = piped
+    dev = torch.device("cuda", 0)
+    n = 1 << 22
+    k = random_fr_limbs(n, 0x0BE1)
+    c = random_fr_limbs(n, 0x0BE2)
+    z = random_fr_limbs(1, 0x0BE3)[0]
+    d_pts = _gen_points_dev(hip, torch, dev, k)
+    srs = hip.srs_g1_wrap_dev(d_pts.data_ptr(), n)
+    try:
+        assert hip.srs_g1_precompute(srs) > 0
+        q, v = oc.fr_quotient(c, z)
+        g1, _ = oc.generators()
+        exp = oc.g1_mul_batch(g1, oc.fr_dot(q, k[:n - 1]).reshape(1, 4))[0]
+        proof, val = hip.kzg_open(srs, c, z)
+        assert np.array_equal(val.reshape(-1), v.reshape(-1)) and np.array_equal(_aff(proof), exp)
+        hip.set_option("msm_pipe_chunks", 0)
+        proof0, val0 = hip.kzg_open(srs, c, z)
+        assert np.array_equal(proof0, proof) and np.array_equal(val0, val)
+    finally:
+        srs.free()
+        del d_pts
+        torch.cuda.empty_cache()

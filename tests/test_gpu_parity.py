@@ -705,10 +705,10 @@ def test_kzg_verify_abi_degenerate_left_point(oc, py, hip, rand_fr):
     assert hip.kzg_verify(comh, tau_g2, mont(oc, [(z + 1) % py.R])[0], mont(oc, [val])[0], prh) is False
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 3, 255, 256, 257, 5000, 70000])
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 31, 32, 33, 34, 1024, 1025, 1057, 5000, 32769, 70000])
 def test_kzg_open_quotient_on_device(oc, py, hip, rand_fr, n):
     """keaki_hip_kzg_open (row f-4): p(z) and the commitment of (p - p(z)) / (x - z), the quotient made on the device by the blockwise
-    Horner recurrence (block 256: sizes around one, two and three levels). Against the oracle's Horner quotient + MSM."""
+    Horner recurrence (block 32: sizes around one, two, three and four levels). Against the oracle's Horner quotient + MSM."""
     N = max(n, 2)
     ks, pts = make_points_g1(oc, hip, N, 950)
     c = rand_fr(n, 951 + n)
