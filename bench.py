@@ -566,10 +566,10 @@ def main():
         fk_traffic, fk_traffic_note = None, None
         try:
             from bench_tools.srchash import library_hashes
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r03_fk_pairing_hbm_traffic_pmc.json")))
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r05_fk_pairing_hbm_traffic_pmc.json")))
             hip.lib.keaki_hip_version.restype = C.c_char_p
             if pj.get("hashes", {}).get("fk") != library_hashes(hip.lib.keaki_hip_version().decode()).get("fk"):
-                fk_traffic_note = "profiles/r03_fk_pairing_hbm_traffic_pmc.json was measured on other FK23 kernel sources: refused"
+                fk_traffic_note = "profiles/r05_fk_pairing_hbm_traffic_pmc.json was measured on other FK23 kernel sources: refused"
             elif pj.get("fk_one_call", {}).get("log2d") != lg:
                 fk_traffic_note = "committed PMC figure is for another domain size"
             else:

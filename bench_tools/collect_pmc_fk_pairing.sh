@@ -1,7 +1,7 @@
 #!/bin/bash
 # Fabric traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the FK23 stage kernels at d = 2^21 and of the pairing kernel at 2^14 pairings,
 # and the SQ instruction counters of the FK23 kernels (per wave).
-# Usage (repo root): bench_tools/collect_pmc_fk_pairing.sh <tag>   ->  gpurun_out/<tag>/r03_fk_pairing_hbm_traffic_pmc.json
+# Usage (repo root): bench_tools/collect_pmc_fk_pairing.sh <tag>   ->  gpurun_out/<tag>/r05_fk_pairing_hbm_traffic_pmc.json
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/$1; mkdir -p $O
 cd /tmp
@@ -51,7 +51,7 @@ def total(tag, counter):
     return sum(sum(v) for k, v in per_kernel(tag + "_" + counter, counter).items() if any(x in k for x in ("fft_stage", "pointwise", "mul_jac", "fk_finish", "k_fr_", "k_fk_")))
 res["fk_one_call"] = {"fetch_bytes": total("fk", "FETCH_SIZE") - total("fk1", "FETCH_SIZE"), "write_bytes": total("fk", "WRITE_SIZE") - total("fk1", "WRITE_SIZE"), "log2d": 21}
 print("one call of open_fk at d = 2^21: fetch %.1f GB, write %.1f GB" % (res["fk_one_call"]["fetch_bytes"] / 1e9, res["fk_one_call"]["write_bytes"] / 1e9))
-json.dump(res, open(O + "/r03_fk_pairing_hbm_traffic_pmc.json", "w"), indent=1)
+json.dump(res, open(O + "/r05_fk_pairing_hbm_traffic_pmc.json", "w"), indent=1)
 for k, v in res["kernels"].items():
     print("%-50s launches %3d  fetch %.3f GB  write %.3f GB (totals)" % (k, v["launches"], v["fetch_bytes_total"] / 1e9, v["write_bytes_total"] / 1e9))
 PY

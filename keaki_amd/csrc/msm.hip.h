@@ -446,7 +446,10 @@ KDEV void chunk_slow(const u32* __restrict__ tiles, const uint2* __restrict__ cm
     }
   }
 }
-template <u32 L, u32 R, u32 Q>
+// MASKED (round 5, the default): the ~45 % empty slots of the gather shape are skipped under the exec mask; before, every empty slot was an LDS
+// atomic on a dummy word per lane (branch-free loops): the LDS pipeline, not the VALU, bounds this kernel, and it saw twice the operations it
+// needed (0.84 -> 0.70 ms at 2^24 points, same box; option cs_masked = 0 for the A/B)
+template <u32 L, u32 R, u32 Q, bool MASKED = true>
 static __global__ void __launch_bounds__(C2_THREADS) k_chunk_sort(const u32* __restrict__ tiles, const uint2* __restrict__ cellmeta,
                                                                   const BinMeta* __restrict__ bins, MsmShape s, PartShape ps, u32 nbuckets_total,
                                                                   u32* __restrict__ sorted, v4u_t* __restrict__ segtab, u32* __restrict__ segoff,
@@ -462,7 +465,6 @@ static __global__ void __launch_bounds__(C2_THREADS) k_chunk_sort(const u32* __r
   const BinMeta bm = bins[b];
   const uint2* cm = cellmeta + (size_t)b * ps.ntiles;
   u32 tot[2] = {0, 0};                                      // the bin's per-bucket totals: buckets 2 t, 2 t + 1 of this lane
-  u32 seg[2][SEG_INLINE] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // and their first SEG_INLINE segment words
   u32 c0 = 0;                                               // first cell that reaches into the chunk
   // prologue: counters cleared, descriptors of the first chunk's cells staged
   for (u32 f = t; f < PART_MAX_FINE + 64; f += C2_THREADS) hist[f] = 0;
@@ -541,7 +543,8 @@ static __global__ void __launch_bounds__(C2_THREADS) k_chunk_sort(const u32* __r
 #pragma unroll
             for (u32 x = 0; x < 4; x++) {
               const u32 en = cur[q][r][x];
-              atomicAdd(&hist[en ? (en >> TE_FINE) & (PART_MAX_FINE - 1u) : dummy], 1u);    // an entry: its fine bucket; 0: the lane's dummy counter
+              if constexpr (MASKED) { if (en) atomicAdd(&hist[(en >> TE_FINE) & (PART_MAX_FINE - 1u)], 1u); }
+              else atomicAdd(&hist[en ? (en >> TE_FINE) & (PART_MAX_FINE - 1u) : dummy], 1u);    // an entry: its fine bucket; 0: the lane's dummy counter
             }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -555,38 +558,48 @@ static __global__ void __launch_bounds__(C2_THREADS) k_chunk_sort(const u32* __r
     const bool slow = sh_odd != 0;
     if (slow) {                                             // count again, the plain way
       lds_barrier();
-      for (u32 f = t; f < nf; f += C2_THREADS) hist[f] = 0;
+      u32 ts = threadIdx.x;
+      asm volatile("" : "+v"(ts));
+      for (u32 f = ts; f < nf; f += C2_THREADS) hist[f] = 0;
       lds_barrier();
       chunk_slow<0>(tiles, cm, ps, s.stride, c0, lo, hi, hist, pay, &sh_next);
       lds_barrier();
     }
     const u32 c_next = sh_next;
+    u32 tm = threadIdx.x;
+    asm volatile("" : "+v"(tm));                          // (addresses formed from the lane index are formed here, per chunk: hoisted out of the loop they were spilled)
     uint2 mnext[C2_META / C2_THREADS];
     if (k + 1 < bm.nch) {                                   // the next chunk's descriptors: in flight under the scan and the placing pass
 #pragma unroll
       for (u32 i = 0; i < C2_META / C2_THREADS; i++) {
-        const u32 ci = t + i * C2_THREADS;
+        const u32 ci = tm + i * C2_THREADS;
         mnext[i] = ci < CELLS && c_next + ci < ps.ntiles ? cm[c_next + ci] : make_uint2(0xFFFFFFFFu, 0u);
       }
     }
     // exclusive scan of the 2048 counters: two per lane, wave scan, wave totals through LDS
-    const u32 x0 = hist[2 * t], x1 = hist[2 * t + 1], sum = x0 + x1;
+    const u32 x0 = hist[2 * tm], x1 = hist[2 * tm + 1], sum = x0 + x1;
     tot[0] += x0; tot[1] += x1;
     u32 v = sum;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up(v, o, 64); if ((t & 63u) >= (u32)o) v += y; }
-    if ((t & 63u) == 63u) wsum[t >> 6] = v;
+    for (int o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up(v, o, 64); if ((tm & 63u) >= (u32)o) v += y; }
+    if ((tm & 63u) == 63u) wsum[tm >> 6] = v;
     lds_barrier();                                                                                  // ---- 2: wave totals
     u32 base = 0;
 #pragma unroll
-    for (u32 w = 0; w < C2_THREADS / 64; w++) base += w < (t >> 6) ? wsum[w] : 0u;
+    for (u32 w = 0; w < C2_THREADS / 64; w++) base += w < (tm >> 6) ? wsum[w] : 0u;
     const u32 ex = base + v - sum;
-    hist[2 * t] = ex; hist[2 * t + 1] = ex + x0;            // first position of buckets 2 t, 2 t + 1 inside the chunk
+    hist[2 * tm] = ex; hist[2 * tm + 1] = ex + x0;            // first position of buckets 2 tm, 2 tm + 1 inside the chunk
     {
       const u32 w0 = ex | ((ex + x0) << 16), w1 = (ex + x0) | ((ex + sum) << 16);                   // first | end << 16, <= 32768 each
+      // the first SEG_INLINE words of a bucket go straight to its row of the bucket-major table (round 5: kept in eight registers until the end of
+      // the bin they were what the masked gather loops spilled), the later ones to the chunk-major rows
+      if (k < SEG_INLINE) {
 #pragma unroll
-      for (u32 kk = 0; kk < SEG_INLINE; kk++) if (kk == k) { seg[0][kk] = w0; seg[1][kk] = w1; }
-      if (k >= SEG_INLINE && 2 * t < nf) { u32* so = segoff + (size_t)(bm.chunk_first + k) * nf + 2 * t; so[0] = w0; so[1] = w1; }
+        for (u32 i = 0; i < 2; i++) {
+          const u32 f = 2 * tm + i, g = part_bucket(ps, b, f);
+          if (f < nf && g < nbuckets_total) reinterpret_cast<u32*>(segtab)[(size_t)g * SEG_INLINE + k] = i ? w1 : w0;
+        }
+      } else if (2 * tm < nf) { u32* so = segoff + (size_t)(bm.chunk_first + k) * nf + 2 * tm; so[0] = w0; so[1] = w1; }
     }
     STAMP(b == 100 && t == 0 && k < 8, k * 16 + 4);
     lds_barrier();                                                                                  // ---- 3: positions complete
@@ -610,8 +623,12 @@ static __global__ void __launch_bounds__(C2_THREADS) k_chunk_sort(const u32* __r
 #pragma unroll
             for (u32 x = 0; x < 4; x++) {
               const u32 en = cur[q][r][x];
-              const u32 pos = atomicAdd(&hist[en ? (en >> TE_FINE) & (PART_MAX_FINE - 1u) : dummy], 1u);
-              pay[en ? pos : C2_CAP + (t & 63u)] = chunk_payload(en, ibase, s.stride);
+              if constexpr (MASKED) {
+                if (en) { const u32 pos = atomicAdd(&hist[(en >> TE_FINE) & (PART_MAX_FINE - 1u)], 1u); pay[pos] = chunk_payload(en, ibase, s.stride); }
+              } else {
+                const u32 pos = atomicAdd(&hist[en ? (en >> TE_FINE) & (PART_MAX_FINE - 1u) : dummy], 1u);
+                pay[en ? pos : C2_CAP + (t & 63u)] = chunk_payload(en, ibase, s.stride);
+              }
             }
         }
         __builtin_amdgcn_sched_barrier(0);                  // a batch's returning atomics in flight, not all
@@ -626,14 +643,16 @@ static __global__ void __launch_bounds__(C2_THREADS) k_chunk_sort(const u32* __r
     STAMP(b == 100 && t == 0 && k < 8, k * 16 + 6);
     lds_barrier();                                                                                  // ---- 4: image complete
     STAMP(b == 100 && t == 0 && k < 8, k * 16 + 7);
+    u32 tw = threadIdx.x;
+    asm volatile("" : "+v"(tw));
     u32* dst = sorted + bm.img_base + lo;
 #pragma unroll 4
-    for (u32 q = t; q < hi - lo; q += C2_THREADS) dst[q] = pay[q];
+    for (u32 q = tw; q < hi - lo; q += C2_THREADS) dst[q] = pay[q];
     // ready the next chunk: counters cleared, descriptors staged
-    for (u32 f = t; f < PART_MAX_FINE + 64; f += C2_THREADS) hist[f] = 0;
+    for (u32 f = tw; f < PART_MAX_FINE + 64; f += C2_THREADS) hist[f] = 0;
     if (k + 1 < bm.nch) {
 #pragma unroll
-      for (u32 i = 0; i < C2_META / C2_THREADS; i++) if (t + i * C2_THREADS < CELLS) meta[t + i * C2_THREADS] = mnext[i];
+      for (u32 i = 0; i < C2_META / C2_THREADS; i++) if (tw + i * C2_THREADS < CELLS) meta[tw + i * C2_THREADS] = mnext[i];
     }
     if (t == 0) { sh_next = ps.ntiles; sh_odd = 0; }
     c0 = c_next;
@@ -647,7 +666,7 @@ static __global__ void __launch_bounds__(C2_THREADS) k_chunk_sort(const u32* __r
     const u32 f = 2 * te + i, g = part_bucket(ps, b, f);
     if (f < nf && g < nbuckets_total) {
       bucket_counts[g] = tot[i];
-      segtab[g] = v4u_t{seg[i][0], seg[i][1], seg[i][2], seg[i][3]};
+      for (u32 kk = bm.nch; kk < SEG_INLINE; kk++) reinterpret_cast<u32*>(segtab)[(size_t)g * SEG_INLINE + kk] = 0u;     // chunks the bin does not have
     }
   }
 }
@@ -988,8 +1007,8 @@ KDEV Aff<Fq> msm_load_row(const Aff<Fq>* __restrict__ p) {
 // empty, leaves the registers in state29 | ACC_MIDDLE state29 -> state29 (buckets without pairs in this pass are not touched) |
 // ACC_LAST state29 -> canonical bucket (every bucket, also the ones the heavy path owns in this pass: k_msm_heavy_combine adds to them)
 enum { ACC_WHOLE = 0, ACC_FIRST = 1, ACC_MIDDLE = 2, ACC_LAST = 3 };
-template <int NT, int MODE>
-static __global__ void __launch_bounds__(256) k_msm_accumulate_g1_u29(const Aff<Fq>* __restrict__ points, SortView v,
+template <int NT, int MODE, int PF = 1>      // PF = 0: the loop of rounds 1-4 (loads at the top of every iteration): A/B switch acc_prefetch
+static __global__ void __launch_bounds__(256, 3) k_msm_accumulate_g1_u29(const Aff<Fq>* __restrict__ points, SortView v,
                                                                       const u32* __restrict__ counts, const u32* __restrict__ perm,
                                                                       u32 nbuckets_total, Xyzz<Fq>* __restrict__ buckets,
                                                                       Acc29* __restrict__ state29) {
@@ -1010,9 +1029,28 @@ static __global__ void __launch_bounds__(256) k_msm_accumulate_g1_u29(const Aff<
   U29 X1, Y1, ZZ, ZZZ;
   bool empty = true;
   if constexpr (MODE == ACC_MIDDLE || MODE == ACC_LAST) empty = acc29_load(state29 + t, X1, Y1, ZZ, ZZZ);
+  // Software pipeline (round 5): the index of pair k + 2 and the table row of pair k + 1 are requested before pair k is added, so a wave
+  // never waits for its gather -- until then every iteration began with two dependent loads (index, then the 64-byte row) that only the
+  // other two waves of the SIMD could cover (alu.frac 0.94). 18 more registers: 167 of the 168 that three waves per SIMD allow.
+  u32 e1 = 0, e2 = 0;
+  Aff<Fq> q1;
+  if constexpr (PF != 0) {
+    e1 = cnt > 0 ? seg_next(sw, v) : 0u; e2 = cnt > 1 ? seg_next(sw, v) : 0u;
+    q1 = msm_load_row<NT>(points + (e1 & 0x7FFFFFFFu));
+  }
   for (u32 k = 0; k < cnt; k++) {
-    u32 e = seg_next(sw, v);
-    Aff<Fq> q = msm_load_row<NT>(points + (e & 0x7FFFFFFFu));
+    u32 e;
+    Aff<Fq> q;
+    if constexpr (PF != 0) {
+      e = e1;
+      q = q1;
+      e1 = e2;
+      if (k + 1 < cnt) q1 = msm_load_row<NT>(points + (e1 & 0x7FFFFFFFu));
+      if (k + 2 < cnt) e2 = seg_next(sw, v);
+    } else {
+      e = seg_next(sw, v);
+      q = msm_load_row<NT>(points + (e & 0x7FFFFFFFu));
+    }
     if (aff_is_inf(q)) continue;
     q.y = f_cneg(q.y, (e >> 31) != 0);
     const U29 X2 = u29_from_sat_shift5(q.x.l), Y2 = u29_from_sat_shift5(q.y.l);

@@ -167,15 +167,17 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
     hipLaunchKernelGGL(k_cell_prefix, dim3(ps.nbins), dim3(1024), 0, st, (const u16*)tstart, ps, cellmeta, bin_total);
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, (const u32*)bin_total, ps.nbins, bins);
     {
-#define KEAKI_CHUNK_SORT(L, R, Q)                                                                                                                       \
-  hipLaunchKernelGGL((k_chunk_sort<L, R, Q>), dim3(ps.nbins), dim3(C2_THREADS), 0, st, (const u32*)tiles, (const uint2*)cellmeta, (const BinMeta*)bins, sj, \
+#define KEAKI_CHUNK_SORT1(L, R, Q, M)                                                                                                                  \
+  hipLaunchKernelGGL((k_chunk_sort<L, R, Q, M>), dim3(ps.nbins), dim3(C2_THREADS), 0, st, (const u32*)tiles, (const uint2*)cellmeta, (const BinMeta*)bins, sj, \
                      ps, (u32)nb, sorted, segtab, segoff, hist)
+#define KEAKI_CHUNK_SORT(L, R, Q) do { if (ctx->tune.cs_masked) KEAKI_CHUNK_SORT1(L, R, Q, true); else KEAKI_CHUNK_SORT1(L, R, Q, false); } while (0)
       switch (ps.geom) {                // lanes per cell, 16-byte pieces per lane and cell, cells per group: for cells of about 18 / 36 / 72 / 144+ entries
         case 0: KEAKI_CHUNK_SORT(8, 1, 16); break;
         case 1: KEAKI_CHUNK_SORT(16, 1, 16); break;
         case 2: KEAKI_CHUNK_SORT(16, 2, 8); break;
         default: KEAKI_CHUNK_SORT(16, 4, 4); break;
       }
+#undef KEAKI_CHUNK_SORT1
 #undef KEAKI_CHUNK_SORT
     }
     ST_TRY(launch_check(ctx, "chunk_sort"));
@@ -193,7 +195,12 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
     if constexpr (std::is_same<F, Fq>::value) {
       if (u29) {
 #define KEAKI_ACC(NT, MODE) hipLaunchKernelGGL((k_msm_accumulate_g1_u29<NT, MODE>), ga, ba, 0, st, pts, view, (const u32*)hist, (const u32*)perm, (u32)nb, buckets, state29)
-        if (K == 1) { if (ctx->tune.acc_nt) KEAKI_ACC(1, ACC_WHOLE); else KEAKI_ACC(0, ACC_WHOLE); }
+        if (K == 1) {
+          if (ctx->tune.acc_nt) KEAKI_ACC(1, ACC_WHOLE);
+          else if (!ctx->tune.acc_prefetch)
+            hipLaunchKernelGGL((k_msm_accumulate_g1_u29<0, ACC_WHOLE, 0>), ga, ba, 0, st, pts, view, (const u32*)hist, (const u32*)perm, (u32)nb, buckets, state29);
+          else KEAKI_ACC(0, ACC_WHOLE);
+        }
         else if (first) KEAKI_ACC(0, ACC_FIRST);
         else if (!last) KEAKI_ACC(0, ACC_MIDDLE);
         else KEAKI_ACC(0, ACC_LAST);

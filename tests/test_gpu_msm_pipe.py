@@ -391,3 +391,34 @@ def test_open_2p22_chunked_equals_unchunked(oc, piped):
         srs.free()
         del d_pts
         torch.cuda.empty_cache()
+
+
+def test_a_chunked_call_that_fails_leaves_the_context_usable(oc, rand_fr):
+    """a chunked host-pointer MSM / open whose workspace cannot be had (keaki_hip_debug_set_alloc_limit) returns KEAKI_ERR_OOM before any pass
+    runs, no copy is left reading the caller's array (the copy stream is drained on every exit), and the same context then gives the right
+    answer -- with the limit lifted, and in chunks again"""
+    from keaki_amd.hip import KeakiHip, KeakiHipError
+    h = KeakiHip(0)
+    try:
+        n = 70000
+        g1, _ = oc.generators()
+        pts = h.g1_mul_batch(g1, _mont(oc, rand_fr(n, 7700)))
+        s = _mont(oc, rand_fr(n, 7701))
+        z = _mont(oc, rand_fr(1, 7702))[0]
+        exp = oc.msm_g1(pts, s, threads=os.cpu_count() or 1)
+        q, v = oc.fr_quotient(s, z)
+        exp_open = oc.msm_g1(pts[:n - 1], q, threads=os.cpu_count() or 1)
+        srs = h.srs_g1_upload(pts)
+        h.set_option("msm_pipe_chunks", 4)
+        h.debug_set_alloc_limit(1 << 16)                      # every workspace of a 70000-term MSM is larger
+        for call in (lambda: h.msm_g1(srs, s), lambda: h.kzg_open(srs, s, z)):
+            with pytest.raises(KeakiHipError) as e:
+                call()
+            assert e.value.status == -3
+        h.debug_set_alloc_limit(0)
+        assert np.array_equal(_aff(h.msm_g1(srs, s)), exp)
+        proof, val = h.kzg_open(srs, s, z)
+        assert np.array_equal(_aff(proof), exp_open) and np.array_equal(val.reshape(-1), v.reshape(-1))
+        srs.free()
+    finally:
+        h.close()
