@@ -703,7 +703,13 @@ def main():
     isa, isa_why = stamped_profile("r05_accumulate_isa.json", MSM_KERNEL_SOURCES)
     mul_cyc, simple_cyc, cyc_src = stream_cycles_from_ubench(3)
     if isa is not None and mul_cyc is not None and simple_cyc is not None:
-        ipa, mads = float(isa["loop_instructions"]), float(isa["loop_v_mad_u64_u32"])
+        ipa, mads = float(isa.get("loop_valu", isa["loop_instructions"])), float(isa["loop_v_mad_u64_u32"])
+        ipa_src = "static: VALU instructions on the common path of the loop in the emitted ISA"
+        # the DYNAMIC count where a counter pass of this build is committed: SQ_INSTS_VALU of one launch / the wave-additions it performs
+        sq, _ = stamped_profile("r05_msm_sq_insts.json", MSM_KERNEL_SOURCES)
+        if sq is not None and sq.get("log2n") == args.log2n and bool(sq.get("precompute", True)) == (not args.no_precompute) and sq.get("accumulate_valu"):
+            ipa = float(sq["accumulate_valu"]) / (n * windows / 64.0)
+            ipa_src = "dynamic: SQ_INSTS_VALU of one launch / (n x windows / 64) wave-additions (profiles/r05_msm_sq_insts.json)"
         # model: every 162 multiply-adds are one product stream of 205 instructions at its measured rate, what is left of the loop body runs
         # at the rate of a plain 32-bit VALU instruction
         model_cycles = mads / 162.0 * mul_cyc + max(0.0, ipa - mads / 162.0 * 205.0) * simple_cyc
@@ -712,10 +718,12 @@ def main():
         modmuls = 10.0 * n * windows / avg_bucket_s
         alu = {"bound": "integer issue (v_mad_u64_u32 streams)", "achieved": modmuls / 1e9, "peak": modmuls / 1e9 * measured_cycles / model_cycles, "unit": "G modmul/s",
                "frac": model_cycles / measured_cycles, "simd_cycles_per_mixed_add_measured": measured_cycles, "simd_cycles_per_mixed_add_at_stream_rate": model_cycles,
-               "issues_per_mixed_add": ipa, "v_mad_u64_u32_per_mixed_add": mads, "product_stream_cycles": mul_cyc, "plain_valu_cycles": simple_cyc,
+               "issues_per_mixed_add": ipa, "issues_per_mixed_add_source": ipa_src, "v_mad_u64_u32_per_mixed_add": mads, "product_stream_cycles": mul_cyc, "plain_valu_cycles": simple_cyc,
                "sources": ["profiles/r05_accumulate_isa.json", cyc_src],
                "note": "a schedule diagnostic (how close the kernel runs to the issue rate of ITS OWN instruction stream at 3 waves per SIMD and "
-                       "2.4 GHz), not a claim that the stream is minimal"}
+                       "2.4 GHz), not a claim that the stream is minimal. Round 5 corrected the count: until then the loop body included the exact-zero test that "
+                       "hangs off the filter (241 instructions, one product stream, taken 18 times in 2^29 additions), which put frac at 0.94-0.96; the common "
+                       "path holds 9.06 product streams, not 10.06"}
     else:
         alu = {"note": isa_why or "no micro-benchmark file"}
     result = {

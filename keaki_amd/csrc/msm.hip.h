@@ -1101,7 +1101,7 @@ static __global__ void __launch_bounds__(256, 3) k_msm_accumulate_g1_u29(const A
 // G2 bucket accumulation in the lazy limbs (xyzz29_g2.hip.h): same schedule, ~5,600 instead of ~9,000 instructions per mixed addition.
 // Buckets are written back saturated and canonical (the tail keeps the generic arithmetic).
 template <int CONT>
-static __global__ void __launch_bounds__(256) k_msm_accumulate_g2_u29(const Aff<Fq2>* __restrict__ points, SortView v,
+static __global__ void __launch_bounds__(256, 2) k_msm_accumulate_g2_u29(const Aff<Fq2>* __restrict__ points, SortView v,
                                                                       const u32* __restrict__ counts, const u32* __restrict__ perm,
                                                                       u32 nbuckets_total, Xyzz<Fq2>* __restrict__ buckets) {
   u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
