@@ -16,7 +16,8 @@ handle the keaki context is created on), so the K timed steps are ordered withou
 the dominant kernel (`roofline.kernel_ms`) is read in a separate, untimed pass over the same steps.
 
 Prints ONE JSON line (rank 0). `roofline` prices the dominant kernel (bucket accumulation) against HBM with the algorithmic 96 B
-per scalar-mult; `alu` prices it against the measured integer-issue rate, which is what actually bounds this path; `cpu_baseline`
+per scalar-mult; `alu` prices it against the measured integer-issue rate, which is what actually bounds this path (the shader clock is power-limited to
+1.45-2.0 GHz while the multipliers run: `frac_of_power_limited_rate` compares VALU instructions per second with the pure product stream); `cpu_baseline`
 times the CPU restatement of the arkworks algorithm (oracle/, the checker -- never the product) on a bounded sample. Besides
 `value` the line carries `value_no_tables`, `value_incl_scalar_h2d`, a `strong` block (BASELINE config 4: 2^26 points in total)
 when N > 1 or --strong is given, the `kem` block (second half of the BASELINE metric; `pairings_per_s` = BASELINE config 3), an `fk`
@@ -100,6 +101,20 @@ def stream_cycles_from_ubench(waves=3):
     except OSError:
         pass
     return mul, simple, os.path.relpath(path, ROOT)
+
+
+def power_limited_valu_rate(waves):
+    """VALU wave-instructions per second and SIMD of the pure product stream (u29_mul: 205 instructions, 162 v_mad_u64_u32) at `waves` waves per
+    SIMD, from the committed clock micro-benchmark (bench_tools/ubench_clock.hip -> profiles/r05_ubench_clock.txt): the shader clock drops from
+    2.4 GHz to 1.45-2.0 GHz while the multipliers run, so this rate -- not a cycle count at the peak clock -- is what the arithmetic kernels can reach"""
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "r05_ubench_clock.txt")):
+            m = re.match(r"u29_mul chain on every SIMD\s+waves/SIMD=%d\s+launch\s+([0-9.]+) ms" % waves, line)
+            if m:
+                return waves * 40000 * 205 / (float(m.group(1)) * 1e-3)
+    except OSError:
+        pass
+    return None
 
 
 def stamped_profile(name, files):
@@ -513,6 +528,9 @@ def main():
                               "valu_per_wave_of_32_pairings": valu_per_wave, "waves_per_simd": 2, "simd_cycles_per_valu_instruction_measured": cyc,
                               "simd_cycles_per_valu_instruction_at_issue_rate": model, "frac": model / cyc, "v_mad_u64_u32_share": f_mad,
                               "issue_cycles_at_two_waves": rates,
+                              "valu_wave_instructions_per_s_per_simd": waves * valu_per_wave / (dec_ms * 1e-3) / 1024.0,
+                              "power_limited_stream_rate_per_simd": power_limited_valu_rate(2),
+                              "frac_of_power_limited_rate": (waves * valu_per_wave / (dec_ms * 1e-3) / 1024.0 / power_limited_valu_rate(2)) if power_limited_valu_rate(2) else None,
                               "sources": ["profiles/r05_pairing_pmc_sq_insts.json", "profiles/r05_pairing_isa.json", "profiles/r01_ubench_u29_gfx950.txt"],
                               "note": "dec_ms includes the KDF kernel (k_blake3_gt_xof, < 1 %); frac = how close the launch runs to the issue rate of its own "
                                       "instruction mix at the two waves per SIMD its 255 registers allow -- a schedule diagnostic, not a claim that the stream is minimal"}
@@ -587,7 +605,10 @@ def main():
                 if tot_valu:
                     cyc = stages_ms * 1e-3 * 2.4e9 * 1024.0 / float(tot_valu)
                     f_mad = 0.6                                  # share of v_mad_u64_u32 in the 29-bit product streams the ladders are made of (205-instruction product: 162)
-                    fk["alu"].update({"stage_valu_wave_instructions_per_call": float(tot_valu), "simd_cycles_per_valu_instruction_measured": cyc,
+                    fk["alu"].update({"valu_wave_instructions_per_s_per_simd": float(tot_valu) / (stages_ms * 1e-3) / 1024.0,
+                                      "power_limited_stream_rate_per_simd": power_limited_valu_rate(3),
+                                      "frac_of_power_limited_rate": (float(tot_valu) / (stages_ms * 1e-3) / 1024.0 / power_limited_valu_rate(3)) if power_limited_valu_rate(3) else None,
+                                      "stage_valu_wave_instructions_per_call": float(tot_valu), "simd_cycles_per_valu_instruction_measured": cyc,
                                       "simd_cycles_per_valu_instruction_at_issue_rate": f_mad * 4.8 + (1 - f_mad) * 4.1, "frac": (f_mad * 4.8 + (1 - f_mad) * 4.1) / cyc,
                                       "frac_note": "SIMD-cycles of the butterfly stages of this run / VALU wave-instructions of the stage kernels in one call (profiles/r05_fk_sq_insts.json), "
                                                    "against the issue rates of profiles/r01_ubench_u29_gfx950.txt at two waves per SIMD (4.8 multiply-add, 4.1 plain)"})
@@ -719,7 +740,10 @@ def main():
         alu = {"bound": "integer issue (v_mad_u64_u32 streams)", "achieved": modmuls / 1e9, "peak": modmuls / 1e9 * measured_cycles / model_cycles, "unit": "G modmul/s",
                "frac": model_cycles / measured_cycles, "simd_cycles_per_mixed_add_measured": measured_cycles, "simd_cycles_per_mixed_add_at_stream_rate": model_cycles,
                "issues_per_mixed_add": ipa, "issues_per_mixed_add_source": ipa_src, "v_mad_u64_u32_per_mixed_add": mads, "product_stream_cycles": mul_cyc, "plain_valu_cycles": simple_cyc,
-               "sources": ["profiles/r05_accumulate_isa.json", cyc_src],
+               "valu_wave_instructions_per_s_per_simd": ipa * (n * windows / 64.0) / avg_bucket_s / 1024.0,
+               "power_limited_stream_rate_per_simd": power_limited_valu_rate(3),
+               "frac_of_power_limited_rate": (ipa * (n * windows / 64.0) / avg_bucket_s / 1024.0 / power_limited_valu_rate(3)) if power_limited_valu_rate(3) else None,
+               "sources": ["profiles/r05_accumulate_isa.json", cyc_src, "profiles/r05_ubench_clock.txt"],
                "note": "a schedule diagnostic (how close the kernel runs to the issue rate of ITS OWN instruction stream at 3 waves per SIMD and "
                        "2.4 GHz), not a claim that the stream is minimal. Round 5 corrected the count: until then the loop body included the exact-zero test that "
                        "hangs off the filter (241 instructions, one product stream, taken 18 times in 2^29 additions), which put frac at 0.94-0.96; the common "
