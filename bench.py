@@ -16,8 +16,8 @@ handle the keaki context is created on), so the K timed steps are ordered withou
 the dominant kernel (`roofline.kernel_ms`) is read in a separate, untimed pass over the same steps.
 
 Prints ONE JSON line (rank 0). `roofline` prices the dominant kernel (bucket accumulation) against HBM with the algorithmic 96 B
-per scalar-mult; `alu` prices it against the measured integer-issue rate, which is what actually bounds this path (the shader clock is power-limited to
-1.45-2.0 GHz while the multipliers run: `frac_of_power_limited_rate` compares VALU instructions per second with the pure product stream); `cpu_baseline`
+per scalar-mult; `alu` prices it against the measured integer-issue rate, which is what actually bounds this path (the shader clock is 1.86-2.35 GHz while these kernels
+run, not the 2.4 GHz peak: `frac_of_power_limited_rate` compares VALU instructions per second with the pure product stream); `cpu_baseline`
 times the CPU restatement of the arkworks algorithm (oracle/, the checker -- never the product) on a bounded sample. Besides
 `value` the line carries `value_no_tables`, `value_incl_scalar_h2d`, a `strong` block (BASELINE config 4: 2^26 points in total)
 when N > 1 or --strong is given, the `kem` block (second half of the BASELINE metric; `pairings_per_s` = BASELINE config 3), an `fk`
@@ -105,13 +105,13 @@ def stream_cycles_from_ubench(waves=3):
 
 def power_limited_valu_rate(waves):
     """VALU wave-instructions per second and SIMD of the pure product stream (u29_mul: 205 instructions, 162 v_mad_u64_u32) at `waves` waves per
-    SIMD, from the committed clock micro-benchmark (bench_tools/ubench_clock.hip -> profiles/r05_ubench_clock.txt): the shader clock drops from
-    2.4 GHz to 1.45-2.0 GHz while the multipliers run, so this rate -- not a cycle count at the peak clock -- is what the arithmetic kernels can reach"""
+    SIMD, from the committed clock micro-benchmark (bench_tools/ubench_clock.hip -> profiles/r05_ubench_clock.txt): wall clock, so the power-dependent
+    shader clock (1.86-2.35 GHz while these kernels run, 2.4 idle) is inside it -- this rate, not a cycle count at the peak clock, is what the arithmetic can reach"""
     try:
         for line in open(os.path.join(ROOT, "profiles", "r05_ubench_clock.txt")):
-            m = re.match(r"u29_mul chain on every SIMD\s+waves/SIMD=%d\s+launch\s+([0-9.]+) ms" % waves, line)
+            m = re.match(r"u29_mul chain \(205 instr, 162 mads\)\s+waves/SIMD=%d\s+launch\s+([0-9.]+) ms" % waves, line)
             if m:
-                return waves * 40000 * 205 / (float(m.group(1)) * 1e-3)
+                return waves * 60000 * 205 / (float(m.group(1)) * 1e-3)
     except OSError:
         pass
     return None
