@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the MSM pipeline against the CPU oracle: random sizes (also just around tile / chunk boundaries), with and
-without window tables, random / sparse / repeated scalars, some identity points.  python tests/fuzz/fuzz_msm.py [rounds [seed]]"""
+without window tables, random / sparse / repeated scalars, some identity points; since round 5 every call of the host-pointer entry draws a
+random chunk count and growth of the chunked upload (0 = one copy in front), and `open` runs beside `commit` on the same inputs.
+python tests/fuzz/fuzz_msm.py [rounds [seed]]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,16 +35,29 @@ for it, n in enumerate(sizes):
     scm = mont(sc)
     exp = oc.msm_g1(pts, scm, threads=8)
     srs = hip.srs_g1_upload(pts)
+    def draw_pipe():
+        hip.set_option("msm_pipe_chunks", int(rng.choice([0, 0, 2, 3, 4, 6, 9, 17])))
+        hip.set_option("msm_pipe_growth", int(rng.choice([100, 140, 300])))
     try:
+        draw_pipe()
         got = jac_to_affine_words(hip.msm_g1(srs, scm))
         hip.srs_g1_precompute(srs)
+        draw_pipe()
         got_t = jac_to_affine_words(hip.msm_g1(srs, scm))
         m = max(1, n // 3)                                   # a shorter polynomial on the same SRS / tables
+        draw_pipe()
         got_p = jac_to_affine_words(hip.msm_g1(srs, scm[:m]))
         exp_p = oc.msm_g1(pts[:m], scm[:m], threads=8)
+        # `open` on the same coefficients: device quotient from the top, chunk by chunk, + MSM
+        z = mont(rand_fr_ints(1, S0 + 777 + it))[0]
+        draw_pipe()
+        proof, val = hip.kzg_open(srs, scm, z)
+        q, v = oc.fr_quotient(scm, z)
+        ok_open = np.array_equal(val.reshape(-1), v.reshape(-1)) and (n < 2 or np.array_equal(jac_to_affine_words(proof), oc.msm_g1(pts[:n - 1], q, threads=8)))
     finally:
         srs.free()
-    ok = np.array_equal(got, exp) and np.array_equal(got_t, exp) and np.array_equal(got_p, exp_p)
+        hip.set_option("msm_pipe_chunks", -1); hip.set_option("msm_pipe_growth", 140)
+    ok = np.array_equal(got, exp) and np.array_equal(got_t, exp) and np.array_equal(got_p, exp_p) and ok_open
     bad += not ok
     print("n=%6d mode=%d %s" % (n, mode, "ok" if ok else "MISMATCH"), flush=True)
 print("mismatches:", bad)
