@@ -491,6 +491,7 @@ void keaki_hip_ctx_destroy(keaki_hip_ctx* ctx) {
   for (auto& e : ctx->fk_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : ctx->pipe_in) if (e) (void)hipEventDestroy(e);
   for (auto& e : ctx->pipe_done) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ctx->open_ev) if (e) (void)hipEventDestroy(e);
   if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
   for (auto& e : ctx->aux_ev) if (e) (void)hipEventDestroy(e);
   if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
@@ -1563,9 +1564,9 @@ keaki_status keaki_hip_kzg_open(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs,
   // uploaded on the copy stream while chunk j - 1's quotient and MSM pass run; its quotient starts from the carry Q_hi the chunk above left
   // (planted as one more "coefficient" behind the chunk), and the MSM consumes the quotient chunk by chunk (msm_host.hip.h: MsmPipe).
   std::vector<std::pair<size_t, size_t>> cch;                                    // coefficient chunks [lo, hi), top first
-  // (automatic from 2^22 coefficients on: every chunk pays ~0.3 ms of dependent Horner levels, which a 2^20-coefficient call -- 2.56 ms with
-  // the copy in front, 2.89 ms in three chunks -- does not earn back; 2^24: 20.8 against 28.5 ms, profiles/r05_open_chunked.txt)
-  if (ctx->tune.msm_pipe_chunks >= 2 || n >= ((size_t)1 << 22)) {
+  // (automatic from 2^21 coefficients on: the first chunk's quotient stays in front of the first pass; 2^20: 2.71 ms in three chunks against 2.64
+  // with the copy in front, 2^21: 4.05 / 4.36, 2^22: 6.43 / 8.10, 2^24: 19.2 / 28.0 ms -- profiles/r05_open_chunked.txt)
+  if (ctx->tune.msm_pipe_chunks >= 2 || n >= ((size_t)1 << 21)) {
     const std::vector<size_t> bounds = msm_pipe_bounds(ctx->tune, n);
     for (size_t j = 0; j + 1 < bounds.size(); j++) cch.push_back({n - bounds[j + 1], n - bounds[j]});
     if (cch.size() >= 2 && cch.back().second == 1) { cch[cch.size() - 2].first = 0; cch.pop_back(); }     // the lowest chunk must leave a quotient coefficient
@@ -1575,17 +1576,35 @@ keaki_status keaki_hip_kzg_open(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs,
     if (n) ST_TRY(open_quotient_run(ctx, ctx->io_a.p, n, point, b + o_q, b + o_v, b + o_w));
     ST_TRY(msm_g1_run(ctx, srs->d, srs->n, b + o_q, nq, ctx->io_b.p, tb.first, tb.second));
   } else {
+    // Three streams: the copy stream brings chunk j up, the AUX stream turns it into quotient coefficients (a handful of short,
+    // latency-bound kernels that depend on the chunk above only through its carry), the context's stream runs the MSM passes. The quotient of
+    // chunk j + 1 therefore runs beside the MSM pass of chunk j instead of in front of its own (2^24 coefficients: 20.8 -> 18.5 ms).
     ChunkUploader up(ctx);
     ST_TRY(up.begin());
+    ST_TRY(aux_ready(ctx));
+    for (auto& e : ctx->open_ev) if (!e) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipStream_t ax = ctx->aux_stream, main_st = ctx->stream;
+    HIP_TRY(ctx, hipEventRecord(ctx->open_ev[4], main_st));              // behind the value slot's memset and every earlier user of io_a / io_c
+    HIP_TRY(ctx, hipStreamWaitEvent(ax, ctx->open_ev[4], 0));
+    struct AuxFence { hipStream_t s; ~AuxFence() { (void)hipStreamSynchronize(s); } } aux_fence{ax};      // nothing of this call is left on it at any exit
     MsmPipe pipe;
     for (const auto& c : cch) pipe.ranges.push_back({c.first ? c.first - 1 : 0, c.second - 1 - (c.first ? c.first - 1 : 0)});   // q_i = Q_(i+1): chunk [lo, hi) yields q_(lo-1) .. q_(hi-2)
     char* a = (char*)ctx->io_a.p;
     pipe.stage = [&](size_t j) -> keaki_status {
       const size_t lo = cch[j].first, hi = cch[j].second;
-      ST_TRY(up.chunk(j, a + lo * 32, (const char*)coeffs + lo * 32, (hi - lo) * 32));
-      // the carry: Q_hi = q_(hi-1), written by the chunk above; it takes the place of c_hi, which that chunk has consumed
-      if (j) HIP_TRY(ctx, hipMemcpyAsync(a + hi * 32, b + o_q + (hi - 1) * 32, 32, hipMemcpyDeviceToDevice, ctx->stream));
-      return open_quotient_run(ctx, a + lo * 32, hi - lo + (j ? 1 : 0), point, b + o_q + lo * 32, lo ? b + o_q + (lo - 1) * 32 : b + o_v, b + o_w);
+      const int h = (int)(j & 1);
+      HIP_TRY(ctx, hipMemcpyAsync(a + lo * 32, (const char*)coeffs + lo * 32, (hi - lo) * 32, hipMemcpyHostToDevice, up.cs));
+      HIP_TRY(ctx, hipEventRecord(ctx->open_ev[h], up.cs));
+      HIP_TRY(ctx, hipStreamWaitEvent(ax, ctx->open_ev[h], 0));
+      {
+        StreamSwap on_aux(ctx, ax);                                      // the launchers enqueue on ctx->stream
+        // the carry: Q_hi = q_(hi-1), written by the chunk above; it takes the place of c_hi, which that chunk has consumed
+        if (j) HIP_TRY(ctx, hipMemcpyAsync(a + hi * 32, b + o_q + (hi - 1) * 32, 32, hipMemcpyDeviceToDevice, ax));
+        ST_TRY(open_quotient_run(ctx, a + lo * 32, hi - lo + (j ? 1 : 0), point, b + o_q + lo * 32, lo ? b + o_q + (lo - 1) * 32 : b + o_v, b + o_w, j != 0));
+      }
+      HIP_TRY(ctx, hipEventRecord(ctx->open_ev[2 + h], ax));
+      HIP_TRY(ctx, hipStreamWaitEvent(main_st, ctx->open_ev[2 + h], 0));
+      return KEAKI_OK;
     };
     ST_TRY(msm_g1_run(ctx, srs->d, srs->n, b + o_q, nq, ctx->io_b.p, tb.first, tb.second, &pipe));
   }

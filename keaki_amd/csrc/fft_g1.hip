@@ -424,8 +424,10 @@ static __global__ void __launch_bounds__(64) k_fr_horner_up(const Fr* __restrict
 }
 // q_up[b] = suffix value at the start of block b of this level (nullptr at the top level: nothing above). out[k - shift] = Q_k;
 // with shift = 1 (level 0) Q_0 goes to *value_out instead.
+// keep_top: the top `keep_top` outputs are not written (a chunk of a longer polynomial whose top "coefficient" is the carry from the chunk above:
+// that slot of the quotient already holds the same value and another stream may be reading it)
 static __global__ void __launch_bounds__(64) k_fr_horner_down(const Fr* __restrict__ a, u32 m, const Fr* __restrict__ wp, const Fr* __restrict__ q_up,
-                                                              u32 nblocks, Fr* __restrict__ out, u32 shift, Fr* __restrict__ value_out) {
+                                                              u32 nblocks, Fr* __restrict__ out, u32 shift, Fr* __restrict__ value_out, u32 keep_top) {
   u32 b = blockIdx.x * blockDim.x + threadIdx.x;
   u32 lo = b * HORNER_L;
   if (lo >= m) return;
@@ -434,7 +436,7 @@ static __global__ void __launch_bounds__(64) k_fr_horner_down(const Fr* __restri
   Fr carry = (q_up && b + 1 < nblocks) ? q_up[b + 1] : fp_zero<FrParams>();
   for (u32 k = hi; k-- > lo;) {
     carry = fp_add<FrParams>(fr_mul(carry, w), a[k]);
-    if (k >= shift) out[k - shift] = carry;
+    if (k >= shift) { if (k + keep_top < m) out[k - shift] = carry; }
     else if (value_out) *value_out = carry;
   }
 }
@@ -731,7 +733,7 @@ keaki_status fk_precompute_run(keaki_hip_ctx* ctx, const void* d_srs, void** hat
 // d_c: n coefficients (Fr). d_q: n - 1 quotient coefficients out (n >= 1; n == 1: nothing written). d_value: p(z) out (1 Fr).
 // d_work: open_quotient_work_bytes(n).
 size_t open_quotient_work_bytes(size_t n) { return (2 * (n / (HORNER_L - 1) + 16) + 8) * sizeof(Fr); }
-keaki_status open_quotient_run(keaki_hip_ctx* ctx, const void* d_c, size_t n, const uint64_t* z, void* d_q, void* d_value, void* d_work) {
+keaki_status open_quotient_run(keaki_hip_ctx* ctx, const void* d_c, size_t n, const uint64_t* z, void* d_q, void* d_value, void* d_work, bool top_is_carry) {
   hipStream_t st = ctx->stream;
   Fr zz;
   memcpy(&zz, z, 32);
@@ -754,9 +756,9 @@ keaki_status open_quotient_run(keaki_hip_ctx* ctx, const void* d_c, size_t n, co
     const Fr* q_up = (k + 1 < levels) ? Q[k + 1] : nullptr;
     const u32 nblocks = cdiv(m[k], HORNER_L);
     if (k == 0)
-      hipLaunchKernelGGL(k_fr_horner_down, dim3(cdiv(nblocks, 64)), dim3(64), 0, st, a[0], m[0], (const Fr*)w, q_up, nblocks, (Fr*)d_q, 1u, (Fr*)d_value);
+      hipLaunchKernelGGL(k_fr_horner_down, dim3(cdiv(nblocks, 64)), dim3(64), 0, st, a[0], m[0], (const Fr*)w, q_up, nblocks, (Fr*)d_q, 1u, (Fr*)d_value, top_is_carry ? 1u : 0u);
     else
-      hipLaunchKernelGGL(k_fr_horner_down, dim3(cdiv(nblocks, 64)), dim3(64), 0, st, a[k], m[k], (const Fr*)(w + k), q_up, nblocks, Q[k], 0u, (Fr*)nullptr);
+      hipLaunchKernelGGL(k_fr_horner_down, dim3(cdiv(nblocks, 64)), dim3(64), 0, st, a[k], m[k], (const Fr*)(w + k), q_up, nblocks, Q[k], 0u, (Fr*)nullptr, 0u);
   }
   return launch_check(ctx, "open_quotient");
 }

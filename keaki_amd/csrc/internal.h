@@ -111,6 +111,7 @@ struct keaki_hip_ctx {
   hipEvent_t aux_ev[2] = {nullptr, nullptr};
   hipStream_t copy_stream = nullptr;
   hipEvent_t pipe_in[2] = {nullptr, nullptr}, pipe_done[2] = {nullptr, nullptr};
+  hipEvent_t open_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // chunked kzg_open: [chunk uploaded x 2 | chunk's quotient ready x 2 | start]
 };
 
 namespace keaki_internal {
@@ -208,7 +209,8 @@ keaki_status encap_g1_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_
 keaki_status encap_g2_fixed_run(keaki_hip_ctx* ctx, const void* d_tab_a, uint32_t wb_a, const void* d_tab_b, uint32_t wb_b, const void* d_xs, const void* d_rs, size_t n, void* d_out, bool share_simds = false);
 keaki_status g1_curve_check_run(keaki_hip_ctx* ctx, const void* d_pts, size_t n, void* d_bad2);   // d_bad2: u64 count, u64 first index
 keaki_status g2_curve_check_run(keaki_hip_ctx* ctx, const void* d_pts, size_t n, void* d_bad2);
-keaki_status open_quotient_run(keaki_hip_ctx* ctx, const void* d_c, size_t n, const uint64_t* z, void* d_q, void* d_value, void* d_work);
+// top_is_carry: d_c[n - 1] is not a coefficient but the suffix value carried in from the chunk above (its quotient slot is left alone)
+keaki_status open_quotient_run(keaki_hip_ctx* ctx, const void* d_c, size_t n, const uint64_t* z, void* d_q, void* d_value, void* d_work, bool top_is_carry = false);
 size_t open_quotient_work_bytes(size_t n);           // size of d_work for n coefficients
 keaki_status fr_fft_run(keaki_hip_ctx* ctx, void* d_data, uint32_t log2n, const uint64_t* omega, const uint64_t* scale_or_null, void* d_tw);
 keaki_status open_fk_poly_run(keaki_hip_ctx* ctx, const void* d_srs, void** hat_s_cache, int* hat_s_log2d, uint32_t log2d, const void* d_p,
