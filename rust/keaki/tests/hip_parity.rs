@@ -24,11 +24,11 @@ use keaki::{
 /// serialize_uncompressed(e(G1, G2)) according to the oracle (sha-256 e109983de6d3ff0d8d4e1236dd4d91d2a313d7e7a22e3a15062b6759ad70331c)
 const GT_OF_GENERATORS_HEX: &str = concat!(
     "950e879d73631f5eb5788589eb5f7ef8d63e0a28de1ba00dfe4ca9ed3f252b264a8afb8eb4349db466ed1809ea4d7c39",
-    "bdab7938821f1b0a00a295c72c2de002e01dbdfd0254134efcb1ec877395d25f937719b344adb1a58d129be2d6f2a913"
+    "bdab7938821f1b0a00a295c72c2de002e01dbdfd0254134efcb1ec877395d25f937719b344adb1a58d129be2d6f2a913",
     "2b16a16e8ab030b130e69c69bd20b4c45986e6744a98314b5c1a0f50faa90b04dbaf9ef8aeeee3f50be31c210b598f47",
-    "52f073987f9d35be8f6770d83f2ffc0af0d18dd9d2dbcdf943825acc12a7a9ddca45e629d962c6bd64908c3930a5541c"
+    "52f073987f9d35be8f6770d83f2ffc0af0d18dd9d2dbcdf943825acc12a7a9ddca45e629d962c6bd64908c3930a5541c",
     "fe2924dcc5580d5cef7a4bfdec90a91b59926f850d4a7923c01a5a5dbf0f5c094a2b9fb9d415820fa6b40c59bb9eade9",
-    "c953407b0fc11da350a9d872cad6d3142974ca385854afdf5f583c04231adc5957c8914b6b20dc89660ed7c3bbe7c01d"
+    "c953407b0fc11da350a9d872cad6d3142974ca385854afdf5f583c04231adc5957c8914b6b20dc89660ed7c3bbe7c01d",
     "972be2d53ecdb27a1bcc16ac610db95aa7d237c8ff55a898cb88645a0e32530b23d7ebf5dafdd79b0f9c2ac4ba07ce18",
     "d3d16cf36e47916c4cae5d08d3afa813972c769e8514533e380c9443b3e1ee5c96fa3a0a73f301b626454721527bf900"
 );
@@ -41,11 +41,11 @@ const KEM_VALUE: &str = "1979652574466742634987351846639987637568750263332337721
 const KEM_R: &str = "9222778255153844183597133810292204042513128492245322607305955548628659646598";
 const KEM_GT_HEX: &str = concat!(
     "b5951694bedc946d0cb033071ebccb74905604a0b0c5a66cda9c8ec0b2e10c0a549140177daa327d0e89b4f21beafb13",
-    "b29e86fd6d4e1f2a87eff1c5cd622409115543ce297d946d44217ccb7af716346077588ce8f2c449f7e37a0bb676e31f"
+    "b29e86fd6d4e1f2a87eff1c5cd622409115543ce297d946d44217ccb7af716346077588ce8f2c449f7e37a0bb676e31f",
     "c496512b3851851460add03bf4f0abcfbc7d63b0cafcb3b0fd90b1bf7b6ef62d430e57ebde40785394be150e2dd1ad2f",
-    "94f51e4a6131bacd70d51a03f43d162db1e54bca000e2298bb3470421d549bcb6e356d30cff97fb72c80eb17972f4406"
+    "94f51e4a6131bacd70d51a03f43d162db1e54bca000e2298bb3470421d549bcb6e356d30cff97fb72c80eb17972f4406",
     "4a47cee237e27b4bfa0f2104b2cdf7c36c40387931f6ef4210dcfb5f69f46c18f60fda3398158fd95ac72daf927a92ae",
-    "c4344361f53c9614b9d2e3cd1605bd2e24fd3035cbddcb02f6339450936132ccf6de676e86110e5f7332d2fd8c32812f"
+    "c4344361f53c9614b9d2e3cd1605bd2e24fd3035cbddcb02f6339450936132ccf6de676e86110e5f7332d2fd8c32812f",
     "7cc69690d85e3b2294297f5e83e878d20c8088a6d5a3a057f6e2ad4948a24d27b3b8f2912973c67d62718db3ee083c6e",
     "d2b7cf4b311016dff36b1e9057fd2217042a0c386d65cf3816ee890850be5aff54630b783984b079925b4d6ffdca7100"
 );

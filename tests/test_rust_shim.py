@@ -100,6 +100,52 @@ def test_glue_calls_only_declared_symbols():
     assert re.search(r"keaki_hip_srs_g1_precompute\(\s*dev\.ctx,\s*srs,\s*core::ptr::null_mut\(\)\s*\)", glue)
 
 
+def _call_args(text, start):
+    """the top-level arguments of the call whose `(` is at text[start]: split on commas outside (), [], {} and closures' |...| are left alone"""
+    depth, args, cur, i = 0, [], "", start
+    while True:
+        ch = text[i]
+        if ch in "([{":
+            depth += 1
+            if depth > 1: cur += ch
+        elif ch in ")]}":
+            depth -= 1
+            if depth == 0:
+                break
+            cur += ch
+        elif ch == "," and depth == 1:
+            args.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+        i += 1
+    if cur.strip():
+        args.append(cur.strip())
+    return args
+
+
+def test_glue_calls_pass_as_many_arguments_as_declared():
+    """rustc has never seen these files (no toolchain in the image): at least the arity of every FFI call is checked here"""
+    declared = rust_functions()
+    seen = 0
+    for rel in ("keaki/src/hip.rs", "keaki/tests/hip_parity.rs"):
+        text = re.sub(r"//.*", "", open(os.path.join(RUST, rel)).read())
+        for m in re.finditer(r"\bsys::(keaki_hip_\w+)\s*\(", text):
+            name = m.group(1)
+            args = _call_args(text, m.end() - 1)
+            assert len(args) == len(declared[name][1]), "%s: %s called with %d arguments %r, declared with %d" % (rel, name, len(args), args, len(declared[name][1]))
+            seen += 1
+    assert seen >= 40
+
+
+def test_concat_literals_are_comma_separated():
+    """Rust does not join adjacent string literals: inside concat!( ... ) every literal but the last must be followed by a comma (round 5: six were not)"""
+    for rel in ("keaki/src/hip.rs", "keaki/tests/hip_parity.rs", "keaki-hip-sys/src/lib.rs", "keaki-hip-sys/src/rccl.rs", "keaki-hip-sys/build.rs"):
+        text = open(os.path.join(RUST, rel)).read()
+        for m in re.finditer(r"concat!\((.*?)\)", text, flags=re.S):
+            lits = [l.strip() for l in m.group(1).split("\n") if l.strip().startswith('"')]
+            assert lits and all(l.endswith(",") for l in lits[:-1]), (rel, [l[:20] for l in lits if not l.endswith(",")])
+
+
 def test_patch_touches_the_cited_call_sites_and_applies():
     patch = open(os.path.join(RUST, "keaki", "keaki-hip.patch")).read()
     for f in ("Cargo.toml", "src/lib.rs", "src/kzg.rs", "src/kem.rs", "src/vec.rs"):
