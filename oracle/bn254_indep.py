@@ -25,7 +25,7 @@ from __future__ import annotations
 Z = 4965661367192848881
 P = 36 * Z**4 + 36 * Z**3 + 24 * Z**2 + 6 * Z + 1
 R = 36 * Z**4 + 36 * Z**3 + 18 * Z**2 + 6 * Z + 1
-HARD_MULT = 2 * Z * (6 * Z * Z + 3 * Z + 1)          # recalled: ark-ec 0.4.2 models/bn final_exponentiation (hard part)
+HARD_MULT = 2 * Z * (6 * Z * Z + 3 * Z + 1)          # ark-ec 0.4.2 models/bn final_exponentiation (hard part) = the published Fuentes-Castaneda decomposition (tests/test_oracle.py checks the identity)
 N = 12
 # w^12 = 18 w^6 - 82
 

@@ -75,6 +75,22 @@ def test_final_exponent_and_bilinearity(py):
     assert hashlib.sha256(py.gt_serialize(e)).hexdigest() == "e109983de6d3ff0d8d4e1236dd4d91d2a313d7e7a22e3a15062b6759ad70331c"
 
 
+def test_final_exponent_multiple_is_the_published_hard_part(py):
+    """The multiple 2z(6z^2 + 3z + 1) of (p^12 - 1)/r is not a free-standing recollection: it is what the PUBLISHED hard-part decomposition of
+    Fuentes-Castaneda, Knapp, Rodriguez-Henriquez ("Faster hashing to G2", SAC 2011, section 5, BN curves) computes, the one ark-ec 0.4.2's
+    models/bn final_exponentiation cites in its comment:  f^(l0 + l1 p + l2 p^2 + l3 p^3)  with
+        l0 = 1 + 6z + 12z^2 + 12z^3,  l1 = 4z + 6z^2 + 12z^3,  l2 = 6z + 6z^2 + 12z^3,  l3 = -1 + 4z + 6z^2 + 12z^3.
+    Pure integer identity over the BN parametrisation: l0 + l1 p + l2 p^2 + l3 p^3 == 2z(6z^2 + 3z + 1) (p^4 - p^2 + 1)/r."""
+    z, p, r = py.Z, py.P, py.R
+    assert p == 36 * z**4 + 36 * z**3 + 24 * z**2 + 6 * z + 1 and r == 36 * z**4 + 36 * z**3 + 18 * z**2 + 6 * z + 1
+    l0, l1, l2, l3 = 1 + 6 * z + 12 * z**2 + 12 * z**3, 4 * z + 6 * z**2 + 12 * z**3, 6 * z + 6 * z**2 + 12 * z**3, -1 + 4 * z + 6 * z**2 + 12 * z**3
+    assert (p**4 - p**2 + 1) % r == 0
+    assert l0 + l1 * p + l2 * p**2 + l3 * p**3 == py.HARD_MULT * ((p**4 - p**2 + 1) // r)
+    assert py.HARD_MULT == 2 * z * (6 * z * z + 3 * z + 1) and py.HARD_MULT % r != 0        # the pairing stays non-degenerate
+    import bn254_indep as ind
+    assert ind.HARD_MULT == py.HARD_MULT
+
+
 def test_pairing_against_an_independent_derivation(py):
     """oracle/bn254_indep.py computes the same pairing with nothing in common with bn254_py's (and bn254_ref.c's) pairing code: one flat
     extension Fq[w]/(w^12 - 18 w^6 + 82) instead of the tower, Q untwisted to y^2 = x^3 + 3 over Fq12 (asserted on the curve: the twist
