@@ -2,8 +2,10 @@
 """bench.py -- headline benchmark: BN254 G1 scalar-mults/s on a 2^24-point Pippenger MSM per MI355X.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          # N > 1 typed like this: starts its N ranks itself, as a child
+                                                           # torch.distributed.run job (keaki_amd/launch.py), and relays rank 0's line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # the same through the launcher directly (already inside it: no child)
 
 A "step" = one full MSM (kzg::commit's msm_unchecked, reference src/kzg.rs:98) over a batch of synthetic scalars with the SRS
 and the scalars already resident in HBM. With N > 1 every rank holds its own contiguous chunk of 2^LOG2N (scalar, point) pairs
@@ -21,8 +23,9 @@ run, not the 2.4 GHz peak: `frac_of_power_limited_rate` compares VALU instructio
 times the CPU restatement of the arkworks algorithm (oracle/, the checker -- never the product) on a bounded sample. Besides
 `value` the line carries `value_no_tables`, `value_incl_scalar_h2d`, a `strong` block (BASELINE config 4: 2^26 points in total)
 when N > 1 or --strong is given, the `kem` block (second half of the BASELINE metric; `pairings_per_s` = BASELINE config 3), an `fk`
-block (FK23 openings at d = 2^21, the kernel family that dominates config 5) and a `laconic` block (the three phases of the
-reference's Laconic OT test at 2^20 bits on one GPU). Exit code 1 if any parity check fails.
+block (FK23 openings at d = 2^21, the kernel family that dominates config 5; rank 0's GPU) and a `laconic` block (BASELINE config 5: the
+three phases of the reference's Laconic OT test at 2^20 bits, sharded over ALL ranks of the job: laconic_ot.run_flow). Exit code 1 if any
+parity check fails.
 """
 import argparse
 import json
@@ -35,6 +38,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+from keaki_amd.launch import self_launch, under_launcher  # noqa: E402  (standard library only: no torch, no HIP call)
 
 R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 P_MOD = 21888242871839275222246405745257275088696311157297823662689037894645226208583
@@ -152,6 +157,11 @@ def main():
     ap.add_argument("--g2-log2n", type=int, default=20, help="log2 of the points of the `msm_g2` block; 0 disables")
     ap.add_argument("--laconic-log2n", type=int, default=20, help="log2 of the receiver bits of the `laconic` block (BASELINE config 5: 2^20); 0 disables")
     args = ap.parse_args()
+    if args.gpus > 1 and not under_launcher():
+        # `python3 bench.py --gpus N` typed as it stands (the driver's N = 1 line has that shape): this process -- which has not imported
+        # torch and never touches the GPU -- starts the N ranks as a CHILD torch.distributed.run job with the same arguments; rank 0 of the
+        # child prints the one JSON line on the inherited stdout; the child's exit code is ours (keaki_amd/launch.py)
+        raise SystemExit(self_launch(__file__, sys.argv[1:], args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -162,9 +172,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N with N > 1 must be launched through torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+        args.gpus = world                                  # inside a launcher the launcher's world size is the truth
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
     ndev = torch.cuda.device_count()
@@ -567,7 +575,7 @@ def main():
         # integer-issue diagnostic: butterflies = d * log2(d) (two size-d transforms of d/2 * log2 d each) + 2d pointwise + d twist scalar-mults,
         # one scalar-mult ~ 129 doublings + 43..66 additions in the 29-bit ladder
         fk = {"workload": "FK23 openings (kzg::open_fk) of a degree-(2^%d - 1) polynomial at the 2^%d roots of unity, hat_s cached per SRS" % (lg, lg),
-              "proofs_per_s": d / call_s[best], "call_ms": call_s[best] * 1e3, "call_ms_all": [round(x * 1e3, 2) for x in call_s],
+              "n_gpus": 1, "proofs_per_s": d / call_s[best], "call_ms": call_s[best] * 1e3, "call_ms_all": [round(x * 1e3, 2) for x in call_s],
               "call_note": "keaki_hip_open_fk_poly: coefficients from host memory in (%d MiB), affine proofs to host memory out (%d MiB)" % (d * 32 >> 20, d * 64 >> 20),
               "device_ms": st_ms[best]["device_ms"], "pointwise_ms": st_ms[best]["pointwise_ms"], "setup_hat_s_s": round(fk_setup_s, 3),
               "scalar_mults": d * lg + 3 * d,
@@ -618,46 +626,21 @@ def main():
         fk["roofline"]["traffic_note"] = fk_traffic_note or ("FETCH_SIZE + WRITE_SIZE of ONE call, all FK23 kernels: the per-lane window tables of the ladders (1 KB written, "
                                                              "43..66 x 128 B read per scalar-mult) and the 96-byte points, not the algorithmic 96 B per opening")
         fk_check = (fsrs, coeffs, proofs, om)
-    # ---- Laconic OT, one GPU: the three phases the reference's test prints (tests/laconic_ot.rs:143-188) at 2^--laconic-log2n bits --------
+    # ---- Laconic OT (BASELINE config 5): the three phases the reference's test prints (tests/laconic_ot.rs:143-188) at 2^--laconic-log2n
+    # bits, on ALL ranks of this job: with N > 1 the FK23 openings of Receiver::new are sharded (ShardedFk: two all-to-alls + one all-gather
+    # per call), the commit MSM is split by point range, encapsulations / decapsulations by item range -- laconic_ot.py's flow on this
+    # process group (one rank: the un-sharded calls through the host mirror)
     laconic = None
-    if not args.no_extras and args.laconic_log2n > 0 and rank == 0:
+    if not args.no_extras and args.laconic_log2n > 0:
         from keaki_amd import keaki as K
-        ln = 1 << args.laconic_log2n
-        lrng = K.Rng(2024)
-        t0 = time.perf_counter()
-        ls = K.KZGSetup.setup(lrng.fr_rand(), 2 * ln, dev_index)
-        K.precompute_open_fk(ls, 2 * ln)
-        K.kem_prepare(ls, ln)                              # the tables of encapsulation that depend on the setup only (generators, [tau]_2, e(g1, g2))
-        l_setup = time.perf_counter() - t0
-        np_rng = np.random.default_rng(7)
-        bits = np_rng.integers(0, 2, ln)
-        zero, one = K.fr(0), K.fr(1)
-        choices = np.where(bits[:, None] == 0, zero[None, :], one[None, :]).astype(np.uint64)
-        t0 = time.perf_counter()
-        l_com, l_proofs = K.vec_commit(lrng, ls, choices)
-        t_new = time.perf_counter() - t0
-        sets = [np_rng.integers(0, 256, size=(ln, 32), dtype=np.uint8) for _ in range(2)]
-        elements = K.domain_elements(ln + K.PADDING_LEN)
-        zeros, ones = np.repeat(zero[None, :], ln, 0), np.repeat(one[None, :], ln, 0)
-        t0 = time.perf_counter()
-        g2_0, body_0 = K.vec_encrypt_arrays(lrng, ls, l_com, elements, zeros, sets[0])
-        g2_1, body_1 = K.vec_encrypt_arrays(lrng, ls, l_com, elements, ones, sets[1])
-        t_send = time.perf_counter() - t0
-        pick0 = bits[:, None] == 0
-        sel_g2, sel_body = np.where(pick0, g2_0, g2_1), np.where(pick0, body_0, body_1)      # the receiver picks the ciphertext of its bit (references in the reference's loop)
-        t0 = time.perf_counter()
-        got = K.vec_decrypt_arrays(ls, l_proofs[:ln], sel_g2, sel_body)
-        t_recv = time.perf_counter() - t0
-        l_ok = bool(np.array_equal(got, np.where(pick0, sets[0], sets[1])))
-        checks["laconic.all_messages_recovered"] = l_ok
-        laconic = {"workload": "Laconic OT (tests/laconic_ot.rs:126-200), %d receiver bits, 2 x 32-byte messages per bit, ONE GPU (rank 0), through the host mirror" % ln,
-                   "n_choices": ln, "setup_s": round(l_setup, 3), "receiver_new_s": round(t_new, 3), "sender_send_s": round(t_send, 3),
-                   "receiver_receive_s": round(t_recv, 3), "bits_per_s_end_to_end": ln / (t_new + t_send + t_recv), "all_messages_recovered": l_ok,
-                   "note": "wall clock of vec_commit (iFFT + FK23 openings at d = 2^%d + commit MSM) / 2 x vec_encrypt (2^%d encapsulations) / "
-                           "vec_decrypt (2^%d pairings), host arrays in and out; the N-GPU form is laconic_ot.py --gpus N"
-                           % (args.laconic_log2n + 1, args.laconic_log2n + 1, args.laconic_log2n)}
-        ls.close()
-        del l_proofs, g2_0, g2_1, body_0, body_1, got, sel_g2, sel_body
+        import laconic_ot
+        lshard = Shard(rank, world, dist if world > 1 else None)
+        laconic = laconic_ot.run_flow(K, lshard, dev_index, args.laconic_log2n, 32, "sharded", False, args.backend)
+        checks["laconic.all_messages_recovered"] = bool(laconic["all_messages_recovered"])
+        laconic["workload"] = ("Laconic OT (tests/laconic_ot.rs:126-200), %d receiver bits, 2 x 32-byte messages per bit, %s, through the host mirror"
+                               % (1 << args.laconic_log2n, "ONE GPU" if world == 1 else "sharded over all %d ranks" % world))
+        laconic["note"] = ("wall clock (max over ranks per phase) of vec_commit (iFFT + FK23 openings at d = 2^%d + commit MSM) / 2 x vec_encrypt (2^%d "
+                           "encapsulations) / vec_decrypt (2^%d pairings), host arrays in and out" % (args.laconic_log2n + 1, args.laconic_log2n + 1, args.laconic_log2n))
 
     # ---- BASELINE config 1 (degree-128 commit + open, and verify / the single KEM calls on the same setup): what ONE call costs --------------
     single = None
@@ -809,8 +792,13 @@ def main():
         t0 = time.perf_counter()
         oc.msm_g1(inst.d_pts[:nall].cpu().numpy().view(np.uint64), s0[:nall], threads=ncores)
         cpu_all_s = time.perf_counter() - t0
+        import shutil
+        import socket
+        have_rust = shutil.which("cargo") and shutil.which("rustc")
         result["cpu_baseline"] = {
             "value": ns / cpu_s, "unit": "scalar-mults/s", "cores": 1, "kind": "port",
+            "reference_toolchain": ("cargo + rustc present on %s: rust/README.md's recipe can time arkworks itself" if have_rust
+                                    else "absent on %s (no cargo / rustc: keaki + arkworks cannot be built here; profiles/r06_rust_toolchain_probe.txt)") % socket.gethostname(),
             "sample": "first 2^%d (scalar, point) pairs of the workload, CPU restatement of ark-ec msm_bigint_wnaf (not arkworks itself); "
                       "GPU result on the same sample bit-exact: %s" % (int(np.log2(ns)), checks["sample_bit_exact"]),
             "all_cores": {"value": nall / cpu_all_s, "cores": min(ncores, (254 + oc.window_size(nall) - 1) // oc.window_size(nall)), "host_cores": ncores,

@@ -2,8 +2,10 @@
 """Laconic OT end-to-end -- the reference's integration flow (tests/laconic_ot.rs:15-200) at any size, on 1..N GPUs.
 
     python laconic_ot.py --log2n 16                      # N_CHOICES = 2^16 receiver bits, 2 x 32-byte messages per bit, one GPU
+    python laconic_ot.py --gpus N --log2n 20             # BASELINE config 5: one rank per GPU (RCCL); starts its own ranks as a child
+                                                         # torch.distributed.run when it is not already inside one (keaki_amd/launch.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        laconic_ot.py --gpus N --log2n 20                # BASELINE config 5: one rank per GPU (RCCL)
+        laconic_ot.py --gpus N --log2n 20                # the same through the launcher directly
 
 Receiver::new  -> vec_commit : pad with one random scalar, iFFT to coefficients (GPU Fr FFT), FK23 openings (GPU Fr + G1 FFTs), commit (GPU MSM)
 Sender::send   -> 2 x vec_encrypt : one batched GPU encapsulation per message set (fixed-base GT path), XOR on host
@@ -32,49 +34,21 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from keaki_amd.launch import self_launch, under_launcher  # noqa: E402  (standard library only: no torch, no HIP)
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--log2n", type=int, default=10)
-    ap.add_argument("--value-bytes", type=int, default=32)   # VALUE_BYTES (tests/laconic_ot.rs:124)
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo lets several ranks share one GPU (1-GPU box)")
-    ap.add_argument("--fk", default="sharded", choices=["sharded", "replicated"], help="FK23 openings of Receiver::new on N > 1 ranks")
-    ap.add_argument("--check-single", action="store_true",
-                    help="rank 0 also runs the un-sharded calls with the same seeds and compares commitment and ciphertexts bit for bit")
-    args = ap.parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("laconic_ot.py --gpus N with N > 1 must be launched through torch.distributed.run (one rank per GPU)")
-    from keaki_amd import keaki as K
-    from keaki_amd.dist import Shard, ShardedFk, sharded_vec_commit, sharded_vec_encrypt, sharded_vec_decrypt
-    dist = None
-    device = 0
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        ndev = torch.cuda.device_count()          # does not initialise the GPU
-        if ndev == 0:
-            raise SystemExit("laconic_ot.py needs an MI355X (there is no CPU fallback)")
-        if args.backend == "nccl" and world > ndev:
-            raise SystemExit("%d ranks but %d GPUs: RCCL needs one GPU per rank (use --backend gloo to share a GPU)" % (world, ndev))
-        device = local_rank % ndev
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(device)
-        torch.cuda.init()                         # torch first, the library second (the exchange buffers of the sharded FK23 are torch tensors)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-    shard = Shard(rank, world, dist)
+
+def run_flow(K, shard, device, log2n, value_bytes=32, fk_mode="sharded", check_single=False, backend=None):
+    """The whole flow on the ranks of `shard` (one rank: the un-sharded calls). Every rank calls this; returns the report (a dict; the same on
+    every rank except for `sharded_equals_single_process`, which only rank 0 computes) whose `all_messages_recovered` is the AND over all
+    ranks. bench.py's `laconic` block is this function on the bench's own process group."""
+    from keaki_amd.dist import ShardedFk, sharded_vec_commit, sharded_vec_encrypt
+    rank, world = shard.rank, shard.world
 
     def phase_max(t):
         return float(shard.all_gather_np(np.array([np.float64(t)]).view(np.uint64)).view(np.float64).max())
 
-    n = 1 << args.log2n
-    vb = args.value_bytes
+    n = 1 << log2n
+    vb = value_bytes
     rng = K.Rng(2024)                              # the same stream on every rank: setup secret, padding, r values
     t0 = time.time()
     setup_degree = 1
@@ -82,7 +56,7 @@ def main():
         setup_degree <<= 1
     s = K.KZGSetup.setup(rng.fr_rand(), setup_degree, device)      # SETUP_DEGREE: the domain of n+1 evaluations
     fk = None
-    if args.fk == "sharded" and ShardedFk.can_shard(K, s, setup_degree, shard):
+    if fk_mode == "sharded" and ShardedFk.can_shard(K, s, setup_degree, shard):
         fk = ShardedFk(K, s, setup_degree, shard, device)
         fk.prepare()                                       # this rank's part of the SRS-only transform (one all-to-all)
     else:
@@ -120,7 +94,7 @@ def main():
         other = K.vec_decrypt_arrays(s, proofs[lo:lo + m], np.where(pick, g2_1, g2_0)[:m], np.where(pick, body_1, body_0)[:m])
         ok = ok and not np.array_equal(other, np.where(pick, sets[1][lo:hi], sets[0][lo:hi])[:m])
     single = None
-    if args.check_single and rank == 0:
+    if check_single and rank == 0:
         # the un-sharded calls with the same seeds: commitment, proofs and this rank's ciphertexts must be the same bytes
         rng1 = K.Rng(2024)
         rng1.fr_rand()                                                                         # the setup secret
@@ -131,25 +105,70 @@ def main():
                       and np.array_equal(b0[lo:hi], body_0) and np.array_equal(a1[lo:hi], g2_1) and np.array_equal(b1[lo:hi], body_1))
         ok = ok and single
     all_ok = bool(shard.all_gather_np(np.array([1 if ok else 0], np.uint64)).min() == 1)
-    if rank == 0:
-        print(json.dumps({"flow": "laconic_ot", "n_choices": n, "value_bytes": vb, "n_gpus": world, "ranks_seen": shard.world,
-                          "backend": args.backend if world > 1 else None, "setup_s": round(t_setup, 3),
-                          "receiver_new_s": round(t_receiver_new, 3), "sender_send_s": round(t_sender_send, 3),
-                          "receiver_receive_s": round(t_receive, 3), "all_messages_recovered": all_ok,
-                          "sharded_equals_single_process": single,
-                          "fk_sharded": fk is not None, "fk_exchange_bytes_sent_per_rank": fk.bytes_moved if fk is not None else 0,
-                          "sharding": None if world == 1 else "commit MSM by point range (1 all-gather of 96-B partials); FK23 openings %s; "
-                                                              "encaps / decaps by item, no collective"
-                                                              % ("sharded (2 all-to-alls of 96-B points + 1 all-gather of the proofs per call)"
-                                                                 if fk is not None else "replicated on every rank"),
-                          "note": "wall-clock through the C++ host mirror (contiguous arrays in, arrays out), max over ranks per phase; "
-                                  "GPU work: FK23 + MSM / 2n encaps / n decaps"}), flush=True)
+    report = {"flow": "laconic_ot", "n_choices": n, "value_bytes": vb, "n_gpus": world, "ranks_seen": shard.world,
+              "backend": backend if world > 1 else None, "setup_s": round(t_setup, 3),
+              "receiver_new_s": round(t_receiver_new, 3), "sender_send_s": round(t_sender_send, 3),
+              "receiver_receive_s": round(t_receive, 3),
+              "bits_per_s_end_to_end": n / (t_receiver_new + t_sender_send + t_receive), "all_messages_recovered": all_ok,
+              "sharded_equals_single_process": single,
+              "fk_sharded": fk is not None, "fk_exchange_bytes_sent_per_rank": fk.bytes_moved if fk is not None else 0,
+              "sharding": None if world == 1 else "commit MSM by point range (1 all-gather of 96-B partials); FK23 openings %s; "
+                                                  "encaps / decaps by item, no collective"
+                                                  % ("sharded (2 all-to-alls of 96-B points + 1 all-gather of the proofs per call)"
+                                                     if fk is not None else "replicated on every rank"),
+              "note": "wall-clock through the C++ host mirror (contiguous arrays in, arrays out), max over ranks per phase; "
+                      "GPU work: FK23 + MSM / 2n encaps / n decaps"}
     if fk is not None:
         fk.close()
+    s.close()
+    return report
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log2n", type=int, default=10)
+    ap.add_argument("--value-bytes", type=int, default=32)   # VALUE_BYTES (tests/laconic_ot.rs:124)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo lets several ranks share one GPU (1-GPU box)")
+    ap.add_argument("--fk", default="sharded", choices=["sharded", "replicated"], help="FK23 openings of Receiver::new on N > 1 ranks")
+    ap.add_argument("--check-single", action="store_true",
+                    help="rank 0 also runs the un-sharded calls with the same seeds and compares commitment and ciphertexts bit for bit")
+    args = ap.parse_args()
+    if args.gpus > 1 and not under_launcher():
+        # typed without torch.distributed.run: this process -- which has not imported torch or touched the GPU -- starts the N ranks as a
+        # child job and hands back its exit code (keaki_amd/launch.py)
+        raise SystemExit(self_launch(__file__, sys.argv[1:], args.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from keaki_amd import keaki as K
+    from keaki_amd.dist import Shard
+    dist = None
+    device = 0
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        ndev = torch.cuda.device_count()          # does not initialise the GPU
+        if ndev == 0:
+            raise SystemExit("laconic_ot.py needs an MI355X (there is no CPU fallback)")
+        if args.backend == "nccl" and world > ndev:
+            raise SystemExit("%d ranks but %d GPUs: RCCL needs one GPU per rank (use --backend gloo to share a GPU)" % (world, ndev))
+        device = local_rank % ndev
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(device)
+        torch.cuda.init()                         # torch first, the library second (the exchange buffers of the sharded FK23 are torch tensors)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    shard = Shard(rank, world, dist)
+    report = run_flow(K, shard, device, args.log2n, args.value_bytes, args.fk, args.check_single, args.backend)
+    if rank == 0:
+        print(json.dumps(report), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if not all_ok:
+    if not report["all_messages_recovered"]:
         raise SystemExit(1)
 
 

@@ -50,10 +50,18 @@ def multirank_runs(request, tmp_path_factory):
         logs.append(o); rcs.append(p.returncode)
     out["msm"] = {"rc": rcs, "log": "\n---- rank ----\n".join(logs), "dir": d, "n_total": n_total}
     launch = [py_exe, "-m", "torch.distributed.run", "--nnodes=1", "--master-addr", "127.0.0.1"]
-    # (2) bench.py at world 2 (gloo, both ranks on GPU 0): weak line + strong block (2^19 total) + KEM block, small sizes
+    # (2) bench.py at world 2 (gloo, both ranks on GPU 0): weak line + strong block (2^19 total) + KEM block + the sharded Laconic OT block,
+    # small sizes, through torch.distributed.run ...
     rc, log = _run(launch + ["--nproc-per-node", "2", "--master-port", str(port + 1), "bench.py", "--gpus", "2", "--backend", "gloo", "--log2n", "18",
-                             "--kem-log2n", "10", "--steps", "3", "--warmup", "1", "--cpu-log2n", "14", "--strong-log2n", "19"], 1500)
+                             "--kem-log2n", "10", "--steps", "3", "--warmup", "1", "--cpu-log2n", "14", "--strong-log2n", "19", "--laconic-log2n", "12"], 1500)
     out["bench"] = {"rc": rc, "log": log}
+    # (2b) ... and typed WITHOUT a launcher, the shape of the driver's recorded line (`python3 bench.py --gpus N --steps K --warmup W`,
+    # BENCH_r05.json:cmd): bench.py starts its two ranks itself as a child job (keaki_amd/launch.py) and relays rank 0's line
+    rc, log = _run([py_exe, "bench.py", "--gpus", "2", "--backend", "gloo", "--log2n", "18", "--kem-log2n", "10", "--steps", "3", "--warmup", "1",
+                    "--cpu-log2n", "14", "--strong-log2n", "19", "--laconic-log2n", "12"], 1500)
+    out["bench_self"] = {"rc": rc, "log": log}
+    rc, log = _run([py_exe, "laconic_ot.py", "--gpus", "2", "--backend", "gloo", "--log2n", "10", "--check-single"], 1500)
+    out["laconic_self"] = {"rc": rc, "log": log}
     # (3) laconic_ot.py at world 2
     rc, log = _run(launch + ["--nproc-per-node", "2", "--master-port", str(port + 2), "laconic_ot.py", "--gpus", "2", "--backend", "gloo", "--log2n", "15",
                              "--check-single"], 1500)
@@ -65,7 +73,8 @@ def multirank_runs(request, tmp_path_factory):
     rc, log = _run(launch + ["--nproc-per-node", "3", "--master-port", str(port + 6), "laconic_ot.py", "--gpus", "3", "--backend", "gloo", "--log2n", "8",
                              "--check-single"], 1500)
     out["laconic3"] = {"rc": rc, "log": log}
-    # (4) the driver's launch line at N = 1
+    # (4) ONE rank under torch.distributed.run (the form the contract gives for N > 1, at N = 1; the driver's own N = 1 line is the plain
+    # `python3 bench.py --gpus 1 --steps K --warmup W`, which the bench-line tests and smoke() run in-process)
     rc, log = _run(launch + ["--nproc-per-node", "1", "--master-port", str(port + 3), "bench.py", "--gpus", "1", "--log2n", "18", "--kem-log2n", "10",
                              "--steps", "2", "--warmup", "1", "--cpu-log2n", "14"], 1500)
     out["bench1"] = {"rc": rc, "log": log}

@@ -111,3 +111,21 @@ def test_laconic_ot_two_ranks_over_rccl():
     j = _json_line(log)
     assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["all_messages_recovered"] is True and j["sharded_equals_single_process"] is True
     assert j["fk_sharded"] is True
+
+
+@needs_two
+def test_bench_self_launched_two_ranks_over_rccl():
+    """the driver's line shape at N = 2, typed without a launcher: `python3 bench.py --gpus 2 ...` starts its own ranks (keaki_amd/launch.py),
+    RCCL between two devices; the one line carries the weak value, the strong block, the KEM aggregate and the sharded Laconic OT flow"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2n", "20", "--steps", "3", "--warmup", "1", "--kem-log2n", "12",
+                        "--cpu-log2n", "14", "--fk-log2d", "0", "--laconic-log2n", "14", "--strong-log2n", "21"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["ranks_seen"] == 2 and j["config"]["backend"] == "nccl" and j["config"]["exchange_ms"] > 0
+    assert j["strong"]["ranks_seen"] == 2 and j["strong"]["full_size_check"] is True
+    assert j["laconic"]["n_gpus"] == 2 and j["laconic"]["backend"] == "nccl" and j["laconic"]["fk_sharded"] is True
+    assert j["laconic"]["all_messages_recovered"] is True and all(j["checks"].values())

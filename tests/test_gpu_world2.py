@@ -57,6 +57,35 @@ def test_world2_bench_line(multirank_runs):
     assert j["roofline"]["frac"] > 0 and j["cpu_baseline"]["value"] > 0
 
 
+def test_world2_bench_self_launched_carries_the_whole_metric(multirank_runs):
+    """`python3 bench.py --gpus 2 ...` typed WITHOUT torch.distributed.run: the parent starts the ranks as a child job
+    before it imports torch; the ONE JSON line holds the weak value, the strong block (config 4's shape), the KEM aggregate and the Laconic OT
+    flow (config 5's shape) run SHARDED over both ranks, every check true. Both launch forms must give the same line shape."""
+    for name in ("bench_self", "bench"):
+        run = multirank_runs[name]
+        assert run["rc"] == 0, run["log"][-3000:]
+        lines = [ln for ln in run["log"].splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, "exactly ONE JSON line (rank 0): %d" % len(lines)
+        j = json.loads(lines[0])
+        assert j["n_gpus"] == 2 and j["config"]["ranks_seen"] == 2 and j["config"]["backend"] == "gloo" and j["scaling"] == "weak"
+        assert j["value"] and j["value"] > 0 and j["config"]["exchange_ms"] is not None and j["config"]["exchange_ms"] > 0
+        st = j["strong"]
+        assert st["ranks_seen"] == 2 and st["total_points"] == 1 << 19 and st["points_per_gpu"] == 1 << 18 and st["full_size_check"] is True
+        k = j["kem"]
+        assert k["encaps_per_s"] > 0 and k["decaps_per_s"] > 0 and k["batch_per_gpu"] == 1 << 10
+        lo = j["laconic"]
+        assert lo["n_gpus"] == 2 and lo["ranks_seen"] == 2 and lo["backend"] == "gloo" and lo["n_choices"] == 1 << 12
+        assert lo["fk_sharded"] is True and lo["fk_exchange_bytes_sent_per_rank"] > 0 and lo["all_messages_recovered"] is True
+        assert lo["receiver_new_s"] > 0 and lo["sender_send_s"] > 0 and lo["receiver_receive_s"] > 0 and lo["bits_per_s_end_to_end"] > 0
+        assert all(j["checks"].values()), j["checks"]
+        assert "absent on" in j["cpu_baseline"]["reference_toolchain"] or "present on" in j["cpu_baseline"]["reference_toolchain"]
+    assert "[launch]" in multirank_runs["bench_self"]["log"] and "torch.distributed.run" in multirank_runs["bench_self"]["log"]
+    run = multirank_runs["laconic_self"]
+    assert run["rc"] == 0, run["log"][-3000:]
+    j = _json_line(run["log"])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["all_messages_recovered"] is True and j["sharded_equals_single_process"] is True
+
+
 def test_world2_laconic_ot(multirank_runs):
     run = multirank_runs["laconic"]
     assert run["rc"] == 0, run["log"][-3000:]
