@@ -400,7 +400,11 @@ extern "C" {
 #endif
 // "... src=<hash>": the hash of the kernel sources this binary was built from (csrc/Makefile, bench_tools/srchash.py); the profile
 // collectors stamp their output with it and bench.py refuses figures measured on another build.
+#ifdef KEAKI_DIAG
+const char* keaki_hip_version(void) { return "keaki-hip 0.3 (gfx950) DIAGNOSTIC BUILD (diag_row_mask available: not the product) src=" KEAKI_SRC_HASH; }
+#else
 const char* keaki_hip_version(void) { return "keaki-hip 0.3 (gfx950) src=" KEAKI_SRC_HASH; }
+#endif
 
 extern "C++" {
 namespace {
@@ -541,6 +545,9 @@ keaki_status keaki_hip_ctx_set_option(keaki_hip_ctx* ctx, const char* name, int6
   } else if (k == "encap_gt") t.encap_gt = value;
   else if (k == "host_prefault") t.host_prefault = value != 0;
   else if (k == "pipe_chunks") t.pipe_chunks = value != 0;
+#ifdef KEAKI_DIAG
+  else if (k == "diag_row_mask") t.diag_row_mask = (unsigned)value;
+#endif
   else if (k == "msm_pipe_chunks") t.msm_pipe_chunks = (int)value;
   else if (k == "msm_pipe_min") t.msm_pipe_min = value;
   else if (k == "msm_pipe_growth") t.msm_pipe_growth = (int)value;

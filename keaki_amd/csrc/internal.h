@@ -52,6 +52,9 @@ struct Tuning {
   int msm_pipe_chunks = -1;      // KEAKI_MSM_PIPE_CHUNKS / "msm_pipe_chunks": chunks of a host-pointer MSM (upload under the kernels); -1 = automatic, 0 / 1 = one copy in front, k = k chunks at any length
   long long msm_pipe_min = 1 << 20;   // KEAKI_MSM_PIPE_MIN / "msm_pipe_min": automatic chunking from this many scalars on
   int msm_pipe_growth = 140;     // KEAKI_MSM_PIPE_GROWTH / "msm_pipe_growth": size of chunk j + 1 in percent of chunk j (100 = equal chunks)
+#ifdef KEAKI_DIAG
+  unsigned diag_row_mask = 0;    // "diag_row_mask" (ONLY in the diagnostic build, `make -C keaki_amd/csrc diag`; never in libkeaki_hip.so): the table-row index of every (row, sign) entry of the bucket-ordered stream is ANDed with this mask before the bucket kernel runs, so its gathers hit a table of (mask + 1) x 64 B -- the arithmetic, the instruction stream and the kernel binary stay the shipped ones, the RESULT IS WRONG by construction (bench_tools/r6_bucket_clock_diag.py)
+#endif
   size_t alloc_limit = 0;        // keaki_hip_debug_set_alloc_limit: single allocations above it fail with KEAKI_ERR_OOM; 0 = none
 };
 }  // namespace keaki_internal

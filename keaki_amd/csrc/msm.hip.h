@@ -1003,6 +1003,15 @@ KDEV Aff<Fq> msm_load_row(const Aff<Fq>* __restrict__ p) {
     return q;
   }
 }
+#ifdef KEAKI_DIAG
+// diagnostic build only (Tuning::diag_row_mask): confines the gathers of the bucket kernel to the first mask + 1 table rows; sign bits stay
+static __global__ void k_diag_mask_rows(u32* __restrict__ sorted, size_t words, u32 mask) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) {
+    const u32 e = sorted[i];
+    sorted[i] = (e & 0x80000000u) | (e & mask);
+  }
+}
+#endif
 // MODE (passes of a chunked MSM, see Acc29): ACC_WHOLE the one-pass MSM: starts empty, writes the canonical bucket | ACC_FIRST starts
 // empty, leaves the registers in state29 | ACC_MIDDLE state29 -> state29 (buckets without pairs in this pass are not touched) |
 // ACC_LAST state29 -> canonical bucket (every bucket, also the ones the heavy path owns in this pass: k_msm_heavy_combine adds to them)

@@ -181,6 +181,9 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
 #undef KEAKI_CHUNK_SORT
     }
     ST_TRY(launch_check(ctx, "chunk_sort"));
+#ifdef KEAKI_DIAG
+    if (ctx->tune.diag_row_mask) hipLaunchKernelGGL(k_diag_mask_rows, dim3(4096), dim3(256), 0, st, sorted, (size_t)q.pairs, (u32)ctx->tune.diag_row_mask);
+#endif
     const SortView view = {sorted, bins, segtab, segoff, ps};
     // bucket schedule: descending size
     HIP_TRY(ctx, hipMemsetAsync(ghist, 0, CNT_BINS * 4 + sizeof(HeavyList), st));

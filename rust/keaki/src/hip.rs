@@ -15,9 +15,46 @@ use ark_ff::{BigInt, Zero};
 use core::any::TypeId;
 use keaki_hip_sys as sys;
 use std::{
+    cell::Cell,
     ffi::CStr,
-    sync::{Arc, OnceLock},
+    sync::{
+        atomic::{AtomicU64, Ordering},
+        Arc, OnceLock,
+    },
 };
+
+// ------------------------------------------------------------------------------------------------ evidence and per-thread switches
+/// Status codes that came back from `libkeaki_hip.so` since the process started: every call into the C ABI is followed by
+/// `Device::check` / `check_group`, which count here. A test that compares "the GPU path" with arkworks asserts that this advanced while
+/// its GPU leg ran (and stood still during its arkworks leg) -- otherwise a leg that silently fell back would compare arkworks with itself.
+static LIBRARY_CALLS: AtomicU64 = AtomicU64::new(0);
+pub fn calls() -> u64 {
+    LIBRARY_CALLS.load(Ordering::SeqCst)
+}
+
+thread_local! {
+    /// `with_disabled`: BN254 goes back to arkworks on THIS thread only (keaki's functions run on the caller's thread)
+    static DISABLED: Cell<bool> = const { Cell::new(false) };
+    /// `with_min_batch`: per-thread override of the small-call thresholds (`KEAKI_HIP_MIN_BATCH` is the process-wide one)
+    static MIN_BATCH: Cell<Option<usize>> = const { Cell::new(None) };
+}
+struct Restore<T: Copy + 'static>(&'static std::thread::LocalKey<Cell<T>>, T);
+impl<T: Copy + 'static> Drop for Restore<T> {
+    fn drop(&mut self) {
+        self.0.with(|c| c.set(self.1)); // also on unwinding: a failing assertion inside `f` must not leave the thread switched
+    }
+}
+/// Runs `f` with the `hip` path switched off on this thread: what `KEAKI_HIP=off` does for the process, without touching the environment
+/// (`set_var` while other threads call `var` is a data race, and it would switch THEIR "GPU legs" to arkworks as well).
+pub fn with_disabled<R>(f: impl FnOnce() -> R) -> R {
+    let _r = Restore(&DISABLED, DISABLED.with(|c| c.replace(true)));
+    f()
+}
+/// Runs `f` with the small-call thresholds of `active_batch` / `active_encap` set to `n` on this thread (`0`: everything to the GPU).
+pub fn with_min_batch<R>(n: usize, f: impl FnOnce() -> R) -> R {
+    let _r = Restore(&MIN_BATCH, MIN_BATCH.with(|c| c.replace(Some(n))));
+    f()
+}
 
 // ark-ff 0.4.2: Fp<MontBackend<_, 4>, 4> is `Fp(BigInt<4>, PhantomData)`, BigInt<4> is `BigInt([u64; 4])`: 32 bytes of Montgomery
 // limbs. The slices of scalars are handed to the library in place; these asserts (and `Device::self_check`) guard the assumption.
@@ -103,6 +140,7 @@ impl Device {
     }
 
     fn check_group(&self, st: sys::keaki_status, what: &str) {
+        LIBRARY_CALLS.fetch_add(1, Ordering::SeqCst);
         if st != sys::KEAKI_OK {
             let msg = unsafe { CStr::from_ptr(sys::keaki_hip_group_last_error(self.group)) }.to_string_lossy().into_owned();
             panic!("libkeaki_hip: {what} failed with status {st}: {msg}");
@@ -110,6 +148,7 @@ impl Device {
     }
 
     fn check(&self, st: sys::keaki_status, what: &str) {
+        LIBRARY_CALLS.fetch_add(1, Ordering::SeqCst);
         if st != sys::KEAKI_OK {
             let msg = unsafe { CStr::from_ptr(sys::keaki_hip_last_error(self.ctx)) }.to_string_lossy().into_owned();
             panic!("libkeaki_hip: {what} failed with status {st}: {msg}");
@@ -651,9 +690,10 @@ pub fn fr_ifft_in_place(data: &mut [Fr], group_gen_inv: &Fr, size_inv: &Fr) {
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch from the generic functions
-/// `true` when the generic parameter is BN254 and the feature is not switched off at run time (`KEAKI_HIP=off`).
+/// `true` when the generic parameter is BN254 and the feature is not switched off at run time (`KEAKI_HIP=off` for the process,
+/// `with_disabled` for the calling thread).
 pub fn active<E: Pairing>() -> bool {
-    TypeId::of::<E>() == TypeId::of::<Bn254>() && std::env::var("KEAKI_HIP").map(|v| v != "off").unwrap_or(true)
+    TypeId::of::<E>() == TypeId::of::<Bn254>() && !DISABLED.with(|c| c.get()) && std::env::var("KEAKI_HIP").map(|v| v != "off").unwrap_or(true)
 }
 
 /// Small calls. The thresholds follow the single-call figures of `bench.py`'s `single_calls` block (BENCH_r05: wall clock of one call through
@@ -671,7 +711,7 @@ pub fn active<E: Pairing>() -> bool {
 /// MSM-shaped calls (`commit`, `open`, `open_fk`) always go to the GPU (a 129-coefficient commit: 0.58 ms against 2.4 ms).
 /// (Rounds 1-4 kept fewer than 8 items on arkworks: one pairing then cost 5 ms on a lane pair.)
 fn min_batch_override() -> Option<usize> {
-    std::env::var("KEAKI_HIP_MIN_BATCH").ok().and_then(|v| v.parse::<usize>().ok())
+    MIN_BATCH.with(|c| c.get()).or_else(|| std::env::var("KEAKI_HIP_MIN_BATCH").ok().and_then(|v| v.parse::<usize>().ok()))
 }
 /// pairing-shaped work of `items` pairings with per-item second arguments: `decapsulate` (1), `verify` (2), `vec_decrypt` (its length)
 pub fn active_batch<E: Pairing>(items: usize) -> bool {

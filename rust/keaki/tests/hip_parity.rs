@@ -2,7 +2,12 @@
 //! (no Rust toolchain there), and the one that closes its "parity unpinned" residual: the absolute GT value (final-exponent multiple,
 //! tower basis, serialisation order) and therefore every KEM key.
 //!
-//!     KEAKI_HIP_LIB_DIR=/path/to/keaki_amd cargo test --release --features hip --test hip_parity -- --nocapture
+//!     KEAKI_HIP_LIB_DIR=/path/to/keaki_amd cargo test --release --features hip --test hip_parity -- --nocapture --test-threads=1
+//!
+//! No test here can pass without the GPU: every "GPU leg" runs inside `on_gpu`, which asserts that status codes came back from
+//! `libkeaki_hip.so` while it ran (`hip::calls()` advanced), every "arkworks leg" inside `on_cpu` (`hip::with_disabled`: a thread-local
+//! switch, no environment variable is written while tests run), which asserts the opposite. The tests also take one process-wide lock
+//! (`serial()`): some of them change options of the shared `Device::global()`; `--test-threads=1` is the second belt.
 //!
 //! The constants below are tests/golden/bn254_vectors.json of the MI355X tree (made by its CPU oracle): if arkworks disagrees with
 //! them, the ORACLE is wrong; if the GPU disagrees with arkworks, the kernels are.
@@ -51,9 +56,35 @@ const KEM_GT_HEX: &str = concat!(
 );
 const KEM_KEY_HEX: &str = "e7f29112b1833c5614ca4457b23f10fce69eabfb19695af33781b81007d8c244";
 
-/// single-item calls and short vectors stay on arkworks by default (`hip::active_batch`): the parity tests want them on the GPU
-fn gpu_for_small_batches() {
-    std::env::set_var("KEAKI_HIP_MIN_BATCH", "0");
+/// One test at a time: tests change options of the process-wide `Device::global()`. A poisoned lock (an earlier test failed) is taken anyway.
+static SERIAL: std::sync::Mutex<()> = std::sync::Mutex::new(());
+fn serial() -> std::sync::MutexGuard<'static, ()> {
+    SERIAL.lock().unwrap_or_else(|e| e.into_inner())
+}
+/// A GPU leg: `f` with the small-call thresholds at 0 on this thread (single calls and short vectors stay on arkworks by default,
+/// `hip::active_batch`; the parity tests want them on the device) -- and the proof that it reached the library.
+fn on_gpu<R>(what: &str, f: impl FnOnce() -> R) -> R {
+    hip::Device::global(); // context creation + self-check happen outside the counted window
+    let before = hip::calls();
+    let r = hip::with_min_batch(0, f);
+    assert!(hip::calls() > before, "{what}: the GPU leg never reached libkeaki_hip.so -- it ran on arkworks, the comparison would be arkworks against arkworks");
+    r
+}
+/// An arkworks leg: `f` with the `hip` path off on this thread -- and the proof that the library was not called.
+fn on_cpu<R>(what: &str, f: impl FnOnce() -> R) -> R {
+    let before = hip::calls();
+    let r = hip::with_disabled(f);
+    assert_eq!(hip::calls(), before, "{what}: the arkworks leg called libkeaki_hip.so");
+    r
+}
+/// puts the options a test changed back when it ends, also when it fails
+struct RestoreOptions(&'static [(&'static str, i64)]);
+impl Drop for RestoreOptions {
+    fn drop(&mut self) {
+        for &(name, value) in self.0 {
+            hip::Device::global().set_option(name, value);
+        }
+    }
 }
 
 fn fr(s: &str) -> Fr {
@@ -112,20 +143,22 @@ impl rand::RngCore for Replay {
 
 #[test]
 fn gt_of_generators_arkworks_oracle_gpu() {
-    let ark = gt_bytes(G1Affine::generator(), G2Affine::generator());
+    let _serial = serial();
+    let ark = on_cpu("e(G1, G2) on arkworks", || gt_bytes(G1Affine::generator(), G2Affine::generator()));
     assert_eq!(hex(&ark), GT_OF_GENERATORS_HEX, "arkworks disagrees with the oracle's golden vector: the oracle's GT convention is wrong");
-    let gpu = hip::pairing_bytes(&[G1Affine::generator()], &[G2Affine::generator()]);
+    let gpu = on_gpu("e(G1, G2) on the GPU", || hip::pairing_bytes(&[G1Affine::generator()], &[G2Affine::generator()]));
     assert_eq!(gpu, ark, "GPU pairing bytes differ from arkworks");
 }
 
 #[test]
 fn pairing_batch_matches_arkworks_on_random_points() {
+    let _serial = serial();
     let rng = &mut test_rng();
     let n = 64;
     let ps: Vec<G1Affine> = (0..n).map(|_| G1Affine::generator().mul(Fr::rand(rng)).into_affine()).collect();
     let mut qs: Vec<G2Affine> = (0..n).map(|_| G2Affine::generator().mul(Fr::rand(rng)).into_affine()).collect();
     qs[3] = G2Affine::identity(); // identity in a slot -> GT one
-    let gpu = hip::pairing_bytes(&ps, &qs);
+    let gpu = on_gpu("64 pairings", || hip::pairing_bytes(&ps, &qs));
     for i in 0..n {
         assert_eq!(&gpu[384 * i..384 * (i + 1)], &gt_bytes(ps[i], qs[i])[..], "item {i}");
     }
@@ -133,24 +166,31 @@ fn pairing_batch_matches_arkworks_on_random_points() {
 
 #[test]
 fn msm_commit_open_verify_match_arkworks() {
-    gpu_for_small_batches();
+    let _serial = serial();
     let rng = &mut test_rng();
     for &n in &[1usize, 2, 33, 129, 1 << 12] {
         let setup = KZGSetup::<Bn254>::setup(Fr::rand(rng), n);
         let p = DensePolynomial::from_coefficients_vec((0..n).map(|_| Fr::rand(rng)).collect());
-        let gpu = commit(&setup, &p).unwrap(); // hip path
-        let cpu = <G1Projective as VariableBaseMSM>::msm_unchecked(setup.g1_aff(), &p.coeffs);
+        let gpu = on_gpu("commit", || commit(&setup, &p).unwrap()); // hip path
+        let cpu = on_cpu("msm_unchecked", || <G1Projective as VariableBaseMSM>::msm_unchecked(setup.g1_aff(), &p.coeffs));
         assert_eq!(gpu.into_affine(), cpu.into_affine(), "commit n={n}");
         let z = Fr::rand(rng);
-        let proof = open(&setup, &p, &z).unwrap(); // hip path: device quotient + MSM
-        std::env::set_var("KEAKI_HIP", "off");
-        let proof_cpu = open(&setup, &p, &z).unwrap(); // arkworks path
-        std::env::remove_var("KEAKI_HIP");
-        assert_eq!(proof.into_affine(), proof_cpu.into_affine(), "open n={n}");
+        let proof_cpu = on_cpu("open", || open(&setup, &p, &z).unwrap()); // arkworks path
+        if n >= 2 {
+            let proof = on_gpu("open", || open(&setup, &p, &z).unwrap()); // hip path: quotient + MSM on the device
+            assert_eq!(proof.into_affine(), proof_cpu.into_affine(), "open n={n}");
+        } else {
+            // a constant polynomial: the quotient is empty, the glue may answer the identity without a device call
+            assert_eq!(hip::with_min_batch(0, || open(&setup, &p, &z).unwrap()).into_affine(), proof_cpu.into_affine(), "open n={n}");
+        }
         use ark_poly::Polynomial;
         let v = p.evaluate(&z);
-        assert!(verify(&setup, gpu, z, v, proof).unwrap());
-        assert!(!verify(&setup, gpu, z, v + Fr::from(1u64), proof).unwrap());
+        // arkworks says true / false ...
+        assert!(on_cpu("verify", || verify(&setup, gpu, z, v, proof_cpu).unwrap()));
+        assert!(!on_cpu("verify", || verify(&setup, gpu, z, v + Fr::from(1u64), proof_cpu).unwrap()));
+        // ... and so does the device (keaki_hip_kzg_verify: two pairings, from the threshold of two on)
+        assert!(on_gpu("verify", || verify(&setup, gpu, z, v, proof_cpu).unwrap()));
+        assert!(!on_gpu("verify", || verify(&setup, gpu, z, v + Fr::from(1u64), proof_cpu).unwrap()));
     }
 }
 
@@ -159,27 +199,24 @@ fn msm_commit_open_verify_match_arkworks() {
 /// host-side helpers switched off (`host_prefault` = 0, `pipe_chunks` = 0) and on: the same points as arkworks either way.
 #[test]
 fn chunked_commit_and_open_and_the_helper_off_switches_match_arkworks() {
-    gpu_for_small_batches();
+    let _serial = serial();
     let rng = &mut test_rng();
-    let n = (1usize << 12) + 17;
+    let n = (1usize << 14) + 17; // above the 8,192 coefficients up to which the glue forms the quotient on the host: keaki_hip_kzg_open itself
     let setup = KZGSetup::<Bn254>::setup(Fr::rand(rng), n);
     let p = DensePolynomial::from_coefficients_vec((0..n).map(|_| Fr::rand(rng)).collect());
     let z = Fr::rand(rng);
-    let cpu = <G1Projective as VariableBaseMSM>::msm_unchecked(setup.g1_aff(), &p.coeffs).into_affine();
-    std::env::set_var("KEAKI_HIP", "off");
-    let proof_cpu = open(&setup, &p, &z).unwrap().into_affine();
-    std::env::remove_var("KEAKI_HIP");
+    // arkworks directly (no switch involved): the MSM of the coefficients, and the proof through the reference's own body of `open`
+    let cpu = on_cpu("msm_unchecked", || <G1Projective as VariableBaseMSM>::msm_unchecked(setup.g1_aff(), &p.coeffs).into_affine());
+    let proof_cpu = on_cpu("open", || open(&setup, &p, &z).unwrap().into_affine());
     let dev = keaki::hip::Device::global();
+    let _restore = RestoreOptions(&[("msm_pipe_chunks", -1), ("host_prefault", 1), ("pipe_chunks", 1)]);
     for &(chunks, prefault, pipe) in &[(5i64, 1i64, 1i64), (5, 0, 1), (0, 0, 0), (-1, 1, 1)] {
         dev.set_option("msm_pipe_chunks", chunks);
         dev.set_option("host_prefault", prefault);
         dev.set_option("pipe_chunks", pipe);
-        assert_eq!(commit(&setup, &p).unwrap().into_affine(), cpu, "commit chunks={chunks} prefault={prefault} pipe={pipe}");
-        assert_eq!(open(&setup, &p, &z).unwrap().into_affine(), proof_cpu, "open chunks={chunks} prefault={prefault} pipe={pipe}");
+        assert_eq!(on_gpu("commit", || commit(&setup, &p).unwrap()).into_affine(), cpu, "commit chunks={chunks} prefault={prefault} pipe={pipe}");
+        assert_eq!(on_gpu("open", || open(&setup, &p, &z).unwrap()).into_affine(), proof_cpu, "open chunks={chunks} prefault={prefault} pipe={pipe}");
     }
-    dev.set_option("msm_pipe_chunks", -1);
-    dev.set_option("host_prefault", 1);
-    dev.set_option("pipe_chunks", 1);
 }
 
 /// In-process multi-GPU (`KEAKI_HIP_DEVICES=4`, or `0,0,0` to put three contexts on one GPU): `commit` / `open` are then the sharded
@@ -187,6 +224,7 @@ fn chunked_commit_and_open_and_the_helper_off_switches_match_arkworks() {
 /// Run the whole file once more with the variable set: every test above then goes through the device group as well.
 #[test]
 fn sharded_commit_over_a_device_group_matches_arkworks() {
+    let _serial = serial();
     let rng = &mut test_rng();
     let n = 1usize << 12;
     let setup = KZGSetup::<Bn254>::setup(Fr::rand(rng), n);
@@ -199,46 +237,51 @@ fn sharded_commit_over_a_device_group_matches_arkworks() {
     for &len in &[0usize, 1, 5, n / 3, n - 1, n] {
         // shorter than the SRS: members whose range lies beyond the polynomial contribute the identity
         let coeffs: Vec<Fr> = (0..len).map(|_| Fr::rand(rng)).collect();
-        let cpu = <G1Projective as VariableBaseMSM>::msm_unchecked(&setup.g1_aff()[..len], &coeffs);
-        assert_eq!(sharded.commit(&coeffs).into_affine(), cpu.into_affine(), "sharded commit len={len}");
+        let cpu = on_cpu("msm_unchecked", || <G1Projective as VariableBaseMSM>::msm_unchecked(&setup.g1_aff()[..len], &coeffs));
+        let gpu = if len == 0 { sharded.commit(&coeffs) } else { on_gpu("sharded commit", || sharded.commit(&coeffs)) };
+        assert_eq!(gpu.into_affine(), cpu.into_affine(), "sharded commit len={len}");
     }
     let p = DensePolynomial::from_coefficients_vec((0..n).map(|_| Fr::rand(rng)).collect());
     let z = Fr::rand(rng);
-    std::env::set_var("KEAKI_HIP", "off");
-    let proof_cpu = open(&setup, &p, &z).unwrap();
-    std::env::remove_var("KEAKI_HIP");
-    assert_eq!(sharded.open(&p.coeffs, &z).into_affine(), proof_cpu.into_affine(), "sharded open");
+    let proof_cpu = on_cpu("open", || open(&setup, &p, &z).unwrap());
+    assert_eq!(on_gpu("sharded open", || sharded.open(&p.coeffs, &z)).into_affine(), proof_cpu.into_affine(), "sharded open");
 }
 
 #[test]
 fn kem_vector_of_the_oracle_arkworks_and_gpu() {
-    gpu_for_small_batches();
+    let _serial = serial();
     let tau = fr(KEM_TAU);
     let setup = KZGSetup::<Bn254>::setup(tau, 8);
     let com: G1Projective = G1Affine::new(fq(KEM_COM[0]), fq(KEM_COM[1])).into();
     let (point, value, r) = (fr(KEM_POINT), fr(KEM_VALUE), fr(KEM_R));
     // arkworks path with r replayed
-    std::env::set_var("KEAKI_HIP", "off");
-    let (ct_cpu, key_cpu) = encapsulate::<Bn254>(&mut Replay::of(&[r]), &setup, com, point, value, 32);
-    std::env::remove_var("KEAKI_HIP");
+    let (ct_cpu, key_cpu) = on_cpu("encapsulate", || encapsulate::<Bn254>(&mut Replay::of(&[r]), &setup, com, point, value, 32));
     assert_eq!(hex(&key_cpu), KEM_KEY_HEX, "arkworks disagrees with the oracle's KEM key");
-    let secret = gt_bytes((com - G1Affine::generator().mul(value)).mul(r).into_affine(), G2Affine::generator());
+    let secret = on_cpu("pairing", || gt_bytes((com - G1Affine::generator().mul(value)).mul(r).into_affine(), G2Affine::generator()));
     assert_eq!(hex(&secret), KEM_GT_HEX);
     // GPU path, same r
-    let (ct_gpu, key_gpu) = encapsulate::<Bn254>(&mut Replay::of(&[r]), &setup, com, point, value, 32);
+    let (ct_gpu, key_gpu) = on_gpu("encapsulate", || encapsulate::<Bn254>(&mut Replay::of(&[r]), &setup, com, point, value, 32));
     assert_eq!(ct_gpu.into_affine(), ct_cpu.into_affine());
     assert_eq!(key_gpu, key_cpu);
+    // and back: one decapsulation on the device (it stays on arkworks by default; the threshold is 0 inside on_gpu) and one on arkworks
+    let proof = on_cpu("open", || {
+        // any polynomial with p(point) = value committed to `com` would do; the KEM only needs e(proof, ct) == e(com - value g1, g2)^r, so
+        // take proof = (com - value g1) / (tau - point)
+        (com - G1Affine::generator().mul(value)).mul((tau - point).inverse().unwrap())
+    });
+    use ark_ff::Field;
+    let key_dec_cpu = on_cpu("decapsulate", || decapsulate::<Bn254>(proof, ct_cpu, 32));
+    let key_dec_gpu = on_gpu("decapsulate", || decapsulate::<Bn254>(proof, ct_cpu, 32));
+    assert_eq!(key_dec_cpu, key_cpu, "arkworks decapsulation recovers the key");
+    assert_eq!(key_dec_gpu, key_cpu, "GPU decapsulation recovers the key");
 }
 
 #[test]
 fn vec_flow_matches_serial_arkworks_loop() {
-    gpu_for_small_batches();
+    let _serial = serial();
     // Laconic-OT shaped: vec_commit, vec_encrypt to "value i == b", vec_decrypt; GPU path and arkworks path from the same rng seed
     let n = 15usize; // domain 16
-    let run = |hip_on: bool| {
-        if !hip_on {
-            std::env::set_var("KEAKI_HIP", "off");
-        }
+    let flow = || {
         let rng = &mut test_rng();
         let setup = KZGSetup::<Bn254>::setup(Fr::rand(rng), 16);
         let v: Vec<Fr> = (0..n).map(|i| Fr::from((i % 2) as u64)).collect();
@@ -250,11 +293,10 @@ fn vec_flow_matches_serial_arkworks_loop() {
         let cts = vec_encrypt(rng, &setup, com, &points, &v, &refs);
         let ct_refs: Vec<_> = cts.iter().collect();
         let dec = vec_decrypt::<Bn254>(&proofs, &ct_refs);
-        std::env::remove_var("KEAKI_HIP");
         (com.into_affine(), G1Projective::normalize_batch(&proofs), cts.iter().map(|c| (c.0.into_affine(), c.1.clone())).collect::<Vec<_>>(), dec, msgs)
     };
-    let (c1, p1, e1, d1, m1) = run(true);
-    let (c0, p0, e0, d0, _) = run(false);
+    let (c1, p1, e1, d1, m1) = on_gpu("vec flow", flow);
+    let (c0, p0, e0, d0, _) = on_cpu("vec flow", flow);
     assert_eq!(c1, c0);
     assert_eq!(p1, p0, "FK23 proofs");
     assert_eq!(e1, e0, "ciphertexts");
@@ -265,14 +307,11 @@ fn vec_flow_matches_serial_arkworks_loop() {
 
 #[test]
 fn vec_flow_equal_length_messages_device_dem_matches_serial_arkworks_loop() {
-    gpu_for_small_batches();
+    let _serial = serial();
     // Laconic OT's own shape (tests/laconic_ot.rs:121-124): 32-byte messages of equal length -> keaki_hip_encrypt_batch / _decrypt_batch, the XOR of
     // src/enc.rs:32-36 / :48-52 on the device behind the KDF (with KEAKI_HIP_DEVICES set: the group variants, by item range)
     let n = 15usize;
-    let run = |hip_on: bool| {
-        if !hip_on {
-            std::env::set_var("KEAKI_HIP", "off");
-        }
+    let flow = || {
         let rng = &mut test_rng();
         let setup = KZGSetup::<Bn254>::setup(Fr::rand(rng), 16);
         let v: Vec<Fr> = (0..n).map(|i| Fr::from((i % 2) as u64)).collect();
@@ -284,11 +323,10 @@ fn vec_flow_equal_length_messages_device_dem_matches_serial_arkworks_loop() {
         let cts = vec_encrypt(rng, &setup, com, &points, &v, &refs);
         let ct_refs: Vec<_> = cts.iter().collect();
         let dec = vec_decrypt::<Bn254>(&proofs, &ct_refs);
-        std::env::remove_var("KEAKI_HIP");
         (cts.iter().map(|c| (c.0.into_affine(), c.1.clone())).collect::<Vec<_>>(), dec, msgs)
     };
-    let (e1, d1, m1) = run(true);
-    let (e0, d0, _) = run(false);
+    let (e1, d1, m1) = on_gpu("vec flow, equal lengths", flow);
+    let (e0, d0, _) = on_cpu("vec flow, equal lengths", flow);
     assert_eq!(e1, e0, "ciphertext points and bodies");
     assert_eq!(d1, d0);
     assert_eq!(d1, m1, "messages recovered");
