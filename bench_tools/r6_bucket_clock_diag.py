@@ -40,7 +40,7 @@ hip.srs_g1_precompute(srs)
 d_s = torch.from_numpy(random_fr_limbs(n, SEED + 2).view(np.int64)).to(dev)
 d_out = torch.zeros(12, dtype=torch.int64, device=dev)
 torch.cuda.synchronize()
-DEFAULTS = {"acc_nt": 0, "acc_prefetch": 1, "diag_row_mask": 0, "msm_c_shared": 0}
+DEFAULTS = {"acc_nt": 0, "acc_prefetch": 1, "acc_idxq": 1, "diag_row_mask": 0, "msm_c_shared": 0}
 
 
 def msm(reps=1):
@@ -101,7 +101,8 @@ if not PRODUCT:
     configs += [("rows masked to 128 MiB (Infinity-Cache resident)", {"diag_row_mask": (1 << 21) - 1}),
                 ("rows masked to 2 MiB (L2 resident)", {"diag_row_mask": (1 << 15) - 1}),
                 ("rows masked to 32 KiB (L1 resident)", {"diag_row_mask": (1 << 9) - 1})]
-configs += [("acc_nt = 1 (non-temporal row loads)", {"acc_nt": 1}),
+configs += [("acc_idxq = 0 (index stream one 4-byte entry per load, rounds 1-5)", {"acc_idxq": 0}),
+            ("acc_nt = 1 (non-temporal row loads)", {"acc_nt": 1}),
             ("acc_prefetch = 0 (loads at the top of the iteration)", {"acc_prefetch": 0})]
 for extra in sys.argv[1:]:
     if extra.startswith("--opt="):

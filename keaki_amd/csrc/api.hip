@@ -420,6 +420,7 @@ void tune_from_env(Tuning& t) {
   if (geti("KEAKI_ACC_U29_G2", v)) t.acc_u29_g2 = v != 0;
   if (geti("KEAKI_ACC_NT", v)) t.acc_nt = v != 0;
   if (geti("KEAKI_ACC_PREFETCH", v)) t.acc_prefetch = v != 0;
+  if (geti("KEAKI_ACC_IDXQ", v)) t.acc_idxq = v != 0;
   if (geti("KEAKI_CS_MASKED", v)) t.cs_masked = v != 0;
   if (geti("KEAKI_FK_UNIFORM", v)) t.fk_uniform = v != 0;
   if (geti("KEAKI_FK_GTAB", v)) t.fk_gtab = v != 0;
@@ -529,6 +530,7 @@ keaki_status keaki_hip_ctx_set_option(keaki_hip_ctx* ctx, const char* name, int6
   else if (k == "acc_u29_g2") t.acc_u29_g2 = value != 0;
   else if (k == "acc_nt") t.acc_nt = value != 0;
   else if (k == "acc_prefetch") t.acc_prefetch = value != 0;
+  else if (k == "acc_idxq") t.acc_idxq = value != 0;
   else if (k == "cs_masked") t.cs_masked = value != 0;
   else if (k == "fk_uniform") t.fk_uniform = value != 0;
   else if (k == "fk_gtab") t.fk_gtab = value != 0;

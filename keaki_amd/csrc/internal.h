@@ -36,6 +36,7 @@ struct Tuning {
   bool acc_u29 = true;           // KEAKI_ACC_U29 / "acc_u29": G1 bucket kernel in the 29-bit lazy limbs (A/B switch for profiling)
   bool acc_u29_g2 = true;        // KEAKI_ACC_U29_G2 / "acc_u29_g2"
   bool acc_prefetch = true;      // KEAKI_ACC_PREFETCH / "acc_prefetch": the G1 bucket kernel requests the next pair's table row an iteration ahead (A/B switch)
+  bool acc_idxq = true;          // KEAKI_ACC_IDXQ / "acc_idxq": the G1 bucket kernel reads its index stream by aligned 16-byte quads through a lane-private LDS slot (0: one 4-byte load per entry, as until round 5; A/B switch)
   bool cs_masked = true;         // KEAKI_CS_MASKED / "cs_masked": pass 2 of the bucket sort skips empty gather slots under the exec mask (0: every empty slot counts into a dummy word per lane, as in round 4; A/B switch: 0.84 -> 0.70 ms at 2^24)
   bool acc_nt = false;           // KEAKI_ACC_NT / "acc_nt": non-temporal loads of the table rows in the G1 bucket kernel
   bool fk_uniform = true;        // KEAKI_FK_UNIFORM / "fk_uniform": sliding-window ladder in the wave-uniform FK23 stages

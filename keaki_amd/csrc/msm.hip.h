@@ -714,6 +714,72 @@ KDEV u32 seg_next(SegWalker& w, const SortView& v) {
   w.left--;
   return v.sorted[w.pos++];
 }
+// ---- the index stream by QUADS (round 6; G1 bucket kernel) ---------------------------------------------------------------------------
+// seg_next reads ONE 4-byte entry per call at a per-lane address. A lane's entries are consecutive words, but between two calls of one lane
+// the wave gathers 64 table rows (and the CU's other eleven waves theirs): the 32-KB L1 has long dropped the line, so every entry is an
+// L1 -> L2 request of its own (2.0 requests per table row: one row, one entry), and L2 -- 4 MiB per XCD against 3 MiB of index lines in
+// use plus the stream of rows -- misses 42 % of them: each 128-byte index line came over the fabric 13.5 times, 10.9 GB of a launch's
+// 37 GB (profiles/r06_bucket_clock_diagnosis.txt; the same counters with the rows confined to 2 MiB leave exactly this part). Here
+// a lane fetches the ALIGNED 64-byte group (four quads) that holds its next entry into a lane-private LDS slot by LDS-DMA loads (no register
+// for the data: the kernel sits at 168 of the 168 it may use) and takes its entries from there; the next group is requested when the last
+// entry of the current one has been read, an iteration before its first entry is needed. ~8 entries per request on 16-entry segments.
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* global_void_ptr;
+// The quad walker keeps seven words (seg_next's SegWalker: ten): the bin's image base, chunk count and row of the chunk-major table are read
+// again from bins[] (16 KB, L2-resident) at every segment change -- once per ~16 entries -- instead of riding in registers.
+struct SegWalkerQ {
+  u32 pos, left;        // next entry of the current segment, entries left in it
+  u32 w0, w1, w2, w3;   // the next segment words
+  u32 c;                // chunks consumed
+};
+KDEV void segq_init(SegWalkerQ& w, const SortView& v, u32 t) {
+  const v4u_t sw = v.segtab[t];
+  w.w0 = sw[0]; w.w1 = sw[1]; w.w2 = sw[2]; w.w3 = sw[3];
+  w.c = 0; w.left = 0; w.pos = 0;
+}
+// to the bucket's next non-empty segment (call with left == 0); leaves left == 0 when there is none
+KDEV void segq_advance(SegWalkerQ& w, const SortView& v, u32 t) {
+  const BinMeta bm = v.bins[part_bin(v.ps, t)];
+  const u32 o = bm.chunk_first * v.ps.nf + part_fine(v.ps, t);
+  u32 s, e, ci;
+  do {
+    s = w.w0 & 0xFFFFu; e = w.w0 >> 16; ci = w.c;
+    w.w0 = w.w1; w.w1 = w.w2; w.w2 = w.w3;
+    w.w3 = w.c + SEG_INLINE < bm.nch ? v.segoff[o + (w.c + SEG_INLINE) * v.ps.nf] : 0u;
+    w.c++;
+  } while (e == s && w.c <= bm.nch);
+  w.pos = bm.img_base + ci * C2_CAP + s;
+  w.left = e - s;
+}
+// A lane's slot holds the aligned group of IDXQ_NQ quads (16 IDXQ_NQ bytes) around its next entry: quad j of every lane of the workgroup in plane j
+// (256 x 16 bytes), because one LDS-DMA instruction writes lane i's 16 bytes at base + 16 i. The IDXQ_NQ requests of a group go out back to
+// back and meet in the L1 like the four loads of a table row: one L1 -> L2 request per group.
+constexpr u32 IDXQ_NQ = 4, IDXQ_PLANE = 256 * 4;      // quads per group; words per plane
+// request the group of entry `pos` into the lane's slot: `wave_slots` is the wave's 1-KiB block of plane 0 (wave-uniform)
+KDEV void segq_fetch(const SegWalkerQ& w, const SortView& v, u32* wave_slots) {
+  const u32* src = v.sorted + (w.pos & ~(4u * IDXQ_NQ - 1u));
+#pragma unroll
+  for (u32 j = 0; j < IDXQ_NQ; j++)
+    __builtin_amdgcn_global_load_lds((global_void_ptr)(src + 4 * j), (lds_void_ptr)(wave_slots + j * IDXQ_PLANE), 16, 0, 0);
+}
+// next entry of the bucket. The group that holds it must have LANDED: the caller has waited (s_waitcnt vmcnt(0)) since the fetch was issued.
+KDEV u32 segq_next(SegWalkerQ& w, const SortView& v, u32 t, const u32* my_slot, u32* wave_slots) {
+  const u32 e = my_slot[((w.pos >> 2) & (IDXQ_NQ - 1u)) * IDXQ_PLANE + (w.pos & 3u)];
+  w.pos++; w.left--;
+  bool refill = (w.pos & (4u * IDXQ_NQ - 1u)) == 0;
+  if (w.left == 0) { segq_advance(w, v, t); refill = true; }
+  // `left` is re-read from its register behind the advance loop: asked as `w.left != 0` directly, hipcc (ROCm 7.2) takes the lane mask of the
+  // loop's exit test e != s from the LAST trip of the loop only -- lanes that had left the loop a trip earlier (their neighbours stepped over an
+  // empty segment: skewed scalars) came out with left = 0 and no request. Found by tests/test_gpu_msm_pipe.py::test_chunked_heavy_buckets.
+  u32 left_now = w.left;
+  asm volatile("" : "+v"(left_now));
+  w.left = left_now;
+  if (refill && left_now != 0) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the read above has left the slot before the DMA may write it
+    segq_fetch(w, v, wave_slots);
+  }
+  return e;
+}
 // segment word of bucket t in chunk c (random access: the heavy-bucket kernel)
 KDEV u32 seg_word(const SortView& v, u32 t, const BinMeta& bm, u32 c) {
   if (c < SEG_INLINE) return ((const u32*)v.segtab)[(size_t)t * SEG_INLINE + c];
@@ -1016,7 +1082,9 @@ static __global__ void k_diag_mask_rows(u32* __restrict__ sorted, size_t words, 
 // empty, leaves the registers in state29 | ACC_MIDDLE state29 -> state29 (buckets without pairs in this pass are not touched) |
 // ACC_LAST state29 -> canonical bucket (every bucket, also the ones the heavy path owns in this pass: k_msm_heavy_combine adds to them)
 enum { ACC_WHOLE = 0, ACC_FIRST = 1, ACC_MIDDLE = 2, ACC_LAST = 3 };
-template <int NT, int MODE, int PF = 1>      // PF = 0: the loop of rounds 1-4 (loads at the top of every iteration): A/B switch acc_prefetch
+// PF = 0: the loop of rounds 1-4 (loads at the top of every iteration): A/B switch acc_prefetch. PF = 2 (round 6, the default): the pipeline of
+// PF = 1 with the index stream by quads through LDS (segq_*): A/B switch acc_idxq.
+template <int NT, int MODE, int PF = 2>
 static __global__ void __launch_bounds__(256, 3) k_msm_accumulate_g1_u29(const Aff<Fq>* __restrict__ points, SortView v,
                                                                       const u32* __restrict__ counts, const u32* __restrict__ perm,
                                                                       u32 nbuckets_total, Xyzz<Fq>* __restrict__ buckets,
@@ -1034,7 +1102,8 @@ static __global__ void __launch_bounds__(256, 3) k_msm_accumulate_g1_u29(const A
     if (cnt == 0) return;
   }
   SegWalker sw;
-  seg_init(sw, v, t);
+  SegWalkerQ sq;
+  if constexpr (PF == 2) segq_init(sq, v, t); else seg_init(sw, v, t);
   U29 X1, Y1, ZZ, ZZZ;
   bool empty = true;
   if constexpr (MODE == ACC_MIDDLE || MODE == ACC_LAST) empty = acc29_load(state29 + t, X1, Y1, ZZ, ZZZ);
@@ -1043,14 +1112,44 @@ static __global__ void __launch_bounds__(256, 3) k_msm_accumulate_g1_u29(const A
   // other two waves of the SIMD could cover (alu.frac 0.94). 18 more registers: 167 of the 168 that three waves per SIMD allow.
   u32 e1 = 0, e2 = 0;
   Aff<Fq> q1;
-  if constexpr (PF != 0) {
+  __shared__ __attribute__((aligned(16))) u32 idx_slots[PF == 2 ? IDXQ_NQ * IDXQ_PLANE : 4];       // PF == 2: IDXQ_NQ quads of the index stream per lane
+  const u32* my_slot = idx_slots + threadIdx.x * 4;
+  u32* wave_slots = idx_slots + (threadIdx.x & ~63u) * 4;
+  if constexpr (PF == 2) {
+    if (cnt > 0) {
+      segq_advance(sq, v, t);
+      segq_fetch(sq, v, wave_slots);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      e1 = segq_next(sq, v, t, my_slot, wave_slots);
+      if (cnt > 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the first call may have requested the next quad
+        e2 = segq_next(sq, v, t, my_slot, wave_slots);
+      }
+    }
+    q1 = msm_load_row<NT>(points + (e1 & 0x7FFFFFFFu));
+  } else if constexpr (PF != 0) {
     e1 = cnt > 0 ? seg_next(sw, v) : 0u; e2 = cnt > 1 ? seg_next(sw, v) : 0u;
     q1 = msm_load_row<NT>(points + (e1 & 0x7FFFFFFFu));
   }
   for (u32 k = 0; k < cnt; k++) {
     u32 e;
     Aff<Fq> q;
-    if constexpr (PF != 0) {
+    if constexpr (PF == 2) {
+      e = e1;
+      // row k (requested an iteration ago) is needed now, and so is the quad a call of the last iteration may have requested: one wait for both,
+      // BEFORE row k + 1 is requested (a wait behind that request would expose its latency)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      q = q1;
+      // the copy happens HERE: left to itself hipcc sinks these moves below the quad request, and -- a use of a load result while an LDS-DMA is in
+      // flight -- puts an s_waitcnt vmcnt(0) in front of them that waits for the request just made
+#pragma unroll
+      for (int i = 0; i < 8; i++) { asm volatile("" : "+v"(q.x.l[i])); asm volatile("" : "+v"(q.y.l[i])); }
+      u32 e3 = 0;
+      if (k + 2 < cnt) e3 = segq_next(sq, v, t, my_slot, wave_slots);
+      e1 = e2;
+      if (k + 1 < cnt) q1 = msm_load_row<NT>(points + (e1 & 0x7FFFFFFFu));
+      e2 = e3;
+    } else if constexpr (PF != 0) {
       e = e1;
       q = q1;
       e1 = e2;

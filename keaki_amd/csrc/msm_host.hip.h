@@ -100,7 +100,7 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
     q.sg_bytes = nb * sizeof(v4u_t);
     q.ts_bytes = (size_t)q.ps.ntiles * (q.ps.nbins + 1) * 2;
     w_digits = std::max(w_digits, (size_t)q.ps.ntiles * q.ps.te * 4);
-    w_sorted = std::max(w_sorted, q.pairs * 4);
+    w_sorted = std::max(w_sorted, q.pairs * 4 + 64);      // + 64: the bucket kernel reads the index stream in aligned 64-byte groups (segq_fetch)
     w_offsets = std::max(w_offsets, q.max_chunks * q.ps.nf * 4);
     w_cursor = std::max(w_cursor, q.cm_bytes + q.bt_bytes + q.bm_bytes + q.sg_bytes + q.ts_bytes);
     w_pairs = std::max(w_pairs, q.pairs);
@@ -202,6 +202,8 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
           if (ctx->tune.acc_nt) KEAKI_ACC(1, ACC_WHOLE);
           else if (!ctx->tune.acc_prefetch)
             hipLaunchKernelGGL((k_msm_accumulate_g1_u29<0, ACC_WHOLE, 0>), ga, ba, 0, st, pts, view, (const u32*)hist, (const u32*)perm, (u32)nb, buckets, state29);
+          else if (!ctx->tune.acc_idxq)
+            hipLaunchKernelGGL((k_msm_accumulate_g1_u29<0, ACC_WHOLE, 1>), ga, ba, 0, st, pts, view, (const u32*)hist, (const u32*)perm, (u32)nb, buckets, state29);
           else KEAKI_ACC(0, ACC_WHOLE);
         }
         else if (first) KEAKI_ACC(0, ACC_FIRST);
