@@ -94,7 +94,8 @@ const char* keaki_hip_version(void);
 /* keaki_hip_last_error: the returned string is a copy private to the calling thread (valid until its next call of this function). */
 /* Tuning / A-B switches of a context (profiling and tests; defaults are what ships). Initial values come from the environment variable
  * KEAKI_<NAME> at keaki_hip_ctx_create; afterwards only this call changes them. Names: "msm_c", "msm_c_shared" (window bits, 0 = automatic),
- * "reduce_l", "part_shift", "acc_u29", "acc_u29_g2", "acc_nt", "fk_uniform", "fk_gtab", "fk_addsub29", "fk_radix4", "fb_occ1", "gt_wb_b" (window bits of the table of
+ * "reduce_l", "part_shift", "acc_u29", "acc_u29_g2", "acc_nt", "acc_prefetch", "acc_idxq" (the G1 bucket kernel reads its index stream by aligned
+ * 64-byte groups through a lane-private LDS slot; 0 = one 4-byte load per entry as until round 5), "cs_masked", "fk_uniform", "fk_gtab", "fk_addsub29", "fk_radix4", "fb_occ1", "gt_wb_b" (window bits of the table of
  * e(g1, g2), 0 = automatic; a change rebuilds the table on the next use), "encap_gt" (batch size from which encap_batch takes the GT
  * fixed-base path and below which -- for a commitment that has no table yet -- it runs a pairing per item; -1 = automatic: always the GT path),
  * "pair_wide_max" (pairing batches up to this size run the twelve-lanes-per-pairing kernel; -1 = automatic (4096), 0 = never), "pair_two_waves"
@@ -106,8 +107,11 @@ const char* keaki_hip_version(void);
  *       huge pages on them (madvise(MADV_HUGEPAGE)); chunked batches do this on up to three helper std::threads that live for the duration of
  *       the call. 0: no helper threads, no write into and no madvise on caller memory -- every byte that appears in an output array was put there
  *       by a device-to-host copy. Results are identical; downloads into pages that do not exist yet are slower (160 MB: 30 ms instead of 3).
- *   "pipe_chunks" (default 1): host-array batches (encap / decap / encrypt / decrypt from 2 x 65,536 items on; MSMs from "msm_pipe_min" scalars on)
- *       run as chunk pipelines over a copy stream of the context's own. 0: upload, kernels, download, in that order, on the context's stream.
+ *   "pipe_chunks" (default 1): host-array batches (encap / decap / encrypt / decrypt from 2 x 65,536 items on; MSMs from "msm_pipe_min" scalars on;
+ *       kzg_open from 2^21 coefficients on) run as chunk pipelines over a copy stream (kzg_open: and an auxiliary stream) of the context's own.
+ *       0: upload, kernels, download, in that order, on the context's stream -- for every AUTOMATIC choice. An explicit "msm_pipe_chunks" >= 2
+ *       names the chunked path itself and takes precedence: a caller who wants no other stream sets "pipe_chunks" = 0 and leaves
+ *       "msm_pipe_chunks" at -1 (or sets it to 0).
  *   "msm_pipe_chunks" (-1 = automatic: 6 chunks from 2^22 scalars on, 4 from 2^21, 3 from "msm_pipe_min" = 2^20 on; 0 / 1 = one copy in front; k >= 2 = k chunks at
  *       any length), "msm_pipe_growth" (size of chunk j + 1 in percent of chunk j, default 140: a short first chunk starts the device early).
  *   A host-array call that FAILS (status != KEAKI_OK) leaves its output arrays unspecified: any prefix may hold results, and with

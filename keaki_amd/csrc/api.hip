@@ -374,7 +374,11 @@ static keaki_status msm_from_host(keaki_hip_ctx* ctx, const uint64_t* scalars, s
   for (size_t j = 0; j + 1 < bounds.size(); j++) pipe.ranges.push_back({bounds[j], bounds[j + 1] - bounds[j]});
   if (pipe.ranges.size() <= 1) {
     if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->io_a.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    return run(nullptr);
+    const keaki_status st = run(nullptr);
+    // a FAILED call returns as well only when no copy reads the caller's array any more (header; with a pinned source the copy above is truly
+    // asynchronous): the successful path synchronises when it downloads the result, the failing one here
+    if (st != KEAKI_OK && n) (void)hipStreamSynchronize(ctx->stream);
+    return st;
   }
   ChunkUploader up(ctx);
   ST_TRY(up.begin());
@@ -1575,15 +1579,18 @@ keaki_status keaki_hip_kzg_open(keaki_hip_ctx* ctx, const keaki_hip_srs_g1* srs,
   std::vector<std::pair<size_t, size_t>> cch;                                    // coefficient chunks [lo, hi), top first
   // (automatic from 2^21 coefficients on: the first chunk's quotient stays in front of the first pass; 2^20: 2.71 ms in three chunks against 2.64
   // with the copy in front, 2^21: 4.05 / 4.36, 2^22: 6.43 / 8.10, 2^24: 19.2 / 28.0 ms -- profiles/r05_open_chunked.txt)
-  if (ctx->tune.msm_pipe_chunks >= 2 || n >= ((size_t)1 << 21)) {
+  if (ctx->tune.msm_pipe_chunks >= 2 || (ctx->tune.msm_pipe_chunks < 0 && ctx->tune.pipe_chunks && n >= ((size_t)1 << 21))) {     // "pipe_chunks" = 0 or "msm_pipe_chunks" = 0 / 1: one copy in front, on the context's stream
     const std::vector<size_t> bounds = msm_pipe_bounds(ctx->tune, n);
     for (size_t j = 0; j + 1 < bounds.size(); j++) cch.push_back({n - bounds[j + 1], n - bounds[j]});
     if (cch.size() >= 2 && cch.back().second == 1) { cch[cch.size() - 2].first = 0; cch.pop_back(); }     // the lowest chunk must leave a quotient coefficient
   }
   if (cch.size() <= 1 || nq == 0) {
     if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->io_a.p, coeffs, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    // a failing call, too, returns only when no copy reads `coeffs` any more (header): the successful path synchronises in `download` below
+    struct UploadFence { hipStream_t s; bool armed; ~UploadFence() { if (armed) (void)hipStreamSynchronize(s); } } fence{ctx->stream, n != 0};
     if (n) ST_TRY(open_quotient_run(ctx, ctx->io_a.p, n, point, b + o_q, b + o_v, b + o_w));
     ST_TRY(msm_g1_run(ctx, srs->d, srs->n, b + o_q, nq, ctx->io_b.p, tb.first, tb.second));
+    fence.armed = false;
   } else {
     // Three streams: the copy stream brings chunk j up, the AUX stream turns it into quotient coefficients (a handful of short,
     // latency-bound kernels that depend on the chunk above only through its carry), the context's stream runs the MSM passes. The quotient of

@@ -725,29 +725,35 @@ KDEV u32 seg_next(SegWalker& w, const SortView& v) {
 // entry of the current one has been read, an iteration before its first entry is needed. ~8 entries per request on 16-entry segments.
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* global_void_ptr;
-// The quad walker keeps seven words (seg_next's SegWalker: ten): the bin's image base, chunk count and row of the chunk-major table are read
-// again from bins[] (16 KB, L2-resident) at every segment change -- once per ~16 entries -- instead of riding in registers.
+// The quad walker keeps TWO words in registers (seg_next's SegWalker: ten). The bucket's next four segment words and its chunk counter are parked in
+// LDS between segment changes (eight words per lane beside the index slot), the bin's image base, chunk count and row of the chunk-major table are
+// read again from bins[] (16 KB, L2-resident) at every change -- once per ~16 entries. With all of it in registers the kernel's chunked modes
+// spilled (12-16 B/lane) at the 168 registers three waves per SIMD allow.
 struct SegWalkerQ {
   u32 pos, left;        // next entry of the current segment, entries left in it
-  u32 w0, w1, w2, w3;   // the next segment words
-  u32 c;                // chunks consumed
 };
-KDEV void segq_init(SegWalkerQ& w, const SortView& v, u32 t) {
+constexpr u32 SEGQ_PARK = 8;        // parked words per lane: w0..w3 (the next segment words), c (chunks consumed), 3 unused
+KDEV void segq_init(SegWalkerQ& w, const SortView& v, u32 t, u32* park) {
   const v4u_t sw = v.segtab[t];
-  w.w0 = sw[0]; w.w1 = sw[1]; w.w2 = sw[2]; w.w3 = sw[3];
-  w.c = 0; w.left = 0; w.pos = 0;
+  *reinterpret_cast<v4u_t*>(park) = sw;
+  park[4] = 0;
+  w.left = 0; w.pos = 0;
 }
 // to the bucket's next non-empty segment (call with left == 0); leaves left == 0 when there is none
-KDEV void segq_advance(SegWalkerQ& w, const SortView& v, u32 t) {
+KDEV void segq_advance(SegWalkerQ& w, const SortView& v, u32 t, u32* park) {
   const BinMeta bm = v.bins[part_bin(v.ps, t)];
   const u32 o = bm.chunk_first * v.ps.nf + part_fine(v.ps, t);
+  const v4u_t sw = *reinterpret_cast<const v4u_t*>(park);
+  u32 w0 = sw[0], w1 = sw[1], w2 = sw[2], w3 = sw[3], c = park[4];
   u32 s, e, ci;
   do {
-    s = w.w0 & 0xFFFFu; e = w.w0 >> 16; ci = w.c;
-    w.w0 = w.w1; w.w1 = w.w2; w.w2 = w.w3;
-    w.w3 = w.c + SEG_INLINE < bm.nch ? v.segoff[o + (w.c + SEG_INLINE) * v.ps.nf] : 0u;
-    w.c++;
-  } while (e == s && w.c <= bm.nch);
+    s = w0 & 0xFFFFu; e = w0 >> 16; ci = c;
+    w0 = w1; w1 = w2; w2 = w3;
+    w3 = c + SEG_INLINE < bm.nch ? v.segoff[o + (c + SEG_INLINE) * v.ps.nf] : 0u;
+    c++;
+  } while (e == s && c <= bm.nch);
+  *reinterpret_cast<v4u_t*>(park) = v4u_t{w0, w1, w2, w3};
+  park[4] = c;
   w.pos = bm.img_base + ci * C2_CAP + s;
   w.left = e - s;
 }
@@ -763,11 +769,11 @@ KDEV void segq_fetch(const SegWalkerQ& w, const SortView& v, u32* wave_slots) {
     __builtin_amdgcn_global_load_lds((global_void_ptr)(src + 4 * j), (lds_void_ptr)(wave_slots + j * IDXQ_PLANE), 16, 0, 0);
 }
 // next entry of the bucket. The group that holds it must have LANDED: the caller has waited (s_waitcnt vmcnt(0)) since the fetch was issued.
-KDEV u32 segq_next(SegWalkerQ& w, const SortView& v, u32 t, const u32* my_slot, u32* wave_slots) {
+KDEV u32 segq_next(SegWalkerQ& w, const SortView& v, u32 t, const u32* my_slot, u32* wave_slots, u32* park) {
   const u32 e = my_slot[((w.pos >> 2) & (IDXQ_NQ - 1u)) * IDXQ_PLANE + (w.pos & 3u)];
   w.pos++; w.left--;
   bool refill = (w.pos & (4u * IDXQ_NQ - 1u)) == 0;
-  if (w.left == 0) { segq_advance(w, v, t); refill = true; }
+  if (w.left == 0) { segq_advance(w, v, t, park); refill = true; }
   // `left` is re-read from its register behind the advance loop: asked as `w.left != 0` directly, hipcc (ROCm 7.2) takes the lane mask of the
   // loop's exit test e != s from the LAST trip of the loop only -- lanes that had left the loop a trip earlier (their neighbours stepped over an
   // empty segment: skewed scalars) came out with left = 0 and no request. Found by tests/test_gpu_msm_pipe.py::test_chunked_heavy_buckets.
@@ -1103,7 +1109,7 @@ static __global__ void __launch_bounds__(256, 3) k_msm_accumulate_g1_u29(const A
   }
   SegWalker sw;
   SegWalkerQ sq;
-  if constexpr (PF == 2) segq_init(sq, v, t); else seg_init(sw, v, t);
+  if constexpr (PF != 2) seg_init(sw, v, t);
   U29 X1, Y1, ZZ, ZZZ;
   bool empty = true;
   if constexpr (MODE == ACC_MIDDLE || MODE == ACC_LAST) empty = acc29_load(state29 + t, X1, Y1, ZZ, ZZZ);
@@ -1113,17 +1119,20 @@ static __global__ void __launch_bounds__(256, 3) k_msm_accumulate_g1_u29(const A
   u32 e1 = 0, e2 = 0;
   Aff<Fq> q1;
   __shared__ __attribute__((aligned(16))) u32 idx_slots[PF == 2 ? IDXQ_NQ * IDXQ_PLANE : 4];       // PF == 2: IDXQ_NQ quads of the index stream per lane
+  __shared__ __attribute__((aligned(16))) u32 idx_park[PF == 2 ? 256 * SEGQ_PARK : 4];             //          and the walker's parked words
   const u32* my_slot = idx_slots + threadIdx.x * 4;
   u32* wave_slots = idx_slots + (threadIdx.x & ~63u) * 4;
+  u32* park = idx_park + threadIdx.x * SEGQ_PARK;
   if constexpr (PF == 2) {
+    segq_init(sq, v, t, park);
     if (cnt > 0) {
-      segq_advance(sq, v, t);
+      segq_advance(sq, v, t, park);
       segq_fetch(sq, v, wave_slots);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      e1 = segq_next(sq, v, t, my_slot, wave_slots);
+      e1 = segq_next(sq, v, t, my_slot, wave_slots, park);
       if (cnt > 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the first call may have requested the next quad
-        e2 = segq_next(sq, v, t, my_slot, wave_slots);
+        e2 = segq_next(sq, v, t, my_slot, wave_slots, park);
       }
     }
     q1 = msm_load_row<NT>(points + (e1 & 0x7FFFFFFFu));
@@ -1145,7 +1154,7 @@ static __global__ void __launch_bounds__(256, 3) k_msm_accumulate_g1_u29(const A
 #pragma unroll
       for (int i = 0; i < 8; i++) { asm volatile("" : "+v"(q.x.l[i])); asm volatile("" : "+v"(q.y.l[i])); }
       u32 e3 = 0;
-      if (k + 2 < cnt) e3 = segq_next(sq, v, t, my_slot, wave_slots);
+      if (k + 2 < cnt) e3 = segq_next(sq, v, t, my_slot, wave_slots, park);
       e1 = e2;
       if (k + 1 < cnt) q1 = msm_load_row<NT>(points + (e1 & 0x7FFFFFFFu));
       e2 = e3;
@@ -1195,14 +1204,18 @@ static __global__ void __launch_bounds__(256, 3) k_msm_accumulate_g1_u29(const A
     ZZ = u29_mul(ZZ, PP);
     ZZZ = u29_mul(ZZZ, PPP);
   }
+  // the addresses of the final stores are formed HERE, from a copy of t the compiler cannot connect with the one the state was loaded through: kept
+  // from the top of the kernel (the chunked modes load through state29 + t) the 64-bit address was spilled across the loop (12-16 B/lane of scratch)
+  u32 ts = t;
+  asm volatile("" : "+v"(ts));
   if constexpr (MODE == ACC_FIRST || MODE == ACC_MIDDLE) {
-    acc29_store(state29 + t, X1, Y1, ZZ, ZZZ, empty);
+    acc29_store(state29 + ts, X1, Y1, ZZ, ZZZ, empty);
   } else {
     Xyzz<Fq> out = xyzz_inf<Fq>();
     if (!empty) {
       out.x = u29_to_fq(X1); out.y = u29_to_fq(Y1); out.zz = u29_to_fq(ZZ); out.zzz = u29_to_fq(ZZZ);
     }
-    buckets[t] = out;
+    buckets[ts] = out;
   }
 }
 
@@ -1218,16 +1231,31 @@ static __global__ void __launch_bounds__(256, 2) k_msm_accumulate_g2_u29(const A
   u32 cnt = counts[t];
   if (msm_bucket_is_heavy(cnt)) return;   // done by k_msm_heavy / k_msm_heavy_combine
   if (CONT && cnt == 0) return;
-  SegWalker sw;
-  seg_init(sw, v, t);
+  // the index stream as in the G1 kernel (round 6): aligned 64-byte groups through a lane-private LDS slot, the walker's segment words parked in LDS
+  // (eight registers fewer across the addition: the one dword this kernel reloaded from scratch in every iteration is gone; what -Rpass still
+  // reports as scratch is the call frame of the out-of-line saturated Fq2 products of the same-point path, 18 in 2^29 additions)
+  __shared__ __attribute__((aligned(16))) u32 idx_slots[IDXQ_NQ * IDXQ_PLANE];
+  __shared__ __attribute__((aligned(16))) u32 idx_park[256 * SEGQ_PARK];
+  const u32* my_slot = idx_slots + threadIdx.x * 4;
+  u32* wave_slots = idx_slots + (threadIdx.x & ~63u) * 4;
+  u32* park = idx_park + threadIdx.x * SEGQ_PARK;
+  SegWalkerQ sq;
+  segq_init(sq, v, t, park);
   X29G2 acc = x29g2_inf();
   if constexpr (CONT != 0) acc = x29g2_load(buckets[t]);
+  if (cnt > 0) {
+    segq_advance(sq, v, t, park);
+    segq_fetch(sq, v, wave_slots);
+  }
   for (u32 k = 0; k < cnt; k++) {
-    u32 e = seg_next(sw, v);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the group requested by the call of the last iteration (or in front of the loop) has landed
+    const u32 e = segq_next(sq, v, t, my_slot, wave_slots, park);
     Aff<Fq2> q = points[e & 0x7FFFFFFFu];
     x29g2_add_mixed(acc, aff_cneg(q, (e >> 31) != 0));
   }
-  buckets[t] = x29g2_store(acc);
+  u32 ts = t;
+  asm volatile("" : "+v"(ts));
+  buckets[ts] = x29g2_store(acc);
 }
 
 // ---- K5: per-window weighted sum, chunked ----------------------------------------------------------

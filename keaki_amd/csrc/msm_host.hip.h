@@ -109,7 +109,7 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   bool u29 = false;
   if constexpr (std::is_same<F, Fq>::value) u29 = ctx->tune.acc_u29;          // A/B switches for profiling
   if constexpr (std::is_same<F, Fq2>::value) u29 = ctx->tune.acc_u29_g2;
-  const bool lazy_state = K > 1 && u29 && std::is_same<F, Fq>::value;         // the G1 kernel's registers stay in Acc29 between the passes
+  bool lazy_state = K > 1 && u29 && std::is_same<F, Fq>::value;               // the G1 kernel's registers stay in Acc29 between the passes
   // every workspace is reserved BEFORE the first pass (sized for the largest one): a reserve that grows a buffer waits for the stream
   // pass-1 images | bucket-ordered index stream | per-bucket counts | chunk-major segment words of the chunks beyond SEG_INLINE
   ST_TRY(reserve(ctx, ctx->digits, w_digits));
@@ -124,7 +124,13 @@ keaki_status msm_dev(keaki_hip_ctx* ctx, const Aff<F>* d_points, size_t srs_len,
   const u32 hv_cap = (u32)(w_pairs / HEAVY_MIN + 1), hv_slice_cap = (u32)(hv_cap + w_pairs / HEAVY_SLICE + 1);
   const size_t hv_hdr = ((2 * (size_t)hv_cap + hv_slice_cap) * 4 + 255) & ~(size_t)255;
   ST_TRY(reserve(ctx, ctx->heavy, hv_hdr + (size_t)hv_slice_cap * sizeof(Xyzz<F>)));
-  if (lazy_state) ST_TRY(reserve(ctx, ctx->acc29, nb * sizeof(Acc29)));
+  if (lazy_state) {
+    // 144 B per bucket on top of the canonical 128 (302 MB at 2^21 buckets): optional memory like the window tables -- when it does not fit, the
+    // passes go on from the canonical bucket through the saturated kernel (slower, same result) instead of failing commit / open
+    const keaki_status st29 = reserve(ctx, ctx->acc29, nb * sizeof(Acc29));
+    if (st29 == KEAKI_ERR_OOM) { lazy_state = false; u29 = false; ctx->err.clear(); }
+    else if (st29 != KEAKI_OK) return st29;
+  }
   u32 *tiles = (u32*)ctx->digits.p, *sorted = (u32*)ctx->sorted.p, *hist = (u32*)ctx->hist.p;
   u32* segoff = (u32*)ctx->offsets.p;
   Xyzz<F>* buckets = (Xyzz<F>*)ctx->buckets.p;

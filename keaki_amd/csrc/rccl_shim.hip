@@ -18,8 +18,7 @@ struct keaki_hip_rccl {
   void* gathered = nullptr;      // world x 96 bytes: the partials of the sharded MSM
   void* partial = nullptr;       // 96 bytes
   void* d_status = nullptr;      // world + 1 int32: [this rank's status of the collective in flight | every rank's, gathered]
-  int32_t* h_status = nullptr;   // pinned: [0, world) the gathered ones (keaki_hip_rccl_collective_status) | [world, world + 8) this rank's word of the last eight calls (upload source)
-  uint32_t seq = 0;
+  int32_t* h_status = nullptr;   // pinned: [0, world) the gathered status words of the last collective MSM (keaki_hip_rccl_collective_status)
   std::mutex mu;
   std::string err;
 };
@@ -83,12 +82,12 @@ keaki_status keaki_hip_rccl_create(keaki_hip_ctx* ctx, const uint8_t id128[128],
   ncclResult_t r = ncclCommInitRank(&rc->comm, world, id, rank);
   if (r != ncclSuccess) { rfail(nullptr, KEAKI_ERR_RCCL, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, ncclGetErrorString(r)); delete rc; return KEAKI_ERR_RCCL; }
   if (hipMalloc(&rc->gathered, (size_t)world * 96) != hipSuccess || hipMalloc(&rc->partial, 96) != hipSuccess ||
-      hipMalloc(&rc->d_status, (size_t)(world + 1) * 4) != hipSuccess || hipHostMalloc((void**)&rc->h_status, (size_t)(world + 8) * 4) != hipSuccess) {
+      hipMalloc(&rc->d_status, (size_t)(world + 1) * 4) != hipSuccess || hipHostMalloc((void**)&rc->h_status, (size_t)world * 4) != hipSuccess) {
     rfail(nullptr, KEAKI_ERR_OOM, "rccl_create: hipMalloc failed");
     keaki_hip_rccl_destroy(rc);
     return KEAKI_ERR_OOM;
   }
-  memset(rc->h_status, 0, (size_t)(world + 8) * 4);      // collective_status before the first MSM: every rank fine
+  memset(rc->h_status, 0, (size_t)world * 4);      // collective_status before the first MSM: every rank fine
   *out = rc;
   return KEAKI_OK;
 }
@@ -149,13 +148,12 @@ keaki_status keaki_hip_rccl_msm_g1(keaki_hip_rccl* rc, const keaki_hip_srs_g1* s
     if (local != KEAKI_OK) rfail(rc, local, "rccl_msm_g1: %s", keaki_hip_last_error(rc->ctx));
   }
   if (local != KEAKI_OK && hipMemsetAsync(rc->partial, 0, 96, st_) != hipSuccess) local = KEAKI_ERR_HIP;   // the identity: the sum ignores it
-  // this rank's status word goes up from PINNED memory (a slot of its own per call in flight: eight deep), so nothing here waits for the
-  // stream -- the call stays asynchronous on the context's stream as the header says. A HIP failure of the two small copies is folded into
-  // `local` and the collectives are still enqueued: leaving before them would split the ranks.
-  int32_t* mine = rc->h_status + rc->world + (rc->seq++ & 7u);
-  *mine = (int32_t)local;
-  if (hipMemcpyAsync(rc->d_status, mine, 4, hipMemcpyHostToDevice, st_) != hipSuccess && local == KEAKI_OK)
-    local = rfail(rc, KEAKI_ERR_HIP, "rccl_msm_g1: status upload failed");
+  // this rank's status word is written by a 32-bit memset ON the stream: no host memory is read later, so nothing here waits for the stream (the call
+  // stays asynchronous, as the header says) and any number of calls may be in flight (until round 5 the word was copied up from a ring of eight
+  // pinned slots, which a ninth un-synchronised call would have overwritten before its copy ran). A HIP failure is folded into `local` and the
+  // collectives are still enqueued: leaving before them would split the ranks.
+  if (hipMemsetD32Async((hipDeviceptr_t)rc->d_status, (int)local, 1, st_) != hipSuccess && local == KEAKI_OK)
+    local = rfail(rc, KEAKI_ERR_HIP, "rccl_msm_g1: status write failed");
   // EC addition is not an RCCL reduction operator: all-gather the 96-byte partials, add them on every rank.
   // (A failing RCCL call itself cannot be repaired from here: the communicator is dead on every rank alike.)
   NCCL_TRY(rc, ncclAllGather(rc->partial, rc->gathered, 96, ncclUint8, rc->comm, st_));

@@ -24,7 +24,7 @@ def _mont(oc, ints):
 def piped(hip):
     """the session context with the chunking options under the test's control; automatic again afterwards"""
     yield hip
-    for k, v in (("msm_pipe_chunks", -1), ("msm_pipe_growth", 140), ("msm_pipe_min", 1 << 20), ("acc_u29", 1), ("acc_u29_g2", 1)):
+    for k, v in (("msm_pipe_chunks", -1), ("msm_pipe_growth", 140), ("msm_pipe_min", 1 << 20), ("acc_u29", 1), ("acc_u29_g2", 1), ("acc_idxq", 1)):
         hip.set_option(k, v)
 
 
@@ -422,3 +422,81 @@ def test_a_chunked_call_that_fails_leaves_the_context_usable(oc, rand_fr):
         srs.free()
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("nb,length", [(7, 3000), (64, 468), (15, 2000), (3, 8000), (1, 5000)])
+def test_index_groups_when_neighbouring_lanes_step_over_empty_segments(oc, piped, nb, length):
+    """Round 6: the G1 / G2 bucket kernels read their index stream by aligned 64-byte groups through a lane-private LDS slot (csrc/msm.hip.h segq_*).
+    The case that broke the first version: `nb` buckets own a stretch of nb x length entries, so in one chunk of their bin the other buckets' segments
+    are EMPTY -- lanes of one wave leave the walker's segment loop after different trip counts (hipcc took a lane mask from the loop's last trip
+    only; see segq_next). Every variant must give the oracle's point: groups on / off (acc_idxq), tables or none, resident and in chunks, G1 and G2."""
+    hip = piped
+    n = 1 << 17
+    g1, g2 = oc.generators()
+    rng = np.random.default_rng(1000 * nb + length)
+    k = rng.integers(0, 2**63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+    k[:, 3] &= np.uint64((1 << 60) - 1)
+    vals = rng.integers(300, 1000, n)
+    st = np.repeat(np.arange(2, 2 + nb), length)
+    rng.shuffle(st)
+    vals[n // 2: n // 2 + nb * length] = st
+    sc = oc.fr_to_mont(np.concatenate([vals[:, None].astype(np.uint64), np.zeros((n, 3), np.uint64)], 1))
+    dot = oc.fr_dot(sc, k).reshape(1, 4)
+    exp = oc.g1_mul_batch(g1, dot)[0]
+    pts = hip.g1_mul_batch(g1, k)
+    srs = hip.srs_g1_upload(pts)
+    try:
+        for tables in (False, True):
+            if tables:
+                hip.srs_g1_precompute(srs)
+            for idxq in (1, 0):
+                hip.set_option("acc_idxq", idxq)
+                for chunks in (0, 3):
+                    hip.set_option("msm_pipe_chunks", chunks)
+                    hip.set_option("msm_pipe_growth", 100)
+                    assert np.array_equal(_aff(hip.msm_g1(srs, sc)), exp), (tables, idxq, chunks)
+    finally:
+        srs.free()
+    m = 1 << 14                                            # G2: the same shape on a smaller instance (the oracle forms the expected point by one scalar-mult)
+    cut = max(1, length * m // n)
+    vals2 = rng.integers(300, 1000, m)
+    st2 = np.repeat(np.arange(2, 2 + nb), cut)
+    rng.shuffle(st2)
+    vals2[m // 2: m // 2 + nb * cut] = st2
+    sc2 = oc.fr_to_mont(np.concatenate([vals2[:, None].astype(np.uint64), np.zeros((m, 3), np.uint64)], 1))
+    pts2 = hip.g2_mul_batch(g2, k[:m])
+    exp2 = oc.g2_mul_batch(g2, oc.fr_dot(sc2, k[:m]).reshape(1, 4))[0]
+    srs2 = hip.srs_g2_upload(pts2)
+    try:
+        for chunks in (0, 3):
+            hip.set_option("msm_pipe_chunks", chunks)
+            assert np.array_equal(_aff(hip.msm_g2(srs2, sc2)), exp2), chunks
+    finally:
+        srs2.free()
+
+
+def test_chunked_call_without_room_for_the_parked_registers_falls_back(oc, rand_fr):
+    """the chunked G1 call parks the bucket kernel's registers between passes in a 144-B-per-bucket workspace (Acc29) -- optional memory.
+    When that one allocation fails (keaki_hip_debug_set_alloc_limit between the canonical buckets' 128 B and the 144 B per bucket) the passes go on
+    from the canonical bucket through the saturated kernel: same point as the oracle, no KEAKI_ERR_OOM; with the limit lifted the workspace appears."""
+    from keaki_amd.hip import KeakiHip
+    hip = KeakiHip(0)                                      # a context of its own: its workspaces start empty
+    try:
+        n = 70001
+        pts, s = _edge_instance(oc, hip, rand_fr, n, 424242)
+        exp = oc.msm_g1(pts, s, threads=os.cpu_count() or 1)
+        srs = hip.srs_g1_upload(pts)
+        hip.srs_g1_precompute(srs)
+        hip.set_option("msm_pipe_chunks", 0)
+        assert np.array_equal(_aff(hip.msm_g1(srs, s)), exp)
+        nb = 1 << (hip.last_msm_stats()["window_bits"] - 1)             # shared buckets of the table path
+        hip.set_option("msm_pipe_chunks", 3)
+        hip.debug_set_alloc_limit(nb * 136)
+        assert np.array_equal(_aff(hip.msm_g1(srs, s)), exp), "fallback to the canonical-state passes"
+        held = hip.memory()["workspaces"]
+        hip.debug_set_alloc_limit(0)
+        assert np.array_equal(_aff(hip.msm_g1(srs, s)), exp)
+        assert hip.memory()["workspaces"] - held >= nb * 144, "with room, the parked-register workspace is taken"
+        srs.free()
+    finally:
+        hip.close()
