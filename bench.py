@@ -110,16 +110,33 @@ def stream_cycles_from_ubench(waves=3):
 
 def power_limited_valu_rate(waves):
     """VALU wave-instructions per second and SIMD of the pure product stream (u29_mul: 205 instructions, 162 v_mad_u64_u32) at `waves` waves per
-    SIMD, from the committed clock micro-benchmark (bench_tools/ubench_clock.hip -> profiles/r05_ubench_clock.txt): wall clock, so the power-dependent
+    SIMD, from the committed clock micro-benchmark (bench_tools/ubench_clock.hip -> profiles/r06_ubench_clock.txt): wall clock, so the power-dependent
     shader clock (1.86-2.35 GHz while these kernels run, 2.4 idle) is inside it -- this rate, not a cycle count at the peak clock, is what the arithmetic can reach"""
     try:
-        for line in open(os.path.join(ROOT, "profiles", "r05_ubench_clock.txt")):
+        for line in open(os.path.join(ROOT, "profiles", "r06_ubench_clock.txt")):
             m = re.match(r"u29_mul chain \(205 instr, 162 mads\)\s+waves/SIMD=%d\s+launch\s+([0-9.]+) ms" % waves, line)
             if m:
                 return waves * 60000 * 205 / (float(m.group(1)) * 1e-3)
     except OSError:
         pass
     return None
+
+
+def yardstick_valu_rate(label, waves):
+    """VALU wave-instructions per second and SIMD of a synthetic stream of profiles/r06_ubench_clock.txt (bench_tools/ubench_clock.hip; wall clock, so the
+    power-dependent shader clock is inside it) at `waves` waves per SIMD: `label` = "XYZZ mixed addition" (the bucket kernel's own arithmetic -- 8M + 2S, one
+    dual product, the differences and carry passes -- without any memory access) or "pairing mix" (60 % v_mad_u64_u32, k_pairing's share). A line reads
+    `<label> (<N> VALU, ...)  waves/SIMD=<w>  launch <ms> ms ...  <ns> ns per wave-unit and SIMD`; several runs -> the fastest (the ceiling)."""
+    best = None
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "r06_ubench_clock.txt")):
+            m = re.match(r"%s \((\d+) VALU.*?waves/SIMD=%d\s.*?([0-9.]+) ns per wave-unit and SIMD" % (re.escape(label), waves), line)
+            if m:
+                rate = float(m.group(1)) / (float(m.group(2)) * 1e-9)
+                best = rate if best is None else max(best, rate)
+    except OSError:
+        pass
+    return best
 
 
 def stamped_profile(name, files):
@@ -534,11 +551,17 @@ def main():
                 model = f_mad * rates["v_mad_u64_u32"] + (1.0 - f_mad) * rates["v_and_b32"]
                 kem["alu"] = {"bound": "integer issue", "kernel": "k_pairing (decaps_per_s / pairings_per_s)", "valu_wave_instructions_per_pairing": valu_per_wave / 32.0,
                               "valu_per_wave_of_32_pairings": valu_per_wave, "waves_per_simd": 2, "simd_cycles_per_valu_instruction_measured": cyc,
-                              "simd_cycles_per_valu_instruction_at_issue_rate": model, "frac": model / cyc, "v_mad_u64_u32_share": f_mad,
+                              "simd_cycles_per_valu_instruction_at_issue_rate": model, "frac_vs_issue_model_at_2p4ghz": model / cyc, "v_mad_u64_u32_share": f_mad,
+                              "frac": (waves * valu_per_wave / (dec_ms * 1e-3) / 1024.0 / yardstick_valu_rate("pairing mix", 2)) if yardstick_valu_rate("pairing mix", 2) else None,
+                              "frac_note": "= frac_of_power_limited_rate: against a measured ceiling (the synthetic stream of the kernel's own mix, wall clock). "
+                                           "frac_vs_issue_model_at_2p4ghz (rounds 2-5's `frac`: a cycle model at the nominal clock) can exceed one and is kept for continuity only",
                               "issue_cycles_at_two_waves": rates,
                               "valu_wave_instructions_per_s_per_simd": waves * valu_per_wave / (dec_ms * 1e-3) / 1024.0,
-                              "power_limited_stream_rate_per_simd": power_limited_valu_rate(2),
-                              "frac_of_power_limited_rate": (waves * valu_per_wave / (dec_ms * 1e-3) / 1024.0 / power_limited_valu_rate(2)) if power_limited_valu_rate(2) else None,
+                              "power_limited_stream_rate_per_simd": yardstick_valu_rate("pairing mix", 2),
+                              "frac_of_power_limited_rate": (waves * valu_per_wave / (dec_ms * 1e-3) / 1024.0 / yardstick_valu_rate("pairing mix", 2)) if yardstick_valu_rate("pairing mix", 2) else None,
+                              "power_limited_stream": "a synthetic stream with k_pairing's own mix (270 VALU instructions per unit, 162 of them v_mad_u64_u32 = 60 %) at two waves per "
+                                                      "SIMD, wall clock (bench_tools/ubench_clock.hip -> profiles/r06_ubench_clock.txt): a ceiling for this mix -- until round 5 the yardstick "
+                                                      "was the pure product stream (76 % multiply-adds), which clocks lower than the kernel and put this fraction above one",
                               "sources": ["profiles/r05_pairing_pmc_sq_insts.json", "profiles/r05_pairing_isa.json", "profiles/r01_ubench_u29_gfx950.txt"],
                               "note": "dec_ms includes the KDF kernel (k_blake3_gt_xof, < 1 %); frac = how close the launch runs to the issue rate of its own "
                                       "instruction mix at the two waves per SIMD its 255 registers allow -- a schedule diagnostic, not a claim that the stream is minimal"}
@@ -599,7 +622,8 @@ def main():
             elif pj.get("fk_one_call", {}).get("log2d") != lg:
                 fk_traffic_note = "committed PMC figure is for another domain size"
             else:
-                fk_traffic = pj["fk_one_call"]["fetch_bytes"] + pj["fk_one_call"]["write_bytes"]
+                # the r05 file holds the raw FETCH_SIZE counter: x 2 = bytes moved (every fabric request is a 128-byte line: profiles/r06_fetch_size_calibration.txt)
+                fk_traffic = 2.0 * pj["fk_one_call"]["fetch_bytes"] + pj["fk_one_call"]["write_bytes"]
                 ipw = pj.get("fk_instructions_per_wave", {})
                 pick = lambda tag: next((round(v["insts_valu"]) for k, v in ipw.items() if tag in k), None)
                 # averages over the launches of each kernel (the first stages' twiddles are short scalars: their ladders are cheaper)
@@ -623,7 +647,7 @@ def main():
         except (OSError, ValueError, KeyError) as e:
             fk_traffic_note = "no committed PMC figure (%s)" % type(e).__name__
         fk["roofline"]["traffic"] = fk_traffic
-        fk["roofline"]["traffic_note"] = fk_traffic_note or ("FETCH_SIZE + WRITE_SIZE of ONE call, all FK23 kernels: the per-lane window tables of the ladders (1 KB written, "
+        fk["roofline"]["traffic_note"] = fk_traffic_note or ("FETCH_SIZE x 2 + WRITE_SIZE of ONE call (bytes moved over the fabric; counters of profiles/r05_fk_pairing_hbm_traffic_pmc.json, kernels unchanged since), all FK23 kernels: the per-lane window tables of the ladders (1 KB written, "
                                                              "43..66 x 128 B read per scalar-mult) and the 96-byte points, not the algorithmic 96 B per opening")
         fk_check = (fsrs, coeffs, proofs, om)
     # ---- Laconic OT (BASELINE config 5): the three phases the reference's test prints (tests/laconic_ot.rs:143-188) at 2^--laconic-log2n
@@ -692,7 +716,7 @@ def main():
     # HBM traffic of the dominant kernel from PMC counters (separate rocprofv3 --pmc passes, committed under profiles/, stamped with
     # the kernel sources they were measured on)
     traffic, traffic_note = None, None
-    tj, why = stamped_profile("r05_msm_2p24_hbm_traffic_pmc.json", MSM_KERNEL_SOURCES)
+    tj, why = stamped_profile("r06_msm_2p24_hbm_traffic_pmc.json", MSM_KERNEL_SOURCES)
     if tj is None:
         traffic_note = why
     elif tj.get("log2n") != args.log2n or bool(tj.get("precompute", True)) != (not args.no_precompute):
@@ -702,18 +726,18 @@ def main():
             if "k_msm_accumulate" in kname:
                 traffic = kv["fetch_bytes"] + kv["write_bytes"]
     # integer roofline: one XYZZ mixed add = 8M + 2S = 10 Montgomery products; instruction count of the loop body from the shipped
-    # ISA (bench_tools/count_isa.py -> profiles/r05_accumulate_isa.json), issue rate from the committed micro-benchmark
+    # ISA (bench_tools/count_isa.py -> profiles/r06_accumulate_isa.json), issue rate from the committed micro-benchmark
     alu = None
-    isa, isa_why = stamped_profile("r05_accumulate_isa.json", MSM_KERNEL_SOURCES)
+    isa, isa_why = stamped_profile("r06_accumulate_isa.json", MSM_KERNEL_SOURCES)
     mul_cyc, simple_cyc, cyc_src = stream_cycles_from_ubench(3)
     if isa is not None and mul_cyc is not None and simple_cyc is not None:
         ipa, mads = float(isa.get("loop_valu", isa["loop_instructions"])), float(isa["loop_v_mad_u64_u32"])
         ipa_src = "static: VALU instructions on the common path of the loop in the emitted ISA"
         # the DYNAMIC count where a counter pass of this build is committed: SQ_INSTS_VALU of one launch / the wave-additions it performs
-        sq, _ = stamped_profile("r05_msm_sq_insts.json", MSM_KERNEL_SOURCES)
+        sq, _ = stamped_profile("r06_msm_sq_insts.json", MSM_KERNEL_SOURCES)
         if sq is not None and sq.get("log2n") == args.log2n and bool(sq.get("precompute", True)) == (not args.no_precompute) and sq.get("accumulate_valu"):
             ipa = float(sq["accumulate_valu"]) / (n * windows / 64.0)
-            ipa_src = "dynamic: SQ_INSTS_VALU of one launch / (n x windows / 64) wave-additions (profiles/r05_msm_sq_insts.json)"
+            ipa_src = "dynamic: SQ_INSTS_VALU of one launch / (n x windows / 64) wave-additions (profiles/r06_msm_sq_insts.json)"
         # model: every 162 multiply-adds are one product stream of 205 instructions at its measured rate, what is left of the loop body runs
         # at the rate of a plain 32-bit VALU instruction
         model_cycles = mads / 162.0 * mul_cyc + max(0.0, ipa - mads / 162.0 * 205.0) * simple_cyc
@@ -721,12 +745,20 @@ def main():
         measured_cycles = avg_bucket_s * 2.4e9 / wave_adds_per_simd
         modmuls = 10.0 * n * windows / avg_bucket_s
         alu = {"bound": "integer issue (v_mad_u64_u32 streams)", "achieved": modmuls / 1e9, "peak": modmuls / 1e9 * measured_cycles / model_cycles, "unit": "G modmul/s",
-               "frac": model_cycles / measured_cycles, "simd_cycles_per_mixed_add_measured": measured_cycles, "simd_cycles_per_mixed_add_at_stream_rate": model_cycles,
+               "frac": (ipa * (n * windows / 64.0) / avg_bucket_s / 1024.0 / yardstick_valu_rate("XYZZ mixed addition", 3)) if yardstick_valu_rate("XYZZ mixed addition", 3) else None,
+               "frac_vs_issue_model_at_2p4ghz": model_cycles / measured_cycles, "simd_cycles_per_mixed_add_measured": measured_cycles, "simd_cycles_per_mixed_add_at_stream_rate": model_cycles,
                "issues_per_mixed_add": ipa, "issues_per_mixed_add_source": ipa_src, "v_mad_u64_u32_per_mixed_add": mads, "product_stream_cycles": mul_cyc, "plain_valu_cycles": simple_cyc,
                "valu_wave_instructions_per_s_per_simd": ipa * (n * windows / 64.0) / avg_bucket_s / 1024.0,
                "power_limited_stream_rate_per_simd": power_limited_valu_rate(3),
                "frac_of_power_limited_rate": (ipa * (n * windows / 64.0) / avg_bucket_s / 1024.0 / power_limited_valu_rate(3)) if power_limited_valu_rate(3) else None,
-               "sources": ["profiles/r05_accumulate_isa.json", cyc_src, "profiles/r05_ubench_clock.txt"],
+               "xyzz_addition_rate_per_simd": yardstick_valu_rate("XYZZ mixed addition", 3),
+               "frac_of_xyzz_addition_rate": (ipa * (n * windows / 64.0) / avg_bucket_s / 1024.0 / yardstick_valu_rate("XYZZ mixed addition", 3)) if yardstick_valu_rate("XYZZ mixed addition", 3) else None,
+               "frac_of_xyzz_addition_rate_note": "= `frac`, THE figure to read: VALU wave-instructions per second and SIMD of this launch against the kernel's own addition (same formulas, same "
+                                                  "streams, same three waves per SIMD) run WITHOUT any memory access on this chip (bench_tools/ubench_clock.hip). What is missing from 1 is "
+                                                  "shader clock that the gathers' traffic takes out of the package's power budget: HBM 7.4 %, fabric / Infinity Cache 5.3 %, L2 -> L1 1.4 % "
+                                                  "of the kernel at round 5's traffic (profiles/r06_bucket_clock_diagnosis.txt). `frac_vs_issue_model_at_2p4ghz` (rounds 2-5's `frac`) and `frac_of_power_limited_rate` compare with "
+                                                  "yardsticks that hide this (a nominal 2.4 GHz; the pure product stream, which itself clocks lower than this kernel's mix)",
+               "sources": ["profiles/r06_accumulate_isa.json", cyc_src, "profiles/r06_ubench_clock.txt"],
                "note": "a schedule diagnostic (how close the kernel runs to the issue rate of ITS OWN instruction stream at 3 waves per SIMD and "
                        "2.4 GHz), not a claim that the stream is minimal. Round 5 corrected the count: until then the loop body included the exact-zero test that "
                        "hangs off the filter (241 instructions, one product stream, taken 18 times in 2^29 additions), which put frac at 0.94-0.96; the common "
@@ -755,7 +787,11 @@ def main():
             "exchange_ms": exchange_ms},
         "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate_g1_u29", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_ratio": (traffic / (ALGO_BYTES_PER_SCALAR_MUL * n)) if traffic else None,
-                     "traffic_note": traffic_note,
+                     "traffic_note": traffic_note or ("bytes MOVED over the fabric by one launch = (FETCH_SIZE x 2) + WRITE_SIZE, separate rocprofv3 --pmc passes. Factor 2, calibrated on "
+                                                      "this kernel's own access shape (profiles/r06_fetch_size_calibration.txt): FETCH_SIZE = TCC_EA0_RDREQ x 64 B, but every request "
+                                                      "moves a whole 128-byte L2 line -- a 64-byte table row costs a line (1.0 request per row, half of it unwanted: structural for "
+                                                      "a bucket method, profiles/r06_bucket_clock_diagnosis.txt); 1.15 requests per row in all since the index stream goes through "
+                                                      "LDS in 64-byte groups (1.44 until round 5). Rounds 1-5 reported the raw counter (18.8 GB for what was 37.2 GB)"),
                      "algorithmic_bytes": ALGO_BYTES_PER_SCALAR_MUL * n, "kernel_ms": avg_bucket_s * 1e3, "kernel_ms_stat": "mean of %d launches (HIP events, untimed pass)" % len(bucket_ms),
                      "kernel_ms_min": float(np.min(bucket_ms)), "kernel_ms_median": float(np.median(bucket_ms)), "kernel_ms_max": float(np.max(bucket_ms)),
                      "msm_total_ms": stats["total_ms"]},

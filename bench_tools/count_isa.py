@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Instruction counts of the bucket kernel's loop body from the ISA hipcc emits for THIS tree (runs on the CPU box: hipcc cross-compiles).
 
-    python bench_tools/count_isa.py            # writes profiles/r05_accumulate_isa.json
+    python bench_tools/count_isa.py            # writes profiles/r06_accumulate_isa.json
     python bench_tools/count_isa.py --pairing  # writes profiles/r05_pairing_isa.json (static VALU mix of k_pairing and its out-of-line products)
 
 Compiles keaki_amd/csrc/msm_g1.hip to gfx950 assembly (the flags of the Makefile), cuts k_msm_accumulate_g1_u29 into basic blocks and
@@ -30,8 +30,8 @@ def main():
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", src, "-o", asm],
                               cwd=os.path.dirname(src), stderr=subprocess.DEVNULL)
         lines = open(asm).read().split("\n")
-    # the one-pass form <NT = 0, MODE = ACC_WHOLE, PF = 1> (the chunked host-pointer calls run <0, 1..3>: the same loop body, other prologue / epilogue)
-    start = [i for i, l in enumerate(lines) if re.match(r"^_ZN5bn254L\d+%sILi0ELi0ELi1E\w*:" % KERNEL, l)][0]
+    # the one-pass form <NT = 0, MODE = ACC_WHOLE, PF = 2> (the chunked host-pointer calls run <0, 1..3>: the same loop body, other prologue / epilogue)
+    start = [i for i, l in enumerate(lines) if re.match(r"^_ZN5bn254L\d+%sILi0ELi0ELi2E\w*:" % KERNEL, l)][0]
     end = [i for i, l in enumerate(lines) if i > start and l.startswith(".Lfunc_end")][0]
     # basic blocks: a label `.LBBn_m:` or the fall-through marker `; %bb.N:` starts one; the trailing comment says whether it lies in the loop
     blocks, cur = [], ["entry", [], False]
@@ -60,14 +60,14 @@ def main():
     best = sum(b["v_mad_u64_u32"] for b in common)
     meta = {}
     for l in lines:
-        m = re.match(r"\s*\.set\s+_ZN5bn254L\d+%sILi0ELi0ELi1E\w*\.(num_vgpr|num_agpr|numbered_sgpr|private_seg_size),\s*(\d+)" % KERNEL, l)
+        m = re.match(r"\s*\.set\s+_ZN5bn254L\d+%sILi0ELi0ELi2E\w*\.(num_vgpr|num_agpr|numbered_sgpr|private_seg_size),\s*(\d+)" % KERNEL, l)
         if m:
             meta[m.group(1)] = int(m.group(2))
     out = {"kernel": KERNEL, "kernel_source_sha256": source_hash(MSM_KERNEL_SOURCES), "compiler": "hipcc -O3 -std=c++17 --offload-arch=gfx950 (ROCm 7.2)",
            "loop_blocks": [b["block"] for b in common], "loop_instructions": loop_instructions, "loop_valu": sum(b["valu"] for b in common),
            "loop_v_mad_u64_u32": best, "loop_branches": sum(b["branches"] for b in common), "registers": meta, "blocks": table,
            "rule": "blocks inside the loop minus the rare ones (one-product blocks = exact zero tests, the two-product first-point block, the doubling path)"}
-    dst = os.path.join(ROOT, "profiles", "r05_accumulate_isa.json")
+    dst = os.path.join(ROOT, "profiles", "r06_accumulate_isa.json")
     json.dump(out, open(dst, "w"), indent=1)
     print("common path of one mixed addition: %d instructions (%d VALU, %d v_mad_u64_u32, %d branches) in %d blocks; registers %s -> %s"
           % (loop_instructions, out["loop_valu"], best, out["loop_branches"], len(common), meta, dst))

@@ -156,12 +156,12 @@ def test_host_scalar_field_and_domain(py):
 
 
 def test_committed_isa_counts_belong_to_this_tree():
-    """profiles/r05_accumulate_isa.json and r05_pairing_isa.json (bench.py's `alu` / `kem.alu` diagnostics read them) must have been made from
+    """profiles/r06_accumulate_isa.json and r05_pairing_isa.json (the pairing kernels did not change in round 6) (bench.py's `alu` / `kem.alu` diagnostics read them) must have been made from
     the kernel sources of this tree: re-run `python bench_tools/count_isa.py` (`--pairing`) after touching the MSM (pairing) kernels."""
     import json
     from bench_tools.srchash import source_hash, MSM_KERNEL_SOURCES
     from bench_tools.srchash import PAIRING_KERNEL_SOURCES
-    j = json.load(open(os.path.join(ROOT, "profiles", "r05_accumulate_isa.json")))
+    j = json.load(open(os.path.join(ROOT, "profiles", "r06_accumulate_isa.json")))
     assert j["kernel_source_sha256"] == source_hash(MSM_KERNEL_SOURCES), "stale: run python bench_tools/count_isa.py"
     pj = json.load(open(os.path.join(ROOT, "profiles", "r05_pairing_isa.json")))
     assert pj["kernel_source_sha256"] == source_hash(PAIRING_KERNEL_SOURCES), "stale: run python bench_tools/count_isa.py --pairing"
