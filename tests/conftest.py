@@ -99,7 +99,7 @@ def multirank_runs(request, tmp_path_factory):
     # by point range, 2^21 encapsulations and 2^20 decapsulations by item range; rank 0 re-runs the un-sharded calls and compares bytes)
     rc, log = _run(launch + ["--nproc-per-node", "8", "--master-port", str(port + 9), "bench.py", "--gpus", "8", "--backend", "gloo", "--log2n", "20",
                              "--kem-log2n", "10", "--steps", "2", "--warmup", "1", "--cpu-log2n", "14", "--strong-log2n", "26",
-                             "--fk-log2d", "0", "--laconic-log2n", "0"], 1500)
+                             "--fk-log2d", "0", "--laconic-log2n", "10"], 1500)
     out["bench8"] = {"rc": rc, "log": log}
     rc, log = _run(launch + ["--nproc-per-node", "8", "--master-port", str(port + 10), "laconic_ot.py", "--gpus", "8", "--backend", "gloo", "--log2n", "20",
                              "--check-single"], 1500)

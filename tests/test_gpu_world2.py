@@ -157,6 +157,8 @@ def test_eight_ranks_config4_and_config5_at_full_size(multirank_runs):
     assert j["checks"]["full_size_check"] is True and j["checks"]["sample_bit_exact"] is True
     st = j["strong"]
     assert st["total_points"] == 1 << 26 and st["points_per_gpu"] == 1 << 23 and st["ranks_seen"] == 8 and st["full_size_check"] is True
+    lo = j["laconic"]                                      # the bench line's own Laconic OT block, sharded over the eight ranks (small here; full size below)
+    assert lo["n_gpus"] == 8 and lo["ranks_seen"] == 8 and lo["fk_sharded"] is True and lo["all_messages_recovered"] is True and lo["n_choices"] == 1 << 10
     run = multirank_runs["laconic8"]
     assert run["rc"] == 0, run["log"][-3000:]
     j = _json_line(run["log"])
