@@ -304,6 +304,27 @@ def main():
     stats = hip.last_msm_stats()
     hip.set_timing(False)
     checks = {}
+    # An exception inside an OPTIONAL block (not a parity mismatch: those are `checks`) must not cost the line its headline: the block reports
+    # {"error": ...}, the line lists it under `blocks_failed`, everything else goes on. Rank-0-only blocks hold no collective; the `laconic` block
+    # runs on every rank, where an exception every rank raises alike (an unsupported call) is survived -- a one-sided one still ends in the
+    # launcher's timeout, as any desynchronised collective does.
+    block_errors = {}
+    g2_check = fk_check = None
+
+    class Guard:
+        def __init__(self, name):
+            self.name = name
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, et, ev, tb):
+            if et is None or not issubclass(et, Exception):
+                return False
+            import traceback
+            traceback.print_exception(et, ev, tb, file=sys.stderr)
+            block_errors[self.name] = "%s: %s" % (et.__name__, ev)
+            return True
 
     # ---- extras (each outside the contract's timed region) ------------------------------------------------------------------------
     extras = {}
@@ -371,57 +392,61 @@ def main():
     # ---- G2 MSM (north_star: "Pippenger variable-base MSM over BN254 G1/G2"; keaki itself only forms [tau]_2 and ciphertexts on G2) -------------
     msm_g2 = None
     if not args.no_extras and args.g2_log2n > 0 and rank == 0:
-        n2 = 1 << min(args.g2_log2n, args.log2n)
-        g2_words = []
-        for c in G2_GEN:
-            g2_words += mont_words(c)
-        d_g2gen = torch.from_numpy(np.array(g2_words, np.uint64).view(np.int64)).to(dev)
-        d_k2 = torch.from_numpy(inst.k_host[:n2].view(np.int64).copy()).to(dev)
-        d_pts2 = torch.empty((n2, 16), dtype=torch.int64, device=dev)
-        torch.cuda.synchronize(dev)
-        hip.g2_mul_batch_dev(d_g2gen.data_ptr(), 0, d_k2.data_ptr(), n2, d_pts2.data_ptr())      # Q_i = k_i g2: valid r-torsion points
-        hip.synchronize()
-        del d_k2
-        srs2 = hip.srs_g2_wrap_dev(d_pts2.data_ptr(), n2)
-        d_out2 = torch.zeros(24, dtype=torch.int64, device=dev)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with Guard('msm_g2'):
+            n2 = 1 << min(args.g2_log2n, args.log2n)
+            g2_words = []
+            for c in G2_GEN:
+                g2_words += mont_words(c)
+            d_g2gen = torch.from_numpy(np.array(g2_words, np.uint64).view(np.int64)).to(dev)
+            d_k2 = torch.from_numpy(inst.k_host[:n2].view(np.int64).copy()).to(dev)
+            d_pts2 = torch.empty((n2, 16), dtype=torch.int64, device=dev)
+            torch.cuda.synchronize(dev)
+            hip.g2_mul_batch_dev(d_g2gen.data_ptr(), 0, d_k2.data_ptr(), n2, d_pts2.data_ptr())      # Q_i = k_i g2: valid r-torsion points
+            hip.synchronize()
+            del d_k2
+            srs2 = hip.srs_g2_wrap_dev(d_pts2.data_ptr(), n2)
+            d_out2 = torch.zeros(24, dtype=torch.int64, device=dev)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-        def g2_rate(reps=3):
+            def g2_rate(reps=3):
+                hip.msm_g2_dev(srs2, inst.d_s[0].data_ptr(), n2, d_out2.data_ptr())
+                sync_all_local()
+                ev0.record(stream)
+                for i in range(reps):
+                    hip.msm_g2_dev(srs2, inst.d_s[i & 1].data_ptr(), n2, d_out2.data_ptr())
+                ev1.record(stream)
+                sync_all_local()
+                return ev0.elapsed_time(ev1) / reps
+            sync_all_local = lambda: torch.cuda.synchronize(dev)
+            ms_gen = g2_rate()
             hip.msm_g2_dev(srs2, inst.d_s[0].data_ptr(), n2, d_out2.data_ptr())
             sync_all_local()
-            ev0.record(stream)
-            for i in range(reps):
-                hip.msm_g2_dev(srs2, inst.d_s[i & 1].data_ptr(), n2, d_out2.data_ptr())
-            ev1.record(stream)
+            r_gen = d_out2.cpu().numpy().view(np.uint64).copy()
+            t0 = time.perf_counter()
+            g2_table_bytes = hip.srs_g2_precompute(srs2)
+            g2_setup_s = time.perf_counter() - t0
+            ms_tab = g2_rate()
+            hip.msm_g2_dev(srs2, inst.d_s[0].data_ptr(), n2, d_out2.data_ptr())
             sync_all_local()
-            return ev0.elapsed_time(ev1) / reps
-        sync_all_local = lambda: torch.cuda.synchronize(dev)
-        ms_gen = g2_rate()
-        hip.msm_g2_dev(srs2, inst.d_s[0].data_ptr(), n2, d_out2.data_ptr())
-        sync_all_local()
-        r_gen = d_out2.cpu().numpy().view(np.uint64).copy()
-        t0 = time.perf_counter()
-        g2_table_bytes = hip.srs_g2_precompute(srs2)
-        g2_setup_s = time.perf_counter() - t0
-        ms_tab = g2_rate()
-        hip.msm_g2_dev(srs2, inst.d_s[0].data_ptr(), n2, d_out2.data_ptr())
-        sync_all_local()
-        r_tab = d_out2.cpu().numpy().view(np.uint64).copy()
-        t0 = time.perf_counter()
-        r_host = hip.msm_g2(srs2, inst.s_host[0][:n2])
-        host_ms = (time.perf_counter() - t0) * 1e3
-        checks["msm_g2.tables_equals_no_tables_equals_host_pointer"] = bool(np.array_equal(r_gen, r_tab) and np.array_equal(r_host, r_tab))
-        ALGO_G2 = 160                                               # 32 B scalar + 128 B affine point
-        msm_g2 = {"workload": "2^%d-point BN254 G2 Pippenger MSM, points k_i g2 generated on the device, scalars resident (the first 2^%d of the G1 vectors)" % (int(np.log2(n2)), int(np.log2(n2))),
-                  "points": n2, "value": n2 / (ms_tab * 1e-3), "value_no_tables": n2 / (ms_gen * 1e-3), "unit": "scalar-mults/s",
-                  "ms_per_msm": ms_tab, "ms_per_msm_no_tables": ms_gen, "host_pointer_call_ms": host_ms, "window_tables_bytes": g2_table_bytes,
-                  "window_tables_setup_s": round(g2_setup_s, 3),
-                  "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate_g2_u29 (whole MSM timed, stream events)", "algorithmic_bytes": ALGO_G2 * n2,
-                               "achieved": ALGO_G2 * n2 / (ms_tab * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ALGO_G2 * n2 / (ms_tab * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "note": "integer-issue bound: ~5,600 instructions per mixed addition in Fq2 (4,700 v_mad_u64_u32), one wave per SIMD at 256 VGPRs"}}
-        g2_check = (r_tab, n2)
-        srs2.free()
-        del d_pts2
+            r_tab = d_out2.cpu().numpy().view(np.uint64).copy()
+            t0 = time.perf_counter()
+            r_host = hip.msm_g2(srs2, inst.s_host[0][:n2])
+            host_ms = (time.perf_counter() - t0) * 1e3
+            checks["msm_g2.tables_equals_no_tables_equals_host_pointer"] = bool(np.array_equal(r_gen, r_tab) and np.array_equal(r_host, r_tab))
+            ALGO_G2 = 160                                               # 32 B scalar + 128 B affine point
+            msm_g2 = {"workload": "2^%d-point BN254 G2 Pippenger MSM, points k_i g2 generated on the device, scalars resident (the first 2^%d of the G1 vectors)" % (int(np.log2(n2)), int(np.log2(n2))),
+                      "points": n2, "value": n2 / (ms_tab * 1e-3), "value_no_tables": n2 / (ms_gen * 1e-3), "unit": "scalar-mults/s",
+                      "ms_per_msm": ms_tab, "ms_per_msm_no_tables": ms_gen, "host_pointer_call_ms": host_ms, "window_tables_bytes": g2_table_bytes,
+                      "window_tables_setup_s": round(g2_setup_s, 3),
+                      "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate_g2_u29 (whole MSM timed, stream events)", "algorithmic_bytes": ALGO_G2 * n2,
+                                   "achieved": ALGO_G2 * n2 / (ms_tab * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ALGO_G2 * n2 / (ms_tab * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "note": "integer-issue bound: ~5,600 instructions per mixed addition in Fq2 (4,700 v_mad_u64_u32), one wave per SIMD at 256 VGPRs"}}
+            g2_check = (r_tab, n2)
+            srs2.free()
+            del d_pts2
+    if 'msm_g2' in block_errors:
+        msm_g2 = {"error": block_errors['msm_g2']}
+        g2_check = None
 
     # ---- BASELINE config 4: 2^26 points in TOTAL, split over the ranks (strong scaling) ----------------------------------------------
     strong = None
@@ -571,126 +596,137 @@ def main():
     # ---- FK23 batch openings (kzg::open_fk, src/kzg.rs:157-203): the kernel family that dominates Receiver::new of BASELINE config 5 ----
     fk = None
     if not args.no_extras and args.fk_log2d > 0 and (1 << args.fk_log2d) <= n and rank == 0:
-        import ctypes as C
-        lg = args.fk_log2d
-        d = 1 << lg
-        w2d = pow(5, (R_MOD - 1) >> (lg + 1), R_MOD)                       # ark-poly's group_gen of Radix2EvaluationDomain::new(2d): GENERATOR = 5
-        assert pow(w2d, d, R_MOD) == R_MOD - 1
-        mont_fr = lambda v: np.frombuffer(((v << 256) % R_MOD).to_bytes(32, "little"), np.uint64).copy()
-        om, omi, inv2d = mont_fr(w2d), mont_fr(pow(w2d, -1, R_MOD)), mont_fr(pow(2 * d, -1, R_MOD))
-        fsrs = hip.srs_g1_wrap_dev(inst.d_pts.data_ptr(), d)               # the first d points of this rank's SRS
-        coeffs = random_fr_limbs(d, SEED + 4242)
-        proofs = np.zeros((d, 8), np.uint64)
-        t0 = time.perf_counter()
-        hip._ck(hip.lib.keaki_hip_srs_g1_precompute_fk(hip.ctx, fsrs.handle, lg, om.ctypes.data_as(C.c_void_p)))   # hat_s: setup, like the window tables
-        fk_setup_s = time.perf_counter() - t0
-        hip.set_timing(True)
-        call_s, st_ms = [], []
-        for it in range(3):
+        with Guard('fk'):
+            import ctypes as C
+            lg = args.fk_log2d
+            d = 1 << lg
+            w2d = pow(5, (R_MOD - 1) >> (lg + 1), R_MOD)                       # ark-poly's group_gen of Radix2EvaluationDomain::new(2d): GENERATOR = 5
+            assert pow(w2d, d, R_MOD) == R_MOD - 1
+            mont_fr = lambda v: np.frombuffer(((v << 256) % R_MOD).to_bytes(32, "little"), np.uint64).copy()
+            om, omi, inv2d = mont_fr(w2d), mont_fr(pow(w2d, -1, R_MOD)), mont_fr(pow(2 * d, -1, R_MOD))
+            fsrs = hip.srs_g1_wrap_dev(inst.d_pts.data_ptr(), d)               # the first d points of this rank's SRS
+            coeffs = random_fr_limbs(d, SEED + 4242)
+            proofs = np.zeros((d, 8), np.uint64)
             t0 = time.perf_counter()
-            proofs = hip.open_fk_poly(fsrs, lg, coeffs, om, omi, inv2d)
-            call_s.append(time.perf_counter() - t0)
-            st_ms.append(hip.last_fk_stats())
-        hip.set_timing(False)
-        best = int(np.argmin(call_s))
-        stages_ms = st_ms[best]["stages_ms"]
-        fk_algo = d * (32 + 64)                                            # d coefficients in, d affine proofs out (checked against the oracle below)
-        # integer-issue diagnostic: butterflies = d * log2(d) (two size-d transforms of d/2 * log2 d each) + 2d pointwise + d twist scalar-mults,
-        # one scalar-mult ~ 129 doublings + 43..66 additions in the 29-bit ladder
-        fk = {"workload": "FK23 openings (kzg::open_fk) of a degree-(2^%d - 1) polynomial at the 2^%d roots of unity, hat_s cached per SRS" % (lg, lg),
-              "n_gpus": 1, "proofs_per_s": d / call_s[best], "call_ms": call_s[best] * 1e3, "call_ms_all": [round(x * 1e3, 2) for x in call_s],
-              "call_note": "keaki_hip_open_fk_poly: coefficients from host memory in (%d MiB), affine proofs to host memory out (%d MiB)" % (d * 32 >> 20, d * 64 >> 20),
-              "device_ms": st_ms[best]["device_ms"], "pointwise_ms": st_ms[best]["pointwise_ms"], "setup_hat_s_s": round(fk_setup_s, 3),
-              "scalar_mults": d * lg + 3 * d,
-              "roofline": {"bound": "hbm", "kernel": "k_g1_fft_stage_map / k_g1_fft_stage4 (the 2 x %d butterfly stages: one butterfly = one 254-bit scalar-mult + add + sub; from span 16 on two stages per radix-4 pass)" % lg,
-                           "algorithmic_bytes": fk_algo, "kernel_ms": stages_ms, "kernel_ms_stat": "all butterfly stages of one call, HIP events on the ctx stream",
-                           "achieved": fk_algo / (stages_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fk_algo / (stages_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "note": "integer-issue bound like every kernel of the path: d log2 d butterfly scalar-mults of ~129 doublings + 43..66 mixed additions each"},
-              "alu": {"scalar_mults_per_s_in_stages": d * lg / (stages_ms * 1e-3), "simd_cycles_per_butterfly": stages_ms * 1e-3 * 2.4e9 / (d * lg / 64.0 / 1024.0),
-                      "note": "SIMD cycles one wave (64 butterflies) spends per butterfly stage step = scalar-mult + add + sub, at 2.4 GHz on 1024 SIMDs. The ladder: "
-                              "129 doublings + 43 mixed additions (one twiddle per wave: sliding windows) or 66 (a twiddle per lane: fixed windows) on an "
-                              "effective-affine window table; valu_per_wave = SQ_INSTS_VALU / SQ_WAVES of the stage kernels from the committed counter "
-                              "pass (DESIGN 4.2b, 7.3)"}}
-        # fabric traffic of one call from the committed counter passes (bench_tools/collect_pmc_fk_pairing.sh), when they were made on this build
-        fk_traffic, fk_traffic_note = None, None
-        try:
-            from bench_tools.srchash import library_hashes
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r05_fk_pairing_hbm_traffic_pmc.json")))
-            hip.lib.keaki_hip_version.restype = C.c_char_p
-            if pj.get("hashes", {}).get("fk") != library_hashes(hip.lib.keaki_hip_version().decode()).get("fk"):
-                fk_traffic_note = "profiles/r05_fk_pairing_hbm_traffic_pmc.json was measured on other FK23 kernel sources: refused"
-            elif pj.get("fk_one_call", {}).get("log2d") != lg:
-                fk_traffic_note = "committed PMC figure is for another domain size"
-            else:
-                # the r05 file holds the raw FETCH_SIZE counter: x 2 = bytes moved (every fabric request is a 128-byte line: profiles/r06_fetch_size_calibration.txt)
-                fk_traffic = 2.0 * pj["fk_one_call"]["fetch_bytes"] + pj["fk_one_call"]["write_bytes"]
-                ipw = pj.get("fk_instructions_per_wave", {})
-                pick = lambda tag: next((round(v["insts_valu"]) for k, v in ipw.items() if tag in k), None)
-                # averages over the launches of each kernel (the first stages' twiddles are short scalars: their ladders are cheaper)
-                fk["alu"]["valu_per_wave"] = {"radix4_pass_per_group_of_four_points": pick("fft_stage4<true"),
-                                              "radix2_one_twiddle_per_wave_per_butterfly": pick("stage_map<true, true, false"),
-                                              "radix2_twiddle_per_lane_per_butterfly": pick("stage_map<true, false, true")}
-                # cycles per issued VALU instruction of the stage kernels: the wave-instructions of one call (counter pass) over the SIMD-cycles of
-                # the stages (events of this run), against the plain / multiply-add issue rates at the stage kernels' occupancy (2 waves per SIMD)
-                sj = json.load(open(os.path.join(ROOT, "profiles", "r05_fk_sq_insts.json")))
-                tot_valu = sj.get("stage_kernels_valu_wave_instructions_one_call") if sj.get("hashes", {}).get("fk") == pj["hashes"]["fk"] and sj.get("log2d") == lg else None
-                if tot_valu:
-                    cyc = stages_ms * 1e-3 * 2.4e9 * 1024.0 / float(tot_valu)
-                    f_mad = 0.6                                  # share of v_mad_u64_u32 in the 29-bit product streams the ladders are made of (205-instruction product: 162)
-                    fk["alu"].update({"valu_wave_instructions_per_s_per_simd": float(tot_valu) / (stages_ms * 1e-3) / 1024.0,
-                                      "power_limited_stream_rate_per_simd": power_limited_valu_rate(3),
-                                      "frac_of_power_limited_rate": (float(tot_valu) / (stages_ms * 1e-3) / 1024.0 / power_limited_valu_rate(3)) if power_limited_valu_rate(3) else None,
-                                      "stage_valu_wave_instructions_per_call": float(tot_valu), "simd_cycles_per_valu_instruction_measured": cyc,
-                                      "simd_cycles_per_valu_instruction_at_issue_rate": f_mad * 4.8 + (1 - f_mad) * 4.1, "frac": (f_mad * 4.8 + (1 - f_mad) * 4.1) / cyc,
-                                      "frac_note": "SIMD-cycles of the butterfly stages of this run / VALU wave-instructions of the stage kernels in one call (profiles/r05_fk_sq_insts.json), "
-                                                   "against the issue rates of profiles/r01_ubench_u29_gfx950.txt at two waves per SIMD (4.8 multiply-add, 4.1 plain)"})
-        except (OSError, ValueError, KeyError) as e:
-            fk_traffic_note = "no committed PMC figure (%s)" % type(e).__name__
-        fk["roofline"]["traffic"] = fk_traffic
-        fk["roofline"]["traffic_note"] = fk_traffic_note or ("FETCH_SIZE x 2 + WRITE_SIZE of ONE call (bytes moved over the fabric; counters of profiles/r05_fk_pairing_hbm_traffic_pmc.json, kernels unchanged since), all FK23 kernels: the per-lane window tables of the ladders (1 KB written, "
-                                                             "43..66 x 128 B read per scalar-mult) and the 96-byte points, not the algorithmic 96 B per opening")
-        fk_check = (fsrs, coeffs, proofs, om)
+            hip._ck(hip.lib.keaki_hip_srs_g1_precompute_fk(hip.ctx, fsrs.handle, lg, om.ctypes.data_as(C.c_void_p)))   # hat_s: setup, like the window tables
+            fk_setup_s = time.perf_counter() - t0
+            hip.set_timing(True)
+            call_s, st_ms = [], []
+            for it in range(3):
+                t0 = time.perf_counter()
+                proofs = hip.open_fk_poly(fsrs, lg, coeffs, om, omi, inv2d)
+                call_s.append(time.perf_counter() - t0)
+                st_ms.append(hip.last_fk_stats())
+            hip.set_timing(False)
+            best = int(np.argmin(call_s))
+            stages_ms = st_ms[best]["stages_ms"]
+            fk_algo = d * (32 + 64)                                            # d coefficients in, d affine proofs out (checked against the oracle below)
+            # integer-issue diagnostic: butterflies = d * log2(d) (two size-d transforms of d/2 * log2 d each) + 2d pointwise + d twist scalar-mults,
+            # one scalar-mult ~ 129 doublings + 43..66 additions in the 29-bit ladder
+            fk = {"workload": "FK23 openings (kzg::open_fk) of a degree-(2^%d - 1) polynomial at the 2^%d roots of unity, hat_s cached per SRS" % (lg, lg),
+                  "n_gpus": 1, "proofs_per_s": d / call_s[best], "call_ms": call_s[best] * 1e3, "call_ms_all": [round(x * 1e3, 2) for x in call_s],
+                  "call_note": "keaki_hip_open_fk_poly: coefficients from host memory in (%d MiB), affine proofs to host memory out (%d MiB)" % (d * 32 >> 20, d * 64 >> 20),
+                  "device_ms": st_ms[best]["device_ms"], "pointwise_ms": st_ms[best]["pointwise_ms"], "setup_hat_s_s": round(fk_setup_s, 3),
+                  "scalar_mults": d * lg + 3 * d,
+                  "roofline": {"bound": "hbm", "kernel": "k_g1_fft_stage_map / k_g1_fft_stage4 (the 2 x %d butterfly stages: one butterfly = one 254-bit scalar-mult + add + sub; from span 16 on two stages per radix-4 pass)" % lg,
+                               "algorithmic_bytes": fk_algo, "kernel_ms": stages_ms, "kernel_ms_stat": "all butterfly stages of one call, HIP events on the ctx stream",
+                               "achieved": fk_algo / (stages_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fk_algo / (stages_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "note": "integer-issue bound like every kernel of the path: d log2 d butterfly scalar-mults of ~129 doublings + 43..66 mixed additions each"},
+                  "alu": {"scalar_mults_per_s_in_stages": d * lg / (stages_ms * 1e-3), "simd_cycles_per_butterfly": stages_ms * 1e-3 * 2.4e9 / (d * lg / 64.0 / 1024.0),
+                          "note": "SIMD cycles one wave (64 butterflies) spends per butterfly stage step = scalar-mult + add + sub, at 2.4 GHz on 1024 SIMDs. The ladder: "
+                                  "129 doublings + 43 mixed additions (one twiddle per wave: sliding windows) or 66 (a twiddle per lane: fixed windows) on an "
+                                  "effective-affine window table; valu_per_wave = SQ_INSTS_VALU / SQ_WAVES of the stage kernels from the committed counter "
+                                  "pass (DESIGN 4.2b, 7.3)"}}
+            # fabric traffic of one call from the committed counter passes (bench_tools/collect_pmc_fk_pairing.sh), when they were made on this build
+            fk_traffic, fk_traffic_note = None, None
+            try:
+                from bench_tools.srchash import library_hashes
+                pj = json.load(open(os.path.join(ROOT, "profiles", "r05_fk_pairing_hbm_traffic_pmc.json")))
+                hip.lib.keaki_hip_version.restype = C.c_char_p
+                if pj.get("hashes", {}).get("fk") != library_hashes(hip.lib.keaki_hip_version().decode()).get("fk"):
+                    fk_traffic_note = "profiles/r05_fk_pairing_hbm_traffic_pmc.json was measured on other FK23 kernel sources: refused"
+                elif pj.get("fk_one_call", {}).get("log2d") != lg:
+                    fk_traffic_note = "committed PMC figure is for another domain size"
+                else:
+                    # the r05 file holds the raw FETCH_SIZE counter: x 2 = bytes moved (every fabric request is a 128-byte line: profiles/r06_fetch_size_calibration.txt)
+                    fk_traffic = 2.0 * pj["fk_one_call"]["fetch_bytes"] + pj["fk_one_call"]["write_bytes"]
+                    ipw = pj.get("fk_instructions_per_wave", {})
+                    pick = lambda tag: next((round(v["insts_valu"]) for k, v in ipw.items() if tag in k), None)
+                    # averages over the launches of each kernel (the first stages' twiddles are short scalars: their ladders are cheaper)
+                    fk["alu"]["valu_per_wave"] = {"radix4_pass_per_group_of_four_points": pick("fft_stage4<true"),
+                                                  "radix2_one_twiddle_per_wave_per_butterfly": pick("stage_map<true, true, false"),
+                                                  "radix2_twiddle_per_lane_per_butterfly": pick("stage_map<true, false, true")}
+                    # cycles per issued VALU instruction of the stage kernels: the wave-instructions of one call (counter pass) over the SIMD-cycles of
+                    # the stages (events of this run), against the plain / multiply-add issue rates at the stage kernels' occupancy (2 waves per SIMD)
+                    sj = json.load(open(os.path.join(ROOT, "profiles", "r05_fk_sq_insts.json")))
+                    tot_valu = sj.get("stage_kernels_valu_wave_instructions_one_call") if sj.get("hashes", {}).get("fk") == pj["hashes"]["fk"] and sj.get("log2d") == lg else None
+                    if tot_valu:
+                        cyc = stages_ms * 1e-3 * 2.4e9 * 1024.0 / float(tot_valu)
+                        f_mad = 0.6                                  # share of v_mad_u64_u32 in the 29-bit product streams the ladders are made of (205-instruction product: 162)
+                        fk["alu"].update({"valu_wave_instructions_per_s_per_simd": float(tot_valu) / (stages_ms * 1e-3) / 1024.0,
+                                          "power_limited_stream_rate_per_simd": power_limited_valu_rate(3),
+                                          "frac_of_power_limited_rate": (float(tot_valu) / (stages_ms * 1e-3) / 1024.0 / power_limited_valu_rate(3)) if power_limited_valu_rate(3) else None,
+                                          "stage_valu_wave_instructions_per_call": float(tot_valu), "simd_cycles_per_valu_instruction_measured": cyc,
+                                          "simd_cycles_per_valu_instruction_at_issue_rate": f_mad * 4.8 + (1 - f_mad) * 4.1, "frac": (f_mad * 4.8 + (1 - f_mad) * 4.1) / cyc,
+                                          "frac_note": "SIMD-cycles of the butterfly stages of this run / VALU wave-instructions of the stage kernels in one call (profiles/r05_fk_sq_insts.json), "
+                                                       "against the issue rates of profiles/r01_ubench_u29_gfx950.txt at two waves per SIMD (4.8 multiply-add, 4.1 plain)"})
+            except (OSError, ValueError, KeyError) as e:
+                fk_traffic_note = "no committed PMC figure (%s)" % type(e).__name__
+            fk["roofline"]["traffic"] = fk_traffic
+            fk["roofline"]["traffic_note"] = fk_traffic_note or ("FETCH_SIZE x 2 + WRITE_SIZE of ONE call (bytes moved over the fabric; counters of profiles/r05_fk_pairing_hbm_traffic_pmc.json, kernels unchanged since), all FK23 kernels: the per-lane window tables of the ladders (1 KB written, "
+                                                                 "43..66 x 128 B read per scalar-mult) and the 96-byte points, not the algorithmic 96 B per opening")
+            fk_check = (fsrs, coeffs, proofs, om)
+    if 'fk' in block_errors:
+        fk = {"error": block_errors['fk']}
+        fk_check = None
+
     # ---- Laconic OT (BASELINE config 5): the three phases the reference's test prints (tests/laconic_ot.rs:143-188) at 2^--laconic-log2n
     # bits, on ALL ranks of this job: with N > 1 the FK23 openings of Receiver::new are sharded (ShardedFk: two all-to-alls + one all-gather
     # per call), the commit MSM is split by point range, encapsulations / decapsulations by item range -- laconic_ot.py's flow on this
     # process group (one rank: the un-sharded calls through the host mirror)
     laconic = None
     if not args.no_extras and args.laconic_log2n > 0:
-        from keaki_amd import keaki as K
-        import laconic_ot
-        lshard = Shard(rank, world, dist if world > 1 else None)
-        laconic = laconic_ot.run_flow(K, lshard, dev_index, args.laconic_log2n, 32, "sharded", False, args.backend)
-        checks["laconic.all_messages_recovered"] = bool(laconic["all_messages_recovered"])
-        laconic["workload"] = ("Laconic OT (tests/laconic_ot.rs:126-200), %d receiver bits, 2 x 32-byte messages per bit, %s, through the host mirror"
-                               % (1 << args.laconic_log2n, "ONE GPU" if world == 1 else "sharded over all %d ranks" % world))
-        laconic["note"] = ("wall clock (max over ranks per phase) of vec_commit (iFFT + FK23 openings at d = 2^%d + commit MSM) / 2 x vec_encrypt (2^%d "
-                           "encapsulations) / vec_decrypt (2^%d pairings), host arrays in and out" % (args.laconic_log2n + 1, args.laconic_log2n + 1, args.laconic_log2n))
+        with Guard('laconic'):
+            from keaki_amd import keaki as K
+            import laconic_ot
+            lshard = Shard(rank, world, dist if world > 1 else None)
+            laconic = laconic_ot.run_flow(K, lshard, dev_index, args.laconic_log2n, 32, "sharded", False, args.backend)
+            checks["laconic.all_messages_recovered"] = bool(laconic["all_messages_recovered"])
+            laconic["workload"] = ("Laconic OT (tests/laconic_ot.rs:126-200), %d receiver bits, 2 x 32-byte messages per bit, %s, through the host mirror"
+                                   % (1 << args.laconic_log2n, "ONE GPU" if world == 1 else "sharded over all %d ranks" % world))
+            laconic["note"] = ("wall clock (max over ranks per phase) of vec_commit (iFFT + FK23 openings at d = 2^%d + commit MSM) / 2 x vec_encrypt (2^%d "
+                               "encapsulations) / vec_decrypt (2^%d pairings), host arrays in and out" % (args.laconic_log2n + 1, args.laconic_log2n + 1, args.laconic_log2n))
+    if 'laconic' in block_errors:
+        laconic = {"error": block_errors['laconic']}
 
     # ---- BASELINE config 1 (degree-128 commit + open, and verify / the single KEM calls on the same setup): what ONE call costs --------------
     single = None
     if not args.no_extras and rank == 0:
-        from keaki_amd import keaki as K
-        srng = K.Rng(1)
-        ss = K.KZGSetup.setup(srng.fr_rand(), 129, dev_index)
-        sp = np.stack([srng.fr_rand() for _ in range(129)])
-        s_com = K.commit(ss, sp); sz = srng.fr_rand(); s_pr = K.open(ss, sp, sz); sv = K.poly_evaluate(sp, sz)
-        ok_true = bool(K.verify(ss, s_com, sz, sv, s_pr)) and not bool(K.verify(ss, s_com, sz, K.fr_add(sv, K.fr(1)), s_pr))
-        s_ct, s_key = K.encapsulate(srng, ss, s_com, sz, sv, 32)
-        ok_true = ok_true and K.decapsulate(ss, s_pr, s_ct, 32) == s_key
-        def ms_of(fn, reps=5):
-            for _ in range(4): fn()              # past the table builds of a first call
-            t0 = time.perf_counter()
-            for _ in range(reps): fn()
-            return round((time.perf_counter() - t0) / reps * 1e3, 3)
-        single = {"workload": "BASELINE config 1: degree-128 KZG on KZGSetup::setup(secret, 129) through the host mirror, one call at a time (wall clock, host arrays in and out)",
-                  "commit_ms": ms_of(lambda: K.commit(ss, sp)), "open_ms": ms_of(lambda: K.open(ss, sp, sz)),
-                  "verify_ms": ms_of(lambda: K.verify(ss, s_com, sz, sv, s_pr)),
-                  "encapsulate_ms": ms_of(lambda: K.encapsulate(srng, ss, s_com, sz, sv, 32)),
-                  "decapsulate_ms": ms_of(lambda: K.decapsulate(ss, s_pr, s_ct, 32)),
-                  "note": "a call with few pairings runs each on twelve lanes and two waves (pairing_wide.hip.h): 1.4 ms per pairing instead of 4.9 on a lane pair; "
-                          "encapsulate is to a commitment the context has seen (its GT table is there)"}
-        checks["single_calls_consistent"] = ok_true
-        ss.close()
+        with Guard('single_calls'):
+            from keaki_amd import keaki as K
+            srng = K.Rng(1)
+            ss = K.KZGSetup.setup(srng.fr_rand(), 129, dev_index)
+            sp = np.stack([srng.fr_rand() for _ in range(129)])
+            s_com = K.commit(ss, sp); sz = srng.fr_rand(); s_pr = K.open(ss, sp, sz); sv = K.poly_evaluate(sp, sz)
+            ok_true = bool(K.verify(ss, s_com, sz, sv, s_pr)) and not bool(K.verify(ss, s_com, sz, K.fr_add(sv, K.fr(1)), s_pr))
+            s_ct, s_key = K.encapsulate(srng, ss, s_com, sz, sv, 32)
+            ok_true = ok_true and K.decapsulate(ss, s_pr, s_ct, 32) == s_key
+            def ms_of(fn, reps=5):
+                for _ in range(4): fn()              # past the table builds of a first call
+                t0 = time.perf_counter()
+                for _ in range(reps): fn()
+                return round((time.perf_counter() - t0) / reps * 1e3, 3)
+            single = {"workload": "BASELINE config 1: degree-128 KZG on KZGSetup::setup(secret, 129) through the host mirror, one call at a time (wall clock, host arrays in and out)",
+                      "commit_ms": ms_of(lambda: K.commit(ss, sp)), "open_ms": ms_of(lambda: K.open(ss, sp, sz)),
+                      "verify_ms": ms_of(lambda: K.verify(ss, s_com, sz, sv, s_pr)),
+                      "encapsulate_ms": ms_of(lambda: K.encapsulate(srng, ss, s_com, sz, sv, 32)),
+                      "decapsulate_ms": ms_of(lambda: K.decapsulate(ss, s_pr, s_ct, 32)),
+                      "note": "a call with few pairings runs each on twelve lanes and two waves (pairing_wide.hip.h): 1.4 ms per pairing instead of 4.9 on a lane pair; "
+                              "encapsulate is to a commitment the context has seen (its GT table is there)"}
+            checks["single_calls_consistent"] = ok_true
+            ss.close()
+    if 'single_calls' in block_errors:
+        single = {"error": block_errors['single_calls']}
 
     # ---- full-size correctness of what was timed (every rank takes part: the expected value needs every rank's dot product) --------
     oc = None
@@ -858,7 +894,7 @@ def main():
             checks["kem_bit_exact"] = bool(ok)
             kem["cpu_baseline"] = {"encaps_per_s": mc / ce, "decaps_per_s": mc / cd, "cores": 1, "kind": "port",
                                    "sample": "first %d items, CPU restatement of src/kem.rs:13-72; GPU ct/GT/key bytes bit-exact: %s" % (mc, bool(ok))}
-    if msm_g2 is not None and oc is not None:
+    if msm_g2 is not None and g2_check is not None and oc is not None:
         r_tab, n2 = g2_check
         _, g2g = oc.generators()
         exp2 = oc.g2_mul_batch(g2g, oc.fr_dot(inst.s_host[0][:n2], inst.k_host[:n2]).reshape(1, 4))[0]
@@ -866,7 +902,7 @@ def main():
         checks["msm_g2.full_size_check"] = bool(np.array_equal(_j2a(r_tab), exp2))
         msm_g2["checked"] = "MSM(s, k_i g2) == (sum s_i k_i) g2 at full size, tables == no tables == host-pointer call: %s" % (
             checks["msm_g2.full_size_check"] and checks["msm_g2.tables_equals_no_tables_equals_host_pointer"])
-    if single is not None and oc is not None:
+    if single is not None and "error" not in single and oc is not None:
         # the same five calls on ONE host core through the CPU restatement (the stand-in for keaki's single-threaded arkworks path)
         g1g, g2g = oc.generators()
         cp = oc.g1_mul_batch(g1g, random_fr_limbs(129, 51), threads=os.cpu_count() or 1)
@@ -893,7 +929,7 @@ def main():
                             "encapsulate": cpu_ms(lambda: oc.encap_batch(cp[0], cq[0], ca, cv, cr, 32, threads=1)),
                             "decapsulate": cpu_ms(lambda: oc.decap_batch(cp[:1], c_ct, 32, threads=1)), "cores": 1, "kind": "port",
                             "note": "the same five calls through the CPU restatement (oracle/, the checker) on one host core, same shapes (129 coefficients, 32-byte key)"}
-    if fk is not None and oc is not None:
+    if fk is not None and fk_check is not None and oc is not None:
         # two proofs against the oracle's per-point opening (its quotient, its MSM over the downloaded points)
         fsrs, coeffs, proofs, om = fk_check
         dd = coeffs.shape[0]
@@ -907,6 +943,8 @@ def main():
         fk["checked"] = "proofs 1 and d/2 + 3 equal the oracle's per-point opening (its quotient + its Pippenger MSM): %s" % ok
         fsrs.free()
     result["checks"] = checks
+    if block_errors:
+        result["blocks_failed"] = sorted(block_errors)          # optional blocks that raised (their entries hold the message); the headline stands
     failed = [k for k, v in checks.items() if not v]
     if failed:
         result["value"] = None                         # a number whose result is wrong is not a measurement
