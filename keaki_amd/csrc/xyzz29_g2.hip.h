@@ -61,8 +61,12 @@ KDEV Xyzz<Fq2> x29g2_store(const X29G2& p) {
   if (p.empty) return xyzz_inf<Fq2>();
   return {l2_to_fq2(p.x), l2_to_fq2(p.y), l2_to_fq2(p.zz), l2_to_fq2(p.zzz)};
 }
+struct X29G2;
+KDEV X29G2 x29g2_dbl_of_acc(const X29G2& acc);
 // acc += q (affine, saturated 2^256 form as the tables hold it; q.y already negated by the caller for a negative digit). Identity in
-// either slot, equal points (doubling) and opposite points are handled; the last two are rare and take the saturated formulas.
+// either slot, equal points (doubling) and opposite points are handled. The doubling (18 in 2^29 additions on unrelated points) doubles the
+// ACCUMULATOR in the lazy limbs (round 6: until then the affine point went through the saturated formulas, whose out-of-line Fq2 products gave
+// the bucket kernel a call frame -- the 80 B/lane of scratch -Rpass reported for it).
 KDEV void x29g2_add_mixed(X29G2& acc, const Aff<Fq2>& q) {
   if (aff_is_inf(q)) return;
   const L2 X2 = l2_from_table(q.x), Y2 = l2_from_table(q.y);
@@ -78,7 +82,7 @@ KDEV void x29g2_add_mixed(X29G2& acc, const Aff<Fq2>& q) {
   const L2 P = l2_sub(U2, acc.x, Q29::K2), R = l2_sub(S2, acc.y, Q29::K4);
   if (u29_maybe_zero(P.a) && u29_maybe_zero(P.b)) {        // cheap filter first (limb 0 is exact after the carry pass); exact test only then
     if (u29_is_zero(P.a) && u29_is_zero(P.b)) {
-      if (u29_is_zero(R.a) && u29_is_zero(R.b)) acc = x29g2_load(xyzz_dbl_aff(q));     // same point
+      if (u29_is_zero(R.a) && u29_is_zero(R.b)) acc = x29g2_dbl_of_acc(acc);            // same point: acc == q as a point, so 2 q = 2 acc
       else acc.empty = true;                                                            // opposite points
       return;
     }
@@ -148,6 +152,9 @@ KDEV X29G2 x29g2_dbl(const X29G2& a) {
   r.empty = false;
   return r;
 }
+// the mixed addition's accumulator doubled: first brought to the tail's working form (canonical value, reloaded: < 1.2p, the bounds x29g2_dbl is
+// modelled for -- the mixed addition's own chain allows its accumulator more)
+KDEV X29G2 x29g2_dbl_of_acc(const X29G2& acc) { return x29g2_dbl(x29g2_load(x29g2_store(acc))); }
 KDEV X29G2 x29g2_add(const X29G2& a, const X29G2& b) {
   if (a.empty) return b;
   if (b.empty) return a;

@@ -500,3 +500,31 @@ def test_chunked_call_without_room_for_the_parked_registers_falls_back(oc, rand_
         srs.free()
     finally:
         hip.close()
+
+
+@pytest.mark.parametrize("n", [64, 1000])
+def test_g2_repeated_points_double_the_accumulator(oc, piped, rand_fr, n):
+    """Round 6: when the incoming G2 point equals the bucket's accumulator the mixed addition doubles the ACCUMULATOR in the lazy limbs
+    (x29g2_dbl_of_acc) instead of sending the affine point through the saturated formulas. A handful of distinct points, each many times with
+    scalars from a small set: buckets see Q, Q (-> 2Q), Q (2Q + Q), Q, -Q ... in every window. Same for the fixed-base G2 sums of encapsulate,
+    which share the addition (covered by the KEM parity tests)."""
+    hip = piped
+    _, g2 = oc.generators()
+    base_k = rand_fr(3, 7700 + n)
+    base_s = rand_fr(4, 7701 + n)
+    from conftest import R_MOD
+    k = [base_k[i % 3] for i in range(n)]
+    s = [base_s[(i // 3) % 4] if i % 7 else (R_MOD - base_s[(i // 3) % 4]) for i in range(n)]      # every seventh: the opposite scalar = the opposite point in every window
+    pts = hip.g2_mul_batch(g2, _mont(oc, k))
+    sm = _mont(oc, s)
+    exp = oc.msm_g2(pts, sm)
+    srs = hip.srs_g2_upload(pts)
+    try:
+        for tables in (False, True):
+            if tables:
+                hip.srs_g2_precompute(srs)
+            for chunks in (0, 3):
+                hip.set_option("msm_pipe_chunks", chunks)
+                assert np.array_equal(_aff(hip.msm_g2(srs, sm)), exp), (n, tables, chunks)
+    finally:
+        srs.free()
