@@ -12,6 +12,7 @@ Imports nothing beyond the standard library.
 from __future__ import annotations
 
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -48,13 +49,41 @@ def self_launch(script: str, argv: list[str], nproc: int) -> int:
     env["KEAKI_SELF_LAUNCHED"] = "1"
     cmd = launch_command(os.path.abspath(script), argv, nproc)
     print("[launch] %s" % " ".join(cmd), file=sys.stderr, flush=True)
-    proc = subprocess.Popen(cmd, env=env, cwd=os.getcwd())
+    # Whatever ends this process early must end the job: SIGTERM (a driver's timeout), Ctrl-C and a closed terminal are passed on to the child
+    # launcher, which shuts its ranks down; should this process be killed outright (SIGKILL cannot be caught), the kernel sends the child SIGTERM
+    # on our death (PR_SET_PDEATHSIG). The child stays in OUR process group, so a group-wide kill reaches it as well. No rank is left holding a GPU.
+    import ctypes
+    libc = ctypes.CDLL(None, use_errno=True)
+
+    def die_with_parent():                     # runs in the child between fork and exec
+        libc.prctl(1, int(signal.SIGTERM), 0, 0, 0)          # PR_SET_PDEATHSIG
+
+    proc = subprocess.Popen(cmd, env=env, cwd=os.getcwd(), preexec_fn=die_with_parent)
+
+    def stop_group(sig):
+        try:
+            proc.send_signal(sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+
+    def on_signal(signum, _frame):
+        stop_group(signal.SIGTERM)
+        try:
+            proc.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            stop_group(signal.SIGKILL)
+        raise SystemExit(128 + signum)
+
+    previous = {}
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        try:
+            previous[sg] = signal.signal(sg, on_signal)
+        except (ValueError, OSError):          # not the main thread: the caller keeps its own handling
+            pass
     try:
         return proc.wait()
-    except KeyboardInterrupt:
-        proc.terminate()
-        try:
-            return proc.wait(timeout=30)
-        except subprocess.TimeoutExpired:
-            proc.kill()
-            return proc.wait()
+    finally:
+        for sg, h in previous.items():
+            signal.signal(sg, h)
+        if proc.poll() is None:                # leaving by an exception: take the job down with us
+            stop_group(signal.SIGTERM)

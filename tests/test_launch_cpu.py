@@ -51,3 +51,77 @@ def test_bench_and_laconic_self_launch_then_fail_loudly_without_a_gpu():
         assert "[launch]" in err and "torch.distributed.run" in err and "--nproc-per-node 2" in err
         assert "must be launched through" not in err + out
         assert needle in err + out
+
+
+def test_terminating_the_parent_takes_the_ranks_down():
+    """a driver's timeout sends SIGTERM to `python3 bench.py --gpus N`: the child launcher and its ranks (a process group of their own) must go too"""
+    import signal
+    import time
+    script = os.path.join(ROOT, "tests", "multirank", "sleepy_rank.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    marker = os.path.join(ROOT, "tests", "multirank", ".sleepy_%d" % os.getpid())
+    p = subprocess.Popen([sys.executable, script, "--gpus", "2", "--marker", marker], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        deadline = time.time() + 120
+        while time.time() < deadline and not (os.path.exists(marker + ".0") and os.path.exists(marker + ".1")):
+            time.sleep(0.2)
+        assert os.path.exists(marker + ".0") and os.path.exists(marker + ".1"), "the ranks never came up"
+        pids = [int(open(marker + ".%d" % q).read()) for q in range(2)]
+        p.send_signal(signal.SIGTERM)
+        rc = p.wait(timeout=60)
+        assert rc == 128 + signal.SIGTERM
+        time.sleep(1.0)
+        for pid in pids:
+            alive = True
+            try:
+                os.kill(pid, 0)
+            except ProcessLookupError:
+                alive = False
+            assert not alive, "rank process %d survived its parent" % pid
+    finally:
+        if p.poll() is None:
+            p.kill()
+        for q in range(2):
+            try:
+                os.remove(marker + ".%d" % q)
+            except OSError:
+                pass
+
+
+def test_killing_the_parent_outright_takes_the_ranks_down_too():
+    """SIGKILL cannot be caught: the child launcher dies with its parent through PR_SET_PDEATHSIG and takes its ranks along"""
+    import signal
+    import time
+    script = os.path.join(ROOT, "tests", "multirank", "sleepy_rank.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    marker = os.path.join(ROOT, "tests", "multirank", ".sleepyk_%d" % os.getpid())
+    p = subprocess.Popen([sys.executable, script, "--gpus", "2", "--marker", marker], cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        deadline = time.time() + 120
+        while time.time() < deadline and not (os.path.exists(marker + ".0") and os.path.exists(marker + ".1")):
+            time.sleep(0.2)
+        assert os.path.exists(marker + ".0") and os.path.exists(marker + ".1"), "the ranks never came up"
+        pids = [int(open(marker + ".%d" % q).read()) for q in range(2)]
+        p.send_signal(signal.SIGKILL)
+        p.wait(timeout=30)
+        gone = False
+        for _ in range(150):                  # the launcher needs a moment to stop its workers
+            gone = True
+            for pid in pids:
+                try:
+                    os.kill(pid, 0)
+                    gone = False
+                except ProcessLookupError:
+                    pass
+            if gone:
+                break
+            time.sleep(0.2)
+        assert gone, "rank processes survived a killed parent"
+    finally:
+        if p.poll() is None:
+            p.kill()
+        for q in range(2):
+            try:
+                os.remove(marker + ".%d" % q)
+            except OSError:
+                pass
