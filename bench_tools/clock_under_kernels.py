@@ -46,3 +46,25 @@ def pair():
     for _ in range(2): hip.pairing_batch_dev(d_pts.data_ptr(), d_q.data_ptr(), 1, m, d_gt.data_ptr())
 for _ in range(2):
     print("2^16 pairings (window of 6 ms): %.0f MHz" % clock_during(pair, 6000))
+# FK23 openings at d = 2^20 (the butterfly stages: ladders with per-lane window tables in memory, ~1.1 TB/s over the fabric)
+import ctypes as C
+lg = 20
+d = 1 << lg
+w2d = pow(5, (R_MOD - 1) >> (lg + 1), R_MOD)
+mont_fr = lambda v: np.frombuffer(((v << 256) % R_MOD).to_bytes(32, "little"), np.uint64).copy()
+om, omi, inv2d = mont_fr(w2d), mont_fr(pow(w2d, -1, R_MOD)), mont_fr(pow(2 * d, -1, R_MOD))
+fsrs = hip.srs_g1_wrap_dev(d_pts.data_ptr(), d)
+coeffs = random_fr_limbs(d, SEED + 4242)
+hip._ck(hip.lib.keaki_hip_srs_g1_precompute_fk(hip.ctx, fsrs.handle, lg, om.ctypes.data_as(C.c_void_p)))
+hip.open_fk_poly(fsrs, lg, coeffs, om, omi, inv2d)
+import threading
+for _ in range(2):
+    res = {}
+    def probe():
+        time.sleep(0.08)                       # well inside the ~0.2 s of butterfly stages
+        assert pr.probe_start(8000) == 0
+        res["mhz"] = pr.probe_wait()
+    th = threading.Thread(target=probe); th.start()
+    hip.open_fk_poly(fsrs, lg, coeffs, om, omi, inv2d)
+    th.join()
+    print("FK23 openings, d = 2^20 (window of 8 ms inside the butterfly stages): %.0f MHz" % res["mhz"])
