@@ -111,8 +111,14 @@ static void timed(const char* name, double bytes, F launch) {
 int main(int argc, char** argv) {
   const u32 log2rows = argc > 1 ? (u32)atoi(argv[1]) : 26;              // 2^26 rows x 64 B = 4 GiB
   const size_t bytes = (size_t)64 << log2rows;
+  // argv[2]: how the table is allocated -- 0 hipMalloc (what the library does), 1 hipDeviceMallocUncached, 2 hipDeviceMallocFinegrained: would a
+  // non-cached memory type make the fabric fetch 64 bytes for a 64-byte row? (answer in profiles/r06_fetch_size_calibration.txt)
+  const int mode = argc > 2 ? atoi(argv[2]) : 0;
   v4u* t; u32* out;
-  CK(hipMalloc(&t, bytes)); CK(hipMalloc(&out, 4096 * 256 * 4));
+  if (mode == 0) CK(hipMalloc(&t, bytes));
+  else CK(hipExtMallocWithFlags((void**)&t, bytes, mode == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
+  printf("# allocation mode %d\n", mode);
+  CK(hipMalloc(&out, 4096 * 256 * 4));
   CK(hipMemset(t, 0x5A, bytes)); CK(hipDeviceSynchronize());
   const dim3 g(4096), b(256);
   printf("# table %zu MiB, every kernel reads every byte of it exactly once\n", bytes >> 20);
