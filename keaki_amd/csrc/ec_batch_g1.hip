@@ -13,10 +13,13 @@ keaki_status encap_g1_run(keaki_hip_ctx* ctx, const void* d_com, const void* d_v
                      (G1Aff*)d_out);
   return launch_check(ctx, "encap_g1");
 }
+// (a kernel, not hipMemcpyFromSymbol: two device variables named from the host came out of hipcc in either order -- see ec_batch_g2.hip)
+static __global__ void k_g1_generator_to(Fq* __restrict__ dst) {
+  if (threadIdx.x == 0) { dst[0] = G1_GEN_X; dst[1] = G1_GEN_Y; }
+}
 keaki_status g1_generator_to(keaki_hip_ctx* ctx, void* d_dst) {
-  HIP_TRY(ctx, hipMemcpyFromSymbolAsync(d_dst, HIP_SYMBOL(G1_GEN_X), sizeof(Fq), 0, hipMemcpyDeviceToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyFromSymbolAsync((char*)d_dst + sizeof(Fq), HIP_SYMBOL(G1_GEN_Y), sizeof(Fq), 0, hipMemcpyDeviceToDevice, ctx->stream));
-  return KEAKI_OK;
+  hipLaunchKernelGGL(k_g1_generator_to, dim3(1), dim3(64), 0, ctx->stream, (Fq*)d_dst);
+  return launch_check(ctx, "g1_generator_to");
 }
 // table[j * entries + d] = d 2^(wb j) * base
 keaki_status g1_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, void* d_table, uint32_t wb) {

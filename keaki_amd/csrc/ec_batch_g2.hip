@@ -10,10 +10,14 @@ keaki_status g2_mul_batch_run(keaki_hip_ctx* ctx, const void* d_pts, int stride,
                      (G2Aff*)d_out);
   return launch_check(ctx, "g2_mul_batch");
 }
+// (a kernel, not hipMemcpyFromSymbol: a device variable named from the host is externalised under a per-compilation `__hip_cuid_` symbol whose place
+// in the symbol table changed from build to build -- this object was the one file that kept a clean build from being byte-identical to the last)
+static __global__ void k_g2_generator_to(Fq2* __restrict__ dst) {
+  if (threadIdx.x < 2) dst[threadIdx.x] = G2_GEN_XY[threadIdx.x];
+}
 keaki_status g2_generator_to(keaki_hip_ctx* ctx, void* d_dst) {
-  HIP_TRY(ctx, hipMemcpyFromSymbolAsync(d_dst, HIP_SYMBOL(G2_GEN_X), sizeof(Fq2), 0, hipMemcpyDeviceToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyFromSymbolAsync((char*)d_dst + sizeof(Fq2), HIP_SYMBOL(G2_GEN_Y), sizeof(Fq2), 0, hipMemcpyDeviceToDevice, ctx->stream));
-  return KEAKI_OK;
+  hipLaunchKernelGGL(k_g2_generator_to, dim3(1), dim3(64), 0, ctx->stream, (Fq2*)d_dst);
+  return launch_check(ctx, "g2_generator_to");
 }
 // table[j*256+d] = d 2^(8j) * base   (8192 affine entries)
 keaki_status g2_fb_table_run(keaki_hip_ctx* ctx, const void* d_base, void* d_table, uint32_t wb) {
