@@ -59,6 +59,10 @@ print("n = 2^%d, tables %d: scalars resident %.2f ms (%.3e/s)" % (log2n, tables,
 cells = [(0, 100)]
 if grid == "full":
     cells += [(c, g) for c in (2, 3, 4, 6, 8, 12, 16) for g in (100, 140, 200)]
+elif grid == "fine":                                   # around the shipped 6 x 1.4
+    cells += [(c, g) for c in (5, 6, 7, 8, 10) for g in (120, 130, 140, 150, 160, 170)]
+elif grid == "auto":                                   # the automatic chunk count of this size against the growth
+    cells += [(-1, g) for g in (120, 140, 150, 160, 170, 180, 200)]
 else:
     cells += [(-1, 140)]
 for c, g in cells:

@@ -113,7 +113,7 @@ const char* keaki_hip_version(void);
  *       names the chunked path itself and takes precedence: a caller who wants no other stream sets "pipe_chunks" = 0 and leaves
  *       "msm_pipe_chunks" at -1 (or sets it to 0).
  *   "msm_pipe_chunks" (-1 = automatic: 6 chunks from 2^22 scalars on, 4 from 2^21, 3 from "msm_pipe_min" = 2^20 on; 0 / 1 = one copy in front; k >= 2 = k chunks at
- *       any length), "msm_pipe_growth" (size of chunk j + 1 in percent of chunk j, default 140: a short first chunk starts the device early).
+ *       any length), "msm_pipe_growth" (size of chunk j + 1 in percent of chunk j, default 160: a short first chunk starts the device early).
  *   A host-array call that FAILS (status != KEAKI_OK) leaves its output arrays unspecified: any prefix may hold results, and with
  *   "host_prefault" = 1 pages may hold the zeros of the first touch. Input arrays are never written.
  * Unknown name -> KEAKI_ERR_BAD_ARG. */

@@ -52,7 +52,7 @@ struct Tuning {
   bool pipe_chunks = true;       // KEAKI_PIPE_CHUNKS / "pipe_chunks": host-pointer batches (KEM, MSM) run as chunk pipelines over a copy stream; 0 = upload, kernels, download in that order on the context's stream
   int msm_pipe_chunks = -1;      // KEAKI_MSM_PIPE_CHUNKS / "msm_pipe_chunks": chunks of a host-pointer MSM (upload under the kernels); -1 = automatic, 0 / 1 = one copy in front, k = k chunks at any length
   long long msm_pipe_min = 1 << 20;   // KEAKI_MSM_PIPE_MIN / "msm_pipe_min": automatic chunking from this many scalars on
-  int msm_pipe_growth = 140;     // KEAKI_MSM_PIPE_GROWTH / "msm_pipe_growth": size of chunk j + 1 in percent of chunk j (100 = equal chunks)
+  int msm_pipe_growth = 160;     // KEAKI_MSM_PIPE_GROWTH / "msm_pipe_growth": size of chunk j + 1 in percent of chunk j (100 = equal chunks; round 6: 160, measured best or tied at 2^20 .. 2^24, profiles/r06_msm_pipe_growth.txt; 140 until round 5)
 #ifdef KEAKI_DIAG
   unsigned diag_row_mask = 0;    // "diag_row_mask" (ONLY in the diagnostic build, `make -C keaki_amd/csrc diag`; never in libkeaki_hip.so): the table-row index of every (row, sign) entry of the bucket-ordered stream is ANDed with this mask before the bucket kernel runs, so its gathers hit a table of (mask + 1) x 64 B -- the arithmetic, the instruction stream and the kernel binary stay the shipped ones, the RESULT IS WRONG by construction (bench_tools/r6_bucket_clock_diag.py)
 #endif

@@ -56,7 +56,7 @@ for it, n in enumerate(sizes):
         ok_open = np.array_equal(val.reshape(-1), v.reshape(-1)) and (n < 2 or np.array_equal(jac_to_affine_words(proof), oc.msm_g1(pts[:n - 1], q, threads=8)))
     finally:
         srs.free()
-        hip.set_option("msm_pipe_chunks", -1); hip.set_option("msm_pipe_growth", 140)
+        hip.set_option("msm_pipe_chunks", -1); hip.set_option("msm_pipe_growth", 160)
     ok = np.array_equal(got, exp) and np.array_equal(got_t, exp) and np.array_equal(got_p, exp_p) and ok_open
     bad += not ok
     print("n=%6d mode=%d %s" % (n, mode, "ok" if ok else "MISMATCH"), flush=True)

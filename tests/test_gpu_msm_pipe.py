@@ -24,7 +24,7 @@ def _mont(oc, ints):
 def piped(hip):
     """the session context with the chunking options under the test's control; automatic again afterwards"""
     yield hip
-    for k, v in (("msm_pipe_chunks", -1), ("msm_pipe_growth", 140), ("msm_pipe_min", 1 << 20), ("acc_u29", 1), ("acc_u29_g2", 1), ("acc_idxq", 1)):
+    for k, v in (("msm_pipe_chunks", -1), ("msm_pipe_growth", 160), ("msm_pipe_min", 1 << 20), ("acc_u29", 1), ("acc_u29_g2", 1), ("acc_idxq", 1)):
         hip.set_option(k, v)
 
 
